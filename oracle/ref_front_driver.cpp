@@ -1,0 +1,100 @@
+// TEST INFRASTRUCTURE — never linked into, imported by, or shipped with the product.
+//
+// ref_front: a harness `main` (build-owned code) that links the UNMODIFIED
+// reference translation units which compile on their own in this image
+//   Common.cpp Commandline.cpp Compressed_sequence.cpp Contig.cpp Longread.cpp
+//   Backbone_graph.cpp Cleaning.cpp                  (/root/reference/src/haslr_assemble/src)
+// and calls the reference's own functions in the order of the reference's
+// main() (main.cpp:38-199): load -> filters/sort/group -> overlap fix -> chaining
+// -> graph build -> weak edges -> tips x3 -> simple bubbles -> super bubbles ->
+// small bubbles -> branching report. It stops where main.cpp:203 enters
+// Assemble.cpp, which cannot be built here: Assemble.cpp:6 includes spoa.hpp
+// (rvaser/spoa 1.1.3, cloned at build time by the reference Makefile:41-47, not
+// vendored, no network), and writing a stand-in header is not allowed. So the
+// real reference pins SURVEY.md rows a1-a7 and a10(cleaning, GFA/stat writers);
+// rows a8/a9 and path stitching are "parity unpinned".
+//
+// Besides the reference's own output files this harness dumps, with its own
+// printing code, two internal states that no reference file exposes:
+//   alignments.loaded.paf / alignments.fixed.paf  (via the reference's
+//       print_loaded_alignments, Longread.cpp:705) — pins filters + sort + overlap trim
+//   edge_supp.01.txt / edge_supp.02.txt — every edge's support vector in stored
+//       order (pins Backbone_graph.cpp:10-25,148-171 ordering, and :348-375)
+//
+// Output goes to the directory given by -d; sources are read where they lie under
+// /root/reference and are never copied. Built by oracle/Makefile into oracle/_ref/.
+#include "Common.hpp"
+#include "Commandline.hpp"
+#include "Contig.hpp"
+#include "Longread.hpp"
+#include "Backbone_graph.hpp"
+#include "Cleaning.hpp"
+
+static void dump_edge_supp(std::vector<BBG_Node_t>& graph, const std::string& path) {
+    FILE* fp = file_open_write(path);
+    for (uint32_t i = 0; i < graph.size(); i++)
+        for (int rev = 0; rev < 2; rev++)
+            for (auto it = graph[i].edges[rev].begin(); it != graph[i].edges[rev].end(); ++it) {
+                fprintf(fp, "E\t%u\t%d\t%u\t%u\t%zu", i, rev, it->first >> 1, it->first & 1, it->second.edge_supp.size());
+                for (auto& s : it->second.edge_supp)
+                    fprintf(fp, "\t%u:%u:%u:%u", (uint32_t)s.lr_id, (uint32_t)s.lr_strand, s.cmp_head_id, s.cmp_tail_id);
+                fprintf(fp, "\n");
+            }
+    fclose(fp);
+}
+
+int main(int argc, char* argv[]) {
+    if (!parse_command_line(argc, argv)) return EXIT_FAILURE;
+    const std::string d = gopt.out_dir;
+    Contig_List_t contig_list;
+    initialize_contig(contig_list);
+    load_contig_compressed(gopt.contig_path, contig_list);
+    calc_uniq_freq(contig_list);
+    fprintf(stderr, "[ref_front] uniq_freq %.17g\n", gopt.uniq_freq);
+    {
+        FILE* fp = file_open_write(d + "/uniq_freq.txt");
+        fprintf(fp, "%.17g\n", gopt.uniq_freq);
+        fclose(fp);
+    }
+    Longread_List_t lr_list;
+    initialize_longread(lr_list);
+    load_longread_compressed(gopt.long_path, lr_list);
+    update_longreads(lr_list);
+    load_alignment(gopt.mapping_path, contig_list, lr_list);
+    update_longreads(lr_list);
+    print_loaded_alignments(lr_list, d + "/alignments.loaded.paf");
+    fix_alignments(lr_list);
+    print_loaded_alignments(lr_list, d + "/alignments.fixed.paf");
+    std::vector<std::vector<Align_Seq_t*>> compact_lr_list;
+    build_compact_longreads(lr_list, compact_lr_list, contig_list, gopt.min_aln_block, 1);
+    print_compact_longreads(compact_lr_list, d + "/compact_uniq.txt");
+
+    std::vector<BBG_Node_t> g;
+    bbg_build_graph(g, contig_list, compact_lr_list);
+    dump_edge_supp(g, d + "/edge_supp.01.txt");
+    bbg_general_stats(g, contig_list, d + "/backbone.01.init.stat");
+    bbg_print_graph_gfa(g, contig_list, d + "/backbone.01.init.gfa");
+    bbg_remove_weak_edges(g);
+    dump_edge_supp(g, d + "/edge_supp.02.txt");
+    bbg_general_stats(g, contig_list, d + "/backbone.02.weakEdge.stat");
+    bbg_print_graph_gfa(g, contig_list, d + "/backbone.02.weakEdge.gfa");
+    clean_tips(g, 1, d + "/backbone.03.tip.log");
+    clean_tips(g, 2, d + "/backbone.03.tip.log");
+    clean_tips(g, 3, d + "/backbone.03.tip.log");
+    bbg_general_stats(g, contig_list, d + "/backbone.03.tip.stat");
+    bbg_print_graph_gfa(g, contig_list, d + "/backbone.03.tip.gfa");
+    clean_simple_bubbles_old(g, 4, d + "/backbone.04.simplebubble.log");
+    bbg_general_stats(g, contig_list, d + "/backbone.04.simplebubble.stat");
+    bbg_print_graph_gfa(g, contig_list, d + "/backbone.04.simplebubble.gfa");
+    clean_super_bubbles(g, 50000, d + "/backbone.05.superbubble.log");
+    bbg_general_stats(g, contig_list, d + "/backbone.05.superbubble.stat");
+    bbg_print_graph_gfa(g, contig_list, d + "/backbone.05.superbubble.gfa");
+    clean_small_bubbles(g, d + "/backbone.06.smallbubble.log");
+    bbg_general_stats(g, contig_list, d + "/backbone.06.smallbubble.stat");
+    bbg_print_graph_gfa(g, contig_list, d + "/backbone.06.smallbubble.gfa");
+    dump_edge_supp(g, d + "/edge_supp.06.txt");
+    bbg_report_branching_nodes(g, d + "/backbone.branching.log");
+    finalize_contig(contig_list);
+    finalize_longread(lr_list);
+    return EXIT_SUCCESS;
+}
