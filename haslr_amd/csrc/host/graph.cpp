@@ -1,0 +1,326 @@
+// graph.cpp — backbone graph, its writers, and the four serial cleaning passes.
+//
+// These are order-dependent edits of a small graph and stay on the host.
+// Output bytes (GFA, .stat, cleaning logs) are a parity gate and are checked against files produced
+// by the compiled reference (tests/golden/, oracle/_ref/ref_front). Reference functions followed
+// (paths under /root/reference/src/haslr_assemble/src/):
+//   bbg_remove_weak_edges Backbone_graph.cpp:348-375     bbg_print_graph_gfa :540-588
+//   bbg_general_stats :595-659                            bbg_report_branching_nodes :682-694
+//   bbg_find_simple_path_from_source :378-402             clean_tips Cleaning.cpp:59-96
+//   clean_simple_bubbles_old Cleaning.cpp:98-184          detect_super_bubble/clean_super_bubbles :488-648
+//   clean_small_bubbles Cleaning.cpp:7-57
+#include <algorithm>
+#include <cstdio>
+#include <map>
+#include <queue>
+#include <set>
+#include <stack>
+#include <tuple>
+#include <unordered_map>
+
+#include "host_internal.h"
+
+namespace hxh {
+
+#define LOGF(fp, ...) do { if (fp) fprintf(fp, __VA_ARGS__); } while (0)
+
+FILE* open_or_null(const std::string& path, const char* mode) {
+    if (path.empty()) return nullptr;
+    FILE* fp = fopen(path.c_str(), mode);
+    if (!fp) { fprintf(stderr, "[ERROR] (Common::file_open_write) could not open file: %s\n", path.c_str()); exit(EXIT_FAILURE); }
+    return fp;
+}
+
+std::string revcomp(const std::string& s) {
+    std::string r(s.size(), 'N');
+    for (size_t i = 0; i < s.size(); i++) {
+        char c = s[s.size() - 1 - i];
+        r[i] = c == 'A' || c == 'a' ? 'T' : c == 'C' || c == 'c' ? 'G' : c == 'G' || c == 'g' ? 'C' : c == 'T' || c == 't' ? 'A' : 'N';
+    }
+    return r;
+}
+
+Arc* Graph::find(uint32_t v, uint32_t key) {
+    auto& a = adj[v];
+    auto it = std::lower_bound(a.begin(), a.end(), key, [](const Arc& x, uint32_t k) { return x.key < k; });
+    return it != a.end() && it->key == key ? &*it : nullptr;
+}
+
+void Graph::erase_arc(uint32_t v, uint32_t key) {
+    auto& a = adj[v];
+    auto it = std::lower_bound(a.begin(), a.end(), key, [](const Arc& x, uint32_t k) { return x.key < k; });
+    if (it != a.end() && it->key == key) a.erase(it);
+}
+
+// Edge keys arrive sorted by (source vertex, map key), so every arc vector is born sorted.
+void graph_build(Graph& g, uint32_t n_nodes, const hx_edges_out& e) {
+    g.n_nodes = n_nodes;
+    g.adj.assign((size_t)n_nodes * 2, {});
+    for (uint64_t i = 0; i < e.n_edge; i++) {
+        uint32_t v = (uint32_t)(e.edge_key[i] >> 32), key = (uint32_t)e.edge_key[i];
+        Arc a;
+        a.key = key; a.supp = (uint32_t)(e.edge_off[i + 1] - e.edge_off[i]); a.dev_edge = (uint32_t)i;
+        g.adj[v].push_back(a);
+    }
+}
+
+int graph_remove_weak_edges(Graph& g, uint32_t min_edge_sup) {
+    int removed = 0;
+    for (uint32_t v = 0; v < g.adj.size(); v++) {
+        for (size_t k = 0; k < g.adj[v].size();) {
+            if (g.adj[v][k].supp < min_edge_sup) {
+                uint32_t key = g.adj[v][k].key;
+                g.adj[v].erase(g.adj[v].begin() + k);
+                g.erase_arc(Graph::twin_vertex(key), Graph::twin_key(v));
+                removed++;
+            } else k++;
+        }
+    }
+    return removed;
+}
+
+void graph_write_gfa(const Graph& g, const Dataset& d, const std::string& path) {
+    FILE* fp = open_or_null(path, "w");
+    if (!fp) return;
+    std::set<uint32_t> to_print;
+    for (uint32_t v = 0; v < g.adj.size(); v++)
+        for (const Arc& a : g.adj[v]) { to_print.insert(v >> 1); to_print.insert(a.key >> 1); }
+    for (uint32_t id : to_print) {
+        std::string s = d.contig_seq(id);
+        fprintf(fp, "S\t%u\t%s\tLN:i:%zu\tKC:i:%u\n", id, s.c_str(), s.size(), d.contig_kc[id]);
+    }
+    for (uint32_t v = 0; v < g.adj.size(); v++)
+        for (const Arc& a : g.adj[v])
+            fprintf(fp, "L\t%u\t%c\t%u\t%c\t0M\n", v >> 1, "+-"[v & 1], a.key >> 1, (a.key & 1) ? '-' : '+');
+    fclose(fp);
+}
+
+void graph_write_stats(const Graph& g, const Dataset& d, const std::string& path) {
+    FILE* fp = open_or_null(path, "w");
+    if (!fp) return;
+    uint32_t num = g.n_nodes, nb_node = 0, nb_edge = 0;
+    for (uint32_t i = 0; i < num; i++) {
+        nb_node += (g.deg(i, 0) > 0 || g.deg(i, 1) > 0);
+        nb_edge += g.deg(i, 0) + g.deg(i, 1);
+    }
+    fprintf(fp, "nodes: %d\n", nb_node);
+    fprintf(fp, "edges: %d\n", nb_edge / 2);
+    std::vector<bool> visited(num, false);
+    // (size, nodes, representative), narrowed to 32 bits exactly like the reference's tuple (:612,:644)
+    std::vector<std::tuple<uint32_t, uint32_t, uint32_t>> comps;
+    for (uint32_t i = 0; i < num; i++) {
+        if (visited[i] || !(g.deg(i, 0) > 0 || g.deg(i, 1) > 0)) continue;
+        uint64_t cc_size = d.contig_len[i], cc_node = 1;
+        std::queue<uint32_t> q;
+        q.push(i);
+        visited[i] = true;
+        while (!q.empty()) {
+            uint32_t cur = q.front();
+            q.pop();
+            for (int side = 0; side < 2; side++)
+                for (const Arc& a : g.adj[(cur << 1) | side]) {
+                    uint32_t nx = a.key >> 1;
+                    if (!visited[nx]) { q.push(nx); cc_node++; cc_size += d.contig_len[nx]; visited[nx] = true; }
+                }
+        }
+        comps.push_back(std::make_tuple((uint32_t)cc_size, (uint32_t)cc_node, i));
+    }
+    // comparator on size only, std::sort: equal sizes land where libstdc++'s introsort puts them, as in the reference (:651)
+    std::sort(comps.begin(), comps.end(), [](const std::tuple<uint32_t, uint32_t, uint32_t>& a, const std::tuple<uint32_t, uint32_t, uint32_t>& b) {
+        return std::get<0>(a) > std::get<0>(b);
+    });
+    fprintf(fp, "connected_components: %zu\n", comps.size());
+    for (uint32_t i = 0; i < comps.size(); i++)
+        fprintf(fp, "\tcomponent:%u\tsize:%u\tnodes:%u\trepresentative:%u\n", i, std::get<0>(comps[i]), std::get<1>(comps[i]), std::get<2>(comps[i]));
+    fclose(fp);
+}
+
+void graph_report_branching(const Graph& g, const std::string& path) {
+    FILE* fp = open_or_null(path, "w");
+    if (!fp) return;
+    for (uint32_t i = 0; i < g.n_nodes; i++)
+        if (g.deg(i, 0) >= 2 || g.deg(i, 1) >= 2)   // labels are swapped in the reference too (:691)
+            fprintf(fp, "node:%u\tincoming:%zu\toutgoing:%zu\n", i, g.deg(i, 0), g.deg(i, 1));
+    fclose(fp);
+}
+
+namespace {
+
+struct PathElem { uint32_t strand, id; };
+
+// bbg_find_simple_path_from_source: follow the arc at index `k` of vertex (src,side) while nodes are 1-in 1-out.
+bool simple_path_from(const Graph& g, uint32_t src, uint32_t side, size_t k, int max_depth, std::vector<PathElem>& path, float& cov) {
+    path.clear();
+    cov = 0;
+    path.push_back({side, src});
+    const Arc* it = &g.adj[(src << 1) | side][k];
+    uint32_t cn = it->key >> 1, cs = it->key & 1;
+    int depth = 1;
+    while (depth <= max_depth) {
+        path.push_back({cs, cn});
+        cov += it->supp;
+        if (g.deg(cn, cs) == 0) break;
+        if (g.deg(cn, cs) > 1 || g.deg(cn, 1 - cs) > 1) break;
+        it = &g.adj[(cn << 1) | cs][0];
+        cn = it->key >> 1; cs = it->key & 1;
+        depth++;
+    }
+    if (depth > max_depth) return false;
+    cov = cov / depth;
+    return true;
+}
+
+void remove_path(Graph& g, const std::vector<PathElem>& p) {
+    for (size_t j = 0; j + 1 < p.size(); j++) g.remove_edge(p[j].id, p[j].strand, p[j + 1].id, p[j + 1].strand);
+}
+
+}  // namespace
+
+int clean_tips(Graph& g, int max_depth, const std::string& logpath) {
+    FILE* fp = open_or_null(logpath, max_depth == 1 ? "w" : "a");
+    int removed = 0;
+    for (uint32_t i = 0; i < g.n_nodes; i++) {
+        uint32_t side;
+        if (g.deg(i, 1) == 0 && g.deg(i, 0) == 1) side = 0;
+        else if (g.deg(i, 1) == 1 && g.deg(i, 0) == 0) side = 1;
+        else continue;
+        std::vector<PathElem> p;
+        float cov;
+        if (simple_path_from(g, i, side, 0, max_depth, p, cov)) {
+            if (g.deg(p.back().id, p.back().strand) == 0) continue;
+            LOGF(fp, "tip_len:%zu\t%u:%c -> %u:%c\n", p.size() - 1, p.front().id, "+-"[p.front().strand], p.back().id, "+-"[p.back().strand]);
+            remove_path(g, p);
+            removed++;
+        }
+    }
+    if (fp) fclose(fp);
+    return removed;
+}
+
+int clean_simple_bubbles(Graph& g, int max_depth, const std::string& logpath) {
+    FILE* fp = open_or_null(logpath, "w");
+    int removed = 0;
+    for (uint32_t i = 0; i < g.n_nodes; i++) {
+        if (g.deg(i, 0) < 2 && g.deg(i, 1) < 2) continue;
+        bool again = false;
+        for (uint32_t side = 0; side < 2 && !again; side++) {
+            if (g.deg(i, side) != 2) continue;
+            std::vector<PathElem> p1, p2;
+            float c1, c2;
+            bool f1 = simple_path_from(g, i, side, 0, max_depth, p1, c1);
+            bool f2 = simple_path_from(g, i, side, 1, max_depth, p2, c2);
+            if (f1 && f2 && p1.back().id == p2.back().id && p1.back().strand == p2.back().strand) {
+                LOGF(fp, "simple_bubble cov:%.2lf ", c1);
+                for (auto& e : p1) LOGF(fp, "%u:%c ", e.id, "+-"[e.strand]);
+                LOGF(fp, "\n              cov:%.2lf ", c2);
+                for (auto& e : p2) LOGF(fp, "%u:%c ", e.id, "+-"[e.strand]);
+                LOGF(fp, "\n");
+                remove_path(g, c1 < c2 ? p1 : p2);
+                removed++;
+                again = true;   // the reference re-examines the same node (i--; continue)
+            }
+        }
+        if (again) i--;   // wraps at 0 and comes back with the loop increment, like the reference's uint32_t
+    }
+    if (fp) fclose(fp);
+    return removed;
+}
+
+namespace {
+
+// detect_super_bubble (Cleaning.cpp:488-562), miniasm-style; keeps the reference's arithmetic including the
+// division by (path length - 1) == 0 at the source, in IEEE doubles.
+bool detect_super_bubble(const Graph& g, uint32_t src_vertex, std::vector<uint32_t>& best_path, std::set<std::pair<uint32_t, uint32_t>>& bubble_edges) {
+    std::stack<uint32_t> S;
+    S.push(src_vertex);
+    std::unordered_map<uint32_t, int32_t> visited, gamma;
+    std::unordered_map<uint32_t, std::vector<uint32_t>> path;
+    std::unordered_map<uint32_t, uint32_t> support;
+    visited[src_vertex] = 1;
+    path[src_vertex].push_back(src_vertex);
+    support[src_vertex] = 0;
+    int p = 0;
+    while (!S.empty()) {
+        uint32_t v = S.top();
+        S.pop();
+        for (const Arc& a : g.adj[v]) {
+            bubble_edges.insert({v, a.key});
+            uint32_t w = a.key, next_supp = a.supp;
+            if ((w >> 1) == (v >> 1)) return false;
+            if (visited.count(w) == 0) { gamma[w] = (int32_t)g.adj[w ^ 1u].size(); visited[w] = 1; p++; }
+            if (support.count(w) == 0 ||
+                double(support[v] + next_supp) / path[v].size() > double(support[w]) / (path[v].size() - 1)) {
+                support[w] = support[v] + next_supp;
+                std::vector<uint32_t> np = path[v];
+                np.push_back(w);
+                path[w] = np;
+            }
+            gamma[w]--;
+            if (gamma[w] == 0 && !g.adj[w].empty()) { S.push(w); p--; }
+        }
+        if (S.size() == 1 && p == 0) { best_path = path[S.top()]; return true; }
+    }
+    return false;
+}
+
+}  // namespace
+
+int clean_super_bubbles(Graph& g, const std::string& logpath) {
+    FILE* fp = open_or_null(logpath, "w");
+    int removed = 0;
+    for (uint32_t i = 0; i < g.n_nodes; i++) {
+        if (g.deg(i, 0) < 2 && g.deg(i, 1) < 2) continue;
+        bool again = false;
+        for (uint32_t side = 0; side < 2 && !again; side++) {
+            if (g.deg(i, side) < 2) continue;
+            std::vector<uint32_t> best;
+            std::set<std::pair<uint32_t, uint32_t>> be;
+            if (!detect_super_bubble(g, (i << 1) | side, best, be)) continue;
+            LOGF(fp, "bubble_src %u:%c\tbubble_sink %u:%c\n", i, "+-"[side], best.back() >> 1, "+-"[best.back() & 1]);
+            LOGF(fp, "\tbest_path ");
+            for (uint32_t v : best) LOGF(fp, "%u:%c ", v >> 1, "+-"[v & 1]);
+            LOGF(fp, "\n");
+            for (size_t j = 0; j + 1 < best.size(); j++) be.erase({best[j], best[j + 1]});
+            LOGF(fp, "\tremoved_edges:\n");
+            for (auto& e : be) {
+                g.remove_edge(e.first >> 1, e.first & 1, e.second >> 1, e.second & 1);
+                LOGF(fp, "\t\t%u:%c -> %u:%c\n", e.first >> 1, "+-"[e.first & 1], e.second >> 1, "+-"[e.second & 1]);
+            }
+            LOGF(fp, "\n");
+            removed++;
+            again = true;
+        }
+        if (again) i--;
+    }
+    if (fp) fclose(fp);
+    return removed;
+}
+
+int clean_small_bubbles(Graph& g, const std::string& logpath) {
+    FILE* fp = open_or_null(logpath, "w");
+    int removed = 0;
+    for (uint32_t i = 0; i < g.n_nodes; i++) {
+        if (!(g.deg(i, 1) > 0 && g.deg(i, 0) > 0)) continue;
+        bool done = false;
+        for (size_t ki = 0; ki < g.adj[(i << 1) | 1].size() && !done; ki++) {
+            for (size_t ko = 0; ko < g.adj[i << 1].size() && !done; ko++) {
+                const Arc ain = g.adj[(i << 1) | 1][ki], aout = g.adj[i << 1][ko];
+                uint32_t node1 = ain.key >> 1, rev1 = ain.key & 1, to = aout.key, node2 = to >> 1, rev2 = to & 1;
+                const Arc* direct = g.find((node1 << 1) | (1 - rev1), to);
+                if (!direct) continue;
+                double short_cov = direct->supp;
+                double long_cov = (ain.supp + aout.supp) / 2.0;
+                LOGF(fp, "small_bubble cov:%.2lf %u:%c -> %u:%c\n", short_cov, node1, "+-"[1 - rev1], node2, "+-"[rev2]);
+                LOGF(fp, "             cov:%.2lf %u:%c -> %u:%c -> %u:%c\n", long_cov, node1, "+-"[1 - rev1], i, "+-"[0], node2, "+-"[rev2]);
+                if (short_cov < long_cov) g.remove_edge(node1, 1 - rev1, node2, rev2);
+                else { g.remove_edge(node1, 1 - rev1, i, 0); g.remove_edge(i, 0, node2, rev2); }
+                removed++;
+                done = true;
+            }
+        }
+    }
+    if (fp) fclose(fp);
+    return removed;
+}
+
+}  // namespace hxh

@@ -1,0 +1,72 @@
+/* haslr_host.h — host side of the stage (C++ implementation, C interface so that the
+ * Python mirror in haslr_amd/ and the tests can drive it through ctypes).
+ *
+ * This is the part of haslr_assemble that stays on the CPU by design:
+ * text ingest, the order-dependent serial graph cleaning, path stitching and the writers whose
+ * bytes are the parity gate. All per-read and per-edge arithmetic goes through the `hx_backend`
+ * table, which the product fills with the HIP entry points of include/haslr_hip.h.
+ */
+#ifndef HASLR_HOST_H
+#define HASLR_HOST_H
+#include "haslr_types.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hxh_dataset hxh_dataset; /* parsed inputs, resident in host memory */
+typedef struct hxh_graph hxh_graph;     /* backbone graph */
+typedef struct hxh_run hxh_run;         /* one execution of the stage: dataset + params + backend + state */
+
+const char* hxh_last_error(void);
+
+/* ---- ingest (Contig.cpp:43-117, Longread.cpp:109-162, :234-302; kseq-compatible FASTA/FASTQ[.gz]) */
+hxh_dataset* hxh_dataset_load(const char* contig_path, const char* long_path, int long_fofn,
+                              const char* mapping_path, int mapping_fofn);
+void hxh_dataset_free(hxh_dataset*);
+void hxh_dataset_views(const hxh_dataset*, hx_contigs*, hx_reads*, hx_hits*, const uint64_t** read_hit_off);
+double hxh_dataset_uniq_freq(const hxh_dataset*);   /* Contig.cpp:162-174 */
+uint64_t hxh_dataset_total_read_bases(const hxh_dataset*);
+/* contig sequence as ASCII into caller buffer of contig length bytes */
+void hxh_dataset_contig_seq(const hxh_dataset*, uint32_t id, char* dst);
+
+/* ---- compute backend: the four hot-path operators. ctx is opaque to the host pipeline.
+ * The signatures are exactly the C-ABI of include/haslr_hip.h. */
+typedef struct {
+    void* ctx;
+    int (*chain_reads)(void* ctx, const hx_params*, hx_chain_out*);
+    int (*edge_support)(void* ctx, const hx_params*, hx_edges_out*);
+    int (*edge_coords)(void* ctx, uint32_t n_sel, const uint32_t* sel_edge, hx_coords_out*);
+    int (*poa_batch)(void* ctx, const hx_poa_params*, hx_cns_out*);
+    void (*free_chain)(void* ctx, hx_chain_out*);
+    void (*free_edges)(void* ctx, hx_edges_out*);
+    void (*free_coords)(void* ctx, hx_coords_out*);
+    void (*free_cns)(void* ctx, hx_cns_out*);
+    const char* (*last_error)(void);
+} hx_backend;
+
+/* ---- one run of the stage (main.cpp:115-219). out_dir may be NULL: no files are written
+ * (bench timing of the compute path); otherwise every reference output file is produced. */
+hxh_run* hxh_run_create(const hxh_dataset*, const hx_params*, const hx_backend*, const char* out_dir);
+void hxh_run_free(hxh_run*);
+/* stages, in reference order; each returns 0 or <0 */
+int hxh_run_chain(hxh_run*);          /* fix_alignments + build_compact_longreads (+ compact_uniq.txt) */
+int hxh_run_graph(hxh_run*);          /* bbg_build_graph .. clean_small_bubbles + branching log (+ gfa/stat/log files) */
+int hxh_run_coords(hxh_run*);         /* asm_calc_edge_coordinates_MT */
+int hxh_run_consensus(hxh_run*);      /* asm_cal_cns_seq_MT */
+int hxh_run_assemble(hxh_run*);       /* asm_get_assembly: asm.final.fa / .ann / log_asmfinal.txt */
+int hxh_run_all(hxh_run*);            /* all of the above */
+/* wall seconds of the last call of each stage: chain, graph(host), coords, consensus, assemble */
+void hxh_run_timings(const hxh_run*, double out[5]);
+/* results for tests: number of surviving undirected edges / their consensus */
+uint32_t hxh_run_n_edges(const hxh_run*);
+const hx_chain_out* hxh_run_chain_out(const hxh_run*);
+const hx_edges_out* hxh_run_edges_out(const hxh_run*);
+const hx_coords_out* hxh_run_coords_out(const hxh_run*);
+const hx_cns_out* hxh_run_cns_out(const hxh_run*);
+/* the assembled contigs, FASTA text (same bytes as asm.final.fa); valid until the run is freed */
+const char* hxh_run_assembly_fasta(const hxh_run*, uint64_t* len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,91 @@
+// host_internal.h — C++ internals of the host side (not part of any ABI).
+#ifndef HASLR_HOST_INTERNAL_H
+#define HASLR_HOST_INTERNAL_H
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "haslr_host.h"
+
+namespace hxh {
+
+extern thread_local std::string g_err;
+
+struct Dataset {
+    // contigs
+    std::vector<uint32_t> contig_len, contig_kc;
+    std::vector<double> contig_km;
+    std::vector<uint64_t> contig_off;
+    std::vector<uint8_t> contig_packed;
+    double uniq_freq = 0;
+    // reads
+    std::vector<uint32_t> read_len;
+    std::vector<uint64_t> read_off;
+    std::vector<uint8_t> read_packed;
+    uint64_t total_read_bases = 0;
+    // raw PAF records
+    std::vector<uint32_t> q_id, q_start, q_end, t_id, t_len, t_start, t_end, n_match, n_block;
+    std::vector<uint8_t> is_rev, mapq;
+    std::vector<uint64_t> cg_off;
+    std::vector<uint32_t> cg_ops;
+    std::vector<uint64_t> read_hit_off;
+
+    std::string contig_seq(uint32_t id) const {
+        std::string s(contig_len[id], 'A');
+        const uint8_t* p = contig_packed.data() + contig_off[id];
+        for (uint32_t i = 0; i < contig_len[id]; i++) s[i] = "ACGT"[(p[i >> 2] >> ((i & 3) * 2)) & 3];
+        return s;
+    }
+};
+
+Dataset* load_dataset(const char* contig_path, const char* long_path, bool long_fofn, const char* mapping_path, bool mapping_fofn);
+
+// ---------------------------------------------------------------------------------------------
+// Backbone graph. The reference keeps `vector<BBG_Node_t>` with two std::map<uint32_t,BBG_Edge_t>
+// per node (Backbone_graph.hpp:39-54). Here: one sorted arc vector per vertex (vertex = node*2 + side,
+// side 0 = leaving through the contig's 3' end), which iterates in the same ascending-key order.
+// Every undirected edge is two arcs (the arc and its twin), exactly as in the reference.
+// ---------------------------------------------------------------------------------------------
+struct Arc {
+    uint32_t key;        // (to_node << 1) | to_rev — the reference's map key
+    uint32_t supp;       // edge_supp.size()
+    uint32_t dev_edge;   // index of this directed edge in hx_edges_out
+    uint8_t flag = 0;    // traversal marker (Assemble.cpp:365-434: 11, 12, 21)
+    uint32_t head_end = 0, tail_beg = 0;
+    uint32_t n_cns_supp = 0;
+    int32_t cns_id = -1; // index into Run::cns (consensus in THIS arc's direction), -1 = none yet
+};
+
+struct Graph {
+    std::vector<std::vector<Arc>> adj;   // 2 * n_nodes
+    uint32_t n_nodes = 0;
+
+    static uint32_t twin_vertex(uint32_t key) { return key ^ 1u; }                 // (node2<<1)|(1-rev2)
+    static uint32_t twin_key(uint32_t vertex) { return vertex ^ 1u; }              // (node1<<1)|(1-rev1)
+    Arc* find(uint32_t v, uint32_t key);
+    const Arc* find(uint32_t v, uint32_t key) const { return const_cast<Graph*>(this)->find(v, key); }
+    void erase_arc(uint32_t v, uint32_t key);
+    // bbg_remove_edge (Backbone_graph.cpp:45-51)
+    void remove_edge(uint32_t node1, uint32_t rev1, uint32_t node2, uint32_t rev2) {
+        erase_arc((node1 << 1) | rev1, (node2 << 1) | rev2);
+        erase_arc((node2 << 1) | (1 - rev2), (node1 << 1) | (1 - rev1));
+    }
+    size_t deg(uint32_t node, uint32_t side) const { return adj[(node << 1) | side].size(); }
+};
+
+void graph_build(Graph& g, uint32_t n_nodes, const hx_edges_out& e);
+int graph_remove_weak_edges(Graph& g, uint32_t min_edge_sup);
+void graph_write_stats(const Graph& g, const Dataset& d, const std::string& path);
+void graph_write_gfa(const Graph& g, const Dataset& d, const std::string& path);
+void graph_report_branching(const Graph& g, const std::string& path);
+int clean_tips(Graph& g, int max_depth, const std::string& logpath);
+int clean_simple_bubbles(Graph& g, int max_depth, const std::string& logpath);
+int clean_super_bubbles(Graph& g, const std::string& logpath);
+int clean_small_bubbles(Graph& g, const std::string& logpath);
+
+std::string revcomp(const std::string& s);
+FILE* open_or_null(const std::string& path, const char* mode);   // "" -> nullptr (no file output)
+
+}  // namespace hxh
+#endif

@@ -1,0 +1,132 @@
+"""Python mirror of the host pipeline (libhaslr_host.so): ingest, graph cleaning, stitching, writers.
+
+Stage names follow the reference's main() (main.cpp:115-219): chain -> graph -> coords -> consensus ->
+assemble. The compute backend is a `ctypes_defs.Backend` table; the product fills it from
+libhaslr_hip.so (`haslr_amd.hip.HipContext.backend()`).
+"""
+import ctypes as C
+import os
+
+from . import ctypes_defs as T
+
+_LIBDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_LIBDIR, "libhaslr_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (or make -C haslr_amd/csrc)")
+        L = C.CDLL(path)
+        L.hxh_last_error.restype = C.c_char_p
+        L.hxh_dataset_load.restype = C.c_void_p
+        L.hxh_dataset_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+        L.hxh_dataset_free.argtypes = [C.c_void_p]
+        L.hxh_dataset_views.argtypes = [C.c_void_p, C.POINTER(T.Contigs), C.POINTER(T.Reads), C.POINTER(T.Hits), C.POINTER(T.u64p)]
+        L.hxh_dataset_uniq_freq.restype = C.c_double
+        L.hxh_dataset_uniq_freq.argtypes = [C.c_void_p]
+        L.hxh_dataset_total_read_bases.restype = C.c_uint64
+        L.hxh_dataset_total_read_bases.argtypes = [C.c_void_p]
+        L.hxh_run_create.restype = C.c_void_p
+        L.hxh_run_create.argtypes = [C.c_void_p, C.POINTER(T.Params), C.POINTER(T.Backend), C.c_char_p]
+        L.hxh_run_free.argtypes = [C.c_void_p]
+        for name in ("chain", "graph", "coords", "consensus", "assemble", "all"):
+            getattr(L, "hxh_run_" + name).argtypes = [C.c_void_p]
+        L.hxh_run_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double * 5)]
+        L.hxh_run_n_edges.argtypes = [C.c_void_p]
+        L.hxh_run_n_edges.restype = C.c_uint32
+        for name, ty in (("chain_out", T.ChainOut), ("edges_out", T.EdgesOut), ("coords_out", T.CoordsOut), ("cns_out", T.CnsOut)):
+            f = getattr(L, "hxh_run_" + name)
+            f.argtypes = [C.c_void_p]
+            f.restype = C.POINTER(ty)
+        L.hxh_run_assembly_fasta.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.hxh_run_assembly_fasta.restype = C.POINTER(C.c_char)
+        _lib = L
+    return _lib
+
+
+class HostError(RuntimeError):
+    pass
+
+
+class Dataset:
+    """Parsed inputs resident in host memory (contigs, packed long reads, raw PAF records)."""
+
+    def __init__(self, contigs, reads, paf, long_fofn=False, mapping_fofn=False):
+        L = lib()
+        self._h = L.hxh_dataset_load(os.fsencode(contigs), os.fsencode(reads), int(long_fofn), os.fsencode(paf), int(mapping_fofn))
+        if not self._h:
+            raise HostError(L.hxh_last_error().decode())
+        self.contigs, self.reads, self.hits = T.Contigs(), T.Reads(), T.Hits()
+        self.read_hit_off = T.u64p()
+        L.hxh_dataset_views(self._h, C.byref(self.contigs), C.byref(self.reads), C.byref(self.hits), C.byref(self.read_hit_off))
+        self.uniq_freq = L.hxh_dataset_uniq_freq(self._h)
+        self.total_read_bases = L.hxh_dataset_total_read_bases(self._h)
+
+    def params(self, **kw):
+        return T.default_params(self.uniq_freq, **kw)
+
+    def close(self):
+        if self._h:
+            lib().hxh_dataset_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Run:
+    """One execution of the stage. `out_dir=None` writes no files (timing of the compute path)."""
+
+    def __init__(self, dataset, params, backend, out_dir=None):
+        self._ds, self._be, self._prm = dataset, backend, params   # keep alive
+        if out_dir is not None:
+            os.makedirs(out_dir, exist_ok=True)
+        self._h = lib().hxh_run_create(dataset._h, C.byref(params), C.byref(backend), os.fsencode(out_dir) if out_dir else None)
+
+    def _call(self, name):
+        if getattr(lib(), "hxh_run_" + name)(self._h) != 0:
+            raise HostError(lib().hxh_last_error().decode())
+
+    def chain(self): self._call("chain")
+    def graph(self): self._call("graph")
+    def coords(self): self._call("coords")
+    def consensus(self): self._call("consensus")
+    def assemble(self): self._call("assemble")
+    def all(self): self._call("all")
+
+    def timings(self):
+        t = (C.c_double * 5)()
+        lib().hxh_run_timings(self._h, C.byref(t))
+        return dict(zip(("chain", "graph", "coords", "consensus", "assemble"), t))
+
+    @property
+    def n_edges(self): return lib().hxh_run_n_edges(self._h)
+    def chain_out(self): return T.chain_to_dict(lib().hxh_run_chain_out(self._h).contents)
+    def edges_out(self, sides=True): return T.edges_to_dict(lib().hxh_run_edges_out(self._h).contents, sides)
+    def coords_out(self): return T.coords_to_dict(lib().hxh_run_coords_out(self._h).contents)
+    def cns_out(self): return T.cns_to_list(lib().hxh_run_cns_out(self._h).contents)
+    def cns_stats(self):
+        c = lib().hxh_run_cns_out(self._h).contents
+        return {"dp_cells": c.dp_cells, "seq_bases": c.seq_bases, "n_aligned": c.n_aligned}
+
+    def assembly_fasta(self):
+        n = C.c_uint64()
+        p = lib().hxh_run_assembly_fasta(self._h, C.byref(n))
+        return C.string_at(p, n.value).decode()
+
+    def close(self):
+        if self._h:
+            lib().hxh_run_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,49 @@
+"""ctypes loader for the TEST ORACLE (oracle/liboracle.so). Only tests/, smoke() and bench.py's
+cpu_baseline leg may import this."""
+import ctypes as C
+import os
+
+from haslr_amd import ctypes_defs as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_ctx_create.restype = C.c_void_p
+        L.orc_ctx_create.argtypes = [C.POINTER(T.Contigs), C.POINTER(T.Reads), C.POINTER(T.Hits), T.u64p, C.c_int]
+        L.orc_ctx_destroy.argtypes = [C.c_void_p]
+        L.orc_backend_fill.argtypes = [C.c_void_p, C.POINTER(T.Backend)]
+        L.orc_poa_consensus.restype = C.c_void_p
+        L.orc_poa_consensus.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(T.PoaParams)]
+        L.orc_free_str.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class OracleBackend:
+    """The CPU restatement behind the host pipeline's backend table."""
+
+    def __init__(self, dataset, n_threads=1):
+        self._ds = dataset
+        self._ctx = lib().orc_ctx_create(C.byref(dataset.contigs), C.byref(dataset.reads), C.byref(dataset.hits), dataset.read_hit_off, n_threads)
+        self.table = T.Backend()
+        lib().orc_backend_fill(self._ctx, C.byref(self.table))
+
+    def close(self):
+        if self._ctx:
+            lib().orc_ctx_destroy(self._ctx)
+            self._ctx = None
+
+
+def poa_consensus(seqs, match=5, mismatch=-4, gap=-8):
+    arr = (C.c_char_p * len(seqs))(*[s.encode() for s in seqs])
+    pp = T.PoaParams(match, mismatch, gap)
+    p = lib().orc_poa_consensus(arr, len(seqs), C.byref(pp))
+    s = C.string_at(p).decode()
+    lib().orc_free_str(p)
+    return s
