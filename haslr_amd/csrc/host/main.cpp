@@ -1,0 +1,150 @@
+// haslr_assemble — drop-in replacement of the reference's CLI for the backbone + consensus stage.
+//
+// Same command line as the reference binary that bin/haslr.py:66 invokes (Commandline.cpp:77-93):
+//   haslr_assemble -t N -c contigs.fa -l reads.fa -m map.paf -d outdir
+//                  [--aln-block INT] [--aln-sim FLOAT] [--uniq-dev FLOAT] [--edge-sup INT]
+//                  [--long-fofn] [--mapping-fofn] [--version] [-h]
+// and the same conventions: exit 0 on success and for -h / --version (haslr.py's check_program relies on it),
+// `[ERROR] ...` on stderr + EXIT_FAILURE otherwise, progress on stderr, outputs inside -d.
+// Build-only additions: --device INT (HIP device, default 0), --poa-block INT.
+// -t is accepted and clamped like the reference's, but the per-read / per-edge work runs on the GPU.
+// index.contig / index.longread (raw struct dumps with process pointers, Contig.cpp:119-159,
+// Longread.cpp:322-372) are not written: they are caches of the reference's own memory layout.
+#include <getopt.h>
+#include <sys/resource.h>
+#include <sys/stat.h>
+#include <sys/time.h>
+
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+
+#include "../../../include/haslr_hip.h"
+#include "haslr_host.h"
+
+static const char* kVersion = "0.8a1";   // the reference's prog_version (Commandline.cpp:65): same pipeline stage, same outputs
+
+static double cpu_time() {
+    struct rusage t;
+    getrusage(RUSAGE_SELF, &t);
+    return t.ru_utime.tv_sec + t.ru_utime.tv_usec / 1e6 + t.ru_stime.tv_sec + t.ru_stime.tv_usec / 1e6;
+}
+static double real_time() {
+    struct timeval t;
+    gettimeofday(&t, nullptr);
+    return t.tv_sec + t.tv_usec / 1e6;
+}
+
+static void help_short() { fprintf(stderr, "usage: haslr_assemble -c contig.fasta -l longread.fasta -m lr2contig.paf -d outdir [options]\n"); }
+
+static void help(const hx_params& p) {
+    help_short();
+    fprintf(stderr, "\nRequired options:\n");
+    fprintf(stderr, "    -c STR            Path to contigs file (also --contig)\n");
+    fprintf(stderr, "    -l STR            Path to long read dataset (also --long)\n");
+    fprintf(stderr, "    -m STR            Path to mappings of long reads onto contigs (also --mapping)\n");
+    fprintf(stderr, "    -d STR            Path to the output directory (also --dir)\n");
+    fprintf(stderr, "\nAdvanced options:\n");
+    fprintf(stderr, "    --aln-block       Minimum length of alignment block [%d]\n", p.min_aln_block);
+    fprintf(stderr, "    --aln-sim         Minimum alignment similarity [%.2lf]\n", p.min_aln_sim);
+    fprintf(stderr, "    --uniq-dev        Maximum deviation from mean frequency of uniq contigs [%.2lf]\n", p.max_uniq_dev);
+    fprintf(stderr, "    --edge-sup        Minimum number of long read supporting each edge [%d]\n", p.min_edge_sup);
+    fprintf(stderr, "\nOther options:\n");
+    fprintf(stderr, "    -t INT            Number of CPU cores to use (also --threads)\n");
+    fprintf(stderr, "    --long-fofn       The file passed by -l is fofn\n");
+    fprintf(stderr, "    --mapping-fofn    The file passed by -m is fofn\n");
+    fprintf(stderr, "    --device INT      HIP device to run on [0]\n");
+    fprintf(stderr, "    --version         Prints version (%s)\n", kVersion);
+    fprintf(stderr, "    -h                Prints this help message (also --help)\n\n");
+}
+
+int main(int argc, char* argv[]) {
+    hx_params prm{500, 0.85, 55, 0.15, 3, 0.0};
+    std::string contig_path, long_path, mapping_path, out_dir;
+    bool long_fofn = false, mapping_fofn = false;
+    unsigned num_threads = 1;
+    int device = 0, poa_block = 0;
+    if (argc == 1) { help_short(); return EXIT_FAILURE; }
+    static struct option lo[] = {{"contig", required_argument, 0, 'c'}, {"long", required_argument, 0, 'l'}, {"mapping", required_argument, 0, 'm'},
+                                 {"dir", required_argument, 0, 'd'}, {"help", no_argument, 0, 'h'}, {"threads", required_argument, 0, 't'},
+                                 {"version", no_argument, 0, 0}, {"long-fofn", no_argument, 0, 0}, {"mapping-fofn", no_argument, 0, 0},
+                                 {"aln-block", required_argument, 0, 0}, {"aln-sim", required_argument, 0, 0}, {"uniq-dev", required_argument, 0, 0},
+                                 {"edge-sup", required_argument, 0, 0}, {"device", required_argument, 0, 0}, {"poa-block", required_argument, 0, 0}, {0, 0, 0, 0}};
+    int ch, li;
+    while ((ch = getopt_long(argc, argv, "c:l:m:d:t:h", lo, &li)) != -1) {
+        switch (ch) {
+            case 'c': contig_path = optarg; break;
+            case 'l': long_path = optarg; break;
+            case 'm': mapping_path = optarg; break;
+            case 'd': out_dir = optarg; break;
+            case 't': {
+                int v = atoi(optarg), hw = (int)std::thread::hardware_concurrency();
+                num_threads = v < 1 ? 1 : (v > hw ? (unsigned)hw : (unsigned)v);
+                break;
+            }
+            case 'h': help(prm); return EXIT_SUCCESS;
+            case 0:
+                if (li == 6) { fprintf(stdout, "%s\n", kVersion); return EXIT_SUCCESS; }
+                else if (li == 7) long_fofn = true;
+                else if (li == 8) mapping_fofn = true;
+                else if (li == 9) { int v = atoi(optarg); prm.min_aln_block = v < 0 ? 500 : (uint32_t)v; }
+                else if (li == 10) { prm.min_aln_sim = atof(optarg); if (prm.min_aln_sim < 0 || prm.min_aln_sim > 1) prm.min_aln_sim = 0.85; }
+                else if (li == 11) prm.max_uniq_dev = atof(optarg);
+                else if (li == 12) { int v = atoi(optarg); prm.min_edge_sup = v < 0 ? 3 : (uint32_t)v; }
+                else if (li == 13) device = atoi(optarg);
+                else if (li == 14) poa_block = atoi(optarg);
+                else { help_short(); return EXIT_FAILURE; }
+                break;
+            default: help_short(); return EXIT_FAILURE;
+        }
+    }
+    const char* req[4][2] = {{"c", contig_path.c_str()}, {"l", long_path.c_str()}, {"m", mapping_path.c_str()}, {"d", out_dir.c_str()}};
+    for (auto& r : req)
+        if (!*r[1]) { fprintf(stderr, "[ERROR] (CommandLine:parseCommandLine) option -%s is required!\n", r[0]); help_short(); return EXIT_FAILURE; }
+    errno = 0;
+    if (mkdir(out_dir.c_str(), S_IRWXU | S_IRWXG | S_IROTH | S_IXOTH) == -1 && errno != EEXIST) return EXIT_FAILURE;
+    if (long_fofn) fprintf(stderr, "[NOTE] file passed by -l is a file of file names (FOFN)\n");
+    if (mapping_fofn) fprintf(stderr, "[NOTE] file passed by -m is a file of file names (FOFN)\n");
+    fprintf(stderr, "\n[NOTE] number of threads: %d\n\n", num_threads);
+    const double c0 = cpu_time(), r0 = real_time();
+    auto elapsed = [&]() { fprintf(stderr, "       elapsed time %.2lf CPU seconds (%.2lf real seconds)\n\n", cpu_time() - c0, real_time() - r0); };
+
+    hx_ctx* ctx = nullptr;
+    if (hx_ctx_create(device, nullptr, &ctx) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
+    if (poa_block) hx_set_poa_block(ctx, poa_block);
+
+    fprintf(stderr, "[NOTE] loading contig sequences, long read sequences and alignments...\n");
+    hxh_dataset* ds = hxh_dataset_load(contig_path.c_str(), long_path.c_str(), long_fofn, mapping_path.c_str(), mapping_fofn);
+    if (!ds) { fprintf(stderr, "%s\n", hxh_last_error()); return EXIT_FAILURE; }
+    hx_contigs vc; hx_reads vr; hx_hits vh; const uint64_t* rho;
+    hxh_dataset_views(ds, &vc, &vr, &vh, &rho);
+    fprintf(stderr, "       loaded %u contigs\n       loaded %u long reads\n       loaded %lu alignments\n", vc.n, vr.n, (unsigned long)vh.n);
+    prm.uniq_freq = hxh_dataset_uniq_freq(ds);
+    fprintf(stderr, "[NOTE] calculating kmer frequency of unique contigs\n       mean: %.2lf\n", prm.uniq_freq);
+    elapsed();
+    if (hx_upload(ctx, &vc, &vr, &vh, rho) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
+
+    hx_backend be;
+    hx_backend_fill(ctx, &be);
+    hxh_run* run = hxh_run_create(ds, &prm, &be, out_dir.c_str());
+    struct { const char* note; int (*fn)(hxh_run*); } stages[] = {
+        {"[NOTE] fixing overlapping alignments and building compact long reads...", hxh_run_chain},
+        {"[NOTE] building and cleaning the backbone graph...", hxh_run_graph},
+        {"[NOTE] calculating long read coordinates between anchors...", hxh_run_coords},
+        {"[NOTE] calling consensus sequence between anchors...", hxh_run_consensus},
+        {"[NOTE] generating the assembly from the cleaned backbone graph...", hxh_run_assemble}};
+    for (auto& st : stages) {
+        fprintf(stderr, "%s\n", st.note);
+        if (st.fn(run) != 0) { fprintf(stderr, "[ERROR] %s\n", hxh_last_error()); return EXIT_FAILURE; }
+        elapsed();
+    }
+    fprintf(stderr, "[NOTE] cleaning up the memory!\n");
+    hxh_run_free(run);
+    hxh_dataset_free(ds);
+    hx_ctx_destroy(ctx);
+    fprintf(stderr, "[NOTE] elapsed time %.2lf CPU seconds (%.2lf real seconds)\n\n*** BYE ***\n\n", cpu_time() - c0, real_time() - r0);
+    return EXIT_SUCCESS;
+}

@@ -1,0 +1,590 @@
+// hx_api.hip — implementation of the C-ABI in include/haslr_hip.h: device context, resident inputs,
+// the four hot-path operators (kernel orchestration + result download), multi-GPU record exchange, timing.
+// There is no CPU fallback here: without a usable HIP device every entry point fails with an error.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/haslr_hip.h"
+#include "host/haslr_host.h"
+#include "kernels/kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string& m) { g_err = m; return -1; }
+
+#define HIPCHK(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+    } while (0)
+
+template <class T>
+struct DV {   // device vector (capacity grows, never shrinks)
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) cap = std::max<size_t>(n, 1);
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    ~DV() { release(); }
+};
+
+struct DevSideBuf {
+    DV<uint32_t> qs, qe, ts, te, skf, skb;
+    DV<uint8_t> rev;
+    DV<uint64_t> cb, ce;
+    hipError_t reserve(size_t n) {
+        hipError_t e;
+        if ((e = qs.reserve(n)) || (e = qe.reserve(n)) || (e = ts.reserve(n)) || (e = te.reserve(n)) || (e = skf.reserve(n)) ||
+            (e = skb.reserve(n)) || (e = rev.reserve(n)) || (e = cb.reserve(n)) || (e = ce.reserve(n))) return e;
+        return hipSuccess;
+    }
+    DevSide view() { return DevSide{qs.p, qe.p, ts.p, te.p, rev.p, cb.p, ce.p, skf.p, skb.p}; }
+};
+
+struct RecBuf {
+    DV<uint64_t> key;
+    DV<uint32_t> lr, ch, ct;
+    DevSideBuf head, tail;
+    hipError_t reserve(size_t n) {
+        hipError_t e;
+        if ((e = key.reserve(n)) || (e = lr.reserve(n)) || (e = ch.reserve(n)) || (e = ct.reserve(n)) || (e = head.reserve(n)) || (e = tail.reserve(n))) return e;
+        return hipSuccess;
+    }
+    hxk::EdgeRecs view() { return hxk::EdgeRecs{key.p, lr.p, ch.p, ct.p, head.view(), tail.view()}; }
+};
+
+template <class T> T* host_copy(const T* d, size_t n) {
+    T* h = (T*)malloc(std::max<size_t>(1, n) * sizeof(T));
+    if (n) (void)hipMemcpy(h, d, n * sizeof(T), hipMemcpyDeviceToHost);
+    return h;
+}
+
+struct Timer {
+    hipEvent_t a = nullptr, b = nullptr;
+    double ms[4] = {0, 0, 0, 0};
+    uint64_t launches[4] = {0, 0, 0, 0};
+};
+
+}  // namespace
+
+struct hx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // resident inputs
+    uint32_t n_contigs = 0, n_reads = 0;
+    uint64_t n_hits = 0, n_ops = 0;
+    DV<double> km;
+    DV<uint32_t> clen;
+    DV<uint8_t> cls;
+    DV<uint32_t> rlen;
+    DV<uint64_t> roff;
+    DV<uint8_t> packed;
+    DV<uint32_t> q_id, q_start, q_end, t_id, t_len, t_start, t_end, n_match, n_block, cg_ops;
+    DV<uint8_t> is_rev, mapq;
+    DV<uint64_t> cg_off, rho;
+    std::vector<uint32_t> h_rlen;
+    std::vector<uint64_t> h_rho;
+    uint32_t lr_begin = 0, lr_end = 0;
+    DV<uint32_t> err;
+    // chain results
+    DV<uint32_t> c_hit, c_qs, c_qe, c_ts, c_te, c_nm, c_nb, c_skf, c_skb, c_cmp;
+    DV<uint64_t> c_cb, c_ce, aln_off, cmp_off;
+    uint64_t n_aln = 0, n_cmp = 0;
+    bool have_chain = false;
+    // edge records
+    RecBuf rec_un, rec;   // unsorted (emission order) and sorted
+    uint64_t n_rec_un = 0, n_rec = 0, n_edge = 0;
+    DV<uint64_t> edge_key, edge_off;
+    std::vector<uint64_t> h_edge_key, h_edge_off;
+    bool have_edges = false;
+    // coords results
+    DV<uint32_t> k_head_end, k_tail_beg, k_supp_lr, k_spos, k_epos;
+    std::vector<uint64_t> h_supp_off;
+    std::vector<uint32_t> h_supp_lr, h_spos, h_epos;
+    uint32_t n_sel = 0;
+    bool have_coords = false;
+    int poa_block = 256;
+    Timer tm;
+
+    DevHits hits_view() const {
+        return DevHits{n_hits, q_id.p, q_start.p, q_end.p, t_id.p, t_len.p, t_start.p, t_end.p, n_match.p, n_block.p, is_rev.p, mapq.p, cg_off.p, cg_ops.p};
+    }
+    hxk::ChainFinal chain_view() { return hxk::ChainFinal{c_hit.p, c_qs.p, c_qe.p, c_ts.p, c_te.p, c_nm.p, c_nb.p, c_skf.p, c_skb.p, c_cb.p, c_ce.p, c_cmp.p}; }
+    void tick() { (void)hipEventRecord(tm.a, stream); }
+    void tock(int k) {
+        (void)hipEventRecord(tm.b, stream);
+        (void)hipEventSynchronize(tm.b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, tm.a, tm.b);
+        tm.ms[k] += ms; tm.launches[k]++;
+    }
+};
+
+extern "C" const char* hx_last_error(void) { return g_err.c_str(); }
+
+extern "C" int hx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return fail("hipGetDeviceCount failed: no usable HIP device (the HIP path has no CPU fallback)");
+    return n;
+}
+
+extern "C" int hx_ctx_create(int device, void* stream, hx_ctx** out) {
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail("hx_ctx_create: no HIP device available (libhaslr_hip.so has no CPU fallback)");
+    if (device < 0 || device >= n) return fail("hx_ctx_create: device index out of range");
+    HIPCHK(hipSetDevice(device));
+    hx_ctx* c = new hx_ctx;
+    c->device = device;
+    if (stream) c->stream = (hipStream_t)stream;
+    else { HIPCHK(hipStreamCreate(&c->stream)); c->own_stream = true; }
+    HIPCHK(hipEventCreate(&c->tm.a));
+    HIPCHK(hipEventCreate(&c->tm.b));
+    HIPCHK(c->err.reserve(1));
+    *out = c;
+    return 0;
+}
+
+extern "C" void hx_ctx_destroy(hx_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->tm.a) (void)hipEventDestroy(c->tm.a);
+    if (c->tm.b) (void)hipEventDestroy(c->tm.b);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+template <class T>
+static int up(DV<T>& d, const T* h, size_t n) {
+    HIPCHK(d.reserve(n));
+    if (n) HIPCHK(hipMemcpy(d.p, h, n * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int hx_upload(hx_ctx* c, const hx_contigs* ctg, const hx_reads* rd, const hx_hits* h, const uint64_t* rho) {
+    HIPCHK(hipSetDevice(c->device));
+    c->n_contigs = ctg->n; c->n_reads = rd->n; c->n_hits = h->n; c->n_ops = h->cg_off[h->n];
+    if (up(c->km, ctg->mean_kmer, ctg->n) || up(c->clen, ctg->len, ctg->n)) return -1;
+    HIPCHK(c->cls.reserve(ctg->n));
+    if (up(c->rlen, rd->len, rd->n) || up(c->roff, rd->off, (size_t)rd->n + 1) || up(c->packed, rd->packed, (size_t)rd->off[rd->n])) return -1;
+    size_t n = h->n;
+    if (up(c->q_id, h->q_id, n) || up(c->q_start, h->q_start, n) || up(c->q_end, h->q_end, n) || up(c->t_id, h->t_id, n) || up(c->t_len, h->t_len, n) ||
+        up(c->t_start, h->t_start, n) || up(c->t_end, h->t_end, n) || up(c->n_match, h->n_match, n) || up(c->n_block, h->n_block, n) ||
+        up(c->is_rev, h->is_rev, n) || up(c->mapq, h->mapq, n) || up(c->cg_off, h->cg_off, n + 1) || up(c->cg_ops, h->cg_ops, (size_t)c->n_ops) ||
+        up(c->rho, rho, (size_t)rd->n + 1)) return -1;
+    c->h_rlen.assign(rd->len, rd->len + rd->n);
+    c->h_rho.assign(rho, rho + rd->n + 1);
+    c->lr_begin = 0; c->lr_end = rd->n;
+    c->have_chain = c->have_edges = c->have_coords = false;
+    return 0;
+}
+
+extern "C" int hx_set_read_shard(hx_ctx* c, uint32_t b, uint32_t e) {
+    if (b > e || e > c->n_reads) return fail("hx_set_read_shard: bad range");
+    c->lr_begin = b; c->lr_end = e;
+    return 0;
+}
+
+static int check_err(hx_ctx* c, const char* who) {
+    uint32_t e = 0;
+    HIPCHK(hipMemcpy(&e, c->err.p, 4, hipMemcpyDeviceToHost));
+    if (!e) return 0;
+    std::string m = std::string(who) + ":";
+    if (e & HXE_TRIM_NO_M) m += " overlap trim ran off an alignment without M;";
+    if (e & HXE_CHAIN_TOO_MANY) m += " more than 10000 chainable hits on one read (reference limit, Longread.cpp:529);";
+    if (e & HXE_SPOS_RANGE) m += " consensus support starts beyond its read;";
+    if (e & HXE_BAD_TID) m += " contig id out of range;";
+    return fail(m);
+}
+
+// ================================================================================================ K1-K3
+extern "C" int hx_chain_reads(hx_ctx* c, const hx_params* prm, hx_chain_out* out) {
+    memset(out, 0, sizeof(*out));
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t nr = c->lr_end - c->lr_begin;
+    const uint64_t nraw = c->h_rho[c->lr_end] - c->h_rho[c->lr_begin];
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemsetAsync(c->err.p, 0, 4, s));
+    const double thr_load = prm->uniq_freq * (3 + prm->max_uniq_dev), thr_uniq = prm->uniq_freq * (1 + prm->max_uniq_dev);
+    // scratch at raw-hit granularity
+    DV<uint32_t> s_hit, s_qs, s_qe, s_ts, s_te, s_nm, s_nb, s_skf, s_skb, s_dp, s_cmp, s_naln, s_ncmp;
+    DV<uint64_t> s_cb, s_ce;
+    DV<int32_t> s_from;
+    HIPCHK(s_hit.reserve(nraw)); HIPCHK(s_qs.reserve(nraw)); HIPCHK(s_qe.reserve(nraw)); HIPCHK(s_ts.reserve(nraw)); HIPCHK(s_te.reserve(nraw));
+    HIPCHK(s_nm.reserve(nraw)); HIPCHK(s_nb.reserve(nraw)); HIPCHK(s_skf.reserve(nraw)); HIPCHK(s_skb.reserve(nraw)); HIPCHK(s_dp.reserve(nraw));
+    HIPCHK(s_cmp.reserve(nraw)); HIPCHK(s_cb.reserve(nraw)); HIPCHK(s_ce.reserve(nraw)); HIPCHK(s_from.reserve(nraw));
+    HIPCHK(s_naln.reserve(nr)); HIPCHK(s_ncmp.reserve(nr));
+    hxk::ChainScratch sc{s_hit.p, s_qs.p, s_qe.p, s_ts.p, s_te.p, s_nm.p, s_nb.p, s_skf.p, s_skb.p, s_cb.p, s_ce.p, s_dp.p, s_from.p, s_cmp.p, s_naln.p, s_ncmp.p};
+    HIPCHK(c->aln_off.reserve((size_t)nr + 1)); HIPCHK(c->cmp_off.reserve((size_t)nr + 1));
+    c->tick();
+    hxk::contig_class(c->km.p, c->n_contigs, thr_load, thr_uniq, c->cls.p, s);
+    hxk::chain_reads(c->hits_view(), c->rho.p, c->cls.p, c->n_contigs, c->lr_begin, c->lr_end, prm->min_aln_block, prm->min_aln_sim, prm->min_aln_mapq, sc, c->err.p, s);
+    hxk::exclusive_scan_u32(s_naln.p, c->aln_off.p, nr, s);
+    hxk::exclusive_scan_u32(s_ncmp.p, c->cmp_off.p, nr, s);
+    uint64_t tot[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(&tot[0], c->aln_off.p + nr, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&tot[1], c->cmp_off.p + nr, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    c->n_aln = tot[0]; c->n_cmp = tot[1];
+    if (c->n_aln >= 0xffffffffULL) return fail("hx_chain_reads: more than 2^32-1 alignments in one shard");
+    HIPCHK(c->c_hit.reserve(c->n_aln)); HIPCHK(c->c_qs.reserve(c->n_aln)); HIPCHK(c->c_qe.reserve(c->n_aln)); HIPCHK(c->c_ts.reserve(c->n_aln));
+    HIPCHK(c->c_te.reserve(c->n_aln)); HIPCHK(c->c_nm.reserve(c->n_aln)); HIPCHK(c->c_nb.reserve(c->n_aln)); HIPCHK(c->c_skf.reserve(c->n_aln));
+    HIPCHK(c->c_skb.reserve(c->n_aln)); HIPCHK(c->c_cb.reserve(c->n_aln)); HIPCHK(c->c_ce.reserve(c->n_aln)); HIPCHK(c->c_cmp.reserve(c->n_cmp));
+    hxk::chain_compact(sc, c->rho.p, c->lr_begin, c->lr_end, c->aln_off.p, c->cmp_off.p, c->chain_view(), s);
+    c->tock(0);
+    HIPCHK(hipGetLastError());
+    if (check_err(c, "hx_chain_reads")) return -1;
+    c->have_chain = true; c->have_edges = c->have_coords = false;
+    // download
+    out->n_aln = c->n_aln; out->n_reads = nr; out->n_cmp = c->n_cmp;
+    out->hit = host_copy(c->c_hit.p, c->n_aln); out->q_start = host_copy(c->c_qs.p, c->n_aln); out->q_end = host_copy(c->c_qe.p, c->n_aln);
+    out->t_start = host_copy(c->c_ts.p, c->n_aln); out->t_end = host_copy(c->c_te.p, c->n_aln); out->n_match = host_copy(c->c_nm.p, c->n_aln);
+    out->n_block = host_copy(c->c_nb.p, c->n_aln); out->cg_begin = host_copy(c->c_cb.p, c->n_aln); out->cg_end = host_copy(c->c_ce.p, c->n_aln);
+    out->cg_skip_front = host_copy(c->c_skf.p, c->n_aln); out->cg_skip_back = host_copy(c->c_skb.p, c->n_aln);
+    out->read_off = host_copy(c->aln_off.p, (size_t)nr + 1); out->cmp_off = host_copy(c->cmp_off.p, (size_t)nr + 1); out->cmp_aln = host_copy(c->c_cmp.p, c->n_cmp);
+    return 0;
+}
+
+extern "C" void hx_free_chain(hx_ctx*, hx_chain_out* o) {
+    free(o->hit); free(o->q_start); free(o->q_end); free(o->t_start); free(o->t_end); free(o->n_match); free(o->n_block);
+    free(o->cg_begin); free(o->cg_end); free(o->cg_skip_front); free(o->cg_skip_back); free(o->read_off); free(o->cmp_off); free(o->cmp_aln);
+    memset(o, 0, sizeof(*o));
+}
+
+// ================================================================================================ K4
+extern "C" int hx_edge_emit(hx_ctx* c, const hx_params*, uint64_t* n_records) {
+    if (!c->have_chain) return fail("hx_edge_emit: hx_chain_reads has not run");
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t nr = c->lr_end - c->lr_begin;
+    hipStream_t s = c->stream;
+    DV<uint32_t> npairs;
+    DV<uint64_t> pair_off;
+    HIPCHK(npairs.reserve(nr)); HIPCHK(pair_off.reserve((size_t)nr + 1));
+    c->tick();
+    hxk::edge_count(c->hits_view(), c->cls.p, c->chain_view(), c->cmp_off.p, c->lr_begin, c->lr_end, npairs.p, s);
+    hxk::exclusive_scan_u32(npairs.p, pair_off.p, nr, s);
+    uint64_t tot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, pair_off.p + nr, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    c->n_rec_un = 2 * tot;
+    HIPCHK(c->rec_un.reserve(c->n_rec_un));
+    hxk::edge_emit(c->hits_view(), c->cls.p, c->chain_view(), c->cmp_off.p, c->lr_begin, c->lr_end, pair_off.p, c->rec_un.view(), s);
+    c->tock(1);
+    HIPCHK(hipGetLastError());
+    if (n_records) *n_records = c->n_rec_un;
+    return 0;
+}
+
+static void download_side(hx_rec_side& h, DevSideBuf& d, size_t n) {
+    h.q_start = host_copy(d.qs.p, n); h.q_end = host_copy(d.qe.p, n); h.t_start = host_copy(d.ts.p, n); h.t_end = host_copy(d.te.p, n);
+    h.is_rev = host_copy(d.rev.p, n); h.cg_begin = host_copy(d.cb.p, n); h.cg_end = host_copy(d.ce.p, n);
+    h.cg_skip_front = host_copy(d.skf.p, n); h.cg_skip_back = host_copy(d.skb.p, n);
+}
+
+// sort the n records sitting in rec_un by key (stable), segment into edges, download
+static int finish_edges(hx_ctx* c, uint64_t n, hx_edges_out* out) {
+    hipStream_t s = c->stream;
+    if (n >= 0xffffffffULL) return fail("hx_edge_support: more than 2^32-1 edge-support records");
+    int bits = 1;
+    while (bits < 32 && (1ull << bits) < 2ull * std::max<uint32_t>(1, c->n_contigs)) bits++;
+    DV<uint32_t> perm, perm_tmp, flag;
+    DV<uint64_t> key_tmp, fscan;
+    HIPCHK(perm.reserve(n)); HIPCHK(perm_tmp.reserve(n)); HIPCHK(flag.reserve(n)); HIPCHK(key_tmp.reserve(n)); HIPCHK(fscan.reserve(n + 1));
+    HIPCHK(c->rec.reserve(n));
+    c->tick();
+    hxk::iota_u32(perm.p, n, s);
+    hxk::radix_sort_pairs(c->rec_un.key.p, perm.p, key_tmp.p, perm_tmp.p, n, bits, bits, s);
+    if (n) HIPCHK(hipMemcpyAsync(c->rec.key.p, c->rec_un.key.p, n * 8, hipMemcpyDeviceToDevice, s));
+    hxk::edge_gather(c->rec_un.view(), perm.p, n, c->rec.view(), s);
+    hxk::segment_flags(c->rec.key.p, n, flag.p, s);
+    hxk::exclusive_scan_u32(flag.p, fscan.p, n, s);
+    uint64_t ne = 0;
+    HIPCHK(hipMemcpyAsync(&ne, fscan.p + n, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(c->edge_key.reserve(ne)); HIPCHK(c->edge_off.reserve(ne + 1));
+    if (n == 0) HIPCHK(hipMemsetAsync(c->edge_off.p, 0, 8, s));
+    hxk::segment_scatter(c->rec.key.p, fscan.p, n, c->edge_key.p, c->edge_off.p, s);
+    c->tock(1);
+    HIPCHK(hipGetLastError());
+    c->n_rec = n; c->n_edge = ne;
+    c->h_edge_key.resize(ne); c->h_edge_off.resize(ne + 1);
+    if (ne) HIPCHK(hipMemcpy(c->h_edge_key.data(), c->edge_key.p, ne * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(c->h_edge_off.data(), c->edge_off.p, (ne + 1) * 8, hipMemcpyDeviceToHost));
+    c->have_edges = true; c->have_coords = false;
+    memset(out, 0, sizeof(*out));
+    out->n_rec = n; out->n_edge = ne;
+    out->key = host_copy(c->rec.key.p, n); out->lr = host_copy(c->rec.lr.p, n); out->cmp_head = host_copy(c->rec.ch.p, n); out->cmp_tail = host_copy(c->rec.ct.p, n);
+    download_side(out->head, c->rec.head, n); download_side(out->tail, c->rec.tail, n);
+    out->edge_key = (uint64_t*)malloc(std::max<size_t>(1, ne) * 8); memcpy(out->edge_key, c->h_edge_key.data(), ne * 8);
+    out->edge_off = (uint64_t*)malloc((ne + 1) * 8); memcpy(out->edge_off, c->h_edge_off.data(), (ne + 1) * 8);
+    return 0;
+}
+
+extern "C" int hx_edge_support(hx_ctx* c, const hx_params* prm, hx_edges_out* out) {
+    memset(out, 0, sizeof(*out));
+    uint64_t n = 0;
+    if (hx_edge_emit(c, prm, &n)) return -1;
+    return finish_edges(c, n, out);
+}
+
+extern "C" uint32_t hx_edge_records_bytes(void) { return hxk::EDGE_REC_WORDS * 4; }
+
+extern "C" int hx_edge_records_export(hx_ctx* c, void* dst, uint64_t cap) {
+    if (cap < c->n_rec_un) return fail("hx_edge_records_export: destination too small");
+    HIPCHK(hipSetDevice(c->device));
+    hxk::edge_pack(c->rec_un.view(), c->n_rec_un, (uint32_t*)dst, c->stream);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int hx_edge_records_import(hx_ctx* c, const void* src, uint64_t n, hx_edges_out* out) {
+    memset(out, 0, sizeof(*out));
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(c->rec_un.reserve(n));
+    hxk::edge_unpack((const uint32_t*)src, n, c->rec_un.view(), c->stream);
+    c->n_rec_un = n;
+    return finish_edges(c, n, out);
+}
+
+static void free_side(hx_rec_side& s) {
+    free(s.q_start); free(s.q_end); free(s.t_start); free(s.t_end); free(s.is_rev); free(s.cg_begin); free(s.cg_end); free(s.cg_skip_front); free(s.cg_skip_back);
+}
+extern "C" void hx_free_edges(hx_ctx*, hx_edges_out* o) {
+    free(o->key); free(o->lr); free(o->cmp_head); free(o->cmp_tail); free_side(o->head); free_side(o->tail); free(o->edge_key); free(o->edge_off);
+    memset(o, 0, sizeof(*o));
+}
+
+// ================================================================================================ K5
+extern "C" int hx_edge_coords(hx_ctx* c, uint32_t n_sel, const uint32_t* sel, hx_coords_out* out) {
+    memset(out, 0, sizeof(*out));
+    if (!c->have_edges) return fail("hx_edge_coords: hx_edge_support has not run");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    std::vector<uint64_t> cap_off((size_t)n_sel + 1, 0);
+    for (uint32_t i = 0; i < n_sel; i++) {
+        if (sel[i] >= c->n_edge) return fail("hx_edge_coords: edge index out of range");
+        uint64_t key = c->h_edge_key[sel[i]], n = c->h_edge_off[sel[i] + 1] - c->h_edge_off[sel[i]];
+        bool hairpin = (((uint32_t)key) ^ 1u) == (uint32_t)(key >> 32);
+        cap_off[i + 1] = cap_off[i] + (hairpin ? 2 * n : n);
+    }
+    const uint64_t cap = cap_off[n_sel];
+    DV<uint32_t> d_sel, d_nsupp, t_lr, t_sp, t_ep, best_list;
+    DV<uint64_t> d_cap, d_out_off, b1, e1, b2, e2;
+    DV<uint8_t> cur;
+    HIPCHK(d_sel.reserve(n_sel)); HIPCHK(d_nsupp.reserve(n_sel)); HIPCHK(t_lr.reserve(cap)); HIPCHK(t_sp.reserve(cap)); HIPCHK(t_ep.reserve(cap));
+    HIPCHK(best_list.reserve(cap)); HIPCHK(d_cap.reserve((size_t)n_sel + 1)); HIPCHK(d_out_off.reserve((size_t)n_sel + 1));
+    HIPCHK(b1.reserve(cap)); HIPCHK(e1.reserve(cap)); HIPCHK(b2.reserve(cap)); HIPCHK(e2.reserve(cap)); HIPCHK(cur.reserve(cap));
+    HIPCHK(c->k_head_end.reserve(n_sel)); HIPCHK(c->k_tail_beg.reserve(n_sel));
+    if (n_sel) HIPCHK(hipMemcpyAsync(d_sel.p, sel, (size_t)n_sel * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_cap.p, cap_off.data(), ((size_t)n_sel + 1) * 8, hipMemcpyHostToDevice, s));
+    hxk::CoordsScratch sc{b1.p, e1.p, b2.p, e2.p, cur.p, nullptr, nullptr, best_list.p};
+    c->tick();
+    hxk::edge_coords(c->rec.view(), c->edge_key.p, c->edge_off.p, c->cg_ops.p, c->clen.p, c->rlen.p, n_sel, d_sel.p, d_cap.p, sc,
+                     c->k_head_end.p, c->k_tail_beg.p, d_nsupp.p, t_lr.p, t_sp.p, t_ep.p, s);
+    hxk::exclusive_scan_u32(d_nsupp.p, d_out_off.p, n_sel, s);
+    uint64_t tot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, d_out_off.p + n_sel, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(c->k_supp_lr.reserve(tot)); HIPCHK(c->k_spos.reserve(tot)); HIPCHK(c->k_epos.reserve(tot));
+    hxk::coords_compact(d_cap.p, d_out_off.p, n_sel, t_lr.p, t_sp.p, t_ep.p, c->k_supp_lr.p, c->k_spos.p, c->k_epos.p, s);
+    c->tock(2);
+    HIPCHK(hipGetLastError());
+    c->n_sel = n_sel;
+    c->h_supp_off.resize((size_t)n_sel + 1); c->h_supp_lr.resize(tot); c->h_spos.resize(tot); c->h_epos.resize(tot);
+    HIPCHK(hipMemcpy(c->h_supp_off.data(), d_out_off.p, ((size_t)n_sel + 1) * 8, hipMemcpyDeviceToHost));
+    if (tot) {
+        HIPCHK(hipMemcpy(c->h_supp_lr.data(), c->k_supp_lr.p, tot * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(c->h_spos.data(), c->k_spos.p, tot * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(c->h_epos.data(), c->k_epos.p, tot * 4, hipMemcpyDeviceToHost));
+    }
+    c->have_coords = true;
+    out->n_edge = n_sel;
+    out->head_end = host_copy(c->k_head_end.p, n_sel); out->tail_beg = host_copy(c->k_tail_beg.p, n_sel);
+    out->supp_off = (uint64_t*)malloc(((size_t)n_sel + 1) * 8); memcpy(out->supp_off, c->h_supp_off.data(), ((size_t)n_sel + 1) * 8);
+    out->supp_lr = (uint32_t*)malloc(std::max<size_t>(1, tot) * 4); memcpy(out->supp_lr, c->h_supp_lr.data(), tot * 4);
+    out->spos = (uint32_t*)malloc(std::max<size_t>(1, tot) * 4); memcpy(out->spos, c->h_spos.data(), tot * 4);
+    out->epos = (uint32_t*)malloc(std::max<size_t>(1, tot) * 4); memcpy(out->epos, c->h_epos.data(), tot * 4);
+    return 0;
+}
+
+extern "C" void hx_free_coords(hx_ctx*, hx_coords_out* o) {
+    free(o->head_end); free(o->tail_beg); free(o->supp_off); free(o->supp_lr); free(o->spos); free(o->epos);
+    memset(o, 0, sizeof(*o));
+}
+
+// ================================================================================================ K6
+namespace {
+struct PoaPlan {
+    std::vector<hxk::PoaSeq> seqs;
+    std::vector<hxk::PoaEdge> edges;
+    std::vector<uint64_t> sumL;
+    std::vector<uint32_t> nseq;
+};
+
+struct PoaPoolBufs {
+    DV<uint8_t> code, n_aligned, mark, check, row_code, row_sink, seq;
+    DV<uint32_t> aligned, in_head, in_tail, out_head, out_tail, rank2node, node2rank, stack, row_pred_off, pred_rank, e_from, e_to, e_next_in, e_next_out;
+    DV<int32_t> score, pred, e_w, aln_node, aln_pos, H;
+};
+}  // namespace
+
+extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out) {
+    memset(out, 0, sizeof(*out));
+    if (!c->have_coords) return fail("hx_poa_batch: hx_edge_coords has not run");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint32_t ne = c->n_sel;
+    // ---- plan: the sub-sequence rule of Assemble.cpp:530-537 (u32 wrap + substr clamp; empty ones skipped)
+    PoaPlan P;
+    P.edges.resize(ne); P.sumL.assign(ne, 0); P.nseq.assign(ne, 0);
+    uint64_t seq_bases = 0, n_aligned = 0;
+    for (uint32_t e = 0; e < ne; e++) {
+        hxk::PoaEdge& E = P.edges[e];
+        memset(&E, 0, sizeof(E));
+        E.seq_begin = (uint32_t)P.seqs.size();
+        for (uint64_t k = c->h_supp_off[e]; k < c->h_supp_off[e + 1]; k++) {
+            uint32_t rid = c->h_supp_lr[k] & 0x7fffffffu, strand = c->h_supp_lr[k] >> 31;
+            uint32_t rl = c->h_rlen[rid], sp = c->h_spos[k], ep = c->h_epos[k];
+            if (sp > rl) return fail("hx_poa_batch: consensus support starts beyond its read (the reference would throw std::out_of_range, Assemble.cpp:530)");
+            uint32_t want = ep - sp + 1, n = std::min(want, rl - sp);
+            if (n == 0) continue;
+            P.seqs.push_back({rid, strand, sp, n});
+            P.sumL[e] += n; P.nseq[e]++; E.lmax = std::max(E.lmax, n);
+            seq_bases += n; n_aligned++;
+        }
+        E.seq_end = (uint32_t)P.seqs.size();
+    }
+    std::vector<uint32_t> todo;
+    for (uint32_t e = 0; e < ne; e++) if (P.nseq[e]) todo.push_back(e);
+    std::vector<uint32_t> cns_len(ne, 0);
+    std::vector<std::string> cns(ne);
+    DV<hxk::PoaSeq> d_seqs;
+    HIPCHK(d_seqs.reserve(P.seqs.size()));
+    if (!P.seqs.empty()) HIPCHK(hipMemcpyAsync(d_seqs.p, P.seqs.data(), P.seqs.size() * sizeof(hxk::PoaSeq), hipMemcpyHostToDevice, s));
+    DV<unsigned long long> d_cells;
+    HIPCHK(d_cells.reserve(1));
+    HIPCHK(hipMemsetAsync(d_cells.p, 0, 8, s));
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t budget = (uint64_t)(free_b * 0.8);
+    PoaPoolBufs B;
+    DV<hxk::PoaEdge> d_edges;
+    DV<uint32_t> d_order, d_len, d_status;
+    DV<char> d_cns;
+    bool worst_case = false;
+    while (!todo.empty()) {
+        // ---- workspace sizes; estimated graph capacity first, the proven worst case on retry
+        for (uint32_t e : todo) {
+            hxk::PoaEdge& E = P.edges[e];
+            uint64_t est = (uint64_t)E.lmax * (3 + P.nseq[e] / 10) + 1024;
+            uint64_t vc = worst_case ? P.sumL[e] : std::min<uint64_t>(P.sumL[e], est);
+            if (vc >= 0x7fffffffULL) return fail("hx_poa_batch: POA graph too large");
+            E.vcap = (uint32_t)vc; E.hrows = E.vcap; E.ecap = (uint32_t)(P.sumL[e] + P.nseq[e] + 1);
+        }
+        // largest first (block scheduling is in grid order): cost ~ rows x columns x sequences
+        std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) {
+            uint64_t ca = (uint64_t)P.edges[a].vcap * P.edges[a].lmax, cb = (uint64_t)P.edges[b].vcap * P.edges[b].lmax;
+            return ca != cb ? ca > cb : a < b;
+        });
+        // ---- batches that fit the memory budget
+        size_t pos = 0;
+        std::vector<uint32_t> retry;
+        while (pos < todo.size()) {
+            uint64_t no = 0, eo = 0, ho = 0, so = 0, co = 0, sto = 0, ao = 0, bytes = 0;
+            size_t end = pos;
+            std::vector<uint32_t> batch;
+            while (end < todo.size()) {
+                hxk::PoaEdge& E = P.edges[todo[end]];
+                uint64_t nn = (uint64_t)E.vcap + 1, hc = nn * ((uint64_t)E.lmax + 1);
+                uint64_t b = nn * 56 + (uint64_t)E.ecap * 24 + hc * 4 + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8;
+                if (!batch.empty() && bytes + b > budget) break;
+                E.node_off = no; E.edge_off = eo; E.h_off = ho; E.seq_off = so; E.cns_off = co; E.stack_off = sto; E.aln_off = ao;
+                no += nn; eo += E.ecap; ho += hc; so += E.lmax; co += E.vcap; sto += 4 * nn + E.ecap; ao += nn + E.lmax + 2;
+                bytes += b;
+                batch.push_back(todo[end]);
+                end++;
+            }
+            if (bytes > budget) return fail("hx_poa_batch: a single edge needs more POA workspace than the device has free");
+            HIPCHK(B.code.reserve(no)); HIPCHK(B.n_aligned.reserve(no)); HIPCHK(B.mark.reserve(no)); HIPCHK(B.check.reserve(no));
+            HIPCHK(B.row_code.reserve(no)); HIPCHK(B.row_sink.reserve(no)); HIPCHK(B.aligned.reserve(3 * no)); HIPCHK(B.in_head.reserve(no));
+            HIPCHK(B.in_tail.reserve(no)); HIPCHK(B.out_head.reserve(no)); HIPCHK(B.out_tail.reserve(no)); HIPCHK(B.rank2node.reserve(no));
+            HIPCHK(B.node2rank.reserve(no)); HIPCHK(B.row_pred_off.reserve(no)); HIPCHK(B.score.reserve(no)); HIPCHK(B.pred.reserve(no));
+            HIPCHK(B.pred_rank.reserve(eo)); HIPCHK(B.e_from.reserve(eo)); HIPCHK(B.e_to.reserve(eo)); HIPCHK(B.e_next_in.reserve(eo));
+            HIPCHK(B.e_next_out.reserve(eo)); HIPCHK(B.e_w.reserve(eo)); HIPCHK(B.stack.reserve(sto)); HIPCHK(B.aln_node.reserve(ao));
+            HIPCHK(B.aln_pos.reserve(ao)); HIPCHK(B.H.reserve(ho)); HIPCHK(B.seq.reserve(so)); HIPCHK(d_cns.reserve(co));
+            HIPCHK(d_edges.reserve(ne)); HIPCHK(d_order.reserve(batch.size())); HIPCHK(d_len.reserve(ne)); HIPCHK(d_status.reserve(ne));
+            HIPCHK(hipMemcpyAsync(d_edges.p, P.edges.data(), (size_t)ne * sizeof(hxk::PoaEdge), hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(d_order.p, batch.data(), batch.size() * 4, hipMemcpyHostToDevice, s));
+            hxk::PoaPools pools{B.code.p, B.n_aligned.p, B.aligned.p, B.in_head.p, B.in_tail.p, B.out_head.p, B.out_tail.p, B.rank2node.p, B.node2rank.p,
+                                B.mark.p, B.check.p, B.stack.p, B.score.p, B.pred.p, B.row_code.p, B.row_sink.p, B.row_pred_off.p, B.pred_rank.p,
+                                B.e_from.p, B.e_to.p, B.e_next_in.p, B.e_next_out.p, B.e_w.p, B.aln_node.p, B.aln_pos.p, B.H.p, B.seq.p};
+            c->tick();
+            hxk::poa_run(d_edges.p, d_order.p, (uint32_t)batch.size(), d_seqs.p, c->packed.p, c->roff.p, c->rlen.p, pools, 0, pp->match, pp->mismatch, pp->gap,
+                         d_cns.p, d_len.p, d_status.p, d_cells.p, c->poa_block, s);
+            c->tock(3);
+            HIPCHK(hipGetLastError());
+            std::vector<uint32_t> h_len(ne), h_status(ne);
+            HIPCHK(hipMemcpy(h_len.data(), d_len.p, (size_t)ne * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(h_status.data(), d_status.p, (size_t)ne * 4, hipMemcpyDeviceToHost));
+            std::vector<char> h_cns(co);
+            if (co) HIPCHK(hipMemcpy(h_cns.data(), d_cns.p, co, hipMemcpyDeviceToHost));
+            for (uint32_t e : batch) {
+                if (h_status[e] & HXE_POA_OVERFLOW) {
+                    if (worst_case) return fail("hx_poa_batch: POA workspace overflow at worst-case size (internal error)");
+                    retry.push_back(e);
+                } else cns[e].assign(h_cns.data() + P.edges[e].cns_off, h_len[e]);
+            }
+            pos = end;
+        }
+        todo.swap(retry);
+        worst_case = true;
+    }
+    unsigned long long cells = 0;
+    HIPCHK(hipMemcpy(&cells, d_cells.p, 8, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> off((size_t)ne + 1, 0);
+    for (uint32_t e = 0; e < ne; e++) off[e + 1] = off[e] + cns[e].size();
+    out->n_edge = ne;
+    out->cns_off = (uint64_t*)malloc(((size_t)ne + 1) * 8); memcpy(out->cns_off, off.data(), ((size_t)ne + 1) * 8);
+    out->cns = (char*)malloc(std::max<uint64_t>(1, off[ne]));
+    for (uint32_t e = 0; e < ne; e++) memcpy(out->cns + off[e], cns[e].data(), cns[e].size());
+    out->dp_cells = cells; out->seq_bases = seq_bases; out->n_aligned = n_aligned;
+    return 0;
+}
+
+extern "C" void hx_free_cns(hx_ctx*, hx_cns_out* o) { free(o->cns_off); free(o->cns); memset(o, 0, sizeof(*o)); }
+
+// ================================================================================================ misc
+extern "C" void hx_timing_reset(hx_ctx* c) { for (int i = 0; i < 4; i++) { c->tm.ms[i] = 0; c->tm.launches[i] = 0; } }
+extern "C" void hx_timing_get(hx_ctx* c, double* ms, uint64_t* launches) { for (int i = 0; i < 4; i++) { ms[i] = c->tm.ms[i]; launches[i] = c->tm.launches[i]; } }
+extern "C" void hx_set_poa_block(hx_ctx* c, int t) { c->poa_block = t >= 512 ? 512 : t >= 256 ? 256 : 64; }
+
+static int be_chain(void* p, const hx_params* a, hx_chain_out* o) { return hx_chain_reads((hx_ctx*)p, a, o); }
+static int be_edges(void* p, const hx_params* a, hx_edges_out* o) { return hx_edge_support((hx_ctx*)p, a, o); }
+static int be_coords(void* p, uint32_t n, const uint32_t* s, hx_coords_out* o) { return hx_edge_coords((hx_ctx*)p, n, s, o); }
+static int be_poa(void* p, const hx_poa_params* a, hx_cns_out* o) { return hx_poa_batch((hx_ctx*)p, a, o); }
+static void be_fc(void* p, hx_chain_out* o) { hx_free_chain((hx_ctx*)p, o); }
+static void be_fe(void* p, hx_edges_out* o) { hx_free_edges((hx_ctx*)p, o); }
+static void be_fk(void* p, hx_coords_out* o) { hx_free_coords((hx_ctx*)p, o); }
+static void be_fn(void* p, hx_cns_out* o) { hx_free_cns((hx_ctx*)p, o); }
+
+extern "C" void hx_backend_fill(hx_ctx* c, void* table) {
+    hx_backend* b = (hx_backend*)table;
+    b->ctx = c; b->chain_reads = be_chain; b->edge_support = be_edges; b->edge_coords = be_coords; b->poa_batch = be_poa;
+    b->free_chain = be_fc; b->free_edges = be_fe; b->free_coords = be_fk; b->free_cns = be_fn; b->last_error = hx_last_error;
+}

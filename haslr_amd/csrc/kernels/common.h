@@ -1,0 +1,74 @@
+// common.h — shared device helpers for the gfx950 kernels (wave = 64 lanes everywhere).
+#ifndef HX_KERNELS_COMMON_H
+#define HX_KERNELS_COMMON_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "haslr_types.h"
+
+#define HX_WAVE 64
+
+// error bits reported through hx_ctx's device error word
+enum {
+    HXE_TRIM_NO_M = 1,        // overlap trim ran off an alignment without any M (undefined in the reference)
+    HXE_CHAIN_TOO_MANY = 2,   // > 10000 chainable hits on one read (reference stack arrays, Longread.cpp:529)
+    HXE_SPOS_RANGE = 4,       // consensus support starts beyond its read (std::out_of_range in the reference)
+    HXE_POA_OVERFLOW = 8,     // POA graph outgrew its workspace (host retries with the worst-case size)
+    HXE_BAD_TID = 16,
+};
+
+// contig class bits, computed once per run from mean_kmer and the three thresholds of SURVEY.md A.1
+enum {
+    HXC_DROP_LOAD = 1,   // mean_kmer >  uniq*(3+dev)   Longread.cpp:272
+    HXC_UNIQUE = 2,      // mean_kmer <  uniq*(1+dev)   Longread.cpp:191  (palindrome rule)
+    HXC_DROP_CHAIN = 4,  // mean_kmer >  uniq*(1+dev)   Longread.cpp:539  (copy_count = 1)
+    HXC_EDGE_OK = 8,     // mean_kmer <= uniq*(1+dev)   Backbone_graph.cpp:160
+};
+
+struct DevHits {
+    uint64_t n;
+    const uint32_t *q_id, *q_start, *q_end, *t_id, *t_len, *t_start, *t_end, *n_match, *n_block;
+    const uint8_t *is_rev, *mapq;
+    const uint64_t* cg_off;
+    const uint32_t* cg_ops;
+};
+
+// one side of an edge-support record (device SoA, mirrors hx_rec_side)
+struct DevSide {
+    uint32_t *q_start, *q_end, *t_start, *t_end;
+    uint8_t* is_rev;
+    uint64_t *cg_begin, *cg_end;
+    uint32_t *cg_skip_front, *cg_skip_back;
+};
+
+struct CgView {
+    const uint32_t* ops;
+    uint64_t b, e;
+    uint32_t skf, skb;
+    __device__ __forceinline__ uint32_t eff(uint64_t k) const {
+        uint32_t l = HX_CG_LEN(ops[k]);
+        if (k == b) l -= skf;
+        if (k + 1 == e) l -= skb;
+        return l;
+    }
+};
+
+// wave-wide inclusive max-scan / sum-scan (64 lanes)
+__device__ __forceinline__ int wave_scan_max(int v) {
+#pragma unroll
+    for (int d = 1; d < HX_WAVE; d <<= 1) {
+        int o = __shfl_up(v, d, HX_WAVE);
+        if ((int)(threadIdx.x & (HX_WAVE - 1)) >= d) v = max(v, o);
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+#pragma unroll
+    for (int d = 1; d < HX_WAVE; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, HX_WAVE);
+        if ((int)(threadIdx.x & (HX_WAVE - 1)) >= d) v += o;
+    }
+    return v;
+}
+
+#endif

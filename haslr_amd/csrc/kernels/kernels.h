@@ -1,0 +1,105 @@
+// kernels.h — host-callable launchers of the gfx950 kernels. All launch on `stream` and return
+// immediately; temporary buffers they need come from the caller (sizes via the *_temp_* helpers)
+// or are allocated internally where noted.
+#ifndef HX_KERNELS_H
+#define HX_KERNELS_H
+#include "common.h"
+
+namespace hxk {
+
+// ---- primitives.hip
+// out[i] = sum(in[0..i)), out[n] = total.  (n+1 outputs)
+void exclusive_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, hipStream_t s);
+// stable LSD radix sort of (key, val) pairs on bits [0,bits_lo) and [32,32+bits_hi) of the key
+void radix_sort_pairs(uint64_t* key, uint32_t* val, uint64_t* key_tmp, uint32_t* val_tmp, uint64_t n,
+                      int bits_lo, int bits_hi, hipStream_t s);
+
+// ---- chain.hip (K0-K3)
+struct ChainScratch {   // all sized by the number of raw hits in the shard (+1)
+    uint32_t *hit, *qs, *qe, *ts, *te, *nm, *nb, *skf, *skb;
+    uint64_t *cb, *ce;
+    uint32_t* dp;
+    int32_t* from;
+    uint32_t* cmp;        // local compact indices
+    uint32_t *n_aln, *n_cmp;   // per read of the shard
+};
+void contig_class(const double* mean_kmer, uint32_t n, double thr_load, double thr_uniq, uint8_t* cls, hipStream_t s);
+void chain_reads(const DevHits& h, const uint64_t* read_hit_off, const uint8_t* cls, uint32_t n_contigs,
+                 uint32_t lr_begin, uint32_t lr_end, uint32_t min_aln_block, double min_aln_sim, uint32_t min_mapq,
+                 const ChainScratch& sc, uint32_t* err, hipStream_t s);
+struct ChainFinal {
+    uint32_t *hit, *qs, *qe, *ts, *te, *nm, *nb, *skf, *skb;
+    uint64_t *cb, *ce;
+    uint32_t* cmp_aln;
+};
+void chain_compact(const ChainScratch& sc, const uint64_t* read_hit_off, uint32_t lr_begin, uint32_t lr_end,
+                   const uint64_t* aln_off, const uint64_t* cmp_off, const ChainFinal& out, hipStream_t s);
+
+// ---- edges.hip (K4)
+struct EdgeRecs {
+    uint64_t* key;
+    uint32_t *lr, *cmp_head, *cmp_tail;
+    DevSide head, tail;
+};
+void edge_count(const DevHits& h, const uint8_t* cls, const ChainFinal& c, const uint64_t* cmp_off,
+                uint32_t lr_begin, uint32_t lr_end, uint32_t* n_pairs, hipStream_t s);
+void edge_emit(const DevHits& h, const uint8_t* cls, const ChainFinal& c, const uint64_t* cmp_off,
+               uint32_t lr_begin, uint32_t lr_end, const uint64_t* pair_off, const EdgeRecs& out, hipStream_t s);
+void edge_gather(const EdgeRecs& in, const uint32_t* perm, uint64_t n, const EdgeRecs& out, hipStream_t s);
+constexpr int EDGE_REC_WORDS = 28;   // packed exchange record, dwords
+void edge_pack(const EdgeRecs& r, uint64_t n, uint32_t* dst, hipStream_t s);
+void edge_unpack(const uint32_t* src, uint64_t n, const EdgeRecs& r, hipStream_t s);
+void iota_u32(uint32_t* p, uint64_t n, hipStream_t s);
+// head flags of equal-key segments (flag[i] = key[i] != key[i-1])
+void segment_flags(const uint64_t* key, uint64_t n, uint32_t* flag, hipStream_t s);
+void segment_scatter(const uint64_t* key, const uint64_t* flag_scan, uint64_t n, uint64_t* edge_key, uint64_t* edge_off, hipStream_t s);
+
+// ---- coords.hip (K5)
+struct CoordsScratch {   // sized by records of the selected edges (x2 for the output lists)
+    uint64_t *beg1, *end1, *beg2, *end2;   // sorted (value<<32 | support index)
+    uint8_t *cur, *best1, *best2;
+    uint32_t* best_list;
+};
+void edge_coords(const EdgeRecs& recs, const uint64_t* edge_key, const uint64_t* edge_off, const uint32_t* cg_ops,
+                 const uint32_t* contig_len, const uint32_t* read_len, uint32_t n_sel, const uint32_t* sel_edge,
+                 const uint64_t* sel_rec_off,   // n_sel+1: scratch / output capacity offsets (records, doubled for hairpins)
+                 const CoordsScratch& sc, uint32_t* head_end, uint32_t* tail_beg, uint32_t* n_supp,
+                 uint32_t* supp_lr, uint32_t* spos, uint32_t* epos, hipStream_t s);
+void coords_compact(const uint64_t* cap_off, const uint64_t* out_off, uint32_t n_sel, const uint32_t* lr_in, const uint32_t* sp_in,
+                    const uint32_t* ep_in, uint32_t* lr_out, uint32_t* sp_out, uint32_t* ep_out, hipStream_t s);
+
+// ---- poa.hip (K6)
+struct PoaSeq { uint32_t rid; uint32_t strand; uint32_t spos; uint32_t len; };
+struct PoaEdge {
+    uint32_t seq_begin, seq_end;   // into the PoaSeq table
+    uint32_t vcap, ecap, lmax, hrows;
+    uint64_t node_off, edge_off;   // into the node / edge pools (elements)
+    uint64_t h_off;                // into the H pool (int32 cells)
+    uint64_t seq_off;              // into the decoded-sequence pool (bytes, lmax per edge)
+    uint64_t cns_off;              // into the consensus output (bytes, capacity vcap)
+    uint64_t stack_off;            // into the toposort stack pool (4*(vcap+1) + ecap entries per edge)
+    uint64_t aln_off;              // into the alignment pools (vcap + lmax + 2 entries per edge)
+};
+struct PoaPools {
+    // per node (pool length = sum (vcap+1))
+    uint8_t* code; uint8_t* n_aligned; uint32_t* aligned;   // aligned: 3 per node
+    uint32_t *in_head, *in_tail, *out_head, *out_tail;
+    uint32_t *rank2node, *node2rank;
+    uint8_t *mark, *check; uint32_t* stack;                 // toposort scratch (stack has its own pool, PoaEdge::stack_off)
+    int32_t* score; int32_t* pred;                          // consensus scratch (score as int64 is not needed: weights < 2^31)
+    // rank-order CSR rebuilt after every toposort
+    uint8_t* row_code; uint8_t* row_sink; uint32_t* row_pred_off; uint32_t* pred_rank;   // row_pred_off: vcap+1 per edge; pred_rank: ecap
+    // per graph edge (pool length = sum ecap)
+    uint32_t *e_from, *e_to, *e_next_in, *e_next_out; int32_t* e_w;
+    // alignment output of the traceback (node|-1, pos|-1), own pool, PoaEdge::aln_off
+    int32_t* aln_node; int32_t* aln_pos;
+    int32_t* H;
+    uint8_t* seq;
+};
+void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_edges, const PoaSeq* seqs, const uint8_t* packed,
+             const uint64_t* read_off, const uint32_t* read_len, PoaPools pools, uint64_t stack_stride_unused,
+             int32_t match, int32_t mismatch, int32_t gap, char* cns, uint32_t* cns_len, uint32_t* status,
+             unsigned long long* cells, int block_threads, hipStream_t s);
+
+}  // namespace hxk
+#endif

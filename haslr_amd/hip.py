@@ -1,0 +1,154 @@
+"""Python mirror of the C-ABI in include/haslr_hip.h (libhaslr_hip.so, gfx950 kernels).
+
+No fallback: if the library or a HIP device is missing, construction raises.
+"""
+import ctypes as C
+import os
+
+from . import ctypes_defs as T
+
+_LIBDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+_lib = None
+
+SYMBOLS = ["hx_last_error", "hx_device_count", "hx_ctx_create", "hx_ctx_destroy", "hx_upload", "hx_set_read_shard",
+           "hx_chain_reads", "hx_edge_support", "hx_edge_coords", "hx_poa_batch", "hx_free_chain", "hx_free_edges",
+           "hx_free_coords", "hx_free_cns", "hx_edge_emit", "hx_edge_records_bytes", "hx_edge_records_export",
+           "hx_edge_records_import", "hx_timing_reset", "hx_timing_get", "hx_set_poa_block", "hx_backend_fill"]
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_LIBDIR, "libhaslr_hip.so")
+        if not os.path.exists(path):
+            raise HipError(f"{path} is missing: the HIP extension must be built (python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        L = C.CDLL(path)
+        L.hx_last_error.restype = C.c_char_p
+        L.hx_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.hx_ctx_destroy.argtypes = [C.c_void_p]
+        L.hx_upload.argtypes = [C.c_void_p, C.POINTER(T.Contigs), C.POINTER(T.Reads), C.POINTER(T.Hits), T.u64p]
+        L.hx_set_read_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.hx_chain_reads.argtypes = [C.c_void_p, C.POINTER(T.Params), C.POINTER(T.ChainOut)]
+        L.hx_edge_support.argtypes = [C.c_void_p, C.POINTER(T.Params), C.POINTER(T.EdgesOut)]
+        L.hx_edge_coords.argtypes = [C.c_void_p, C.c_uint32, T.u32p, C.POINTER(T.CoordsOut)]
+        L.hx_poa_batch.argtypes = [C.c_void_p, C.POINTER(T.PoaParams), C.POINTER(T.CnsOut)]
+        L.hx_free_chain.argtypes = [C.c_void_p, C.POINTER(T.ChainOut)]
+        L.hx_free_edges.argtypes = [C.c_void_p, C.POINTER(T.EdgesOut)]
+        L.hx_free_coords.argtypes = [C.c_void_p, C.POINTER(T.CoordsOut)]
+        L.hx_free_cns.argtypes = [C.c_void_p, C.POINTER(T.CnsOut)]
+        L.hx_edge_emit.argtypes = [C.c_void_p, C.POINTER(T.Params), C.POINTER(C.c_uint64)]
+        L.hx_edge_records_bytes.restype = C.c_uint32
+        L.hx_edge_records_export.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.hx_edge_records_import.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(T.EdgesOut)]
+        L.hx_timing_reset.argtypes = [C.c_void_p]
+        L.hx_timing_get.argtypes = [C.c_void_p, C.POINTER(C.c_double * 4), C.POINTER(C.c_uint64 * 4)]
+        L.hx_set_poa_block.argtypes = [C.c_void_p, C.c_int]
+        L.hx_backend_fill.argtypes = [C.c_void_p, C.POINTER(T.Backend)]
+        _lib = L
+    return _lib
+
+
+class HipContext:
+    """One GPU: resident inputs + the four hot-path operators."""
+
+    def __init__(self, device=0, stream=None):
+        L = lib()
+        h = C.c_void_p()
+        if L.hx_ctx_create(device, stream, C.byref(h)) != 0:
+            raise HipError(L.hx_last_error().decode())
+        self._h = h
+        self._ds = None
+        self.table = T.Backend()
+        L.hx_backend_fill(self._h, C.byref(self.table))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HipError(lib().hx_last_error().decode())
+
+    def upload(self, dataset):
+        self._ds = dataset
+        self._chk(lib().hx_upload(self._h, C.byref(dataset.contigs), C.byref(dataset.reads), C.byref(dataset.hits), dataset.read_hit_off))
+
+    def set_read_shard(self, b, e):
+        self._chk(lib().hx_set_read_shard(self._h, b, e))
+
+    def set_poa_block(self, threads):
+        lib().hx_set_poa_block(self._h, threads)
+
+    def backend(self):
+        return self.table
+
+    # ---- direct operator calls (tests); results are returned as dicts of numpy arrays
+    def chain_reads(self, params):
+        o = T.ChainOut()
+        self._chk(lib().hx_chain_reads(self._h, C.byref(params), C.byref(o)))
+        d = T.chain_to_dict(o)
+        lib().hx_free_chain(self._h, C.byref(o))
+        return d
+
+    def edge_support(self, params, sides=True):
+        o = T.EdgesOut()
+        self._chk(lib().hx_edge_support(self._h, C.byref(params), C.byref(o)))
+        d = T.edges_to_dict(o, sides)
+        lib().hx_free_edges(self._h, C.byref(o))
+        return d
+
+    def edge_emit(self, params):
+        n = C.c_uint64()
+        self._chk(lib().hx_edge_emit(self._h, C.byref(params), C.byref(n)))
+        return n.value
+
+    def edge_records_export(self, dst_ptr, capacity):
+        self._chk(lib().hx_edge_records_export(self._h, dst_ptr, capacity))
+
+    def edge_records_import(self, src_ptr, n, sides=True):
+        o = T.EdgesOut()
+        self._chk(lib().hx_edge_records_import(self._h, src_ptr, n, C.byref(o)))
+        d = T.edges_to_dict(o, sides)
+        lib().hx_free_edges(self._h, C.byref(o))
+        return d
+
+    def edge_coords(self, sel):
+        import numpy as np
+        sel = np.ascontiguousarray(sel, dtype=np.uint32)
+        o = T.CoordsOut()
+        self._chk(lib().hx_edge_coords(self._h, len(sel), sel.ctypes.data_as(T.u32p), C.byref(o)))
+        d = T.coords_to_dict(o)
+        lib().hx_free_coords(self._h, C.byref(o))
+        return d
+
+    def poa_batch(self, match=5, mismatch=-4, gap=-8):
+        o = T.CnsOut()
+        pp = T.PoaParams(match, mismatch, gap)
+        self._chk(lib().hx_poa_batch(self._h, C.byref(pp), C.byref(o)))
+        r = T.cns_to_list(o), {"dp_cells": o.dp_cells, "seq_bases": o.seq_bases, "n_aligned": o.n_aligned}
+        lib().hx_free_cns(self._h, C.byref(o))
+        return r
+
+    def timing_reset(self):
+        lib().hx_timing_reset(self._h)
+
+    def timing(self):
+        ms, n = (C.c_double * 4)(), (C.c_uint64 * 4)()
+        lib().hx_timing_get(self._h, C.byref(ms), C.byref(n))
+        names = ("chain", "edges", "coords", "poa")
+        return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(names)}
+
+    def close(self):
+        if self._h:
+            lib().hx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def records_bytes():
+    return lib().hx_edge_records_bytes()

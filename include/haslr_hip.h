@@ -1,0 +1,81 @@
+/* haslr_hip.h — C-ABI of the MI355X (gfx950) implementation of haslr_assemble's hot path.
+ *
+ * Plain C: opaque context, caller-visible PODs from haslr_types.h, `int` results (0 = ok, <0 = error,
+ * text via hx_last_error()), no exceptions and no C++/torch types across the boundary. One context per GPU,
+ * one host thread per context. The library fails loudly (error return) when no HIP device is usable;
+ * there is no CPU fallback behind these symbols.
+ *
+ * What each entry point replaces in the reference (paths under /root/reference/src/haslr_assemble/src/):
+ *
+ *   hx_upload          the in-memory products of load_contig_compressed (Contig.cpp:43-117),
+ *                      load_longread_compressed (Longread.cpp:109-162) and the record parse of
+ *                      load_alignment (Longread.cpp:250-289), copied once to HBM
+ *   hx_chain_reads     filters 1-4 of load_alignment (Longread.cpp:262-272) + per-read sort (:256) +
+ *                      process_lr_alignment_group (:182-232) + fix_alignments (:626-635, :430-512) +
+ *                      build_compact_longreads (:612-624, :524-610); called from main.cpp:98,116,124
+ *   hx_edge_support    bbg_build_graph / bbg_add_edge (Backbone_graph.cpp:148-171, :10-25); main.cpp:131.
+ *                      (bbg_remove_weak_edges :348-375 is a count test the host applies to the result.)
+ *   hx_edge_coords     asm_calc_edge_coordinates_MT (Assemble.cpp:453-477 -> :157-363); main.cpp:203
+ *   hx_poa_batch       asm_cal_cns_seq_MT (Assemble.cpp:580-605 -> :479-560), i.e. the five SPOA 1.1.3 calls
+ *                      createAlignmentEngine/createGraph/align_sequence_with_graph/add_alignment/
+ *                      generate_consensus at Assemble.cpp:499,500,539,540,554; main.cpp:207
+ *
+ * The four operators have the signature of the host pipeline's `hx_backend` table
+ * (haslr_amd/csrc/host/haslr_host.h); hx_backend_fill() wires them.
+ */
+#ifndef HASLR_HIP_H
+#define HASLR_HIP_H
+#include "haslr_types.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hx_ctx hx_ctx;
+
+const char* hx_last_error(void);
+int hx_device_count(void); /* number of HIP devices, <0 on error */
+
+/* stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL to create one */
+int hx_ctx_create(int device, void* stream, hx_ctx** out);
+void hx_ctx_destroy(hx_ctx*);
+
+/* copy inputs to HBM; they stay resident for the life of the context (replicated on every GPU in a
+ * multi-GPU run). Read shard defaults to all reads. */
+int hx_upload(hx_ctx*, const hx_contigs*, const hx_reads*, const hx_hits*, const uint64_t* read_hit_off);
+int hx_set_read_shard(hx_ctx*, uint32_t lr_begin, uint32_t lr_end);
+
+int hx_chain_reads(hx_ctx*, const hx_params*, hx_chain_out* out);
+int hx_edge_support(hx_ctx*, const hx_params*, hx_edges_out* out);
+int hx_edge_coords(hx_ctx*, uint32_t n_sel, const uint32_t* sel_edge, hx_coords_out* out);
+int hx_poa_batch(hx_ctx*, const hx_poa_params*, hx_cns_out* out);
+void hx_free_chain(hx_ctx*, hx_chain_out*);
+void hx_free_edges(hx_ctx*, hx_edges_out*);
+void hx_free_coords(hx_ctx*, hx_coords_out*);
+void hx_free_cns(hx_ctx*, hx_cns_out*);
+
+/* multi-GPU exchange of the edge-support multiset (one all-gather between hx_chain_reads and the sort):
+ *   hx_edge_emit            emit this shard's records (unsorted) on the device, returns their number
+ *   hx_edge_records_bytes   bytes per record in the packed exchange layout
+ *   hx_edge_records_export  pack the local records into a caller-owned DEVICE buffer (n * bytes)
+ *   hx_edge_records_import  replace the record set by n records unpacked from a DEVICE buffer (all ranks,
+ *                           rank order), then sort + segment; fills `out` like hx_edge_support */
+int hx_edge_emit(hx_ctx*, const hx_params*, uint64_t* n_records);
+uint32_t hx_edge_records_bytes(void);
+int hx_edge_records_export(hx_ctx*, void* dst_device, uint64_t capacity_records);
+int hx_edge_records_import(hx_ctx*, const void* src_device, uint64_t n_records, hx_edges_out* out);
+
+/* kernel timing measured with hipEvents on the context's stream, accumulated per kernel family since the
+ * last reset: 0 chain, 1 edges (emit+sort+segment), 2 coords, 3 poa. ms[] and launches[] have 4 entries. */
+void hx_timing_reset(hx_ctx*);
+void hx_timing_get(hx_ctx*, double* ms, uint64_t* launches);
+/* POA work-group size (64, 256 or 512 lanes per edge); default 256 */
+void hx_set_poa_block(hx_ctx*, int threads);
+
+/* fill the host pipeline's backend table with the entry points above (struct hx_backend of haslr_host.h,
+ * passed as void* to keep this header free of host-side types) */
+void hx_backend_fill(hx_ctx*, void* backend_table);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -679,6 +679,12 @@ int poa_edge(const hx_reads* R, const hx_coords_out* C, uint32_t s, const hx_poa
         G.add_alignment(aln, seq.data(), n);
         non_empty++; *bases += n; (*naln)++;
     }
+    if (getenv("ORC_POA_STATS")) {
+        uint32_t lmax = 0; uint64_t sum = 0; uint32_t ns = 0;
+        for (uint64_t k = C->supp_off[s]; k < C->supp_off[s + 1]; k++) { uint32_t rl = R->len[C->supp_lr[k] & 0x7fffffffu]; uint32_t w = C->epos[k] - C->spos[k] + 1; uint32_t n = std::min(w, rl - C->spos[k]); lmax = std::max(lmax, n); sum += n; ns++; }
+        size_t maxin = 0; for (auto& v : G.in) maxin = std::max(maxin, v.size());
+        fprintf(stderr, "POASTAT nseq=%u lmax=%u sumL=%lu V=%zu E=%zu maxin=%zu\n", ns, lmax, (unsigned long)sum, G.code.size(), G.edges.size(), maxin);
+    }
     cns.clear();
     if (non_empty == 0) return 0;   // :544-551
     for (uint32_t n : G.consensus()) cns.push_back("ACGT"[G.code[n]]);
