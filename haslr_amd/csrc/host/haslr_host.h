@@ -48,6 +48,9 @@ typedef struct {
  * (bench timing of the compute path); otherwise every reference output file is produced. */
 hxh_run* hxh_run_create(const hxh_dataset*, const hx_params*, const hx_backend*, const char* out_dir);
 void hxh_run_free(hxh_run*);
+/* multi-GPU: this run computes coordinates + consensus only for its share of the surviving edges
+ * (hxh_run_assemble is then meaningful only after the consensus strings have been gathered) */
+void hxh_run_set_edge_shard(hxh_run*, uint32_t rank, uint32_t world);
 /* stages, in reference order; each returns 0 or <0 */
 int hxh_run_chain(hxh_run*);          /* fix_alignments + build_compact_longreads (+ compact_uniq.txt) */
 int hxh_run_graph(hxh_run*);          /* bbg_build_graph .. clean_small_bubbles + branching log (+ gfa/stat/log files) */

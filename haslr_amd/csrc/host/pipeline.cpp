@@ -8,6 +8,7 @@
 //   asm_extract_all_simple_paths   Assemble.cpp:757-810
 //   asm_assemble_single_path       Assemble.cpp:624-755  (asm.final.fa / asm.final.ann bytes)
 //   asm_get_assembly               Assemble.cpp:1045-1077
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -35,7 +36,7 @@ struct Run {
     std::vector<std::string> cns;   // consensus strings; Arc::cns_id indexes this
     std::string fasta;
     double t[5] = {0, 0, 0, 0, 0};
-    int fails = 0;
+    uint32_t shard_rank = 0, shard_world = 1;   // multi-GPU: this run computes coordinates/consensus for its share of the edges
 
     std::string path(const char* name) const { return out_dir.empty() ? std::string() : out_dir + "/" + name; }
     void release() {
@@ -135,6 +136,18 @@ static int run_graph(Run& r) {
 static int run_coords(Run& r) {
     double t0 = now();
     r.work = work_queue(r.g, 11);
+    if (r.shard_world > 1) {   // deal the queue out by descending support count (a cost proxy), round-robin
+        std::vector<uint32_t> ord(r.work.size());
+        for (uint32_t i = 0; i < ord.size(); i++) ord[i] = i;
+        std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+            return r.g.find(r.work[a].first, r.work[a].second)->supp > r.g.find(r.work[b].first, r.work[b].second)->supp;
+        });
+        std::vector<char> mine(r.work.size(), 0);
+        for (uint32_t k = 0; k < ord.size(); k++) if (k % r.shard_world == r.shard_rank) mine[ord[k]] = 1;
+        std::vector<std::pair<uint32_t, uint32_t>> w;
+        for (uint32_t i = 0; i < r.work.size(); i++) if (mine[i]) w.push_back(r.work[i]);
+        r.work.swap(w);
+    }
     std::vector<uint32_t> sel(r.work.size());
     for (size_t i = 0; i < r.work.size(); i++) sel[i] = r.g.find(r.work[i].first, r.work[i].second)->dev_edge;
     if (r.have_coords) r.be.free_coords(r.be.ctx, &r.coords), r.have_coords = false;
@@ -170,7 +183,7 @@ static int run_consensus(Run& r) {
     double t0 = now();
     // second pass of the work queue (flag 12) hands out the same arcs in the same order as the first
     std::vector<std::pair<uint32_t, uint32_t>> again = work_queue(r.g, 12);
-    if (again != r.work) { g_err = "internal: consensus work queue differs from coordinate work queue"; return -1; }
+    if (r.shard_world == 1 && again != r.work) { g_err = "internal: consensus work queue differs from coordinate work queue"; return -1; }
     hx_poa_params pp{5, -4, -8};   // Assemble.cpp:8-11
     if (r.have_cns) r.be.free_cns(r.be.ctx, &r.cnsout), r.have_cns = false;
     if (r.be.poa_batch(r.be.ctx, &pp, &r.cnsout) != 0) return backend_fail(r, "poa_batch");
@@ -349,6 +362,10 @@ extern "C" int hxh_run_all(hxh_run* p) {
     if ((rc = run_coords(r))) return rc;
     if ((rc = run_consensus(r))) return rc;
     return run_assemble(r);
+}
+extern "C" void hxh_run_set_edge_shard(hxh_run* p, uint32_t rank, uint32_t world) {
+    Run* r = reinterpret_cast<Run*>(p);
+    r->shard_rank = rank; r->shard_world = world ? world : 1;
 }
 extern "C" void hxh_run_timings(const hxh_run* p, double out[5]) { memcpy(out, reinterpret_cast<const Run*>(p)->t, sizeof(double) * 5); }
 extern "C" uint32_t hxh_run_n_edges(const hxh_run* p) { return (uint32_t)reinterpret_cast<const Run*>(p)->work.size(); }

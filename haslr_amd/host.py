@@ -34,6 +34,7 @@ def lib():
         L.hxh_run_free.argtypes = [C.c_void_p]
         for name in ("chain", "graph", "coords", "consensus", "assemble", "all"):
             getattr(L, "hxh_run_" + name).argtypes = [C.c_void_p]
+        L.hxh_run_set_edge_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.hxh_run_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double * 5)]
         L.hxh_run_n_edges.argtypes = [C.c_void_p]
         L.hxh_run_n_edges.restype = C.c_uint32
@@ -99,6 +100,9 @@ class Run:
     def consensus(self): self._call("consensus")
     def assemble(self): self._call("assemble")
     def all(self): self._call("all")
+
+    def set_edge_shard(self, rank, world):
+        lib().hxh_run_set_edge_shard(self._h, rank, world)
 
     def timings(self):
         t = (C.c_double * 5)()

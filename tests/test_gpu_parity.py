@@ -1,0 +1,235 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI (libhaslr_hip.so), against the CPU oracle on
+the same seeded inputs — bit-exact for every stage — plus golden fixtures, edge cases, size-independent
+properties, and the drop-in CLI."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orclib
+import util
+from haslr_amd import ctypes_defs as T
+from haslr_amd import hip, host
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx(built):
+    c = hip.HipContext(0)   # raises without a device: these tests never run on a fallback
+    yield c
+    c.close()
+
+
+def both(ds, ctx, out_o, out_g, params=None, threads=8):
+    prm = params or ds.params()
+    ob = orclib.OracleBackend(ds, threads)
+    ro = host.Run(ds, prm, ob.table, out_o)
+    ro.all()
+    ctx.upload(ds)
+    rg = host.Run(ds, prm, ctx.backend(), out_g)
+    rg.all()
+    return ro, rg, ob
+
+
+def assert_same_arrays(a, b, what):
+    for k in a:
+        assert np.array_equal(a[k], b[k]), f"{what}.{k} differs between the HIP path and the oracle"
+
+
+CASES = [("--genome-len", "150000", "--seed", "21", "--variant-per-mb", "30"),
+         ("--genome-len", "120000", "--seed", "22", "--variant-per-mb", "30", "--model", "nanopore"),
+         ("--genome-len", "100000", "--seed", "23", "--model", "perfect", "--cov", "15"),
+         ("--genome-len", "90000", "--seed", "24", "--variant-per-mb", "40", "--cov", "40", "--read-median", "4000")]
+
+
+@pytest.mark.parametrize("args", CASES, ids=lambda a: "_".join(a[1:4:2]))
+def test_every_stage_bit_exact(args, sim, ctx, tmp_path):
+    pre = sim(*args)
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    ro, rg, ob = both(ds, ctx, str(tmp_path / "o"), str(tmp_path / "g"))
+    assert_same_arrays(ro.chain_out(), rg.chain_out(), "chain")
+    assert_same_arrays(ro.edges_out(), rg.edges_out(), "edges")
+    assert_same_arrays(ro.coords_out(), rg.coords_out(), "coords")
+    assert ro.cns_out() == rg.cns_out()
+    assert ro.cns_stats() == rg.cns_stats()
+    assert util.compare_dirs(str(tmp_path / "o"), str(tmp_path / "g")) == []
+    assert os.path.getsize(tmp_path / "g" / "asm.final.fa") > 0
+
+
+@pytest.mark.parametrize("block", [64, 512])
+def test_poa_block_sizes_agree(block, sim, ctx, tmp_path):
+    pre = sim("--genome-len", "100000", "--seed", "25", "--variant-per-mb", "20")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    ctx.set_poa_block(block)
+    try:
+        ro, rg, ob = both(ds, ctx, None, None)
+        assert ro.cns_out() == rg.cns_out()
+    finally:
+        ctx.set_poa_block(256)
+
+
+def test_nondefault_parameters(sim, ctx, tmp_path):
+    pre = sim("--genome-len", "150000", "--seed", "21", "--variant-per-mb", "30")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    prm = ds.params(min_aln_block=900, min_aln_sim=0.87, min_edge_sup=2, max_uniq_dev=0.1)
+    ro, rg, ob = both(ds, ctx, str(tmp_path / "o"), str(tmp_path / "g"), prm)
+    assert_same_arrays(ro.chain_out(), rg.chain_out(), "chain")
+    assert_same_arrays(ro.edges_out(), rg.edges_out(), "edges")
+    assert util.compare_dirs(str(tmp_path / "o"), str(tmp_path / "g")) == []
+
+
+@pytest.mark.parametrize("case", sorted(d for d in os.listdir(GOLD) if os.path.isdir(os.path.join(GOLD, d)) and not d.startswith("committed")))
+def test_golden_fixtures_through_hip(case, sim, ctx, tmp_path):
+    """front-half outputs of the HIP path against the files the compiled reference produced"""
+    import gzip
+    cd = os.path.join(GOLD, case)
+    man = json.load(open(os.path.join(cd, "manifest.json")))
+    pre = sim(*man["hxsim_args"])
+    for k, h in man["inputs"].items():
+        if util.sha256_file(pre + k) != h:
+            pytest.skip("generator bytes differ from fixture")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    ctx.upload(ds)
+    out = str(tmp_path / "g")
+    run = host.Run(ds, ds.params(), ctx.backend(), out)
+    run.chain()
+    run.graph()
+    exp = os.path.join(cd, "expected")
+    for f in sorted(os.listdir(exp)):
+        if f.endswith(".skel"):
+            assert util.sha256_file(os.path.join(out, f[:-5])) == man["outputs"][f[:-5]], f
+        elif not f.endswith(".gz") and f != "uniq_freq.txt":
+            assert open(os.path.join(out, f)).read() == open(os.path.join(exp, f)).read(), f
+    assert util.sha256_bytes(util.alignments_paf(ds, run.chain_out()).encode()) == man["outputs"]["alignments.fixed.paf"]
+    assert util.edge_supp_text(run.edges_out(sides=False)) == gzip.open(os.path.join(exp, "edge_supp.01.txt.gz"), "rt").read()
+
+
+def test_against_compiled_reference_front_half(sim, ctx, ref_front, tmp_path):
+    pre = sim("--genome-len", "110000", "--seed", "31", "--variant-per-mb", "40", "--cov", "14")
+    rd = tmp_path / "ref"
+    rd.mkdir()
+    subprocess.check_call([ref_front, "-c", pre + ".contigs.fa", "-l", pre + ".reads.fa", "-m", pre + ".paf", "-d", str(rd)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    ctx.upload(ds)
+    run = host.Run(ds, ds.params(), ctx.backend(), str(tmp_path / "g"))
+    run.chain()
+    run.graph()
+    assert util.compare_dirs(str(rd), str(tmp_path / "g")) == []
+    assert util.alignments_paf(ds, run.chain_out()) == open(rd / "alignments.fixed.paf").read()
+    assert util.edge_supp_text(run.edges_out(sides=False)) == open(rd / "edge_supp.01.txt").read()
+
+
+def test_cli_drop_in(sim, built, tmp_path):
+    """the haslr_assemble binary with haslr.py's argv (bin/haslr.py:66) reproduces the oracle-backed run"""
+    pre = sim("--genome-len", "100000", "--seed", "25", "--variant-per-mb", "20")
+    exe = os.path.join(ROOT, "haslr_amd", "bin", "haslr_assemble")
+    out = tmp_path / "cli"
+    r = subprocess.run([exe, "-t", "4", "-c", pre + ".contigs.fa", "-l", pre + ".reads.fa", "-m", pre + ".paf", "-d", str(out),
+                        "--aln-block", "500", "--aln-sim", "0.85", "--edge-sup", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    ob = orclib.OracleBackend(ds, 8)
+    ro = host.Run(ds, ds.params(), ob.table, str(tmp_path / "o"))
+    ro.all()
+    names = [f for f in os.listdir(tmp_path / "o")]
+    assert "asm.final.fa" in names and "backbone.06.smallbubble.gfa" in names
+    assert util.compare_dirs(str(tmp_path / "o"), str(out), names) == []
+
+
+def test_edge_cases(ctx, built, tmp_path):
+    """empty PAF, reads without hits, a read with a single hit (dropped, Longread.cpp:184), ragged sizes"""
+    c = tmp_path / "c.fa"
+    seqs = ["ACGT" * 300, "TTGCA" * 250, "GATTACA" * 200]
+    c.write_text("".join(f">{i} LN:i:{len(s)} KC:i:{30 * len(s)} km:f:30.0\n{s}\n" for i, s in enumerate(seqs)))
+    r = tmp_path / "r.fa"
+    r.write_text(">0\n" + "ACGT" * 900 + "\n>1\nACGTA\n>2\n" + "G" * 3000 + "\n")
+    p = tmp_path / "m.paf"
+    p.write_text("")
+    for paf_text in ("", "0\t3600\t0\t1200\t+\t0\t1200\t0\t1200\t1200\t1200\t60\tcg:Z:1200M\n"):
+        p.write_text(paf_text)
+        ds = host.Dataset(str(c), str(r), str(p))
+        ro, rg, ob = both(ds, ctx, str(tmp_path / "o"), str(tmp_path / "g"))
+        assert_same_arrays(ro.chain_out(), rg.chain_out(), "chain")
+        assert rg.chain_out()["cmp_aln"].size == 0 and rg.n_edges == 0
+        assert util.compare_dirs(str(tmp_path / "o"), str(tmp_path / "g")) == []
+        assert open(tmp_path / "g" / "compact_uniq.txt").read() == ">0\t\n>1\t\n>2\t\n"
+
+
+def test_error_free_reads_reassemble_genome_on_gpu(sim, ctx, tmp_path):
+    """size-independent property: with perfect reads every consensus is exact, so each assembled contig is a
+    substring of the truth genome (either strand)"""
+    pre = sim("--genome-len", "400000", "--seed", "41", "--model", "perfect", "--no-variants", "--cov", "15")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    ctx.upload(ds)
+    run = host.Run(ds, ds.params(), ctx.backend(), None)
+    run.all()
+    genome = open(pre + ".genome.fa").read().split("\n")[1]
+    comp = str.maketrans("ACGT", "TGCA")
+    recs = [l for l in run.assembly_fasta().split("\n") if l and not l.startswith(">")]
+    assert recs and sum(map(len, recs)) > 0.6 * len(genome)
+    for s in recs:
+        assert s in genome or s.translate(comp)[::-1] in genome
+
+
+def test_full_size_properties(sim, ctx, tmp_path):
+    """BASELINE configs[1] size (4.6 Mb, 25x): too big for the oracle in a test, so check invariants:
+    twin symmetry of the edge multiset, sortedness, idempotence of a second run, identity vs truth."""
+    pre = sim("--genome-len", "4600000", "--seed", hex(0x4841534C + 1), "--variant-per-mb", "1.5")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    ctx.upload(ds)
+    prm = ds.params()
+    out = str(tmp_path / "g")
+    run = host.Run(ds, prm, ctx.backend(), out)
+    run.all()
+    e = run.edges_out(sides=False)
+    assert np.all(e["key"][1:] >= e["key"][:-1])
+    twin = ((e["edge_key"] & 0xffffffff) ^ 1) << np.uint64(32) | ((e["edge_key"] >> np.uint64(32)) ^ np.uint64(1))
+    cnt = dict(zip(e["edge_key"].tolist(), np.diff(e["edge_off"]).tolist()))
+    for k, t in zip(e["edge_key"].tolist(), twin.tolist()):
+        assert cnt[t] == cnt[k]          # every edge has a twin with the same support
+    c = run.chain_out()
+    for a, b in zip(c["cmp_off"][:-1], c["cmp_off"][1:]):
+        q = c["cmp_aln"][int(a):int(b)]
+        assert np.all(c["q_end"][q][:-1] <= c["q_start"][q][1:])   # chained hits never overlap on the read
+    fasta1 = run.assembly_fasta()
+    run2 = host.Run(ds, prm, ctx.backend(), None)
+    run2.all()
+    assert run2.assembly_fasta() == fasta1                           # idempotent / deterministic
+    o = subprocess.check_output([os.path.join(ROOT, "tools", "hxident"), pre + ".genome.fa", os.path.join(out, "asm.final.fa")], text=True)
+    ident = float(o.strip().split("\n")[-1].split()[1])
+    assert ident >= 0.998, o[-500:]
+
+
+def test_record_exchange_roundtrip(sim, ctx):
+    """multi-GPU plumbing on one GPU: emit two read shards separately, pack, concatenate in rank order, import:
+    identical to the unsharded edge multiset"""
+    import torch
+    pre = sim("--genome-len", "150000", "--seed", "21", "--variant-per-mb", "30")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    prm = ds.params()
+    ctx.upload(ds)
+    ctx.chain_reads(prm)
+    whole = ctx.edge_support(prm)
+    from haslr_amd import distributed as hd
+    b = hd.shard_bounds(ds.read_hit_off, ds.reads.n, 3)
+    rb = hip.records_bytes()
+    parts = []
+    for r in range(3):
+        ctx.set_read_shard(b[r], b[r + 1])
+        ctx.chain_reads(prm)
+        n = ctx.edge_emit(prm)
+        t = torch.empty(max(n, 1) * rb, dtype=torch.uint8, device="cuda")
+        ctx.edge_records_export(C.c_void_p(t.data_ptr()), n)
+        parts.append(t[: n * rb])
+    merged = torch.cat(parts).contiguous()
+    torch.cuda.synchronize()
+    got = ctx.edge_records_import(C.c_void_p(merged.data_ptr()), merged.numel() // rb)
+    ctx.set_read_shard(0, ds.reads.n)
+    for k in whole:
+        assert np.array_equal(whole[k], got[k]), k
