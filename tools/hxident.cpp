@@ -58,32 +58,46 @@ int main(int argc, char** argv) {
     if (argc < 3) { fprintf(stderr, "usage: hxident genome.fa asm.fa [band]\n"); return 2; }
     auto g = read_fa(argv[1]);
     auto qs = read_fa(argv[2]);
-    long B = argc > 3 ? atol(argv[3]) : 3000;
+    long B = argc > 3 ? atol(argv[3]) : 400;
     if (g.empty()) return 2;
     const std::string& G = g[0].second;
     const int K = 24;
     std::unordered_map<std::string, long> idx;
     for (long i = 0; i + K <= (long)G.size(); i += 7) idx.emplace(G.substr(i, K), i);
     double wsum = 0; long wlen = 0; int unplaced = 0;
+    const long WIN = 20000;
     for (auto& rec : qs) {
-        const std::string* qq = &rec.second;
+        // strand: the one whose first placeable window hits
         std::string r = rc(rec.second);
-        long off = -1; bool rev = false;
-        for (int s = 0; s < 2 && off < 0; s++) {
-            const std::string& q = s == 0 ? rec.second : r;
-            for (long i = 0; i + K <= (long)q.size() && i < 20000; i++) {
-                auto it = idx.find(q.substr(i, K));
-                if (it != idx.end()) { off = it->second - i; rev = s == 1; break; }
-            }
+        long total_ed = 0, total_len = 0, bad_win = 0;
+        int strand = -1;
+        for (int s2 = 0; s2 < 2 && strand < 0; s2++) {
+            const std::string& q = s2 == 0 ? rec.second : r;
+            for (long i = 0; i + K <= (long)q.size() && i < 50000; i++)
+                if (idx.count(q.substr(i, K))) { strand = s2; break; }
         }
-        if (off < 0) { unplaced++; printf("%s\tlen=%zu\tUNPLACED\n", rec.first.c_str(), rec.second.size()); continue; }
-        if (rev) qq = &r;
-        long st = std::max(0L, off);
-        std::string t = G.substr(st, std::min<long>((long)G.size() - st, (long)qq->size() + B / 2));
-        long ed = banded_ed(*qq, t, B);
-        double ident = 1.0 - (double)ed / (double)qq->size();
-        printf("%s\tlen=%zu\t%c\toff=%ld\ted=%ld\tidentity=%.6f\n", rec.first.c_str(), rec.second.size(), rev ? '-' : '+', off, ed, ident);
-        wsum += ident * qq->size(); wlen += qq->size();
+        if (strand < 0) { unplaced++; printf("%s\tlen=%zu\tUNPLACED\n", rec.first.c_str(), rec.second.size()); continue; }
+        const std::string& q = strand == 0 ? rec.second : r;
+        // windows are placed independently (seeded inside the window), so cumulative indel drift never leaves the band
+        for (long w0 = 0; w0 < (long)q.size(); w0 += WIN) {
+            long wl = std::min<long>(WIN, (long)q.size() - w0);
+            std::string win = q.substr(w0, wl);
+            long off = -1;
+            for (long i = 0; i + K <= wl && i < 4000; i++) {
+                auto it = idx.find(win.substr(i, K));
+                if (it != idx.end()) { off = it->second - i; break; }
+            }
+            if (off < -B || wl < K) { bad_win++; total_ed += wl; total_len += wl; continue; }
+            long st = std::max(0L, off - 50);
+            std::string t = G.substr(st, std::min<long>((long)G.size() - st, wl + B));
+            // free start shift of up to ~100 bases: take the best of a few start offsets
+            long ed = banded_ed(win, t, B);
+            for (long sh = 25; sh <= 100 && st + sh < (long)G.size(); sh += 25) ed = std::min(ed, banded_ed(win, G.substr(st + sh, std::min<long>((long)G.size() - st - sh, wl + B)), B));
+            total_ed += std::min(ed, wl); total_len += wl;
+        }
+        double ident = 1.0 - (double)total_ed / (double)total_len;
+        printf("%s\tlen=%zu\t%c\ted=%ld\tunplaced_windows=%ld\tidentity=%.6f\n", rec.first.c_str(), rec.second.size(), strand ? '-' : '+', total_ed, bad_win, ident);
+        wsum += ident * total_len; wlen += total_len;
     }
     printf("identity %.6f aligned_bases %ld records %zu unplaced %d\n", wlen ? wsum / wlen : 0.0, wlen, qs.size(), unplaced);
     return 0;
