@@ -26,6 +26,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before HIP initialises (see haslr_amd/hip.py)
 
 GENOME_PER_GPU = 4_600_000
 SEED = 0x4841534C + 1   # seed = 0x4841534c + config index
@@ -187,6 +188,7 @@ def main():
                          "note": "POA is an O(L^2) integer DP over O(L) bytes: HBM fraction is low by construction (SURVEY.md 8d); GCUPS is the figure of merit"},
             "stage_ms": {k: v * 1e3 for k, v in last.timings().items()},
             "kernel_ms": {k: v["ms"] / max(1, v["launches"]) for k, v in tim.items()},
+            "poa_phase_cycles": ctx.poa_phase_cycles(),
         }
         if not args.no_cpu_baseline and world == 1:
             try:

@@ -118,8 +118,14 @@ struct hx_ctx {
     std::vector<uint32_t> h_supp_lr, h_spos, h_epos;
     uint32_t n_sel = 0;
     bool have_coords = false;
-    int poa_block = 256;
+    uint32_t dbg_slowest = 0;
+    std::vector<uint32_t> dbg_lmax, dbg_nseq;
+    bool poa_no_dir = false;   // diagnostics: force the score-matrix traceback
+    int poa_block = 0;   // 0 = automatic (lanes per edge chosen from the gap length)
+    hipStream_t poa_streams[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t poa_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     Timer tm;
+    std::vector<unsigned long long> poa_phase;   // per edge x 6, cycles of the last hx_poa_batch
 
     DevHits hits_view() const {
         return DevHits{n_hits, q_id.p, q_start.p, q_end.p, t_id.p, t_len.p, t_start.p, t_end.p, n_match.p, n_block.p, is_rev.p, mapq.p, cg_off.p, cg_ops.p};
@@ -145,6 +151,9 @@ extern "C" int hx_device_count(void) {
 
 extern "C" int hx_ctx_create(int device, void* stream, hx_ctx** out) {
     *out = nullptr;
+    // the POA classes are launched on separate streams and must really overlap: ask the runtime for enough hardware queues
+    // (only effective if HIP has not been initialised in this process yet; haslr_amd/hip.py and bench.py set it before importing torch)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail("hx_ctx_create: no HIP device available (libhaslr_hip.so has no CPU fallback)");
     if (device < 0 || device >= n) return fail("hx_ctx_create: device index out of range");
@@ -155,6 +164,8 @@ extern "C" int hx_ctx_create(int device, void* stream, hx_ctx** out) {
     else { HIPCHK(hipStreamCreate(&c->stream)); c->own_stream = true; }
     HIPCHK(hipEventCreate(&c->tm.a));
     HIPCHK(hipEventCreate(&c->tm.b));
+    for (int i = 0; i < 5; i++) HIPCHK(hipStreamCreateWithFlags(&c->poa_streams[i], hipStreamNonBlocking));
+    for (int i = 0; i < 6; i++) HIPCHK(hipEventCreateWithFlags(&c->poa_ev[i], hipEventDisableTiming));
     HIPCHK(c->err.reserve(1));
     *out = c;
     return 0;
@@ -166,6 +177,8 @@ extern "C" void hx_ctx_destroy(hx_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->tm.a) (void)hipEventDestroy(c->tm.a);
     if (c->tm.b) (void)hipEventDestroy(c->tm.b);
+    for (int i = 0; i < 5; i++) if (c->poa_streams[i]) (void)hipStreamDestroy(c->poa_streams[i]);
+    for (int i = 0; i < 6; i++) if (c->poa_ev[i]) (void)hipEventDestroy(c->poa_ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -441,6 +454,8 @@ struct PoaPoolBufs {
     DV<uint8_t> code, n_aligned, mark, check, row_code, row_sink, seq;
     DV<uint32_t> aligned, in_head, in_tail, out_head, out_tail, rank2node, node2rank, stack, row_pred_off, pred_rank, e_from, e_to, e_next_in, e_next_out;
     DV<int32_t> score, pred, e_w, aln_node, aln_pos, H;
+    DV<uint32_t> row_meta, row_pred0, row_pred1;
+    DV<uint8_t> dir;
 };
 }  // namespace
 
@@ -472,6 +487,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     }
     std::vector<uint32_t> todo;
     for (uint32_t e = 0; e < ne; e++) if (P.nseq[e]) todo.push_back(e);
+    c->dbg_nseq = P.nseq; c->dbg_lmax.resize(ne); for (uint32_t e = 0; e < ne; e++) c->dbg_lmax[e] = P.edges[e].lmax;
     std::vector<uint32_t> cns_len(ne, 0);
     std::vector<std::string> cns(ne);
     DV<hxk::PoaSeq> d_seqs;
@@ -487,6 +503,9 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     DV<hxk::PoaEdge> d_edges;
     DV<uint32_t> d_order, d_len, d_status;
     DV<char> d_cns;
+    DV<unsigned long long> d_phase;
+    HIPCHK(d_phase.reserve((size_t)ne * 6));
+    HIPCHK(hipMemsetAsync(d_phase.p, 0, std::max<size_t>(1, (size_t)ne * 6) * 8, s));
     bool worst_case = false;
     while (!todo.empty()) {
         // ---- workspace sizes; estimated graph capacity first, the proven worst case on retry
@@ -511,8 +530,8 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             std::vector<uint32_t> batch;
             while (end < todo.size()) {
                 hxk::PoaEdge& E = P.edges[todo[end]];
-                uint64_t nn = (uint64_t)E.vcap + 1, hc = nn * ((uint64_t)E.lmax + 1);
-                uint64_t b = nn * 56 + (uint64_t)E.ecap * 24 + hc * 4 + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8;
+                uint64_t nn = (uint64_t)E.vcap + 1, hc = nn * (((uint64_t)E.lmax + 1 + 15) & ~15ull);   // rows padded to 16 columns (vector-aligned lane chunks)
+                uint64_t b = nn * 68 + (uint64_t)E.ecap * 24 + hc * 5 + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8;
                 if (!batch.empty() && bytes + b > budget) break;
                 E.node_off = no; E.edge_off = eo; E.h_off = ho; E.seq_off = so; E.cns_off = co; E.stack_off = sto; E.aln_off = ao;
                 no += nn; eo += E.ecap; ho += hc; so += E.lmax; co += E.vcap; sto += 4 * nn + E.ecap; ao += nn + E.lmax + 2;
@@ -527,16 +546,57 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             HIPCHK(B.node2rank.reserve(no)); HIPCHK(B.row_pred_off.reserve(no)); HIPCHK(B.score.reserve(no)); HIPCHK(B.pred.reserve(no));
             HIPCHK(B.pred_rank.reserve(eo)); HIPCHK(B.e_from.reserve(eo)); HIPCHK(B.e_to.reserve(eo)); HIPCHK(B.e_next_in.reserve(eo));
             HIPCHK(B.e_next_out.reserve(eo)); HIPCHK(B.e_w.reserve(eo)); HIPCHK(B.stack.reserve(sto)); HIPCHK(B.aln_node.reserve(ao));
-            HIPCHK(B.aln_pos.reserve(ao)); HIPCHK(B.H.reserve(ho)); HIPCHK(B.seq.reserve(so)); HIPCHK(d_cns.reserve(co));
+            HIPCHK(B.aln_pos.reserve(ao)); HIPCHK(B.H.reserve(ho)); HIPCHK(B.dir.reserve(ho)); HIPCHK(B.row_meta.reserve(no)); HIPCHK(B.row_pred0.reserve(no)); HIPCHK(B.row_pred1.reserve(no)); HIPCHK(B.seq.reserve(so)); HIPCHK(d_cns.reserve(co));
             HIPCHK(d_edges.reserve(ne)); HIPCHK(d_order.reserve(batch.size())); HIPCHK(d_len.reserve(ne)); HIPCHK(d_status.reserve(ne));
+            // lanes per edge. Gaps up to 2047 bases: ONE wavefront per edge (row in registers, no barriers, many edges per CU).
+            // Longer gaps: a multi-wave workgroup with ~8 columns per lane (256..1024 lanes). One launch per class, classes run concurrently.
+            static const int kClassNT[5] = {1024, 512, 256, 128, 64};
+            std::vector<uint32_t> cls_list[5];
+            uint32_t cls_cm[5] = {1, 1, 1, 1, 1};
+            bool cls_dir[5] = {true, true, true, true, true};
+            for (uint32_t e : batch) {
+                const uint32_t ncol = P.edges[e].lmax + 1;
+                int k = 4;
+                if (c->poa_block) { for (k = 0; k < 4 && kClassNT[k] > c->poa_block; k++) {} if (k == 4 && ncol > 2048) k = 3; }
+                else if (ncol > 2048) { k = 2; while (k > 0 && (uint64_t)kClassNT[k] * 8 < ncol) k--; }
+                cls_list[k].push_back(e);   // batch is cost-sorted, so every class list is too
+                uint32_t cm = (ncol + kClassNT[k] - 1) / kClassNT[k], cmr = k == 4 ? 4 : 1;
+                while (cmr < cm) cmr <<= 1;
+                cls_cm[k] = std::max(cls_cm[k], cmr);
+                if (P.nseq[e] > 63 || c->poa_no_dir) cls_dir[k] = false;   // in-degree <= #sequences must fit the 6-bit predecessor slot
+            }
+            std::vector<uint32_t> order_all;
+            for (int k = 0; k < 5; k++) order_all.insert(order_all.end(), cls_list[k].begin(), cls_list[k].end());
             HIPCHK(hipMemcpyAsync(d_edges.p, P.edges.data(), (size_t)ne * sizeof(hxk::PoaEdge), hipMemcpyHostToDevice, s));
-            HIPCHK(hipMemcpyAsync(d_order.p, batch.data(), batch.size() * 4, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(d_order.p, order_all.data(), order_all.size() * 4, hipMemcpyHostToDevice, s));
             hxk::PoaPools pools{B.code.p, B.n_aligned.p, B.aligned.p, B.in_head.p, B.in_tail.p, B.out_head.p, B.out_tail.p, B.rank2node.p, B.node2rank.p,
-                                B.mark.p, B.check.p, B.stack.p, B.score.p, B.pred.p, B.row_code.p, B.row_sink.p, B.row_pred_off.p, B.pred_rank.p,
-                                B.e_from.p, B.e_to.p, B.e_next_in.p, B.e_next_out.p, B.e_w.p, B.aln_node.p, B.aln_pos.p, B.H.p, B.seq.p};
+                                B.mark.p, B.check.p, B.stack.p, B.score.p, B.pred.p, B.row_code.p, B.row_sink.p, B.row_pred_off.p, B.pred_rank.p, B.row_meta.p, B.row_pred0.p, B.row_pred1.p,
+                                B.e_from.p, B.e_to.p, B.e_next_in.p, B.e_next_out.p, B.e_w.p, B.aln_node.p, B.aln_pos.p, B.H.p, B.dir.p, B.seq.p};
             c->tick();
-            hxk::poa_run(d_edges.p, d_order.p, (uint32_t)batch.size(), d_seqs.p, c->packed.p, c->roff.p, c->rlen.p, pools, 0, pp->match, pp->mismatch, pp->gap,
-                         d_cns.p, d_len.p, d_status.p, d_cells.p, c->poa_block, s);
+            HIPCHK(hipEventRecord(c->poa_ev[5], s));
+            size_t opos = 0;
+            for (int k = 0; k < 5; k++) {
+                if (cls_list[k].empty()) continue;
+                const uint32_t nt = kClassNT[k];
+                const uint64_t row_bytes = (uint64_t)cls_cm[k] * nt * 4;
+                const uint64_t lds_budget = nt >= 1024 ? 128 * 1024 : nt == 64 ? 32 * 1024 : 64 * 1024;
+                uint32_t R = (uint32_t)std::min<uint64_t>(8, lds_budget / row_bytes);
+                R = R >= 8 ? 8 : R >= 4 ? 4 : R >= 2 ? 2 : 0;   // power of two (slot = rank & (R-1))
+                if (cls_cm[k] > 32) R = 0;
+                // few edges: ask for enough LDS per workgroup that the dispatcher cannot stack them on a handful of CUs while others idle
+                // (a lone wave runs at twice the speed of two waves sharing a SIMD); many edges: request only what the ring needs
+                uint64_t lds_bytes = R * row_bytes;
+                {
+                    const uint64_t per_cu = (order_all.size() + 255) / 256;
+                    if (per_cu < 8) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(144 * 1024, (156 * 1024) / per_cu - 6 * 1024));
+                }
+                HIPCHK(hipStreamWaitEvent(c->poa_streams[k], c->poa_ev[5], 0));
+                hxk::poa_run(d_edges.p, d_order.p + opos, (uint32_t)cls_list[k].size(), d_seqs.p, c->packed.p, c->roff.p, c->rlen.p, pools, 0, pp->match, pp->mismatch,
+                             pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)nt, R, (uint32_t)lds_bytes, cls_cm[k] > (nt >= 1024 ? 8u : 16u), cls_dir[k], c->poa_streams[k]);
+                HIPCHK(hipEventRecord(c->poa_ev[k], c->poa_streams[k]));
+                HIPCHK(hipStreamWaitEvent(s, c->poa_ev[k], 0));
+                opos += cls_list[k].size();
+            }
             c->tock(3);
             HIPCHK(hipGetLastError());
             std::vector<uint32_t> h_len(ne), h_status(ne);
@@ -557,6 +617,8 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     }
     unsigned long long cells = 0;
     HIPCHK(hipMemcpy(&cells, d_cells.p, 8, hipMemcpyDeviceToHost));
+    c->poa_phase.assign((size_t)ne * 6, 0);
+    if (ne) HIPCHK(hipMemcpy(c->poa_phase.data(), d_phase.p, (size_t)ne * 6 * 8, hipMemcpyDeviceToHost));
     std::vector<uint64_t> off((size_t)ne + 1, 0);
     for (uint32_t e = 0; e < ne; e++) off[e + 1] = off[e] + cns[e].size();
     out->n_edge = ne;
@@ -572,7 +634,22 @@ extern "C" void hx_free_cns(hx_ctx*, hx_cns_out* o) { free(o->cns_off); free(o->
 // ================================================================================================ misc
 extern "C" void hx_timing_reset(hx_ctx* c) { for (int i = 0; i < 4; i++) { c->tm.ms[i] = 0; c->tm.launches[i] = 0; } }
 extern "C" void hx_timing_get(hx_ctx* c, double* ms, uint64_t* launches) { for (int i = 0; i < 4; i++) { ms[i] = c->tm.ms[i]; launches[i] = c->tm.launches[i]; } }
-extern "C" void hx_set_poa_block(hx_ctx* c, int t) { c->poa_block = t >= 512 ? 512 : t >= 256 ? 256 : 64; }
+extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max6) {
+    // lane-0 cycle counters of the last hx_poa_batch: [decode, dp, traceback, graph update+consensus, toposort, csr];
+    // sum over edges and the breakdown of the edge with the largest total (the critical path)
+    for (int k = 0; k < 6; k++) { sum6[k] = 0; max6[k] = 0; }
+    unsigned long long best = 0;
+    size_t ne = c->poa_phase.size() / 6;
+    for (size_t e = 0; e < ne; e++) {
+        unsigned long long t = 0;
+        for (int k = 0; k < 6; k++) { sum6[k] += c->poa_phase[e * 6 + k]; t += c->poa_phase[e * 6 + k]; }
+        if (t > best) { best = t; for (int k = 0; k < 6; k++) max6[k] = c->poa_phase[e * 6 + k]; c->dbg_slowest = (uint32_t)e; }
+    }
+    if (getenv("HX_DEBUG") && ne) fprintf(stderr, "[hx] slowest edge %u: lmax=%u nseq=%u\n", c->dbg_slowest, c->dbg_lmax[c->dbg_slowest], c->dbg_nseq[c->dbg_slowest]);
+    return (uint32_t)ne;
+}
+extern "C" void hx_set_poa_traceback(hx_ctx* c, int use_direction_bytes) { c->poa_no_dir = !use_direction_bytes; }
+extern "C" void hx_set_poa_block(hx_ctx* c, int t) { c->poa_block = t <= 0 ? 0 : t >= 1024 ? 1024 : t >= 512 ? 512 : t >= 256 ? 256 : t >= 128 ? 128 : 64; }
 
 static int be_chain(void* p, const hx_params* a, hx_chain_out* o) { return hx_chain_reads((hx_ctx*)p, a, o); }
 static int be_edges(void* p, const hx_params* a, hx_edges_out* o) { return hx_edge_support((hx_ctx*)p, a, o); }

@@ -53,14 +53,28 @@ struct CgView {
     }
 };
 
-// wave-wide inclusive max-scan / sum-scan (64 lanes)
+// wave-wide inclusive max-scan over 64 lanes with DPP (no LDS round trips): the classic GCN/CDNA sequence
+// row_shr:1,2,3 of the original value, then row_shr:4 / row_shr:8 (bank-masked) inside each 16-lane row,
+// then row_bcast:15 / row_bcast:31 across rows. Lanes without a source keep `ident` (bound_ctrl off).
 __device__ __forceinline__ int wave_scan_max(int v) {
-#pragma unroll
-    for (int d = 1; d < HX_WAVE; d <<= 1) {
-        int o = __shfl_up(v, d, HX_WAVE);
-        if ((int)(threadIdx.x & (HX_WAVE - 1)) >= d) v = max(v, o);
-    }
-    return v;
+    constexpr int ident = -(1 << 30);
+    int x = v;
+    x = max(x, __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    x = max(x, __builtin_amdgcn_update_dpp(ident, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    x = max(x, __builtin_amdgcn_update_dpp(ident, v, 0x113, 0xf, 0xf, false));   // row_shr:3
+    x = max(x, __builtin_amdgcn_update_dpp(ident, x, 0x114, 0xf, 0xe, false));   // row_shr:4 bank_mask:0xe
+    x = max(x, __builtin_amdgcn_update_dpp(ident, x, 0x118, 0xf, 0xc, false));   // row_shr:8 bank_mask:0xc
+    x = max(x, __builtin_amdgcn_update_dpp(ident, x, 0x142, 0xa, 0xf, false));   // row_bcast:15 row_mask:0xa
+    x = max(x, __builtin_amdgcn_update_dpp(ident, x, 0x143, 0xc, 0xf, false));   // row_bcast:31 row_mask:0xc
+    return x;
+}
+// value of the previous lane (lane 0 gets `fill`): wave_shr:1
+__device__ __forceinline__ int wave_shift_up1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+// workgroup barrier that only waits for LDS traffic (outstanding global stores keep flying)
+__device__ __forceinline__ void barrier_lds_only() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
 #pragma unroll

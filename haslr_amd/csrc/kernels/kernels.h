@@ -89,17 +89,22 @@ struct PoaPools {
     int32_t* score; int32_t* pred;                          // consensus scratch (score as int64 is not needed: weights < 2^31)
     // rank-order CSR rebuilt after every toposort
     uint8_t* row_code; uint8_t* row_sink; uint32_t* row_pred_off; uint32_t* pred_rank;   // row_pred_off: vcap+1 per edge; pred_rank: ecap
+    uint32_t *row_meta, *row_pred0, *row_pred1;   // code | sink<<2 | far<<3 | npred<<8 ; first two predecessor ranks
     // per graph edge (pool length = sum ecap)
     uint32_t *e_from, *e_to, *e_next_in, *e_next_out; int32_t* e_w;
     // alignment output of the traceback (node|-1, pos|-1), own pool, PoaEdge::aln_off
     int32_t* aln_node; int32_t* aln_pos;
     int32_t* H;
+    uint8_t* dir;   // traceback direction bytes, same geometry/offsets as H (used when every edge has <= 63 sequences)
     uint8_t* seq;
 };
 void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_edges, const PoaSeq* seqs, const uint8_t* packed,
              const uint64_t* read_off, const uint32_t* read_len, PoaPools pools, uint64_t stack_stride_unused,
              int32_t match, int32_t mismatch, int32_t gap, char* cns, uint32_t* cns_len, uint32_t* status,
-             unsigned long long* cells, int block_threads, hipStream_t s);
+             unsigned long long* cells, unsigned long long* phase_cycles /* 6 per edge or null */, int block_threads /* multiple of 64, <= 1024 */,
+             uint32_t ring_rows, uint32_t ring_bytes /* dynamic LDS: ring_rows x pow2ceil(ceil((lmax+1)/block)) x block x 4 */,
+             bool big /* some edge needs more than 16 columns per lane */,
+             bool use_dir /* direction-byte traceback: needs in-degree <= 63, i.e. <= 63 sequences per edge */, hipStream_t s);
 
 }  // namespace hxk
 #endif

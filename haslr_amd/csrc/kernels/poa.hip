@@ -32,6 +32,7 @@ struct G {   // per-edge views into the pools
     uint8_t *mark, *check; uint32_t* stack;
     int32_t *score, *pred;
     uint8_t *row_code, *row_sink; uint32_t *row_pred_off, *pred_rank;
+    uint32_t *row_meta, *row_pred0, *row_pred1;   // per rank: code | sink<<2 | far<<3 | npred<<8 ; ranks of the first two predecessors
     uint32_t *e_from, *e_to, *e_next_in, *e_next_out; int32_t* e_w;
     int32_t *aln_node, *aln_pos;
     uint32_t vcap, ecap;
@@ -179,22 +180,26 @@ __device__ uint32_t consensus(G& g, uint32_t V, char* out) {
     return len;
 }
 
-template <int NT>
-__device__ __forceinline__ int block_excl_scan_max(int v, int* lds /* NT/64 + 1 */) {
+__device__ __forceinline__ int block_excl_scan_max(int v, int* lds /* blockDim/64 */) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int inc = wave_scan_max(v);
     if (lane == 63) lds[w] = inc;
-    __syncthreads();
-    int base = NEG;
-    for (int i = 0; i < w; i++) base = max(base, lds[i]);
-    int prev = __shfl_up(inc, 1, 64);
-    int ex = lane == 0 ? NEG : prev;
-    return max(base, ex);
+    barrier_lds_only();
+    // wave totals (<= 16): one LDS read per lane, a 16-lane DPP row scan, and a scalar read of entry w-1
+    const int nw = blockDim.x >> 6;
+    int tot = (lane & 15) < nw ? lds[lane & 15] : NEG;
+    int x = tot;
+    x = max(x, __builtin_amdgcn_update_dpp(NEG, tot, 0x111, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(NEG, tot, 0x112, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(NEG, tot, 0x113, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(NEG, x, 0x114, 0xf, 0xe, false));
+    x = max(x, __builtin_amdgcn_update_dpp(NEG, x, 0x118, 0xf, 0xc, false));
+    const int base = w == 0 ? NEG : __builtin_amdgcn_readlane(x, w - 1);
+    return max(base, wave_shift_up1(inc, NEG));
 }
 
-template <int NT>
-__device__ __forceinline__ uint32_t block_excl_scan_add(uint32_t v, uint32_t* lds /* NT/64 */, uint32_t* total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+__device__ __forceinline__ uint32_t block_excl_scan_add(uint32_t v, uint32_t* lds /* blockDim/64 */, uint32_t* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NT = blockDim.x;
     uint32_t inc = wave_scan_add(v);
     if (lane == 63) lds[w] = inc;
     __syncthreads();
@@ -205,14 +210,356 @@ __device__ __forceinline__ uint32_t block_excl_scan_add(uint32_t v, uint32_t* ld
     return base + inc - v;
 }
 
-template <int NT>
-__global__ void __launch_bounds__(NT) k_poa(const PoaEdge* __restrict__ edges, const uint32_t* __restrict__ order, uint32_t n_edges,
+
+
+// contiguous per-lane chunk stores/loads as single wide memory instructions (rows are padded to 16 columns, chunks are CM-aligned)
+template <int CM> __device__ __forceinline__ void store_chunk_i32(int32_t* p, const int (&v)[CM]) {
+    if constexpr (CM >= 4) {
+#pragma unroll
+        for (int q = 0; q < CM / 4; q++) reinterpret_cast<int4*>(p)[q] = make_int4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else if constexpr (CM == 2) *reinterpret_cast<int2*>(p) = make_int2(v[0], v[1]);
+    else p[0] = v[0];
+}
+template <int CM> __device__ __forceinline__ void load_chunk_i32(const int32_t* p, int (&v)[CM]) {
+    if constexpr (CM >= 4) {
+#pragma unroll
+        for (int q = 0; q < CM / 4; q++) { const int4 x = reinterpret_cast<const int4*>(p)[q]; v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w; }
+    } else if constexpr (CM == 2) { const int2 x = *reinterpret_cast<const int2*>(p); v[0] = x.x; v[1] = x.y; }
+    else v[0] = p[0];
+}
+template <int CM> __device__ __forceinline__ void store_chunk_u8(uint8_t* p, const uint32_t (&v)[CM]) {
+    if constexpr (CM >= 4) {
+        uint32_t w[CM / 4];
+#pragma unroll
+        for (int q = 0; q < CM / 4; q++) w[q] = (v[4 * q] & 0xffu) | ((v[4 * q + 1] & 0xffu) << 8) | ((v[4 * q + 2] & 0xffu) << 16) | (v[4 * q + 3] << 24);
+        if constexpr (CM == 4) *reinterpret_cast<uint32_t*>(p) = w[0];
+        else if constexpr (CM == 8) *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);
+        else {
+#pragma unroll
+            for (int q = 0; q < CM / 16; q++) reinterpret_cast<uint4*>(p)[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+        }
+    } else if constexpr (CM == 2) *reinterpret_cast<uint16_t*>(p) = (uint16_t)((v[0] & 0xffu) | (v[1] << 8));
+    else p[0] = (uint8_t)v[0];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// DP over (rank, column) for one sequence against the current graph.
+// Lane t owns the CM contiguous columns [t*CM, t*CM+CM) of every row and keeps them in registers.
+// The last R rows live in an LDS ring in a lane-transposed layout (column t*CM+k of a row sits at word
+// k*NT + t): a wave's access to "its k-th column" is 64 consecutive words, so ring reads and writes are
+// bank-conflict free for every CM, which a row-major ring read with stride CM is not. Predecessor rows
+// older than R ranks (rare: graph bubbles longer than the ring) and the traceback read the row-major int32
+// matrix in HBM, which every row is also written to (16-64 contiguous bytes per lane).
+// Horizontal recurrence H[j] = max(T[j], H[j-1]+g): serial inside a lane's chunk, then a wavefront
+// prefix-max scan (shuffles) + LDS exchange between waves over the chunk ends of T[k]-k*g, then the carry.
+// ---------------------------------------------------------------------------------------------------
+template <int CM, bool DIR>
+__device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, const uint32_t W, const uint8_t* __restrict__ seq, const uint32_t L,
+                        const uint32_t V, int32_t* ring, const uint32_t R, const uint32_t ring_w, const int match, const int mismatch, const int gap,
+                        int* lds_i, uint32_t* smeta, int& bestScoreOut, int& bestIOut) {
+    constexpr uint32_t MT = 256;   // metadata tile (rows)
+    const uint32_t tid = threadIdx.x, NT = blockDim.x;
+    const uint32_t ncol = L + 1;
+    const uint32_t j0 = tid * CM;
+    const bool in_row = j0 < W;                                      // lane has columns inside the padded row (may store to HBM)
+    const bool owns_last = j0 <= L && L < j0 + CM;                   // lane holding column L
+    const uint32_t klast = owns_last ? L - j0 : 0;
+    // Columns beyond L ("pad" columns, in lanes at or right of the one holding column L) are computed like real ones and never
+    // read by a real column: dependencies only run left-to-right and down the same column. So the row loop has no per-column
+    // predicates. Column 0 needs no special case either: its diagonal source (left) and horizontal source (run) start at NEG.
+    // eq[c]: bit k set iff the sequence base under column j0+k is c
+    uint32_t eq[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < CM; k++) {
+        const uint32_t j = j0 + k;
+        const uint32_t b = (j >= 1 && j < ncol) ? seq[j - 1] : 0xffu;
+#pragma unroll
+        for (int c = 0; c < 4; c++) eq[c] |= (b == (uint32_t)c ? 1u : 0u) << k;
+    }
+    const int dsc = match - mismatch;
+    const int jg0 = (int)j0 * gap;
+    {   // row 0 (always kept in HBM: it is the virtual predecessor of every source node)
+        int r0[CM];
+#pragma unroll
+        for (int k = 0; k < CM; k++) { r0[k] = jg0 + k * gap; if (R) ring[k * NT + tid] = r0[k]; }
+        if (in_row) store_chunk_i32<CM>(H + j0, r0);
+    }
+    int bestScore = INT32_MIN + 1024, bestI = -1;
+    __syncthreads();
+    for (uint32_t i = 1; i <= V; i++) {
+        // row metadata comes through LDS in tiles of MT rows (one coalesced cooperative load per tile): a per-row global load with a
+        // uniform address would put a full L2 round trip on the critical path of every row
+        const uint32_t ti = (i - 1) & (MT - 1);
+        if (ti == 0) {
+            __syncthreads();   // previous tile fully consumed
+            for (uint32_t q = tid; q < MT && i - 1 + q < V; q += NT) {
+                smeta[0 * MT + q] = g.row_meta[i - 1 + q]; smeta[1 * MT + q] = g.row_pred0[i - 1 + q];
+                smeta[2 * MT + q] = g.row_pred1[i - 1 + q]; smeta[3 * MT + q] = g.row_pred_off[i - 1 + q];
+            }
+            __syncthreads();
+        }
+        const uint32_t meta = smeta[ti], p0 = smeta[MT + ti], p1 = smeta[2 * MT + ti], po = smeta[3 * MT + ti];
+        const uint32_t rc = meta & 3u, npred = meta >> 8;
+        const uint32_t mask = rc == 0 ? eq[0] : rc == 1 ? eq[1] : rc == 2 ? eq[2] : eq[3];
+        int t[CM];            // diagonal/vertical maximum, then the finished row values
+        uint32_t dcode[CM];   // what the reference's traceback picks at the cell: (slot<<2)|0 diagonal, (slot<<2)|1 vertical, 2 horizontal
+        auto load_pred = [&](uint32_t pr, int (&hp)[CM], int& left) {
+            if (R && i - pr < R) {
+                const int32_t* S = ring + (size_t)(pr & (R - 1)) * ring_w;
+#pragma unroll
+                for (int k = 0; k < CM; k++) hp[k] = S[k * NT + tid];
+                left = tid > 0 ? S[(CM - 1) * NT + tid - 1] : NEG;
+            } else if (in_row) {
+                const int32_t* Gp = H + (uint64_t)pr * W + j0;
+                load_chunk_i32<CM>(Gp, hp);
+                left = j0 > 0 ? Gp[-1] : NEG;
+            } else {
+#pragma unroll
+                for (int k = 0; k < CM; k++) hp[k] = NEG;
+                left = NEG;
+            }
+        };
+        if (npred <= 1) {   // the common case: one predecessor (or the virtual row 0 for a source node): no arg-max bookkeeping
+            int hp[CM], left;
+            load_pred(npred == 0 ? 0u : p0 + 1, hp, left);
+#pragma unroll
+            for (int k = 0; k < CM; k++) {
+                const int dg = (k == 0 ? left : hp[k - 1]) + mismatch + (dsc & -(int)((mask >> k) & 1u));
+                const int up = hp[k] + gap;
+                t[k] = max(dg, up);
+                dcode[k] = dg >= up ? 0u : 1u;     // diagonal is tried first
+            }
+        } else {
+            int bd[CM], bv[CM];
+            uint32_t pp[CM];   // first predecessor slot reaching the diagonal maximum (bits 0-7) / the vertical maximum (bits 8-15)
+#pragma unroll
+            for (int k = 0; k < CM; k++) { bd[k] = NEG; bv[k] = NEG; pp[k] = 0; }
+            for (uint32_t p = 0; p < npred; p++) {
+                int hp[CM], left;
+                load_pred((p == 0 ? p0 : p == 1 ? p1 : g.pred_rank[po + p]) + 1, hp, left);
+#pragma unroll
+                for (int k = 0; k < CM; k++) {
+                    const int dg = (k == 0 ? left : hp[k - 1]) + mismatch + (dsc & -(int)((mask >> k) & 1u));
+                    const int up = hp[k] + gap;
+                    if (dg > bd[k]) { bd[k] = dg; pp[k] = (pp[k] & 0xff00u) | p; }          // strict '>' keeps the first predecessor reaching the maximum
+                    if (up > bv[k]) { bv[k] = up; pp[k] = (pp[k] & 0x00ffu) | (p << 8); }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CM; k++) {
+                t[k] = max(bd[k], bv[k]);
+                dcode[k] = bd[k] >= bv[k] ? ((pp[k] & 0xffu) << 2) : (((pp[k] >> 8) << 2) | 1u);
+            }
+        }
+        // chunk-local horizontal recurrence: a horizontal move is recorded only when strictly better (it is tried last)
+        int run = NEG;
+#pragma unroll
+        for (int k = 0; k < CM; k++) {
+            const int hz = run + gap;
+            if (hz > t[k]) { t[k] = hz; dcode[k] = 2u; }
+            run = t[k];
+        }
+        // carry from the lanes to the left: prefix maximum of (chunk end value - its column * gap)
+        const int ex = block_excl_scan_max(run - (jg0 + (CM - 1) * gap), lds_i);
+        if (ex > NEG / 2) {
+            const int base = ex + jg0;
+#pragma unroll
+            for (int k = 0; k < CM; k++) { const int via = base + k * gap; if (via > t[k]) { t[k] = via; dcode[k] = 2u; } }
+        }
+        if (R) {
+            int32_t* S = ring + (size_t)(i & (R - 1)) * ring_w;
+#pragma unroll
+            for (int k = 0; k < CM; k++) S[k * NT + tid] = t[k];
+        }
+        if (in_row) {
+            if (!DIR || !R || (meta & 8u)) store_chunk_i32<CM>(H + (uint64_t)i * W + j0, t);   // H row to HBM only if the traceback or a far successor needs it
+            if (DIR) store_chunk_u8<CM>(D + (uint64_t)i * W + j0, dcode);
+        }
+        if (owns_last && (meta & 4u)) {   // sink node: candidate end of the global alignment (first maximum in rank order)
+            int v = NEG;
+#pragma unroll
+            for (int k = 0; k < CM; k++) if ((uint32_t)k == klast) v = t[k];
+            if (bestScore < v) { bestScore = v; bestI = (int)i; }
+        }
+        // row i is complete in the ring after an LDS-only barrier; rows spilled to HBM are only read R or more rows later, so a full
+        // (vmcnt) synchronisation every R-1 rows is enough to order those stores before their readers. Without a ring every row is read from HBM.
+        if (!R || (i % (R - 1)) == 0) __syncthreads(); else barrier_lds_only();
+    }
+    if (owns_last) { bestScoreOut = bestScore; bestIOut = bestI; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Single-wavefront DP: one 64-lane wave owns an edge, lane t keeps columns [t*CM, t*CM+CM) of the CURRENT row
+// in registers. The common predecessor of row i is row i-1, i.e. the lane's own registers plus one DPP
+// wave_shr for the left neighbour's last column: no LDS, no barrier, no HBM read on the critical path.
+// Rows that a later row needs as a non-adjacent predecessor are flagged by the CSR build and copied to
+// the LDS ring (distance < R) or to HBM (distance >= R). The horizontal recurrence is a lane-serial pass
+// plus one 64-lane DPP prefix-max scan. Many such waves (different edges) share a CU and hide each
+// other's latencies, which a 16-wave workgroup synchronising twice per row cannot.
+// ---------------------------------------------------------------------------------------------------
+template <int CM, bool DIR>
+__device__ void dp_rows_wave(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, const uint32_t W, const uint8_t* __restrict__ seq,
+                             const uint32_t L, const uint32_t V, int32_t* ring, const uint32_t R, const uint32_t ring_w, const int match,
+                             const int mismatch, const int gap, uint32_t* smeta, int& bestScoreOut, int& bestIOut) {
+    constexpr uint32_t MT = 256;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t ncol = L + 1;
+    const uint32_t j0 = lane * CM;
+    const bool in_row = j0 < W;
+    const bool owns_last = j0 <= L && L < j0 + CM;
+    const uint32_t klast = owns_last ? L - j0 : 0;
+    uint32_t eq[4] = {0, 0, 0, 0};   // CM <= 32: one bit per column
+#pragma unroll
+    for (int k = 0; k < CM; k++) {
+        const uint32_t j = j0 + k;
+        const uint32_t b = (j >= 1 && j < ncol) ? seq[j - 1] : 0xffu;
+#pragma unroll
+        for (int c = 0; c < 4; c++) eq[c] |= (b == (uint32_t)c ? 1u : 0u) << k;
+    }
+    uint32_t nkept = 0;   // kept rows produced so far (ring slot counter; mirrors the CSR build's numbering)
+    const int dsc = match - mismatch;
+    const int jg0 = (int)j0 * gap;
+    int t[CM];   // the previous row, then the current one
+#pragma unroll
+    for (int k = 0; k < CM; k++) { t[k] = jg0 + k * gap; if (R) ring[k * 64 + lane] = t[k]; }
+    if (in_row) store_chunk_i32<CM>(H + j0, t);   // row 0 stays in HBM: virtual predecessor of every source node
+    int bestScore = INT32_MIN + 1024, bestI = -1;
+    for (uint32_t i = 1; i <= V; i++) {
+        const uint32_t ti = (i - 1) & (MT - 1);
+        if (ti == 0) {   // metadata tile; LDS operations of one wave execute in order, so no barrier is needed
+            for (uint32_t q = lane; q < MT && i - 1 + q < V; q += 64) {
+                smeta[0 * MT + q] = g.row_meta[i - 1 + q]; smeta[1 * MT + q] = g.row_pred0[i - 1 + q];
+                smeta[2 * MT + q] = g.row_pred1[i - 1 + q]; smeta[3 * MT + q] = g.row_pred_off[i - 1 + q];
+            }
+            if (i > 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // orders earlier HBM row spills before later reads (once per tile)
+        }
+        const uint32_t meta = smeta[ti], p0 = smeta[MT + ti], p1 = smeta[2 * MT + ti], po = smeta[3 * MT + ti];
+        const uint32_t rc = meta & 3u, npred = meta >> 8;
+        const uint32_t mask = rc == 0 ? eq[0] : rc == 1 ? eq[1] : rc == 2 ? eq[2] : eq[3];
+        int nt[CM];
+        uint32_t dcode[CM];
+        // predecessor reference = rank | location << 28 (location: 0 registers = previous row, 1..14 ring slot + 1, 15 HBM)
+        auto load_pred = [&](uint32_t ent, int (&hp)[CM], int& left) {
+            const uint32_t loc = ent >> 28;
+            if (loc == 0) {
+#pragma unroll
+                for (int k = 0; k < CM; k++) hp[k] = t[k];
+                left = wave_shift_up1(t[CM - 1], NEG);
+            } else if (loc != 15) {
+                const int32_t* S = ring + (size_t)(loc - 1) * ring_w;
+#pragma unroll
+                for (int k = 0; k < CM; k++) hp[k] = S[k * 64 + lane];
+                left = lane > 0 ? S[(CM - 1) * 64 + lane - 1] : NEG;
+            } else if (in_row) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's earlier row spills have reached memory before it reads one back
+                const int32_t* Gp = H + (uint64_t)((ent & 0x0fffffffu) + 1) * W + j0;
+                load_chunk_i32<CM>(Gp, hp);
+                left = j0 > 0 ? Gp[-1] : NEG;
+            } else {
+#pragma unroll
+                for (int k = 0; k < CM; k++) hp[k] = NEG;
+                left = NEG;
+            }
+        };
+        auto load_row0 = [&](int (&hp)[CM], int& left) {   // virtual predecessor of a source node (always in HBM)
+            if (i == 1) {
+#pragma unroll
+                for (int k = 0; k < CM; k++) hp[k] = t[k];
+                left = wave_shift_up1(t[CM - 1], NEG);
+            } else if (in_row) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                load_chunk_i32<CM>(H + j0, hp);
+                left = j0 > 0 ? H[j0 - 1] : NEG;
+            } else {
+#pragma unroll
+                for (int k = 0; k < CM; k++) hp[k] = NEG;
+                left = NEG;
+            }
+        };
+        if (npred <= 1) {
+            int hp[CM], left;
+            if (npred == 0) load_row0(hp, left); else load_pred(p0, hp, left);
+#pragma unroll
+            for (int k = 0; k < CM; k++) {
+                const int dg = (k == 0 ? left : hp[k - 1]) + mismatch + (dsc & -(int)((mask >> k) & 1u));
+                const int up = hp[k] + gap;
+                nt[k] = max(dg, up);
+                dcode[k] = dg >= up ? 0u : 1u;
+            }
+        } else {
+            int bd[CM], bv[CM];
+            uint32_t pp[CM];
+#pragma unroll
+            for (int k = 0; k < CM; k++) { bd[k] = NEG; bv[k] = NEG; pp[k] = 0; }
+            for (uint32_t p = 0; p < npred; p++) {
+                int hp[CM], left;
+                load_pred(p == 0 ? p0 : p == 1 ? p1 : g.pred_rank[po + p], hp, left);
+#pragma unroll
+                for (int k = 0; k < CM; k++) {
+                    const int dg = (k == 0 ? left : hp[k - 1]) + mismatch + (dsc & -(int)((mask >> k) & 1u));
+                    const int up = hp[k] + gap;
+                    if (dg > bd[k]) { bd[k] = dg; pp[k] = (pp[k] & 0xff00u) | p; }
+                    if (up > bv[k]) { bv[k] = up; pp[k] = (pp[k] & 0x00ffu) | (p << 8); }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CM; k++) {
+                nt[k] = max(bd[k], bv[k]);
+                dcode[k] = bd[k] >= bv[k] ? ((pp[k] & 0xffu) << 2) : (((pp[k] >> 8) << 2) | 1u);
+            }
+        }
+        int run = NEG;
+#pragma unroll
+        for (int k = 0; k < CM; k++) {
+            const int hz = run + gap;
+            if (hz > nt[k]) { nt[k] = hz; dcode[k] = 2u; }
+            run = nt[k];
+        }
+        const int inc = wave_scan_max(run - (jg0 + (CM - 1) * gap));
+        const int ex = wave_shift_up1(inc, NEG);
+        if (ex > NEG / 2) {
+            const int base = ex + jg0;
+#pragma unroll
+            for (int k = 0; k < CM; k++) { const int via = base + k * gap; if (via > nt[k]) { nt[k] = via; dcode[k] = 2u; } }
+        }
+#pragma unroll
+        for (int k = 0; k < CM; k++) t[k] = nt[k];
+        if (meta & 16u) {   // kept row: a later row reads it as a non-adjacent predecessor
+            if (R) {
+                int32_t* S = ring + (size_t)(nkept & (R - 1)) * ring_w;
+#pragma unroll
+                for (int k = 0; k < CM; k++) S[k * 64 + lane] = t[k];
+            }
+            nkept++;
+        }
+        if (in_row) {
+            if (!DIR || (meta & 8u)) store_chunk_i32<CM>(H + (uint64_t)i * W + j0, t);
+            if (DIR) store_chunk_u8<CM>(D + (uint64_t)i * W + j0, dcode);
+        }
+        if (owns_last && (meta & 4u)) {
+            int v = NEG;
+#pragma unroll
+            for (int k = 0; k < CM; k++) if ((uint32_t)k == klast) v = t[k];
+            if (bestScore < v) { bestScore = v; bestI = (int)i; }
+        }
+    }
+    if (owns_last) { bestScoreOut = bestScore; bestIOut = bestI; }
+}
+
+template <int MAXNT, int CMMAX, bool DIR, bool WAVE>
+__global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges, const uint32_t* __restrict__ order, uint32_t n_edges,
                                             const PoaSeq* __restrict__ seqs, const uint8_t* __restrict__ packed, const uint64_t* __restrict__ read_off,
                                             const uint32_t* __restrict__ read_len, PoaPools P, int32_t match, int32_t mismatch, int32_t gap,
-                                            char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells) {
+                                            char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells, unsigned long long* phase,
+                                            uint32_t ring_rows) {
     const uint32_t eidx = order[blockIdx.x];
+    __shared__ unsigned long long ph[6];             // lane-0 cycle counts: decode, dp, traceback, graph update, toposort, csr
+    __shared__ long long tc;
+    if (threadIdx.x == 0) { for (int k = 0; k < 6; k++) ph[k] = 0; tc = clock64(); }
+#define PHASE(k) do { if (tid == 0) { long long _n = clock64(); ph[k] += (unsigned long long)(_n - tc); tc = _n; } } while (0)
     const PoaEdge ED = edges[eidx];
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, NT = blockDim.x;
+    extern __shared__ int32_t ring[];
     G g;
     {
         const uint64_t no = ED.node_off, eo = ED.edge_off;
@@ -221,16 +568,24 @@ __global__ void __launch_bounds__(NT) k_poa(const PoaEdge* __restrict__ edges, c
         g.rank2node = P.rank2node + no; g.node2rank = P.node2rank + no; g.mark = P.mark + no; g.check = P.check + no;
         g.stack = P.stack + ED.stack_off; g.score = P.score + no; g.pred = P.pred + no;
         g.row_code = P.row_code + no; g.row_sink = P.row_sink + no; g.row_pred_off = P.row_pred_off + no; g.pred_rank = P.pred_rank + eo;
+        g.row_meta = P.row_meta + no; g.row_pred0 = P.row_pred0 + no; g.row_pred1 = P.row_pred1 + no;
         g.e_from = P.e_from + eo; g.e_to = P.e_to + eo; g.e_next_in = P.e_next_in + eo; g.e_next_out = P.e_next_out + eo; g.e_w = P.e_w + eo;
         g.aln_node = P.aln_node + ED.aln_off; g.aln_pos = P.aln_pos + ED.aln_off;
         g.vcap = ED.vcap; g.ecap = ED.ecap;
     }
     int32_t* H = P.H + ED.h_off;
+    uint8_t* Dm = DIR ? P.dir + ED.h_off : nullptr;   // direction bytes share the score matrix' geometry
+    // ring geometry is a property of the edge (its longest sequence) and of the launch
+    const uint32_t cme = (ED.lmax + 1 + NT - 1) / NT;
+    const uint32_t cmr = WAVE ? (cme <= 4 ? 4 : cme <= 8 ? 8 : cme <= 16 ? 16 : 32) : (cme <= 1 ? 1 : cme <= 2 ? 2 : cme <= 4 ? 4 : cme <= 8 ? 8 : cme <= 16 ? 16 : cme <= 32 ? 32 : 64);
+    const uint32_t ring_w = cmr * NT;
+    const uint32_t R = ring_rows >= 2 && cmr <= 32 ? ring_rows : 0;
     uint8_t* seq = P.seq + ED.seq_off;
-    const uint32_t W = ED.lmax + 1;
+    const uint32_t W = (ED.lmax + 1 + 15) & ~15u;   // row stride, padded so that every lane chunk is vector-aligned
 
-    __shared__ int lds_i[NT / 64 + 1];
-    __shared__ uint32_t lds_u[NT / 64];
+    __shared__ int lds_i[17];
+    __shared__ uint32_t smeta[4 * 256];
+    __shared__ uint32_t lds_u[16];
     __shared__ uint32_t sV, sE, sNaln, sOk;
     __shared__ int sBestScore, sBestI;
     if (tid == 0) { sV = 0; sE = 0; sOk = 1; }
@@ -250,65 +605,53 @@ __global__ void __launch_bounds__(NT) k_poa(const PoaEdge* __restrict__ edges, c
             }
         }
         __syncthreads();
+        PHASE(0);
         const uint32_t V = sV;
         if (V > 0) {
             // =================================================== DP over (rank, column)
-            const uint32_t ncol = L + 1;
-            const uint32_t C = (ncol + NT - 1) / NT;
-            const uint32_t j0 = tid * C, j1 = min(j0 + C, ncol);
-            for (uint32_t j = j0; j < j1; j++) H[j] = (int32_t)j * gap;   // row 0
-            int bestScore = INT32_MIN + 1024, bestI = -1;                // tracked by the lane owning column L
-            __syncthreads();
-            for (uint32_t i = 1; i <= V; i++) {
-                const uint32_t rc = g.row_code[i - 1];
-                const uint32_t po = g.row_pred_off[i - 1], pe = g.row_pred_off[i];
-                int32_t* row = H + (uint64_t)i * W;
-                int run = NEG, endv = NEG;
-                if (j0 < j1) {
-                    // pass 1: T[j] and the chunk-local horizontal recurrence
-                    for (uint32_t j = j0; j < j1; j++) {
-                        int t;
-                        if (j == 0) {
-                            if (po == pe) t = gap;
-                            else { t = NEG; for (uint32_t p = po; p < pe; p++) t = max(t, H[(uint64_t)(g.pred_rank[p] + 1) * W]); t += gap; }
-                            run = t;
-                        } else {
-                            const int sc = seq[j - 1] == rc ? match : mismatch;
-                            if (po == pe) t = max(H[j - 1] + sc, H[j] + gap);
-                            else {
-                                t = NEG;
-                                for (uint32_t p = po; p < pe; p++) {
-                                    const int32_t* pw = H + (uint64_t)(g.pred_rank[p] + 1) * W;
-                                    t = max(t, max(pw[j - 1] + sc, pw[j] + gap));
-                                }
-                            }
-                            run = max(t, run + gap);
-                        }
-                        row[j] = run;
-                    }
-                    endv = run - (int)(j1 - 1) * gap;
+            {
+                const uint32_t cm = (L + 1 + NT - 1) / NT;     // columns per lane for this sequence
+                int bs = 0, bi = -1;
+#define HX_DP(CMV) dp_rows<CMV, DIR>(g, H, Dm, W, seq, L, V, ring, R, ring_w, match, mismatch, gap, lds_i, smeta, bs, bi)
+                if constexpr (WAVE) {          // one wavefront per edge: whole row in the wave's registers (CMMAX columns per lane at most)
+#define HX_DPW(CMV) dp_rows_wave<CMV, DIR>(g, H, Dm, W, seq, L, V, ring, R, ring_w, match, mismatch, gap, smeta, bs, bi)
+                    const uint32_t cw = (L + 1 + 63) / 64;
+                    if (cw <= 4) HX_DPW(4); else if (cw <= 8) HX_DPW(8); else if (cw <= 16) HX_DPW(16); else HX_DPW(32);
+#undef HX_DPW
+                } else if constexpr (CMMAX == 8) {    // 1024-lane workgroups: 128 VGPRs per lane, chunks of at most 8 columns stay in registers
+                    if (cm <= 1) HX_DP(1); else if (cm <= 2) HX_DP(2); else if (cm <= 4) HX_DP(4); else HX_DP(8);
+                } else if constexpr (CMMAX == 16) {   // <= 512 lanes: chunks of at most 16 columns
+                    if (cm <= 1) HX_DP(1); else if (cm <= 2) HX_DP(2); else if (cm <= 4) HX_DP(4); else if (cm <= 8) HX_DP(8); else HX_DP(16);
+                } else {                        // gaps longer than 16 x 1024 columns: rare, separate kernel so its registers do not tax the common one
+                    if (cm <= 16) HX_DP(16); else if (cm <= 32) HX_DP(32); else HX_DP(64);
                 }
-                // pass 2: carry from the columns to the left (prefix max of T[k]-k*g)
-                int ex = block_excl_scan_max<NT>(endv, lds_i);
-                if (j0 < j1 && j0 > 0 && ex > NEG / 2) {
-                    for (uint32_t j = j0; j < j1; j++) {
-                        int viaLeft = ex + (int)j * gap;
-                        if (viaLeft > row[j]) row[j] = viaLeft; else break;   // once the chunk-local value wins it wins for the rest
-                    }
-                }
-                if (j1 == ncol && j0 < j1 && g.row_sink[i - 1]) {
-                    int v = row[L];
-                    if (bestScore < v) { bestScore = v; bestI = (int)i; }
-                }
-                __syncthreads();   // row i complete and visible; lds_i free again
+#undef HX_DP
+                if (bi >= 0) { sBestScore = bs; sBestI = bi; }
             }
-            if (j1 == ncol && j0 < j1) { sBestScore = bestScore; sBestI = bestI; }
             __syncthreads();
+            PHASE(1);
             // =================================================== traceback (lane 0), stored reversed
             if (tid == 0) {
                 atomicAdd(cells, (unsigned long long)V * L);
                 uint32_t i = (uint32_t)sBestI, j = L, na = 0;
-                while (!(i == 0 && j == 0)) {
+                while (DIR && !(i == 0 && j == 0)) {
+                    uint32_t pi_ = i, pj_ = j;
+                    if (i == 0) pj_ = j - 1;   // only horizontal moves in the virtual row
+                    else {
+                        const uint8_t d = Dm[(uint64_t)i * W + j];
+                        if ((d & 3u) == 2u) pj_ = j - 1;
+                        else {
+                            const uint32_t np = g.row_meta[i - 1] >> 8, slot = d >> 2;
+                            pi_ = np == 0 ? 0u : ((slot == 0 ? g.row_pred0[i - 1] : slot == 1 ? g.row_pred1[i - 1] : g.pred_rank[g.row_pred_off[i - 1] + slot]) & 0x0fffffffu) + 1;
+                            if ((d & 3u) == 0u) pj_ = j - 1;
+                        }
+                    }
+                    g.aln_node[na] = i == pi_ ? -1 : (int32_t)g.rank2node[i - 1];
+                    g.aln_pos[na] = j == pj_ ? -1 : (int32_t)(j - 1);
+                    na++;
+                    i = pi_; j = pj_;
+                }
+                while (!DIR && !(i == 0 && j == 0)) {
                     const int hij = H[(uint64_t)i * W + j];
                     uint32_t pi_ = i, pj_ = j;
                     bool found = false;
@@ -318,14 +661,14 @@ __global__ void __launch_bounds__(NT) k_poa(const PoaEdge* __restrict__ edges, c
                         const int mc = seq[j - 1] == g.row_code[i - 1] ? match : mismatch;
                         if (po == pe) { if (hij == H[j - 1] + mc) { pi_ = 0; pj_ = j - 1; found = true; } }
                         else for (uint32_t p = po; p < pe && !found; p++) {
-                            uint32_t pr = g.pred_rank[p] + 1;
+                            uint32_t pr = (g.pred_rank[p] & 0x0fffffffu) + 1;
                             if (hij == H[(uint64_t)pr * W + j - 1] + mc) { pi_ = pr; pj_ = j - 1; found = true; }
                         }
                     }
                     if (!found && i != 0) {
                         if (po == pe) { if (hij == H[j] + gap) { pi_ = 0; pj_ = j; found = true; } }
                         else for (uint32_t p = po; p < pe && !found; p++) {
-                            uint32_t pr = g.pred_rank[p] + 1;
+                            uint32_t pr = (g.pred_rank[p] & 0x0fffffffu) + 1;
                             if (hij == H[(uint64_t)pr * W + j] + gap) { pi_ = pr; pj_ = j; found = true; }
                         }
                     }
@@ -339,6 +682,7 @@ __global__ void __launch_bounds__(NT) k_poa(const PoaEdge* __restrict__ edges, c
             }
         } else if (tid == 0) sNaln = 0;
         __syncthreads();
+        PHASE(2);
         // =================================================== graph update + topological sort
         {
             uint32_t Vn = sV;   // marks are cleared for the node count AFTER the update; clear generously up to V+L
@@ -349,7 +693,7 @@ __global__ void __launch_bounds__(NT) k_poa(const PoaEdge* __restrict__ edges, c
         if (tid == 0) {
             uint32_t V2 = sV, E2 = sE;
             if (!add_alignment(g, V2, E2, sNaln, seq, L)) sOk = 0;
-            else { toposort(g, V2); sV = V2; sE = E2; }
+            else { PHASE(3); toposort(g, V2); sV = V2; sE = E2; PHASE(4); }
         }
         __syncthreads();
         if (!sOk) break;
@@ -366,21 +710,72 @@ __global__ void __launch_bounds__(NT) k_poa(const PoaEdge* __restrict__ edges, c
                 for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) cnt++;
             }
             uint32_t tot;
-            uint32_t off = block_excl_scan_add<NT>(cnt, lds_u, &tot);
+            uint32_t off = block_excl_scan_add(cnt, lds_u, &tot);
             for (uint32_t r = r0; r < r1; r++) {
                 uint32_t n = g.rank2node[r];
                 g.row_pred_off[r] = off;
-                g.row_code[r] = g.code[n];
-                g.row_sink[r] = g.out_head[n] == NONE;
-                for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) g.pred_rank[off++] = g.node2rank[g.e_from[e]];
+                const uint32_t cd = g.code[n], sink = g.out_head[n] == NONE;
+                g.row_code[r] = (uint8_t)cd;
+                g.row_sink[r] = (uint8_t)sink;
+                uint32_t np = 0, q0 = 0, q1 = 0;
+                for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) {
+                    const uint32_t pr = g.node2rank[g.e_from[e]];
+                    g.pred_rank[off++] = pr;
+                    if (np == 0) q0 = pr; else if (np == 1) q1 = pr;
+                    np++;
+                }
+                g.row_meta[r] = cd | (sink << 2) | (np << 8);
+                g.row_pred0[r] = q0; g.row_pred1[r] = q1;
             }
             if (tid == NT - 1) g.row_pred_off[V2] = tot;
+            __syncthreads();
+            if constexpr (WAVE) {
+                // Wave kernel: a row lives in the owning lanes' registers for exactly one more row. Rows with a NON-adjacent successor
+                // are "kept": they get ring slots in the order they are produced (slot = #kept rows before it, mod R), and every
+                // predecessor reference is tagged with where the DP will find the row: 0 registers, 1..14 ring slot + 1, 15 HBM.
+                for (uint32_t r = r0; r < r1; r++)
+                    for (uint32_t q = g.row_pred_off[r], qe = q + (g.row_meta[r] >> 8); q < qe; q++)
+                        if (r - g.pred_rank[q] >= 2) atomicOr(&g.row_meta[g.pred_rank[q]], 16u);
+                __syncthreads();
+                uint32_t kc = 0;
+                for (uint32_t r = r0; r < r1; r++) kc += (g.row_meta[r] >> 4) & 1u;
+                uint32_t ktot;
+                uint32_t kex = block_excl_scan_add(kc, lds_u, &ktot);
+                for (uint32_t r = r0; r < r1; r++) { g.score[r] = (int32_t)kex; kex += (g.row_meta[r] >> 4) & 1u; }   // kept rows before r
+                __syncthreads();
+                for (uint32_t r = r0; r < r1; r++) {
+                    const uint32_t po = g.row_pred_off[r], np = g.row_meta[r] >> 8;
+                    for (uint32_t q = 0; q < np; q++) {
+                        const uint32_t pr = g.pred_rank[po + q];
+                        uint32_t loc = 0;
+                        if (r - pr >= 2) {
+                            const uint32_t live = (uint32_t)g.score[r] - (uint32_t)g.score[pr];   // kept rows produced in [pr, r), pr included
+                            if (R && live <= R) loc = 1 + ((uint32_t)g.score[pr] & (R - 1));
+                            else { loc = 15; atomicOr(&g.row_meta[pr], 8u); }
+                        }
+                        const uint32_t ent = pr | (loc << 28);
+                        g.pred_rank[po + q] = ent;
+                        if (q == 0) g.row_pred0[r] = ent; else if (q == 1) g.row_pred1[r] = ent;
+                    }
+                }
+            } else {
+                // a row whose successor sits R or more ranks later cannot be served from the rank-indexed LDS ring: flag it so the DP spills it to HBM
+                for (uint32_t r = r0; r < r1; r++) {
+                    for (uint32_t q = g.row_pred_off[r], qe = q + (g.row_meta[r] >> 8); q < qe; q++) {
+                        const uint32_t pr = g.pred_rank[q];
+                        if (!R || r - pr >= R) atomicOr(&g.row_meta[pr], 8u);
+                    }
+                }
+            }
         }
         __syncthreads();
+        PHASE(5);
     }
     if (tid == 0) {
         if (!sOk) { status[eidx] = HXE_POA_OVERFLOW; cns_len[eidx] = 0; }
         else { status[eidx] = 0; cns_len[eidx] = sV ? consensus(g, sV, cns + ED.cns_off) : 0; }
+        PHASE(3);
+        if (phase) for (int k = 0; k < 6; k++) phase[(uint64_t)eidx * 6 + k] = ph[k];
     }
 }
 
@@ -388,14 +783,20 @@ __global__ void __launch_bounds__(NT) k_poa(const PoaEdge* __restrict__ edges, c
 
 void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_edges, const PoaSeq* seqs, const uint8_t* packed, const uint64_t* read_off,
              const uint32_t* read_len, PoaPools pools, uint64_t, int32_t match, int32_t mismatch, int32_t gap, char* cns, uint32_t* cns_len,
-             uint32_t* status, unsigned long long* cells, int block_threads, hipStream_t s) {
+             uint32_t* status, unsigned long long* cells, unsigned long long* phase, int block_threads, uint32_t ring_rows, uint32_t ring_bytes, bool big,
+             bool use_dir, hipStream_t s) {
     if (!n_edges) return;
-    if (block_threads >= 512)
-        k_poa<512><<<n_edges, 512, 0, s>>>(edges, order, n_edges, seqs, packed, read_off, read_len, pools, match, mismatch, gap, cns, cns_len, status, cells);
-    else if (block_threads >= 256)
-        k_poa<256><<<n_edges, 256, 0, s>>>(edges, order, n_edges, seqs, packed, read_off, read_len, pools, match, mismatch, gap, cns, cns_len, status, cells);
-    else
-        k_poa<64><<<n_edges, 64, 0, s>>>(edges, order, n_edges, seqs, packed, read_off, read_len, pools, match, mismatch, gap, cns, cns_len, status, cells);
+#define HX_LAUNCH(MNT, CMX, DIRV) do { \
+        (void)hipFuncSetAttribute((const void*)k_poa<MNT, CMX, DIRV, (MNT == 64)>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+        k_poa<MNT, CMX, DIRV, (MNT == 64)><<<n_edges, block_threads, ring_bytes, s>>>(edges, order, n_edges, seqs, packed, read_off, read_len, pools, match, mismatch, gap, \
+                                                                       cns, cns_len, status, cells, phase, ring_rows); } while (0)
+    // one binary per (lane-count class, direction bytes): the register budget of a 256-lane workgroup is not taxed by the 1024-lane bound
+    if (block_threads == 64) { if (use_dir) HX_LAUNCH(64, 32, true); else HX_LAUNCH(64, 32, false); }
+    else if (big) { if (use_dir) HX_LAUNCH(1024, 64, true); else HX_LAUNCH(1024, 64, false); }
+    else if (block_threads <= 256) { if (use_dir) HX_LAUNCH(256, 16, true); else HX_LAUNCH(256, 16, false); }
+    else if (block_threads <= 512) { if (use_dir) HX_LAUNCH(512, 16, true); else HX_LAUNCH(512, 16, false); }
+    else { if (use_dir) HX_LAUNCH(1024, 8, true); else HX_LAUNCH(1024, 8, false); }
+#undef HX_LAUNCH
 }
 
 }  // namespace hxk

@@ -5,6 +5,8 @@ No fallback: if the library or a HIP device is missing, construction raises.
 import ctypes as C
 import os
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # POA classes run on separate streams that must map to distinct hardware queues
+
 from . import ctypes_defs as T
 
 _LIBDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
@@ -13,7 +15,7 @@ _lib = None
 SYMBOLS = ["hx_last_error", "hx_device_count", "hx_ctx_create", "hx_ctx_destroy", "hx_upload", "hx_set_read_shard",
            "hx_chain_reads", "hx_edge_support", "hx_edge_coords", "hx_poa_batch", "hx_free_chain", "hx_free_edges",
            "hx_free_coords", "hx_free_cns", "hx_edge_emit", "hx_edge_records_bytes", "hx_edge_records_export",
-           "hx_edge_records_import", "hx_timing_reset", "hx_timing_get", "hx_set_poa_block", "hx_backend_fill"]
+           "hx_edge_records_import", "hx_timing_reset", "hx_timing_get", "hx_set_poa_block", "hx_backend_fill", "hx_poa_phase_cycles", "hx_set_poa_traceback"]
 
 
 class HipError(RuntimeError):
@@ -47,6 +49,9 @@ def lib():
         L.hx_timing_reset.argtypes = [C.c_void_p]
         L.hx_timing_get.argtypes = [C.c_void_p, C.POINTER(C.c_double * 4), C.POINTER(C.c_uint64 * 4)]
         L.hx_set_poa_block.argtypes = [C.c_void_p, C.c_int]
+        L.hx_set_poa_traceback.argtypes = [C.c_void_p, C.c_int]
+        L.hx_poa_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 6), C.POINTER(C.c_uint64 * 6)]
+        L.hx_poa_phase_cycles.restype = C.c_uint32
         L.hx_backend_fill.argtypes = [C.c_void_p, C.POINTER(T.Backend)]
         _lib = L
     return _lib
@@ -78,6 +83,9 @@ class HipContext:
 
     def set_poa_block(self, threads):
         lib().hx_set_poa_block(self._h, threads)
+
+    def set_poa_traceback(self, use_direction_bytes):
+        lib().hx_set_poa_traceback(self._h, int(use_direction_bytes))
 
     def backend(self):
         return self.table
@@ -128,6 +136,12 @@ class HipContext:
         r = T.cns_to_list(o), {"dp_cells": o.dp_cells, "seq_bases": o.seq_bases, "n_aligned": o.n_aligned}
         lib().hx_free_cns(self._h, C.byref(o))
         return r
+
+    def poa_phase_cycles(self):
+        a, b = (C.c_uint64 * 6)(), (C.c_uint64 * 6)()
+        n = lib().hx_poa_phase_cycles(self._h, C.byref(a), C.byref(b))
+        names = ("decode", "dp", "traceback", "graph_update", "toposort", "csr")
+        return {"edges": n, "sum": dict(zip(names, a)), "slowest_edge": dict(zip(names, b))}
 
     def timing_reset(self):
         lib().hx_timing_reset(self._h)

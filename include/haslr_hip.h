@@ -68,8 +68,14 @@ int hx_edge_records_import(hx_ctx*, const void* src_device, uint64_t n_records, 
  * last reset: 0 chain, 1 edges (emit+sort+segment), 2 coords, 3 poa. ms[] and launches[] have 4 entries. */
 void hx_timing_reset(hx_ctx*);
 void hx_timing_get(hx_ctx*, double* ms, uint64_t* launches);
-/* POA work-group size (64, 256 or 512 lanes per edge); default 256 */
+/* diagnostics of the last hx_poa_batch: shader-clock cycles spent by lane 0 per phase [decode, dp, traceback,
+ * graph update + consensus, toposort, csr], summed over edges (sum6) and for the slowest edge (max6); returns #edges */
+uint32_t hx_poa_phase_cycles(hx_ctx*, uint64_t* sum6, uint64_t* max6);
+/* POA work-group size: 0 = automatic (64..1024 lanes per edge, ~8 DP columns per lane), or force 64/128/256/512/1024 */
 void hx_set_poa_block(hx_ctx*, int threads);
+/* traceback source: 1 (default) = 1-byte direction codes written by the DP (edges with <= 63 sequences), 0 = always re-derive the
+ * moves from the int32 score matrix like the reference engine does (diagnostics / A-B comparison; results are identical) */
+void hx_set_poa_traceback(hx_ctx*, int use_direction_bytes);
 
 /* fill the host pipeline's backend table with the entry points above (struct hx_backend of haslr_host.h,
  * passed as void* to keep this header free of host-side types) */

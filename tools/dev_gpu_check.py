@@ -13,7 +13,7 @@ ds = host.Dataset('/tmp/gt/s.contigs.fa','/tmp/gt/s.reads.fa','/tmp/gt/s.paf')
 prm = ds.params()
 be = orclib.OracleBackend(ds, 8)
 t=time.time(); ro = host.Run(ds, prm, be.table, '/tmp/gt/orc'); ro.all(); print('oracle run', time.time()-t, ro.timings())
-ctx = hip.HipContext(0); ctx.upload(ds); ctx.set_poa_block(blk)
+ctx = hip.HipContext(0); ctx.upload(ds); ctx.set_poa_block(blk); ctx.set_poa_traceback(int(os.environ.get('HX_DIR','1')))
 t=time.time(); rg = host.Run(ds, prm, ctx.backend(), '/tmp/gt/hip'); rg.all(); print('hip run', time.time()-t, rg.timings(), ctx.timing())
 def cmpd(a,b,name):
     bad=[k for k in a if not np.array_equal(a[k],b[k])]
