@@ -455,6 +455,7 @@ struct PoaPoolBufs {
     DV<uint32_t> aligned, in_head, in_tail, out_head, out_tail, rank2node, node2rank, stack, row_pred_off, pred_rank, e_from, e_to, e_next_in, e_next_out;
     DV<int32_t> score, pred, e_w, aln_node, aln_pos, H;
     DV<uint32_t> row_meta, row_pred0, row_pred1;
+    DV<uint4> nrec;
     DV<uint8_t> dir;
 };
 }  // namespace
@@ -531,7 +532,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             while (end < todo.size()) {
                 hxk::PoaEdge& E = P.edges[todo[end]];
                 uint64_t nn = (uint64_t)E.vcap + 1, hc = nn * (((uint64_t)E.lmax + 1 + 15) & ~15ull);   // rows padded to 16 columns (vector-aligned lane chunks)
-                uint64_t b = nn * 68 + (uint64_t)E.ecap * 24 + hc * 5 + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8;
+                uint64_t b = nn * 84 + (uint64_t)E.ecap * 24 + hc * 5 + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8;
                 if (!batch.empty() && bytes + b > budget) break;
                 E.node_off = no; E.edge_off = eo; E.h_off = ho; E.seq_off = so; E.cns_off = co; E.stack_off = sto; E.aln_off = ao;
                 no += nn; eo += E.ecap; ho += hc; so += E.lmax; co += E.vcap; sto += 4 * nn + E.ecap; ao += nn + E.lmax + 2;
@@ -546,21 +547,26 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             HIPCHK(B.node2rank.reserve(no)); HIPCHK(B.row_pred_off.reserve(no)); HIPCHK(B.score.reserve(no)); HIPCHK(B.pred.reserve(no));
             HIPCHK(B.pred_rank.reserve(eo)); HIPCHK(B.e_from.reserve(eo)); HIPCHK(B.e_to.reserve(eo)); HIPCHK(B.e_next_in.reserve(eo));
             HIPCHK(B.e_next_out.reserve(eo)); HIPCHK(B.e_w.reserve(eo)); HIPCHK(B.stack.reserve(sto)); HIPCHK(B.aln_node.reserve(ao));
-            HIPCHK(B.aln_pos.reserve(ao)); HIPCHK(B.H.reserve(ho)); HIPCHK(B.dir.reserve(ho)); HIPCHK(B.row_meta.reserve(no)); HIPCHK(B.row_pred0.reserve(no)); HIPCHK(B.row_pred1.reserve(no)); HIPCHK(B.seq.reserve(so)); HIPCHK(d_cns.reserve(co));
+            HIPCHK(B.aln_pos.reserve(ao)); HIPCHK(B.H.reserve(ho)); HIPCHK(B.dir.reserve(ho)); HIPCHK(B.row_meta.reserve(no)); HIPCHK(B.row_pred0.reserve(no)); HIPCHK(B.row_pred1.reserve(no)); HIPCHK(B.nrec.reserve(no)); HIPCHK(B.seq.reserve(so)); HIPCHK(d_cns.reserve(co));
             HIPCHK(d_edges.reserve(ne)); HIPCHK(d_order.reserve(batch.size())); HIPCHK(d_len.reserve(ne)); HIPCHK(d_status.reserve(ne));
             // lanes per edge. Gaps up to 2047 bases: ONE wavefront per edge (row in registers, no barriers, many edges per CU).
             // Longer gaps: a multi-wave workgroup with ~8 columns per lane (256..1024 lanes). One launch per class, classes run concurrently.
             static const int kClassNT[5] = {1024, 512, 256, 128, 64};
+            const uint32_t wave_max = getenv("HX_POA_WAVE_MAX") ? (uint32_t)atoi(getenv("HX_POA_WAVE_MAX")) : 512;   // columns handled by ONE wavefront per edge
+            const uint32_t cols_per_lane = getenv("HX_POA_COLS") ? (uint32_t)atoi(getenv("HX_POA_COLS")) : 8;
             std::vector<uint32_t> cls_list[5];
             uint32_t cls_cm[5] = {1, 1, 1, 1, 1};
             bool cls_dir[5] = {true, true, true, true, true};
             for (uint32_t e : batch) {
                 const uint32_t ncol = P.edges[e].lmax + 1;
+                static const uint32_t kMaxCm[5] = {8, 16, 32, 32, 32};   // columns per lane each kernel variant keeps in registers
                 int k = 4;
-                if (c->poa_block) { for (k = 0; k < 4 && kClassNT[k] > c->poa_block; k++) {} if (k == 4 && ncol > 2048) k = 3; }
-                else if (ncol > 2048) { k = 2; while (k > 0 && (uint64_t)kClassNT[k] * 8 < ncol) k--; }
+                if (c->poa_block) { for (k = 0; k < 4 && kClassNT[k] > c->poa_block; k++) {} }
+                else if (ncol > wave_max) { k = 3; while (k > 0 && (uint64_t)kClassNT[k] * cols_per_lane < ncol) k--; }
+                while (k > 0 && (uint64_t)kClassNT[k] * kMaxCm[k] < ncol) k--;
+                if (ncol > 65536) return fail("hx_poa_batch: gap sub-sequence longer than 65535 bases is not supported by the POA kernel");
                 cls_list[k].push_back(e);   // batch is cost-sorted, so every class list is too
-                uint32_t cm = (ncol + kClassNT[k] - 1) / kClassNT[k], cmr = k == 4 ? 4 : 1;
+                uint32_t cm = (ncol + kClassNT[k] - 1) / kClassNT[k], cmr = 4;
                 while (cmr < cm) cmr <<= 1;
                 cls_cm[k] = std::max(cls_cm[k], cmr);
                 if (P.nseq[e] > 63 || c->poa_no_dir) cls_dir[k] = false;   // in-degree <= #sequences must fit the 6-bit predecessor slot
@@ -570,7 +576,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             HIPCHK(hipMemcpyAsync(d_edges.p, P.edges.data(), (size_t)ne * sizeof(hxk::PoaEdge), hipMemcpyHostToDevice, s));
             HIPCHK(hipMemcpyAsync(d_order.p, order_all.data(), order_all.size() * 4, hipMemcpyHostToDevice, s));
             hxk::PoaPools pools{B.code.p, B.n_aligned.p, B.aligned.p, B.in_head.p, B.in_tail.p, B.out_head.p, B.out_tail.p, B.rank2node.p, B.node2rank.p,
-                                B.mark.p, B.check.p, B.stack.p, B.score.p, B.pred.p, B.row_code.p, B.row_sink.p, B.row_pred_off.p, B.pred_rank.p, B.row_meta.p, B.row_pred0.p, B.row_pred1.p,
+                                B.mark.p, B.check.p, B.stack.p, B.score.p, B.pred.p, B.row_code.p, B.row_sink.p, B.row_pred_off.p, B.pred_rank.p, B.row_meta.p, B.row_pred0.p, B.row_pred1.p, B.nrec.p,
                                 B.e_from.p, B.e_to.p, B.e_next_in.p, B.e_next_out.p, B.e_w.p, B.aln_node.p, B.aln_pos.p, B.H.p, B.dir.p, B.seq.p};
             c->tick();
             HIPCHK(hipEventRecord(c->poa_ev[5], s));
@@ -579,10 +585,9 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
                 if (cls_list[k].empty()) continue;
                 const uint32_t nt = kClassNT[k];
                 const uint64_t row_bytes = (uint64_t)cls_cm[k] * nt * 4;
-                const uint64_t lds_budget = nt >= 1024 ? 128 * 1024 : nt == 64 ? 32 * 1024 : 64 * 1024;
+                const uint64_t lds_budget = nt >= 1024 ? 128 * 1024 : nt == 64 ? 32 * 1024 : 64 * 1024 * (nt / 128 > 2 ? 2 : 1);
                 uint32_t R = (uint32_t)std::min<uint64_t>(8, lds_budget / row_bytes);
-                R = R >= 8 ? 8 : R >= 4 ? 4 : R >= 2 ? 2 : 0;   // power of two (slot = rank & (R-1))
-                if (cls_cm[k] > 32) R = 0;
+                R = R >= 8 ? 8 : R >= 4 ? 4 : R >= 2 ? 2 : 0;   // power of two (slot = kept-row counter & (R-1))
                 // few edges: ask for enough LDS per workgroup that the dispatcher cannot stack them on a handful of CUs while others idle
                 // (a lone wave runs at twice the speed of two waves sharing a SIMD); many edges: request only what the ring needs
                 uint64_t lds_bytes = R * row_bytes;
@@ -592,7 +597,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
                 }
                 HIPCHK(hipStreamWaitEvent(c->poa_streams[k], c->poa_ev[5], 0));
                 hxk::poa_run(d_edges.p, d_order.p + opos, (uint32_t)cls_list[k].size(), d_seqs.p, c->packed.p, c->roff.p, c->rlen.p, pools, 0, pp->match, pp->mismatch,
-                             pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)nt, R, (uint32_t)lds_bytes, cls_cm[k] > (nt >= 1024 ? 8u : 16u), cls_dir[k], c->poa_streams[k]);
+                             pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)nt, R, (uint32_t)lds_bytes, nt >= 1024 && cls_cm[k] > 8u, cls_dir[k], c->poa_streams[k]);
                 HIPCHK(hipEventRecord(c->poa_ev[k], c->poa_streams[k]));
                 HIPCHK(hipStreamWaitEvent(s, c->poa_ev[k], 0));
                 opos += cls_list[k].size();
@@ -605,6 +610,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             std::vector<char> h_cns(co);
             if (co) HIPCHK(hipMemcpy(h_cns.data(), d_cns.p, co, hipMemcpyDeviceToHost));
             for (uint32_t e : batch) {
+                if (h_status[e] & ~(uint32_t)HXE_POA_OVERFLOW) return fail("hx_poa_batch: internal error (kernel variant / column count mismatch)");
                 if (h_status[e] & HXE_POA_OVERFLOW) {
                     if (worst_case) return fail("hx_poa_batch: POA workspace overflow at worst-case size (internal error)");
                     retry.push_back(e);

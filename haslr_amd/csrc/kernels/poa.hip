@@ -17,6 +17,8 @@
 //     the rank-ordered CSR that the DP reads (row code, predecessor ranks, sink flag) is rebuilt by all lanes.
 // Full (V+1)x(L+1) int32 score matrix in HBM, as in the reference's engine; banding and LDS-resident row rings
 // are the next optimisation steps (DESIGN.md "K6 roadmap").
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace hxk {
@@ -33,6 +35,7 @@ struct G {   // per-edge views into the pools
     int32_t *score, *pred;
     uint8_t *row_code, *row_sink; uint32_t *row_pred_off, *pred_rank;
     uint32_t *row_meta, *row_pred0, *row_pred1;   // per rank: code | sink<<2 | far<<3 | npred<<8 ; ranks of the first two predecessors
+    uint4* nrec;   // per node, one 16-byte record for the serial graph walks: {1st in-edge source, 2nd in-edge source, 3 aligned ids (+1) x 21 bit, bit 63: more in-edges}
     uint32_t *e_from, *e_to, *e_next_in, *e_next_out; int32_t* e_w;
     int32_t *aln_node, *aln_pos;
     uint32_t vcap, ecap;
@@ -42,6 +45,7 @@ __device__ __forceinline__ uint32_t add_node(G& g, uint32_t& V, uint8_t c) {
     uint32_t n = V++;
     g.code[n] = c; g.n_aligned[n] = 0;
     g.in_head[n] = g.in_tail[n] = g.out_head[n] = g.out_tail[n] = NONE;
+    g.nrec[n] = make_uint4(NONE, NONE, 0u, 0u);
     return n;
 }
 
@@ -53,8 +57,20 @@ __device__ void add_edge(G& g, uint32_t& E, uint32_t f, uint32_t t, int32_t w) {
     g.e_from[e] = f; g.e_to[e] = t; g.e_w[e] = w; g.e_next_in[e] = NONE; g.e_next_out[e] = NONE;
     if (g.out_tail[f] == NONE) g.out_head[f] = e; else g.e_next_out[g.out_tail[f]] = e;
     g.out_tail[f] = e;
-    if (g.in_tail[t] == NONE) g.in_head[t] = e; else g.e_next_in[g.in_tail[t]] = e;
+    uint32_t* r = reinterpret_cast<uint32_t*>(&g.nrec[t]);
+    if (g.in_tail[t] == NONE) { g.in_head[t] = e; r[0] = f; }
+    else { g.e_next_in[g.in_tail[t]] = e; if (r[1] == NONE) r[1] = f; else r[3] |= 0x80000000u; }   // third and later in-edges: walk the list
     g.in_tail[t] = e;
+}
+
+// append node `a` to node n's aligned list (array form + the packed copy in the node record)
+__device__ __forceinline__ void push_aligned(G& g, uint32_t n, uint32_t a) {
+    const uint32_t k = g.n_aligned[n]++;
+    g.aligned[3 * n + k] = a;
+    uint32_t* r = reinterpret_cast<uint32_t*>(&g.nrec[n]);
+    unsigned long long packed = (unsigned long long)r[2] | ((unsigned long long)r[3] << 32);
+    packed |= (unsigned long long)(a + 1) << (21 * k);   // ids are stored +1 so that 0 means "no entry"
+    r[2] = (uint32_t)packed; r[3] = (uint32_t)(packed >> 32);
 }
 
 // spoa Graph::add_sequence for seq[b,e): returns first node or NONE
@@ -100,6 +116,78 @@ __device__ void toposort(G& g, uint32_t V) {
     }
 }
 
+
+// Same traversal, executed by one whole wavefront in lock step (every lane computes the same scalars) so that the 63 lanes which
+// would idle beside lane 0 can fetch node records cooperatively: records are read through a direct-mapped LDS cache of 16-record
+// lines (one coalesced 256-byte load per miss; node ids are visited in nearly ascending runs, so most visits hit). The mark/check
+// bits of every node sit in one LDS byte (st[]), the top of the DFS stack in an LDS window that spills to the HBM stack.
+// Requires node ids < 2^21 - 1 (aligned ids are packed 3 x 21 bit).
+constexpr uint32_t TOPO_LCAP = 1024;     // stack window entries
+constexpr uint32_t TOPO_LINES = 64;      // cache lines of 16 records (16 KiB)
+__device__ void toposort_coop(G& g, const uint32_t V, uint8_t* st, uint32_t* lstack, uint4* cache, uint32_t* tags) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i = lane; i < TOPO_LINES; i += 64) tags[i] = NONE;
+    uint32_t sp = 0, nr = 0, base = 0;
+    auto push = [&](uint32_t v) {
+        if (sp - base == TOPO_LCAP) { if (lane == 0) g.stack[base] = lstack[base & (TOPO_LCAP - 1)]; base++; }
+        if (lane == 0) lstack[sp & (TOPO_LCAP - 1)] = v;
+        sp++;
+    };
+    auto record = [&](uint32_t n) -> uint4 {
+        const uint32_t line = n >> 4, slot = line & (TOPO_LINES - 1);
+        if (tags[slot] != line) {
+            if (lane < 16) { const uint32_t id = (line << 4) + lane; cache[slot * 16 + lane] = id < g.vcap ? g.nrec[id] : make_uint4(NONE, NONE, 0u, 0u); }
+            if (lane == 0) tags[slot] = line;
+        }
+        return cache[slot * 16 + (n & 15u)];
+    };
+    for (uint32_t i = 0; i < V; i++) {
+        if (st[i] & 3u) continue;
+        push(i);
+        while (sp) {
+            if (sp == base) { base--; if (lane == 0) lstack[base & (TOPO_LCAP - 1)] = g.stack[base]; }
+            const uint32_t n = lstack[(sp - 1) & (TOPO_LCAP - 1)];
+            bool valid = true;
+            const uint32_t sn = st[n];
+            if ((sn & 3u) != 2u) {
+                const uint4 rec = record(n);
+                if (rec.w & 0x80000000u) {   // three or more in-edges: the list
+                    for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) {
+                        const uint32_t f = g.e_from[e];
+                        if ((st[f] & 3u) != 2u) { push(f); valid = false; }
+                    }
+                } else {
+                    if (rec.x != NONE && (st[rec.x] & 3u) != 2u) { push(rec.x); valid = false; }
+                    if (rec.y != NONE && (st[rec.y] & 3u) != 2u) { push(rec.y); valid = false; }
+                }
+                const bool chk = sn & 4u;
+                const unsigned long long al = ((unsigned long long)rec.z | ((unsigned long long)rec.w << 32)) & 0x7fffffffffffffffULL;
+                if (chk) {
+                    for (uint32_t k = 0; k < 3; k++) {
+                        const uint32_t a1 = (uint32_t)(al >> (21 * k)) & 0x1fffffu;
+                        if (!a1) break;
+                        if ((st[a1 - 1] & 3u) != 2u) { push(a1 - 1); if (lane == 0) st[a1 - 1] &= (uint8_t)~4u; valid = false; }
+                    }
+                }
+                if (valid) {
+                    if (lane == 0) st[n] = (uint8_t)((sn & ~3u) | 2u);
+                    if (chk) {
+                        if (lane == 0) g.rank2node[nr] = n;
+                        nr++;
+                        for (uint32_t k = 0; k < 3; k++) {
+                            const uint32_t a1 = (uint32_t)(al >> (21 * k)) & 0x1fffffu;
+                            if (!a1) break;
+                            if (lane == 0) g.rank2node[nr] = a1 - 1;
+                            nr++;
+                        }
+                    }
+                } else if (lane == 0) st[n] = (uint8_t)((sn & ~3u) | 1u);
+            }
+            if (valid) sp--;
+        }
+    }
+}
+
 // spoa Graph::add_alignment with unit weights; alignment is stored REVERSED (index n_aln-1 is the first pair). lane 0 only.
 // returns false on workspace overflow
 __device__ bool add_alignment(G& g, uint32_t& V, uint32_t& E, uint32_t n_aln, const uint8_t* seq, uint32_t len) {
@@ -127,11 +215,11 @@ __device__ bool add_alignment(G& g, uint32_t& V, uint32_t& E, uint32_t n_aln, co
                 nn = add_node(g, V, c);
                 for (uint32_t q = 0; q < na; q++) {
                     uint32_t a = g.aligned[3 * an + q];
-                    g.aligned[3 * nn + g.n_aligned[nn]++] = a;
-                    g.aligned[3 * a + g.n_aligned[a]++] = nn;
+                    push_aligned(g, nn, a);
+                    push_aligned(g, a, nn);
                 }
-                g.aligned[3 * nn + g.n_aligned[nn]++] = (uint32_t)an;
-                g.aligned[3 * an + g.n_aligned[an]++] = nn;
+                push_aligned(g, nn, (uint32_t)an);
+                push_aligned(g, (uint32_t)an, nn);
             } else nn = hit;
         }
         if (head != NONE) add_edge(g, E, head, nn, 2);
@@ -243,74 +331,80 @@ template <int CM> __device__ __forceinline__ void store_chunk_u8(uint8_t* p, con
 }
 
 // ---------------------------------------------------------------------------------------------------
-// DP over (rank, column) for one sequence against the current graph.
-// Lane t owns the CM contiguous columns [t*CM, t*CM+CM) of every row and keeps them in registers.
-// The last R rows live in an LDS ring in a lane-transposed layout (column t*CM+k of a row sits at word
-// k*NT + t): a wave's access to "its k-th column" is 64 consecutive words, so ring reads and writes are
-// bank-conflict free for every CM, which a row-major ring read with stride CM is not. Predecessor rows
-// older than R ranks (rare: graph bubbles longer than the ring) and the traceback read the row-major int32
-// matrix in HBM, which every row is also written to (16-64 contiguous bytes per lane).
-// Horizontal recurrence H[j] = max(T[j], H[j-1]+g): serial inside a lane's chunk, then a wavefront
-// prefix-max scan (shuffles) + LDS exchange between waves over the chunk ends of T[k]-k*g, then the carry.
+// DP over (rank, column) for one sequence against the current graph — rows live in registers.
+//
+// Lane t owns the CM contiguous columns [t*CM, t*CM+CM) and keeps the CURRENT row there. The common predecessor of
+// row i is row i-1: the lane's own registers, plus the value left of its first column, which falls out of the
+// prefix scan that row i-1 needed anyway (exclusive scan + (j0-1)*gap). So the usual row costs no LDS row traffic
+// and exactly ONE cross-lane operation: the prefix-max scan of (chunk end - column*gap) that resolves the horizontal
+// recurrence H[j] = max(T[j], H[j-1]+g) — 64-lane DPP scan inside a wave, wave totals through LDS (double-buffered,
+// one LDS-only barrier per row) when the workgroup has several waves. A single-wave workgroup never synchronises.
+// Rows that a later row needs as a NON-adjacent predecessor are flagged by the CSR build ("kept") and copied to an LDS
+// ring in the order they are produced (lane-transposed layout: column t*CM+k at word k*NT+t, conflict-free), or to
+// HBM when the ring has wrapped; predecessor references carry that location (0 registers, 1..14 ring slot+1, 15 HBM).
+// Traceback information is one direction byte per cell written to HBM (what the reference's traceback would choose:
+// diagonal first, then vertical with the first predecessor in in-edge order, horizontal only if strictly better).
+// Columns beyond L are computed like real ones and never read by a real column, so the loop has no column predicates.
 // ---------------------------------------------------------------------------------------------------
 template <int CM, bool DIR>
 __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, const uint32_t W, const uint8_t* __restrict__ seq, const uint32_t L,
                         const uint32_t V, int32_t* ring, const uint32_t R, const uint32_t ring_w, const int match, const int mismatch, const int gap,
-                        int* lds_i, uint32_t* smeta, int& bestScoreOut, int& bestIOut) {
+                        int* lds_tot /* 2 x 16 */, uint32_t* smeta, int& bestScoreOut, int& bestIOut) {
     constexpr uint32_t MT = 256;   // metadata tile (rows)
-    const uint32_t tid = threadIdx.x, NT = blockDim.x;
+    const uint32_t tid = threadIdx.x, NT = blockDim.x, lane = tid & 63u, wv = tid >> 6;
+    const bool multi = NT > 64;
     const uint32_t ncol = L + 1;
     const uint32_t j0 = tid * CM;
-    const bool in_row = j0 < W;                                      // lane has columns inside the padded row (may store to HBM)
-    const bool owns_last = j0 <= L && L < j0 + CM;                   // lane holding column L
+    const bool in_row = j0 < W;
+    const bool owns_last = j0 <= L && L < j0 + CM;
     const uint32_t klast = owns_last ? L - j0 : 0;
-    // Columns beyond L ("pad" columns, in lanes at or right of the one holding column L) are computed like real ones and never
-    // read by a real column: dependencies only run left-to-right and down the same column. So the row loop has no per-column
-    // predicates. Column 0 needs no special case either: its diagonal source (left) and horizontal source (run) start at NEG.
-    // eq[c]: bit k set iff the sequence base under column j0+k is c
-    uint32_t eq[4] = {0, 0, 0, 0};
+    using mask_t = typename std::conditional<(CM <= 32), uint32_t, uint64_t>::type;
+    mask_t eq[4] = {0, 0, 0, 0};     // bit k of eq[c] = the base under column j0+k is c
 #pragma unroll
     for (int k = 0; k < CM; k++) {
         const uint32_t j = j0 + k;
         const uint32_t b = (j >= 1 && j < ncol) ? seq[j - 1] : 0xffu;
 #pragma unroll
-        for (int c = 0; c < 4; c++) eq[c] |= (b == (uint32_t)c ? 1u : 0u) << k;
+        for (int c = 0; c < 4; c++) eq[c] |= (mask_t)(b == (uint32_t)c ? 1u : 0u) << k;
     }
     const int dsc = match - mismatch;
     const int jg0 = (int)j0 * gap;
-    {   // row 0 (always kept in HBM: it is the virtual predecessor of every source node)
-        int r0[CM];
+    int t[CM];                                          // row i-1, then row i
 #pragma unroll
-        for (int k = 0; k < CM; k++) { r0[k] = jg0 + k * gap; if (R) ring[k * NT + tid] = r0[k]; }
-        if (in_row) store_chunk_i32<CM>(H + j0, r0);
-    }
+    for (int k = 0; k < CM; k++) t[k] = jg0 + k * gap;  // row 0
+    int left_prev = tid > 0 ? jg0 - gap : NEG;          // H[i-1][j0-1]
+    if (in_row) store_chunk_i32<CM>(H + j0, t);         // row 0 stays in HBM: virtual predecessor of every source node
+    uint32_t nkept = 0;                                 // kept rows produced so far (ring slot counter; mirrors the CSR build)
     int bestScore = INT32_MIN + 1024, bestI = -1;
-    __syncthreads();
+    if (multi) __syncthreads();
     for (uint32_t i = 1; i <= V; i++) {
-        // row metadata comes through LDS in tiles of MT rows (one coalesced cooperative load per tile): a per-row global load with a
-        // uniform address would put a full L2 round trip on the critical path of every row
         const uint32_t ti = (i - 1) & (MT - 1);
-        if (ti == 0) {
-            __syncthreads();   // previous tile fully consumed
+        if (ti == 0) {   // metadata tile through LDS (a per-row uniform global load would put an L2 round trip on every row)
+            if (multi) __syncthreads();
             for (uint32_t q = tid; q < MT && i - 1 + q < V; q += NT) {
                 smeta[0 * MT + q] = g.row_meta[i - 1 + q]; smeta[1 * MT + q] = g.row_pred0[i - 1 + q];
                 smeta[2 * MT + q] = g.row_pred1[i - 1 + q]; smeta[3 * MT + q] = g.row_pred_off[i - 1 + q];
             }
-            __syncthreads();
+            if (multi) __syncthreads();
         }
         const uint32_t meta = smeta[ti], p0 = smeta[MT + ti], p1 = smeta[2 * MT + ti], po = smeta[3 * MT + ti];
         const uint32_t rc = meta & 3u, npred = meta >> 8;
-        const uint32_t mask = rc == 0 ? eq[0] : rc == 1 ? eq[1] : rc == 2 ? eq[2] : eq[3];
-        int t[CM];            // diagonal/vertical maximum, then the finished row values
-        uint32_t dcode[CM];   // what the reference's traceback picks at the cell: (slot<<2)|0 diagonal, (slot<<2)|1 vertical, 2 horizontal
-        auto load_pred = [&](uint32_t pr, int (&hp)[CM], int& left) {
-            if (R && i - pr < R) {
-                const int32_t* S = ring + (size_t)(pr & (R - 1)) * ring_w;
+        const mask_t mask = rc == 0 ? eq[0] : rc == 1 ? eq[1] : rc == 2 ? eq[2] : eq[3];
+        int nt[CM];
+        uint32_t dcode[CM];
+        auto load_pred = [&](uint32_t ent, int (&hp)[CM], int& left) {
+            const uint32_t loc = ent >> 28;
+            if (loc == 0) {                 // previous row: registers
+#pragma unroll
+                for (int k = 0; k < CM; k++) hp[k] = t[k];
+                left = left_prev;
+            } else if (loc != 15) {         // kept row in the LDS ring
+                const int32_t* S = ring + (size_t)(loc - 1) * ring_w;
 #pragma unroll
                 for (int k = 0; k < CM; k++) hp[k] = S[k * NT + tid];
                 left = tid > 0 ? S[(CM - 1) * NT + tid - 1] : NEG;
-            } else if (in_row) {
-                const int32_t* Gp = H + (uint64_t)pr * W + j0;
+            } else if (in_row) {            // kept row that fell out of the ring: HBM (spill stores were drained before the barrier that followed them)
+                const int32_t* Gp = H + (uint64_t)((ent & 0x0fffffffu) + 1) * W + j0;
                 load_chunk_i32<CM>(Gp, hp);
                 left = j0 > 0 ? Gp[-1] : NEG;
             } else {
@@ -319,14 +413,29 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
                 left = NEG;
             }
         };
-        if (npred <= 1) {   // the common case: one predecessor (or the virtual row 0 for a source node): no arg-max bookkeeping
+        auto load_row0 = [&](int (&hp)[CM], int& left) {   // virtual predecessor of a source node
+            if (i == 1) {
+#pragma unroll
+                for (int k = 0; k < CM; k++) hp[k] = t[k];
+                left = left_prev;
+            } else if (in_row) {
+                if (!multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                load_chunk_i32<CM>(H + j0, hp);
+                left = j0 > 0 ? H[j0 - 1] : NEG;
+            } else {
+#pragma unroll
+                for (int k = 0; k < CM; k++) hp[k] = NEG;
+                left = NEG;
+            }
+        };
+        if (npred <= 1) {   // one predecessor (or the virtual row 0): no arg-max bookkeeping
             int hp[CM], left;
-            load_pred(npred == 0 ? 0u : p0 + 1, hp, left);
+            if (npred == 0) load_row0(hp, left); else load_pred(p0, hp, left);
 #pragma unroll
             for (int k = 0; k < CM; k++) {
                 const int dg = (k == 0 ? left : hp[k - 1]) + mismatch + (dsc & -(int)((mask >> k) & 1u));
                 const int up = hp[k] + gap;
-                t[k] = max(dg, up);
+                nt[k] = max(dg, up);
                 dcode[k] = dg >= up ? 0u : 1u;     // diagonal is tried first
             }
         } else {
@@ -336,7 +445,7 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
             for (int k = 0; k < CM; k++) { bd[k] = NEG; bv[k] = NEG; pp[k] = 0; }
             for (uint32_t p = 0; p < npred; p++) {
                 int hp[CM], left;
-                load_pred((p == 0 ? p0 : p == 1 ? p1 : g.pred_rank[po + p]) + 1, hp, left);
+                load_pred(p == 0 ? p0 : p == 1 ? p1 : g.pred_rank[po + p], hp, left);
 #pragma unroll
                 for (int k = 0; k < CM; k++) {
                     const int dg = (k == 0 ? left : hp[k - 1]) + mismatch + (dsc & -(int)((mask >> k) & 1u));
@@ -347,7 +456,7 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
             }
 #pragma unroll
             for (int k = 0; k < CM; k++) {
-                t[k] = max(bd[k], bv[k]);
+                nt[k] = max(bd[k], bv[k]);
                 dcode[k] = bd[k] >= bv[k] ? ((pp[k] & 0xffu) << 2) : (((pp[k] >> 8) << 2) | 1u);
             }
         }
@@ -356,23 +465,46 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
 #pragma unroll
         for (int k = 0; k < CM; k++) {
             const int hz = run + gap;
-            if (hz > t[k]) { t[k] = hz; dcode[k] = 2u; }
-            run = t[k];
+            if (hz > nt[k]) { nt[k] = hz; dcode[k] = 2u; }
+            run = nt[k];
         }
-        // carry from the lanes to the left: prefix maximum of (chunk end value - its column * gap)
-        const int ex = block_excl_scan_max(run - (jg0 + (CM - 1) * gap), lds_i);
+        // prefix maximum over the lanes to the left of (chunk end value - its column * gap)
+        const int inc = wave_scan_max(run - (jg0 + (CM - 1) * gap));
+        int ex = wave_shift_up1(inc, NEG);
+        if (multi) {
+            int* tot = lds_tot + (i & 1u) * 16;
+            if (lane == 63) tot[wv] = inc;
+            // One barrier per row. A spilled row is read back by other waves only 2+ rows later, but its stores must have left this
+            // wave before the barrier that the readers also pass: rows that spill drain vmcnt first, all others wait for LDS only.
+            if (meta & 8u) __syncthreads(); else barrier_lds_only();
+            const int nw = NT >> 6;
+            const int w16 = (int)(lane & 15u);
+            int x0 = w16 < nw ? tot[w16] : NEG, x = x0;
+            x = max(x, __builtin_amdgcn_update_dpp(NEG, x0, 0x111, 0xf, 0xf, false));
+            x = max(x, __builtin_amdgcn_update_dpp(NEG, x0, 0x112, 0xf, 0xf, false));
+            x = max(x, __builtin_amdgcn_update_dpp(NEG, x0, 0x113, 0xf, 0xf, false));
+            x = max(x, __builtin_amdgcn_update_dpp(NEG, x, 0x114, 0xf, 0xe, false));
+            x = max(x, __builtin_amdgcn_update_dpp(NEG, x, 0x118, 0xf, 0xc, false));
+            if (wv > 0) ex = max(ex, __builtin_amdgcn_readlane(x, wv - 1));
+        }
         if (ex > NEG / 2) {
             const int base = ex + jg0;
 #pragma unroll
-            for (int k = 0; k < CM; k++) { const int via = base + k * gap; if (via > t[k]) { t[k] = via; dcode[k] = 2u; } }
-        }
-        if (R) {
-            int32_t* S = ring + (size_t)(i & (R - 1)) * ring_w;
+            for (int k = 0; k < CM; k++) { const int via = base + k * gap; if (via > nt[k]) { nt[k] = via; dcode[k] = 2u; } }
+            left_prev = base - gap;     // H[i][j0-1]: the exclusive prefix already is the finished value left of this chunk
+        } else left_prev = NEG;
 #pragma unroll
-            for (int k = 0; k < CM; k++) S[k * NT + tid] = t[k];
+        for (int k = 0; k < CM; k++) t[k] = nt[k];
+        if (meta & 16u) {   // kept row: a later row reads it as a non-adjacent predecessor
+            if (R) {
+                int32_t* S = ring + (size_t)(nkept & (R - 1)) * ring_w;
+#pragma unroll
+                for (int k = 0; k < CM; k++) S[k * NT + tid] = t[k];
+            }
+            nkept++;
         }
         if (in_row) {
-            if (!DIR || !R || (meta & 8u)) store_chunk_i32<CM>(H + (uint64_t)i * W + j0, t);   // H row to HBM only if the traceback or a far successor needs it
+            if (!DIR || (meta & 8u)) store_chunk_i32<CM>(H + (uint64_t)i * W + j0, t);   // score row to HBM only if the traceback or a far successor needs it
             if (DIR) store_chunk_u8<CM>(D + (uint64_t)i * W + j0, dcode);
         }
         if (owns_last && (meta & 4u)) {   // sink node: candidate end of the global alignment (first maximum in rank order)
@@ -381,177 +513,16 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
             for (int k = 0; k < CM; k++) if ((uint32_t)k == klast) v = t[k];
             if (bestScore < v) { bestScore = v; bestI = (int)i; }
         }
-        // row i is complete in the ring after an LDS-only barrier; rows spilled to HBM are only read R or more rows later, so a full
-        // (vmcnt) synchronisation every R-1 rows is enough to order those stores before their readers. Without a ring every row is read from HBM.
-        if (!R || (i % (R - 1)) == 0) __syncthreads(); else barrier_lds_only();
     }
     if (owns_last) { bestScoreOut = bestScore; bestIOut = bestI; }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Single-wavefront DP: one 64-lane wave owns an edge, lane t keeps columns [t*CM, t*CM+CM) of the CURRENT row
-// in registers. The common predecessor of row i is row i-1, i.e. the lane's own registers plus one DPP
-// wave_shr for the left neighbour's last column: no LDS, no barrier, no HBM read on the critical path.
-// Rows that a later row needs as a non-adjacent predecessor are flagged by the CSR build and copied to
-// the LDS ring (distance < R) or to HBM (distance >= R). The horizontal recurrence is a lane-serial pass
-// plus one 64-lane DPP prefix-max scan. Many such waves (different edges) share a CU and hide each
-// other's latencies, which a 16-wave workgroup synchronising twice per row cannot.
-// ---------------------------------------------------------------------------------------------------
-template <int CM, bool DIR>
-__device__ void dp_rows_wave(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, const uint32_t W, const uint8_t* __restrict__ seq,
-                             const uint32_t L, const uint32_t V, int32_t* ring, const uint32_t R, const uint32_t ring_w, const int match,
-                             const int mismatch, const int gap, uint32_t* smeta, int& bestScoreOut, int& bestIOut) {
-    constexpr uint32_t MT = 256;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t ncol = L + 1;
-    const uint32_t j0 = lane * CM;
-    const bool in_row = j0 < W;
-    const bool owns_last = j0 <= L && L < j0 + CM;
-    const uint32_t klast = owns_last ? L - j0 : 0;
-    uint32_t eq[4] = {0, 0, 0, 0};   // CM <= 32: one bit per column
-#pragma unroll
-    for (int k = 0; k < CM; k++) {
-        const uint32_t j = j0 + k;
-        const uint32_t b = (j >= 1 && j < ncol) ? seq[j - 1] : 0xffu;
-#pragma unroll
-        for (int c = 0; c < 4; c++) eq[c] |= (b == (uint32_t)c ? 1u : 0u) << k;
-    }
-    uint32_t nkept = 0;   // kept rows produced so far (ring slot counter; mirrors the CSR build's numbering)
-    const int dsc = match - mismatch;
-    const int jg0 = (int)j0 * gap;
-    int t[CM];   // the previous row, then the current one
-#pragma unroll
-    for (int k = 0; k < CM; k++) { t[k] = jg0 + k * gap; if (R) ring[k * 64 + lane] = t[k]; }
-    if (in_row) store_chunk_i32<CM>(H + j0, t);   // row 0 stays in HBM: virtual predecessor of every source node
-    int bestScore = INT32_MIN + 1024, bestI = -1;
-    for (uint32_t i = 1; i <= V; i++) {
-        const uint32_t ti = (i - 1) & (MT - 1);
-        if (ti == 0) {   // metadata tile; LDS operations of one wave execute in order, so no barrier is needed
-            for (uint32_t q = lane; q < MT && i - 1 + q < V; q += 64) {
-                smeta[0 * MT + q] = g.row_meta[i - 1 + q]; smeta[1 * MT + q] = g.row_pred0[i - 1 + q];
-                smeta[2 * MT + q] = g.row_pred1[i - 1 + q]; smeta[3 * MT + q] = g.row_pred_off[i - 1 + q];
-            }
-            if (i > 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // orders earlier HBM row spills before later reads (once per tile)
-        }
-        const uint32_t meta = smeta[ti], p0 = smeta[MT + ti], p1 = smeta[2 * MT + ti], po = smeta[3 * MT + ti];
-        const uint32_t rc = meta & 3u, npred = meta >> 8;
-        const uint32_t mask = rc == 0 ? eq[0] : rc == 1 ? eq[1] : rc == 2 ? eq[2] : eq[3];
-        int nt[CM];
-        uint32_t dcode[CM];
-        // predecessor reference = rank | location << 28 (location: 0 registers = previous row, 1..14 ring slot + 1, 15 HBM)
-        auto load_pred = [&](uint32_t ent, int (&hp)[CM], int& left) {
-            const uint32_t loc = ent >> 28;
-            if (loc == 0) {
-#pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] = t[k];
-                left = wave_shift_up1(t[CM - 1], NEG);
-            } else if (loc != 15) {
-                const int32_t* S = ring + (size_t)(loc - 1) * ring_w;
-#pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] = S[k * 64 + lane];
-                left = lane > 0 ? S[(CM - 1) * 64 + lane - 1] : NEG;
-            } else if (in_row) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's earlier row spills have reached memory before it reads one back
-                const int32_t* Gp = H + (uint64_t)((ent & 0x0fffffffu) + 1) * W + j0;
-                load_chunk_i32<CM>(Gp, hp);
-                left = j0 > 0 ? Gp[-1] : NEG;
-            } else {
-#pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] = NEG;
-                left = NEG;
-            }
-        };
-        auto load_row0 = [&](int (&hp)[CM], int& left) {   // virtual predecessor of a source node (always in HBM)
-            if (i == 1) {
-#pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] = t[k];
-                left = wave_shift_up1(t[CM - 1], NEG);
-            } else if (in_row) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                load_chunk_i32<CM>(H + j0, hp);
-                left = j0 > 0 ? H[j0 - 1] : NEG;
-            } else {
-#pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] = NEG;
-                left = NEG;
-            }
-        };
-        if (npred <= 1) {
-            int hp[CM], left;
-            if (npred == 0) load_row0(hp, left); else load_pred(p0, hp, left);
-#pragma unroll
-            for (int k = 0; k < CM; k++) {
-                const int dg = (k == 0 ? left : hp[k - 1]) + mismatch + (dsc & -(int)((mask >> k) & 1u));
-                const int up = hp[k] + gap;
-                nt[k] = max(dg, up);
-                dcode[k] = dg >= up ? 0u : 1u;
-            }
-        } else {
-            int bd[CM], bv[CM];
-            uint32_t pp[CM];
-#pragma unroll
-            for (int k = 0; k < CM; k++) { bd[k] = NEG; bv[k] = NEG; pp[k] = 0; }
-            for (uint32_t p = 0; p < npred; p++) {
-                int hp[CM], left;
-                load_pred(p == 0 ? p0 : p == 1 ? p1 : g.pred_rank[po + p], hp, left);
-#pragma unroll
-                for (int k = 0; k < CM; k++) {
-                    const int dg = (k == 0 ? left : hp[k - 1]) + mismatch + (dsc & -(int)((mask >> k) & 1u));
-                    const int up = hp[k] + gap;
-                    if (dg > bd[k]) { bd[k] = dg; pp[k] = (pp[k] & 0xff00u) | p; }
-                    if (up > bv[k]) { bv[k] = up; pp[k] = (pp[k] & 0x00ffu) | (p << 8); }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < CM; k++) {
-                nt[k] = max(bd[k], bv[k]);
-                dcode[k] = bd[k] >= bv[k] ? ((pp[k] & 0xffu) << 2) : (((pp[k] >> 8) << 2) | 1u);
-            }
-        }
-        int run = NEG;
-#pragma unroll
-        for (int k = 0; k < CM; k++) {
-            const int hz = run + gap;
-            if (hz > nt[k]) { nt[k] = hz; dcode[k] = 2u; }
-            run = nt[k];
-        }
-        const int inc = wave_scan_max(run - (jg0 + (CM - 1) * gap));
-        const int ex = wave_shift_up1(inc, NEG);
-        if (ex > NEG / 2) {
-            const int base = ex + jg0;
-#pragma unroll
-            for (int k = 0; k < CM; k++) { const int via = base + k * gap; if (via > nt[k]) { nt[k] = via; dcode[k] = 2u; } }
-        }
-#pragma unroll
-        for (int k = 0; k < CM; k++) t[k] = nt[k];
-        if (meta & 16u) {   // kept row: a later row reads it as a non-adjacent predecessor
-            if (R) {
-                int32_t* S = ring + (size_t)(nkept & (R - 1)) * ring_w;
-#pragma unroll
-                for (int k = 0; k < CM; k++) S[k * 64 + lane] = t[k];
-            }
-            nkept++;
-        }
-        if (in_row) {
-            if (!DIR || (meta & 8u)) store_chunk_i32<CM>(H + (uint64_t)i * W + j0, t);
-            if (DIR) store_chunk_u8<CM>(D + (uint64_t)i * W + j0, dcode);
-        }
-        if (owns_last && (meta & 4u)) {
-            int v = NEG;
-#pragma unroll
-            for (int k = 0; k < CM; k++) if ((uint32_t)k == klast) v = t[k];
-            if (bestScore < v) { bestScore = v; bestI = (int)i; }
-        }
-    }
-    if (owns_last) { bestScoreOut = bestScore; bestIOut = bestI; }
-}
-
-template <int MAXNT, int CMMAX, bool DIR, bool WAVE>
+template <int MAXNT, int CMMAX, bool DIR>
 __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges, const uint32_t* __restrict__ order, uint32_t n_edges,
                                             const PoaSeq* __restrict__ seqs, const uint8_t* __restrict__ packed, const uint64_t* __restrict__ read_off,
                                             const uint32_t* __restrict__ read_len, PoaPools P, int32_t match, int32_t mismatch, int32_t gap,
                                             char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells, unsigned long long* phase,
-                                            uint32_t ring_rows) {
+                                            uint32_t ring_rows, uint32_t lds_bytes) {
     const uint32_t eidx = order[blockIdx.x];
     __shared__ unsigned long long ph[6];             // lane-0 cycle counts: decode, dp, traceback, graph update, toposort, csr
     __shared__ long long tc;
@@ -568,7 +539,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         g.rank2node = P.rank2node + no; g.node2rank = P.node2rank + no; g.mark = P.mark + no; g.check = P.check + no;
         g.stack = P.stack + ED.stack_off; g.score = P.score + no; g.pred = P.pred + no;
         g.row_code = P.row_code + no; g.row_sink = P.row_sink + no; g.row_pred_off = P.row_pred_off + no; g.pred_rank = P.pred_rank + eo;
-        g.row_meta = P.row_meta + no; g.row_pred0 = P.row_pred0 + no; g.row_pred1 = P.row_pred1 + no;
+        g.row_meta = P.row_meta + no; g.row_pred0 = P.row_pred0 + no; g.row_pred1 = P.row_pred1 + no; g.nrec = P.nrec + no;
         g.e_from = P.e_from + eo; g.e_to = P.e_to + eo; g.e_next_in = P.e_next_in + eo; g.e_next_out = P.e_next_out + eo; g.e_w = P.e_w + eo;
         g.aln_node = P.aln_node + ED.aln_off; g.aln_pos = P.aln_pos + ED.aln_off;
         g.vcap = ED.vcap; g.ecap = ED.ecap;
@@ -577,13 +548,13 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     uint8_t* Dm = DIR ? P.dir + ED.h_off : nullptr;   // direction bytes share the score matrix' geometry
     // ring geometry is a property of the edge (its longest sequence) and of the launch
     const uint32_t cme = (ED.lmax + 1 + NT - 1) / NT;
-    const uint32_t cmr = WAVE ? (cme <= 4 ? 4 : cme <= 8 ? 8 : cme <= 16 ? 16 : 32) : (cme <= 1 ? 1 : cme <= 2 ? 2 : cme <= 4 ? 4 : cme <= 8 ? 8 : cme <= 16 ? 16 : cme <= 32 ? 32 : 64);
+    const uint32_t cmr = cme <= 4 ? 4 : cme <= 8 ? 8 : cme <= 16 ? 16 : cme <= 32 ? 32 : 64;
     const uint32_t ring_w = cmr * NT;
-    const uint32_t R = ring_rows >= 2 && cmr <= 32 ? ring_rows : 0;
+    const uint32_t R = ring_rows >= 2 ? ring_rows : 0;
     uint8_t* seq = P.seq + ED.seq_off;
     const uint32_t W = (ED.lmax + 1 + 15) & ~15u;   // row stride, padded so that every lane chunk is vector-aligned
 
-    __shared__ int lds_i[17];
+    __shared__ int lds_i[32];
     __shared__ uint32_t smeta[4 * 256];
     __shared__ uint32_t lds_u[16];
     __shared__ uint32_t sV, sE, sNaln, sOk;
@@ -613,18 +584,9 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                 const uint32_t cm = (L + 1 + NT - 1) / NT;     // columns per lane for this sequence
                 int bs = 0, bi = -1;
 #define HX_DP(CMV) dp_rows<CMV, DIR>(g, H, Dm, W, seq, L, V, ring, R, ring_w, match, mismatch, gap, lds_i, smeta, bs, bi)
-                if constexpr (WAVE) {          // one wavefront per edge: whole row in the wave's registers (CMMAX columns per lane at most)
-#define HX_DPW(CMV) dp_rows_wave<CMV, DIR>(g, H, Dm, W, seq, L, V, ring, R, ring_w, match, mismatch, gap, smeta, bs, bi)
-                    const uint32_t cw = (L + 1 + 63) / 64;
-                    if (cw <= 4) HX_DPW(4); else if (cw <= 8) HX_DPW(8); else if (cw <= 16) HX_DPW(16); else HX_DPW(32);
-#undef HX_DPW
-                } else if constexpr (CMMAX == 8) {    // 1024-lane workgroups: 128 VGPRs per lane, chunks of at most 8 columns stay in registers
-                    if (cm <= 1) HX_DP(1); else if (cm <= 2) HX_DP(2); else if (cm <= 4) HX_DP(4); else HX_DP(8);
-                } else if constexpr (CMMAX == 16) {   // <= 512 lanes: chunks of at most 16 columns
-                    if (cm <= 1) HX_DP(1); else if (cm <= 2) HX_DP(2); else if (cm <= 4) HX_DP(4); else if (cm <= 8) HX_DP(8); else HX_DP(16);
-                } else {                        // gaps longer than 16 x 1024 columns: rare, separate kernel so its registers do not tax the common one
-                    if (cm <= 16) HX_DP(16); else if (cm <= 32) HX_DP(32); else HX_DP(64);
-                }
+                if (cm <= 4) HX_DP(4); else if (cm <= 8) HX_DP(8); else if (cm <= 16) HX_DP(16);
+                else if (cm <= 32) { if constexpr (CMMAX >= 32) HX_DP(32); else sOk = 2; }   // the host never asks a 16-column kernel for more
+                else { if constexpr (CMMAX >= 64) HX_DP(64); else sOk = 2; }
 #undef HX_DP
                 if (bi >= 0) { sBestScore = bs; sBestI = bi; }
             }
@@ -684,19 +646,31 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         __syncthreads();
         PHASE(2);
         // =================================================== graph update + topological sort
-        {
-            uint32_t Vn = sV;   // marks are cleared for the node count AFTER the update; clear generously up to V+L
-            uint32_t lim = min(Vn + L, g.vcap);
-            for (uint32_t i = tid; i < lim; i += NT) { g.mark[i] = 0; g.check[i] = 1; }
-        }
+        // the ring's LDS is idle between DPs: it holds the toposort state (1 byte per node), the top of the DFS stack and a record cache
+        const uint32_t topo_lim = min(sV + L, g.vcap);
+        const uint32_t topo_fixed = TOPO_LCAP * 4 + TOPO_LINES * 256 + TOPO_LINES * 4;
+        const bool topo_lds = (uint64_t)topo_lim + topo_fixed + 16 <= lds_bytes && g.vcap < (1u << 21) - 1;
+        uint32_t* t_stack = reinterpret_cast<uint32_t*>(ring);
+        uint4* t_cache = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(ring) + TOPO_LCAP * 4);
+        uint32_t* t_tags = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ring) + TOPO_LCAP * 4 + TOPO_LINES * 256);
+        uint8_t* st_lds = reinterpret_cast<uint8_t*>(ring) + topo_fixed;
+        if (topo_lds) { for (uint32_t i = tid; i < topo_lim; i += NT) st_lds[i] = 4u; }              // mark 0, check 1
+        else { for (uint32_t i = tid; i < topo_lim; i += NT) { g.mark[i] = 0; g.check[i] = 1; } }
         __syncthreads();
         if (tid == 0) {
             uint32_t V2 = sV, E2 = sE;
             if (!add_alignment(g, V2, E2, sNaln, seq, L)) sOk = 0;
-            else { PHASE(3); toposort(g, V2); sV = V2; sE = E2; PHASE(4); }
+            else { sV = V2; sE = E2; }
+            PHASE(3);
         }
         __syncthreads();
-        if (!sOk) break;
+        if (sOk == 1) {
+            if (topo_lds) { if (tid < 64) toposort_coop(g, sV, st_lds, t_stack, t_cache, t_tags); }   // wave 0, all 64 lanes in lock step
+            else if (tid == 0) toposort(g, sV);
+        }
+        PHASE(4);
+        __syncthreads();
+        if (sOk != 1) break;
         // =================================================== rank-order CSR for the next DP (all lanes)
         {
             const uint32_t V2 = sV;
@@ -729,7 +703,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
             }
             if (tid == NT - 1) g.row_pred_off[V2] = tot;
             __syncthreads();
-            if constexpr (WAVE) {
+            {
                 // Wave kernel: a row lives in the owning lanes' registers for exactly one more row. Rows with a NON-adjacent successor
                 // are "kept": they get ring slots in the order they are produced (slot = #kept rows before it, mod R), and every
                 // predecessor reference is tagged with where the DP will find the row: 0 registers, 1..14 ring slot + 1, 15 HBM.
@@ -758,21 +732,14 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                         if (q == 0) g.row_pred0[r] = ent; else if (q == 1) g.row_pred1[r] = ent;
                     }
                 }
-            } else {
-                // a row whose successor sits R or more ranks later cannot be served from the rank-indexed LDS ring: flag it so the DP spills it to HBM
-                for (uint32_t r = r0; r < r1; r++) {
-                    for (uint32_t q = g.row_pred_off[r], qe = q + (g.row_meta[r] >> 8); q < qe; q++) {
-                        const uint32_t pr = g.pred_rank[q];
-                        if (!R || r - pr >= R) atomicOr(&g.row_meta[pr], 8u);
-                    }
-                }
             }
         }
         __syncthreads();
         PHASE(5);
     }
     if (tid == 0) {
-        if (!sOk) { status[eidx] = HXE_POA_OVERFLOW; cns_len[eidx] = 0; }
+        if (sOk == 2) { status[eidx] = HXE_SPOS_RANGE << 8; cns_len[eidx] = 0; }   // internal: kernel variant cannot hold this many columns per lane
+        else if (!sOk) { status[eidx] = HXE_POA_OVERFLOW; cns_len[eidx] = 0; }
         else { status[eidx] = 0; cns_len[eidx] = sV ? consensus(g, sV, cns + ED.cns_off) : 0; }
         PHASE(3);
         if (phase) for (int k = 0; k < 6; k++) phase[(uint64_t)eidx * 6 + k] = ph[k];
@@ -787,13 +754,12 @@ void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_edges, cons
              bool use_dir, hipStream_t s) {
     if (!n_edges) return;
 #define HX_LAUNCH(MNT, CMX, DIRV) do { \
-        (void)hipFuncSetAttribute((const void*)k_poa<MNT, CMX, DIRV, (MNT == 64)>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
-        k_poa<MNT, CMX, DIRV, (MNT == 64)><<<n_edges, block_threads, ring_bytes, s>>>(edges, order, n_edges, seqs, packed, read_off, read_len, pools, match, mismatch, gap, \
-                                                                       cns, cns_len, status, cells, phase, ring_rows); } while (0)
-    // one binary per (lane-count class, direction bytes): the register budget of a 256-lane workgroup is not taxed by the 1024-lane bound
-    if (block_threads == 64) { if (use_dir) HX_LAUNCH(64, 32, true); else HX_LAUNCH(64, 32, false); }
-    else if (big) { if (use_dir) HX_LAUNCH(1024, 64, true); else HX_LAUNCH(1024, 64, false); }
-    else if (block_threads <= 256) { if (use_dir) HX_LAUNCH(256, 16, true); else HX_LAUNCH(256, 16, false); }
+        (void)hipFuncSetAttribute((const void*)k_poa<MNT, CMX, DIRV>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+        k_poa<MNT, CMX, DIRV><<<n_edges, block_threads, ring_bytes, s>>>(edges, order, n_edges, seqs, packed, read_off, read_len, pools, match, mismatch, gap, \
+                                                                       cns, cns_len, status, cells, phase, ring_rows, ring_bytes); } while (0)
+    // one binary per register budget: <= 256 lanes may use 32-column chunks (256+ VGPRs per lane), 512/1024-lane workgroups 16 / 8
+    if (big) { if (use_dir) HX_LAUNCH(1024, 64, true); else HX_LAUNCH(1024, 64, false); }   // gaps of 8192..65535 bases: slow path (register spills), rare
+    else if (block_threads <= 256) { if (use_dir) HX_LAUNCH(256, 32, true); else HX_LAUNCH(256, 32, false); }
     else if (block_threads <= 512) { if (use_dir) HX_LAUNCH(512, 16, true); else HX_LAUNCH(512, 16, false); }
     else { if (use_dir) HX_LAUNCH(1024, 8, true); else HX_LAUNCH(1024, 8, false); }
 #undef HX_LAUNCH
