@@ -4,6 +4,13 @@ import sys
 
 import pytest
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+try:   # torch bundles its own HIP runtime: let it initialise first so that libhaslr_hip.so binds to the same one
+    import torch
+    torch.cuda.is_available()
+except Exception:   # noqa: BLE001
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -180,7 +180,9 @@ def test_error_free_reads_reassemble_genome_on_gpu(sim, ctx, tmp_path):
 def test_full_size_properties(sim, ctx, tmp_path):
     """BASELINE configs[1] size (4.6 Mb, 25x): too big for the oracle in a test, so check invariants:
     twin symmetry of the edge multiset, sortedness, idempotence of a second run, identity vs truth."""
-    pre = sim("--genome-len", "4600000", "--seed", hex(0x4841534C + 1), "--variant-per-mb", "1.5")
+    # no planted variant molecules here: their novel segments are not part of genome.fa, so identity vs truth would measure the planted
+    # haplotype differences rather than consensus quality (the bench data set keeps them; its parity is covered by the smaller cases)
+    pre = sim("--genome-len", "4600000", "--seed", hex(0x4841534C + 1), "--no-variants")
     ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
     ctx.upload(ds)
     prm = ds.params()

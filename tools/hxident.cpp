@@ -32,13 +32,13 @@ static long banded_ed(const std::string& q, const std::string& t, long B) {
     const long n = q.size(), m = t.size(), INF = 1L << 40;
     std::vector<long> prev(2 * B + 1, INF), cur(2 * B + 1, INF);
     // cell (i, j) with j in [i - B, i + B] stored at j - i + B
-    for (long k = 0; k <= 2 * B; k++) { long j = k - B; if (j >= 0 && j <= m) prev[k] = j; }
+    for (long k = 0; k <= 2 * B; k++) { long j = k - B; if (j >= 0 && j <= m) prev[k] = 0; }   // free start in the target window (semi-global)
     for (long i = 1; i <= n; i++) {
         for (long k = 0; k <= 2 * B; k++) {
             long j = i + k - B;
             long best = INF;
             if (j >= 0 && j <= m) {
-                if (j == 0) best = i;
+                if (j == 0) best = i;   // query prefix unaligned
                 else {
                     if (prev[k] < INF) best = std::min(best, prev[k] + (q[i - 1] != t[j - 1]));          // diag: (i-1, j-1) -> same k
                     if (k + 1 <= 2 * B && prev[k + 1] < INF) best = std::min(best, prev[k + 1] + 1);     // up: (i-1, j)
@@ -82,17 +82,26 @@ int main(int argc, char** argv) {
         for (long w0 = 0; w0 < (long)q.size(); w0 += WIN) {
             long wl = std::min<long>(WIN, (long)q.size() - w0);
             std::string win = q.substr(w0, wl);
-            long off = -1;
-            for (long i = 0; i + K <= wl && i < 4000; i++) {
+            // offset by majority vote of seeds spread over the window (a single seed may sit in a repeat copy or straddle an error)
+            std::vector<long> offs;
+            for (long i = 0; i + K <= wl; i += 31) {
                 auto it = idx.find(win.substr(i, K));
-                if (it != idx.end()) { off = it->second - i; break; }
+                if (it != idx.end()) offs.push_back(it->second - i);
             }
-            if (off < -B || wl < K) { bad_win++; total_ed += wl; total_len += wl; continue; }
-            long st = std::max(0L, off - 50);
-            std::string t = G.substr(st, std::min<long>((long)G.size() - st, wl + B));
-            // free start shift of up to ~100 bases: take the best of a few start offsets
+            long off = -1000000000L;
+            if (!offs.empty()) {
+                std::sort(offs.begin(), offs.end());
+                size_t bi = 0, bc = 0;
+                for (size_t a2 = 0, b2 = 0; a2 < offs.size(); a2++) {       // densest cluster within +-150
+                    while (b2 < offs.size() && offs[b2] - offs[a2] <= 300) b2++;
+                    if (b2 - a2 > bc) { bc = b2 - a2; bi = a2; }
+                }
+                off = offs[bi];   // smallest offset of the cluster = alignment of the window start (insertions only push later seeds right)
+            }
+            if (off < -1000000 || wl < K) { bad_win++; total_ed += wl; total_len += wl; continue; }
+            long st = std::max(0L, off - 200);
+            std::string t = G.substr(st, std::min<long>((long)G.size() - st, wl + 400 + B / 2));
             long ed = banded_ed(win, t, B);
-            for (long sh = 25; sh <= 100 && st + sh < (long)G.size(); sh += 25) ed = std::min(ed, banded_ed(win, G.substr(st + sh, std::min<long>((long)G.size() - st - sh, wl + B)), B));
             total_ed += std::min(ed, wl); total_len += wl;
         }
         double ident = 1.0 - (double)total_ed / (double)total_len;
