@@ -98,6 +98,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    torch.zeros(1, device="cuda")   # initialise torch's HIP context (streams, queues) now, not inside the timed region
+    torch.cuda.synchronize()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -148,7 +150,9 @@ def main():
     for _ in range(args.steps):
         if last is not None:
             last.close()
+        ts = time.perf_counter()
         last = step()
+        log(f"[rank {rank}] step {time.perf_counter() - ts:.3f} s  stages {last.timings()}")
     sync()
     dt = time.perf_counter() - t0
     if world > 1:

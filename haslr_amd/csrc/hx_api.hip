@@ -81,6 +81,24 @@ struct Timer {
 
 }  // namespace
 
+namespace {
+struct PoaPlan {
+    std::vector<hxk::PoaSeq> seqs;
+    std::vector<hxk::PoaEdge> edges;
+    std::vector<uint64_t> sumL;
+    std::vector<uint32_t> nseq;
+};
+
+struct PoaPoolBufs {
+    DV<uint8_t> code, n_aligned, mark, check, row_code, row_sink, seq;
+    DV<uint32_t> aligned, in_head, in_tail, out_head, out_tail, rank2node, node2rank, stack, row_pred_off, pred_rank, e_from, e_to, e_next_in, e_next_out;
+    DV<int32_t> score, pred, e_w, aln_node, aln_pos, H;
+    DV<uint32_t> row_meta, row_pred0, row_pred1;
+    DV<uint4> nrec;
+    DV<uint8_t> dir;
+};
+}  // namespace
+
 struct hx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -125,6 +143,14 @@ struct hx_ctx {
     hipStream_t poa_streams[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t poa_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     Timer tm;
+    // POA workspace lives as long as the context: allocating tens of GB per call costs more than the kernel
+    PoaPoolBufs poa_pools;
+    uint64_t poa_budget = 0;
+    DV<hxk::PoaEdge> poa_edges;
+    DV<hxk::PoaSeq> poa_seqs;
+    DV<uint32_t> poa_order, poa_len, poa_status;
+    DV<char> poa_cns;
+    DV<unsigned long long> poa_phase_d, poa_cells_d;
     std::vector<unsigned long long> poa_phase;   // per edge x 6, cycles of the last hx_poa_batch
 
     DevHits hits_view() const {
@@ -164,7 +190,14 @@ extern "C" int hx_ctx_create(int device, void* stream, hx_ctx** out) {
     else { HIPCHK(hipStreamCreate(&c->stream)); c->own_stream = true; }
     HIPCHK(hipEventCreate(&c->tm.a));
     HIPCHK(hipEventCreate(&c->tm.b));
-    for (int i = 0; i < 5; i++) HIPCHK(hipStreamCreateWithFlags(&c->poa_streams[i], hipStreamNonBlocking));
+    {   // distinct priorities map to distinct hardware queues, so the lane-count classes really run side by side
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least priority (largest number), hi = greatest
+        for (int i = 0; i < 5; i++) {
+            int pr = hi + i; if (pr > lo) pr = lo;
+            HIPCHK(hipStreamCreateWithPriority(&c->poa_streams[i], hipStreamNonBlocking, pr));
+        }
+    }
     for (int i = 0; i < 6; i++) HIPCHK(hipEventCreateWithFlags(&c->poa_ev[i], hipEventDisableTiming));
     HIPCHK(c->err.reserve(1));
     *out = c;
@@ -442,23 +475,6 @@ extern "C" void hx_free_coords(hx_ctx*, hx_coords_out* o) {
 }
 
 // ================================================================================================ K6
-namespace {
-struct PoaPlan {
-    std::vector<hxk::PoaSeq> seqs;
-    std::vector<hxk::PoaEdge> edges;
-    std::vector<uint64_t> sumL;
-    std::vector<uint32_t> nseq;
-};
-
-struct PoaPoolBufs {
-    DV<uint8_t> code, n_aligned, mark, check, row_code, row_sink, seq;
-    DV<uint32_t> aligned, in_head, in_tail, out_head, out_tail, rank2node, node2rank, stack, row_pred_off, pred_rank, e_from, e_to, e_next_in, e_next_out;
-    DV<int32_t> score, pred, e_w, aln_node, aln_pos, H;
-    DV<uint32_t> row_meta, row_pred0, row_pred1;
-    DV<uint4> nrec;
-    DV<uint8_t> dir;
-};
-}  // namespace
 
 extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out) {
     memset(out, 0, sizeof(*out));
@@ -491,20 +507,23 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     c->dbg_nseq = P.nseq; c->dbg_lmax.resize(ne); for (uint32_t e = 0; e < ne; e++) c->dbg_lmax[e] = P.edges[e].lmax;
     std::vector<uint32_t> cns_len(ne, 0);
     std::vector<std::string> cns(ne);
-    DV<hxk::PoaSeq> d_seqs;
+    DV<hxk::PoaSeq>& d_seqs = c->poa_seqs;
     HIPCHK(d_seqs.reserve(P.seqs.size()));
     if (!P.seqs.empty()) HIPCHK(hipMemcpyAsync(d_seqs.p, P.seqs.data(), P.seqs.size() * sizeof(hxk::PoaSeq), hipMemcpyHostToDevice, s));
-    DV<unsigned long long> d_cells;
+    DV<unsigned long long>& d_cells = c->poa_cells_d;
     HIPCHK(d_cells.reserve(1));
     HIPCHK(hipMemsetAsync(d_cells.p, 0, 8, s));
-    size_t free_b = 0, total_b = 0;
-    HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    const uint64_t budget = (uint64_t)(free_b * 0.8);
-    PoaPoolBufs B;
-    DV<hxk::PoaEdge> d_edges;
-    DV<uint32_t> d_order, d_len, d_status;
-    DV<char> d_cns;
-    DV<unsigned long long> d_phase;
+    if (!c->poa_budget) {   // measured once: later calls would count the context's own (persistent) workspace as used
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        c->poa_budget = (uint64_t)(free_b * 0.8);
+    }
+    const uint64_t budget = c->poa_budget;
+    PoaPoolBufs& B = c->poa_pools;
+    DV<hxk::PoaEdge>& d_edges = c->poa_edges;
+    DV<uint32_t>&d_order = c->poa_order, &d_len = c->poa_len, &d_status = c->poa_status;
+    DV<char>& d_cns = c->poa_cns;
+    DV<unsigned long long>& d_phase = c->poa_phase_d;
     HIPCHK(d_phase.reserve((size_t)ne * 6));
     HIPCHK(hipMemsetAsync(d_phase.p, 0, std::max<size_t>(1, (size_t)ne * 6) * 8, s));
     bool worst_case = false;
