@@ -74,15 +74,16 @@ __device__ __forceinline__ void push_aligned(G& g, uint32_t n, uint32_t a) {
 }
 
 // spoa Graph::add_sequence for seq[b,e): returns first node or NONE
-__device__ uint32_t add_chain(G& g, uint32_t& V, uint32_t& E, const uint8_t* seq, uint32_t b, uint32_t e) {
+__device__ uint32_t add_chain(G& g, uint32_t& V, uint32_t& E, const uint8_t* seq, uint32_t b, uint32_t e, uint32_t* path, uint32_t* colref) {
     if (b == e) return NONE;
     uint32_t first = add_node(g, V, seq[b]);
-    for (uint32_t i = b + 1; i < e; i++) { uint32_t n = add_node(g, V, seq[i]); add_edge(g, E, n - 1, n, 2); }
+    path[b] = first; colref[b] = NONE;
+    for (uint32_t i = b + 1; i < e; i++) { uint32_t n = add_node(g, V, seq[i]); path[i] = n; colref[i] = NONE; add_edge(g, E, n - 1, n, 2); }
     return first;
 }
 
 // spoa Graph::topological_sort (iterative DFS over in-edges and aligned nodes); lane 0 only
-__device__ void toposort(G& g, uint32_t V) {
+__device__ void toposort(G& g, uint32_t V, uint32_t* out) {
     uint32_t sp = 0, nr = 0;
     for (uint32_t i = 0; i < V; i++) {
         if (g.mark[i]) continue;
@@ -105,9 +106,9 @@ __device__ void toposort(G& g, uint32_t V) {
                 if (valid) {
                     g.mark[n] = 2;
                     if (g.check[n]) {
-                        g.rank2node[nr++] = n;
+                        out[nr++] = n;
                         uint32_t na = g.n_aligned[n];
-                        for (uint32_t k = 0; k < na; k++) g.rank2node[nr++] = g.aligned[3 * n + k];
+                        for (uint32_t k = 0; k < na; k++) out[nr++] = g.aligned[3 * n + k];
                     }
                 } else g.mark[n] = 1;
             }
@@ -122,9 +123,10 @@ __device__ void toposort(G& g, uint32_t V) {
 // lines (one coalesced 256-byte load per miss; node ids are visited in nearly ascending runs, so most visits hit). The mark/check
 // bits of every node sit in one LDS byte (st[]), the top of the DFS stack in an LDS window that spills to the HBM stack.
 // Requires node ids < 2^21 - 1 (aligned ids are packed 3 x 21 bit).
+constexpr uint32_t SINK_CAP = 1024;      // sink rows whose end score is kept per alignment (more: error)
 constexpr uint32_t TOPO_LCAP = 1024;     // stack window entries
 constexpr uint32_t TOPO_LINES = 64;      // cache lines of 16 records (16 KiB)
-__device__ void toposort_coop(G& g, const uint32_t V, uint8_t* st, uint32_t* lstack, uint4* cache, uint32_t* tags) {
+__device__ void toposort_coop(G& g, const uint32_t V, uint8_t* st, uint32_t* lstack, uint4* cache, uint32_t* tags, uint32_t* out) {
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i = lane; i < TOPO_LINES; i += 64) tags[i] = NONE;
     uint32_t sp = 0, nr = 0, base = 0;
@@ -172,12 +174,12 @@ __device__ void toposort_coop(G& g, const uint32_t V, uint8_t* st, uint32_t* lst
                 if (valid) {
                     if (lane == 0) st[n] = (uint8_t)((sn & ~3u) | 2u);
                     if (chk) {
-                        if (lane == 0) g.rank2node[nr] = n;
+                        if (lane == 0) out[nr] = n;
                         nr++;
                         for (uint32_t k = 0; k < 3; k++) {
                             const uint32_t a1 = (uint32_t)(al >> (21 * k)) & 0x1fffffu;
                             if (!a1) break;
-                            if (lane == 0) g.rank2node[nr] = a1 - 1;
+                            if (lane == 0) out[nr] = a1 - 1;
                             nr++;
                         }
                     }
@@ -190,16 +192,17 @@ __device__ void toposort_coop(G& g, const uint32_t V, uint8_t* st, uint32_t* lst
 
 // spoa Graph::add_alignment with unit weights; alignment is stored REVERSED (index n_aln-1 is the first pair). lane 0 only.
 // returns false on workspace overflow
-__device__ bool add_alignment(G& g, uint32_t& V, uint32_t& E, uint32_t n_aln, const uint8_t* seq, uint32_t len) {
+__device__ bool add_alignment(G& g, uint32_t& V, uint32_t& E, uint32_t n_aln, const uint8_t* seq, uint32_t len, uint32_t* path /* node of every base */,
+                              uint32_t* colref /* an OLD node of the aligned column the base went to, NONE for an unaligned base */) {
     if (V + len > g.vcap || E + len + 1 > g.ecap) return false;   // worst case: every base a new node / edge
-    if (n_aln == 0) { add_chain(g, V, E, seq, 0, len); return true; }
+    if (n_aln == 0) { add_chain(g, V, E, seq, 0, len, path, colref); return true; }
     int32_t first_valid = -1, last_valid = -1;
     for (int32_t k = (int32_t)n_aln - 1; k >= 0; k--) if (g.aln_pos[k] != -1) { first_valid = g.aln_pos[k]; break; }
     for (uint32_t k = 0; k < n_aln; k++) if (g.aln_pos[k] != -1) { last_valid = g.aln_pos[k]; break; }
     uint32_t before = V;
-    add_chain(g, V, E, seq, 0, (uint32_t)first_valid);
+    add_chain(g, V, E, seq, 0, (uint32_t)first_valid, path, colref);
     uint32_t head = before == V ? NONE : V - 1;
-    uint32_t tail = add_chain(g, V, E, seq, (uint32_t)last_valid + 1, len);
+    uint32_t tail = add_chain(g, V, E, seq, (uint32_t)last_valid + 1, len, path, colref);
     for (int32_t k = (int32_t)n_aln - 1; k >= 0; k--) {
         int32_t pos = g.aln_pos[k];
         if (pos == -1) continue;
@@ -222,6 +225,7 @@ __device__ bool add_alignment(G& g, uint32_t& V, uint32_t& E, uint32_t n_aln, co
                 push_aligned(g, (uint32_t)an, nn);
             } else nn = hit;
         }
+        path[pos] = nn; colref[pos] = an == -1 ? NONE : (uint32_t)an;
         if (head != NONE) add_edge(g, E, head, nn, 2);
         head = nn;
     }
@@ -349,7 +353,7 @@ template <int CM> __device__ __forceinline__ void store_chunk_u8(uint8_t* p, con
 template <int CM, bool DIR>
 __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, const uint32_t W, const uint8_t* __restrict__ seq, const uint32_t L,
                         const uint32_t V, int32_t* ring, const uint32_t R, const uint32_t ring_w, const int match, const int mismatch, const int gap,
-                        int* lds_tot /* 2 x 16 */, uint32_t* smeta, int& bestScoreOut, int& bestIOut) {
+                        int* lds_tot /* 2 x 16 */, uint32_t* smeta, uint32_t* sink_row, int* sink_score, uint32_t& nSinkOut) {
     constexpr uint32_t MT = 256;   // metadata tile (rows)
     const uint32_t tid = threadIdx.x, NT = blockDim.x, lane = tid & 63u, wv = tid >> 6;
     const bool multi = NT > 64;
@@ -375,7 +379,7 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
     int left_prev = tid > 0 ? jg0 - gap : NEG;          // H[i-1][j0-1]
     if (in_row) store_chunk_i32<CM>(H + j0, t);         // row 0 stays in HBM: virtual predecessor of every source node
     uint32_t nkept = 0;                                 // kept rows produced so far (ring slot counter; mirrors the CSR build)
-    int bestScore = INT32_MIN + 1024, bestI = -1;
+    uint32_t nsink = 0;
     if (multi) __syncthreads();
     for (uint32_t i = 1; i <= V; i++) {
         const uint32_t ti = (i - 1) & (MT - 1);
@@ -507,14 +511,15 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
             if (!DIR || (meta & 8u)) store_chunk_i32<CM>(H + (uint64_t)i * W + j0, t);   // score row to HBM only if the traceback or a far successor needs it
             if (DIR) store_chunk_u8<CM>(D + (uint64_t)i * W + j0, dcode);
         }
-        if (owns_last && (meta & 4u)) {   // sink node: candidate end of the global alignment (first maximum in rank order)
+        if (owns_last && (meta & 4u)) {   // sink node: candidate end of the global alignment
             int v = NEG;
 #pragma unroll
             for (int k = 0; k < CM; k++) if ((uint32_t)k == klast) v = t[k];
-            if (bestScore < v) { bestScore = v; bestI = (int)i; }
+            if (nsink < SINK_CAP) { sink_row[nsink] = i; sink_score[nsink] = v; }
+            nsink++;
         }
     }
-    if (owns_last) { bestScoreOut = bestScore; bestIOut = bestI; }
+    if (owns_last) nSinkOut = nsink;
 }
 
 template <int MAXNT, int CMMAX, bool DIR>
@@ -557,10 +562,30 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     __shared__ int lds_i[32];
     __shared__ uint32_t smeta[4 * 256];
     __shared__ uint32_t lds_u[16];
-    __shared__ uint32_t sV, sE, sNaln, sOk;
-    __shared__ int sBestScore, sBestI;
+    __shared__ uint32_t sV, sE, sNaln, sOk, sNsink, sNcand, sBestKey;
+    __shared__ int sBestI;
+    __shared__ uint32_t sink_row[SINK_CAP];
+    __shared__ int sink_score[SINK_CAP];
     if (tid == 0) { sV = 0; sE = 0; sOk = 1; }
     __syncthreads();
+    // The reference's topological order (spoa's DFS, inherently serial) is needed in two places only: to break ties between equally scored
+    // end nodes of an alignment, and for the heaviest-bundle traversal of the finished graph. The DP itself runs on a cheaper order that
+    // is maintained incrementally (see "order update" below): row values do not depend on which valid topological order is used.
+    const uint32_t topo_fixed = TOPO_LCAP * 4 + TOPO_LINES * 256 + TOPO_LINES * 4;
+    uint32_t* t_stack = reinterpret_cast<uint32_t*>(ring);
+    uint4* t_cache = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(ring) + TOPO_LCAP * 4);
+    uint32_t* t_tags = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ring) + TOPO_LCAP * 4 + TOPO_LINES * 256);
+    uint8_t* st_lds = reinterpret_cast<uint8_t*>(ring) + topo_fixed;
+    auto exact_order = [&](uint32_t Vn, uint32_t* out) {   // all lanes; leaves spoa's rank->node order of the current graph in out[]
+        const bool in_lds = (uint64_t)Vn + topo_fixed + 16 <= lds_bytes && g.vcap < (1u << 21) - 1;
+        if (in_lds) { for (uint32_t i = tid; i < Vn; i += NT) st_lds[i] = 4u; }                    // mark 0, check 1
+        else { for (uint32_t i = tid; i < Vn; i += NT) { g.mark[i] = 0; g.check[i] = 1; } }
+        __syncthreads();
+        if (in_lds) { if (tid < 64) toposort_coop(g, Vn, st_lds, t_stack, t_cache, t_tags, out); }   // wave 0, 64 lanes in lock step
+        else if (tid == 0) toposort(g, Vn, out);
+        __syncthreads();
+    };
+    uint32_t* tmp_u32 = reinterpret_cast<uint32_t*>(g.pred);   // vcap+1 words of scratch (heaviest-bundle scratch, free until the end)
 
     for (uint32_t k = ED.seq_begin; k < ED.seq_end; k++) {
         const PoaSeq q = seqs[k];
@@ -582,13 +607,36 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
             // =================================================== DP over (rank, column)
             {
                 const uint32_t cm = (L + 1 + NT - 1) / NT;     // columns per lane for this sequence
-                int bs = 0, bi = -1;
-#define HX_DP(CMV) dp_rows<CMV, DIR>(g, H, Dm, W, seq, L, V, ring, R, ring_w, match, mismatch, gap, lds_i, smeta, bs, bi)
+                uint32_t ns = 0xffffffffu;
+#define HX_DP(CMV) dp_rows<CMV, DIR>(g, H, Dm, W, seq, L, V, ring, R, ring_w, match, mismatch, gap, lds_i, smeta, sink_row, sink_score, ns)
                 if (cm <= 4) HX_DP(4); else if (cm <= 8) HX_DP(8); else if (cm <= 16) HX_DP(16);
                 else if (cm <= 32) { if constexpr (CMMAX >= 32) HX_DP(32); else sOk = 2; }   // the host never asks a 16-column kernel for more
                 else { if constexpr (CMMAX >= 64) HX_DP(64); else sOk = 2; }
 #undef HX_DP
-                if (bi >= 0) { sBestScore = bs; sBestI = bi; }
+                if (ns != 0xffffffffu) sNsink = ns;   // written by the lane that owns column L
+            }
+            __syncthreads();
+            // ---- end node of the global alignment: the best-scoring sink; ties go to the smallest rank in the REFERENCE's order
+            if (tid == 0) {
+                if (sNsink > SINK_CAP) sOk = 2;
+                int best = INT32_MIN + 1024; uint32_t ncand = 0, first = 0;
+                const uint32_t nsk = min(sNsink, SINK_CAP);
+                for (uint32_t q = 0; q < nsk; q++) if (sink_score[q] > best) best = sink_score[q];
+                for (uint32_t q = 0; q < nsk; q++) if (sink_score[q] == best) { if (!ncand) first = q; sink_row[ncand++] = sink_row[q]; }   // compact candidates to the front
+                (void)first;
+                sNcand = ncand; sBestI = ncand ? (int)sink_row[0] : -1; sBestKey = 0xffffffffu;
+            }
+            __syncthreads();
+            if (sNcand > 1 && sOk == 1) {
+                exact_order(V, tmp_u32);
+                const uint32_t nc = sNcand;
+                for (uint32_t r = tid; r < V; r += NT) {
+                    const uint32_t n = tmp_u32[r];
+                    for (uint32_t q = 0; q < nc; q++)
+                        if (g.rank2node[sink_row[q] - 1] == n) atomicMin(&sBestKey, (r << 10) | q);   // nc <= 1024 candidates
+                }
+                __syncthreads();
+                if (tid == 0) { sBestI = (int)sink_row[sBestKey & 1023u]; atomicAdd(&ph[4], 0ull); }
             }
             __syncthreads();
             PHASE(1);
@@ -645,32 +693,79 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         } else if (tid == 0) sNaln = 0;
         __syncthreads();
         PHASE(2);
-        // =================================================== graph update + topological sort
-        // the ring's LDS is idle between DPs: it holds the toposort state (1 byte per node), the top of the DFS stack and a record cache
-        const uint32_t topo_lim = min(sV + L, g.vcap);
-        const uint32_t topo_fixed = TOPO_LCAP * 4 + TOPO_LINES * 256 + TOPO_LINES * 4;
-        const bool topo_lds = (uint64_t)topo_lim + topo_fixed + 16 <= lds_bytes && g.vcap < (1u << 21) - 1;
-        uint32_t* t_stack = reinterpret_cast<uint32_t*>(ring);
-        uint4* t_cache = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(ring) + TOPO_LCAP * 4);
-        uint32_t* t_tags = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ring) + TOPO_LCAP * 4 + TOPO_LINES * 256);
-        uint8_t* st_lds = reinterpret_cast<uint8_t*>(ring) + topo_fixed;
-        if (topo_lds) { for (uint32_t i = tid; i < topo_lim; i += NT) st_lds[i] = 4u; }              // mark 0, check 1
-        else { for (uint32_t i = tid; i < topo_lim; i += NT) { g.mark[i] = 0; g.check[i] = 1; } }
-        __syncthreads();
+        // =================================================== graph update (lane 0) + order update (all lanes)
+        const uint32_t V_old = sV;
+        uint32_t* path = reinterpret_cast<uint32_t*>(g.score);   // node of every base of this sequence (vcap+1 words, free until the CSR build)
+        uint32_t* colref = g.row_pred1;                          // column reference of every base (free until the CSR build)
         if (tid == 0) {
             uint32_t V2 = sV, E2 = sE;
-            if (!add_alignment(g, V2, E2, sNaln, seq, L)) sOk = 0;
+            if (!add_alignment(g, V2, E2, sNaln, seq, L, path, colref)) sOk = 0;
             else { sV = V2; sE = E2; }
             PHASE(3);
         }
         __syncthreads();
-        if (sOk == 1) {
-            if (topo_lds) { if (tid < 64) toposort_coop(g, sV, st_lds, t_stack, t_cache, t_tags); }   // wave 0, all 64 lanes in lock step
-            else if (tid == 0) toposort(g, sV);
+        if (sOk != 1) break;
+        {
+            // Order update. Ranks keep every aligned group ("column") contiguous, like the reference's order does: a later sequence may
+            // enter a column through one member and continue from another, so edges must run from earlier columns to later ones.
+            // The new sequence's path visits existing columns in increasing rank. Each new node gets an insertion point X in the OLD order:
+            //   new mismatch node (joins the column of the old node it was aligned to)  -> X = last rank of that column + 1
+            //   new unaligned node (a new column)                                       -> X = first rank of the next existing column on the path (or the end)
+            // Nodes with the same X keep path order (X never decreases along the path). New rank of an old node = old rank + #new nodes
+            // with X <= old rank: one prefix sum over the old order instead of a serial DFS over the whole graph.
+            const uint32_t V2 = sV;
+            uint32_t* ins = g.stack;          // V_old+1 counters, then their exclusive prefix
+            uint32_t* xq = g.row_pred0;       // insertion point of every new node, by sequence position (free until the CSR build)
+            if (V_old == 0) {
+                for (uint32_t r = tid; r < V2; r += NT) g.rank2node[r] = r;
+            } else {
+                for (uint32_t r = tid; r <= V_old; r += NT) ins[r] = 0;
+                __syncthreads();
+                if (tid == 0) {
+                    auto col_first = [&](uint32_t n) { uint32_t f = g.node2rank[n]; for (uint32_t k = 0, na = g.n_aligned[n]; k < na; k++) { const uint32_t a = g.aligned[3 * n + k]; if (a < V_old) f = min(f, g.node2rank[a]); } return f; };
+                    auto col_last = [&](uint32_t n) { uint32_t f = g.node2rank[n]; for (uint32_t k = 0, na = g.n_aligned[n]; k < na; k++) { const uint32_t a = g.aligned[3 * n + k]; if (a < V_old) f = max(f, g.node2rank[a]); } return f; };
+                    uint32_t q = 0;
+                    while (q < L) {
+                        if (path[q] < V_old) { q++; continue; }
+                        if (colref[q] != NONE) { const uint32_t X = col_last(colref[q]) + 1; xq[q] = X; ins[X]++; q++; continue; }
+                        uint32_t q2 = q;                                  // run of unaligned new nodes: find the next existing column
+                        while (q2 < L && path[q2] >= V_old && colref[q2] == NONE) q2++;
+                        const uint32_t X = q2 < L ? col_first(path[q2] < V_old ? path[q2] : colref[q2]) : V_old;
+                        for (uint32_t z = q; z < q2; z++) xq[z] = X;
+                        ins[X] += q2 - q;
+                        q = q2;
+                    }
+                }
+                __syncthreads();
+                const uint32_t CH = (V_old + 1 + NT - 1) / NT;
+                const uint32_t a0 = min(tid * CH, V_old + 1), a1 = min(a0 + CH, V_old + 1);
+                uint32_t sum = 0;
+                for (uint32_t r = a0; r < a1; r++) sum += ins[r];
+                uint32_t tot;
+                uint32_t ex = block_excl_scan_add(sum, lds_u, &tot);
+                for (uint32_t r = a0; r < a1; r++) {
+                    const uint32_t c = ins[r];
+                    ins[r] = ex;                                            // new nodes with X == r start at r + ex
+                    if (r < V_old) tmp_u32[r + ex + c] = g.rank2node[r];    // the old node itself moves behind them
+                    ex += c;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t lastX = NONE, k = 0;
+                    for (uint32_t q = 0; q < L; q++) {
+                        if (path[q] < V_old) continue;
+                        const uint32_t X = xq[q];
+                        k = X == lastX ? k + 1 : 0;
+                        lastX = X;
+                        tmp_u32[X + ins[X] + k] = path[q];
+                    }
+                }
+                __syncthreads();
+                for (uint32_t r = tid; r < V2; r += NT) g.rank2node[r] = tmp_u32[r];
+            }
         }
         PHASE(4);
         __syncthreads();
-        if (sOk != 1) break;
         // =================================================== rank-order CSR for the next DP (all lanes)
         {
             const uint32_t V2 = sV;
@@ -737,6 +832,11 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         __syncthreads();
         PHASE(5);
     }
+    if (sOk == 1 && sV) {   // heaviest bundle runs on the reference's topological order of the finished graph
+        exact_order(sV, g.rank2node);
+        for (uint32_t r = tid; r < sV; r += NT) g.node2rank[g.rank2node[r]] = r;
+        __syncthreads();
+    }
     if (tid == 0) {
         if (sOk == 2) { status[eidx] = HXE_SPOS_RANGE << 8; cns_len[eidx] = 0; }   // internal: kernel variant cannot hold this many columns per lane
         else if (!sOk) { status[eidx] = HXE_POA_OVERFLOW; cns_len[eidx] = 0; }
@@ -754,7 +854,7 @@ void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_edges, cons
              bool use_dir, hipStream_t s) {
     if (!n_edges) return;
 #define HX_LAUNCH(MNT, CMX, DIRV) do { \
-        (void)hipFuncSetAttribute((const void*)k_poa<MNT, CMX, DIRV>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+        (void)hipFuncSetAttribute((const void*)k_poa<MNT, CMX, DIRV>, hipFuncAttributeMaxDynamicSharedMemorySize, 146 * 1024); \
         k_poa<MNT, CMX, DIRV><<<n_edges, block_threads, ring_bytes, s>>>(edges, order, n_edges, seqs, packed, read_off, read_len, pools, match, mismatch, gap, \
                                                                        cns, cns_len, status, cells, phase, ring_rows, ring_bytes); } while (0)
     // one binary per register budget: <= 256 lanes may use 32-column chunks (256+ VGPRs per lane), 512/1024-lane workgroups 16 / 8
