@@ -175,6 +175,17 @@ def main():
     poa_ms = float(tms.item())
     achieved = alg_bytes / (poa_ms / 1e3) / 1e9 if poa_ms > 0 else 0.0
 
+    # HBM traffic of the POA launch group: measured offline with rocprofv3 PMC passes for exactly this workload (profiles/*_traffic.json)
+    traffic, traffic_src = None, None
+    if world == 1 and not args.genome_len:
+        import glob
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+        if cand:
+            try:
+                traffic = json.load(open(cand[-1]))["hbm_bytes_raw"]
+                traffic_src = os.path.relpath(cand[-1], ROOT)
+            except Exception:  # noqa: BLE001
+                traffic = None
     if rank == 0:
         value = ds.total_read_bases * args.steps / dt
         line = {
@@ -187,7 +198,7 @@ def main():
                        "reads": ds.reads.n, "long_read_bases": ds.total_read_bases, "paf_records": ds.hits.n, "edges": int(n_edges),
                        "poa_block_threads": args.poa_block or 256, "parallelism": f"reads+edges sharded x{world}, 1 all-gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_poa", "kernel_ms_per_launch": poa_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_poa (launch group: one kernel per lane-count class, concurrent)", "kernel_ms_per_launch": poa_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "gcups": cells / (poa_ms / 1e3) / 1e9 if poa_ms > 0 else 0.0, "dp_cells_per_launch": cells,
                          "note": "POA is an O(L^2) integer DP over O(L) bytes: HBM fraction is low by construction (SURVEY.md 8d); GCUPS is the figure of merit"},
             "stage_ms": {k: v * 1e3 for k, v in last.timings().items()},

@@ -62,7 +62,7 @@ def test_every_stage_bit_exact(args, sim, ctx, tmp_path):
     assert os.path.getsize(tmp_path / "g" / "asm.final.fa") > 0
 
 
-@pytest.mark.parametrize("block", [64, 512])
+@pytest.mark.parametrize("block", [64, 128, 512, 1024])
 def test_poa_block_sizes_agree(block, sim, ctx, tmp_path):
     pre = sim("--genome-len", "100000", "--seed", "25", "--variant-per-mb", "20")
     ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
@@ -71,7 +71,7 @@ def test_poa_block_sizes_agree(block, sim, ctx, tmp_path):
         ro, rg, ob = both(ds, ctx, None, None)
         assert ro.cns_out() == rg.cns_out()
     finally:
-        ctx.set_poa_block(256)
+        ctx.set_poa_block(0)
 
 
 def test_nondefault_parameters(sim, ctx, tmp_path):
@@ -235,3 +235,31 @@ def test_record_exchange_roundtrip(sim, ctx):
     ctx.set_read_shard(0, ds.reads.n)
     for k in whole:
         assert np.array_equal(whole[k], got[k]), k
+
+
+@pytest.mark.parametrize("seed", [51, 52, 53, 54, 55, 56])
+def test_consensus_bit_exact_many_seeds(seed, sim, ctx):
+    """more POA instances (different graph shapes, end-node ties, hairpins of the generator's variants) at small size"""
+    pre = sim("--genome-len", "70000", "--seed", str(seed), "--variant-per-mb", "40", "--cov", "30")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    ro, rg, ob = both(ds, ctx, None, None)
+    assert_same_arrays(ro.coords_out(), rg.coords_out(), "coords")
+    assert ro.cns_out() == rg.cns_out()
+    assert ro.assembly_fasta() == rg.assembly_fasta()
+
+
+def test_score_matrix_traceback_matches_direction_bytes(sim, ctx):
+    """the two traceback sources of the POA kernel (1-byte direction codes vs the int32 score matrix) give the same consensus"""
+    pre = sim("--genome-len", "100000", "--seed", "25", "--variant-per-mb", "20")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    ctx.upload(ds)
+    prm = ds.params()
+    a = host.Run(ds, prm, ctx.backend(), None)
+    a.all()
+    ctx.set_poa_traceback(0)
+    try:
+        b = host.Run(ds, prm, ctx.backend(), None)
+        b.all()
+    finally:
+        ctx.set_poa_traceback(1)
+    assert a.cns_out() == b.cns_out() and a.assembly_fasta() == b.assembly_fasta()
