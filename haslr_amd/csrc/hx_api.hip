@@ -534,6 +534,8 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             uint64_t est = (uint64_t)E.lmax * (3 + P.nseq[e] / 10) + 1024;
             uint64_t vc = worst_case ? P.sumL[e] : std::min<uint64_t>(P.sumL[e], est);
             if (vc >= 0x7fffffffULL) return fail("hx_poa_batch: POA graph too large");
+            // DP cells are keys = 64 x score + 6 tie-break bits in an int32: |score| <= 8 * (nodes + columns) must stay below 2^24
+            if (vc + E.lmax + 2 >= (1ull << 21)) return fail("hx_poa_batch: POA graph of an edge exceeds 2^21 nodes + columns (score keys would overflow)");
             E.vcap = (uint32_t)vc; E.hrows = E.vcap; E.ecap = (uint32_t)(P.sumL[e] + P.nseq[e] + 1);
         }
         // largest first (block scheduling is in grid order): cost ~ rows x columns x sequences

@@ -339,28 +339,105 @@ template <int CM> __device__ __forceinline__ void store_chunk_u8(uint8_t* p, con
 //
 // Lane t owns the CM contiguous columns [t*CM, t*CM+CM) and keeps the CURRENT row there. The common predecessor of
 // row i is row i-1: the lane's own registers, plus the value left of its first column, which falls out of the
-// prefix scan that row i-1 needed anyway (exclusive scan + (j0-1)*gap). So the usual row costs no LDS row traffic
-// and exactly ONE cross-lane operation: the prefix-max scan of (chunk end - column*gap) that resolves the horizontal
-// recurrence H[j] = max(T[j], H[j-1]+g) — 64-lane DPP scan inside a wave, wave totals through LDS (double-buffered,
-// one LDS-only barrier per row) when the workgroup has several waves. A single-wave workgroup never synchronises.
+// prefix scan that row i-1 needed anyway. So the usual row costs no LDS row traffic and exactly ONE cross-lane
+// operation: the prefix-max scan of (chunk end - column*gap) that resolves the horizontal recurrence
+// H[j] = max(T[j], H[j-1]+g) — 64-lane DPP scan inside a wave, wave totals through LDS (double-buffered, one LDS-only
+// barrier per row) when the workgroup has several waves. A single-wave workgroup never synchronises; waves that own
+// no real column of this sequence only keep the barrier count.
+//
+// Cells are "keys": 64 x score + 6 low bits. The low bits make one max() do the reference's tie-breaking:
+//   move type     63 diagonal > 62 vertical > 1 horizontal (the reference's traceback tries them in this order and takes a
+//                 horizontal move only when nothing else reaches the score), and
+//   63 - p        while the maximum over several predecessors p is formed (the first predecessor in in-edge order wins ties).
+// Scores stay below 2^24 in magnitude (8*(V+L) with V+L < 2^21, checked by the host), so keys fit 32 bits.
+// One direction byte per cell goes to HBM for the traceback: type in bits 0-1 (3/2/1), predecessor slot in bits 2-7.
+//
 // Rows that a later row needs as a NON-adjacent predecessor are flagged by the CSR build ("kept") and copied to an LDS
 // ring in the order they are produced (lane-transposed layout: column t*CM+k at word k*NT+t, conflict-free), or to
 // HBM when the ring has wrapped; predecessor references carry that location (0 registers, 1..14 ring slot+1, 15 HBM).
-// Traceback information is one direction byte per cell written to HBM (what the reference's traceback would choose:
-// diagonal first, then vertical with the first predecessor in in-edge order, horizontal only if strictly better).
+// Row metadata travels in registers: every wave loads the records of 64 rows with one coalesced load (one batch ahead)
+// and broadcasts the current row's words with v_readlane.
 // Columns beyond L are computed like real ones and never read by a real column, so the loop has no column predicates.
 // ---------------------------------------------------------------------------------------------------
+constexpr int32_t NEGK = -(1 << 30);   // "minus infinity" key
+
+// inclusive prefix maximum over the 64 lanes of a wave: the classic DPP sequence with the max fused into the DPP instruction
+// (lanes without a source keep their value). s_nop 1 = the two wait states a DPP read needs after a VALU write of its source.
+__device__ __forceinline__ int wave_incl_max(int v) {
+    int x;
+    asm volatile(
+        "v_mov_b32 %0, %1\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "=&v"(x) : "v"(v));
+    return x;
+}
+// the same inside every row of 16 lanes (wave totals: at most 16 waves)
+__device__ __forceinline__ int row16_incl_max(int v) {
+    int x;
+    asm volatile(
+        "v_mov_b32 %0, %1\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1"
+        : "=&v"(x) : "v"(v));
+    return x;
+}
+// byte 0 of four registers -> one dword
+__device__ __forceinline__ uint32_t pack_b0(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const uint32_t ab = __builtin_amdgcn_perm(b, a, 0x0c0c0400u), cd = __builtin_amdgcn_perm(d, c, 0x0c0c0400u);
+    return __builtin_amdgcn_perm(cd, ab, 0x05040100u);
+}
+template <int CM> __device__ __forceinline__ void store_dirs(uint8_t* p, const uint32_t (&v)[CM], uint32_t keep) {
+    if constexpr (CM >= 4) {
+        uint32_t w[CM / 4];
+#pragma unroll
+        for (int q = 0; q < CM / 4; q++) w[q] = pack_b0(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]) & keep;
+        if constexpr (CM == 4) *reinterpret_cast<uint32_t*>(p) = w[0];
+        else if constexpr (CM == 8) *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);
+        else {
+#pragma unroll
+            for (int q = 0; q < CM / 16; q++) reinterpret_cast<uint4*>(p)[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < CM; k++) p[k] = (uint8_t)(v[k] & keep);
+    }
+}
+
 template <int CM, bool DIR>
 __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, const uint32_t W, const uint8_t* __restrict__ seq, const uint32_t L,
                         const uint32_t V, int32_t* ring, const uint32_t R, const uint32_t ring_w, const int match, const int mismatch, const int gap,
-                        int* lds_tot /* 2 x 16 */, uint32_t* smeta, uint32_t* sink_row, int* sink_score, uint32_t& nSinkOut) {
-    constexpr uint32_t MT = 256;   // metadata tile (rows)
+                        int* lds_tot /* 2 x 16 */, uint32_t* sink_row, int* sink_score, uint32_t& nSinkOut) {
     const uint32_t tid = threadIdx.x, NT = blockDim.x, lane = tid & 63u, wv = tid >> 6;
     const bool multi = NT > 64;
     const uint32_t ncol = L + 1;
+    const uint32_t nwa = min(NT >> 6, (ncol + 64u * CM - 1) / (64u * CM));   // waves that own a real column
+    if (wv >= nwa) {   // nothing to compute: keep the workgroup's barrier count (one per row, plus the one before the loop)
+        barrier_lds_only();
+        for (uint32_t i = 1; i <= V; i++) barrier_lds_only();
+        return;
+    }
     const uint32_t j0 = tid * CM;
-    const bool in_row = j0 < W;
-    const bool owns_last = j0 <= L && L < j0 + CM;
+    const bool live = j0 <= L;                       // the chunk holds at least one real column: only such chunks touch HBM
+    const bool owns_last = live && L < j0 + CM;
     const uint32_t klast = owns_last ? L - j0 : 0;
     using mask_t = typename std::conditional<(CM <= 32), uint32_t, uint64_t>::type;
     mask_t eq[4] = {0, 0, 0, 0};     // bit k of eq[c] = the base under column j0+k is c
@@ -371,31 +448,42 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
 #pragma unroll
         for (int c = 0; c < 4; c++) eq[c] |= (mask_t)(b == (uint32_t)c ? 1u : 0u) << k;
     }
-    const int dsc = match - mismatch;
-    const int jg0 = (int)j0 * gap;
-    int t[CM];                                          // row i-1, then row i
+    const int mm64 = mismatch * 64, g64 = gap * 64, dsc64 = (match - mismatch) * 64;
+    const int jg0 = (int)j0 * g64;
+    auto sbit = [](mask_t m, int k) -> int {   // 0 or -1
+        if constexpr (CM <= 32) return __builtin_amdgcn_sbfe((int)m, k, 1); else return -(int)((m >> k) & 1u);
+    };
+    int t[CM];                                          // row i-1, then row i: 64 x score
 #pragma unroll
-    for (int k = 0; k < CM; k++) t[k] = jg0 + k * gap;  // row 0
-    int left_prev = tid > 0 ? jg0 - gap : NEG;          // H[i-1][j0-1]
-    if (in_row) store_chunk_i32<CM>(H + j0, t);         // row 0 stays in HBM: virtual predecessor of every source node
+    for (int k = 0; k < CM; k++) t[k] = jg0 + k * g64;  // row 0
+    int left_prev = tid > 0 ? jg0 - g64 : NEGK;         // 64 x H[i-1][j0-1]
+    if (!DIR && live) {                                 // the score-matrix traceback reads row 0 like any other row
+        int pl[CM];
+#pragma unroll
+        for (int k = 0; k < CM; k++) pl[k] = t[k] >> 6;
+        store_chunk_i32<CM>(H + j0, pl);
+    }
     uint32_t nkept = 0;                                 // kept rows produced so far (ring slot counter; mirrors the CSR build)
     uint32_t nsink = 0;
-    if (multi) __syncthreads();
+    // row records of 64 rows per register, the next batch in flight
+    uint32_t mC = 0, aC = 0, bC = 0, oC = 0, mN = 0, aN = 0, bN = 0, oN = 0;
+    auto fetch = [&](uint32_t base, uint32_t& m, uint32_t& a, uint32_t& b, uint32_t& o) {
+        const uint32_t r = base + lane;
+        if (r < V) { m = g.row_meta[r]; a = g.row_pred0[r]; b = g.row_pred1[r]; o = g.row_pred_off[r]; }
+    };
+    fetch(0, mC, aC, bC, oC);
+    fetch(64, mN, aN, bN, oN);
+    if (multi) barrier_lds_only();
+    int32_t* hrow = H;
+    uint8_t* drow = D;
     for (uint32_t i = 1; i <= V; i++) {
-        const uint32_t ti = (i - 1) & (MT - 1);
-        if (ti == 0) {   // metadata tile through LDS (a per-row uniform global load would put an L2 round trip on every row)
-            if (multi) __syncthreads();
-            for (uint32_t q = tid; q < MT && i - 1 + q < V; q += NT) {
-                smeta[0 * MT + q] = g.row_meta[i - 1 + q]; smeta[1 * MT + q] = g.row_pred0[i - 1 + q];
-                smeta[2 * MT + q] = g.row_pred1[i - 1 + q]; smeta[3 * MT + q] = g.row_pred_off[i - 1 + q];
-            }
-            if (multi) __syncthreads();
-        }
-        const uint32_t meta = smeta[ti], p0 = smeta[MT + ti], p1 = smeta[2 * MT + ti], po = smeta[3 * MT + ti];
+        const uint32_t ri = (i - 1) & 63u;
+        if (ri == 0 && i > 1) { mC = mN; aC = aN; bC = bN; oC = oN; fetch(i - 1 + 64, mN, aN, bN, oN); }
+        const uint32_t meta = __builtin_amdgcn_readlane(mC, ri), p0 = __builtin_amdgcn_readlane(aC, ri);
         const uint32_t rc = meta & 3u, npred = meta >> 8;
         const mask_t mask = rc == 0 ? eq[0] : rc == 1 ? eq[1] : rc == 2 ? eq[2] : eq[3];
-        int nt[CM];
-        uint32_t dcode[CM];
+        hrow += W;
+        if (DIR) drow += W;
         auto load_pred = [&](uint32_t ent, int (&hp)[CM], int& left) {
             const uint32_t loc = ent >> 28;
             if (loc == 0) {                 // previous row: registers
@@ -406,99 +494,78 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
                 const int32_t* S = ring + (size_t)(loc - 1) * ring_w;
 #pragma unroll
                 for (int k = 0; k < CM; k++) hp[k] = S[k * NT + tid];
-                left = tid > 0 ? S[(CM - 1) * NT + tid - 1] : NEG;
-            } else if (in_row) {            // kept row that fell out of the ring: HBM (spill stores were drained before the barrier that followed them)
+                left = tid > 0 ? S[(CM - 1) * NT + tid - 1] : NEGK;
+            } else if (live) {              // kept row that fell out of the ring: HBM (spill stores were drained before the barrier that followed them)
                 const int32_t* Gp = H + (uint64_t)((ent & 0x0fffffffu) + 1) * W + j0;
                 load_chunk_i32<CM>(Gp, hp);
-                left = j0 > 0 ? Gp[-1] : NEG;
+                left = j0 > 0 ? Gp[-1] : NEGK;
+                if (!DIR) {                 // the score matrix holds plain scores
+#pragma unroll
+                    for (int k = 0; k < CM; k++) hp[k] <<= 6;
+                    if (j0 > 0) left <<= 6;
+                }
             } else {
 #pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] = NEG;
-                left = NEG;
+                for (int k = 0; k < CM; k++) hp[k] = NEGK;
+                left = NEGK;
             }
         };
-        auto load_row0 = [&](int (&hp)[CM], int& left) {   // virtual predecessor of a source node
-            if (i == 1) {
-#pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] = t[k];
-                left = left_prev;
-            } else if (in_row) {
-                if (!multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                load_chunk_i32<CM>(H + j0, hp);
-                left = j0 > 0 ? H[j0 - 1] : NEG;
-            } else {
-#pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] = NEG;
-                left = NEG;
-            }
-        };
-        if (npred <= 1) {   // one predecessor (or the virtual row 0): no arg-max bookkeeping
+        int m[CM];
+        int bd[CM], bv[CM];   // several predecessors: best diagonal / vertical key with 63 - slot in the low bits
+        if (npred <= 1) {   // one predecessor (or the virtual row 0)
             int hp[CM], left;
-            if (npred == 0) load_row0(hp, left); else load_pred(p0, hp, left);
+            if (npred == 0) {
+#pragma unroll
+                for (int k = 0; k < CM; k++) hp[k] = jg0 + k * g64;
+                left = tid > 0 ? jg0 - g64 : NEGK;
+            } else load_pred(p0, hp, left);
 #pragma unroll
             for (int k = 0; k < CM; k++) {
-                const int dg = (k == 0 ? left : hp[k - 1]) + mismatch + (dsc & -(int)((mask >> k) & 1u));
-                const int up = hp[k] + gap;
-                nt[k] = max(dg, up);
-                dcode[k] = dg >= up ? 0u : 1u;     // diagonal is tried first
+                const int dg = (k == 0 ? left : hp[k - 1]) + ((mm64 + 63) + (dsc64 & sbit(mask, k)));
+                const int up = hp[k] + (g64 + 62);
+                m[k] = max(dg, up);
             }
         } else {
-            int bd[CM], bv[CM];
-            uint32_t pp[CM];   // first predecessor slot reaching the diagonal maximum (bits 0-7) / the vertical maximum (bits 8-15)
+            const uint32_t p1 = __builtin_amdgcn_readlane(bC, ri), po = __builtin_amdgcn_readlane(oC, ri);
+            int sK[CM];
 #pragma unroll
-            for (int k = 0; k < CM; k++) { bd[k] = NEG; bv[k] = NEG; pp[k] = 0; }
+            for (int k = 0; k < CM; k++) { sK[k] = mm64 + (dsc64 & sbit(mask, k)); bd[k] = NEGK; bv[k] = NEGK; }
             for (uint32_t p = 0; p < npred; p++) {
                 int hp[CM], left;
                 load_pred(p == 0 ? p0 : p == 1 ? p1 : g.pred_rank[po + p], hp, left);
+                const int cd = DIR ? 63 - (int)p : 0;   // direction bytes exist only for edges with <= 63 sequences, i.e. <= 63 in-edges per node
+                const int gc = g64 + cd;
 #pragma unroll
                 for (int k = 0; k < CM; k++) {
-                    const int dg = (k == 0 ? left : hp[k - 1]) + mismatch + (dsc & -(int)((mask >> k) & 1u));
-                    const int up = hp[k] + gap;
-                    if (dg > bd[k]) { bd[k] = dg; pp[k] = (pp[k] & 0xff00u) | p; }          // strict '>' keeps the first predecessor reaching the maximum
-                    if (up > bv[k]) { bv[k] = up; pp[k] = (pp[k] & 0x00ffu) | (p << 8); }
+                    bd[k] = max(bd[k], (k == 0 ? left : hp[k - 1]) + sK[k] + cd);
+                    bv[k] = max(bv[k], hp[k] + gc);
                 }
             }
 #pragma unroll
-            for (int k = 0; k < CM; k++) {
-                nt[k] = max(bd[k], bv[k]);
-                dcode[k] = bd[k] >= bv[k] ? ((pp[k] & 0xffu) << 2) : (((pp[k] >> 8) << 2) | 1u);
-            }
+            for (int k = 0; k < CM; k++) m[k] = max(bd[k] | 63, (bv[k] | 63) - 1);
         }
-        // chunk-local horizontal recurrence: a horizontal move is recorded only when strictly better (it is tried last)
-        int run = NEG;
+        // chunk-local horizontal recurrence (type 1 loses every tie)
 #pragma unroll
-        for (int k = 0; k < CM; k++) {
-            const int hz = run + gap;
-            if (hz > nt[k]) { nt[k] = hz; dcode[k] = 2u; }
-            run = nt[k];
-        }
-        // prefix maximum over the lanes to the left of (chunk end value - its column * gap)
-        const int inc = wave_scan_max(run - (jg0 + (CM - 1) * gap));
-        int ex = wave_shift_up1(inc, NEG);
+        for (int k = 1; k < CM; k++) m[k] = max(m[k], (m[k - 1] & ~63) + (g64 + 1));
+        // prefix maximum over the lanes to the left of (chunk end score - its column * gap)
+        const int inc = wave_incl_max((m[CM - 1] & ~63) - (jg0 + (CM - 1) * g64));
+        int ex = wave_shift_up1(inc, NEGK);
         if (multi) {
             int* tot = lds_tot + (i & 1u) * 16;
             if (lane == 63) tot[wv] = inc;
             // One barrier per row. A spilled row is read back by other waves only 2+ rows later, but its stores must have left this
             // wave before the barrier that the readers also pass: rows that spill drain vmcnt first, all others wait for LDS only.
             if (meta & 8u) __syncthreads(); else barrier_lds_only();
-            const int nw = NT >> 6;
-            const int w16 = (int)(lane & 15u);
-            int x0 = w16 < nw ? tot[w16] : NEG, x = x0;
-            x = max(x, __builtin_amdgcn_update_dpp(NEG, x0, 0x111, 0xf, 0xf, false));
-            x = max(x, __builtin_amdgcn_update_dpp(NEG, x0, 0x112, 0xf, 0xf, false));
-            x = max(x, __builtin_amdgcn_update_dpp(NEG, x0, 0x113, 0xf, 0xf, false));
-            x = max(x, __builtin_amdgcn_update_dpp(NEG, x, 0x114, 0xf, 0xe, false));
-            x = max(x, __builtin_amdgcn_update_dpp(NEG, x, 0x118, 0xf, 0xc, false));
+            const uint32_t w16 = lane & 15u;
+            const int x = row16_incl_max(w16 < nwa ? tot[w16] : NEGK);
             if (wv > 0) ex = max(ex, __builtin_amdgcn_readlane(x, wv - 1));
         }
-        if (ex > NEG / 2) {
-            const int base = ex + jg0;
+        const int base = ex + jg0;            // 64 x (score reaching column j0 through a horizontal move from the left neighbour)
 #pragma unroll
-            for (int k = 0; k < CM; k++) { const int via = base + k * gap; if (via > nt[k]) { nt[k] = via; dcode[k] = 2u; } }
-            left_prev = base - gap;     // H[i][j0-1]: the exclusive prefix already is the finished value left of this chunk
-        } else left_prev = NEG;
+        for (int k = 0; k < CM; k++) m[k] = max(m[k], base + (k * g64 + 1));
+        left_prev = base - g64;               // 64 x H[i][j0-1]: the exclusive prefix already is the finished value left of this chunk
 #pragma unroll
-        for (int k = 0; k < CM; k++) t[k] = nt[k];
+        for (int k = 0; k < CM; k++) t[k] = m[k] & ~63;
         if (meta & 16u) {   // kept row: a later row reads it as a non-adjacent predecessor
             if (R) {
                 int32_t* S = ring + (size_t)(nkept & (R - 1)) * ring_w;
@@ -507,15 +574,35 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
             }
             nkept++;
         }
-        if (in_row) {
-            if (!DIR || (meta & 8u)) store_chunk_i32<CM>(H + (uint64_t)i * W + j0, t);   // score row to HBM only if the traceback or a far successor needs it
-            if (DIR) store_chunk_u8<CM>(D + (uint64_t)i * W + j0, dcode);
+        if (live) {
+            if (DIR) {
+                if (meta & 8u) { store_chunk_i32<CM>(hrow + j0, t); if (!multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // far successor: keys
+                uint32_t dc[CM];
+                if (npred <= 1) {
+#pragma unroll
+                    for (int k = 0; k < CM; k++) dc[k] = (uint32_t)m[k];
+                    store_dirs<CM>(drow + j0, dc, 0x03030303u);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < CM; k++) {
+                        const uint32_t sel = (uint32_t)((m[k] & 1) ? bd[k] : bv[k]);
+                        dc[k] = (((sel & 63u) ^ 63u) << 2) | ((uint32_t)m[k] & 3u);
+                    }
+                    store_dirs<CM>(drow + j0, dc, 0xffffffffu);
+                }
+            } else {
+                int pl[CM];
+#pragma unroll
+                for (int k = 0; k < CM; k++) pl[k] = t[k] >> 6;
+                store_chunk_i32<CM>(hrow + j0, pl);
+                if (!multi && (meta & 8u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
         if (owns_last && (meta & 4u)) {   // sink node: candidate end of the global alignment
-            int v = NEG;
+            int v = NEGK;
 #pragma unroll
             for (int k = 0; k < CM; k++) if ((uint32_t)k == klast) v = t[k];
-            if (nsink < SINK_CAP) { sink_row[nsink] = i; sink_score[nsink] = v; }
+            if (nsink < SINK_CAP) { sink_row[nsink] = i; sink_score[nsink] = v >> 6; }
             nsink++;
         }
     }
@@ -560,7 +647,6 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     const uint32_t W = (ED.lmax + 1 + 15) & ~15u;   // row stride, padded so that every lane chunk is vector-aligned
 
     __shared__ int lds_i[32];
-    __shared__ uint32_t smeta[4 * 256];
     __shared__ uint32_t lds_u[16];
     __shared__ uint32_t sV, sE, sNaln, sOk, sNsink, sNcand, sBestKey;
     __shared__ int sBestI;
@@ -608,7 +694,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
             {
                 const uint32_t cm = (L + 1 + NT - 1) / NT;     // columns per lane for this sequence
                 uint32_t ns = 0xffffffffu;
-#define HX_DP(CMV) dp_rows<CMV, DIR>(g, H, Dm, W, seq, L, V, ring, R, ring_w, match, mismatch, gap, lds_i, smeta, sink_row, sink_score, ns)
+#define HX_DP(CMV) dp_rows<CMV, DIR>(g, H, Dm, W, seq, L, V, ring, R, ring_w, match, mismatch, gap, lds_i, sink_row, sink_score, ns)
                 if (cm <= 4) HX_DP(4); else if (cm <= 8) HX_DP(8); else if (cm <= 16) HX_DP(16);
                 else if (cm <= 32) { if constexpr (CMMAX >= 32) HX_DP(32); else sOk = 2; }   // the host never asks a 16-column kernel for more
                 else { if constexpr (CMMAX >= 64) HX_DP(64); else sOk = 2; }
@@ -648,12 +734,12 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                     uint32_t pi_ = i, pj_ = j;
                     if (i == 0) pj_ = j - 1;   // only horizontal moves in the virtual row
                     else {
-                        const uint8_t d = Dm[(uint64_t)i * W + j];
-                        if ((d & 3u) == 2u) pj_ = j - 1;
+                        const uint8_t d = Dm[(uint64_t)i * W + j];   // type 3 diagonal / 2 vertical / 1 horizontal, predecessor slot in bits 2-7
+                        if ((d & 3u) == 1u) pj_ = j - 1;
                         else {
                             const uint32_t np = g.row_meta[i - 1] >> 8, slot = d >> 2;
                             pi_ = np == 0 ? 0u : ((slot == 0 ? g.row_pred0[i - 1] : slot == 1 ? g.row_pred1[i - 1] : g.pred_rank[g.row_pred_off[i - 1] + slot]) & 0x0fffffffu) + 1;
-                            if ((d & 3u) == 0u) pj_ = j - 1;
+                            if ((d & 3u) == 3u) pj_ = j - 1;
                         }
                     }
                     g.aln_node[na] = i == pi_ ? -1 : (int32_t)g.rank2node[i - 1];
