@@ -524,8 +524,8 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     DV<uint32_t>&d_order = c->poa_order, &d_len = c->poa_len, &d_status = c->poa_status;
     DV<char>& d_cns = c->poa_cns;
     DV<unsigned long long>& d_phase = c->poa_phase_d;
-    HIPCHK(d_phase.reserve((size_t)ne * 6));
-    HIPCHK(hipMemsetAsync(d_phase.p, 0, std::max<size_t>(1, (size_t)ne * 6) * 8, s));
+    HIPCHK(d_phase.reserve((size_t)ne * 12));
+    HIPCHK(hipMemsetAsync(d_phase.p, 0, std::max<size_t>(1, (size_t)ne * 12) * 8, s));
     bool worst_case = false;
     while (!todo.empty()) {
         // ---- workspace sizes; estimated graph capacity first, the proven worst case on retry
@@ -644,8 +644,8 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     }
     unsigned long long cells = 0;
     HIPCHK(hipMemcpy(&cells, d_cells.p, 8, hipMemcpyDeviceToHost));
-    c->poa_phase.assign((size_t)ne * 6, 0);
-    if (ne) HIPCHK(hipMemcpy(c->poa_phase.data(), d_phase.p, (size_t)ne * 6 * 8, hipMemcpyDeviceToHost));
+    c->poa_phase.assign((size_t)ne * 12, 0);
+    if (ne) HIPCHK(hipMemcpy(c->poa_phase.data(), d_phase.p, (size_t)ne * 12 * 8, hipMemcpyDeviceToHost));
     std::vector<uint64_t> off((size_t)ne + 1, 0);
     for (uint32_t e = 0; e < ne; e++) off[e + 1] = off[e] + cns[e].size();
     out->n_edge = ne;
@@ -666,13 +666,20 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
     // sum over edges and the breakdown of the edge with the largest total (the critical path)
     for (int k = 0; k < 6; k++) { sum6[k] = 0; max6[k] = 0; }
     unsigned long long best = 0;
-    size_t ne = c->poa_phase.size() / 6;
+    size_t ne = c->poa_phase.size() / 12;
     for (size_t e = 0; e < ne; e++) {
         unsigned long long t = 0;
-        for (int k = 0; k < 6; k++) { sum6[k] += c->poa_phase[e * 6 + k]; t += c->poa_phase[e * 6 + k]; }
-        if (t > best) { best = t; for (int k = 0; k < 6; k++) max6[k] = c->poa_phase[e * 6 + k]; c->dbg_slowest = (uint32_t)e; }
+        for (int k = 0; k < 6; k++) { sum6[k] += c->poa_phase[e * 12 + k]; t += c->poa_phase[e * 12 + k]; }
+        if (t > best) { best = t; for (int k = 0; k < 6; k++) max6[k] = c->poa_phase[e * 12 + k]; c->dbg_slowest = (uint32_t)e; }
     }
-    if (getenv("HX_DEBUG") && ne) fprintf(stderr, "[hx] slowest edge %u: lmax=%u nseq=%u\n", c->dbg_slowest, c->dbg_lmax[c->dbg_slowest], c->dbg_nseq[c->dbg_slowest]);
+    if (getenv("HX_DEBUG") && ne) {
+        const unsigned long long* q = &c->poa_phase[(size_t)c->dbg_slowest * 12];
+        fprintf(stderr, "[hx] slowest edge %u: lmax=%u nseq=%u | DP rows %llu (multi-pred %llu, ring refs %llu, far refs %llu, kept %llu) over %llu sequences\n", c->dbg_slowest,
+                c->dbg_lmax[c->dbg_slowest], c->dbg_nseq[c->dbg_slowest], q[6], q[7], q[8], q[9], q[10], q[11]);
+        unsigned long long tot[6] = {0, 0, 0, 0, 0, 0};
+        for (size_t e = 0; e < ne; e++) for (int k = 0; k < 6; k++) tot[k] += c->poa_phase[e * 12 + 6 + k];
+        fprintf(stderr, "[hx] all edges: DP rows %llu (multi-pred %llu, ring refs %llu, far refs %llu, kept %llu) over %llu sequences\n", tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]);
+    }
     return (uint32_t)ne;
 }
 extern "C" void hx_set_poa_traceback(hx_ctx* c, int use_direction_bytes) { c->poa_no_dir = !use_direction_bytes; }

@@ -471,35 +471,30 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
         const uint32_t r = base + lane;
         if (r < V) { m = g.row_meta[r]; a = g.row_pred0[r]; b = g.row_pred1[r]; o = g.row_pred_off[r]; }
     };
-    fetch(0, mC, aC, bC, oC);
-    fetch(64, mN, aN, bN, oN);
+    fetch(0, mN, aN, bN, oN);
     if (multi) barrier_lds_only();
     int32_t* hrow = H;
     uint8_t* drow = D;
-    for (uint32_t i = 1; i <= V; i++) {
-        const uint32_t ri = (i - 1) & 63u;
-        if (ri == 0 && i > 1) { mC = mN; aC = aN; bC = bN; oC = oN; fetch(i - 1 + 64, mN, aN, bN, oN); }
-        const uint32_t meta = __builtin_amdgcn_readlane(mC, ri), p0 = __builtin_amdgcn_readlane(aC, ri);
-        const uint32_t rc = meta & 3u, npred = meta >> 8;
-        const mask_t mask = rc == 0 ? eq[0] : rc == 1 ? eq[1] : rc == 2 ? eq[2] : eq[3];
-        hrow += W;
-        if (DIR) drow += W;
-        auto load_pred = [&](uint32_t ent, int (&hp)[CM], int& left) {
-            const uint32_t loc = ent >> 28;
-            if (loc == 0) {                 // previous row: registers
+    // Run f(row, left) on a predecessor row, wherever it lives. Every source gets its OWN copy of the consumer code: were the rows
+    // merged into one register set first, the compiler would have to wait for "possibly pending" global loads (vmcnt 0, i.e. also for
+    // the previous row's direction-byte store) on every row, although almost every row takes the register path.
+    auto with_pred = [&](const uint32_t ent, auto&& f) {
+        const uint32_t loc = ent >> 28;
+        if (loc == 0) f(t, left_prev);     // the previous row: the lane's own registers
+        else if (loc != 15) {              // kept row in the LDS ring
+            int hp[CM], left;
+            const int32_t* S = ring + (size_t)(loc - 1) * ring_w;
 #pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] = t[k];
-                left = left_prev;
-            } else if (loc != 15) {         // kept row in the LDS ring
-                const int32_t* S = ring + (size_t)(loc - 1) * ring_w;
-#pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] = S[k * NT + tid];
-                left = tid > 0 ? S[(CM - 1) * NT + tid - 1] : NEGK;
-            } else if (live) {              // kept row that fell out of the ring: HBM (spill stores were drained before the barrier that followed them)
+            for (int k = 0; k < CM; k++) hp[k] = S[k * NT + tid];
+            left = tid > 0 ? S[(CM - 1) * NT + tid - 1] : NEGK;
+            f(hp, left);
+        } else {                           // kept row that fell out of the ring: HBM (spill stores were drained before the barrier that followed them)
+            int hp[CM], left;
+            if (live) {
                 const int32_t* Gp = H + (uint64_t)((ent & 0x0fffffffu) + 1) * W + j0;
                 load_chunk_i32<CM>(Gp, hp);
                 left = j0 > 0 ? Gp[-1] : NEGK;
-                if (!DIR) {                 // the score matrix holds plain scores
+                if (!DIR) {                // the score matrix holds plain scores
 #pragma unroll
                     for (int k = 0; k < CM; k++) hp[k] <<= 6;
                     if (j0 > 0) left <<= 6;
@@ -509,101 +504,117 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
                 for (int k = 0; k < CM; k++) hp[k] = NEGK;
                 left = NEGK;
             }
-        };
-        int m[CM];
-        int bd[CM], bv[CM];   // several predecessors: best diagonal / vertical key with 63 - slot in the low bits
-        if (npred <= 1) {   // one predecessor (or the virtual row 0)
-            int hp[CM], left;
-            if (npred == 0) {
+            f(hp, left);
+        }
+    };
+    for (uint32_t ib = 0; ib < V; ib += 64) {
+        // the batch fetched 64 rows ago becomes current (the only wait for these loads), the next one goes in flight
+        mC = mN; aC = aN; bC = bN; oC = oN;
+        fetch(ib + 64, mN, aN, bN, oN);
+        const uint32_t ie = min(64u, V - ib);
+        for (uint32_t ri = 0; ri < ie; ri++) {
+            const uint32_t i = ib + ri + 1;
+            const uint32_t meta = __builtin_amdgcn_readlane(mC, ri), p0 = __builtin_amdgcn_readlane(aC, ri);
+            const uint32_t rc = meta & 3u, npred = meta >> 8;
+            const mask_t mask = rc == 0 ? eq[0] : rc == 1 ? eq[1] : rc == 2 ? eq[2] : eq[3];
+            hrow += W;
+            if (DIR) drow += W;
+            // everything after the vertical/diagonal maxima: horizontal recurrence, scan, carry, stores. `slot(k, key)` = direction byte of cell k
+            auto finish = [&](int (&m)[CM], auto&& slot_bits, uint32_t keep) {
+                // chunk-local horizontal recurrence (type 1 loses every tie)
 #pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] = jg0 + k * g64;
-                left = tid > 0 ? jg0 - g64 : NEGK;
-            } else load_pred(p0, hp, left);
+                for (int k = 1; k < CM; k++) m[k] = max(m[k], (m[k - 1] & ~63) + (g64 + 1));
+                // prefix maximum over the lanes to the left of (chunk end score - its column * gap)
+                const int inc = wave_incl_max((m[CM - 1] & ~63) - (jg0 + (CM - 1) * g64));
+                int ex = wave_shift_up1(inc, NEGK);
+                if (multi) {
+                    int* tot = lds_tot + (i & 1u) * 16;
+                    if (lane == 63) tot[wv] = inc;
+                    // One barrier per row. A spilled row is read back by other waves only 2+ rows later, but its stores must have left this
+                    // wave before the barrier that the readers also pass: rows that spill drain vmcnt first, all others wait for LDS only.
+                    if (meta & 8u) __syncthreads(); else barrier_lds_only();
+                    const uint32_t w16 = lane & 15u;
+                    const int x = row16_incl_max(w16 < nwa ? tot[w16] : NEGK);
+                    if (wv > 0) ex = max(ex, __builtin_amdgcn_readlane(x, wv - 1));
+                }
+                const int base = ex + jg0;            // 64 x (score reaching column j0 through a horizontal move from the left neighbour)
 #pragma unroll
-            for (int k = 0; k < CM; k++) {
-                const int dg = (k == 0 ? left : hp[k - 1]) + ((mm64 + 63) + (dsc64 & sbit(mask, k)));
-                const int up = hp[k] + (g64 + 62);
-                m[k] = max(dg, up);
-            }
-        } else {
-            const uint32_t p1 = __builtin_amdgcn_readlane(bC, ri), po = __builtin_amdgcn_readlane(oC, ri);
-            int sK[CM];
+                for (int k = 0; k < CM; k++) m[k] = max(m[k], base + (k * g64 + 1));
+                left_prev = base - g64;               // 64 x H[i][j0-1]: the exclusive prefix already is the finished value left of this chunk
 #pragma unroll
-            for (int k = 0; k < CM; k++) { sK[k] = mm64 + (dsc64 & sbit(mask, k)); bd[k] = NEGK; bv[k] = NEGK; }
-            for (uint32_t p = 0; p < npred; p++) {
-                int hp[CM], left;
-                load_pred(p == 0 ? p0 : p == 1 ? p1 : g.pred_rank[po + p], hp, left);
-                const int cd = DIR ? 63 - (int)p : 0;   // direction bytes exist only for edges with <= 63 sequences, i.e. <= 63 in-edges per node
-                const int gc = g64 + cd;
+                for (int k = 0; k < CM; k++) t[k] = m[k] & ~63;
+                if (meta & 16u) {   // kept row: a later row reads it as a non-adjacent predecessor
+                    if (R) {
+                        int32_t* S = ring + (size_t)(nkept & (R - 1)) * ring_w;
+#pragma unroll
+                        for (int k = 0; k < CM; k++) S[k * NT + tid] = t[k];
+                    }
+                    nkept++;
+                }
+                if (live) {
+                    if (DIR) {
+                        if (meta & 8u) { store_chunk_i32<CM>(hrow + j0, t); if (!multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // far successor: keys
+                        uint32_t dc[CM];
+#pragma unroll
+                        for (int k = 0; k < CM; k++) dc[k] = slot_bits(k, (uint32_t)m[k]);
+                        store_dirs<CM>(drow + j0, dc, keep);
+                    } else {
+                        int pl[CM];
+#pragma unroll
+                        for (int k = 0; k < CM; k++) pl[k] = t[k] >> 6;
+                        store_chunk_i32<CM>(hrow + j0, pl);
+                        if (!multi && (meta & 8u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                }
+                if (owns_last && (meta & 4u)) {   // sink node: candidate end of the global alignment
+                    int v = NEGK;
+#pragma unroll
+                    for (int k = 0; k < CM; k++) if ((uint32_t)k == klast) v = t[k];
+                    if (nsink < SINK_CAP) { sink_row[nsink] = i; sink_score[nsink] = v >> 6; }
+                    nsink++;
+                }
+            };
+            auto cells1 = [&](const int (&hp)[CM], const int left, int (&m)[CM]) {
 #pragma unroll
                 for (int k = 0; k < CM; k++) {
-                    bd[k] = max(bd[k], (k == 0 ? left : hp[k - 1]) + sK[k] + cd);
-                    bv[k] = max(bv[k], hp[k] + gc);
+                    const int dg = (k == 0 ? left : hp[k - 1]) + ((mm64 + 63) + (dsc64 & sbit(mask, k)));
+                    const int up = hp[k] + (g64 + 62);
+                    m[k] = max(dg, up);
                 }
-            }
+            };
+            auto row1 = [&](const int (&hp)[CM], const int left) {
+                int m[CM];
+                cells1(hp, left, m);
+                finish(m, [](int, uint32_t key) { return key; }, 0x03030303u);
+            };
+            if (npred == 1) with_pred(p0, row1);
+            else if (npred == 0) {   // source node: the virtual row 0
+                int hp[CM];
 #pragma unroll
-            for (int k = 0; k < CM; k++) m[k] = max(bd[k] | 63, (bv[k] | 63) - 1);
-        }
-        // chunk-local horizontal recurrence (type 1 loses every tie)
-#pragma unroll
-        for (int k = 1; k < CM; k++) m[k] = max(m[k], (m[k - 1] & ~63) + (g64 + 1));
-        // prefix maximum over the lanes to the left of (chunk end score - its column * gap)
-        const int inc = wave_incl_max((m[CM - 1] & ~63) - (jg0 + (CM - 1) * g64));
-        int ex = wave_shift_up1(inc, NEGK);
-        if (multi) {
-            int* tot = lds_tot + (i & 1u) * 16;
-            if (lane == 63) tot[wv] = inc;
-            // One barrier per row. A spilled row is read back by other waves only 2+ rows later, but its stores must have left this
-            // wave before the barrier that the readers also pass: rows that spill drain vmcnt first, all others wait for LDS only.
-            if (meta & 8u) __syncthreads(); else barrier_lds_only();
-            const uint32_t w16 = lane & 15u;
-            const int x = row16_incl_max(w16 < nwa ? tot[w16] : NEGK);
-            if (wv > 0) ex = max(ex, __builtin_amdgcn_readlane(x, wv - 1));
-        }
-        const int base = ex + jg0;            // 64 x (score reaching column j0 through a horizontal move from the left neighbour)
-#pragma unroll
-        for (int k = 0; k < CM; k++) m[k] = max(m[k], base + (k * g64 + 1));
-        left_prev = base - g64;               // 64 x H[i][j0-1]: the exclusive prefix already is the finished value left of this chunk
-#pragma unroll
-        for (int k = 0; k < CM; k++) t[k] = m[k] & ~63;
-        if (meta & 16u) {   // kept row: a later row reads it as a non-adjacent predecessor
-            if (R) {
-                int32_t* S = ring + (size_t)(nkept & (R - 1)) * ring_w;
-#pragma unroll
-                for (int k = 0; k < CM; k++) S[k * NT + tid] = t[k];
-            }
-            nkept++;
-        }
-        if (live) {
-            if (DIR) {
-                if (meta & 8u) { store_chunk_i32<CM>(hrow + j0, t); if (!multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // far successor: keys
-                uint32_t dc[CM];
-                if (npred <= 1) {
-#pragma unroll
-                    for (int k = 0; k < CM; k++) dc[k] = (uint32_t)m[k];
-                    store_dirs<CM>(drow + j0, dc, 0x03030303u);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < CM; k++) {
-                        const uint32_t sel = (uint32_t)((m[k] & 1) ? bd[k] : bv[k]);
-                        dc[k] = (((sel & 63u) ^ 63u) << 2) | ((uint32_t)m[k] & 3u);
-                    }
-                    store_dirs<CM>(drow + j0, dc, 0xffffffffu);
-                }
+                for (int k = 0; k < CM; k++) hp[k] = jg0 + k * g64;
+                row1(hp, tid > 0 ? jg0 - g64 : NEGK);
             } else {
-                int pl[CM];
+                const uint32_t p1 = __builtin_amdgcn_readlane(bC, ri), po = __builtin_amdgcn_readlane(oC, ri);
+                int sK[CM], m[CM];
+                int bd[CM], bv[CM];   // best diagonal / vertical key with 63 - slot in the low bits
 #pragma unroll
-                for (int k = 0; k < CM; k++) pl[k] = t[k] >> 6;
-                store_chunk_i32<CM>(hrow + j0, pl);
-                if (!multi && (meta & 8u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (int k = 0; k < CM; k++) { sK[k] = mm64 + (dsc64 & sbit(mask, k)); bd[k] = NEGK; bv[k] = NEGK; }
+                for (uint32_t p = 0; p < npred; p++) {
+                    const uint32_t ent = p == 0 ? p0 : p == 1 ? p1 : g.pred_rank[po + p];
+                    const int cd = DIR ? 63 - (int)p : 0;   // direction bytes exist only for edges with <= 63 sequences, i.e. <= 63 in-edges per node
+                    const int gc = g64 + cd;
+                    with_pred(ent, [&](const int (&hp)[CM], const int left) {
+#pragma unroll
+                        for (int k = 0; k < CM; k++) {
+                            bd[k] = max(bd[k], (k == 0 ? left : hp[k - 1]) + sK[k] + cd);
+                            bv[k] = max(bv[k], hp[k] + gc);
+                        }
+                    });
+                }
+#pragma unroll
+                for (int k = 0; k < CM; k++) m[k] = max(bd[k] | 63, (bv[k] | 63) - 1);
+                finish(m, [&](int k, uint32_t key) { const uint32_t sel = (uint32_t)((key & 1u) ? bd[k] : bv[k]); return (((sel & 63u) ^ 63u) << 2) | (key & 3u); }, 0xffffffffu);
             }
-        }
-        if (owns_last && (meta & 4u)) {   // sink node: candidate end of the global alignment
-            int v = NEGK;
-#pragma unroll
-            for (int k = 0; k < CM; k++) if ((uint32_t)k == klast) v = t[k];
-            if (nsink < SINK_CAP) { sink_row[nsink] = i; sink_score[nsink] = v >> 6; }
-            nsink++;
         }
     }
     if (owns_last) nSinkOut = nsink;
@@ -616,9 +627,9 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                                             char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells, unsigned long long* phase,
                                             uint32_t ring_rows, uint32_t lds_bytes) {
     const uint32_t eidx = order[blockIdx.x];
-    __shared__ unsigned long long ph[6];             // lane-0 cycle counts: decode, dp, traceback, graph update, toposort, csr
+    __shared__ unsigned long long ph[12];            // lane-0 cycle counts: decode, dp, traceback, graph update, toposort, csr; then row statistics
     __shared__ long long tc;
-    if (threadIdx.x == 0) { for (int k = 0; k < 6; k++) ph[k] = 0; tc = clock64(); }
+    if (threadIdx.x == 0) { for (int k = 0; k < 12; k++) ph[k] = 0; tc = clock64(); }
 #define PHASE(k) do { if (tid == 0) { long long _n = clock64(); ph[k] += (unsigned long long)(_n - tc); tc = _n; } } while (0)
     const PoaEdge ED = edges[eidx];
     const uint32_t tid = threadIdx.x, NT = blockDim.x;
@@ -695,7 +706,8 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                 const uint32_t cm = (L + 1 + NT - 1) / NT;     // columns per lane for this sequence
                 uint32_t ns = 0xffffffffu;
 #define HX_DP(CMV) dp_rows<CMV, DIR>(g, H, Dm, W, seq, L, V, ring, R, ring_w, match, mismatch, gap, lds_i, sink_row, sink_score, ns)
-                if (cm <= 4) HX_DP(4); else if (cm <= 8) HX_DP(8); else if (cm <= 16) HX_DP(16);
+                if (cm <= 4) HX_DP(4); else if (cm <= 8) HX_DP(8);
+                else if (cm <= 16) { if constexpr (CMMAX >= 16) HX_DP(16); else sOk = 2; }
                 else if (cm <= 32) { if constexpr (CMMAX >= 32) HX_DP(32); else sOk = 2; }   // the host never asks a 16-column kernel for more
                 else { if constexpr (CMMAX >= 64) HX_DP(64); else sOk = 2; }
 #undef HX_DP
@@ -783,10 +795,84 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         const uint32_t V_old = sV;
         uint32_t* path = reinterpret_cast<uint32_t*>(g.score);   // node of every base of this sequence (vcap+1 words, free until the CSR build)
         uint32_t* colref = g.row_pred1;                          // column reference of every base (free until the CSR build)
-        if (tid == 0) {
-            uint32_t V2 = sV, E2 = sE;
-            if (!add_alignment(g, V2, E2, sNaln, seq, L, path, colref)) sOk = 0;
-            else { sV = V2; sE = E2; }
+        {
+            // spoa Graph::add_alignment, all lanes. A global alignment consumes every base exactly once and visits every aligned group
+            // ("column") at most once, so bases are independent: base p looks at the node it was aligned to (reuse it, reuse a same-letter
+            // member of its column, or open a new node that joins the column), and the edge (node of base p-1 -> node of base p) either
+            // exists (weight += 2) or is appended. New node / edge ids are prefix sums in base order — the ids the serial walk hands out —
+            // and every node gains at most one in-edge and one out-edge per sequence, so list appends never collide.
+            const uint32_t V0 = sV, E0 = sE, na = sNaln;
+            int32_t* anode = reinterpret_cast<int32_t*>(g.stack);   // node aligned to base p, -1 = none (horizontal move)
+            uint32_t* eref = g.stack + L;                            // existing edge into base p's node, NONE = append one
+            const bool room = V0 + L <= g.vcap && E0 + L + 1 <= g.ecap;   // worst case: every base a new node / edge
+            if (!room) { if (tid == 0) sOk = 0; }
+            else {
+                if (tid == 0) sNcand = 0;
+                for (uint32_t p = tid; p < L; p += NT) anode[p] = -2;
+                __syncthreads();
+                uint32_t nv = 0;
+                for (uint32_t k = tid; k < na; k += NT) { const int32_t pos = g.aln_pos[k]; if (pos != -1) { anode[pos] = g.aln_node[k]; nv++; } }
+                if (nv) atomicAdd(&sNcand, nv);
+                __syncthreads();
+                const bool chain = na == 0;                 // empty graph: the sequence becomes a chain
+                const bool par = chain || sNcand == L;      // always true for a global alignment
+                if (!par) {                                 // (kept for safety: the serial walk handles any alignment shape)
+                    if (tid == 0) { uint32_t V2 = V0, E2 = E0; if (!add_alignment(g, V2, E2, na, seq, L, path, colref)) sOk = 0; else { sV = V2; sE = E2; } }
+                } else {
+                    const uint32_t CH = (L + NT - 1) / NT;
+                    const uint32_t a0 = min(tid * CH, L), a1 = min(a0 + CH, L);
+                    uint32_t cnt = 0;
+                    for (uint32_t p = a0; p < a1; p++) {
+                        const uint8_t c = seq[p];
+                        const int32_t an = chain ? -1 : anode[p];
+                        uint32_t tgt = NONE;                // NONE = new node
+                        if (an >= 0) {
+                            if (g.code[an] == c) tgt = (uint32_t)an;
+                            else for (uint32_t q = 0, nq = g.n_aligned[an]; q < nq; q++) { const uint32_t a = g.aligned[3 * an + q]; if (g.code[a] == c) { tgt = a; break; } }
+                        }
+                        path[p] = tgt; colref[p] = an >= 0 ? (uint32_t)an : NONE;
+                        cnt += tgt == NONE;
+                    }
+                    uint32_t newV;
+                    uint32_t nid = V0 + block_excl_scan_add(cnt, lds_u, &newV);
+                    for (uint32_t p = a0; p < a1; p++) {
+                        if (path[p] != NONE) continue;
+                        uint32_t vv = nid;
+                        const uint32_t nn = add_node(g, vv, seq[p]);
+                        nid++;
+                        const uint32_t an = colref[p];
+                        if (an != NONE) {                   // joins the column of the node it was aligned to
+                            for (uint32_t q = 0, nq = g.n_aligned[an]; q < nq; q++) { const uint32_t a = g.aligned[3 * an + q]; push_aligned(g, nn, a); push_aligned(g, a, nn); }
+                            push_aligned(g, nn, an); push_aligned(g, an, nn);
+                        }
+                        path[p] = nn;
+                    }
+                    __syncthreads();
+                    cnt = 0;
+                    for (uint32_t p = max(a0, 1u); p < a1; p++) {
+                        const uint32_t f = path[p - 1], t = path[p];
+                        uint32_t hit = NONE;
+                        if (f < V0 && t < V0) for (uint32_t e = g.out_head[f]; e != NONE; e = g.e_next_out[e]) if (g.e_to[e] == t) { hit = e; break; }
+                        if (hit != NONE) g.e_w[hit] += 2;
+                        eref[p] = hit;
+                        cnt += hit == NONE;
+                    }
+                    uint32_t newE;
+                    uint32_t eid = E0 + block_excl_scan_add(cnt, lds_u, &newE);
+                    for (uint32_t p = max(a0, 1u); p < a1; p++) {
+                        if (eref[p] != NONE) continue;
+                        const uint32_t f = path[p - 1], t = path[p], e = eid++;
+                        g.e_from[e] = f; g.e_to[e] = t; g.e_w[e] = 2; g.e_next_in[e] = NONE; g.e_next_out[e] = NONE;
+                        if (g.out_tail[f] == NONE) g.out_head[f] = e; else g.e_next_out[g.out_tail[f]] = e;
+                        g.out_tail[f] = e;
+                        uint32_t* r = reinterpret_cast<uint32_t*>(&g.nrec[t]);
+                        if (g.in_tail[t] == NONE) { g.in_head[t] = e; r[0] = f; }
+                        else { g.e_next_in[g.in_tail[t]] = e; if (r[1] == NONE) r[1] = f; else r[3] |= 0x80000000u; }
+                        g.in_tail[t] = e;
+                    }
+                    if (tid == 0) { sV = V0 + newV; sE = E0 + newE; }
+                }
+            }
             PHASE(3);
         }
         __syncthreads();
@@ -898,8 +984,10 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                 uint32_t kex = block_excl_scan_add(kc, lds_u, &ktot);
                 for (uint32_t r = r0; r < r1; r++) { g.score[r] = (int32_t)kex; kex += (g.row_meta[r] >> 4) & 1u; }   // kept rows before r
                 __syncthreads();
+                uint32_t st_multi = 0, st_ring = 0, st_far = 0;
                 for (uint32_t r = r0; r < r1; r++) {
                     const uint32_t po = g.row_pred_off[r], np = g.row_meta[r] >> 8;
+                    st_multi += np >= 2;
                     for (uint32_t q = 0; q < np; q++) {
                         const uint32_t pr = g.pred_rank[po + q];
                         uint32_t loc = 0;
@@ -909,9 +997,16 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                             else { loc = 15; atomicOr(&g.row_meta[pr], 8u); }
                         }
                         const uint32_t ent = pr | (loc << 28);
+                        st_ring += loc != 0 && loc != 15; st_far += loc == 15;
                         g.pred_rank[po + q] = ent;
                         if (q == 0) g.row_pred0[r] = ent; else if (q == 1) g.row_pred1[r] = ent;
                     }
+                }
+                if (phase) {   // statistics of the rows the next DP will run over
+                    if (st_multi) atomicAdd(&ph[7], (unsigned long long)st_multi);
+                    if (st_ring) atomicAdd(&ph[8], (unsigned long long)st_ring);
+                    if (st_far) atomicAdd(&ph[9], (unsigned long long)st_far);
+                    if (tid == 0) { atomicAdd(&ph[6], (unsigned long long)V2); atomicAdd(&ph[10], (unsigned long long)ktot); atomicAdd(&ph[11], 1ull); }
                 }
             }
         }
@@ -928,7 +1023,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         else if (!sOk) { status[eidx] = HXE_POA_OVERFLOW; cns_len[eidx] = 0; }
         else { status[eidx] = 0; cns_len[eidx] = sV ? consensus(g, sV, cns + ED.cns_off) : 0; }
         PHASE(3);
-        if (phase) for (int k = 0; k < 6; k++) phase[(uint64_t)eidx * 6 + k] = ph[k];
+        if (phase) for (int k = 0; k < 12; k++) phase[(uint64_t)eidx * 12 + k] = ph[k];
     }
 }
 
