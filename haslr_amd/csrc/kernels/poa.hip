@@ -738,27 +738,53 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
             }
             __syncthreads();
             PHASE(1);
-            // =================================================== traceback (lane 0), stored reversed
-            if (tid == 0) {
-                atomicAdd(cells, (unsigned long long)V * L);
-                uint32_t i = (uint32_t)sBestI, j = L, na = 0;
-                while (DIR && !(i == 0 && j == 0)) {
-                    uint32_t pi_ = i, pj_ = j;
-                    if (i == 0) pj_ = j - 1;   // only horizontal moves in the virtual row
-                    else {
-                        const uint8_t d = Dm[(uint64_t)i * W + j];   // type 3 diagonal / 2 vertical / 1 horizontal, predecessor slot in bits 2-7
-                        if ((d & 3u) == 1u) pj_ = j - 1;
-                        else {
-                            const uint32_t np = g.row_meta[i - 1] >> 8, slot = d >> 2;
-                            pi_ = np == 0 ? 0u : ((slot == 0 ? g.row_pred0[i - 1] : slot == 1 ? g.row_pred1[i - 1] : g.pred_rank[g.row_pred_off[i - 1] + slot]) & 0x0fffffffu) + 1;
-                            if ((d & 3u) == 3u) pj_ = j - 1;
+            // =================================================== traceback, stored reversed
+            if (DIR) {
+                // Direction bytes: the first wavefront walks the path together. A tile of 16 rows x 8 columns of direction bytes (two registers)
+                // and the records of those 16 rows are fetched with one round of loads; the walk inside the tile runs on v_readlane, i.e. one
+                // memory round trip per ~6 steps instead of 3-4 dependent ones per step. Ranks are turned into node ids by all lanes afterwards.
+                if (tid < 64) {
+                    const uint32_t ln = tid;
+                    if (ln == 0) atomicAdd(cells, (unsigned long long)V * L);
+                    uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane(sBestI), j = L, na = 0;
+                    while (!(i == 0 && j == 0)) {
+                        if (i == 0) {   // only horizontal moves are left in the virtual row
+                            for (uint32_t q = ln; q < j; q += 64) { g.aln_node[na + q] = 0; g.aln_pos[na + q] = (int32_t)(j - 1 - q); }
+                            na += j; j = 0;
+                            break;
+                        }
+                        const uint32_t ti = i, tj = j, r0 = ln >> 3, c0 = ln & 7u;
+                        uint32_t b0 = 0, b1 = 0, mt = 0, q0 = 0, q1 = 0, qo = 0;
+                        if (ti > r0 && tj >= c0) b0 = Dm[(uint64_t)(ti - r0) * W + (tj - c0)];
+                        if (ti > r0 + 8 && tj >= c0) b1 = Dm[(uint64_t)(ti - r0 - 8) * W + (tj - c0)];
+                        if (ln < 16 && ti > ln) { const uint32_t rr = ti - 1 - ln; mt = g.row_meta[rr]; q0 = g.row_pred0[rr]; q1 = g.row_pred1[rr]; qo = g.row_pred_off[rr]; }
+                        for (;;) {
+                            const uint32_t dr = ti - i, idx = (dr & 7u) * 8 + (tj - j);
+                            const uint32_t d = (dr < 8 ? (uint32_t)__builtin_amdgcn_readlane((int)b0, (int)idx) : (uint32_t)__builtin_amdgcn_readlane((int)b1, (int)idx)) & 0xffu;
+                            uint32_t pi_ = i, pj_ = j;   // type 3 diagonal / 2 vertical / 1 horizontal, predecessor slot in bits 2-7
+                            if ((d & 3u) == 1u) pj_ = j - 1;
+                            else {
+                                const uint32_t np = (uint32_t)__builtin_amdgcn_readlane((int)mt, (int)dr) >> 8, slot = d >> 2;
+                                uint32_t ent;
+                                if (slot == 0) ent = (uint32_t)__builtin_amdgcn_readlane((int)q0, (int)dr);
+                                else if (slot == 1) ent = (uint32_t)__builtin_amdgcn_readlane((int)q1, (int)dr);
+                                else ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[(uint32_t)__builtin_amdgcn_readlane((int)qo, (int)dr) + slot]);
+                                pi_ = np == 0 ? 0u : (ent & 0x0fffffffu) + 1;
+                                if ((d & 3u) == 3u) pj_ = j - 1;
+                            }
+                            if (ln == 0) { g.aln_node[na] = i == pi_ ? 0 : (int32_t)i; g.aln_pos[na] = j == pj_ ? -1 : (int32_t)(j - 1); }
+                            na++;
+                            i = pi_; j = pj_;
+                            if (i == 0 || ti - i >= 16 || tj - j >= 8) break;
                         }
                     }
-                    g.aln_node[na] = i == pi_ ? -1 : (int32_t)g.rank2node[i - 1];
-                    g.aln_pos[na] = j == pj_ ? -1 : (int32_t)(j - 1);
-                    na++;
-                    i = pi_; j = pj_;
+                    if (ln == 0) sNaln = na;
                 }
+                __syncthreads();
+                for (uint32_t k = tid, nk = sNaln; k < nk; k += NT) { const int32_t r = g.aln_node[k]; g.aln_node[k] = r == 0 ? -1 : (int32_t)g.rank2node[r - 1]; }
+            } else if (tid == 0) {
+                atomicAdd(cells, (unsigned long long)V * L);
+                uint32_t i = (uint32_t)sBestI, j = L, na = 0;
                 while (!DIR && !(i == 0 && j == 0)) {
                     const int hij = H[(uint64_t)i * W + j];
                     uint32_t pi_ = i, pj_ = j;
