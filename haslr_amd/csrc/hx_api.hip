@@ -96,6 +96,7 @@ struct PoaPoolBufs {
     DV<uint32_t> row_meta, row_pred0, row_pred1;
     DV<uint4> nrec;
     DV<uint8_t> dir;
+    DV<unsigned long long> mbox; DV<int32_t> farleft, sinkbuf; DV<uint32_t> csync;   // cluster mode (edges shared by several workgroups)
 };
 }  // namespace
 
@@ -140,8 +141,8 @@ struct hx_ctx {
     std::vector<uint32_t> dbg_lmax, dbg_nseq;
     bool poa_no_dir = false;   // diagnostics: force the score-matrix traceback
     int poa_block = 0;   // 0 = automatic (lanes per edge chosen from the gap length)
-    hipStream_t poa_streams[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t poa_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t poa_streams[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t poa_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     Timer tm;
     // POA workspace lives as long as the context: allocating tens of GB per call costs more than the kernel
     PoaPoolBufs poa_pools;
@@ -193,12 +194,12 @@ extern "C" int hx_ctx_create(int device, void* stream, hx_ctx** out) {
     {   // distinct priorities map to distinct hardware queues, so the lane-count classes really run side by side
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least priority (largest number), hi = greatest
-        for (int i = 0; i < 5; i++) {
+        for (int i = 0; i < 6; i++) {
             int pr = hi + i; if (pr > lo) pr = lo;
             HIPCHK(hipStreamCreateWithPriority(&c->poa_streams[i], hipStreamNonBlocking, pr));
         }
     }
-    for (int i = 0; i < 6; i++) HIPCHK(hipEventCreateWithFlags(&c->poa_ev[i], hipEventDisableTiming));
+    for (int i = 0; i < 7; i++) HIPCHK(hipEventCreateWithFlags(&c->poa_ev[i], hipEventDisableTiming));
     HIPCHK(c->err.reserve(1));
     *out = c;
     return 0;
@@ -210,8 +211,8 @@ extern "C" void hx_ctx_destroy(hx_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->tm.a) (void)hipEventDestroy(c->tm.a);
     if (c->tm.b) (void)hipEventDestroy(c->tm.b);
-    for (int i = 0; i < 5; i++) if (c->poa_streams[i]) (void)hipStreamDestroy(c->poa_streams[i]);
-    for (int i = 0; i < 6; i++) if (c->poa_ev[i]) (void)hipEventDestroy(c->poa_ev[i]);
+    for (int i = 0; i < 6; i++) if (c->poa_streams[i]) (void)hipStreamDestroy(c->poa_streams[i]);
+    for (int i = 0; i < 7; i++) if (c->poa_ev[i]) (void)hipEventDestroy(c->poa_ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -527,6 +528,10 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     HIPCHK(d_phase.reserve((size_t)ne * 12));
     HIPCHK(hipMemsetAsync(d_phase.p, 0, std::max<size_t>(1, (size_t)ne * 12) * 8, s));
     bool worst_case = false;
+    const uint32_t cl_lanes = getenv("HX_POA_MEMBER_LANES") ? (uint32_t)atoi(getenv("HX_POA_MEMBER_LANES")) : 256;   // lanes per cluster member
+    const uint32_t cl_min = getenv("HX_POA_CLUSTER_MIN") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MIN")) : 2048;       // columns above which an edge is shared
+    const uint32_t cl_max = getenv("HX_POA_CLUSTER_MAX") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MAX")) : 8;          // members per edge at most
+    if (cl_lanes != 64 && cl_lanes != 128 && cl_lanes != 256) return fail("HX_POA_MEMBER_LANES must be 64, 128 or 256");
     while (!todo.empty()) {
         // ---- workspace sizes; estimated graph capacity first, the proven worst case on retry
         for (uint32_t e : todo) {
@@ -537,6 +542,11 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             // DP cells are keys = 64 x score + 6 tie-break bits in an int32: |score| <= 8 * (nodes + columns) must stay below 2^24
             if (vc + E.lmax + 2 >= (1ull << 21)) return fail("hx_poa_batch: POA graph of an edge exceeds 2^21 nodes + columns (score keys would overflow)");
             E.vcap = (uint32_t)vc; E.hrows = E.vcap; E.ecap = (uint32_t)(P.sumL[e] + P.nseq[e] + 1);
+            // long gaps: the DP columns of the edge are shared by several workgroups (one CU each), ~8 columns per lane
+            E.members = 1;
+            const uint32_t ncol = E.lmax + 1;
+            if (!c->poa_block && !c->poa_no_dir && P.nseq[e] <= 63 && ncol > cl_min) E.members = (uint32_t)std::min<uint64_t>(cl_max, (ncol + (uint64_t)cl_lanes * 8 - 1) / ((uint64_t)cl_lanes * 8));
+            if (E.members < 2) E.members = 1;
         }
         // largest first (block scheduling is in grid order): cost ~ rows x columns x sequences
         std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) {
@@ -547,16 +557,17 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
         size_t pos = 0;
         std::vector<uint32_t> retry;
         while (pos < todo.size()) {
-            uint64_t no = 0, eo = 0, ho = 0, so = 0, co = 0, sto = 0, ao = 0, bytes = 0;
+            uint64_t no = 0, eo = 0, ho = 0, so = 0, co = 0, sto = 0, ao = 0, clo = 0, bytes = 0;
             size_t end = pos;
             std::vector<uint32_t> batch;
             while (end < todo.size()) {
                 hxk::PoaEdge& E = P.edges[todo[end]];
                 uint64_t nn = (uint64_t)E.vcap + 1, hc = nn * (((uint64_t)E.lmax + 1 + 15) & ~15ull);   // rows padded to 16 columns (vector-aligned lane chunks)
-                uint64_t b = nn * 84 + (uint64_t)E.ecap * 24 + hc * 5 + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8;
+                const uint64_t cle = E.members > 1 ? (uint64_t)E.members * nn : 0;
+                uint64_t b = nn * 84 + (uint64_t)E.ecap * 24 + hc * 5 + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8 + cle * 12;
                 if (!batch.empty() && bytes + b > budget) break;
-                E.node_off = no; E.edge_off = eo; E.h_off = ho; E.seq_off = so; E.cns_off = co; E.stack_off = sto; E.aln_off = ao;
-                no += nn; eo += E.ecap; ho += hc; so += E.lmax; co += E.vcap; sto += 4 * nn + E.ecap; ao += nn + E.lmax + 2;
+                E.node_off = no; E.edge_off = eo; E.h_off = ho; E.seq_off = so; E.cns_off = co; E.stack_off = sto; E.aln_off = ao; E.cl_off = clo;
+                no += nn; eo += E.ecap; ho += hc; so += E.lmax; co += E.vcap; sto += 4 * nn + E.ecap; ao += nn + E.lmax + 2; clo += cle;
                 bytes += b;
                 batch.push_back(todo[end]);
                 end++;
@@ -569,42 +580,65 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             HIPCHK(B.pred_rank.reserve(eo)); HIPCHK(B.e_from.reserve(eo)); HIPCHK(B.e_to.reserve(eo)); HIPCHK(B.e_next_in.reserve(eo));
             HIPCHK(B.e_next_out.reserve(eo)); HIPCHK(B.e_w.reserve(eo)); HIPCHK(B.stack.reserve(sto)); HIPCHK(B.aln_node.reserve(ao));
             HIPCHK(B.aln_pos.reserve(ao)); HIPCHK(B.H.reserve(ho)); HIPCHK(B.dir.reserve(ho)); HIPCHK(B.row_meta.reserve(no)); HIPCHK(B.row_pred0.reserve(no)); HIPCHK(B.row_pred1.reserve(no)); HIPCHK(B.nrec.reserve(no)); HIPCHK(B.seq.reserve(so)); HIPCHK(d_cns.reserve(co));
-            HIPCHK(d_edges.reserve(ne)); HIPCHK(d_order.reserve(batch.size())); HIPCHK(d_len.reserve(ne)); HIPCHK(d_status.reserve(ne));
+            HIPCHK(B.mbox.reserve(std::max<uint64_t>(1, clo))); HIPCHK(B.farleft.reserve(std::max<uint64_t>(1, clo)));
+            HIPCHK(B.csync.reserve((size_t)ne * 8)); HIPCHK(B.sinkbuf.reserve((size_t)ne * (1 + 2 * 1024)));
+            HIPCHK(hipMemsetAsync(B.csync.p, 0, (size_t)ne * 8 * 4, s));
+            if (clo) HIPCHK(hipMemsetAsync(B.mbox.p, 0, clo * 8, s));   // tag 0 = nothing published
+            uint64_t n_blocks_total = 0;
+            for (uint32_t e : batch) n_blocks_total += P.edges[e].members;
+            HIPCHK(d_edges.reserve(ne)); HIPCHK(d_order.reserve(n_blocks_total)); HIPCHK(d_len.reserve(ne)); HIPCHK(d_status.reserve(ne));
             // lanes per edge. Gaps up to 2047 bases: ONE wavefront per edge (row in registers, no barriers, many edges per CU).
             // Longer gaps: a multi-wave workgroup with ~8 columns per lane (256..1024 lanes). One launch per class, classes run concurrently.
-            static const int kClassNT[5] = {1024, 512, 256, 128, 64};
+            // Class 0 = edges shared by several workgroups (cluster members of cl_lanes lanes); classes 1..5 = one workgroup per edge.
+            static const int kClassNT[6] = {0, 1024, 512, 256, 128, 64};
             const uint32_t wave_max = getenv("HX_POA_WAVE_MAX") ? (uint32_t)atoi(getenv("HX_POA_WAVE_MAX")) : 512;   // columns handled by ONE wavefront per edge
             const uint32_t cols_per_lane = getenv("HX_POA_COLS") ? (uint32_t)atoi(getenv("HX_POA_COLS")) : 8;
-            std::vector<uint32_t> cls_list[5];
-            uint32_t cls_cm[5] = {1, 1, 1, 1, 1};
-            bool cls_dir[5] = {true, true, true, true, true};
+            std::vector<uint32_t> cls_list[6];
+            uint32_t cls_cm[6] = {1, 1, 1, 1, 1, 1};
+            bool cls_dir[6] = {true, true, true, true, true, true};
             for (uint32_t e : batch) {
                 const uint32_t ncol = P.edges[e].lmax + 1;
-                static const uint32_t kMaxCm[5] = {8, 16, 32, 32, 32};   // columns per lane each kernel variant keeps in registers
-                int k = 4;
-                if (c->poa_block) { for (k = 0; k < 4 && kClassNT[k] > c->poa_block; k++) {} }
-                else if (ncol > wave_max) { k = 3; while (k > 0 && (uint64_t)kClassNT[k] * cols_per_lane < ncol) k--; }
-                while (k > 0 && (uint64_t)kClassNT[k] * kMaxCm[k] < ncol) k--;
                 if (ncol > 65536) return fail("hx_poa_batch: gap sub-sequence longer than 65535 bases is not supported by the POA kernel");
+                if (P.edges[e].members > 1) {
+                    const uint32_t lanes = P.edges[e].members * cl_lanes;
+                    uint32_t cm = (ncol + lanes - 1) / lanes, cmr = 4;
+                    while (cmr < cm) cmr <<= 1;
+                    if (cmr > 32) return fail("hx_poa_batch: gap too long for the configured cluster size (raise HX_POA_CLUSTER_MAX)");
+                    cls_cm[0] = std::max(cls_cm[0], cmr);
+                    cls_list[0].push_back(e);
+                    continue;
+                }
+                static const uint32_t kMaxCm[6] = {0, 8, 16, 32, 32, 32};   // columns per lane each kernel variant keeps in registers
+                int k = 5;
+                if (c->poa_block) { for (k = 1; k < 5 && kClassNT[k] > c->poa_block; k++) {} }
+                else if (ncol > wave_max) { k = 4; while (k > 1 && (uint64_t)kClassNT[k] * cols_per_lane < ncol) k--; }
+                while (k > 1 && (uint64_t)kClassNT[k] * kMaxCm[k] < ncol) k--;
                 cls_list[k].push_back(e);   // batch is cost-sorted, so every class list is too
                 uint32_t cm = (ncol + kClassNT[k] - 1) / kClassNT[k], cmr = 4;
                 while (cmr < cm) cmr <<= 1;
                 cls_cm[k] = std::max(cls_cm[k], cmr);
                 if (P.nseq[e] > 63 || c->poa_no_dir) cls_dir[k] = false;   // in-degree <= #sequences must fit the 6-bit predecessor slot
             }
-            std::vector<uint32_t> order_all;
-            for (int k = 0; k < 5; k++) order_all.insert(order_all.end(), cls_list[k].begin(), cls_list[k].end());
+            std::vector<uint32_t> order_all;   // one entry per workgroup: edge | member << 24
+            size_t cls_blocks[6];
+            for (int k = 0; k < 6; k++) {
+                const size_t before = order_all.size();
+                for (uint32_t e : cls_list[k]) for (uint32_t m = 0; m < P.edges[e].members; m++) order_all.push_back(e | (m << 24));
+                cls_blocks[k] = order_all.size() - before;
+            }
+            if (ne >= (1u << 24)) return fail("hx_poa_batch: more than 2^24 edges in one call");
             HIPCHK(hipMemcpyAsync(d_edges.p, P.edges.data(), (size_t)ne * sizeof(hxk::PoaEdge), hipMemcpyHostToDevice, s));
             HIPCHK(hipMemcpyAsync(d_order.p, order_all.data(), order_all.size() * 4, hipMemcpyHostToDevice, s));
             hxk::PoaPools pools{B.code.p, B.n_aligned.p, B.aligned.p, B.in_head.p, B.in_tail.p, B.out_head.p, B.out_tail.p, B.rank2node.p, B.node2rank.p,
                                 B.mark.p, B.check.p, B.stack.p, B.score.p, B.pred.p, B.row_code.p, B.row_sink.p, B.row_pred_off.p, B.pred_rank.p, B.row_meta.p, B.row_pred0.p, B.row_pred1.p, B.nrec.p,
-                                B.e_from.p, B.e_to.p, B.e_next_in.p, B.e_next_out.p, B.e_w.p, B.aln_node.p, B.aln_pos.p, B.H.p, B.dir.p, B.seq.p};
+                                B.e_from.p, B.e_to.p, B.e_next_in.p, B.e_next_out.p, B.e_w.p, B.aln_node.p, B.aln_pos.p, B.H.p, B.dir.p, B.seq.p,
+                                B.mbox.p, B.farleft.p, B.csync.p, B.sinkbuf.p};
             c->tick();
-            HIPCHK(hipEventRecord(c->poa_ev[5], s));
+            HIPCHK(hipEventRecord(c->poa_ev[6], s));
             size_t opos = 0;
-            for (int k = 0; k < 5; k++) {
+            for (int k = 0; k < 6; k++) {
                 if (cls_list[k].empty()) continue;
-                const uint32_t nt = kClassNT[k];
+                const uint32_t nt = k == 0 ? cl_lanes : (uint32_t)kClassNT[k];
                 const uint64_t row_bytes = (uint64_t)cls_cm[k] * nt * 4;
                 const uint64_t lds_budget = nt >= 1024 ? 128 * 1024 : nt == 64 ? 32 * 1024 : 64 * 1024 * (nt / 128 > 2 ? 2 : 1);
                 uint32_t R = (uint32_t)std::min<uint64_t>(8, lds_budget / row_bytes);
@@ -616,12 +650,12 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
                     const uint64_t per_cu = (order_all.size() + 255) / 256;
                     if (per_cu < 8) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(144 * 1024, (156 * 1024) / per_cu - 6 * 1024));
                 }
-                HIPCHK(hipStreamWaitEvent(c->poa_streams[k], c->poa_ev[5], 0));
-                hxk::poa_run(d_edges.p, d_order.p + opos, (uint32_t)cls_list[k].size(), d_seqs.p, c->packed.p, c->roff.p, c->rlen.p, pools, 0, pp->match, pp->mismatch,
+                HIPCHK(hipStreamWaitEvent(c->poa_streams[k], c->poa_ev[6], 0));
+                hxk::poa_run(d_edges.p, d_order.p + opos, (uint32_t)cls_blocks[k], d_seqs.p, c->packed.p, c->roff.p, c->rlen.p, pools, 0, pp->match, pp->mismatch,
                              pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)nt, R, (uint32_t)lds_bytes, nt >= 1024 && cls_cm[k] > 8u, cls_dir[k], c->poa_streams[k]);
                 HIPCHK(hipEventRecord(c->poa_ev[k], c->poa_streams[k]));
                 HIPCHK(hipStreamWaitEvent(s, c->poa_ev[k], 0));
-                opos += cls_list[k].size();
+                opos += cls_blocks[k];
             }
             c->tock(3);
             HIPCHK(hipGetLastError());

@@ -79,6 +79,9 @@ struct PoaEdge {
     uint64_t cns_off;              // into the consensus output (bytes, capacity vcap)
     uint64_t stack_off;            // into the toposort stack pool (4*(vcap+1) + ecap entries per edge)
     uint64_t aln_off;              // into the alignment pools (vcap + lmax + 2 entries per edge)
+    uint64_t cl_off;               // into the cluster pools (members * (vcap+1) entries per edge), members > 1 only
+    uint32_t members;              // workgroups ("members", one CU each) that share this edge's DP columns; 1 = the usual single workgroup
+    uint32_t pad_;
 };
 struct PoaPools {
     // per node (pool length = sum (vcap+1))
@@ -98,8 +101,13 @@ struct PoaPools {
     int32_t* H;
     uint8_t* dir;   // traceback direction bytes, same geometry/offsets as H (used when every edge has <= 63 sequences)
     uint8_t* seq;
+    // cluster mode (an edge's DP columns spread over several workgroups):
+    unsigned long long* mbox;   // [member][row] = {tag, carry}: prefix maximum of the row through the member's last column (PoaEdge::cl_off)
+    int32_t* farleft;           // [member][row] = 64 x H[row][first column of the member - 1] of rows kept in HBM (PoaEdge::cl_off)
+    uint32_t* csync;            // 8 words per edge: go, done, V, L, error
+    int32_t* sinkbuf;           // 1 + 2*1024 words per edge: sink rows / scores when the last column lives in another member
 };
-void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_edges, const PoaSeq* seqs, const uint8_t* packed,
+void poa_run(const PoaEdge* edges, const uint32_t* order /* edge | member << 24, one entry per workgroup */, uint32_t n_blocks, const PoaSeq* seqs, const uint8_t* packed,
              const uint64_t* read_off, const uint32_t* read_len, PoaPools pools, uint64_t stack_stride_unused,
              int32_t match, int32_t mismatch, int32_t gap, char* cns, uint32_t* cns_len, uint32_t* status,
              unsigned long long* cells, unsigned long long* phase_cycles /* 6 per edge or null */, int block_threads /* multiple of 64, <= 1024 */,

@@ -361,6 +361,27 @@ template <int CM> __device__ __forceinline__ void store_chunk_u8(uint8_t* p, con
 // ---------------------------------------------------------------------------------------------------
 constexpr int32_t NEGK = -(1 << 30);   // "minus infinity" key
 
+// ---- cluster mode: the DP columns of one (large) edge are split over several workgroups ("members", one CU each, member m owns the
+// columns [m*NT*CM, (m+1)*NT*CM)). Rows stay the unit of work; what crosses a member boundary is one number per row, the prefix maximum
+// of the horizontal recurrence through the member's last column. It travels through a tagged 64-bit mailbox word per (member, row) in
+// HBM (relaxed device-scope atomics; the tag makes every word self-validating, so no fences are needed inside the DP). A member takes
+// the carries of 64 rows at a time (one coalesced load, lane r = row r of the batch, broadcast per row with v_readlane like the row
+// records), so it naturally runs one batch behind its left neighbour and polls once per 64 rows.
+struct DpCl {
+    uint32_t mem, members;            // this member / members of the edge (1: no cluster)
+    uint32_t stride;                  // rows per member in mbox / farleft (vcap + 1)
+    uint32_t tag0;                    // tag of row i = tag0 + i (rows of all DPs of the edge numbered consecutively)
+    unsigned long long* mbox;         // edge base
+    int32_t* farleft;                 // edge base
+    uint32_t* err;                    // device-visible error word of the edge (set when a poll gives up)
+    int32_t* ringleft;                // LDS, 14 words: 64 x H[kept row][first column of the member - 1] per ring slot
+};
+constexpr uint32_t POLL_LIMIT = 1u << 24;   // polls before a waiter gives up and flags an error instead of hanging the GPU
+__device__ __forceinline__ uint32_t ld_dev(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_dev64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // inclusive prefix maximum over the 64 lanes of a wave: the classic DPP sequence with the max fused into the DPP instruction
 // (lanes without a source keep their value). s_nop 1 = the two wait states a DPP read needs after a VALU write of its source.
 __device__ __forceinline__ int wave_incl_max(int v) {
@@ -425,17 +446,24 @@ template <int CM> __device__ __forceinline__ void store_dirs(uint8_t* p, const u
 template <int CM, bool DIR>
 __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, const uint32_t W, const uint8_t* __restrict__ seq, const uint32_t L,
                         const uint32_t V, int32_t* ring, const uint32_t R, const uint32_t ring_w, const int match, const int mismatch, const int gap,
-                        int* lds_tot /* 2 x 16 */, uint32_t* sink_row, int* sink_score, uint32_t& nSinkOut) {
+                        int* lds_tot /* 2 x 16 */, uint32_t* sink_row, int* sink_score, uint32_t& nSinkOut, const DpCl& cl) {
     const uint32_t tid = threadIdx.x, NT = blockDim.x, lane = tid & 63u, wv = tid >> 6;
     const bool multi = NT > 64;
     const uint32_t ncol = L + 1;
-    const uint32_t nwa = min(NT >> 6, (ncol + 64u * CM - 1) / (64u * CM));   // waves that own a real column
+    const uint32_t col0 = cl.mem * NT * CM;                                   // first column of this member
+    const uint32_t nwa = col0 >= ncol ? 0u : min(NT >> 6, (ncol - col0 + 64u * CM - 1) / (64u * CM));   // waves of this member that own a real column
+    if (nwa == 0) return;      // the whole member has nothing to do for this sequence (no barriers are counted then)
     if (wv >= nwa) {   // nothing to compute: keep the workgroup's barrier count (one per row, plus the one before the loop)
-        barrier_lds_only();
-        for (uint32_t i = 1; i <= V; i++) barrier_lds_only();
+        if (multi) { barrier_lds_only(); for (uint32_t i = 1; i <= V; i++) barrier_lds_only(); }
         return;
     }
-    const uint32_t j0 = tid * CM;
+    const uint32_t gt = cl.mem * NT + tid;                                    // lane index over all members
+    const bool has_in = cl.mem > 0;                                           // a member on the left feeds the horizontal carry
+    const bool has_out = cl.mem + 1 < cl.members && (cl.mem + 1) * NT * CM < ncol;   // a member on the right owns real columns
+    const unsigned long long* mb_in = cl.mbox + (uint64_t)(has_in ? cl.mem - 1 : 0) * cl.stride;
+    unsigned long long* mb_out = cl.mbox + (uint64_t)cl.mem * cl.stride;
+    int32_t* far_own = cl.farleft + (uint64_t)cl.mem * cl.stride;
+    const uint32_t j0 = gt * CM;
     const bool live = j0 <= L;                       // the chunk holds at least one real column: only such chunks touch HBM
     const bool owns_last = live && L < j0 + CM;
     const uint32_t klast = owns_last ? L - j0 : 0;
@@ -456,7 +484,7 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
     int t[CM];                                          // row i-1, then row i: 64 x score
 #pragma unroll
     for (int k = 0; k < CM; k++) t[k] = jg0 + k * g64;  // row 0
-    int left_prev = tid > 0 ? jg0 - g64 : NEGK;         // 64 x H[i-1][j0-1]
+    int left_prev = gt > 0 ? jg0 - g64 : NEGK;          // 64 x H[i-1][j0-1]
     if (!DIR && live) {                                 // the score-matrix traceback reads row 0 like any other row
         int pl[CM];
 #pragma unroll
@@ -486,7 +514,7 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
             const int32_t* S = ring + (size_t)(loc - 1) * ring_w;
 #pragma unroll
             for (int k = 0; k < CM; k++) hp[k] = S[k * NT + tid];
-            left = tid > 0 ? S[(CM - 1) * NT + tid - 1] : NEGK;
+            left = tid > 0 ? S[(CM - 1) * NT + tid - 1] : has_in ? cl.ringleft[loc - 1] : NEGK;
             f(hp, left);
         } else {                           // kept row that fell out of the ring: HBM (spill stores were drained before the barrier that followed them)
             int hp[CM], left;
@@ -499,6 +527,7 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
                     for (int k = 0; k < CM; k++) hp[k] <<= 6;
                     if (j0 > 0) left <<= 6;
                 }
+                if (has_in && tid == 0) left = far_own[(ent & 0x0fffffffu) + 1];   // the column on the left belongs to another CU: own copy (keys)
             } else {
 #pragma unroll
                 for (int k = 0; k < CM; k++) hp[k] = NEGK;
@@ -512,6 +541,18 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
         mC = mN; aC = aN; bC = bN; oC = oN;
         fetch(ib + 64, mN, aN, bN, oN);
         const uint32_t ie = min(64u, V - ib);
+        int cinV = NEGK;     // lane r: carry into this member for row ib + r + 1
+        if (has_in) {
+            const uint32_t row = ib + lane + 1;
+            for (uint32_t spin = 0;; spin++) {
+                unsigned long long v = 0;
+                bool ok = true;
+                if (lane < ie) { v = ld_dev64(mb_in + row); ok = (uint32_t)v == cl.tag0 + row; }
+                if (__ballot(ok) == ~0ull) { cinV = (int)(uint32_t)(v >> 32); break; }
+                if (spin > POLL_LIMIT) { if (lane == 0) st_dev(cl.err, 1u); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
         for (uint32_t ri = 0; ri < ie; ri++) {
             const uint32_t i = ib + ri + 1;
             const uint32_t meta = __builtin_amdgcn_readlane(mC, ri), p0 = __builtin_amdgcn_readlane(aC, ri);
@@ -527,6 +568,7 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
                 // prefix maximum over the lanes to the left of (chunk end score - its column * gap)
                 const int inc = wave_incl_max((m[CM - 1] & ~63) - (jg0 + (CM - 1) * g64));
                 int ex = wave_shift_up1(inc, NEGK);
+                const int cin = has_in ? __builtin_amdgcn_readlane(cinV, ri) : NEGK;
                 if (multi) {
                     int* tot = lds_tot + (i & 1u) * 16;
                     if (lane == 63) tot[wv] = inc;
@@ -536,7 +578,9 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
                     const uint32_t w16 = lane & 15u;
                     const int x = row16_incl_max(w16 < nwa ? tot[w16] : NEGK);
                     if (wv > 0) ex = max(ex, __builtin_amdgcn_readlane(x, wv - 1));
-                }
+                    if (has_out && tid == 0) st_dev64(mb_out + i, (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, __builtin_amdgcn_readlane(x, nwa - 1)) << 32));
+                } else if (has_out && lane == 0) st_dev64(mb_out + i, (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, __builtin_amdgcn_readlane(inc, 63)) << 32));
+                ex = max(ex, cin);
                 const int base = ex + jg0;            // 64 x (score reaching column j0 through a horizontal move from the left neighbour)
 #pragma unroll
                 for (int k = 0; k < CM; k++) m[k] = max(m[k], base + (k * g64 + 1));
@@ -548,9 +592,11 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
                         int32_t* S = ring + (size_t)(nkept & (R - 1)) * ring_w;
 #pragma unroll
                         for (int k = 0; k < CM; k++) S[k * NT + tid] = t[k];
+                        if (has_in && tid == 0) cl.ringleft[nkept & (R - 1)] = left_prev;
                     }
                     nkept++;
                 }
+                if (has_in && tid == 0 && (meta & 8u)) far_own[i] = left_prev;
                 if (live) {
                     if (DIR) {
                         if (meta & 8u) { store_chunk_i32<CM>(hrow + j0, t); if (!multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // far successor: keys
@@ -592,7 +638,7 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
                 int hp[CM];
 #pragma unroll
                 for (int k = 0; k < CM; k++) hp[k] = jg0 + k * g64;
-                row1(hp, tid > 0 ? jg0 - g64 : NEGK);
+                row1(hp, gt > 0 ? jg0 - g64 : NEGK);
             } else {
                 const uint32_t p1 = __builtin_amdgcn_readlane(bC, ri), po = __builtin_amdgcn_readlane(oC, ri);
                 int sK[CM], m[CM];
@@ -626,7 +672,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                                             const uint32_t* __restrict__ read_len, PoaPools P, int32_t match, int32_t mismatch, int32_t gap,
                                             char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells, unsigned long long* phase,
                                             uint32_t ring_rows, uint32_t lds_bytes) {
-    const uint32_t eidx = order[blockIdx.x];
+    const uint32_t eidx = order[blockIdx.x] & 0x00ffffffu, mem = order[blockIdx.x] >> 24;   // edge, member of its cluster (0 unless the edge is shared)
     __shared__ unsigned long long ph[12];            // lane-0 cycle counts: decode, dp, traceback, graph update, toposort, csr; then row statistics
     __shared__ long long tc;
     if (threadIdx.x == 0) { for (int k = 0; k < 12; k++) ph[k] = 0; tc = clock64(); }
@@ -650,7 +696,8 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     int32_t* H = P.H + ED.h_off;
     uint8_t* Dm = DIR ? P.dir + ED.h_off : nullptr;   // direction bytes share the score matrix' geometry
     // ring geometry is a property of the edge (its longest sequence) and of the launch
-    const uint32_t cme = (ED.lmax + 1 + NT - 1) / NT;
+    const uint32_t GM = ED.members;                  // workgroups sharing this edge's DP columns
+    const uint32_t cme = (ED.lmax + 1 + GM * NT - 1) / (GM * NT);
     const uint32_t cmr = cme <= 4 ? 4 : cme <= 8 ? 8 : cme <= 16 ? 16 : cme <= 32 ? 32 : 64;
     const uint32_t ring_w = cmr * NT;
     const uint32_t R = ring_rows >= 2 ? ring_rows : 0;
@@ -663,8 +710,60 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     __shared__ int sBestI;
     __shared__ uint32_t sink_row[SINK_CAP];
     __shared__ int sink_score[SINK_CAP];
+    __shared__ int32_t cl_ringleft[14];
+    __shared__ uint32_t sCtl;
     if (tid == 0) { sV = 0; sE = 0; sOk = 1; }
     __syncthreads();
+    uint32_t* csy = P.csync + (uint64_t)eidx * 8;                 // go, done, V, L, error
+    int32_t* sinkbuf = P.sinkbuf + (uint64_t)eidx * (1 + 2 * SINK_CAP);
+    DpCl cl;
+    cl.mem = mem; cl.members = GM; cl.stride = ED.vcap + 1; cl.tag0 = 0;
+    cl.mbox = P.mbox + ED.cl_off; cl.farleft = P.farleft + ED.cl_off; cl.err = csy + 4; cl.ringleft = cl_ringleft;
+    constexpr uint32_t CL_ABORT = 0xffffffffu;
+    auto cm_sel = [&](uint32_t Lq) -> uint32_t {   // columns per lane of the dp_rows instance that handles a sequence of Lq bases
+        const uint32_t c = (Lq + 1 + GM * NT - 1) / (GM * NT);
+        return c <= 4 ? 4u : c <= 8 ? 8u : c <= 16 ? 16u : c <= 32 ? 32u : 64u;
+    };
+#define HX_DP_DISPATCH(Lq, Vq, nsq) do { \
+        const uint32_t cm_ = ((Lq) + 1 + GM * NT - 1) / (GM * NT);     /* columns per lane for this sequence */ \
+        if (cm_ <= 4) HX_DP(4, Lq, Vq, nsq); else if (cm_ <= 8) HX_DP(8, Lq, Vq, nsq); \
+        else if (cm_ <= 16) { if constexpr (CMMAX >= 16) HX_DP(16, Lq, Vq, nsq); else sOk = 2; } \
+        else if (cm_ <= 32) { if constexpr (CMMAX >= 32) HX_DP(32, Lq, Vq, nsq); else sOk = 2; }   /* the host never asks a 16-column kernel for more */ \
+        else { if constexpr (CMMAX >= 64) HX_DP(64, Lq, Vq, nsq); else sOk = 2; } } while (0)
+#define HX_DP(CMV, Lq, Vq, nsq) dp_rows<CMV, DIR>(g, H, Dm, W, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, lds_i, sink_row, sink_score, nsq, cl)
+    if (mem > 0) {
+        // ---- member of a cluster: only the DP, over its own columns; everything else happens in member 0
+        for (uint32_t k = ED.seq_begin; k < ED.seq_end; k++) {
+            if (tid == 0) {
+                uint32_t v = 0;
+                for (uint32_t spin = 0;; spin++) {
+                    v = ld_dev(csy + 0);
+                    if (v == CL_ABORT || v >= k - ED.seq_begin + 1) break;
+                    if (spin > POLL_LIMIT) { st_dev(csy + 4, 1u); v = CL_ABORT; break; }
+                    __builtin_amdgcn_s_sleep(32);
+                }
+                sCtl = v;
+            }
+            __syncthreads();
+            if (sCtl == CL_ABORT) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // graph rows, sequence and counts written by member 0
+            const uint32_t V = ld_dev(csy + 2), L = ld_dev(csy + 3);
+            uint32_t ns = 0xffffffffu;
+            if (V > 0) HX_DP_DISPATCH(L, V, ns);
+            if (ns != 0xffffffffu) sNsink = ns;   // this member owns the last column: hand the sink rows to member 0
+            cl.tag0 += V;
+            __syncthreads();
+            if (V > 0 && L / (NT * cm_sel(L)) == mem) {   // this member owns the last column: it has recorded the sink rows
+                const uint32_t nsk = min(sNsink, SINK_CAP);
+                if (tid == 0) sinkbuf[0] = (int32_t)sNsink;
+                for (uint32_t q = tid; q < nsk; q += NT) { sinkbuf[1 + q] = (int32_t)sink_row[q]; sinkbuf[1 + SINK_CAP + q] = sink_score[q]; }
+            }
+            __threadfence();                                       // direction bytes, sink rows: visible before "done"
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(csy + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
     // The reference's topological order (spoa's DFS, inherently serial) is needed in two places only: to break ties between equally scored
     // end nodes of an alignment, and for the heaviest-bundle traversal of the finished graph. The DP itself runs on a cheaper order that
     // is maintained incrementally (see "order update" below): row values do not depend on which valid topological order is used.
@@ -703,15 +802,34 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         if (V > 0) {
             // =================================================== DP over (rank, column)
             {
-                const uint32_t cm = (L + 1 + NT - 1) / NT;     // columns per lane for this sequence
+                if (GM > 1) {   // publish this sequence to the other members: graph rows (CSR), decoded sequence, V, L
+                    __threadfence();
+                    __syncthreads();
+                    if (tid == 0) { st_dev(csy + 2, V); st_dev(csy + 3, L); __threadfence(); st_dev(csy + 0, k - ED.seq_begin + 1); }
+                }
                 uint32_t ns = 0xffffffffu;
-#define HX_DP(CMV) dp_rows<CMV, DIR>(g, H, Dm, W, seq, L, V, ring, R, ring_w, match, mismatch, gap, lds_i, sink_row, sink_score, ns)
-                if (cm <= 4) HX_DP(4); else if (cm <= 8) HX_DP(8);
-                else if (cm <= 16) { if constexpr (CMMAX >= 16) HX_DP(16); else sOk = 2; }
-                else if (cm <= 32) { if constexpr (CMMAX >= 32) HX_DP(32); else sOk = 2; }   // the host never asks a 16-column kernel for more
-                else { if constexpr (CMMAX >= 64) HX_DP(64); else sOk = 2; }
-#undef HX_DP
+                HX_DP_DISPATCH(L, V, ns);
                 if (ns != 0xffffffffu) sNsink = ns;   // written by the lane that owns column L
+                cl.tag0 += V;
+                if (GM > 1) {   // wait for the other members' columns (direction bytes, sinks)
+                    __syncthreads();
+                    if (tid == 0) {
+                        const uint32_t need = (GM - 1) * (k - ED.seq_begin + 1);
+                        for (uint32_t spin = 0;; spin++) {
+                            if (ld_dev(csy + 1) >= need) break;
+                            if (spin > POLL_LIMIT) { st_dev(csy + 4, 1u); break; }
+                            __builtin_amdgcn_s_sleep(32);
+                        }
+                    }
+                    __syncthreads();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if (L / (NT * cm_sel(L)) != 0) {   // the last column lives in another member: fetch its sink rows
+                        const uint32_t nsk_all = (uint32_t)sinkbuf[0], nsk = min(nsk_all, SINK_CAP);
+                        for (uint32_t q = tid; q < nsk; q += NT) { sink_row[q] = (uint32_t)sinkbuf[1 + q]; sink_score[q] = sinkbuf[1 + SINK_CAP + q]; }
+                        if (tid == 0) sNsink = nsk_all;
+                    }
+                    if (tid == 0 && ld_dev(csy + 4)) sOk = 2;
+                }
             }
             __syncthreads();
             // ---- end node of the global alignment: the best-scoring sink; ties go to the smallest rank in the REFERENCE's order
@@ -814,7 +932,22 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                 }
                 sNaln = na;
             }
-        } else if (tid == 0) sNaln = 0;
+        } else {
+            if (tid == 0) sNaln = 0;
+            if (GM > 1) {   // nothing to align against yet: the other members only count the sequence (and must have read V = 0 before it changes)
+                __syncthreads();
+                if (tid == 0) {
+                    st_dev(csy + 2, 0u); st_dev(csy + 3, L); __threadfence(); st_dev(csy + 0, k - ED.seq_begin + 1);
+                    const uint32_t need = (GM - 1) * (k - ED.seq_begin + 1);
+                    for (uint32_t spin = 0;; spin++) {
+                        if (ld_dev(csy + 1) >= need) break;
+                        if (spin > POLL_LIMIT) { st_dev(csy + 4, 1u); break; }
+                        __builtin_amdgcn_s_sleep(32);
+                    }
+                }
+                __syncthreads();
+            }
+        }
         __syncthreads();
         PHASE(2);
         // =================================================== graph update (lane 0) + order update (all lanes)
@@ -1039,6 +1172,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         __syncthreads();
         PHASE(5);
     }
+    if (GM > 1 && tid == 0 && sOk != 1) st_dev(csy + 0, CL_ABORT);   // release the other members
     if (sOk == 1 && sV) {   // heaviest bundle runs on the reference's topological order of the finished graph
         exact_order(sV, g.rank2node);
         for (uint32_t r = tid; r < sV; r += NT) g.node2rank[g.rank2node[r]] = r;
