@@ -96,7 +96,7 @@ struct PoaPoolBufs {
     DV<uint32_t> row_meta, row_pred0, row_pred1;
     DV<uint4> nrec;
     DV<uint8_t> dir;
-    DV<unsigned long long> mbox; DV<int32_t> farleft, sinkbuf; DV<uint32_t> csync;   // cluster mode (edges shared by several workgroups)
+    DV<unsigned long long> mbox; DV<int32_t> farleft, sinkbuf; DV<uint32_t> csync; DV<uint16_t> row_al;   // cluster mode (edges shared by several workgroups)
 };
 }  // namespace
 
@@ -531,6 +531,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     const uint32_t cl_lanes = getenv("HX_POA_MEMBER_LANES") ? (uint32_t)atoi(getenv("HX_POA_MEMBER_LANES")) : 256;   // lanes per cluster member
     const uint32_t cl_min = getenv("HX_POA_CLUSTER_MIN") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MIN")) : 2048;       // columns above which an edge is shared
     const uint32_t cl_max = getenv("HX_POA_CLUSTER_MAX") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MAX")) : 8;          // members per edge at most
+    const uint32_t cl_cols = getenv("HX_POA_CLUSTER_COLS") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_COLS")) : 8;            // columns per lane a member aims at
     if (cl_lanes != 64 && cl_lanes != 128 && cl_lanes != 256) return fail("HX_POA_MEMBER_LANES must be 64, 128 or 256");
     while (!todo.empty()) {
         // ---- workspace sizes; estimated graph capacity first, the proven worst case on retry
@@ -545,7 +546,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             // long gaps: the DP columns of the edge are shared by several workgroups (one CU each), ~8 columns per lane
             E.members = 1;
             const uint32_t ncol = E.lmax + 1;
-            if (!c->poa_block && !c->poa_no_dir && P.nseq[e] <= 63 && ncol > cl_min) E.members = (uint32_t)std::min<uint64_t>(cl_max, (ncol + (uint64_t)cl_lanes * 8 - 1) / ((uint64_t)cl_lanes * 8));
+            if (!c->poa_block && !c->poa_no_dir && P.nseq[e] <= 63 && ncol > cl_min) E.members = (uint32_t)std::min<uint64_t>(cl_max, (ncol + (uint64_t)cl_lanes * cl_cols - 1) / ((uint64_t)cl_lanes * cl_cols));
             if (E.members < 2) E.members = 1;
         }
         // largest first (block scheduling is in grid order): cost ~ rows x columns x sequences
@@ -564,7 +565,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
                 hxk::PoaEdge& E = P.edges[todo[end]];
                 uint64_t nn = (uint64_t)E.vcap + 1, hc = nn * (((uint64_t)E.lmax + 1 + 15) & ~15ull);   // rows padded to 16 columns (vector-aligned lane chunks)
                 const uint64_t cle = E.members > 1 ? (uint64_t)E.members * nn : 0;
-                uint64_t b = nn * 84 + (uint64_t)E.ecap * 24 + hc * 5 + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8 + cle * 12;
+                uint64_t b = nn * 86 + (uint64_t)E.ecap * 24 + hc * 5 + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8 + cle * 12;
                 if (!batch.empty() && bytes + b > budget) break;
                 E.node_off = no; E.edge_off = eo; E.h_off = ho; E.seq_off = so; E.cns_off = co; E.stack_off = sto; E.aln_off = ao; E.cl_off = clo;
                 no += nn; eo += E.ecap; ho += hc; so += E.lmax; co += E.vcap; sto += 4 * nn + E.ecap; ao += nn + E.lmax + 2; clo += cle;
@@ -574,7 +575,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             }
             if (bytes > budget) return fail("hx_poa_batch: a single edge needs more POA workspace than the device has free");
             HIPCHK(B.code.reserve(no)); HIPCHK(B.n_aligned.reserve(no)); HIPCHK(B.mark.reserve(no)); HIPCHK(B.check.reserve(no));
-            HIPCHK(B.row_code.reserve(no)); HIPCHK(B.row_sink.reserve(no)); HIPCHK(B.aligned.reserve(3 * no)); HIPCHK(B.in_head.reserve(no));
+            HIPCHK(B.row_code.reserve(no)); HIPCHK(B.row_sink.reserve(no)); HIPCHK(B.row_al.reserve(no)); HIPCHK(B.aligned.reserve(3 * no)); HIPCHK(B.in_head.reserve(no));
             HIPCHK(B.in_tail.reserve(no)); HIPCHK(B.out_head.reserve(no)); HIPCHK(B.out_tail.reserve(no)); HIPCHK(B.rank2node.reserve(no));
             HIPCHK(B.node2rank.reserve(no)); HIPCHK(B.row_pred_off.reserve(no)); HIPCHK(B.score.reserve(no)); HIPCHK(B.pred.reserve(no));
             HIPCHK(B.pred_rank.reserve(eo)); HIPCHK(B.e_from.reserve(eo)); HIPCHK(B.e_to.reserve(eo)); HIPCHK(B.e_next_in.reserve(eo));
@@ -609,6 +610,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
                     continue;
                 }
                 static const uint32_t kMaxCm[6] = {0, 8, 16, 32, 32, 32};   // columns per lane each kernel variant keeps in registers
+                if (ncol > 32768) return fail("hx_poa_batch: a gap longer than 32767 bases needs the shared (cluster) mode: <= 63 sequences, direction-byte traceback, automatic block size");
                 int k = 5;
                 if (c->poa_block) { for (k = 1; k < 5 && kClassNT[k] > c->poa_block; k++) {} }
                 else if (ncol > wave_max) { k = 4; while (k > 1 && (uint64_t)kClassNT[k] * cols_per_lane < ncol) k--; }
@@ -632,7 +634,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             hxk::PoaPools pools{B.code.p, B.n_aligned.p, B.aligned.p, B.in_head.p, B.in_tail.p, B.out_head.p, B.out_tail.p, B.rank2node.p, B.node2rank.p,
                                 B.mark.p, B.check.p, B.stack.p, B.score.p, B.pred.p, B.row_code.p, B.row_sink.p, B.row_pred_off.p, B.pred_rank.p, B.row_meta.p, B.row_pred0.p, B.row_pred1.p, B.nrec.p,
                                 B.e_from.p, B.e_to.p, B.e_next_in.p, B.e_next_out.p, B.e_w.p, B.aln_node.p, B.aln_pos.p, B.H.p, B.dir.p, B.seq.p,
-                                B.mbox.p, B.farleft.p, B.csync.p, B.sinkbuf.p};
+                                B.mbox.p, B.farleft.p, B.csync.p, B.sinkbuf.p, B.row_al.p};
             c->tick();
             HIPCHK(hipEventRecord(c->poa_ev[6], s));
             size_t opos = 0;
@@ -641,11 +643,11 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
                 const uint32_t nt = k == 0 ? cl_lanes : (uint32_t)kClassNT[k];
                 const uint64_t row_bytes = (uint64_t)cls_cm[k] * nt * 4;
                 const uint64_t lds_budget = nt >= 1024 ? 128 * 1024 : nt == 64 ? 32 * 1024 : 64 * 1024 * (nt / 128 > 2 ? 2 : 1);
-                uint32_t R = (uint32_t)std::min<uint64_t>(8, lds_budget / row_bytes);
-                R = R >= 8 ? 8 : R >= 4 ? 4 : R >= 2 ? 2 : 0;   // power of two (slot = kept-row counter & (R-1))
+                uint64_t rows_fit = std::min<uint64_t>(lds_budget * 9 / 8, 140 * 1024) / row_bytes;   // ring slots + 1 scratch slot
+                uint32_t R = rows_fit >= 9 ? 8 : rows_fit >= 5 ? 4 : rows_fit >= 3 ? 2 : 0;   // power of two (slot = kept-row counter & (R-1))
                 // few edges: ask for enough LDS per workgroup that the dispatcher cannot stack them on a handful of CUs while others idle
                 // (a lone wave runs at twice the speed of two waves sharing a SIMD); many edges: request only what the ring needs
-                uint64_t lds_bytes = R * row_bytes;
+                uint64_t lds_bytes = (uint64_t)(R ? R + 1 : 0) * row_bytes;   // R ring slots + the scratch slot of rows nobody keeps
                 {
                     const uint64_t per_cu = (order_all.size() + 255) / 256;
                     if (per_cu < 8) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(144 * 1024, (156 * 1024) / per_cu - 6 * 1024));

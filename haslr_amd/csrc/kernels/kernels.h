@@ -106,6 +106,7 @@ struct PoaPools {
     int32_t* farleft;           // [member][row] = 64 x H[row][first column of the member - 1] of rows kept in HBM (PoaEdge::cl_off)
     uint32_t* csync;            // 8 words per edge: go, done, V, L, error
     int32_t* sinkbuf;           // 1 + 2*1024 words per edge: sink rows / scores when the last column lives in another member
+    uint16_t* row_al;           // per rank: ranks of the node's aligned nodes in list order, 3 x 3 bits (rank delta + 4, 0 = none)
 };
 void poa_run(const PoaEdge* edges, const uint32_t* order /* edge | member << 24, one entry per workgroup */, uint32_t n_blocks, const PoaSeq* seqs, const uint8_t* packed,
              const uint64_t* read_off, const uint32_t* read_len, PoaPools pools, uint64_t stack_stride_unused,

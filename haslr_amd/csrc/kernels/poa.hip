@@ -35,6 +35,7 @@ struct G {   // per-edge views into the pools
     int32_t *score, *pred;
     uint8_t *row_code, *row_sink; uint32_t *row_pred_off, *pred_rank;
     uint32_t *row_meta, *row_pred0, *row_pred1;   // per rank: code | sink<<2 | far<<3 | npred<<8 ; ranks of the first two predecessors
+    uint16_t* row_al;                             // per rank: aligned nodes in list order as rank deltas (3 x 3 bits, delta + 4, 0 = none)
     uint4* nrec;   // per node, one 16-byte record for the serial graph walks: {1st in-edge source, 2nd in-edge source, 3 aligned ids (+1) x 21 bit, bit 63: more in-edges}
     uint32_t *e_from, *e_to, *e_next_in, *e_next_out; int32_t* e_w;
     int32_t *aln_node, *aln_pos;
@@ -127,65 +128,146 @@ constexpr uint32_t SINK_CAP = 1024;      // sink rows whose end score is kept pe
 constexpr uint32_t TOPO_LCAP = 1024;     // stack window entries
 constexpr uint32_t TOPO_LINES = 64;      // cache lines of 16 records (16 KiB)
 __device__ void toposort_coop(G& g, const uint32_t V, uint8_t* st, uint32_t* lstack, uint4* cache, uint32_t* tags, uint32_t* out) {
+    // One visit = three dependent LDS round trips instead of ten: (1) the stack top, (2) the node's state byte and its record (tag and
+    // record are read together), (3) the state bytes of ALL its candidates at once — lane 0/1 look at the two in-edge sources, lanes
+    // 2-4 at the aligned nodes — and a ballot tells which of them still have to be visited; those lanes push themselves.
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i = lane; i < TOPO_LINES; i += 64) tags[i] = NONE;
     uint32_t sp = 0, nr = 0, base = 0;
-    auto push = [&](uint32_t v) {
+    auto push1 = [&](uint32_t v) {   // scalar push (all lanes agree on v)
         if (sp - base == TOPO_LCAP) { if (lane == 0) g.stack[base] = lstack[base & (TOPO_LCAP - 1)]; base++; }
         if (lane == 0) lstack[sp & (TOPO_LCAP - 1)] = v;
         sp++;
     };
-    auto record = [&](uint32_t n) -> uint4 {
-        const uint32_t line = n >> 4, slot = line & (TOPO_LINES - 1);
-        if (tags[slot] != line) {
-            if (lane < 16) { const uint32_t id = (line << 4) + lane; cache[slot * 16 + lane] = id < g.vcap ? g.nrec[id] : make_uint4(NONE, NONE, 0u, 0u); }
-            if (lane == 0) tags[slot] = line;
-        }
-        return cache[slot * 16 + (n & 15u)];
-    };
     for (uint32_t i = 0; i < V; i++) {
-        if (st[i] & 3u) continue;
-        push(i);
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)st[i]) & 3u) continue;
+        push1(i);
         while (sp) {
             if (sp == base) { base--; if (lane == 0) lstack[base & (TOPO_LCAP - 1)] = g.stack[base]; }
-            const uint32_t n = lstack[(sp - 1) & (TOPO_LCAP - 1)];
-            bool valid = true;
-            const uint32_t sn = st[n];
-            if ((sn & 3u) != 2u) {
-                const uint4 rec = record(n);
-                if (rec.w & 0x80000000u) {   // three or more in-edges: the list
-                    for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) {
-                        const uint32_t f = g.e_from[e];
-                        if ((st[f] & 3u) != 2u) { push(f); valid = false; }
-                    }
-                } else {
-                    if (rec.x != NONE && (st[rec.x] & 3u) != 2u) { push(rec.x); valid = false; }
-                    if (rec.y != NONE && (st[rec.y] & 3u) != 2u) { push(rec.y); valid = false; }
-                }
-                const bool chk = sn & 4u;
-                const unsigned long long al = ((unsigned long long)rec.z | ((unsigned long long)rec.w << 32)) & 0x7fffffffffffffffULL;
-                if (chk) {
-                    for (uint32_t k = 0; k < 3; k++) {
-                        const uint32_t a1 = (uint32_t)(al >> (21 * k)) & 0x1fffffu;
-                        if (!a1) break;
-                        if ((st[a1 - 1] & 3u) != 2u) { push(a1 - 1); if (lane == 0) st[a1 - 1] &= (uint8_t)~4u; valid = false; }
-                    }
-                }
-                if (valid) {
-                    if (lane == 0) st[n] = (uint8_t)((sn & ~3u) | 2u);
-                    if (chk) {
-                        if (lane == 0) out[nr] = n;
-                        nr++;
-                        for (uint32_t k = 0; k < 3; k++) {
-                            const uint32_t a1 = (uint32_t)(al >> (21 * k)) & 0x1fffffu;
-                            if (!a1) break;
-                            if (lane == 0) out[nr] = a1 - 1;
-                            nr++;
-                        }
-                    }
-                } else if (lane == 0) st[n] = (uint8_t)((sn & ~3u) | 1u);
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)lstack[(sp - 1) & (TOPO_LCAP - 1)]);
+            const uint32_t line = n >> 4, slot = line & (TOPO_LINES - 1);
+            const uint32_t tg = (uint32_t)__builtin_amdgcn_readfirstlane((int)tags[slot]);
+            const uint32_t sn = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[n]);
+            if ((sn & 3u) == 2u) { sp--; continue; }     // pushed more than once, finished meanwhile
+            if (tg != line) {
+                if (lane < 16) { const uint32_t id = (line << 4) + lane; cache[slot * 16 + lane] = id < g.vcap ? g.nrec[id] : make_uint4(NONE, NONE, 0u, 0u); }
+                if (lane == 0) tags[slot] = line;
             }
-            if (valid) sp--;
+            const uint4 rv = cache[slot * 16 + (n & 15u)];
+            const uint32_t rx = (uint32_t)__builtin_amdgcn_readfirstlane((int)rv.x), ry = (uint32_t)__builtin_amdgcn_readfirstlane((int)rv.y);
+            const uint32_t rz = (uint32_t)__builtin_amdgcn_readfirstlane((int)rv.z), rw = (uint32_t)__builtin_amdgcn_readfirstlane((int)rv.w);
+            const bool chk = sn & 4u;
+            const unsigned long long al = ((unsigned long long)rz | ((unsigned long long)rw << 32)) & 0x7fffffffffffffffULL;
+            const uint32_t spb = sp;
+            if (rw & 0x80000000u) {   // three or more in-edges: walk the list (rare)
+                for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) {
+                    const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.e_from[e]);
+                    if (((uint32_t)__builtin_amdgcn_readfirstlane((int)st[f]) & 3u) != 2u) push1(f);
+                }
+            }
+            // candidates of the lanes: 0/1 in-edge sources (unless the list was walked), 2..4 aligned nodes (only if the node still checks its column)
+            uint32_t cand = NONE;
+            if (lane == 0 && !(rw & 0x80000000u)) cand = rx;
+            else if (lane == 1 && !(rw & 0x80000000u)) cand = ry;
+            else if (lane >= 2 && lane < 5 && chk) { const uint32_t a1 = (uint32_t)(al >> (21 * (lane - 2))) & 0x1fffffu; cand = a1 ? a1 - 1 : NONE; }
+            const bool todo = cand != NONE && (st[cand] & 3u) != 2u;
+            const unsigned long long tm = __ballot(todo);
+            const uint32_t npush = (uint32_t)__popcll(tm);
+            if (npush) {
+                while (sp + npush - base > TOPO_LCAP) { if (lane == 0) g.stack[base] = lstack[base & (TOPO_LCAP - 1)]; base++; }   // make room in the LDS window
+                if (todo) {
+                    const uint32_t pos = sp + (uint32_t)__popcll(tm & ((1ull << lane) - 1));
+                    lstack[pos & (TOPO_LCAP - 1)] = cand;
+                    if (lane >= 2) st[cand] &= (uint8_t)~4u;   // an aligned node reached from its column does not check the column again
+                }
+                sp += npush;
+            }
+            if (sp == spb) {   // every predecessor and column member is final: so is this node
+                if (lane == 0) st[n] = (uint8_t)((sn & ~3u) | 2u);
+                if (chk) {
+                    uint32_t cnt = 1;
+                    if (lane == 0) out[nr] = n;
+                    if (lane >= 2 && lane < 5) { const uint32_t a1 = (uint32_t)(al >> (21 * (lane - 2))) & 0x1fffffu; if (a1) out[nr + lane - 1] = a1 - 1; }
+                    for (uint32_t k = 0; k < 3; k++) if ((uint32_t)(al >> (21 * k)) & 0x1fffffu) cnt++; else break;
+                    nr += cnt;
+                }
+                sp--;
+            } else if (lane == 0) st[n] = (uint8_t)((sn & ~3u) | 1u);
+        }
+    }
+}
+
+// The same traversal on RANKS of the order the DP maintains (any valid topological order with contiguous columns): predecessors have
+// smaller, nearby ranks, so the 16-rank record lines (row_meta, first two predecessor ranks, aligned-rank deltas) hit the LDS cache
+// almost always — node ids are visited in a scattered order, ranks are not. Roots are still taken in node-id order (that is what
+// fixes the reference's result); out[] receives ranks, the caller maps them back to node ids.
+__device__ void toposort_rank(G& g, const uint32_t V, uint8_t* st /* by rank */, uint32_t* lstack, uint4* cache, uint32_t* tags, uint32_t* out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i = lane; i < TOPO_LINES; i += 64) tags[i] = NONE;
+    uint32_t sp = 0, nr = 0, base = 0;
+    uint32_t rootV = 0;
+    for (uint32_t i = 0; i < V; i++) {
+        if ((i & 63u) == 0) rootV = i + lane < V ? g.node2rank[i + lane] : 0;
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)rootV, (int)(i & 63u));
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)st[r0]) & 3u) continue;
+        if (lane == 0) lstack[sp & (TOPO_LCAP - 1)] = r0;
+        sp++;
+        while (sp) {
+            if (sp == base) { base--; if (lane == 0) lstack[base & (TOPO_LCAP - 1)] = g.stack[base]; }
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)lstack[(sp - 1) & (TOPO_LCAP - 1)]);
+            const uint32_t line = n >> 4, slot = line & (TOPO_LINES - 1);
+            const uint32_t tg = (uint32_t)__builtin_amdgcn_readfirstlane((int)tags[slot]);
+            const uint32_t sn = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[n]);
+            if ((sn & 3u) == 2u) { sp--; continue; }     // pushed more than once, finished meanwhile
+            if (tg != line) {
+                if (lane < 16) {
+                    const uint32_t id = (line << 4) + lane;
+                    cache[slot * 16 + lane] = id < V ? make_uint4(g.row_meta[id], g.row_pred0[id], g.row_pred1[id], (uint32_t)g.row_al[id]) : make_uint4(0u, 0u, 0u, 0u);
+                }
+                if (lane == 0) tags[slot] = line;
+            }
+            const uint4 rv = cache[slot * 16 + (n & 15u)];
+            const uint32_t npred = (uint32_t)__builtin_amdgcn_readfirstlane((int)rv.x) >> 8;
+            const uint32_t alp = (uint32_t)__builtin_amdgcn_readfirstlane((int)rv.w);
+            const bool chk = sn & 4u;
+            const uint32_t spb = sp;
+            if (npred > 2) {   // three or more in-edges: the list (rare)
+                const uint32_t po = g.row_pred_off[n];
+                for (uint32_t p = 0; p < npred; p++) {
+                    const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[po + p]) & 0x0fffffffu;
+                    if (((uint32_t)__builtin_amdgcn_readfirstlane((int)st[f]) & 3u) != 2u) {
+                        if (sp - base == TOPO_LCAP) { if (lane == 0) g.stack[base] = lstack[base & (TOPO_LCAP - 1)]; base++; }
+                        if (lane == 0) lstack[sp & (TOPO_LCAP - 1)] = f;
+                        sp++;
+                    }
+                }
+            }
+            // candidates of the lanes: 0/1 the first two in-edge sources (unless the list was walked), 2..4 the aligned ranks (only if the node still checks its column)
+            uint32_t cand = NONE;
+            if (lane == 0 && npred >= 1 && npred <= 2) cand = rv.y & 0x0fffffffu;
+            else if (lane == 1 && npred == 2) cand = rv.z & 0x0fffffffu;
+            else if (lane >= 2 && lane < 5 && chk) { const uint32_t d = (alp >> (3 * (lane - 2))) & 7u; cand = d ? n + d - 4u : NONE; }
+            const bool todo = cand != NONE && (st[cand] & 3u) != 2u;
+            const unsigned long long tm = __ballot(todo);
+            const uint32_t npush = (uint32_t)__popcll(tm);
+            if (npush) {
+                while (sp + npush - base > TOPO_LCAP) { if (lane == 0) g.stack[base] = lstack[base & (TOPO_LCAP - 1)]; base++; }   // make room in the LDS window
+                if (todo) {
+                    const uint32_t pos = sp + (uint32_t)__popcll(tm & ((1ull << lane) - 1));
+                    lstack[pos & (TOPO_LCAP - 1)] = cand;
+                    if (lane >= 2) st[cand] &= (uint8_t)~4u;   // an aligned node reached from its column does not check the column again
+                }
+                sp += npush;
+            }
+            if (sp == spb) {   // every predecessor and column member is final: so is this node
+                if (lane == 0) st[n] = (uint8_t)((sn & ~3u) | 2u);
+                if (chk) {
+                    if (lane == 0) out[nr] = n;
+                    if (lane >= 2 && lane < 5) { const uint32_t d = (alp >> (3 * (lane - 2))) & 7u; if (d) out[nr + lane - 1] = n + d - 4u; }
+                    nr += 1 + ((alp & 7u) != 0) + ((alp & 0x38u) != 0) + ((alp & 0x1c0u) != 0);
+                }
+                sp--;
+            } else if (lane == 0) st[n] = (uint8_t)((sn & ~3u) | 1u);
         }
     }
 }
@@ -443,18 +525,30 @@ template <int CM> __device__ __forceinline__ void store_dirs(uint8_t* p, const u
     }
 }
 
-template <int CM, bool DIR>
-__device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, const uint32_t W, const uint8_t* __restrict__ seq, const uint32_t L,
+#if defined(HX_DP_PROF) && !defined(HX_DP_PROF2)
+#define DP_T(k) do { if (tid == 0) { const long long _n = clock64(); prof[k] += (unsigned long long)(_n - tprev); tprev = _n; } } while (0)
+#else
+#define DP_T(k) do { } while (0)
+#endif
+// The row loop is written for a lone wavefront's latency: on this hardware a VALU instruction costs ~5 cycles whether or not it depends
+// on its predecessor, a taken scalar branch ~35, an LDS round trip ~75, the DPP scan ~90. So a row is ONE dispatch on where its
+// predecessor lives (registers / LDS ring / anything else), then straight-line code: rare events (row spilled to HBM, sink row) share
+// one not-taken branch, the kept-row copy to the LDS ring is unconditional (rows nobody keeps go to a scratch slot), selects are
+// arithmetic.
+template <int CM, bool DIR, bool MULTI>
+__device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, const uint32_t W, const uint8_t* __restrict__ seq, const uint32_t L,
                         const uint32_t V, int32_t* ring, const uint32_t R, const uint32_t ring_w, const int match, const int mismatch, const int gap,
-                        int* lds_tot /* 2 x 16 */, uint32_t* sink_row, int* sink_score, uint32_t& nSinkOut, const DpCl& cl) {
+                        int* lds_tot /* 2 x 16 */, uint32_t* sink_row, int* sink_score, uint32_t& nSinkOut, const DpCl& cl, unsigned long long* prof) {
+#if defined(HX_DP_PROF) && !defined(HX_DP_PROF2)
+    long long tprev = clock64();
+#endif
     const uint32_t tid = threadIdx.x, NT = blockDim.x, lane = tid & 63u, wv = tid >> 6;
-    const bool multi = NT > 64;
     const uint32_t ncol = L + 1;
     const uint32_t col0 = cl.mem * NT * CM;                                   // first column of this member
     const uint32_t nwa = col0 >= ncol ? 0u : min(NT >> 6, (ncol - col0 + 64u * CM - 1) / (64u * CM));   // waves of this member that own a real column
     if (nwa == 0) return;      // the whole member has nothing to do for this sequence (no barriers are counted then)
-    if (wv >= nwa) {   // nothing to compute: keep the workgroup's barrier count (one per row, plus the one before the loop)
-        if (multi) { barrier_lds_only(); for (uint32_t i = 1; i <= V; i++) barrier_lds_only(); }
+    if (wv >= nwa) {   // nothing to compute: keep the workgroup's barrier count (one per row)
+        if (MULTI) for (uint32_t i = 1; i <= V; i++) barrier_lds_only();
         return;
     }
     const uint32_t gt = cl.mem * NT + tid;                                    // lane index over all members
@@ -467,20 +561,17 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
     const bool live = j0 <= L;                       // the chunk holds at least one real column: only such chunks touch HBM
     const bool owns_last = live && L < j0 + CM;
     const uint32_t klast = owns_last ? L - j0 : 0;
-    using mask_t = typename std::conditional<(CM <= 32), uint32_t, uint64_t>::type;
-    mask_t eq[4] = {0, 0, 0, 0};     // bit k of eq[c] = the base under column j0+k is c
+    // bases under the lane's columns, 2 bits per column (bit pair k); columns without a base (column 0, padding) never match
+    using mask_t = typename std::conditional<(CM <= 16), uint32_t, unsigned long long>::type;
+    static_assert(CM <= 32, "at most 32 columns per lane");
+    mask_t bases = 0, nobase = 0;
 #pragma unroll
     for (int k = 0; k < CM; k++) {
         const uint32_t j = j0 + k;
-        const uint32_t b = (j >= 1 && j < ncol) ? seq[j - 1] : 0xffu;
-#pragma unroll
-        for (int c = 0; c < 4; c++) eq[c] |= (mask_t)(b == (uint32_t)c ? 1u : 0u) << k;
+        if (j >= 1 && j < ncol) bases |= (mask_t)seq[j - 1] << (2 * k); else nobase |= (mask_t)1 << (2 * k);
     }
-    const int mm64 = mismatch * 64, g64 = gap * 64, dsc64 = (match - mismatch) * 64;
+    const int mm64 = mismatch * 64, g64 = gap * 64, m64 = match * 64;
     const int jg0 = (int)j0 * g64;
-    auto sbit = [](mask_t m, int k) -> int {   // 0 or -1
-        if constexpr (CM <= 32) return __builtin_amdgcn_sbfe((int)m, k, 1); else return -(int)((m >> k) & 1u);
-    };
     int t[CM];                                          // row i-1, then row i: 64 x score
 #pragma unroll
     for (int k = 0; k < CM; k++) t[k] = jg0 + k * g64;  // row 0
@@ -500,41 +591,34 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
         if (r < V) { m = g.row_meta[r]; a = g.row_pred0[r]; b = g.row_pred1[r]; o = g.row_pred_off[r]; }
     };
     fetch(0, mN, aN, bN, oN);
-    if (multi) barrier_lds_only();
     int32_t* hrow = H;
     uint8_t* drow = D;
-    // Run f(row, left) on a predecessor row, wherever it lives. Every source gets its OWN copy of the consumer code: were the rows
-    // merged into one register set first, the compiler would have to wait for "possibly pending" global loads (vmcnt 0, i.e. also for
-    // the previous row's direction-byte store) on every row, although almost every row takes the register path.
-    auto with_pred = [&](const uint32_t ent, auto&& f) {
+    const int32_t* ring_me = ring + tid;                 // lane-transposed rows: column t*CM+k at word k*NT+t
+    // f(row, left) on a predecessor row that is not the previous row
+    auto with_far_pred = [&](const uint32_t ent, auto&& f) {
         const uint32_t loc = ent >> 28;
-        if (loc == 0) f(t, left_prev);     // the previous row: the lane's own registers
-        else if (loc != 15) {              // kept row in the LDS ring
-            int hp[CM], left;
-            const int32_t* S = ring + (size_t)(loc - 1) * ring_w;
+        int hp[CM], left;
+        if (loc != 15) {                   // kept row in the LDS ring
+            const int32_t* S = ring_me + (size_t)(loc - 1) * ring_w;
 #pragma unroll
-            for (int k = 0; k < CM; k++) hp[k] = S[k * NT + tid];
-            left = tid > 0 ? S[(CM - 1) * NT + tid - 1] : has_in ? cl.ringleft[loc - 1] : NEGK;
-            f(hp, left);
-        } else {                           // kept row that fell out of the ring: HBM (spill stores were drained before the barrier that followed them)
-            int hp[CM], left;
-            if (live) {
-                const int32_t* Gp = H + (uint64_t)((ent & 0x0fffffffu) + 1) * W + j0;
-                load_chunk_i32<CM>(Gp, hp);
-                left = j0 > 0 ? Gp[-1] : NEGK;
-                if (!DIR) {                // the score matrix holds plain scores
+            for (int k = 0; k < CM; k++) hp[k] = S[k * NT];
+            left = tid > 0 ? S[(CM - 1) * NT - 1] : has_in ? cl.ringleft[loc - 1] : NEGK;
+        } else if (live) {                 // kept row that fell out of the ring: HBM
+            const int32_t* Gp = H + (uint64_t)((ent & 0x0fffffffu) + 1) * W + j0;
+            load_chunk_i32<CM>(Gp, hp);
+            left = j0 > 0 ? Gp[-1] : NEGK;
+            if (!DIR) {                    // the score matrix holds plain scores
 #pragma unroll
-                    for (int k = 0; k < CM; k++) hp[k] <<= 6;
-                    if (j0 > 0) left <<= 6;
-                }
-                if (has_in && tid == 0) left = far_own[(ent & 0x0fffffffu) + 1];   // the column on the left belongs to another CU: own copy (keys)
-            } else {
-#pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] = NEGK;
-                left = NEGK;
+                for (int k = 0; k < CM; k++) hp[k] <<= 6;
+                if (j0 > 0) left <<= 6;
             }
-            f(hp, left);
+            if (has_in && tid == 0) left = far_own[(ent & 0x0fffffffu) + 1];   // the column on the left belongs to another CU: own copy (keys)
+        } else {
+#pragma unroll
+            for (int k = 0; k < CM; k++) hp[k] = NEGK;
+            left = NEGK;
         }
+        f(hp, left);
     };
     for (uint32_t ib = 0; ib < V; ib += 64) {
         // the batch fetched 64 rows ago becomes current (the only wait for these loads), the next one goes in flight
@@ -556,61 +640,128 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
         for (uint32_t ri = 0; ri < ie; ri++) {
             const uint32_t i = ib + ri + 1;
             const uint32_t meta = __builtin_amdgcn_readlane(mC, ri), p0 = __builtin_amdgcn_readlane(aC, ri);
-            const uint32_t rc = meta & 3u, npred = meta >> 8;
-            const mask_t mask = rc == 0 ? eq[0] : rc == 1 ? eq[1] : rc == 2 ? eq[2] : eq[3];
+            const uint32_t npred = meta >> 8;
+            // mismatch bits of this row: bit 2k set <=> the base under column k differs from the row's letter
+            mask_t mis;
+            {
+                const mask_t x = bases ^ ((mask_t)(meta & 3u) * (mask_t)0x5555555555555555ull);
+                mis = x | (x >> 1) | nobase;
+            }
+            auto score_of = [&](int k) -> int {   // 64 x substitution score of column k (+63: the diagonal move type)
+                int neg;   // -1 on a mismatch, 0 on a match
+                if constexpr (CM <= 16) neg = __builtin_amdgcn_sbfe((int)mis, 2 * k, 1);
+                else neg = 2 * k < 32 ? __builtin_amdgcn_sbfe((int)(uint32_t)mis, (2 * k) & 31, 1) : __builtin_amdgcn_sbfe((int)(uint32_t)(mis >> 32), (2 * k) & 31, 1);
+                return (m64 + 63) + ((mm64 - m64) & neg);
+            };
             hrow += W;
             if (DIR) drow += W;
-            // everything after the vertical/diagonal maxima: horizontal recurrence, scan, carry, stores. `slot(k, key)` = direction byte of cell k
-            auto finish = [&](int (&m)[CM], auto&& slot_bits, uint32_t keep) {
-                // chunk-local horizontal recurrence (type 1 loses every tie)
+            DP_T(0);   // row decode
+            int m[CM];
+            uint32_t sl[CM];    // several predecessors: slot of the best diagonal (bits 0-7) and vertical (bits 8-15) predecessor
+            auto cells1 = [&](const int (&hp)[CM], const int left) {
 #pragma unroll
-                for (int k = 1; k < CM; k++) m[k] = max(m[k], (m[k - 1] & ~63) + (g64 + 1));
-                // prefix maximum over the lanes to the left of (chunk end score - its column * gap)
-                const int inc = wave_incl_max((m[CM - 1] & ~63) - (jg0 + (CM - 1) * g64));
-                int ex = wave_shift_up1(inc, NEGK);
-                const int cin = has_in ? __builtin_amdgcn_readlane(cinV, ri) : NEGK;
-                if (multi) {
-                    int* tot = lds_tot + (i & 1u) * 16;
-                    if (lane == 63) tot[wv] = inc;
-                    // One barrier per row. A spilled row is read back by other waves only 2+ rows later, but its stores must have left this
-                    // wave before the barrier that the readers also pass: rows that spill drain vmcnt first, all others wait for LDS only.
-                    if (meta & 8u) __syncthreads(); else barrier_lds_only();
-                    const uint32_t w16 = lane & 15u;
-                    const int x = row16_incl_max(w16 < nwa ? tot[w16] : NEGK);
-                    if (wv > 0) ex = max(ex, __builtin_amdgcn_readlane(x, wv - 1));
-                    if (has_out && tid == 0) st_dev64(mb_out + i, (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, __builtin_amdgcn_readlane(x, nwa - 1)) << 32));
-                } else if (has_out && lane == 0) st_dev64(mb_out + i, (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, __builtin_amdgcn_readlane(inc, 63)) << 32));
-                ex = max(ex, cin);
-                const int base = ex + jg0;            // 64 x (score reaching column j0 through a horizontal move from the left neighbour)
+                for (int k = 0; k < CM; k++) m[k] = max((k == 0 ? left : hp[k - 1]) + score_of(k), hp[k] + (g64 + 62));
+            };
+            const uint32_t loc0 = p0 >> 28;
+            if (npred == 1 && loc0 == 0) cells1(t, left_prev);     // the previous row: the lane's own registers
+            else if (npred == 1 && loc0 != 15) {                   // one kept row in the LDS ring
+                int hp[CM], left;
+                const int32_t* S = ring_me + (size_t)(loc0 - 1) * ring_w;
 #pragma unroll
-                for (int k = 0; k < CM; k++) m[k] = max(m[k], base + (k * g64 + 1));
-                left_prev = base - g64;               // 64 x H[i][j0-1]: the exclusive prefix already is the finished value left of this chunk
+                for (int k = 0; k < CM; k++) hp[k] = S[k * NT];
+                left = tid > 0 ? S[(CM - 1) * NT - 1] : has_in ? cl.ringleft[loc0 - 1] : NEGK;
+                cells1(hp, left);
+            } else if (npred == 0) {                               // source node: the virtual row 0
+                int hp[CM];
 #pragma unroll
-                for (int k = 0; k < CM; k++) t[k] = m[k] & ~63;
-                if (meta & 16u) {   // kept row: a later row reads it as a non-adjacent predecessor
-                    if (R) {
-                        int32_t* S = ring + (size_t)(nkept & (R - 1)) * ring_w;
+                for (int k = 0; k < CM; k++) hp[k] = jg0 + k * g64;
+                cells1(hp, gt > 0 ? jg0 - g64 : NEGK);
+            } else if (npred == 1) with_far_pred(p0, cells1);      // one row that left the ring
+            else {
+                const uint32_t p1 = __builtin_amdgcn_readlane(bC, ri), po = __builtin_amdgcn_readlane(oC, ri);
+                int bd[CM], bv[CM];   // best diagonal / vertical key with 63 - slot in the low bits
 #pragma unroll
-                        for (int k = 0; k < CM; k++) S[k * NT + tid] = t[k];
-                        if (has_in && tid == 0) cl.ringleft[nkept & (R - 1)] = left_prev;
-                    }
-                    nkept++;
+                for (int k = 0; k < CM; k++) { bd[k] = NEGK; bv[k] = NEGK; }
+                for (uint32_t p = 0; p < npred; p++) {
+                    const uint32_t ent = p == 0 ? p0 : p == 1 ? p1 : g.pred_rank[po + p];
+                    const int cd = DIR ? 63 - (int)p : 0;   // direction bytes exist only for edges with <= 63 sequences, i.e. <= 63 in-edges per node
+                    const int gc = g64 + cd, dc = cd - 63;
+                    auto acc = [&](const int (&hp)[CM], const int left) {
+#pragma unroll
+                        for (int k = 0; k < CM; k++) {
+                            bd[k] = max(bd[k], (k == 0 ? left : hp[k - 1]) + score_of(k) + dc);
+                            bv[k] = max(bv[k], hp[k] + gc);
+                        }
+                    };
+                    if ((ent >> 28) == 0) acc(t, left_prev); else with_far_pred(ent, acc);
                 }
-                if (has_in && tid == 0 && (meta & 8u)) far_own[i] = left_prev;
-                if (live) {
-                    if (DIR) {
-                        if (meta & 8u) { store_chunk_i32<CM>(hrow + j0, t); if (!multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // far successor: keys
-                        uint32_t dc[CM];
 #pragma unroll
-                        for (int k = 0; k < CM; k++) dc[k] = slot_bits(k, (uint32_t)m[k]);
-                        store_dirs<CM>(drow + j0, dc, keep);
+                for (int k = 0; k < CM; k++) {
+                    m[k] = max(bd[k] | 63, (bv[k] | 63) - 1);
+                    if (DIR) sl[k] = (((uint32_t)bd[k] & 63u) ^ 63u) | ((((uint32_t)bv[k] & 63u) ^ 63u) << 8);
+                }
+            }
+            // chunk-local horizontal recurrence (type 1 loses every tie)
+#pragma unroll
+            for (int k = 1; k < CM; k++) m[k] = max(m[k], (m[k - 1] & ~63) + (g64 + 1));
+            DP_T(1);   // predecessor rows + cells + horizontal chain
+            // prefix maximum over the lanes to the left of (chunk end score - its column * gap)
+            const int inc = wave_incl_max((m[CM - 1] & ~63) - (jg0 + (CM - 1) * g64));
+            int ex = wave_shift_up1(inc, NEGK);
+            DP_T(2);   // wave scan
+            const int cin = __builtin_amdgcn_readlane(cinV, ri);   // NEGK without a member on the left
+            if (MULTI) {
+                int* tot = lds_tot + (i & 1u) * 16;
+                if (lane == 63) tot[wv] = inc;
+                barrier_lds_only();   // one barrier per row
+                const uint32_t w16 = lane & 15u;
+                const int x = row16_incl_max(w16 < nwa ? tot[w16] : NEGK);
+                const int prev = __builtin_amdgcn_readlane(x, wv > 0 ? wv - 1 : 0);
+                ex = max(ex, wv > 0 ? prev : NEGK);
+                if (has_out && tid == 0) st_dev64(mb_out + i, (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, __builtin_amdgcn_readlane(x, nwa - 1)) << 32));
+            } else if (has_out && lane == 0) st_dev64(mb_out + i, (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, __builtin_amdgcn_readlane(inc, 63)) << 32));
+            ex = max(ex, cin);
+            DP_T(3);   // cross-wave exchange
+            const int base = ex + jg0;            // 64 x (score reaching column j0 through a horizontal move from the left neighbour)
+#pragma unroll
+            for (int k = 0; k < CM; k++) m[k] = max(m[k], base + (k * g64 + 1));
+            left_prev = base - g64;               // 64 x H[i][j0-1]: the exclusive prefix already is the finished value left of this chunk
+#pragma unroll
+            for (int k = 0; k < CM; k++) t[k] = m[k] & ~63;
+            if (R) {   // copy to the LDS ring: a kept row (a later row reads it as a non-adjacent predecessor) takes the next slot, any other row the scratch slot R
+                const uint32_t kept = (meta >> 4) & 1u, slot = kept ? (nkept & (R - 1)) : R;
+                int32_t* S = ring + (size_t)slot * ring_w + tid;
+#pragma unroll
+                for (int k = 0; k < CM; k++) S[k * NT] = t[k];
+                if (has_in && tid == 0) cl.ringleft[slot] = left_prev;
+            }
+            nkept += (meta >> 4) & 1u;
+            DP_T(4);   // carry applied, kept-row copy
+            if (live) {
+                if (DIR) {
+                    uint32_t dc[CM];
+                    if (npred >= 2) {
+#pragma unroll
+                        for (int k = 0; k < CM; k++) dc[k] = ((((uint32_t)m[k] & 1u) ? sl[k] : (sl[k] >> 8)) & 63u) << 2 | ((uint32_t)m[k] & 3u);
+                        store_dirs<CM>(drow + j0, dc, 0xffffffffu);
                     } else {
-                        int pl[CM];
 #pragma unroll
-                        for (int k = 0; k < CM; k++) pl[k] = t[k] >> 6;
-                        store_chunk_i32<CM>(hrow + j0, pl);
-                        if (!multi && (meta & 8u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        for (int k = 0; k < CM; k++) dc[k] = (uint32_t)m[k];
+                        store_dirs<CM>(drow + j0, dc, 0x03030303u);
                     }
+                } else {
+                    int pl[CM];
+#pragma unroll
+                    for (int k = 0; k < CM; k++) pl[k] = t[k] >> 6;
+                    store_chunk_i32<CM>(hrow + j0, pl);
+                }
+            }
+            DP_T(5);   // stores
+            if (__builtin_expect((meta & (8u | 4u)) != 0, 0)) {
+                if (meta & 8u) {   // a far successor reads this row back from HBM (keys; with the score matrix it is there already)
+                    if (DIR && live) store_chunk_i32<CM>(hrow + j0, t);
+                    if (has_in && tid == 0) far_own[i] = left_prev;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row has left this wave before any later row's barrier
                 }
                 if (owns_last && (meta & 4u)) {   // sink node: candidate end of the global alignment
                     int v = NEGK;
@@ -619,47 +770,6 @@ __device__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict
                     if (nsink < SINK_CAP) { sink_row[nsink] = i; sink_score[nsink] = v >> 6; }
                     nsink++;
                 }
-            };
-            auto cells1 = [&](const int (&hp)[CM], const int left, int (&m)[CM]) {
-#pragma unroll
-                for (int k = 0; k < CM; k++) {
-                    const int dg = (k == 0 ? left : hp[k - 1]) + ((mm64 + 63) + (dsc64 & sbit(mask, k)));
-                    const int up = hp[k] + (g64 + 62);
-                    m[k] = max(dg, up);
-                }
-            };
-            auto row1 = [&](const int (&hp)[CM], const int left) {
-                int m[CM];
-                cells1(hp, left, m);
-                finish(m, [](int, uint32_t key) { return key; }, 0x03030303u);
-            };
-            if (npred == 1) with_pred(p0, row1);
-            else if (npred == 0) {   // source node: the virtual row 0
-                int hp[CM];
-#pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] = jg0 + k * g64;
-                row1(hp, gt > 0 ? jg0 - g64 : NEGK);
-            } else {
-                const uint32_t p1 = __builtin_amdgcn_readlane(bC, ri), po = __builtin_amdgcn_readlane(oC, ri);
-                int sK[CM], m[CM];
-                int bd[CM], bv[CM];   // best diagonal / vertical key with 63 - slot in the low bits
-#pragma unroll
-                for (int k = 0; k < CM; k++) { sK[k] = mm64 + (dsc64 & sbit(mask, k)); bd[k] = NEGK; bv[k] = NEGK; }
-                for (uint32_t p = 0; p < npred; p++) {
-                    const uint32_t ent = p == 0 ? p0 : p == 1 ? p1 : g.pred_rank[po + p];
-                    const int cd = DIR ? 63 - (int)p : 0;   // direction bytes exist only for edges with <= 63 sequences, i.e. <= 63 in-edges per node
-                    const int gc = g64 + cd;
-                    with_pred(ent, [&](const int (&hp)[CM], const int left) {
-#pragma unroll
-                        for (int k = 0; k < CM; k++) {
-                            bd[k] = max(bd[k], (k == 0 ? left : hp[k - 1]) + sK[k] + cd);
-                            bv[k] = max(bv[k], hp[k] + gc);
-                        }
-                    });
-                }
-#pragma unroll
-                for (int k = 0; k < CM; k++) m[k] = max(bd[k] | 63, (bv[k] | 63) - 1);
-                finish(m, [&](int k, uint32_t key) { const uint32_t sel = (uint32_t)((key & 1u) ? bd[k] : bv[k]); return (((sel & 63u) ^ 63u) << 2) | (key & 3u); }, 0xffffffffu);
             }
         }
     }
@@ -677,6 +787,14 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     __shared__ long long tc;
     if (threadIdx.x == 0) { for (int k = 0; k < 12; k++) ph[k] = 0; tc = clock64(); }
 #define PHASE(k) do { if (tid == 0) { long long _n = clock64(); ph[k] += (unsigned long long)(_n - tc); tc = _n; } } while (0)
+#ifdef HX_DP_PROF2
+    __shared__ long long tc2;
+#define SUBT(k) do { if (tid == 0) { long long _n = clock64(); ph[k] += (unsigned long long)(_n - tc2); tc2 = _n; } } while (0)
+#define SUBT0() do { if (tid == 0) tc2 = clock64(); } while (0)
+#else
+#define SUBT(k) do { } while (0)
+#define SUBT0() do { } while (0)
+#endif
     const PoaEdge ED = edges[eidx];
     const uint32_t tid = threadIdx.x, NT = blockDim.x;
     extern __shared__ int32_t ring[];
@@ -688,7 +806,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         g.rank2node = P.rank2node + no; g.node2rank = P.node2rank + no; g.mark = P.mark + no; g.check = P.check + no;
         g.stack = P.stack + ED.stack_off; g.score = P.score + no; g.pred = P.pred + no;
         g.row_code = P.row_code + no; g.row_sink = P.row_sink + no; g.row_pred_off = P.row_pred_off + no; g.pred_rank = P.pred_rank + eo;
-        g.row_meta = P.row_meta + no; g.row_pred0 = P.row_pred0 + no; g.row_pred1 = P.row_pred1 + no; g.nrec = P.nrec + no;
+        g.row_meta = P.row_meta + no; g.row_pred0 = P.row_pred0 + no; g.row_pred1 = P.row_pred1 + no; g.nrec = P.nrec + no; g.row_al = P.row_al + no;
         g.e_from = P.e_from + eo; g.e_to = P.e_to + eo; g.e_next_in = P.e_next_in + eo; g.e_next_out = P.e_next_out + eo; g.e_w = P.e_w + eo;
         g.aln_node = P.aln_node + ED.aln_off; g.aln_pos = P.aln_pos + ED.aln_off;
         g.vcap = ED.vcap; g.ecap = ED.ecap;
@@ -698,7 +816,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     // ring geometry is a property of the edge (its longest sequence) and of the launch
     const uint32_t GM = ED.members;                  // workgroups sharing this edge's DP columns
     const uint32_t cme = (ED.lmax + 1 + GM * NT - 1) / (GM * NT);
-    const uint32_t cmr = cme <= 4 ? 4 : cme <= 8 ? 8 : cme <= 16 ? 16 : cme <= 32 ? 32 : 64;
+    const uint32_t cmr = cme <= 4 ? 4 : cme <= 8 ? 8 : cme <= 16 ? 16 : 32;
     const uint32_t ring_w = cmr * NT;
     const uint32_t R = ring_rows >= 2 ? ring_rows : 0;
     uint8_t* seq = P.seq + ED.seq_off;
@@ -722,18 +840,74 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     constexpr uint32_t CL_ABORT = 0xffffffffu;
     auto cm_sel = [&](uint32_t Lq) -> uint32_t {   // columns per lane of the dp_rows instance that handles a sequence of Lq bases
         const uint32_t c = (Lq + 1 + GM * NT - 1) / (GM * NT);
-        return c <= 4 ? 4u : c <= 8 ? 8u : c <= 16 ? 16u : c <= 32 ? 32u : 64u;
+        return c <= 4 ? 4u : c <= 8 ? 8u : c <= 16 ? 16u : 32u;
     };
 #define HX_DP_DISPATCH(Lq, Vq, nsq) do { \
         const uint32_t cm_ = ((Lq) + 1 + GM * NT - 1) / (GM * NT);     /* columns per lane for this sequence */ \
         if (cm_ <= 4) HX_DP(4, Lq, Vq, nsq); else if (cm_ <= 8) HX_DP(8, Lq, Vq, nsq); \
         else if (cm_ <= 16) { if constexpr (CMMAX >= 16) HX_DP(16, Lq, Vq, nsq); else sOk = 2; } \
         else if (cm_ <= 32) { if constexpr (CMMAX >= 32) HX_DP(32, Lq, Vq, nsq); else sOk = 2; }   /* the host never asks a 16-column kernel for more */ \
-        else { if constexpr (CMMAX >= 64) HX_DP(64, Lq, Vq, nsq); else sOk = 2; } } while (0)
-#define HX_DP(CMV, Lq, Vq, nsq) dp_rows<CMV, DIR>(g, H, Dm, W, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, lds_i, sink_row, sink_score, nsq, cl)
-    if (mem > 0) {
-        // ---- member of a cluster: only the DP, over its own columns; everything else happens in member 0
-        for (uint32_t k = ED.seq_begin; k < ED.seq_end; k++) {
+        else sOk = 2; } while (0)
+#define HX_DP(CMV, Lq, Vq, nsq) do { if (NT > 64) dp_rows<CMV, DIR, true>(g, H, Dm, W, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, lds_i, sink_row, sink_score, nsq, cl, ph + 6); \
+                                      else dp_rows<CMV, DIR, false>(g, H, Dm, W, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, lds_i, sink_row, sink_score, nsq, cl, ph + 6); } while (0)
+    // The reference's topological order (spoa's DFS, inherently serial) is needed in two places only: to break ties between equally scored
+    // end nodes of an alignment, and for the heaviest-bundle traversal of the finished graph. The DP itself runs on a cheaper order that
+    // is maintained incrementally (see "order update" below): row values do not depend on which valid topological order is used.
+    const uint32_t topo_fixed = TOPO_LCAP * 4 + TOPO_LINES * 256 + TOPO_LINES * 4;
+    uint32_t* t_stack = reinterpret_cast<uint32_t*>(ring);
+    uint4* t_cache = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(ring) + TOPO_LCAP * 4);
+    uint32_t* t_tags = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ring) + TOPO_LCAP * 4 + TOPO_LINES * 256);
+    uint8_t* st_lds = reinterpret_cast<uint8_t*>(ring) + topo_fixed;
+    uint32_t* tmp_u32 = reinterpret_cast<uint32_t*>(g.pred);   // vcap+1 words of scratch (heaviest-bundle scratch, free until the end)
+    auto exact_order = [&](uint32_t Vn, uint32_t* out) {   // all lanes; leaves spoa's rank->node order of the current graph in out[]
+        // (needs the rank-ordered rows of the CURRENT graph: they are rebuilt after every sequence)
+        const bool in_lds = (uint64_t)Vn + topo_fixed + 16 <= lds_bytes;
+        if (in_lds) { for (uint32_t i = tid; i < Vn; i += NT) st_lds[i] = 4u; }                    // mark 0, check 1
+        else { for (uint32_t i = tid; i < Vn; i += NT) { g.mark[i] = 0; g.check[i] = 1; } }
+        __syncthreads();
+        if (in_lds) {
+            uint32_t* ranks = reinterpret_cast<uint32_t*>(g.score);   // free between the CSR build and the graph update
+#ifdef HX_DP_PROF2
+            long long tq0 = clock64();
+#endif
+            if (tid < 64) toposort_rank(g, Vn, st_lds, t_stack, t_cache, t_tags, ranks);   // wave 0, 64 lanes in lock step
+#ifdef HX_DP_PROF2
+            if (tid == 0) ph[11] += (unsigned long long)(clock64() - tq0);
+#endif
+            __syncthreads();
+            for (uint32_t i = tid; i < Vn; i += NT) tmp_u32[i] = g.rank2node[ranks[i]];
+            __syncthreads();
+            if (out != tmp_u32) { for (uint32_t i = tid; i < Vn; i += NT) out[i] = tmp_u32[i]; }
+        } else if (tid == 0) toposort(g, Vn, out);
+        __syncthreads();
+    };
+
+    for (uint32_t k = ED.seq_begin; k < ED.seq_end; k++) {
+        uint32_t L, V;
+        if (mem == 0) {
+            const PoaSeq q = seqs[k];
+            L = q.len;
+            // ---- decode the gap sub-sequence (forward: read[spos+j]; reverse strand: complement of read[rlen-1-(spos+j)])
+            {
+                const uint8_t* rp = packed + read_off[q.rid];
+                const uint32_t rlen = read_len[q.rid];
+                for (uint32_t j = tid; j < L; j += NT) {
+                    uint32_t p = q.strand == 0 ? q.spos + j : rlen - 1 - (q.spos + j);
+                    uint8_t b = (rp[p >> 2] >> ((p & 3) * 2)) & 3;
+                    seq[j] = q.strand == 0 ? b : (uint8_t)(3 - b);
+                }
+            }
+            __syncthreads();
+            PHASE(0);
+            V = sV;
+            SUBT0();
+            if (GM > 1) {   // publish this sequence to the other members: graph rows (CSR), decoded sequence, V, L
+                __threadfence();
+                __syncthreads();
+                if (tid == 0) { st_dev(csy + 2, V); st_dev(csy + 3, L); __threadfence(); st_dev(csy + 0, k - ED.seq_begin + 1); }
+            }
+        } else {
+            // ---- other member of a cluster: only the DP, over its own columns; everything else happens in member 0
             if (tid == 0) {
                 uint32_t v = 0;
                 for (uint32_t spin = 0;; spin++) {
@@ -747,13 +921,19 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
             __syncthreads();
             if (sCtl == CL_ABORT) break;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // graph rows, sequence and counts written by member 0
-            const uint32_t V = ld_dev(csy + 2), L = ld_dev(csy + 3);
+            V = ld_dev(csy + 2); L = ld_dev(csy + 3);
+        }
+        // =================================================== DP over (rank, column): every member, its own columns
+        if (mem == 0) SUBT(6);   // publish
+        if (V > 0) {
             uint32_t ns = 0xffffffffu;
-            if (V > 0) HX_DP_DISPATCH(L, V, ns);
-            if (ns != 0xffffffffu) sNsink = ns;   // this member owns the last column: hand the sink rows to member 0
+            HX_DP_DISPATCH(L, V, ns);
+            if (ns != 0xffffffffu) sNsink = ns;   // written by the lane that owns column L
             cl.tag0 += V;
+        }
+        if (mem > 0) {
             __syncthreads();
-            if (V > 0 && L / (NT * cm_sel(L)) == mem) {   // this member owns the last column: it has recorded the sink rows
+            if (V > 0 && L / (NT * cm_sel(L)) == mem) {   // this member owns the last column: hand the sink rows to member 0
                 const uint32_t nsk = min(sNsink, SINK_CAP);
                 if (tid == 0) sinkbuf[0] = (int32_t)sNsink;
                 for (uint32_t q = tid; q < nsk; q += NT) { sinkbuf[1 + q] = (int32_t)sink_row[q]; sinkbuf[1 + SINK_CAP + q] = sink_score[q]; }
@@ -761,56 +941,11 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
             __threadfence();                                       // direction bytes, sink rows: visible before "done"
             __syncthreads();
             if (tid == 0) __hip_atomic_fetch_add(csy + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
         }
-        return;
-    }
-    // The reference's topological order (spoa's DFS, inherently serial) is needed in two places only: to break ties between equally scored
-    // end nodes of an alignment, and for the heaviest-bundle traversal of the finished graph. The DP itself runs on a cheaper order that
-    // is maintained incrementally (see "order update" below): row values do not depend on which valid topological order is used.
-    const uint32_t topo_fixed = TOPO_LCAP * 4 + TOPO_LINES * 256 + TOPO_LINES * 4;
-    uint32_t* t_stack = reinterpret_cast<uint32_t*>(ring);
-    uint4* t_cache = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(ring) + TOPO_LCAP * 4);
-    uint32_t* t_tags = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ring) + TOPO_LCAP * 4 + TOPO_LINES * 256);
-    uint8_t* st_lds = reinterpret_cast<uint8_t*>(ring) + topo_fixed;
-    auto exact_order = [&](uint32_t Vn, uint32_t* out) {   // all lanes; leaves spoa's rank->node order of the current graph in out[]
-        const bool in_lds = (uint64_t)Vn + topo_fixed + 16 <= lds_bytes && g.vcap < (1u << 21) - 1;
-        if (in_lds) { for (uint32_t i = tid; i < Vn; i += NT) st_lds[i] = 4u; }                    // mark 0, check 1
-        else { for (uint32_t i = tid; i < Vn; i += NT) { g.mark[i] = 0; g.check[i] = 1; } }
-        __syncthreads();
-        if (in_lds) { if (tid < 64) toposort_coop(g, Vn, st_lds, t_stack, t_cache, t_tags, out); }   // wave 0, 64 lanes in lock step
-        else if (tid == 0) toposort(g, Vn, out);
-        __syncthreads();
-    };
-    uint32_t* tmp_u32 = reinterpret_cast<uint32_t*>(g.pred);   // vcap+1 words of scratch (heaviest-bundle scratch, free until the end)
-
-    for (uint32_t k = ED.seq_begin; k < ED.seq_end; k++) {
-        const PoaSeq q = seqs[k];
-        const uint32_t L = q.len;
-        // ---- decode the gap sub-sequence (forward: read[spos+j]; reverse strand: complement of read[rlen-1-(spos+j)])
-        {
-            const uint8_t* rp = packed + read_off[q.rid];
-            const uint32_t rlen = read_len[q.rid];
-            for (uint32_t j = tid; j < L; j += NT) {
-                uint32_t p = q.strand == 0 ? q.spos + j : rlen - 1 - (q.spos + j);
-                uint8_t b = (rp[p >> 2] >> ((p & 3) * 2)) & 3;
-                seq[j] = q.strand == 0 ? b : (uint8_t)(3 - b);
-            }
-        }
-        __syncthreads();
-        PHASE(0);
-        const uint32_t V = sV;
+        SUBT(7);   // own columns
         if (V > 0) {
-            // =================================================== DP over (rank, column)
             {
-                if (GM > 1) {   // publish this sequence to the other members: graph rows (CSR), decoded sequence, V, L
-                    __threadfence();
-                    __syncthreads();
-                    if (tid == 0) { st_dev(csy + 2, V); st_dev(csy + 3, L); __threadfence(); st_dev(csy + 0, k - ED.seq_begin + 1); }
-                }
-                uint32_t ns = 0xffffffffu;
-                HX_DP_DISPATCH(L, V, ns);
-                if (ns != 0xffffffffu) sNsink = ns;   // written by the lane that owns column L
-                cl.tag0 += V;
                 if (GM > 1) {   // wait for the other members' columns (direction bytes, sinks)
                     __syncthreads();
                     if (tid == 0) {
@@ -832,6 +967,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                 }
             }
             __syncthreads();
+            SUBT(8);   // wait for the other members, sinks
             // ---- end node of the global alignment: the best-scoring sink; ties go to the smallest rank in the REFERENCE's order
             if (tid == 0) {
                 if (sNsink > SINK_CAP) sOk = 2;
@@ -844,6 +980,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
             }
             __syncthreads();
             if (sNcand > 1 && sOk == 1) {
+                if (tid == 0) ph[10] += 1;
                 exact_order(V, tmp_u32);
                 const uint32_t nc = sNcand;
                 for (uint32_t r = tid; r < V; r += NT) {
@@ -855,6 +992,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                 if (tid == 0) { sBestI = (int)sink_row[sBestKey & 1023u]; atomicAdd(&ph[4], 0ull); }
             }
             __syncthreads();
+            SUBT(9);   // end node (ties: reference order)
             PHASE(1);
             // =================================================== traceback, stored reversed
             if (DIR) {
@@ -937,7 +1075,6 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
             if (GM > 1) {   // nothing to align against yet: the other members only count the sequence (and must have read V = 0 before it changes)
                 __syncthreads();
                 if (tid == 0) {
-                    st_dev(csy + 2, 0u); st_dev(csy + 3, L); __threadfence(); st_dev(csy + 0, k - ED.seq_begin + 1);
                     const uint32_t need = (GM - 1) * (k - ED.seq_begin + 1);
                     for (uint32_t spin = 0;; spin++) {
                         if (ld_dev(csy + 1) >= need) break;
@@ -1117,6 +1254,11 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                 const uint32_t cd = g.code[n], sink = g.out_head[n] == NONE;
                 g.row_code[r] = (uint8_t)cd;
                 g.row_sink[r] = (uint8_t)sink;
+                {   // the column's other members in list order, as rank deltas (a column is contiguous in this order)
+                    uint32_t alp = 0;
+                    for (uint32_t q = 0, nq = g.n_aligned[n]; q < nq; q++) alp |= ((g.node2rank[g.aligned[3 * n + q]] - r + 4u) & 7u) << (3 * q);
+                    g.row_al[r] = (uint16_t)alp;
+                }
                 uint32_t np = 0, q0 = 0, q1 = 0;
                 for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) {
                     const uint32_t pr = g.node2rank[g.e_from[e]];
@@ -1161,17 +1303,20 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                         if (q == 0) g.row_pred0[r] = ent; else if (q == 1) g.row_pred1[r] = ent;
                     }
                 }
+#ifndef HX_DP_PROF
                 if (phase) {   // statistics of the rows the next DP will run over
                     if (st_multi) atomicAdd(&ph[7], (unsigned long long)st_multi);
                     if (st_ring) atomicAdd(&ph[8], (unsigned long long)st_ring);
                     if (st_far) atomicAdd(&ph[9], (unsigned long long)st_far);
                     if (tid == 0) { atomicAdd(&ph[6], (unsigned long long)V2); atomicAdd(&ph[10], (unsigned long long)ktot); atomicAdd(&ph[11], 1ull); }
                 }
+#endif
             }
         }
         __syncthreads();
         PHASE(5);
     }
+    if (mem > 0) return;
     if (GM > 1 && tid == 0 && sOk != 1) st_dev(csy + 0, CL_ABORT);   // release the other members
     if (sOk == 1 && sV) {   // heaviest bundle runs on the reference's topological order of the finished graph
         exact_order(sV, g.rank2node);
@@ -1199,7 +1344,7 @@ void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_edges, cons
         k_poa<MNT, CMX, DIRV><<<n_edges, block_threads, ring_bytes, s>>>(edges, order, n_edges, seqs, packed, read_off, read_len, pools, match, mismatch, gap, \
                                                                        cns, cns_len, status, cells, phase, ring_rows, ring_bytes); } while (0)
     // one binary per register budget: <= 256 lanes may use 32-column chunks (256+ VGPRs per lane), 512/1024-lane workgroups 16 / 8
-    if (big) { if (use_dir) HX_LAUNCH(1024, 64, true); else HX_LAUNCH(1024, 64, false); }   // gaps of 8192..65535 bases: slow path (register spills), rare
+    if (big) { if (use_dir) HX_LAUNCH(1024, 32, true); else HX_LAUNCH(1024, 32, false); }   // one workgroup for a gap of 8192..32767 bases: slow path (register spills), rare
     else if (block_threads <= 256) { if (use_dir) HX_LAUNCH(256, 32, true); else HX_LAUNCH(256, 32, false); }
     else if (block_threads <= 512) { if (use_dir) HX_LAUNCH(512, 16, true); else HX_LAUNCH(512, 16, false); }
     else { if (use_dir) HX_LAUNCH(1024, 8, true); else HX_LAUNCH(1024, 8, false); }
