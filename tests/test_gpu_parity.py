@@ -263,3 +263,36 @@ def test_score_matrix_traceback_matches_direction_bytes(sim, ctx):
     finally:
         ctx.set_poa_traceback(1)
     assert a.cns_out() == b.cns_out() and a.assembly_fasta() == b.assembly_fasta()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [("300", "64", "8", "8"), ("300", "64", "4", "3"), ("500", "128", "4", "4"), ("400", "256", "8", "8")])
+def test_shared_edges_cluster_mode(sim, ctx, cfg):
+    """cluster mode: the DP columns of an edge spread over several workgroups (forced here on short gaps with small members, so that
+    every variant — single-wave members, multi-wave members, members without columns for a short read, sink rows in another member —
+    is exercised) gives the consensus of the oracle, bit for bit"""
+    import os
+    pre = sim("--genome-len", "150000", "--seed", "31", "--variant-per-mb", "15")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    prm = ds.params()
+    be = orclib.OracleBackend(ds, 8)
+    ro = host.Run(ds, prm, be.table, None)
+    ro.all()
+    ctx.upload(ds)
+    keys = ("HX_POA_CLUSTER_MIN", "HX_POA_MEMBER_LANES", "HX_POA_CLUSTER_COLS", "HX_POA_CLUSTER_MAX")
+    old = {k: os.environ.get(k) for k in keys}
+    try:
+        for k, v in zip(keys, cfg):
+            os.environ[k] = v
+        rg = host.Run(ds, prm, ctx.backend(), None)
+        rg.all()
+    finally:
+        for k in keys:
+            if old[k] is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = old[k]
+    assert ro.cns_out() == rg.cns_out()
+    assert ro.assembly_fasta() == rg.assembly_fasta()
+    assert ro.cns_stats()["dp_cells"] == rg.cns_stats()["dp_cells"]
+    rg.close(); ro.close(); be.close(); ds.close()
