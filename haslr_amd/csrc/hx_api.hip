@@ -563,7 +563,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             std::vector<uint32_t> batch;
             while (end < todo.size()) {
                 hxk::PoaEdge& E = P.edges[todo[end]];
-                uint64_t nn = (uint64_t)E.vcap + 1, hc = nn * (((uint64_t)E.lmax + 1 + 15) & ~15ull);   // rows padded to 16 columns (vector-aligned lane chunks)
+                uint64_t nn = (uint64_t)E.vcap + 1, hc = nn * (((uint64_t)E.lmax + 1 + 31) & ~31ull);   // rows padded to 32 columns (the widest lane chunk)
                 const uint64_t cle = E.members > 1 ? (uint64_t)E.members * nn : 0;
                 uint64_t b = nn * 86 + (uint64_t)E.ecap * 24 + hc * 5 + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8 + cle * 12;
                 if (!batch.empty() && bytes + b > budget) break;

@@ -820,7 +820,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     const uint32_t ring_w = cmr * NT;
     const uint32_t R = ring_rows >= 2 ? ring_rows : 0;
     uint8_t* seq = P.seq + ED.seq_off;
-    const uint32_t W = (ED.lmax + 1 + 15) & ~15u;   // row stride, padded so that every lane chunk is vector-aligned
+    const uint32_t W = (ED.lmax + 1 + 31) & ~31u;   // row stride: a multiple of the widest lane chunk (32 columns), so chunks are vector-aligned and stay inside their row
 
     __shared__ int lds_i[32];
     __shared__ uint32_t lds_u[16];
@@ -977,6 +977,23 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                 for (uint32_t q = 0; q < nsk; q++) if (sink_score[q] == best) { if (!ncand) first = q; sink_row[ncand++] = sink_row[q]; }   // compact candidates to the front
                 (void)first;
                 sNcand = ncand; sBestI = ncand ? (int)sink_row[0] : -1; sBestKey = 0xffffffffu;
+                // Ties, the usual case: all candidates sit in ONE column (aligned group) whose members are all sinks, e.g. the letters seen
+                // at the end of the gap. Such a column is entered by the reference's DFS only through its oldest member (roots are taken in
+                // node-id order, a sink is nobody's predecessor), which emits itself and then its aligned list; every later member was
+                // appended to that list when it was created, so the column appears in node-id order: the smallest id wins, no sort needed.
+                if (ncand > 1 && ncand <= 4) {
+                    const uint32_t n0 = g.rank2node[sink_row[0] - 1], na0 = g.n_aligned[n0];
+                    uint32_t grp[4] = {n0, NONE, NONE, NONE};
+                    bool ok = g.out_head[n0] == NONE;
+                    for (uint32_t q = 0; q < na0; q++) { grp[1 + q] = g.aligned[3 * n0 + q]; ok = ok && g.out_head[grp[1 + q]] == NONE; }
+                    uint32_t best_n = NONE; int best_row = -1;
+                    for (uint32_t c = 0; c < ncand && ok; c++) {
+                        const uint32_t n = g.rank2node[sink_row[c] - 1];
+                        ok = n == grp[0] || n == grp[1] || n == grp[2] || n == grp[3];
+                        if (n < best_n) { best_n = n; best_row = (int)sink_row[c]; }
+                    }
+                    if (ok) { sBestI = best_row; sNcand = 1; }
+                }
             }
             __syncthreads();
             if (sNcand > 1 && sOk == 1) {
