@@ -1204,21 +1204,26 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
             if (V_old == 0) {
                 for (uint32_t r = tid; r < V2; r += NT) g.rank2node[r] = r;
             } else {
-                for (uint32_t r = tid; r <= V_old; r += NT) ins[r] = 0;
+                uint32_t* firstidx = g.stack + (V_old + 1);   // per insertion point: the first new node (in path order) that goes there
+                for (uint32_t r = tid; r <= V_old; r += NT) { ins[r] = 0; firstidx[r] = NONE; }
                 __syncthreads();
-                if (tid == 0) {
+                {
+                    // every base on its own: new node ids are consecutive in path order, so "position among the new nodes" = id - V_old
                     auto col_first = [&](uint32_t n) { uint32_t f = g.node2rank[n]; for (uint32_t k = 0, na = g.n_aligned[n]; k < na; k++) { const uint32_t a = g.aligned[3 * n + k]; if (a < V_old) f = min(f, g.node2rank[a]); } return f; };
                     auto col_last = [&](uint32_t n) { uint32_t f = g.node2rank[n]; for (uint32_t k = 0, na = g.n_aligned[n]; k < na; k++) { const uint32_t a = g.aligned[3 * n + k]; if (a < V_old) f = max(f, g.node2rank[a]); } return f; };
-                    uint32_t q = 0;
-                    while (q < L) {
-                        if (path[q] < V_old) { q++; continue; }
-                        if (colref[q] != NONE) { const uint32_t X = col_last(colref[q]) + 1; xq[q] = X; ins[X]++; q++; continue; }
-                        uint32_t q2 = q;                                  // run of unaligned new nodes: find the next existing column
-                        while (q2 < L && path[q2] >= V_old && colref[q2] == NONE) q2++;
-                        const uint32_t X = q2 < L ? col_first(path[q2] < V_old ? path[q2] : colref[q2]) : V_old;
-                        for (uint32_t z = q; z < q2; z++) xq[z] = X;
-                        ins[X] += q2 - q;
-                        q = q2;
+                    for (uint32_t q = tid; q < L; q += NT) {
+                        const uint32_t n = path[q];
+                        if (n < V_old) continue;
+                        uint32_t X;
+                        if (colref[q] != NONE) X = col_last(colref[q]) + 1;
+                        else {                                                // unaligned new node: the next existing column on the path
+                            uint32_t q2 = q + 1;
+                            while (q2 < L && path[q2] >= V_old && colref[q2] == NONE) q2++;
+                            X = q2 < L ? col_first(path[q2] < V_old ? path[q2] : colref[q2]) : V_old;
+                        }
+                        xq[q] = X;
+                        atomicAdd(&ins[X], 1u);
+                        atomicMin(&firstidx[X], n - V_old);
                     }
                 }
                 __syncthreads();
@@ -1235,15 +1240,11 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                     ex += c;
                 }
                 __syncthreads();
-                if (tid == 0) {
-                    uint32_t lastX = NONE, k = 0;
-                    for (uint32_t q = 0; q < L; q++) {
-                        if (path[q] < V_old) continue;
-                        const uint32_t X = xq[q];
-                        k = X == lastX ? k + 1 : 0;
-                        lastX = X;
-                        tmp_u32[X + ins[X] + k] = path[q];
-                    }
+                for (uint32_t q = tid; q < L; q += NT) {   // nodes with the same insertion point keep path order
+                    const uint32_t n = path[q];
+                    if (n < V_old) continue;
+                    const uint32_t X = xq[q];
+                    tmp_u32[X + ins[X] + (n - V_old - firstidx[X])] = n;
                 }
                 __syncthreads();
                 for (uint32_t r = tid; r < V2; r += NT) g.rank2node[r] = tmp_u32[r];
