@@ -528,6 +528,8 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     HIPCHK(d_phase.reserve((size_t)ne * 12));
     HIPCHK(hipMemsetAsync(d_phase.p, 0, std::max<size_t>(1, (size_t)ne * 12) * 8, s));
     bool worst_case = false;
+    std::vector<uint8_t> force_nodir(ne, 0);   // edges whose in-degrees outgrew the direction bytes
+    const uint32_t max_indeg = getenv("HX_POA_MAX_INDEG") ? std::min<uint32_t>(16, (uint32_t)atoi(getenv("HX_POA_MAX_INDEG"))) : 16;   // (testing: forces the score-matrix retry earlier)
     const uint32_t cl_lanes = getenv("HX_POA_MEMBER_LANES") ? (uint32_t)atoi(getenv("HX_POA_MEMBER_LANES")) : 256;   // lanes per cluster member
     const uint32_t cl_min = getenv("HX_POA_CLUSTER_MIN") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MIN")) : 2048;       // columns above which an edge is shared
     const uint32_t cl_max = getenv("HX_POA_CLUSTER_MAX") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MAX")) : 8;          // members per edge at most
@@ -546,7 +548,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             // long gaps: the DP columns of the edge are shared by several workgroups (one CU each), ~8 columns per lane
             E.members = 1;
             const uint32_t ncol = E.lmax + 1;
-            if (!c->poa_block && !c->poa_no_dir && P.nseq[e] <= 63 && ncol > cl_min) E.members = (uint32_t)std::min<uint64_t>(cl_max, (ncol + (uint64_t)cl_lanes * cl_cols - 1) / ((uint64_t)cl_lanes * cl_cols));
+            if (!c->poa_block && !c->poa_no_dir && !force_nodir[e] && P.nseq[e] <= 63 && ncol > cl_min) E.members = (uint32_t)std::min<uint64_t>(cl_max, (ncol + (uint64_t)cl_lanes * cl_cols - 1) / ((uint64_t)cl_lanes * cl_cols));
             if (E.members < 2) E.members = 1;
         }
         // largest first (block scheduling is in grid order): cost ~ rows x columns x sequences
@@ -556,7 +558,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
         });
         // ---- batches that fit the memory budget
         size_t pos = 0;
-        std::vector<uint32_t> retry;
+        std::vector<uint32_t> retry, retry_same;   // retry with the worst-case workspace / with the score-matrix traceback
         while (pos < todo.size()) {
             uint64_t no = 0, eo = 0, ho = 0, so = 0, co = 0, sto = 0, ao = 0, clo = 0, bytes = 0;
             size_t end = pos;
@@ -619,7 +621,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
                 uint32_t cm = (ncol + kClassNT[k] - 1) / kClassNT[k], cmr = 4;
                 while (cmr < cm) cmr <<= 1;
                 cls_cm[k] = std::max(cls_cm[k], cmr);
-                if (P.nseq[e] > 63 || c->poa_no_dir) cls_dir[k] = false;   // in-degree <= #sequences must fit the 6-bit predecessor slot
+                if (P.nseq[e] > 63 || c->poa_no_dir || force_nodir[e]) cls_dir[k] = false;   // in-degree <= #sequences must fit the 6-bit predecessor slot
             }
             std::vector<uint32_t> order_all;   // one entry per workgroup: edge | member << 24
             size_t cls_blocks[6];
@@ -654,7 +656,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
                 }
                 HIPCHK(hipStreamWaitEvent(c->poa_streams[k], c->poa_ev[6], 0));
                 hxk::poa_run(d_edges.p, d_order.p + opos, (uint32_t)cls_blocks[k], d_seqs.p, c->packed.p, c->roff.p, c->rlen.p, pools, 0, pp->match, pp->mismatch,
-                             pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)nt, R, (uint32_t)lds_bytes, nt >= 1024 && cls_cm[k] > 8u, cls_dir[k], c->poa_streams[k]);
+                             pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)nt, R, (uint32_t)lds_bytes, nt >= 1024 && cls_cm[k] > 8u, cls_dir[k], max_indeg, c->poa_streams[k]);
                 HIPCHK(hipEventRecord(c->poa_ev[k], c->poa_streams[k]));
                 HIPCHK(hipStreamWaitEvent(s, c->poa_ev[k], 0));
                 opos += cls_blocks[k];
@@ -667,6 +669,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             std::vector<char> h_cns(co);
             if (co) HIPCHK(hipMemcpy(h_cns.data(), d_cns.p, co, hipMemcpyDeviceToHost));
             for (uint32_t e : batch) {
+                if (h_status[e] & HXE_POA_NODIR) { if (force_nodir[e]) return fail("hx_poa_batch: internal error (direction-byte retry)"); force_nodir[e] = 1; retry_same.push_back(e); continue; }
                 if (h_status[e] & ~(uint32_t)HXE_POA_OVERFLOW) return fail("hx_poa_batch: internal error (kernel variant / column count mismatch)");
                 if (h_status[e] & HXE_POA_OVERFLOW) {
                     if (worst_case) return fail("hx_poa_batch: POA workspace overflow at worst-case size (internal error)");
@@ -676,6 +679,8 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             pos = end;
         }
         todo.swap(retry);
+        if (!retry_same.empty() && todo.empty()) { todo.swap(retry_same); continue; }   // same workspace estimate, other traceback
+        todo.insert(todo.end(), retry_same.begin(), retry_same.end());
         worst_case = true;
     }
     unsigned long long cells = 0;
@@ -712,6 +717,16 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
         const unsigned long long* q = &c->poa_phase[(size_t)c->dbg_slowest * 12];
         fprintf(stderr, "[hx] slowest edge %u: lmax=%u nseq=%u | DP rows %llu (multi-pred %llu, ring refs %llu, far refs %llu, kept %llu) over %llu sequences\n", c->dbg_slowest,
                 c->dbg_lmax[c->dbg_slowest], c->dbg_nseq[c->dbg_slowest], q[6], q[7], q[8], q[9], q[10], q[11]);
+        {   // the five longest edges (critical-path candidates)
+            std::vector<std::pair<unsigned long long, uint32_t>> tt;
+            for (size_t e = 0; e < ne; e++) { unsigned long long t = 0; for (int k = 0; k < 6; k++) t += c->poa_phase[e * 12 + k]; tt.push_back({t, (uint32_t)e}); }
+            std::sort(tt.rbegin(), tt.rend());
+            for (size_t k = 0; k < std::min<size_t>(5, tt.size()); k++) {
+                const unsigned long long* q2 = &c->poa_phase[(size_t)tt[k].second * 12];
+                fprintf(stderr, "[hx] top edge %u: lmax=%u nseq=%u cycles=%llu (dp %llu tb %llu graph %llu order %llu csr %llu) rows %llu\n", tt[k].second, c->dbg_lmax[tt[k].second], c->dbg_nseq[tt[k].second],
+                        tt[k].first, q2[1], q2[2], q2[3], q2[4], q2[5], q2[6]);
+            }
+        }
         unsigned long long tot[6] = {0, 0, 0, 0, 0, 0};
         for (size_t e = 0; e < ne; e++) for (int k = 0; k < 6; k++) tot[k] += c->poa_phase[e * 12 + 6 + k];
         fprintf(stderr, "[hx] all edges: DP rows %llu (multi-pred %llu, ring refs %llu, far refs %llu, kept %llu) over %llu sequences\n", tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]);

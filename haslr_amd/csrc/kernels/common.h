@@ -15,6 +15,7 @@ enum {
     HXE_SPOS_RANGE = 4,       // consensus support starts beyond its read (std::out_of_range in the reference)
     HXE_POA_OVERFLOW = 8,     // POA graph outgrew its workspace (host retries with the worst-case size)
     HXE_BAD_TID = 16,
+    HXE_POA_NODIR = 32,       // a POA node gained more than 16 in-edges: the 4-bit predecessor slot of the direction bytes is too small (host retries with the score-matrix traceback)
 };
 
 // contig class bits, computed once per run from mean_kmer and the three thresholds of SURVEY.md A.1

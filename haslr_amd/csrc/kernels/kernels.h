@@ -114,7 +114,7 @@ void poa_run(const PoaEdge* edges, const uint32_t* order /* edge | member << 24,
              unsigned long long* cells, unsigned long long* phase_cycles /* 6 per edge or null */, int block_threads /* multiple of 64, <= 1024 */,
              uint32_t ring_rows, uint32_t ring_bytes /* dynamic LDS: ring_rows x pow2ceil(ceil((lmax+1)/block)) x block x 4 */,
              bool big /* some edge needs more than 16 columns per lane */,
-             bool use_dir /* direction-byte traceback: needs in-degree <= 63, i.e. <= 63 sequences per edge */, hipStream_t s);
+             bool use_dir /* direction-byte traceback (in-degrees <= max_indeg <= 16, else the edge comes back with HXE_POA_NODIR) */, uint32_t max_indeg, hipStream_t s);
 
 }  // namespace hxk
 #endif

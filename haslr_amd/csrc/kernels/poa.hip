@@ -427,12 +427,12 @@ template <int CM> __device__ __forceinline__ void store_chunk_u8(uint8_t* p, con
 // barrier per row) when the workgroup has several waves. A single-wave workgroup never synchronises; waves that own
 // no real column of this sequence only keep the barrier count.
 //
-// Cells are "keys": 64 x score + 6 low bits. The low bits make one max() do the reference's tie-breaking:
-//   move type     63 diagonal > 62 vertical > 1 horizontal (the reference's traceback tries them in this order and takes a
-//                 horizontal move only when nothing else reaches the score), and
-//   63 - p        while the maximum over several predecessors p is formed (the first predecessor in in-edge order wins ties).
-// Scores stay below 2^24 in magnitude (8*(V+L) with V+L < 2^21, checked by the host), so keys fit 32 bits.
-// One direction byte per cell goes to HBM for the traceback: type in bits 0-1 (3/2/1), predecessor slot in bits 2-7.
+// Cells are "keys": 64 x score + 6 low bits = move type * 16 + 15 - predecessor slot. The low bits make one max() do the
+// reference's tie-breaking: type 3 diagonal > 2 vertical > 1 horizontal (its traceback tries them in this order and takes a
+// horizontal move only when nothing else reaches the score), and among moves of one type the first predecessor in in-edge order
+// wins. Scores stay below 2^24 in magnitude (8*(V+L) with V+L < 2^21, checked by the host), so keys fit 32 bits. The 6 bits of the
+// winning move ARE the direction byte written to HBM for the traceback (in-degrees above 16 send the edge back to the host, which
+// retries it with the score-matrix traceback).
 //
 // Rows that a later row needs as a NON-adjacent predecessor are flagged by the CSR build ("kept") and copied to an LDS
 // ring in the order they are produced (lane-transposed layout: column t*CM+k at word k*NT+t, conflict-free), or to
@@ -442,6 +442,7 @@ template <int CM> __device__ __forceinline__ void store_chunk_u8(uint8_t* p, con
 // Columns beyond L are computed like real ones and never read by a real column, so the loop has no column predicates.
 // ---------------------------------------------------------------------------------------------------
 constexpr int32_t NEGK = -(1 << 30);   // "minus infinity" key
+constexpr int KD = 63, KV = 47, KH = 16;   // low 6 bits of a key = move type * 16 + 15 - predecessor slot: diagonal 3, vertical 2, horizontal 1
 
 // ---- cluster mode: the DP columns of one (large) edge are split over several workgroups ("members", one CU each, member m owns the
 // columns [m*NT*CM, (m+1)*NT*CM)). Rows stay the unit of work; what crosses a member boundary is one number per row, the prefix maximum
@@ -651,16 +652,15 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 int neg;   // -1 on a mismatch, 0 on a match
                 if constexpr (CM <= 16) neg = __builtin_amdgcn_sbfe((int)mis, 2 * k, 1);
                 else neg = 2 * k < 32 ? __builtin_amdgcn_sbfe((int)(uint32_t)mis, (2 * k) & 31, 1) : __builtin_amdgcn_sbfe((int)(uint32_t)(mis >> 32), (2 * k) & 31, 1);
-                return (m64 + 63) + ((mm64 - m64) & neg);
+                return (m64 + KD) + ((mm64 - m64) & neg);
             };
             hrow += W;
             if (DIR) drow += W;
             DP_T(0);   // row decode
             int m[CM];
-            uint32_t sl[CM];    // several predecessors: slot of the best diagonal (bits 0-7) and vertical (bits 8-15) predecessor
             auto cells1 = [&](const int (&hp)[CM], const int left) {
 #pragma unroll
-                for (int k = 0; k < CM; k++) m[k] = max((k == 0 ? left : hp[k - 1]) + score_of(k), hp[k] + (g64 + 62));
+                for (int k = 0; k < CM; k++) m[k] = max((k == 0 ? left : hp[k - 1]) + score_of(k), hp[k] + (g64 + KV));
             };
             const uint32_t loc0 = p0 >> 28;
             if (npred == 1 && loc0 == 0) cells1(t, left_prev);     // the previous row: the lane's own registers
@@ -679,31 +679,24 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             } else if (npred == 1) with_far_pred(p0, cells1);      // one row that left the ring
             else {
                 const uint32_t p1 = __builtin_amdgcn_readlane(bC, ri), po = __builtin_amdgcn_readlane(oC, ri);
-                int bd[CM], bv[CM];   // best diagonal / vertical key with 63 - slot in the low bits
+                // the maximum over the predecessors: the low bits carry the move type and 15 - p, so ONE running maximum does it all
+                // (a diagonal beats a vertical move of the same score, the first predecessor in in-edge order beats the later ones)
 #pragma unroll
-                for (int k = 0; k < CM; k++) { bd[k] = NEGK; bv[k] = NEGK; }
+                for (int k = 0; k < CM; k++) m[k] = NEGK;
                 for (uint32_t p = 0; p < npred; p++) {
                     const uint32_t ent = p == 0 ? p0 : p == 1 ? p1 : g.pred_rank[po + p];
-                    const int cd = DIR ? 63 - (int)p : 0;   // direction bytes exist only for edges with <= 63 sequences, i.e. <= 63 in-edges per node
-                    const int gc = g64 + cd, dc = cd - 63;
+                    const int ps = DIR ? (int)p : 0;        // direction bytes exist only while in-degrees stay <= 16 (the CSR build checks)
+                    const int gc = g64 + KV - ps;
                     auto acc = [&](const int (&hp)[CM], const int left) {
 #pragma unroll
-                        for (int k = 0; k < CM; k++) {
-                            bd[k] = max(bd[k], (k == 0 ? left : hp[k - 1]) + score_of(k) + dc);
-                            bv[k] = max(bv[k], hp[k] + gc);
-                        }
+                        for (int k = 0; k < CM; k++) m[k] = max(m[k], max((k == 0 ? left : hp[k - 1]) + score_of(k) - ps, hp[k] + gc));
                     };
                     if ((ent >> 28) == 0) acc(t, left_prev); else with_far_pred(ent, acc);
-                }
-#pragma unroll
-                for (int k = 0; k < CM; k++) {
-                    m[k] = max(bd[k] | 63, (bv[k] | 63) - 1);
-                    if (DIR) sl[k] = (((uint32_t)bd[k] & 63u) ^ 63u) | ((((uint32_t)bv[k] & 63u) ^ 63u) << 8);
                 }
             }
             // chunk-local horizontal recurrence (type 1 loses every tie)
 #pragma unroll
-            for (int k = 1; k < CM; k++) m[k] = max(m[k], (m[k - 1] & ~63) + (g64 + 1));
+            for (int k = 1; k < CM; k++) m[k] = max(m[k], (m[k - 1] & ~63) + (g64 + KH));
             DP_T(1);   // predecessor rows + cells + horizontal chain
             // prefix maximum over the lanes to the left of (chunk end score - its column * gap)
             const int inc = wave_incl_max((m[CM - 1] & ~63) - (jg0 + (CM - 1) * g64));
@@ -724,7 +717,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             DP_T(3);   // cross-wave exchange
             const int base = ex + jg0;            // 64 x (score reaching column j0 through a horizontal move from the left neighbour)
 #pragma unroll
-            for (int k = 0; k < CM; k++) m[k] = max(m[k], base + (k * g64 + 1));
+            for (int k = 0; k < CM; k++) m[k] = max(m[k], base + (k * g64 + KH));
             left_prev = base - g64;               // 64 x H[i][j0-1]: the exclusive prefix already is the finished value left of this chunk
 #pragma unroll
             for (int k = 0; k < CM; k++) t[k] = m[k] & ~63;
@@ -740,15 +733,9 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             if (live) {
                 if (DIR) {
                     uint32_t dc[CM];
-                    if (npred >= 2) {
 #pragma unroll
-                        for (int k = 0; k < CM; k++) dc[k] = ((((uint32_t)m[k] & 1u) ? sl[k] : (sl[k] >> 8)) & 63u) << 2 | ((uint32_t)m[k] & 3u);
-                        store_dirs<CM>(drow + j0, dc, 0xffffffffu);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < CM; k++) dc[k] = (uint32_t)m[k];
-                        store_dirs<CM>(drow + j0, dc, 0x03030303u);
-                    }
+                    for (int k = 0; k < CM; k++) dc[k] = (uint32_t)m[k];
+                    store_dirs<CM>(drow + j0, dc, 0x3f3f3f3fu);   // the move code of every cell: type * 16 + 15 - predecessor slot
                 } else {
                     int pl[CM];
 #pragma unroll
@@ -781,7 +768,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                                             const PoaSeq* __restrict__ seqs, const uint8_t* __restrict__ packed, const uint64_t* __restrict__ read_off,
                                             const uint32_t* __restrict__ read_len, PoaPools P, int32_t match, int32_t mismatch, int32_t gap,
                                             char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells, unsigned long long* phase,
-                                            uint32_t ring_rows, uint32_t lds_bytes) {
+                                            uint32_t ring_rows, uint32_t lds_bytes, uint32_t max_indeg) {
     const uint32_t eidx = order[blockIdx.x] & 0x00ffffffu, mem = order[blockIdx.x] >> 24;   // edge, member of its cluster (0 unless the edge is shared)
     __shared__ unsigned long long ph[12];            // lane-0 cycle counts: decode, dp, traceback, graph update, toposort, csr; then row statistics
     __shared__ long long tc;
@@ -830,7 +817,8 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     __shared__ int sink_score[SINK_CAP];
     __shared__ int32_t cl_ringleft[14];
     __shared__ uint32_t sCtl;
-    if (tid == 0) { sV = 0; sE = 0; sOk = 1; }
+    __shared__ unsigned long long sCells;   // DP cells of this edge (reported only when the edge completes: retried edges count once)
+    if (tid == 0) { sV = 0; sE = 0; sOk = 1; sCells = 0; }
     __syncthreads();
     uint32_t* csy = P.csync + (uint64_t)eidx * 8;                 // go, done, V, L, error
     int32_t* sinkbuf = P.sinkbuf + (uint64_t)eidx * (1 + 2 * SINK_CAP);
@@ -884,6 +872,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
 
     for (uint32_t k = ED.seq_begin; k < ED.seq_end; k++) {
         uint32_t L, V;
+        if (mem == 0 && sOk != 1) break;
         if (mem == 0) {
             const PoaSeq q = seqs[k];
             L = q.len;
@@ -1018,7 +1007,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                 // memory round trip per ~6 steps instead of 3-4 dependent ones per step. Ranks are turned into node ids by all lanes afterwards.
                 if (tid < 64) {
                     const uint32_t ln = tid;
-                    if (ln == 0) atomicAdd(cells, (unsigned long long)V * L);
+                    if (ln == 0) sCells += (unsigned long long)V * L;
                     uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane(sBestI), j = L, na = 0;
                     while (!(i == 0 && j == 0)) {
                         if (i == 0) {   // only horizontal moves are left in the virtual row
@@ -1033,17 +1022,17 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                         if (ln < 16 && ti > ln) { const uint32_t rr = ti - 1 - ln; mt = g.row_meta[rr]; q0 = g.row_pred0[rr]; q1 = g.row_pred1[rr]; qo = g.row_pred_off[rr]; }
                         for (;;) {
                             const uint32_t dr = ti - i, idx = (dr & 7u) * 8 + (tj - j);
-                            const uint32_t d = (dr < 8 ? (uint32_t)__builtin_amdgcn_readlane((int)b0, (int)idx) : (uint32_t)__builtin_amdgcn_readlane((int)b1, (int)idx)) & 0xffu;
-                            uint32_t pi_ = i, pj_ = j;   // type 3 diagonal / 2 vertical / 1 horizontal, predecessor slot in bits 2-7
-                            if ((d & 3u) == 1u) pj_ = j - 1;
+                            const uint32_t d = (dr < 8 ? (uint32_t)__builtin_amdgcn_readlane((int)b0, (int)idx) : (uint32_t)__builtin_amdgcn_readlane((int)b1, (int)idx)) & 0x3fu;
+                            uint32_t pi_ = i, pj_ = j;   // move code: type (3 diagonal / 2 vertical / 1 horizontal) * 16 + 15 - predecessor slot
+                            if ((d >> 4) == 1u) pj_ = j - 1;
                             else {
-                                const uint32_t np = (uint32_t)__builtin_amdgcn_readlane((int)mt, (int)dr) >> 8, slot = d >> 2;
+                                const uint32_t np = (uint32_t)__builtin_amdgcn_readlane((int)mt, (int)dr) >> 8, slot = 15u - (d & 15u);
                                 uint32_t ent;
                                 if (slot == 0) ent = (uint32_t)__builtin_amdgcn_readlane((int)q0, (int)dr);
                                 else if (slot == 1) ent = (uint32_t)__builtin_amdgcn_readlane((int)q1, (int)dr);
                                 else ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[(uint32_t)__builtin_amdgcn_readlane((int)qo, (int)dr) + slot]);
                                 pi_ = np == 0 ? 0u : (ent & 0x0fffffffu) + 1;
-                                if ((d & 3u) == 3u) pj_ = j - 1;
+                                if ((d >> 4) == 3u) pj_ = j - 1;
                             }
                             if (ln == 0) { g.aln_node[na] = i == pi_ ? 0 : (int32_t)i; g.aln_pos[na] = j == pj_ ? -1 : (int32_t)(j - 1); }
                             na++;
@@ -1056,7 +1045,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                 __syncthreads();
                 for (uint32_t k = tid, nk = sNaln; k < nk; k += NT) { const int32_t r = g.aln_node[k]; g.aln_node[k] = r == 0 ? -1 : (int32_t)g.rank2node[r - 1]; }
             } else if (tid == 0) {
-                atomicAdd(cells, (unsigned long long)V * L);
+                sCells += (unsigned long long)V * L;
                 uint32_t i = (uint32_t)sBestI, j = L, na = 0;
                 while (!DIR && !(i == 0 && j == 0)) {
                     const int hij = H[(uint64_t)i * W + j];
@@ -1285,6 +1274,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                     np++;
                 }
                 g.row_meta[r] = cd | (sink << 2) | (np << 8);
+                if (DIR && np > max_indeg) sOk = 4;   // the direction bytes hold a 4-bit predecessor slot (max_indeg <= 16)
                 g.row_pred0[r] = q0; g.row_pred1[r] = q1;
             }
             if (tid == NT - 1) g.row_pred_off[V2] = tot;
@@ -1344,7 +1334,8 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     if (tid == 0) {
         if (sOk == 2) { status[eidx] = HXE_SPOS_RANGE << 8; cns_len[eidx] = 0; }   // internal: kernel variant cannot hold this many columns per lane
         else if (!sOk) { status[eidx] = HXE_POA_OVERFLOW; cns_len[eidx] = 0; }
-        else { status[eidx] = 0; cns_len[eidx] = sV ? consensus(g, sV, cns + ED.cns_off) : 0; }
+        else if (sOk == 4) { status[eidx] = HXE_POA_NODIR; cns_len[eidx] = 0; }
+        else { status[eidx] = 0; cns_len[eidx] = sV ? consensus(g, sV, cns + ED.cns_off) : 0; atomicAdd(cells, sCells); }
         PHASE(3);
         if (phase) for (int k = 0; k < 12; k++) phase[(uint64_t)eidx * 12 + k] = ph[k];
     }
@@ -1355,12 +1346,12 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
 void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_edges, const PoaSeq* seqs, const uint8_t* packed, const uint64_t* read_off,
              const uint32_t* read_len, PoaPools pools, uint64_t, int32_t match, int32_t mismatch, int32_t gap, char* cns, uint32_t* cns_len,
              uint32_t* status, unsigned long long* cells, unsigned long long* phase, int block_threads, uint32_t ring_rows, uint32_t ring_bytes, bool big,
-             bool use_dir, hipStream_t s) {
+             bool use_dir, uint32_t max_indeg, hipStream_t s) {
     if (!n_edges) return;
 #define HX_LAUNCH(MNT, CMX, DIRV) do { \
         (void)hipFuncSetAttribute((const void*)k_poa<MNT, CMX, DIRV>, hipFuncAttributeMaxDynamicSharedMemorySize, 146 * 1024); \
         k_poa<MNT, CMX, DIRV><<<n_edges, block_threads, ring_bytes, s>>>(edges, order, n_edges, seqs, packed, read_off, read_len, pools, match, mismatch, gap, \
-                                                                       cns, cns_len, status, cells, phase, ring_rows, ring_bytes); } while (0)
+                                                                       cns, cns_len, status, cells, phase, ring_rows, ring_bytes, max_indeg); } while (0)
     // one binary per register budget: <= 256 lanes may use 32-column chunks (256+ VGPRs per lane), 512/1024-lane workgroups 16 / 8
     if (big) { if (use_dir) HX_LAUNCH(1024, 32, true); else HX_LAUNCH(1024, 32, false); }   // one workgroup for a gap of 8192..32767 bases: slow path (register spills), rare
     else if (block_threads <= 256) { if (use_dir) HX_LAUNCH(256, 32, true); else HX_LAUNCH(256, 32, false); }

@@ -296,3 +296,30 @@ def test_shared_edges_cluster_mode(sim, ctx, cfg):
     assert ro.assembly_fasta() == rg.assembly_fasta()
     assert ro.cns_stats()["dp_cells"] == rg.cns_stats()["dp_cells"]
     rg.close(); ro.close(); be.close(); ds.close()
+
+
+@pytest.mark.gpu
+def test_in_degree_retry_with_score_matrix(sim, ctx):
+    """direction bytes carry a 4-bit predecessor slot; an edge whose graph grows a node with more in-edges comes back from the kernel
+    and is redone with the score-matrix traceback. Forced here by lowering the limit to 2: results (and the reported cell count) stay
+    those of the oracle"""
+    pre = sim("--genome-len", "120000", "--seed", "33", "--variant-per-mb", "15")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    prm = ds.params()
+    be = orclib.OracleBackend(ds, 8)
+    ro = host.Run(ds, prm, be.table, None)
+    ro.all()
+    ctx.upload(ds)
+    old = os.environ.get("HX_POA_MAX_INDEG")
+    try:
+        os.environ["HX_POA_MAX_INDEG"] = "2"
+        rg = host.Run(ds, prm, ctx.backend(), None)
+        rg.all()
+    finally:
+        if old is None:
+            os.environ.pop("HX_POA_MAX_INDEG", None)
+        else:
+            os.environ["HX_POA_MAX_INDEG"] = old
+    assert ro.cns_out() == rg.cns_out()
+    assert ro.cns_stats()["dp_cells"] == rg.cns_stats()["dp_cells"]
+    rg.close(); ro.close(); be.close(); ds.close()
