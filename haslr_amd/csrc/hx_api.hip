@@ -589,7 +589,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             if (clo) HIPCHK(hipMemsetAsync(B.mbox.p, 0, clo * 8, s));   // tag 0 = nothing published
             uint64_t n_blocks_total = 0;
             for (uint32_t e : batch) n_blocks_total += P.edges[e].members;
-            HIPCHK(d_edges.reserve(ne)); HIPCHK(d_order.reserve(n_blocks_total)); HIPCHK(d_len.reserve(ne)); HIPCHK(d_status.reserve(ne));
+            HIPCHK(d_edges.reserve(ne)); HIPCHK(d_len.reserve(ne)); HIPCHK(d_status.reserve(ne));
             // lanes per edge. Gaps up to 2047 bases: ONE wavefront per edge (row in registers, no barriers, many edges per CU).
             // Longer gaps: a multi-wave workgroup with ~8 columns per lane (256..1024 lanes). One launch per class, classes run concurrently.
             // Class 0 = edges shared by several workgroups (cluster members of cl_lanes lanes); classes 1..5 = one workgroup per edge.
@@ -627,11 +627,24 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             size_t cls_blocks[6];
             for (int k = 0; k < 6; k++) {
                 const size_t before = order_all.size();
-                for (uint32_t e : cls_list[k]) for (uint32_t m = 0; m < P.edges[e].members; m++) order_all.push_back(e | (m << 24));
+                if (k == 0 && !getenv("HX_POA_NO_XCD_MAP")) {
+                    // Workgroups are handed to the 8 XCDs round-robin by index: put the members of one edge 8 indices apart so that they share an
+                    // XCD (one L2 for the carries, the handshakes and the direction bytes member 0 walks back over). Holes are no-op workgroups.
+                    for (size_t g0 = 0; g0 < cls_list[0].size(); g0 += 8) {
+                        const size_t g1 = std::min(cls_list[0].size(), g0 + 8);
+                        uint32_t gmax = 0;
+                        for (size_t j = g0; j < g1; j++) gmax = std::max(gmax, P.edges[cls_list[0][j]].members);
+                        for (uint32_t m = 0; m < gmax; m++)
+                            for (size_t j = g0; j < g0 + 8; j++)
+                                order_all.push_back(j < g1 && m < P.edges[cls_list[0][j]].members ? (cls_list[0][j] | (m << 24)) : 0x00ffffffu);
+                    }
+                } else
+                    for (uint32_t e : cls_list[k]) for (uint32_t m = 0; m < P.edges[e].members; m++) order_all.push_back(e | (m << 24));
                 cls_blocks[k] = order_all.size() - before;
             }
             if (ne >= (1u << 24)) return fail("hx_poa_batch: more than 2^24 edges in one call");
             HIPCHK(hipMemcpyAsync(d_edges.p, P.edges.data(), (size_t)ne * sizeof(hxk::PoaEdge), hipMemcpyHostToDevice, s));
+            HIPCHK(d_order.reserve(order_all.size()));
             HIPCHK(hipMemcpyAsync(d_order.p, order_all.data(), order_all.size() * 4, hipMemcpyHostToDevice, s));
             hxk::PoaPools pools{B.code.p, B.n_aligned.p, B.aligned.p, B.in_head.p, B.in_tail.p, B.out_head.p, B.out_tail.p, B.rank2node.p, B.node2rank.p,
                                 B.mark.p, B.check.p, B.stack.p, B.score.p, B.pred.p, B.row_code.p, B.row_sink.p, B.row_pred_off.p, B.pred_rank.p, B.row_meta.p, B.row_pred0.p, B.row_pred1.p, B.nrec.p,

@@ -603,7 +603,10 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             const int32_t* S = ring_me + (size_t)(loc - 1) * ring_w;
 #pragma unroll
             for (int k = 0; k < CM; k++) hp[k] = S[k * NT];
-            left = tid > 0 ? S[(CM - 1) * NT - 1] : has_in ? cl.ringleft[loc - 1] : NEGK;
+            {   // both candidates are read unconditionally (one LDS round trip, no branch), then selected
+                const int nb = S[(CM - 1) * NT - (tid > 0 ? 1 : 0)], rl = cl.ringleft[loc - 1];
+                left = tid > 0 ? nb : has_in ? rl : NEGK;
+            }
         } else if (live) {                 // kept row that fell out of the ring: HBM
             const int32_t* Gp = H + (uint64_t)((ent & 0x0fffffffu) + 1) * W + j0;
             load_chunk_i32<CM>(Gp, hp);
@@ -669,7 +672,10 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 const int32_t* S = ring_me + (size_t)(loc0 - 1) * ring_w;
 #pragma unroll
                 for (int k = 0; k < CM; k++) hp[k] = S[k * NT];
-                left = tid > 0 ? S[(CM - 1) * NT - 1] : has_in ? cl.ringleft[loc0 - 1] : NEGK;
+                {
+                    const int nb = S[(CM - 1) * NT - (tid > 0 ? 1 : 0)], rl = cl.ringleft[loc0 - 1];
+                    left = tid > 0 ? nb : has_in ? rl : NEGK;
+                }
                 cells1(hp, left);
             } else if (npred == 0) {                               // source node: the virtual row 0
                 int hp[CM];
@@ -770,6 +776,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                                             char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells, unsigned long long* phase,
                                             uint32_t ring_rows, uint32_t lds_bytes, uint32_t max_indeg) {
     const uint32_t eidx = order[blockIdx.x] & 0x00ffffffu, mem = order[blockIdx.x] >> 24;   // edge, member of its cluster (0 unless the edge is shared)
+    if (eidx == 0x00ffffffu) return;                  // hole in the XCD-aligned cluster grid
     __shared__ unsigned long long ph[12];            // lane-0 cycle counts: decode, dp, traceback, graph update, toposort, csr; then row statistics
     __shared__ long long tc;
     if (threadIdx.x == 0) { for (int k = 0; k < 12; k++) ph[k] = 0; tc = clock64(); }
