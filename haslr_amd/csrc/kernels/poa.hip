@@ -1009,9 +1009,9 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
             PHASE(1);
             // =================================================== traceback, stored reversed
             if (DIR) {
-                // Direction bytes: the first wavefront walks the path together. A tile of 16 rows x 8 columns of direction bytes (two registers)
-                // and the records of those 16 rows are fetched with one round of loads; the walk inside the tile runs on v_readlane, i.e. one
-                // memory round trip per ~6 steps instead of 3-4 dependent ones per step. Ranks are turned into node ids by all lanes afterwards.
+                // Direction bytes: the first wavefront walks the path together. A tile of 32 rows x 16 columns of direction bytes (two registers)
+                // and the records of those 32 rows are fetched with one round of loads; the walk inside the tile runs on v_readlane, i.e. one
+                // memory round trip per ~12 steps instead of 3-4 dependent ones per step. Ranks are turned into node ids by all lanes afterwards.
                 if (tid < 64) {
                     const uint32_t ln = tid;
                     if (ln == 0) sCells += (unsigned long long)V * L;
@@ -1022,14 +1022,19 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                             na += j; j = 0;
                             break;
                         }
-                        const uint32_t ti = i, tj = j, r0 = ln >> 3, c0 = ln & 7u;
-                        uint32_t b0 = 0, b1 = 0, mt = 0, q0 = 0, q1 = 0, qo = 0;
-                        if (ti > r0 && tj >= c0) b0 = Dm[(uint64_t)(ti - r0) * W + (tj - c0)];
-                        if (ti > r0 + 8 && tj >= c0) b1 = Dm[(uint64_t)(ti - r0 - 8) * W + (tj - c0)];
-                        if (ln < 16 && ti > ln) { const uint32_t rr = ti - 1 - ln; mt = g.row_meta[rr]; q0 = g.row_pred0[rr]; q1 = g.row_pred1[rr]; qo = g.row_pred_off[rr]; }
+                        // tile: 32 rows (ranks ti .. ti-31) x 16 columns (tj .. tj-15); lane = (row, half): 8 bytes of one row in two registers
+                        const uint32_t ti = i, tj = j, r0 = ln >> 1, c0 = (ln & 1u) * 8;
+                        uint32_t w0 = 0, w1 = 0, mt = 0, q0 = 0, q1 = 0, qo = 0;
+                        if (ti > r0) {
+                            const uint8_t* rowp = Dm + (uint64_t)(ti - r0) * W;
+#pragma unroll
+                            for (uint32_t q = 0; q < 4; q++) { if (tj >= c0 + q) w0 |= (uint32_t)rowp[tj - c0 - q] << (8 * q); if (tj >= c0 + 4 + q) w1 |= (uint32_t)rowp[tj - c0 - 4 - q] << (8 * q); }
+                        }
+                        if (ln < 32 && ti > ln) { const uint32_t rr = ti - 1 - ln; mt = g.row_meta[rr]; q0 = g.row_pred0[rr]; q1 = g.row_pred1[rr]; qo = g.row_pred_off[rr]; }
                         for (;;) {
-                            const uint32_t dr = ti - i, idx = (dr & 7u) * 8 + (tj - j);
-                            const uint32_t d = (dr < 8 ? (uint32_t)__builtin_amdgcn_readlane((int)b0, (int)idx) : (uint32_t)__builtin_amdgcn_readlane((int)b1, (int)idx)) & 0x3fu;
+                            const uint32_t dr = ti - i, dcq = tj - j, idx = dr * 2 + (dcq >> 3);
+                            const uint32_t wsel = (dcq & 4u) ? (uint32_t)__builtin_amdgcn_readlane((int)w1, (int)idx) : (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)idx);
+                            const uint32_t d = (wsel >> (8 * (dcq & 3u))) & 0x3fu;
                             uint32_t pi_ = i, pj_ = j;   // move code: type (3 diagonal / 2 vertical / 1 horizontal) * 16 + 15 - predecessor slot
                             if ((d >> 4) == 1u) pj_ = j - 1;
                             else {
@@ -1044,7 +1049,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                             if (ln == 0) { g.aln_node[na] = i == pi_ ? 0 : (int32_t)i; g.aln_pos[na] = j == pj_ ? -1 : (int32_t)(j - 1); }
                             na++;
                             i = pi_; j = pj_;
-                            if (i == 0 || ti - i >= 16 || tj - j >= 8) break;
+                            if (i == 0 || ti - i >= 32 || tj - j >= 16) break;
                         }
                     }
                     if (ln == 0) sNaln = na;
