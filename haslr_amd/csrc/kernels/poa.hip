@@ -689,8 +689,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 // (a diagonal beats a vertical move of the same score, the first predecessor in in-edge order beats the later ones)
 #pragma unroll
                 for (int k = 0; k < CM; k++) m[k] = NEGK;
-                for (uint32_t p = 0; p < npred; p++) {
-                    const uint32_t ent = p == 0 ? p0 : p == 1 ? p1 : g.pred_rank[po + p];
+                auto acc_pred = [&](const uint32_t ent, const uint32_t p) {
                     const int ps = DIR ? (int)p : 0;        // direction bytes exist only while in-degrees stay <= 16 (the CSR build checks)
                     const int gc = g64 + KV - ps;
                     auto acc = [&](const int (&hp)[CM], const int left) {
@@ -698,7 +697,12 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                         for (int k = 0; k < CM; k++) m[k] = max(m[k], max((k == 0 ? left : hp[k - 1]) + score_of(k) - ps, hp[k] + gc));
                     };
                     if ((ent >> 28) == 0) acc(t, left_prev); else with_far_pred(ent, acc);
-                }
+                };
+                // the first two predecessors come with the row record (registers); only a third and later ones are fetched — in their own
+                // loop, so that the common case never waits for a "possibly pending" global load (and with it for the previous rows' stores)
+                acc_pred(p0, 0);
+                acc_pred(p1, 1);
+                for (uint32_t p = 2; p < npred; p++) acc_pred((uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[po + p]), p);
             }
             // chunk-local horizontal recurrence (type 1 loses every tie)
 #pragma unroll
