@@ -656,7 +656,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             for (int k = 0; k < 6; k++) {
                 if (cls_list[k].empty()) continue;
                 const uint32_t nt = k == 0 ? cl_lanes : (uint32_t)kClassNT[k];
-                const uint64_t row_bytes = (uint64_t)cls_cm[k] * nt * 4;
+                const uint64_t row_bytes = (uint64_t)cls_cm[k] * (nt + 1) * 4;   // planes of nt + 1 words
                 const uint64_t lds_budget = nt >= 1024 ? 128 * 1024 : nt == 64 ? 32 * 1024 : 64 * 1024 * (nt / 128 > 2 ? 2 : 1);
                 uint64_t rows_fit = std::min<uint64_t>(lds_budget * 9 / 8, 140 * 1024) / row_bytes;   // ring slots + 1 scratch slot
                 uint32_t R = rows_fit >= 9 ? 8 : rows_fit >= 5 ? 4 : rows_fit >= 3 ? 2 : 0;   // power of two (slot = kept-row counter & (R-1))

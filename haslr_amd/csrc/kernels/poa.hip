@@ -594,7 +594,10 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     fetch(0, mN, aN, bN, oN);
     int32_t* hrow = H;
     uint8_t* drow = D;
-    const int32_t* ring_me = ring + tid;                 // lane-transposed rows: column t*CM+k at word k*NT+t
+    // ring rows, lane-transposed with one spare word per plane: column t*CM+k at word k*(NT+1) + 1 + t. Word 0 of the LAST plane holds the
+    // value left of the workgroup's first column, so "the column left of my chunk" is word (CM-1)*(NT+1) + t for EVERY lane: one load, no select
+    const uint32_t PW = NT + 1;
+    const int32_t* ring_me = ring + tid;
     // f(row, left) on a predecessor row that is not the previous row
     auto with_far_pred = [&](const uint32_t ent, auto&& f) {
         const uint32_t loc = ent >> 28;
@@ -602,11 +605,8 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
         if (loc != 15) {                   // kept row in the LDS ring
             const int32_t* S = ring_me + (size_t)(loc - 1) * ring_w;
 #pragma unroll
-            for (int k = 0; k < CM; k++) hp[k] = S[k * NT];
-            {   // both candidates are read unconditionally (one LDS round trip, no branch), then selected
-                const int nb = S[(CM - 1) * NT - (tid > 0 ? 1 : 0)], rl = cl.ringleft[loc - 1];
-                left = tid > 0 ? nb : has_in ? rl : NEGK;
-            }
+            for (int k = 0; k < CM; k++) hp[k] = S[k * PW + 1];
+            left = S[(CM - 1) * PW];
         } else if (live) {                 // kept row that fell out of the ring: HBM
             const int32_t* Gp = H + (uint64_t)((ent & 0x0fffffffu) + 1) * W + j0;
             load_chunk_i32<CM>(Gp, hp);
@@ -671,11 +671,8 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 int hp[CM], left;
                 const int32_t* S = ring_me + (size_t)(loc0 - 1) * ring_w;
 #pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] = S[k * NT];
-                {
-                    const int nb = S[(CM - 1) * NT - (tid > 0 ? 1 : 0)], rl = cl.ringleft[loc0 - 1];
-                    left = tid > 0 ? nb : has_in ? rl : NEGK;
-                }
+                for (int k = 0; k < CM; k++) hp[k] = S[k * PW + 1];
+                left = S[(CM - 1) * PW];
                 cells1(hp, left);
             } else if (npred == 0) {                               // source node: the virtual row 0
                 int hp[CM];
@@ -735,8 +732,8 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 const uint32_t kept = (meta >> 4) & 1u, slot = kept ? (nkept & (R - 1)) : R;
                 int32_t* S = ring + (size_t)slot * ring_w + tid;
 #pragma unroll
-                for (int k = 0; k < CM; k++) S[k * NT] = t[k];
-                if (has_in && tid == 0) cl.ringleft[slot] = left_prev;
+                for (int k = 0; k < CM; k++) S[k * PW + 1] = t[k];
+                if (tid == 0) S[(CM - 1) * PW] = left_prev;   // (first member: "minus infinity")
             }
             nkept += (meta >> 4) & 1u;
             DP_T(4);   // carry applied, kept-row copy
@@ -815,7 +812,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     const uint32_t GM = ED.members;                  // workgroups sharing this edge's DP columns
     const uint32_t cme = (ED.lmax + 1 + GM * NT - 1) / (GM * NT);
     const uint32_t cmr = cme <= 4 ? 4 : cme <= 8 ? 8 : cme <= 16 ? 16 : 32;
-    const uint32_t ring_w = cmr * NT;
+    const uint32_t ring_w = cmr * (NT + 1);   // planes of NT + 1 words (dp_rows)
     const uint32_t R = ring_rows >= 2 ? ring_rows : 0;
     uint8_t* seq = P.seq + ED.seq_off;
     const uint32_t W = (ED.lmax + 1 + 31) & ~31u;   // row stride: a multiple of the widest lane chunk (32 columns), so chunks are vector-aligned and stay inside their row
