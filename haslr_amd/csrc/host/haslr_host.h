@@ -22,6 +22,11 @@ const char* hxh_last_error(void);
 /* ---- ingest (Contig.cpp:43-117, Longread.cpp:109-162, :234-302; kseq-compatible FASTA/FASTQ[.gz]) */
 hxh_dataset* hxh_dataset_load(const char* contig_path, const char* long_path, int long_fofn,
                               const char* mapping_path, int mapping_fofn);
+/* the same with an explicit number of ingest threads (0 = automatic: HASLR_IO_THREADS or up to 16; 1 = the streaming single-thread
+ * readers). Plain FASTA and PAF files are mapped, cut at record boundaries and parsed in parallel; gzip, FASTQ and small files stream.
+ * The arrays are identical for every thread count. */
+hxh_dataset* hxh_dataset_load_mt(const char* contig_path, const char* long_path, int long_fofn,
+                                 const char* mapping_path, int mapping_fofn, unsigned threads);
 void hxh_dataset_free(hxh_dataset*);
 void hxh_dataset_views(const hxh_dataset*, hx_contigs*, hx_reads*, hx_hits*, const uint64_t** read_hit_off);
 double hxh_dataset_uniq_freq(const hxh_dataset*);   /* Contig.cpp:162-174 */

@@ -39,7 +39,7 @@ struct Dataset {
     }
 };
 
-Dataset* load_dataset(const char* contig_path, const char* long_path, bool long_fofn, const char* mapping_path, bool mapping_fofn);
+Dataset* load_dataset(const char* contig_path, const char* long_path, bool long_fofn, const char* mapping_path, bool mapping_fofn, unsigned threads /* 0 = automatic, 1 = streaming readers only */);
 
 // ---------------------------------------------------------------------------------------------
 // Backbone graph. The reference keeps `vector<BBG_Node_t>` with two std::map<uint32_t,BBG_Edge_t>

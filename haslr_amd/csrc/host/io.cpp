@@ -13,6 +13,10 @@
 #include "host_internal.h"
 
 #include <zlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -20,6 +24,7 @@
 #include <cstring>
 #include <fstream>
 #include <functional>
+#include <thread>
 
 namespace hxh {
 
@@ -119,7 +124,219 @@ bool parse_u32(const char* b, const char* e, uint32_t& v) {
     return true;
 }
 
+// ---- multi-threaded ingest of PLAIN (not gzip) files: the file is mapped, cut at record boundaries, parsed by `threads` workers into
+// private buffers and stitched together in file order. Results are the arrays the streaming readers above produce, element for element
+// (tests/test_ingest_mt.py); gzip input, FASTQ and anything unusual falls back to the streaming readers.
+struct Mapped {
+    const char* p = nullptr; size_t n = 0; int fd = -1;
+    explicit Mapped(const std::string& path) {
+        fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) return;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); fd = -1; return; }
+        n = (size_t)st.st_size;
+        if (n == 0) return;
+        void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); fd = -1; n = 0; return; }
+        p = (const char*)m;
+    }
+    ~Mapped() { if (p) munmap((void*)p, n); if (fd >= 0) close(fd); }
+    bool ok() const { return fd >= 0; }
+    bool gz() const { return n >= 2 && (unsigned char)p[0] == 0x1f && (unsigned char)p[1] == 0x8b; }
+};
+
+template <class F> void run_parallel(unsigned threads, F&& f) {   // f(thread index)
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < threads; t++) th.emplace_back([&f, t]() { f(t); });
+    f(0);
+    for (auto& x : th) x.join();
+}
+
+// start of the line that contains or follows position `pos` ... i.e. first line start >= pos
+inline size_t next_line_start(const char* p, size_t n, size_t pos) {
+    if (pos == 0) return 0;
+    const char* nl = (const char*)memchr(p + pos - 1, '\n', n - (pos - 1));
+    return nl ? (size_t)(nl - p) + 1 : n;
+}
+
+struct PafPart {
+    std::vector<uint32_t> q_id, q_start, q_end, t_id, t_len, t_start, t_end, n_match, n_block, cg_ops;
+    std::vector<uint8_t> is_rev, mapq;
+    std::vector<uint64_t> cg_off;       // local offsets
+    uint64_t lines = 0;                  // lines in this part (for global line numbers)
+    uint64_t first_rec_line = 0;         // local line number of the first record (1-based), 0 = no record
+    uint64_t err_line = 0; std::string err;   // first error of this part (local line number)
+};
+
+// one PAF line -> part; returns false with part.err set
+bool parse_paf_line(const char* b, const char* end, PafPart& d, size_t n_reads, size_t n_contigs, std::vector<std::pair<const char*, const char*>>& f, const std::string& path) {
+    f.clear();
+    for (const char* p = b;; p++) {
+        if (p == end || *p == '\t') { f.push_back({b, p}); b = p + 1; if (p == end) break; }
+    }
+    if (f.size() < 12) { d.err = "has fewer than 12 columns"; return false; }
+    uint32_t v[12] = {0};
+    static const int numeric[] = {0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11};
+    for (int k : numeric)
+        if (!parse_u32(f[k].first, f[k].second, v[k])) {
+            d.err = ": column " + std::to_string(k + 1) + " is not an unsigned integer (read and contig names must be the ordinals haslr.py assigns)";
+            return false;
+        }
+    if (v[0] >= n_reads) { d.err = "Q" + std::to_string(v[0]); return false; }
+    if (v[5] >= n_contigs) { d.err = "T" + std::to_string(v[5]); return false; }
+    if (!d.q_id.empty() && v[0] < d.q_id.back()) { d.err = "ORDER"; return false; }
+    d.q_id.push_back(v[0]); d.q_start.push_back(v[2]); d.q_end.push_back(v[3]);
+    d.is_rev.push_back(*f[4].first == '-' ? 1 : 0);
+    d.t_id.push_back(v[5]); d.t_len.push_back(v[6]); d.t_start.push_back(v[7]); d.t_end.push_back(v[8]);
+    d.n_match.push_back(v[9]); d.n_block.push_back(v[10]); d.mapq.push_back((uint8_t)v[11]);
+    d.cg_off.push_back(d.cg_ops.size());
+    for (size_t k = 12; k < f.size(); k++) {
+        if (f[k].second - f[k].first >= 5 && memcmp(f[k].first, "cg:Z:", 5) == 0) {
+            const char* p = f[k].first + 5;
+            while (p < f[k].second) {
+                uint64_t len = 0;
+                const char* q = p;
+                while (q < f[k].second && *q >= '0' && *q <= '9') { len = len * 10 + (uint64_t)(*q - '0'); q++; }
+                if (q == p || q == f[k].second) break;
+                if (len >= (1u << 30)) { d.err = "CIGAR"; return false; }
+                uint32_t code = *q == 'M' ? HX_CG_M : *q == 'I' ? HX_CG_I : *q == 'D' ? HX_CG_D : HX_CG_OTHER;
+                if (len) d.cg_ops.push_back(((uint32_t)len << 2) | code);
+                p = q + 1;
+            }
+            break;
+        }
+    }
+    return true;
+}
+
+std::string paf_error_text(const std::string& code, uint64_t lineno, const std::string& path) {
+    if (code == "ORDER") return "[ERROR] PAF is not grouped by ascending query id at line " + std::to_string(lineno) + " (the reference silently mis-assigns alignments in that case, Longread.cpp:57-84)";
+    if (code == "CIGAR") return "[ERROR] CIGAR operation longer than 2^30 at PAF line " + std::to_string(lineno);
+    if (code[0] == 'Q') return "[ERROR] PAF query " + code.substr(1) + " is not a loaded long read";
+    if (code[0] == 'T') return "[ERROR] PAF target " + code.substr(1) + " is not a loaded contig";
+    if (code[0] == ':') return "[ERROR] PAF line " + std::to_string(lineno) + " of " + path + code;
+    return "[ERROR] PAF line " + std::to_string(lineno) + " of " + path + " " + code;
+}
+
+// returns 1 done, 0 error (g_err set), -1 not applicable (caller streams)
+int load_paf_parallel(Dataset& d, const std::string& path, unsigned threads) {
+    Mapped m(path);
+    if (!m.ok()) return -1;
+    if (m.gz() || m.n < (1u << 16) || threads < 2) return -1;
+    std::vector<size_t> cut(threads + 1);
+    for (unsigned t = 0; t <= threads; t++) cut[t] = t == threads ? m.n : next_line_start(m.p, m.n, m.n / threads * t);
+    std::vector<PafPart> parts(threads);
+    const size_t n_reads = d.read_len.size(), n_contigs = d.contig_len.size();
+    run_parallel(threads, [&](unsigned t) {
+        PafPart& P = parts[t];
+        std::vector<std::pair<const char*, const char*>> f;
+        const char* p = m.p + cut[t];
+        const char* pe = m.p + cut[t + 1];
+        while (p < pe) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(pe - p));
+            const char* le = nl ? nl : pe;
+            const char* e2 = le;
+            if (e2 > p && e2[-1] == '\r') e2--;
+            P.lines++;
+            if (e2 > p) {
+                if (!parse_paf_line(p, e2, P, n_reads, n_contigs, f, path)) { P.err_line = P.lines; return; }
+                if (!P.first_rec_line) P.first_rec_line = P.lines;
+            }
+            p = nl ? nl + 1 : pe;
+        }
+    });
+    // errors in file order, including the ordering rule across part boundaries
+    uint64_t line0 = 0;
+    bool have_last = !d.q_id.empty();
+    uint32_t last_q = have_last ? d.q_id.back() : 0;
+    for (unsigned t = 0; t < threads; t++) {
+        const PafPart& P = parts[t];
+        const bool boundary_bad = have_last && !P.q_id.empty() && P.q_id.front() < last_q;
+        if (boundary_bad && (!P.err_line || P.first_rec_line <= P.err_line)) { g_err = paf_error_text("ORDER", line0 + P.first_rec_line, path); return 0; }
+        if (P.err_line) { g_err = paf_error_text(P.err, line0 + P.err_line, path); return 0; }
+        if (!P.q_id.empty()) { have_last = true; last_q = P.q_id.back(); }
+        line0 += P.lines;
+    }
+    // stitch
+    std::vector<size_t> rec0(threads + 1, d.q_id.size()), op0(threads + 1, d.cg_ops.size());
+    for (unsigned t = 0; t < threads; t++) { rec0[t + 1] = rec0[t] + parts[t].q_id.size(); op0[t + 1] = op0[t] + parts[t].cg_ops.size(); }
+    const size_t nr = rec0[threads], no = op0[threads];
+    d.q_id.resize(nr); d.q_start.resize(nr); d.q_end.resize(nr); d.t_id.resize(nr); d.t_len.resize(nr); d.t_start.resize(nr); d.t_end.resize(nr);
+    d.n_match.resize(nr); d.n_block.resize(nr); d.is_rev.resize(nr); d.mapq.resize(nr); d.cg_off.resize(nr); d.cg_ops.resize(no);
+    run_parallel(threads, [&](unsigned t) {
+        const PafPart& P = parts[t];
+        const size_t r = rec0[t], k = P.q_id.size();
+        auto cp32 = [&](std::vector<uint32_t>& dst, const std::vector<uint32_t>& src) { if (k) memcpy(dst.data() + r, src.data(), k * 4); };
+        cp32(d.q_id, P.q_id); cp32(d.q_start, P.q_start); cp32(d.q_end, P.q_end); cp32(d.t_id, P.t_id); cp32(d.t_len, P.t_len); cp32(d.t_start, P.t_start);
+        cp32(d.t_end, P.t_end); cp32(d.n_match, P.n_match); cp32(d.n_block, P.n_block);
+        if (k) { memcpy(d.is_rev.data() + r, P.is_rev.data(), k); memcpy(d.mapq.data() + r, P.mapq.data(), k); }
+        for (size_t i = 0; i < k; i++) d.cg_off[r + i] = P.cg_off[i] + op0[t];
+        if (!P.cg_ops.empty()) memcpy(d.cg_ops.data() + op0[t], P.cg_ops.data(), P.cg_ops.size() * 4);
+    });
+    return 1;
+}
+
+// plain FASTA (records start with '>' or '@' at a line start, no '+' lines): lengths first, then every record is packed in place
+int load_reads_parallel(Dataset& d, const std::string& path, unsigned threads) {
+    Mapped m(path);
+    if (!m.ok()) return -1;
+    if (m.gz() || m.n < (1u << 16) || threads < 2 || m.p[0] != '>') return -1;
+    std::vector<size_t> cut(threads + 1);
+    for (unsigned t = 0; t <= threads; t++) cut[t] = t == threads ? m.n : next_line_start(m.p, m.n, m.n / threads * t);
+    std::vector<std::vector<size_t>> starts(threads);
+    std::vector<uint8_t> odd(threads, 0);
+    run_parallel(threads, [&](unsigned t) {   // record starts and a scan for anything FASTQ-like
+        const char* p = m.p + cut[t];
+        const char* pe = m.p + cut[t + 1];
+        while (p < pe) {
+            if (*p == '>' || *p == '@') starts[t].push_back((size_t)(p - m.p));
+            else if (*p == '+') odd[t] = 1;
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(pe - p));
+            p = nl ? nl + 1 : pe;
+        }
+    });
+    for (unsigned t = 0; t < threads; t++) if (odd[t]) return -1;
+    std::vector<size_t> st;
+    for (unsigned t = 0; t < threads; t++) st.insert(st.end(), starts[t].begin(), starts[t].end());
+    const size_t nrec = st.size();
+    st.push_back(m.n);
+    const size_t r0 = d.read_len.size();
+    d.read_len.resize(r0 + nrec);
+    // bases of a record: every character of its sequence lines except blanks, tabs and the line terminator (\n, or \r\n)
+    auto for_seq = [&](size_t r, auto&& fn) {
+        const char* p = m.p + st[r];
+        const char* pe = m.p + st[r + 1];
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(pe - p));   // header line
+        p = nl ? nl + 1 : pe;
+        while (p < pe) {
+            nl = (const char*)memchr(p, '\n', (size_t)(pe - p));
+            const char* le = nl ? nl : pe;
+            const char* e2 = le;
+            if (e2 > p && e2[-1] == '\r') e2--;
+            for (const char* q = p; q < e2; q++) if (*q != ' ' && *q != '\t') fn(*q);
+            p = nl ? nl + 1 : pe;
+        }
+    };
+    run_parallel(threads, [&](unsigned t) {
+        for (size_t r = nrec * t / threads; r < nrec * (t + 1) / threads; r++) { size_t n = 0; for_seq(r, [&](char) { n++; }); d.read_len[r0 + r] = (uint32_t)n; }
+    });
+    size_t base = d.read_packed.size();
+    d.read_off.resize(r0 + nrec);
+    for (size_t r = 0; r < nrec; r++) { d.read_off[r0 + r] = base; base += (((size_t)d.read_len[r0 + r] + 15) / 16) * 4; d.total_read_bases += d.read_len[r0 + r]; }
+    d.read_packed.resize(base, 0);
+    run_parallel(threads, [&](unsigned t) {
+        for (size_t r = nrec * t / threads; r < nrec * (t + 1) / threads; r++) {
+            uint8_t* dst = d.read_packed.data() + d.read_off[r0 + r];
+            size_t i = 0;
+            for_seq(r, [&](char c) { dst[i >> 2] |= (uint8_t)(base_code(c) << ((i & 3) * 2)); i++; });
+        }
+    });
+    return 1;
+}
+
 }  // namespace
+
+unsigned g_io_threads = 1;   // set by load_dataset
 
 bool load_contigs(Dataset& d, const std::string& path) {
     bool bad = false;
@@ -147,6 +364,10 @@ bool load_contigs(Dataset& d, const std::string& path) {
 }
 
 bool load_reads_file(Dataset& d, const std::string& path) {
+    {
+        const int r = load_reads_parallel(d, path, g_io_threads);
+        if (r >= 0) return r == 1;
+    }
     bool ok = read_seq_file(path, [&](const std::string&, const std::string&, const std::string& seq) {
         d.read_len.push_back((uint32_t)seq.size());
         d.total_read_bases += seq.size();
@@ -157,6 +378,10 @@ bool load_reads_file(Dataset& d, const std::string& path) {
 }
 
 bool load_paf_file(Dataset& d, const std::string& path) {
+    {
+        const int r = load_paf_parallel(d, path, g_io_threads);
+        if (r >= 0) return r == 1;
+    }
     GzLines in(path);
     if (!in.ok()) { g_err = "[ERROR] (Longread::load_alignment) could not open file: " + path; return false; }
     std::string line;
@@ -223,8 +448,13 @@ static bool for_each_path(const std::string& path, bool fofn, const std::functio
     return true;
 }
 
-Dataset* load_dataset(const char* contig_path, const char* long_path, bool long_fofn, const char* mapping_path, bool mapping_fofn) {
+Dataset* load_dataset(const char* contig_path, const char* long_path, bool long_fofn, const char* mapping_path, bool mapping_fofn, unsigned threads) {
     std::unique_ptr<Dataset> d(new Dataset);
+    if (threads == 0) {   // automatic: HASLR_IO_THREADS, else up to 16 hardware threads
+        const char* e = getenv("HASLR_IO_THREADS");
+        threads = e ? (unsigned)atoi(e) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    }
+    g_io_threads = std::max(1u, std::min(threads, 256u));
     if (!load_contigs(*d, contig_path)) return nullptr;
     if (!for_each_path(long_path, long_fofn, [&](const std::string& p) { return load_reads_file(*d, p); }, "Longread::load_longread_compressed_fofn")) return nullptr;
     d->read_off.push_back(d->read_packed.size());
@@ -246,8 +476,11 @@ using namespace hxh;
 
 extern "C" const char* hxh_last_error(void) { return g_err.c_str(); }
 
+extern "C" hxh_dataset* hxh_dataset_load_mt(const char* contig_path, const char* long_path, int long_fofn, const char* mapping_path, int mapping_fofn, unsigned threads) {
+    return reinterpret_cast<hxh_dataset*>(load_dataset(contig_path, long_path, long_fofn != 0, mapping_path, mapping_fofn != 0, threads));
+}
 extern "C" hxh_dataset* hxh_dataset_load(const char* contig_path, const char* long_path, int long_fofn, const char* mapping_path, int mapping_fofn) {
-    return reinterpret_cast<hxh_dataset*>(load_dataset(contig_path, long_path, long_fofn != 0, mapping_path, mapping_fofn != 0));
+    return reinterpret_cast<hxh_dataset*>(load_dataset(contig_path, long_path, long_fofn != 0, mapping_path, mapping_fofn != 0, 0));   // automatic thread count
 }
 extern "C" void hxh_dataset_free(hxh_dataset* p) { delete reinterpret_cast<Dataset*>(p); }
 extern "C" double hxh_dataset_uniq_freq(const hxh_dataset* p) { return reinterpret_cast<const Dataset*>(p)->uniq_freq; }

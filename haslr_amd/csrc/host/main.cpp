@@ -117,7 +117,7 @@ int main(int argc, char* argv[]) {
     if (poa_block) hx_set_poa_block(ctx, poa_block);
 
     fprintf(stderr, "[NOTE] loading contig sequences, long read sequences and alignments...\n");
-    hxh_dataset* ds = hxh_dataset_load(contig_path.c_str(), long_path.c_str(), long_fofn, mapping_path.c_str(), mapping_fofn);
+    hxh_dataset* ds = hxh_dataset_load_mt(contig_path.c_str(), long_path.c_str(), long_fofn, mapping_path.c_str(), mapping_fofn, num_threads);   // -t: ingest threads
     if (!ds) { fprintf(stderr, "%s\n", hxh_last_error()); return EXIT_FAILURE; }
     hx_contigs vc; hx_reads vr; hx_hits vh; const uint64_t* rho;
     hxh_dataset_views(ds, &vc, &vr, &vh, &rho);

@@ -23,6 +23,8 @@ def lib():
         L.hxh_last_error.restype = C.c_char_p
         L.hxh_dataset_load.restype = C.c_void_p
         L.hxh_dataset_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+        L.hxh_dataset_load_mt.restype = C.c_void_p
+        L.hxh_dataset_load_mt.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_uint]
         L.hxh_dataset_free.argtypes = [C.c_void_p]
         L.hxh_dataset_views.argtypes = [C.c_void_p, C.POINTER(T.Contigs), C.POINTER(T.Reads), C.POINTER(T.Hits), C.POINTER(T.u64p)]
         L.hxh_dataset_uniq_freq.restype = C.c_double
@@ -55,9 +57,10 @@ class HostError(RuntimeError):
 class Dataset:
     """Parsed inputs resident in host memory (contigs, packed long reads, raw PAF records)."""
 
-    def __init__(self, contigs, reads, paf, long_fofn=False, mapping_fofn=False):
+    def __init__(self, contigs, reads, paf, long_fofn=False, mapping_fofn=False, threads=0):
+        """threads: ingest threads (0 = automatic, 1 = the streaming single-thread readers); the arrays do not depend on it"""
         L = lib()
-        self._h = L.hxh_dataset_load(os.fsencode(contigs), os.fsencode(reads), int(long_fofn), os.fsencode(paf), int(mapping_fofn))
+        self._h = L.hxh_dataset_load_mt(os.fsencode(contigs), os.fsencode(reads), int(long_fofn), os.fsencode(paf), int(mapping_fofn), int(threads))
         if not self._h:
             raise HostError(L.hxh_last_error().decode())
         self.contigs, self.reads, self.hits = T.Contigs(), T.Reads(), T.Hits()
