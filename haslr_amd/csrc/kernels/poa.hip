@@ -315,6 +315,34 @@ __device__ bool add_alignment(G& g, uint32_t& V, uint32_t& E, uint32_t n_aln, co
     return true;
 }
 
+// The forward pass of the heaviest bundle on ANY valid topological order gives the same scores and predecessors (a node looks only at its
+// in-edges, in in-edge order). The order matters in two places: which of several equally heavy nodes is taken as the end ("first in
+// rank order"), and the branch completion that follows when that node is not a sink. So: run the pass on the order the DP maintains;
+// if the heaviest node is unique and a sink, the walk back from it IS the reference's consensus. Otherwise return NONE and let the
+// caller sort the graph the reference's way. lane 0 only.
+__device__ uint32_t consensus_fast(G& g, uint32_t V, char* out) {
+    for (uint32_t i = 0; i < V; i++) { g.pred[i] = -1; g.score[i] = -1; }
+    uint32_t best = NONE, nbest = 0;
+    int32_t bscore = 0;
+    for (uint32_t r = 0; r < V; r++) {
+        const uint32_t n = g.rank2node[r];
+        for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) {
+            const uint32_t f = g.e_from[e]; const int32_t w = g.e_w[e];
+            if (g.score[n] < w || (g.score[n] == w && g.score[g.pred[n]] <= g.score[f])) { g.score[n] = w; g.pred[n] = (int32_t)f; }
+        }
+        if (g.pred[n] != -1) g.score[n] += g.score[g.pred[n]];
+        const int32_t sc = g.score[n];
+        if (best == NONE || sc > bscore) { best = n; bscore = sc; nbest = 1; }
+        else if (sc == bscore) nbest++;
+    }
+    if (nbest != 1 || g.out_head[best] != NONE) return NONE;
+    uint32_t len = 0;
+    for (uint32_t n = best;; n = (uint32_t)g.pred[n]) { len++; if (g.pred[n] == -1) break; }
+    uint32_t w = len;
+    for (uint32_t n = best;; n = (uint32_t)g.pred[n]) { out[--w] = "ACGT"[g.code[n]]; if (g.pred[n] == -1) break; }
+    return len;
+}
+
 // spoa Graph::traverse_heaviest_bundle + branch_completion; lane 0 only. Writes the consensus, returns its length.
 __device__ uint32_t consensus(G& g, uint32_t V, char* out) {
     for (uint32_t i = 0; i < V; i++) { g.pred[i] = -1; g.score[i] = -1; }
@@ -1339,16 +1367,22 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     }
     if (mem > 0) return;
     if (GM > 1 && tid == 0 && sOk != 1) st_dev(csy + 0, CL_ABORT);   // release the other members
-    if (sOk == 1 && sV) {   // heaviest bundle runs on the reference's topological order of the finished graph
-        exact_order(sV, g.rank2node);
-        for (uint32_t r = tid; r < sV; r += NT) g.node2rank[g.rank2node[r]] = r;
+    if (sOk == 1 && sV) {
+        // heaviest bundle: first on the maintained order (exact whenever the heaviest node is unique and a sink); else on the reference's
+        // topological order of the finished graph
+        if (tid == 0) sCtl = consensus_fast(g, sV, cns + ED.cns_off);
         __syncthreads();
+        if (sCtl == NONE) {
+            exact_order(sV, g.rank2node);
+            for (uint32_t r = tid; r < sV; r += NT) g.node2rank[g.rank2node[r]] = r;
+            __syncthreads();
+        }
     }
     if (tid == 0) {
         if (sOk == 2) { status[eidx] = HXE_SPOS_RANGE << 8; cns_len[eidx] = 0; }   // internal: kernel variant cannot hold this many columns per lane
         else if (!sOk) { status[eidx] = HXE_POA_OVERFLOW; cns_len[eidx] = 0; }
         else if (sOk == 4) { status[eidx] = HXE_POA_NODIR; cns_len[eidx] = 0; }
-        else { status[eidx] = 0; cns_len[eidx] = sV ? consensus(g, sV, cns + ED.cns_off) : 0; atomicAdd(cells, sCells); }
+        else { status[eidx] = 0; cns_len[eidx] = !sV ? 0 : sCtl != NONE ? sCtl : consensus(g, sV, cns + ED.cns_off); atomicAdd(cells, sCells); }
         PHASE(3);
         if (phase) for (int k = 0; k < 12; k++) phase[(uint64_t)eidx * 12 + k] = ph[k];
     }
