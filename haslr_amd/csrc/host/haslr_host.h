@@ -27,6 +27,11 @@ hxh_dataset* hxh_dataset_load(const char* contig_path, const char* long_path, in
  * The arrays are identical for every thread count. */
 hxh_dataset* hxh_dataset_load_mt(const char* contig_path, const char* long_path, int long_fofn,
                                  const char* mapping_path, int mapping_fofn, unsigned threads);
+/* index caches of the reference (index.contig / index.longread, main.cpp:39-103; layouts in host/index_cache.cpp): when index_dir holds
+ * them they are loaded instead of the text files (used_* report which); byte-compatible with the reference's own files both ways */
+hxh_dataset* hxh_dataset_load_cached(const char* index_dir, const char* contig_path, const char* long_path, int long_fofn, const char* mapping_path,
+                                     int mapping_fofn, unsigned threads, int* used_contig_index, int* used_longread_index);
+int hxh_dataset_write_contig_index(const hxh_dataset*, const char* path);
 void hxh_dataset_free(hxh_dataset*);
 void hxh_dataset_views(const hxh_dataset*, hx_contigs*, hx_reads*, hx_hits*, const uint64_t** read_hit_off);
 double hxh_dataset_uniq_freq(const hxh_dataset*);   /* Contig.cpp:162-174 */
@@ -64,6 +69,8 @@ int hxh_run_consensus(hxh_run*);      /* asm_cal_cns_seq_MT */
 int hxh_run_assemble(hxh_run*);       /* asm_get_assembly: asm.final.fa / .ann / log_asmfinal.txt */
 int hxh_run_all(hxh_run*);            /* all of the above */
 /* wall seconds of the last call of each stage: chain, graph(host), coords, consensus, assemble */
+/* index.longread: the alignments that survived the chain stage's filters, with their raw fields (needs hxh_run_chain) */
+int hxh_run_write_longread_index(const hxh_run*, const char* path);
 void hxh_run_timings(const hxh_run*, double out[5]);
 /* results for tests: number of surviving undirected edges / their consensus */
 uint32_t hxh_run_n_edges(const hxh_run*);

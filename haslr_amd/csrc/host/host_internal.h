@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "haslr_host.h"
@@ -30,6 +31,7 @@ struct Dataset {
     std::vector<uint64_t> cg_off;
     std::vector<uint32_t> cg_ops;
     std::vector<uint64_t> read_hit_off;
+    std::unordered_map<uint64_t, std::string> cg_text_odd;   // cg:Z: text of the records whose op words do not spell it (index.longread keeps the text)
 
     std::string contig_seq(uint32_t id) const {
         std::string s(contig_len[id], 'A');
@@ -40,6 +42,16 @@ struct Dataset {
 };
 
 Dataset* load_dataset(const char* contig_path, const char* long_path, bool long_fofn, const char* mapping_path, bool mapping_fofn, unsigned threads /* 0 = automatic, 1 = streaming readers only */);
+// the same, but `index.contig` / `index.longread` of index_dir are loaded instead of the text files when they exist (main.cpp:39-103)
+Dataset* load_dataset_cached(const char* index_dir, const char* contig_path, const char* long_path, bool long_fofn, const char* mapping_path, bool mapping_fofn,
+                             unsigned threads, int* used_contig_index, int* used_longread_index);
+void finish_contigs(Dataset& d);
+bool append_cigar(Dataset& d, const char* b, const char* e);
+std::string cigar_text(const Dataset& d, uint64_t rec);
+bool write_contig_index(const Dataset& d, const std::string& path);
+bool write_longread_index(const Dataset& d, const hx_chain_out& chain, const std::string& path);
+bool read_contig_index(Dataset& d, const std::string& path);
+bool read_longread_index(Dataset& d, const std::string& path);
 
 // ---------------------------------------------------------------------------------------------
 // Backbone graph. The reference keeps `vector<BBG_Node_t>` with two std::map<uint32_t,BBG_Edge_t>

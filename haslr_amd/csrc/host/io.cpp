@@ -116,6 +116,25 @@ void pack_into(std::vector<uint8_t>& dst, std::vector<uint64_t>& off, const std:
     for (size_t i = 0; i < s.size(); i++) dst[base + (i >> 2)] |= (uint8_t)(base_code(s[i]) << ((i & 3) * 2));
 }
 
+// CIGAR text -> op words, parsed like sscanf("%u%c") until it stops matching (Common.cpp:108-121). `odd` is set when the op words do
+// not spell the text again (letters other than M/I/D, zero lengths, leading zeros, trailing garbage): such a record keeps its text,
+// because index.longread stores the cg:Z: string as it was (index_cache.cpp).
+bool parse_cigar_text(const char* p, const char* end, std::vector<uint32_t>& ops, bool& odd, bool& too_long) {
+    odd = false; too_long = false;
+    while (p < end) {
+        uint64_t len = 0;
+        const char* q = p;
+        while (q < end && *q >= '0' && *q <= '9') { len = len * 10 + (uint64_t)(*q - '0'); q++; }
+        if (q == p || q == end) { odd = true; break; }
+        if (len >= (1u << 30)) { too_long = true; return false; }
+        const uint32_t code = *q == 'M' ? HX_CG_M : *q == 'I' ? HX_CG_I : *q == 'D' ? HX_CG_D : HX_CG_OTHER;
+        if (code == HX_CG_OTHER || len == 0 || *p == '0') odd = true;
+        if (len) ops.push_back(((uint32_t)len << 2) | code);
+        p = q + 1;
+    }
+    return true;
+}
+
 bool parse_u32(const char* b, const char* e, uint32_t& v) {
     if (b == e) return false;
     uint64_t x = 0;
@@ -166,6 +185,7 @@ struct PafPart {
     uint64_t lines = 0;                  // lines in this part (for global line numbers)
     uint64_t first_rec_line = 0;         // local line number of the first record (1-based), 0 = no record
     uint64_t err_line = 0; std::string err;   // first error of this part (local line number)
+    std::vector<std::pair<uint64_t, std::string>> odd;   // (local record, cg text) of records whose op words do not spell their text
 };
 
 // one PAF line -> part; returns false with part.err set
@@ -192,17 +212,9 @@ bool parse_paf_line(const char* b, const char* end, PafPart& d, size_t n_reads, 
     d.cg_off.push_back(d.cg_ops.size());
     for (size_t k = 12; k < f.size(); k++) {
         if (f[k].second - f[k].first >= 5 && memcmp(f[k].first, "cg:Z:", 5) == 0) {
-            const char* p = f[k].first + 5;
-            while (p < f[k].second) {
-                uint64_t len = 0;
-                const char* q = p;
-                while (q < f[k].second && *q >= '0' && *q <= '9') { len = len * 10 + (uint64_t)(*q - '0'); q++; }
-                if (q == p || q == f[k].second) break;
-                if (len >= (1u << 30)) { d.err = "CIGAR"; return false; }
-                uint32_t code = *q == 'M' ? HX_CG_M : *q == 'I' ? HX_CG_I : *q == 'D' ? HX_CG_D : HX_CG_OTHER;
-                if (len) d.cg_ops.push_back(((uint32_t)len << 2) | code);
-                p = q + 1;
-            }
+            bool odd, too_long;
+            if (!parse_cigar_text(f[k].first + 5, f[k].second, d.cg_ops, odd, too_long)) { d.err = "CIGAR"; return false; }
+            if (odd) d.odd.push_back({d.q_id.size() - 1, std::string(f[k].first + 5, f[k].second)});
             break;
         }
     }
@@ -273,6 +285,7 @@ int load_paf_parallel(Dataset& d, const std::string& path, unsigned threads) {
         for (size_t i = 0; i < k; i++) d.cg_off[r + i] = P.cg_off[i] + op0[t];
         if (!P.cg_ops.empty()) memcpy(d.cg_ops.data() + op0[t], P.cg_ops.data(), P.cg_ops.size() * 4);
     });
+    for (unsigned t = 0; t < threads; t++) for (auto& o : parts[t].odd) d.cg_text_odd[rec0[t] + o.first] = o.second;
     return 1;
 }
 
@@ -352,7 +365,12 @@ bool load_contigs(Dataset& d, const std::string& path) {
     if (!ok) { g_err = "[ERROR] (Contig::load_contig_compressed) could not open file: " + path; return false; }
     if (bad) { g_err = "[ERROR] contig header without KC:i:/km:f: comment in " + path; return false; }
     d.contig_off.push_back(d.contig_packed.size());
-    // calc_uniq_freq
+    finish_contigs(d);
+    return true;
+}
+
+// calc_uniq_freq (Contig.cpp:162-174)
+void finish_contigs(Dataset& d) {
     std::vector<std::pair<uint32_t, double>> cf(d.contig_len.size());
     for (size_t i = 0; i < cf.size(); i++) cf[i] = {d.contig_len[i], d.contig_km[i]};
     std::sort(cf.begin(), cf.end(), std::greater<std::pair<uint32_t, double>>());
@@ -360,6 +378,14 @@ bool load_contigs(Dataset& d, const std::string& path) {
     size_t i = 0;
     for (; i < 20 && i < cf.size(); i++) f += cf[i].second;
     d.uniq_freq = f / i;
+}
+
+// one alignment's CIGAR from text (index.longread): offsets, op words, and the text itself when the words do not spell it
+bool append_cigar(Dataset& d, const char* b, const char* e) {
+    d.cg_off.push_back(d.cg_ops.size());
+    bool odd, too_long;
+    if (!parse_cigar_text(b, e, d.cg_ops, odd, too_long)) { g_err = "[ERROR] CIGAR operation longer than 2^30 in index.longread"; return false; }
+    if (odd) d.cg_text_odd[d.q_id.size() - 1] = std::string(b, e);
     return true;
 }
 
@@ -417,21 +443,13 @@ bool load_paf_file(Dataset& d, const std::string& path) {
         d.is_rev.push_back(*f[4].first == '-' ? 1 : 0);
         d.t_id.push_back(v[5]); d.t_len.push_back(v[6]); d.t_start.push_back(v[7]); d.t_end.push_back(v[8]);
         d.n_match.push_back(v[9]); d.n_block.push_back(v[10]); d.mapq.push_back((uint8_t)v[11]);
-        // CIGAR: first tag starting with cg:Z:, parsed like sscanf("%u%c") until it stops matching (Common.cpp:108-121)
+        // CIGAR: first tag starting with cg:Z:
         d.cg_off.push_back(d.cg_ops.size());
         for (size_t k = 12; k < f.size(); k++) {
             if (f[k].second - f[k].first >= 5 && memcmp(f[k].first, "cg:Z:", 5) == 0) {
-                const char* p = f[k].first + 5;
-                while (p < f[k].second) {
-                    uint64_t len = 0;
-                    const char* q = p;
-                    while (q < f[k].second && *q >= '0' && *q <= '9') { len = len * 10 + (uint64_t)(*q - '0'); q++; }
-                    if (q == p || q == f[k].second) break;
-                    if (len >= (1u << 30)) { g_err = "[ERROR] CIGAR operation longer than 2^30 at PAF line " + std::to_string(lineno); return false; }
-                    uint32_t code = *q == 'M' ? HX_CG_M : *q == 'I' ? HX_CG_I : *q == 'D' ? HX_CG_D : HX_CG_OTHER;
-                    if (len) d.cg_ops.push_back(((uint32_t)len << 2) | code);
-                    p = q + 1;
-                }
+                bool odd, too_long;
+                if (!parse_cigar_text(f[k].first + 5, f[k].second, d.cg_ops, odd, too_long)) { g_err = "[ERROR] CIGAR operation longer than 2^30 at PAF line " + std::to_string(lineno); return false; }
+                if (odd) d.cg_text_odd[d.q_id.size() - 1] = std::string(f[k].first + 5, f[k].second);
                 break;
             }
         }
@@ -448,14 +466,24 @@ static bool for_each_path(const std::string& path, bool fofn, const std::functio
     return true;
 }
 
-Dataset* load_dataset(const char* contig_path, const char* long_path, bool long_fofn, const char* mapping_path, bool mapping_fofn, unsigned threads) {
+static bool file_exists(const std::string& p) { FILE* f = fopen(p.c_str(), "rb"); if (f) fclose(f); return f != nullptr; }
+
+Dataset* load_dataset_cached(const char* index_dir, const char* contig_path, const char* long_path, bool long_fofn, const char* mapping_path, bool mapping_fofn,
+                             unsigned threads, int* used_contig_index, int* used_longread_index) {
     std::unique_ptr<Dataset> d(new Dataset);
     if (threads == 0) {   // automatic: HASLR_IO_THREADS, else up to 16 hardware threads
         const char* e = getenv("HASLR_IO_THREADS");
         threads = e ? (unsigned)atoi(e) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     }
     g_io_threads = std::max(1u, std::min(threads, 256u));
-    if (!load_contigs(*d, contig_path)) return nullptr;
+    const std::string ci = index_dir ? std::string(index_dir) + "/index.contig" : std::string();
+    const std::string li = index_dir ? std::string(index_dir) + "/index.longread" : std::string();
+    const bool use_ci = index_dir && file_exists(ci), use_li = index_dir && file_exists(li);
+    if (used_contig_index) *used_contig_index = use_ci;
+    if (used_longread_index) *used_longread_index = use_li;
+    if (use_ci) { if (!read_contig_index(*d, ci)) return nullptr; }
+    else if (!load_contigs(*d, contig_path)) return nullptr;
+    if (use_li) { if (!read_longread_index(*d, li)) return nullptr; return d.release(); }
     if (!for_each_path(long_path, long_fofn, [&](const std::string& p) { return load_reads_file(*d, p); }, "Longread::load_longread_compressed_fofn")) return nullptr;
     d->read_off.push_back(d->read_packed.size());
     if (!for_each_path(mapping_path, mapping_fofn, [&](const std::string& p) { return load_paf_file(*d, p); }, "Longread::load_alignment_fofn")) return nullptr;
@@ -470,6 +498,10 @@ Dataset* load_dataset(const char* contig_path, const char* long_path, bool long_
     return d.release();
 }
 
+Dataset* load_dataset(const char* contig_path, const char* long_path, bool long_fofn, const char* mapping_path, bool mapping_fofn, unsigned threads) {
+    return load_dataset_cached(nullptr, contig_path, long_path, long_fofn, mapping_path, mapping_fofn, threads, nullptr, nullptr);
+}
+
 }  // namespace hxh
 
 using namespace hxh;
@@ -479,6 +511,12 @@ extern "C" const char* hxh_last_error(void) { return g_err.c_str(); }
 extern "C" hxh_dataset* hxh_dataset_load_mt(const char* contig_path, const char* long_path, int long_fofn, const char* mapping_path, int mapping_fofn, unsigned threads) {
     return reinterpret_cast<hxh_dataset*>(load_dataset(contig_path, long_path, long_fofn != 0, mapping_path, mapping_fofn != 0, threads));
 }
+extern "C" hxh_dataset* hxh_dataset_load_cached(const char* index_dir, const char* contig_path, const char* long_path, int long_fofn, const char* mapping_path,
+                                                int mapping_fofn, unsigned threads, int* used_contig_index, int* used_longread_index) {
+    return reinterpret_cast<hxh_dataset*>(load_dataset_cached(index_dir, contig_path, long_path, long_fofn != 0, mapping_path, mapping_fofn != 0, threads,
+                                                              used_contig_index, used_longread_index));
+}
+extern "C" int hxh_dataset_write_contig_index(const hxh_dataset* p, const char* path) { return write_contig_index(*reinterpret_cast<const Dataset*>(p), path) ? 0 : -1; }
 extern "C" hxh_dataset* hxh_dataset_load(const char* contig_path, const char* long_path, int long_fofn, const char* mapping_path, int mapping_fofn) {
     return reinterpret_cast<hxh_dataset*>(load_dataset(contig_path, long_path, long_fofn != 0, mapping_path, mapping_fofn != 0, 0));   // automatic thread count
 }

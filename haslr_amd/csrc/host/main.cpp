@@ -117,8 +117,14 @@ int main(int argc, char* argv[]) {
     if (poa_block) hx_set_poa_block(ctx, poa_block);
 
     fprintf(stderr, "[NOTE] loading contig sequences, long read sequences and alignments...\n");
-    hxh_dataset* ds = hxh_dataset_load_mt(contig_path.c_str(), long_path.c_str(), long_fofn, mapping_path.c_str(), mapping_fofn, num_threads);   // -t: ingest threads
+    // index.contig / index.longread of the output directory are loaded when they exist, written when they do not (main.cpp:39-103)
+    int used_ci = 0, used_li = 0;
+    hxh_dataset* ds = hxh_dataset_load_cached(out_dir.c_str(), contig_path.c_str(), long_path.c_str(), long_fofn, mapping_path.c_str(), mapping_fofn, num_threads /* -t */,
+                                              &used_ci, &used_li);
     if (!ds) { fprintf(stderr, "%s\n", hxh_last_error()); return EXIT_FAILURE; }
+    if (used_ci) fprintf(stderr, "[NOTE] reading contig index: %s/index.contig...\n", out_dir.c_str());
+    if (used_li) fprintf(stderr, "[NOTE] reading long read and alignment index: %s/index.longread...\n", out_dir.c_str());
+    if (!used_ci && hxh_dataset_write_contig_index(ds, (out_dir + "/index.contig").c_str()) != 0) { fprintf(stderr, "%s\n", hxh_last_error()); return EXIT_FAILURE; }
     hx_contigs vc; hx_reads vr; hx_hits vh; const uint64_t* rho;
     hxh_dataset_views(ds, &vc, &vr, &vh, &rho);
     fprintf(stderr, "       loaded %u contigs\n       loaded %u long reads\n       loaded %lu alignments\n", vc.n, vr.n, (unsigned long)vh.n);
@@ -139,6 +145,9 @@ int main(int argc, char* argv[]) {
     for (auto& st : stages) {
         fprintf(stderr, "%s\n", st.note);
         if (st.fn(run) != 0) { fprintf(stderr, "[ERROR] %s\n", hxh_last_error()); return EXIT_FAILURE; }
+        if (st.fn == hxh_run_chain && !used_li && hxh_run_write_longread_index(run, (out_dir + "/index.longread").c_str()) != 0) {   // the filtered set is known now
+            fprintf(stderr, "%s\n", hxh_last_error()); return EXIT_FAILURE;
+        }
         elapsed();
     }
     fprintf(stderr, "[NOTE] cleaning up the memory!\n");

@@ -367,6 +367,11 @@ extern "C" void hxh_run_set_edge_shard(hxh_run* p, uint32_t rank, uint32_t world
     Run* r = reinterpret_cast<Run*>(p);
     r->shard_rank = rank; r->shard_world = world ? world : 1;
 }
+extern "C" int hxh_run_write_longread_index(const hxh_run* p, const char* path) {
+    const Run* r = reinterpret_cast<const Run*>(p);
+    if (!r->have_chain) { g_err = "index.longread needs the chain stage"; return -1; }
+    return write_longread_index(*r->d, r->chain, path) ? 0 : -1;
+}
 extern "C" void hxh_run_timings(const hxh_run* p, double out[5]) { memcpy(out, reinterpret_cast<const Run*>(p)->t, sizeof(double) * 5); }
 extern "C" uint32_t hxh_run_n_edges(const hxh_run* p) { return (uint32_t)reinterpret_cast<const Run*>(p)->work.size(); }
 extern "C" const hx_chain_out* hxh_run_chain_out(const hxh_run* p) { return &reinterpret_cast<const Run*>(p)->chain; }

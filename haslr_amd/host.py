@@ -25,6 +25,10 @@ def lib():
         L.hxh_dataset_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
         L.hxh_dataset_load_mt.restype = C.c_void_p
         L.hxh_dataset_load_mt.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_uint]
+        L.hxh_dataset_load_cached.restype = C.c_void_p
+        L.hxh_dataset_load_cached.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_uint, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.hxh_dataset_write_contig_index.argtypes = [C.c_void_p, C.c_char_p]
+        L.hxh_run_write_longread_index.argtypes = [C.c_void_p, C.c_char_p]
         L.hxh_dataset_free.argtypes = [C.c_void_p]
         L.hxh_dataset_views.argtypes = [C.c_void_p, C.POINTER(T.Contigs), C.POINTER(T.Reads), C.POINTER(T.Hits), C.POINTER(T.u64p)]
         L.hxh_dataset_uniq_freq.restype = C.c_double
@@ -57,10 +61,19 @@ class HostError(RuntimeError):
 class Dataset:
     """Parsed inputs resident in host memory (contigs, packed long reads, raw PAF records)."""
 
-    def __init__(self, contigs, reads, paf, long_fofn=False, mapping_fofn=False, threads=0):
-        """threads: ingest threads (0 = automatic, 1 = the streaming single-thread readers); the arrays do not depend on it"""
+    def __init__(self, contigs, reads, paf, long_fofn=False, mapping_fofn=False, threads=0, index_dir=None):
+        """threads: ingest threads (0 = automatic, 1 = the streaming single-thread readers); the arrays do not depend on it.
+        index_dir: a directory whose index.contig / index.longread (the reference's cache files) are loaded instead of the text files
+        when they exist, like haslr_assemble does with its output directory."""
         L = lib()
-        self._h = L.hxh_dataset_load_mt(os.fsencode(contigs), os.fsencode(reads), int(long_fofn), os.fsencode(paf), int(mapping_fofn), int(threads))
+        self.used_contig_index = self.used_longread_index = False
+        if index_dir is None:
+            self._h = L.hxh_dataset_load_mt(os.fsencode(contigs), os.fsencode(reads), int(long_fofn), os.fsencode(paf), int(mapping_fofn), int(threads))
+        else:
+            a, b = C.c_int(0), C.c_int(0)
+            self._h = L.hxh_dataset_load_cached(os.fsencode(index_dir), os.fsencode(contigs), os.fsencode(reads), int(long_fofn), os.fsencode(paf),
+                                                int(mapping_fofn), int(threads), C.byref(a), C.byref(b))
+            self.used_contig_index, self.used_longread_index = bool(a.value), bool(b.value)
         if not self._h:
             raise HostError(L.hxh_last_error().decode())
         self.contigs, self.reads, self.hits = T.Contigs(), T.Reads(), T.Hits()
@@ -71,6 +84,10 @@ class Dataset:
 
     def params(self, **kw):
         return T.default_params(self.uniq_freq, **kw)
+
+    def write_contig_index(self, path):
+        if lib().hxh_dataset_write_contig_index(self._h, os.fsencode(path)) != 0:
+            raise HostError(lib().hxh_last_error().decode())
 
     def close(self):
         if self._h:
@@ -106,6 +123,11 @@ class Run:
 
     def set_edge_shard(self, rank, world):
         lib().hxh_run_set_edge_shard(self._h, rank, world)
+
+    def write_longread_index(self, path):
+        """index.longread (the reference's cache file): needs chain()"""
+        if lib().hxh_run_write_longread_index(self._h, os.fsencode(path)) != 0:
+            raise HostError(lib().hxh_last_error().decode())
 
     def timings(self):
         t = (C.c_double * 5)()

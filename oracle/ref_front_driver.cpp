@@ -46,9 +46,18 @@ static void dump_edge_supp(std::vector<BBG_Node_t>& graph, const std::string& pa
 int main(int argc, char* argv[]) {
     if (!parse_command_line(argc, argv)) return EXIT_FAILURE;
     const std::string d = gopt.out_dir;
+    // index caches (main.cpp:39-52, :65-103): REF_FRONT_FROM_INDEX=<dir> loads index.contig / index.longread with the reference's readers
+    // instead of parsing text; REF_FRONT_WRITE_INDEX=1 writes them into -d with the reference's writers; REF_FRONT_DUMP_SEQS=1 dumps
+    // every contig and long read as the reference decodes it (pins the 2-bit codec of files written by the product)
+    const char* from_index = getenv("REF_FRONT_FROM_INDEX");
+    const bool write_index = getenv("REF_FRONT_WRITE_INDEX") != NULL, dump_seqs = getenv("REF_FRONT_DUMP_SEQS") != NULL;
     Contig_List_t contig_list;
-    initialize_contig(contig_list);
-    load_contig_compressed(gopt.contig_path, contig_list);
+    if (from_index) read_contig_index(std::string(from_index) + "/index.contig", contig_list);
+    else {
+        initialize_contig(contig_list);
+        load_contig_compressed(gopt.contig_path, contig_list);
+        if (write_index) write_contig_index(d + "/index.contig", contig_list);
+    }
     calc_uniq_freq(contig_list);
     fprintf(stderr, "[ref_front] uniq_freq %.17g\n", gopt.uniq_freq);
     {
@@ -57,11 +66,24 @@ int main(int argc, char* argv[]) {
         fclose(fp);
     }
     Longread_List_t lr_list;
-    initialize_longread(lr_list);
-    load_longread_compressed(gopt.long_path, lr_list);
-    update_longreads(lr_list);
-    load_alignment(gopt.mapping_path, contig_list, lr_list);
-    update_longreads(lr_list);
+    if (from_index) read_longread_index(std::string(from_index) + "/index.longread", lr_list);
+    else {
+        initialize_longread(lr_list);
+        load_longread_compressed(gopt.long_path, lr_list);
+        update_longreads(lr_list);
+        load_alignment(gopt.mapping_path, contig_list, lr_list);
+        update_longreads(lr_list);
+        if (write_index) write_longread_index(d + "/index.longread", lr_list);
+    }
+    if (dump_seqs) {
+        FILE* fp = file_open_write(d + "/seqs.dump.txt");
+        for (uint64_t i = 0; i < contig_list.contigs_size; i++)
+            fprintf(fp, "C\t%lu\t%u\t%.17g\t%s\n", (unsigned long)i, contig_list.contigs[i].kmer_count, contig_list.contigs[i].mean_kmer,
+                    get_uncompressed_dna(contig_list.contigs[i].comp_seq, contig_list.contigs[i].len, contig_list.contigs[i].comp_len).c_str());
+        for (uint64_t i = 0; i < lr_list.reads_size; i++)
+            fprintf(fp, "R\t%lu\t%s\n", (unsigned long)i, get_uncompressed_dna(lr_list.reads[i].comp_seq, lr_list.reads[i].len, lr_list.reads[i].comp_len).c_str());
+        fclose(fp);
+    }
     print_loaded_alignments(lr_list, d + "/alignments.loaded.paf");
     fix_alignments(lr_list);
     print_loaded_alignments(lr_list, d + "/alignments.fixed.paf");

@@ -323,3 +323,24 @@ def test_in_degree_retry_with_score_matrix(sim, ctx):
     assert ro.cns_out() == rg.cns_out()
     assert ro.cns_stats()["dp_cells"] == rg.cns_stats()["dp_cells"]
     rg.close(); ro.close(); be.close(); ds.close()
+
+
+@pytest.mark.gpu
+def test_cli_reuses_index_caches(sim, built, tmp_path):
+    """like the reference (main.cpp:39-103) the binary leaves index.contig / index.longread in -d and a second run loads them instead of
+    the text files (which may be gone): same outputs"""
+    pre = sim("--genome-len", "100000", "--seed", "27", "--variant-per-mb", "20")
+    exe = os.path.join(ROOT, "haslr_amd", "bin", "haslr_assemble")
+    out = tmp_path / "cli"
+    args = ["-t", "4", "-d", str(out), "--aln-block", "500", "--aln-sim", "0.85", "--edge-sup", "3"]
+    r = subprocess.run([exe, "-c", pre + ".contigs.fa", "-l", pre + ".reads.fa", "-m", pre + ".paf"] + args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert os.path.getsize(out / "index.contig") > 16 and os.path.getsize(out / "index.longread") > 32
+    keep = {f: open(out / f, "rb").read() for f in os.listdir(out) if not f.startswith("index.") and not f.startswith("log_")}
+    for f in keep:
+        os.remove(out / f)
+    r = subprocess.run([exe, "-c", "/nonexistent/c.fa", "-l", "/nonexistent/r.fa", "-m", "/nonexistent/m.paf"] + args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "reading contig index" in r.stderr and "reading long read and alignment index" in r.stderr
+    for f, data in keep.items():
+        assert open(out / f, "rb").read() == data, f
