@@ -1064,17 +1064,15 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                             const uint32_t dr = ti - i, dcq = tj - j, idx = dr * 2 + (dcq >> 3);
                             const uint32_t wsel = (dcq & 4u) ? (uint32_t)__builtin_amdgcn_readlane((int)w1, (int)idx) : (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)idx);
                             const uint32_t d = (wsel >> (8 * (dcq & 3u))) & 0x3fu;
-                            uint32_t pi_ = i, pj_ = j;   // move code: type (3 diagonal / 2 vertical / 1 horizontal) * 16 + 15 - predecessor slot
-                            if ((d >> 4) == 1u) pj_ = j - 1;
-                            else {
-                                const uint32_t np = (uint32_t)__builtin_amdgcn_readlane((int)mt, (int)dr) >> 8, slot = 15u - (d & 15u);
-                                uint32_t ent;
-                                if (slot == 0) ent = (uint32_t)__builtin_amdgcn_readlane((int)q0, (int)dr);
-                                else if (slot == 1) ent = (uint32_t)__builtin_amdgcn_readlane((int)q1, (int)dr);
-                                else ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[(uint32_t)__builtin_amdgcn_readlane((int)qo, (int)dr) + slot]);
-                                pi_ = np == 0 ? 0u : (ent & 0x0fffffffu) + 1;
-                                if ((d >> 4) == 3u) pj_ = j - 1;
-                            }
+                            // move code: type (3 diagonal / 2 vertical / 1 horizontal) * 16 + 15 - predecessor slot. Selects instead of branches:
+                            // a taken scalar branch costs as much as seven ALU instructions here
+                            const uint32_t type = d >> 4, slot = 15u - (d & 15u);
+                            const uint32_t np = (uint32_t)__builtin_amdgcn_readlane((int)mt, (int)dr) >> 8;
+                            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)q0, (int)dr), e1 = (uint32_t)__builtin_amdgcn_readlane((int)q1, (int)dr);
+                            uint32_t ent = slot == 0 ? e0 : e1;
+                            if (__builtin_expect(slot >= 2 && type != 1u, 0)) ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[(uint32_t)__builtin_amdgcn_readlane((int)qo, (int)dr) + slot]);
+                            const uint32_t pv = np == 0 ? 0u : (ent & 0x0fffffffu) + 1;
+                            const uint32_t pi_ = type == 1u ? i : pv, pj_ = type == 2u ? j : j - 1;
                             if (ln == 0) { g.aln_node[na] = i == pi_ ? 0 : (int32_t)i; g.aln_pos[na] = j == pj_ ? -1 : (int32_t)(j - 1); }
                             na++;
                             i = pi_; j = pj_;
