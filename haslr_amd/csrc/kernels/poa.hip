@@ -1055,9 +1055,13 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                         const uint32_t ti = i, tj = j, r0 = ln >> 1, c0 = (ln & 1u) * 8;
                         uint32_t w0 = 0, w1 = 0, mt = 0, q0 = 0, q1 = 0, qo = 0;
                         if (ti > r0) {
-                            const uint8_t* rowp = Dm + (uint64_t)(ti - r0) * W;
-#pragma unroll
-                            for (uint32_t q = 0; q < 4; q++) { if (tj >= c0 + q) w0 |= (uint32_t)rowp[tj - c0 - q] << (8 * q); if (tj >= c0 + 4 + q) w1 |= (uint32_t)rowp[tj - c0 - 4 - q] << (8 * q); }
+                            // two unaligned dword loads per lane: bytes of columns tj-c0-3 .. tj-c0 and tj-c0-7 .. tj-c0-4 (columns below 0 read the
+                            // end of the previous row — row 0 exists — and are never looked at); byte-swapped so that byte q = column tj-c0-q
+                            const uint8_t* rowp = Dm + (uint64_t)(ti - r0) * W + tj - c0;
+                            uint32_t a, b;
+                            __builtin_memcpy(&a, rowp - 3, 4);
+                            __builtin_memcpy(&b, rowp - 7, 4);
+                            w0 = __builtin_bswap32(a); w1 = __builtin_bswap32(b);
                         }
                         if (ln < 32 && ti > ln) { const uint32_t rr = ti - 1 - ln; mt = g.row_meta[rr]; q0 = g.row_pred0[rr]; q1 = g.row_pred1[rr]; qo = g.row_pred_off[rr]; }
                         for (;;) {
