@@ -694,8 +694,9 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 for (int k = 0; k < CM; k++) m[k] = max((k == 0 ? left : hp[k - 1]) + score_of(k), hp[k] + (g64 + KV));
             };
             const uint32_t loc0 = p0 >> 28;
-            if (npred == 1 && loc0 == 0) cells1(t, left_prev);     // the previous row: the lane's own registers
-            else if (npred == 1 && loc0 != 15) {                   // one kept row in the LDS ring
+            const uint32_t rtype = (meta >> 5) & 7u;               // set by the CSR build: 1 previous row, 2 one ring row, 0 anything else
+            if (rtype == 1) cells1(t, left_prev);                  // the previous row: the lane's own registers
+            else if (rtype == 2) {                                 // one kept row in the LDS ring
                 int hp[CM], left;
                 const int32_t* S = ring_me + (size_t)(loc0 - 1) * ring_w;
 #pragma unroll
@@ -1352,6 +1353,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                         st_ring += loc != 0 && loc != 15; st_far += loc == 15;
                         g.pred_rank[po + q] = ent;
                         if (q == 0) g.row_pred0[r] = ent; else if (q == 1) g.row_pred1[r] = ent;
+                        if (np == 1 && loc != 15) atomicOr(&g.row_meta[r], (loc == 0 ? 1u : 2u) << 5);   // row type for the DP's dispatch (other lanes OR flags into this word)
                     }
                 }
 #ifndef HX_DP_PROF
