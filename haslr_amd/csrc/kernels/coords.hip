@@ -18,23 +18,35 @@ namespace {
 
 __device__ long long find_lr_pos(const CgView& v, bool reversed, uint32_t lr, uint32_t c, int lstep, int cstep, uint32_t contig_pos) {
     if ((cstep > 0 && c > contig_pos) || (cstep < 0 && c < contig_pos)) return -1;
+    // Eight op words are fetched at a time (independent addresses, one memory round trip), then walked from registers: the walk's exit
+    // depends on the data, so one-op-at-a-time costs a full memory latency per op.
     const uint64_t n = v.e - v.b;
-    for (uint64_t k = 0; k < n; k++) {
-        uint64_t g = reversed ? v.e - 1 - k : v.b + k;
-        uint32_t len = v.eff(g);
-        if (len == 0) continue;
-        uint32_t code = HX_CG_OP(v.ops[g]);
-        uint32_t d = cstep > 0 ? contig_pos - c : c - contig_pos;
-        if (code == HX_CG_I) {
-            if (d == 0) break;
-            lr += len * lstep;
-        } else {
-            if (d < len) {
-                if (code == HX_CG_M) lr += d * lstep;
-                break;
+    bool stop = false;
+    for (uint64_t k0 = 0; k0 < n && !stop; k0 += 8) {
+        uint32_t w[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint64_t kk = k0 + u < n ? k0 + u : n - 1; w[u] = v.ops[reversed ? v.e - 1 - kk : v.b + kk]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (stop || k0 + u >= n) continue;
+            const uint64_t g = reversed ? v.e - 1 - (k0 + u) : v.b + (k0 + u);
+            uint32_t len = HX_CG_LEN(w[u]);
+            if (g == v.b) len -= v.skf;
+            if (g + 1 == v.e) len -= v.skb;
+            if (len == 0) continue;
+            const uint32_t code = HX_CG_OP(w[u]);
+            const uint32_t d = cstep > 0 ? contig_pos - c : c - contig_pos;
+            if (code == HX_CG_I) {
+                if (d == 0) { stop = true; continue; }
+                lr += len * lstep;
+            } else {
+                if (d < len) {
+                    if (code == HX_CG_M) lr += d * lstep;
+                    stop = true; continue;
+                }
+                if (code == HX_CG_M) lr += len * lstep;
+                c += len * cstep;
             }
-            if (code == HX_CG_M) lr += len * lstep;
-            c += len * cstep;
         }
     }
     return (long long)lr;

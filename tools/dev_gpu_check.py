@@ -8,7 +8,7 @@ glen = sys.argv[1] if len(sys.argv)>1 else '300000'
 seed = sys.argv[2] if len(sys.argv)>2 else '7'
 blk = int(sys.argv[3]) if len(sys.argv)>3 else 256
 os.makedirs('/tmp/gt', exist_ok=True)
-subprocess.check_call([ROOT+'/tools/hxsim','--genome-len',glen,'--seed',seed,'--out-prefix','/tmp/gt/s'])
+subprocess.check_call([ROOT+'/tools/hxsim','--genome-len',glen,'--seed',seed,'--out-prefix','/tmp/gt/s'] + os.environ.get('HXSIM_EXTRA','').split())
 ds = host.Dataset('/tmp/gt/s.contigs.fa','/tmp/gt/s.reads.fa','/tmp/gt/s.paf')
 prm = ds.params()
 be = orclib.OracleBackend(ds, 8)
