@@ -6,17 +6,18 @@
 // the published rvaser/spoa 1.1.3 algorithm as restated in oracle/oracle.cpp (same recurrences, same
 // tie-breaking, same graph update and topological order), so results are bit-identical to the oracle.
 //
-// Round-1 mapping: one workgroup per edge (edges are independent; thousands are in flight).
-//   * sequence k is decoded from the 2-bit packed read arena straight into a byte row (coalesced dword loads)
-//   * DP: rows = graph nodes in topological order (sequential, data-dependent), columns = sequence positions
-//     split into one contiguous chunk per lane. A row is T[j] = max over predecessor rows p of
-//     (H[p][j-1]+s, H[p][j]+g) followed by the horizontal recurrence H[j] = max(T[j], H[j-1]+g), which is a
-//     prefix-max of T[k]-k*g: lanes scan their chunk serially, chunk ends are combined with a wavefront
-//     prefix scan (shuffles) and an LDS exchange between waves, then the carry is applied.
-//   * traceback, graph update, topological sort and heaviest bundle are O(V+L) pointer work done by lane 0;
-//     the rank-ordered CSR that the DP reads (row code, predecessor ranks, sink flag) is rebuilt by all lanes.
-// Full (V+1)x(L+1) int32 score matrix in HBM, as in the reference's engine; banding and LDS-resident row rings
-// are the next optimisation steps (DESIGN.md "K6 roadmap").
+// Mapping (details in DESIGN.md "K6 in detail"): one workgroup per edge, or 2-8 cooperating workgroups ("members", one CU each) for
+// gaps above 2047 columns; sequences of an edge are aligned one after the other, edges run concurrently.
+//   * sequence k is decoded from the 2-bit packed read arena into a byte row
+//   * DP (dp_rows): rows = graph nodes in topological order, columns = sequence positions, CM contiguous columns per lane kept in
+//     registers. Cells are keys (64 x score + 6 tie-break bits), so one max() per decision reproduces the reference's tie rules and the
+//     low bits are the traceback's direction byte. Horizontal recurrence = lane-serial pass + one DPP prefix-max scan (+ wave totals
+//     through LDS and one LDS-only barrier per row; + one tagged mailbox word per row between members). Rows needed later as
+//     non-adjacent predecessors live in an LDS ring, the overflow in HBM.
+//   * traceback: the first wavefront walks 32x16 tiles of direction bytes with v_readlane
+//   * graph update (spoa add_alignment), order update and the rank-ordered CSR rebuild run on all lanes (prefix sums for the ids the
+//     serial walk would hand out); the reference's DFS topological sort runs only for end-node ties that a column cannot decide and
+//     for heaviest bundles that do not end in a unique sink (one wavefront in lock step, on ranks).
 #include <type_traits>
 
 #include "kernels.h"
