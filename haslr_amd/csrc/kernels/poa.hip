@@ -232,7 +232,8 @@ __device__ void toposort_rank(G& g, const uint32_t V, uint8_t* st /* by rank */,
             const uint32_t alp = (uint32_t)__builtin_amdgcn_readfirstlane((int)rv.w);
             const bool chk = sn & 4u;
             const uint32_t spb = sp;
-            if (npred > 2) {   // three or more in-edges: the list (rare)
+            const bool again = (sn & 3u) == 1u;   // second visit: everything this node pushed has been finished (LIFO, no cycles), nothing to check
+            if (!again && npred > 2) {   // three or more in-edges: the list (rare)
                 const uint32_t po = g.row_pred_off[n];
                 for (uint32_t p = 0; p < npred; p++) {
                     const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[po + p]) & 0x0fffffffu;
@@ -248,8 +249,8 @@ __device__ void toposort_rank(G& g, const uint32_t V, uint8_t* st /* by rank */,
             if (lane == 0 && npred >= 1 && npred <= 2) cand = rv.y & 0x0fffffffu;
             else if (lane == 1 && npred == 2) cand = rv.z & 0x0fffffffu;
             else if (lane >= 2 && lane < 5 && chk) { const uint32_t d = (alp >> (3 * (lane - 2))) & 7u; cand = d ? n + d - 4u : NONE; }
-            const bool todo = cand != NONE && (st[cand] & 3u) != 2u;
-            const unsigned long long tm = __ballot(todo);
+            const bool todo = !again && cand != NONE && (st[cand] & 3u) != 2u;
+            const unsigned long long tm = again ? 0ull : __ballot(todo);
             const uint32_t npush = (uint32_t)__popcll(tm);
             if (npush) {
                 while (sp + npush - base > TOPO_LCAP) { if (lane == 0) g.stack[base] = lstack[base & (TOPO_LCAP - 1)]; base++; }   // make room in the LDS window
