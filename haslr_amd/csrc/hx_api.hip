@@ -533,6 +533,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     const uint32_t cl_lanes = getenv("HX_POA_MEMBER_LANES") ? (uint32_t)atoi(getenv("HX_POA_MEMBER_LANES")) : 512;   // lanes per cluster member
     const uint32_t cl_min = getenv("HX_POA_CLUSTER_MIN") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MIN")) : 2048;       // columns above which an edge is shared
     const uint32_t cl_max = getenv("HX_POA_CLUSTER_MAX") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MAX")) : 8;          // members per edge at most
+    const uint32_t cl_topk = getenv("HX_POA_CLUSTER_TOPK") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_TOPK")) : 96;            // shared edges per call at most (the costliest)
     const uint32_t cl_cols = getenv("HX_POA_CLUSTER_COLS") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_COLS")) : 4;            // columns per lane a member aims at
     if (cl_lanes != 64 && cl_lanes != 128 && cl_lanes != 256 && cl_lanes != 512 && cl_lanes != 1024) return fail("HX_POA_MEMBER_LANES must be 64, 128, 256, 512 or 1024");
     while (!todo.empty()) {
@@ -556,6 +557,12 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             uint64_t ca = (uint64_t)P.edges[a].vcap * P.edges[a].lmax, cb = (uint64_t)P.edges[b].vcap * P.edges[b].lmax;
             return ca != cb ? ca > cb : a < b;
         });
+        // Sharing an edge among several CUs buys latency for the edge and costs throughput (the other members idle while member 0 walks
+        // back and updates the graph). It pays while large edges are few; with many of them only the costliest keep their members.
+        {
+            uint32_t shared = 0;
+            for (uint32_t e : todo) if (P.edges[e].members > 1 && ++shared > cl_topk) P.edges[e].members = 1;
+        }
         // ---- batches that fit the memory budget
         size_t pos = 0;
         std::vector<uint32_t> retry, retry_same;   // retry with the worst-case workspace / with the score-matrix traceback
