@@ -550,7 +550,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             E.members = 1;
             const uint32_t ncol = E.lmax + 1;
             if (!c->poa_block && !c->poa_no_dir && !force_nodir[e] && P.nseq[e] <= 63 && ncol > cl_min) E.members = (uint32_t)std::min<uint64_t>(cl_max, (ncol + (uint64_t)cl_lanes * cl_cols - 1) / ((uint64_t)cl_lanes * cl_cols));
-            if (E.members < 2) E.members = 1;
+            if (E.members < 2 || ((uint64_t)ncol + (uint64_t)E.members * cl_lanes - 1) / ((uint64_t)E.members * cl_lanes) > 32) E.members = 1;   // (members too small for this gap: one workgroup)
         }
         // largest first (block scheduling is in grid order): cost ~ rows x columns x sequences
         std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) {

@@ -1,0 +1,48 @@
+"""development aid: GPU path vs oracle over many random small data sets and launch shapes (consensus strings + assembly must be identical)"""
+import os
+import random
+import subprocess
+import sys
+
+ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
+sys.path.insert(0, ROOT)
+sys.path.insert(0, ROOT + '/tests')
+from haslr_amd import host, hip  # noqa: E402
+import orclib  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ctx = hip.HipContext(0)
+os.makedirs('/tmp/fz', exist_ok=True)
+bad = 0
+KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX')
+for it in range(n):
+    glen = rng.choice([40000, 60000, 90000, 150000, 250000])
+    args = ['--genome-len', str(glen), '--seed', str(rng.randrange(1, 10**6)), '--model', rng.choice(['pacbio', 'nanopore', 'pacbio']), '--cov', str(rng.choice([8, 15, 25, 40, 70])),
+            '--variant-per-mb', str(rng.choice([0, 5, 30])), '--gap-median', str(rng.choice([300, 600, 1500, 3000])), '--out-prefix', '/tmp/fz/s']
+    subprocess.check_call([ROOT + '/tools/hxsim'] + args, stderr=subprocess.DEVNULL)
+    env = {}
+    shape = rng.choice(['default', 'small-members', 'one-wave', 'block'])
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    ctx.set_poa_block(0)
+    if shape == 'small-members':
+        env = {'HX_POA_CLUSTER_MIN': str(rng.choice([200, 400, 800])), 'HX_POA_MEMBER_LANES': str(rng.choice([64, 128, 256])),
+               'HX_POA_CLUSTER_COLS': str(rng.choice([4, 8])), 'HX_POA_CLUSTER_MAX': str(rng.choice([2, 3, 8]))}
+    elif shape == 'one-wave':
+        env = {'HX_POA_WAVE_MAX': str(rng.choice([128, 256, 2048])), 'HX_POA_MAX_INDEG': str(rng.choice([2, 3, 16]))}
+    elif shape == 'block':
+        ctx.set_poa_block(rng.choice([64, 128, 256, 512, 1024]))
+    os.environ.update(env)
+    ds = host.Dataset('/tmp/fz/s.contigs.fa', '/tmp/fz/s.reads.fa', '/tmp/fz/s.paf')
+    be = orclib.OracleBackend(ds, 16)
+    ro = host.Run(ds, ds.params(), be.table, None)
+    ro.all()
+    ctx.upload(ds)
+    rg = host.Run(ds, ds.params(), ctx.backend(), None)
+    rg.all()
+    ok = ro.cns_out() == rg.cns_out() and ro.assembly_fasta() == rg.assembly_fasta()
+    print(it, 'OK' if ok else 'DIFF', ' '.join(args[:-2]), shape, env, 'edges', rg.n_edges, flush=True)
+    bad += not ok
+    rg.close(); ro.close(); be.close(); ds.close()
+print('fuzz done, failures:', bad)
