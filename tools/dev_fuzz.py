@@ -17,12 +17,13 @@ os.makedirs('/tmp/fz', exist_ok=True)
 bad = 0
 KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX')
 for it in range(n):
-    glen = rng.choice([40000, 60000, 90000, 150000, 250000])
+    big = os.environ.get('FUZZ_BIG') is not None   # long gaps at real sizes: the default launch shapes (512-lane cluster members) get real work
+    glen = rng.choice([400000, 700000, 1000000]) if big else rng.choice([40000, 60000, 90000, 150000, 250000])
     args = ['--genome-len', str(glen), '--seed', str(rng.randrange(1, 10**6)), '--model', rng.choice(['pacbio', 'nanopore', 'pacbio']), '--cov', str(rng.choice([8, 15, 25, 40, 70])),
-            '--variant-per-mb', str(rng.choice([0, 5, 30])), '--gap-median', str(rng.choice([300, 600, 1500, 3000])), '--out-prefix', '/tmp/fz/s']
+            '--variant-per-mb', str(rng.choice([0, 5, 30])), '--gap-median', str(rng.choice([2500, 4000, 6000]) if big else rng.choice([300, 600, 1500, 3000])), '--out-prefix', '/tmp/fz/s']
     subprocess.check_call([ROOT + '/tools/hxsim'] + args, stderr=subprocess.DEVNULL)
     env = {}
-    shape = rng.choice(['default', 'small-members', 'one-wave', 'block'])
+    shape = rng.choice(['default', 'default', 'small-members', 'block']) if big else rng.choice(['default', 'small-members', 'one-wave', 'block'])
     for k in KNOBS:
         os.environ.pop(k, None)
     ctx.set_poa_block(0)
