@@ -36,11 +36,13 @@ for it in range(n):
         ctx.set_poa_block(rng.choice([64, 128, 256, 512, 1024]))
     os.environ.update(env)
     ds = host.Dataset('/tmp/fz/s.contigs.fa', '/tmp/fz/s.reads.fa', '/tmp/fz/s.paf')
+    pk = dict(min_aln_block=rng.choice([250, 500, 500, 1000]), min_aln_sim=rng.choice([0.8, 0.85, 0.85, 0.9]), min_edge_sup=rng.choice([2, 3, 3, 5]), max_uniq_dev=rng.choice([0.15, 0.15, 0.3]))
+    env = dict(env, **{k: str(v) for k, v in pk.items()})   # (printed with the knobs)
     be = orclib.OracleBackend(ds, 16)
-    ro = host.Run(ds, ds.params(), be.table, None)
+    ro = host.Run(ds, ds.params(**pk), be.table, None)
     ro.all()
     ctx.upload(ds)
-    rg = host.Run(ds, ds.params(), ctx.backend(), None)
+    rg = host.Run(ds, ds.params(**pk), ctx.backend(), None)
     rg.all()
     ok = ro.cns_out() == rg.cns_out() and ro.assembly_fasta() == rg.assembly_fasta()
     print(it, 'OK' if ok else 'DIFF', ' '.join(args[:-2]), shape, env, 'edges', rg.n_edges, flush=True)
