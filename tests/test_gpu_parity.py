@@ -344,3 +344,46 @@ def test_cli_reuses_index_caches(sim, built, tmp_path):
     assert "reading contig index" in r.stderr and "reading long read and alignment index" in r.stderr
     for f, data in keep.items():
         assert open(out / f, "rb").read() == data, f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(8))
+def test_random_data_sets_and_launch_shapes(sim, ctx, case):
+    """a seeded slice of tools/dev_fuzz.py (which has run hundreds of such cases): random generator settings, pipeline parameters and
+    POA launch shapes; consensus strings and the assembly equal the oracle's"""
+    import random
+    rng = random.Random(1000 + case)
+    pre = sim("--genome-len", str(rng.choice([60000, 90000, 150000])), "--seed", str(rng.randrange(1, 10**6)), "--model", rng.choice(["pacbio", "nanopore"]),
+              "--cov", str(rng.choice([8, 15, 25, 40])), "--variant-per-mb", str(rng.choice([0, 5, 30])), "--gap-median", str(rng.choice([300, 600, 1500, 3000])))
+    knobs = ("HX_POA_CLUSTER_MIN", "HX_POA_MEMBER_LANES", "HX_POA_CLUSTER_COLS", "HX_POA_CLUSTER_MAX", "HX_POA_MAX_INDEG", "HX_POA_WAVE_MAX")
+    shape = ["default", "small-members", "one-wave", "block"][case % 4]
+    env, block = {}, 0
+    if shape == "small-members":
+        env = {"HX_POA_CLUSTER_MIN": str(rng.choice([200, 400, 800])), "HX_POA_MEMBER_LANES": str(rng.choice([64, 128, 256])),
+               "HX_POA_CLUSTER_COLS": str(rng.choice([4, 8])), "HX_POA_CLUSTER_MAX": str(rng.choice([2, 3, 8]))}
+    elif shape == "one-wave":
+        env = {"HX_POA_WAVE_MAX": str(rng.choice([128, 256, 2048])), "HX_POA_MAX_INDEG": str(rng.choice([2, 3, 16]))}
+    elif shape == "block":
+        block = rng.choice([64, 128, 256, 512, 1024])
+    pk = dict(min_aln_block=rng.choice([250, 500, 1000]), min_aln_sim=rng.choice([0.8, 0.85, 0.9]), min_edge_sup=rng.choice([2, 3, 5]))
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    be = orclib.OracleBackend(ds, 8)
+    ro = host.Run(ds, ds.params(**pk), be.table, None)
+    ro.all()
+    ctx.upload(ds)
+    old = {k: os.environ.get(k) for k in knobs}
+    try:
+        os.environ.update(env)
+        ctx.set_poa_block(block)
+        rg = host.Run(ds, ds.params(**pk), ctx.backend(), None)
+        rg.all()
+    finally:
+        ctx.set_poa_block(0)
+        for k in knobs:
+            if old[k] is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = old[k]
+    assert ro.cns_out() == rg.cns_out(), (shape, env, block, pk)
+    assert ro.assembly_fasta() == rg.assembly_fasta()
+    rg.close(); ro.close(); be.close(); ds.close()
