@@ -84,7 +84,7 @@ def test_nondefault_parameters(sim, ctx, tmp_path):
     assert util.compare_dirs(str(tmp_path / "o"), str(tmp_path / "g")) == []
 
 
-@pytest.mark.parametrize("case", sorted(d for d in os.listdir(GOLD) if os.path.isdir(os.path.join(GOLD, d)) and not d.startswith("committed")))
+@pytest.mark.parametrize("case", sorted(d for d in os.listdir(GOLD) if os.path.isfile(os.path.join(GOLD, d, "manifest.json")) and not d.startswith("committed")))
 def test_golden_fixtures_through_hip(case, sim, ctx, tmp_path):
     """front-half outputs of the HIP path against the files the compiled reference produced"""
     import gzip
@@ -140,6 +140,31 @@ def test_cli_drop_in(sim, built, tmp_path):
     names = [f for f in os.listdir(tmp_path / "o")]
     assert "asm.final.fa" in names and "backbone.06.smallbubble.gfa" in names
     assert util.compare_dirs(str(tmp_path / "o"), str(out), names) == []
+
+
+def test_pipeline_driver_with_the_real_assembler(sim, built, tmp_path):
+    """haslr.py (haslr_amd/driver/haslr_pipeline.py) end to end: stand-ins only for the external tools (fastutils hands the reads on,
+    minimap2 hands over the simulator's PAF), the real minia_nooverlap and the real MI355X haslr_assemble; the assembly it leaves in
+    asm_*/asm.final.fa is the oracle-backed one, and a second run finds everything done"""
+    import driverlib
+    pre = sim("--genome-len", "120000", "--seed", "27")
+    bindir, out = str(tmp_path / "bin"), str(tmp_path / "out")
+    real = {t: os.path.join(ROOT, "haslr_amd", "bin", t) for t in ("haslr_assemble", "minia_nooverlap")}
+    driverlib.make_bin(bindir, os.path.join(ROOT, "haslr_amd", "bin", "haslr.py"), real=real)
+    data = os.path.dirname(pre)
+    args = ["-o", out, "-g", "120k", "-l", pre + ".reads.fa", "-x", "pacbio", "-c", pre + ".contigs.fa", "-t", "4", "--cov-lr", "0"]
+    r = driverlib.run(bindir, data, out, args, extra_env={"STUB_PAF": pre + ".paf"})
+    assert r["rc"] == 0, r["stdout"] + r["tree"].get("asm_contigs_k49_a3_c250_lrall_b500_s3_sim0.85.err", "")
+    assert [c["tool"] for c in r["calls"]] == ["fastutils", "fastutils", "minimap2"]       # the two real tools do not record
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    ob = orclib.OracleBackend(ds, 8)
+    ro = host.Run(ds, ds.params(), ob.table, None)
+    ro.all()
+    asm = r["tree"]["asm_contigs_k49_a3_c250_lrall_b500_s3_sim0.85/asm.final.fa"]
+    assert asm == ro.assembly_fasta() and asm.count(">") >= 1
+    r2 = driverlib.run(bindir, data, out, args, extra_env={"STUB_PAF": pre + ".paf"})
+    assert r2["rc"] == 0 and r2["calls"] == [] and r2["stdout"].count("already exists") == 5
+    ro.close(); ob.close(); ds.close()
 
 
 def test_edge_cases(ctx, built, tmp_path):

@@ -12,7 +12,7 @@ import util
 from haslr_amd import host
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(d for d in os.listdir(GOLD) if os.path.isdir(os.path.join(GOLD, d)))
+CASES = sorted(d for d in os.listdir(GOLD) if os.path.isfile(os.path.join(GOLD, d, "manifest.json")))
 
 
 def run_oracle(pre_contigs, pre_reads, pre_paf, out):
