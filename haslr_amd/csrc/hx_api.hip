@@ -1,6 +1,7 @@
 // hx_api.hip — implementation of the C-ABI in include/haslr_hip.h: device context, resident inputs,
 // the four hot-path operators (kernel orchestration + result download), multi-GPU record exchange, timing.
 // There is no CPU fallback here: without a usable HIP device every entry point fails with an error.
+#include <chrono>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -97,6 +98,13 @@ struct PoaPoolBufs {
     DV<uint4> nrec;
     DV<uint8_t> dir;
     DV<unsigned long long> mbox; DV<int32_t> farleft, sinkbuf; DV<uint32_t> csync; DV<uint16_t> row_al;   // cluster mode (edges shared by several workgroups)
+    void release_all() {
+        code.release(); n_aligned.release(); mark.release(); check.release(); row_code.release(); row_sink.release(); seq.release();
+        aligned.release(); in_head.release(); in_tail.release(); out_head.release(); out_tail.release(); rank2node.release(); node2rank.release();
+        stack.release(); row_pred_off.release(); pred_rank.release(); e_from.release(); e_to.release(); e_next_in.release(); e_next_out.release();
+        score.release(); pred.release(); e_w.release(); aln_node.release(); aln_pos.release(); H.release(); row_meta.release(); row_pred0.release();
+        row_pred1.release(); nrec.release(); dir.release(); mbox.release(); farleft.release(); sinkbuf.release(); csync.release(); row_al.release();
+    }
 };
 }  // namespace
 
@@ -139,6 +147,7 @@ struct hx_ctx {
     bool have_coords = false;
     uint32_t dbg_slowest = 0;
     std::vector<uint32_t> dbg_lmax, dbg_nseq;
+    std::vector<uint8_t> dbg_cls; uint32_t dbg_ring[11] = {};
     bool poa_no_dir = false;   // diagnostics: force the score-matrix traceback
     int poa_block = 0;   // 0 = automatic (lanes per edge chosen from the gap length)
     hipStream_t poa_streams[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -478,6 +487,7 @@ extern "C" void hx_free_coords(hx_ctx*, hx_coords_out* o) {
 // ================================================================================================ K6
 
 extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out) {
+    const auto dbg_t0 = std::chrono::steady_clock::now();
     memset(out, 0, sizeof(*out));
     if (!c->have_coords) return fail("hx_poa_batch: hx_edge_coords has not run");
     HIPCHK(hipSetDevice(c->device));
@@ -504,7 +514,9 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
         E.seq_end = (uint32_t)P.seqs.size();
     }
     std::vector<uint32_t> todo;
+    if (getenv("HX_DEBUG")) fprintf(stderr, "[hx] POA call: %u edges prepared in %.1f ms\n", (unsigned)ne, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count());
     for (uint32_t e = 0; e < ne; e++) if (P.nseq[e]) todo.push_back(e);
+    c->dbg_cls.assign(ne, 11); for (int k = 0; k < 11; k++) c->dbg_ring[k] = 0;
     c->dbg_nseq = P.nseq; c->dbg_lmax.resize(ne); for (uint32_t e = 0; e < ne; e++) c->dbg_lmax[e] = P.edges[e].lmax;
     std::vector<uint32_t> cns_len(ne, 0);
     std::vector<std::string> cns(ne);
@@ -529,13 +541,41 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     HIPCHK(hipMemsetAsync(d_phase.p, 0, std::max<size_t>(1, (size_t)ne * 12) * 8, s));
     bool worst_case = false;
     std::vector<uint8_t> force_nodir(ne, 0);   // edges whose in-degrees outgrew the direction bytes
+    std::vector<uint8_t> full_h(ne, 0);        // edges that run with the score-matrix traceback
     const uint32_t max_indeg = getenv("HX_POA_MAX_INDEG") ? std::min<uint32_t>(16, (uint32_t)atoi(getenv("HX_POA_MAX_INDEG"))) : 16;   // (testing: forces the score-matrix retry earlier)
     const uint32_t cl_lanes = getenv("HX_POA_MEMBER_LANES") ? (uint32_t)atoi(getenv("HX_POA_MEMBER_LANES")) : 512;   // lanes per cluster member
     const uint32_t cl_min = getenv("HX_POA_CLUSTER_MIN") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MIN")) : 2048;       // columns above which an edge is shared
     const uint32_t cl_max = getenv("HX_POA_CLUSTER_MAX") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MAX")) : 8;          // members per edge at most
     const uint32_t cl_topk = getenv("HX_POA_CLUSTER_TOPK") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_TOPK")) : 96;            // shared edges per call at most (the costliest)
     const uint32_t cl_cols = getenv("HX_POA_CLUSTER_COLS") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_COLS")) : 4;            // columns per lane a member aims at
+    const long far_rows = getenv("HX_POA_FAR_ROWS") ? atol(getenv("HX_POA_FAR_ROWS")) : -1;   // (testing: rows of H per edge on the first attempt)
     if (cl_lanes != 64 && cl_lanes != 128 && cl_lanes != 256 && cl_lanes != 512 && cl_lanes != 1024) return fail("HX_POA_MEMBER_LANES must be 64, 128, 256, 512 or 1024");
+    // lanes per edge. Gaps up to 2047 bases: ONE wavefront per edge (row in registers, no barriers, many edges per CU).
+    // Longer gaps: a multi-wave workgroup with ~8 columns per lane (256..1024 lanes). One launch per class, classes run concurrently.
+    // Class 0 = edges shared by several workgroups (cluster members of cl_lanes lanes); classes 1..5 = one workgroup per edge.
+    // Classes 6..10 = classes 1..5 for the edges that need the score-matrix traceback (rare: more than 63 sequences, an in-degree
+    // the direction bytes cannot hold, or the test switch), launched after their direction-byte twins on the same streams.
+    constexpr int NCLS = 11;
+    static const int kClassNT[NCLS] = {0, 1024, 512, 256, 128, 64, 1024, 512, 256, 128, 64};
+    const uint32_t wave_max = getenv("HX_POA_WAVE_MAX") ? (uint32_t)atoi(getenv("HX_POA_WAVE_MAX")) : 512;   // columns handled by ONE wavefront per edge
+    const uint32_t cols_per_lane = getenv("HX_POA_COLS") ? (uint32_t)atoi(getenv("HX_POA_COLS")) : 4;
+    auto class_of = [&](uint32_t e) -> int {   // launch class of an edge that is not shared (members == 1), direction-byte flavour
+        static const uint32_t kMaxCm[6] = {0, 8, 16, 32, 32, 32};   // columns per lane each kernel variant keeps in registers
+        const uint32_t ncol = P.edges[e].lmax + 1;
+        int k = 5;
+        if (c->poa_block) { for (k = 1; k < 5 && kClassNT[k] > c->poa_block; k++) {} }
+        else if (ncol > wave_max) { k = 4; while (k > 1 && (uint64_t)kClassNT[k] * cols_per_lane < ncol) k--; }
+        while (k > 1 && (uint64_t)kClassNT[k] * kMaxCm[k] < ncol) k--;
+        return k;
+    };
+    auto ring_rows_of = [](uint32_t nt, uint32_t cm, uint64_t& row_bytes) -> uint32_t {   // kept rows the LDS ring of a launch holds
+        row_bytes = (uint64_t)cm * (nt + 1) * 4;   // planes of nt + 1 words
+        const uint64_t lds_budget = nt >= 1024 ? 128 * 1024 : nt == 64 ? 32 * 1024 : 64 * 1024 * (nt / 128 > 2 ? 2 : 1);
+        const uint64_t rows_fit = std::min<uint64_t>(lds_budget * 9 / 8, 140 * 1024) / row_bytes;   // ring slots + 1 scratch slot
+        return rows_fit >= 9 ? 8 : rows_fit >= 5 ? 4 : rows_fit >= 3 ? 2 : 0;   // power of two (slot = kept-row counter & (R-1))
+    };
+    auto cm_round = [](uint32_t ncol, uint32_t lanes) -> uint32_t { uint32_t cm = (ncol + lanes - 1) / lanes, r = 4; while (r < cm) r <<= 1; return r; };
+    std::vector<uint8_t> far_full(ne, 0);      // edges whose far rows outgrew the estimate
     while (!todo.empty()) {
         // ---- workspace sizes; estimated graph capacity first, the proven worst case on retry
         for (uint32_t e : todo) {
@@ -545,67 +585,96 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             if (vc >= 0x7fffffffULL) return fail("hx_poa_batch: POA graph too large");
             // DP cells are keys = 64 x score + 6 tie-break bits in an int32: |score| <= 8 * (nodes + columns) must stay below 2^24
             if (vc + E.lmax + 2 >= (1ull << 21)) return fail("hx_poa_batch: POA graph of an edge exceeds 2^21 nodes + columns (score keys would overflow)");
-            E.vcap = (uint32_t)vc; E.hrows = E.vcap; E.ecap = (uint32_t)(P.sumL[e] + P.nseq[e] + 1);
+            E.vcap = (uint32_t)vc; E.ecap = (uint32_t)(P.sumL[e] + P.nseq[e] + 1);
+            // rows of H. The score-matrix traceback keeps every row; with direction bytes only rows that a successor reads after they left
+            // the LDS ring go to HBM (about 1 row in 1000 on PacBio-like data): a sixteenth of the rows is the estimate, all of them the retry
+            full_h[e] = c->poa_no_dir || force_nodir[e] || P.nseq[e] > 63;   // (in-degree <= #sequences must fit the 6-bit predecessor slot)
+
             // long gaps: the DP columns of the edge are shared by several workgroups (one CU each), ~8 columns per lane
             E.members = 1;
             const uint32_t ncol = E.lmax + 1;
             if (!c->poa_block && !c->poa_no_dir && !force_nodir[e] && P.nseq[e] <= 63 && ncol > cl_min) E.members = (uint32_t)std::min<uint64_t>(cl_max, (ncol + (uint64_t)cl_lanes * cl_cols - 1) / ((uint64_t)cl_lanes * cl_cols));
             if (E.members < 2 || ((uint64_t)ncol + (uint64_t)E.members * cl_lanes - 1) / ((uint64_t)E.members * cl_lanes) > 32) E.members = 1;   // (members too small for this gap: one workgroup)
         }
+        // Sharing an edge among several CUs buys latency for the edge and costs throughput (the other members idle while member 0 walks
+        // back and updates the graph). It pays while large edges are few; with many of them only the costliest keep their members.
+        {
+            std::vector<uint32_t> sh;
+            for (uint32_t e : todo) if (P.edges[e].members > 1) sh.push_back(e);
+            if (sh.size() > cl_topk) {
+                std::sort(sh.begin(), sh.end(), [&](uint32_t a, uint32_t b) {
+                    uint64_t ca = (uint64_t)P.edges[a].vcap * P.edges[a].lmax, cb = (uint64_t)P.edges[b].vcap * P.edges[b].lmax;
+                    return ca != cb ? ca > cb : a < b;
+                });
+                for (size_t q = cl_topk; q < sh.size(); q++) P.edges[sh[q]].members = 1;
+            }
+        }
+        // rows of H (see full_h above): how many rows leave the LDS ring before their last reader depends on how many the ring holds
+        for (uint32_t e : todo) {
+            hxk::PoaEdge& E = P.edges[e];
+            const uint32_t ncol = E.lmax + 1, nt = E.members > 1 ? cl_lanes : (uint32_t)kClassNT[class_of(e)];
+            uint64_t rb;
+            const uint32_t Rp = ring_rows_of(nt, cm_round(ncol, E.members > 1 ? E.members * cl_lanes : nt), rb);
+            uint32_t est = far_rows >= 0 ? (uint32_t)far_rows : Rp >= 8 ? E.vcap / 16 + 256 : Rp >= 4 ? E.vcap / 4 + 256 : E.vcap + 1;
+            E.hrows = full_h[e] || far_full[e] || worst_case ? E.vcap + 1 : std::min<uint32_t>(E.vcap + 1, est);
+        }
         // largest first (block scheduling is in grid order): cost ~ rows x columns x sequences
         std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) {
             uint64_t ca = (uint64_t)P.edges[a].vcap * P.edges[a].lmax, cb = (uint64_t)P.edges[b].vcap * P.edges[b].lmax;
             return ca != cb ? ca > cb : a < b;
         });
-        // Sharing an edge among several CUs buys latency for the edge and costs throughput (the other members idle while member 0 walks
-        // back and updates the graph). It pays while large edges are few; with many of them only the costliest keep their members.
-        {
-            uint32_t shared = 0;
-            for (uint32_t e : todo) if (P.edges[e].members > 1 && ++shared > cl_topk) P.edges[e].members = 1;
-        }
         // ---- batches that fit the memory budget
         size_t pos = 0;
         std::vector<uint32_t> retry, retry_same;   // retry with the worst-case workspace / with the score-matrix traceback
         while (pos < todo.size()) {
-            uint64_t no = 0, eo = 0, ho = 0, so = 0, co = 0, sto = 0, ao = 0, clo = 0, bytes = 0;
+            uint64_t no = 0, eo = 0, ho = 0, dro = 0, so = 0, co = 0, sto = 0, ao = 0, clo = 0, bytes = 0;
             size_t end = pos;
             std::vector<uint32_t> batch;
             while (end < todo.size()) {
                 hxk::PoaEdge& E = P.edges[todo[end]];
-                uint64_t nn = (uint64_t)E.vcap + 1, hc = nn * (((uint64_t)E.lmax + 1 + 31) & ~31ull);   // rows padded to 32 columns (the widest lane chunk)
+                const uint64_t rw = ((uint64_t)E.lmax + 1 + 31) & ~31ull;                 // rows padded to 32 columns (the widest lane chunk)
+                const uint64_t nn = (uint64_t)E.vcap + 1, dc = full_h[todo[end]] ? 0 : nn * rw, hc = (uint64_t)E.hrows * rw;
                 const uint64_t cle = E.members > 1 ? (uint64_t)E.members * nn : 0;
-                uint64_t b = nn * 86 + (uint64_t)E.ecap * 24 + hc * 5 + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8 + cle * 12;
+                uint64_t b = nn * 86 + (uint64_t)E.ecap * 24 + hc * 4 + dc + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8 + cle * 12;
                 if (!batch.empty() && bytes + b > budget) break;
-                E.node_off = no; E.edge_off = eo; E.h_off = ho; E.seq_off = so; E.cns_off = co; E.stack_off = sto; E.aln_off = ao; E.cl_off = clo;
-                no += nn; eo += E.ecap; ho += hc; so += E.lmax; co += E.vcap; sto += 4 * nn + E.ecap; ao += nn + E.lmax + 2; clo += cle;
+                E.node_off = no; E.edge_off = eo; E.h_off = ho; E.d_off = dro; E.seq_off = so; E.cns_off = co; E.stack_off = sto; E.aln_off = ao; E.cl_off = clo;
+                no += nn; eo += E.ecap; ho += hc; dro += dc; so += E.lmax; co += E.vcap; sto += 4 * nn + E.ecap; ao += nn + E.lmax + 2; clo += cle;
                 bytes += b;
                 batch.push_back(todo[end]);
                 end++;
             }
             if (bytes > budget) return fail("hx_poa_batch: a single edge needs more POA workspace than the device has free");
-            HIPCHK(B.code.reserve(no)); HIPCHK(B.n_aligned.reserve(no)); HIPCHK(B.mark.reserve(no)); HIPCHK(B.check.reserve(no));
-            HIPCHK(B.row_code.reserve(no)); HIPCHK(B.row_sink.reserve(no)); HIPCHK(B.row_al.reserve(no)); HIPCHK(B.aligned.reserve(3 * no)); HIPCHK(B.in_head.reserve(no));
-            HIPCHK(B.in_tail.reserve(no)); HIPCHK(B.out_head.reserve(no)); HIPCHK(B.out_tail.reserve(no)); HIPCHK(B.rank2node.reserve(no));
-            HIPCHK(B.node2rank.reserve(no)); HIPCHK(B.row_pred_off.reserve(no)); HIPCHK(B.score.reserve(no)); HIPCHK(B.pred.reserve(no));
-            HIPCHK(B.pred_rank.reserve(eo)); HIPCHK(B.e_from.reserve(eo)); HIPCHK(B.e_to.reserve(eo)); HIPCHK(B.e_next_in.reserve(eo));
-            HIPCHK(B.e_next_out.reserve(eo)); HIPCHK(B.e_w.reserve(eo)); HIPCHK(B.stack.reserve(sto)); HIPCHK(B.aln_node.reserve(ao));
-            HIPCHK(B.aln_pos.reserve(ao)); HIPCHK(B.H.reserve(ho)); HIPCHK(B.dir.reserve(ho)); HIPCHK(B.row_meta.reserve(no)); HIPCHK(B.row_pred0.reserve(no)); HIPCHK(B.row_pred1.reserve(no)); HIPCHK(B.nrec.reserve(no)); HIPCHK(B.seq.reserve(so)); HIPCHK(d_cns.reserve(co));
-            HIPCHK(B.mbox.reserve(std::max<uint64_t>(1, clo))); HIPCHK(B.farleft.reserve(std::max<uint64_t>(1, clo)));
-            HIPCHK(B.csync.reserve((size_t)ne * 8)); HIPCHK(B.sinkbuf.reserve((size_t)ne * (1 + 2 * 1024)));
+            // Pools grow and never shrink, each to the largest batch it has seen: after batches of different shapes (direction bytes for one,
+            // the whole score matrix for a retry) the capacities together can exceed the device although this batch alone fits the budget.
+            // Then everything is released and reserved again at this batch's sizes.
+            auto reserve_pools = [&]() -> hipError_t {
+                hipError_t e;
+#define HX_RSV(buf, n) do { if ((e = (buf).reserve(n)) != hipSuccess) return e; } while (0)
+                HX_RSV(B.H, std::max<uint64_t>(1, ho)); HX_RSV(B.dir, std::max<uint64_t>(1, dro));
+                HX_RSV(B.code, no); HX_RSV(B.n_aligned, no); HX_RSV(B.mark, no); HX_RSV(B.check, no); HX_RSV(B.row_code, no); HX_RSV(B.row_sink, no); HX_RSV(B.row_al, no);
+                HX_RSV(B.aligned, 3 * no); HX_RSV(B.in_head, no); HX_RSV(B.in_tail, no); HX_RSV(B.out_head, no); HX_RSV(B.out_tail, no); HX_RSV(B.rank2node, no);
+                HX_RSV(B.node2rank, no); HX_RSV(B.row_pred_off, no); HX_RSV(B.score, no); HX_RSV(B.pred, no); HX_RSV(B.pred_rank, eo); HX_RSV(B.e_from, eo);
+                HX_RSV(B.e_to, eo); HX_RSV(B.e_next_in, eo); HX_RSV(B.e_next_out, eo); HX_RSV(B.e_w, eo); HX_RSV(B.stack, sto); HX_RSV(B.aln_node, ao); HX_RSV(B.aln_pos, ao);
+                HX_RSV(B.row_meta, no); HX_RSV(B.row_pred0, no); HX_RSV(B.row_pred1, no); HX_RSV(B.nrec, no); HX_RSV(B.seq, so); HX_RSV(d_cns, co);
+                HX_RSV(B.mbox, std::max<uint64_t>(1, clo)); HX_RSV(B.farleft, std::max<uint64_t>(1, clo));
+                HX_RSV(B.csync, (size_t)ne * 8); HX_RSV(B.sinkbuf, (size_t)ne * (1 + 2 * 1024));
+#undef HX_RSV
+                return hipSuccess;
+            };
+            if (reserve_pools() != hipSuccess) {
+                (void)hipGetLastError();
+                HIPCHK(hipStreamSynchronize(s));
+                B.release_all(); d_cns.release();
+                HIPCHK(reserve_pools());
+            }
             HIPCHK(hipMemsetAsync(B.csync.p, 0, (size_t)ne * 8 * 4, s));
             if (clo) HIPCHK(hipMemsetAsync(B.mbox.p, 0, clo * 8, s));   // tag 0 = nothing published
             uint64_t n_blocks_total = 0;
             for (uint32_t e : batch) n_blocks_total += P.edges[e].members;
             HIPCHK(d_edges.reserve(ne)); HIPCHK(d_len.reserve(ne)); HIPCHK(d_status.reserve(ne));
-            // lanes per edge. Gaps up to 2047 bases: ONE wavefront per edge (row in registers, no barriers, many edges per CU).
-            // Longer gaps: a multi-wave workgroup with ~8 columns per lane (256..1024 lanes). One launch per class, classes run concurrently.
-            // Class 0 = edges shared by several workgroups (cluster members of cl_lanes lanes); classes 1..5 = one workgroup per edge.
-            static const int kClassNT[6] = {0, 1024, 512, 256, 128, 64};
-            const uint32_t wave_max = getenv("HX_POA_WAVE_MAX") ? (uint32_t)atoi(getenv("HX_POA_WAVE_MAX")) : 512;   // columns handled by ONE wavefront per edge
-            const uint32_t cols_per_lane = getenv("HX_POA_COLS") ? (uint32_t)atoi(getenv("HX_POA_COLS")) : 4;
-            std::vector<uint32_t> cls_list[6];
-            uint32_t cls_cm[6] = {1, 1, 1, 1, 1, 1};
-            bool cls_dir[6] = {true, true, true, true, true, true};
+            std::vector<uint32_t> cls_list[NCLS];
+            uint32_t cls_cm[NCLS];
+            for (int k = 0; k < NCLS; k++) cls_cm[k] = 1;
             for (uint32_t e : batch) {
                 const uint32_t ncol = P.edges[e].lmax + 1;
                 if (ncol > 65536) return fail("hx_poa_batch: gap sub-sequence longer than 65535 bases is not supported by the POA kernel");
@@ -618,21 +687,17 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
                     cls_list[0].push_back(e);
                     continue;
                 }
-                static const uint32_t kMaxCm[6] = {0, 8, 16, 32, 32, 32};   // columns per lane each kernel variant keeps in registers
                 if (ncol > 32768) return fail("hx_poa_batch: a gap longer than 32767 bases needs the shared (cluster) mode: <= 63 sequences, direction-byte traceback, automatic block size");
-                int k = 5;
-                if (c->poa_block) { for (k = 1; k < 5 && kClassNT[k] > c->poa_block; k++) {} }
-                else if (ncol > wave_max) { k = 4; while (k > 1 && (uint64_t)kClassNT[k] * cols_per_lane < ncol) k--; }
-                while (k > 1 && (uint64_t)kClassNT[k] * kMaxCm[k] < ncol) k--;
+                int k = class_of(e);
+                if (full_h[e]) k += 5;
                 cls_list[k].push_back(e);   // batch is cost-sorted, so every class list is too
                 uint32_t cm = (ncol + kClassNT[k] - 1) / kClassNT[k], cmr = 4;
                 while (cmr < cm) cmr <<= 1;
                 cls_cm[k] = std::max(cls_cm[k], cmr);
-                if (P.nseq[e] > 63 || c->poa_no_dir || force_nodir[e]) cls_dir[k] = false;   // in-degree <= #sequences must fit the 6-bit predecessor slot
             }
             std::vector<uint32_t> order_all;   // one entry per workgroup: edge | member << 24
-            size_t cls_blocks[6];
-            for (int k = 0; k < 6; k++) {
+            size_t cls_blocks[NCLS];
+            for (int k = 0; k < NCLS; k++) {
                 const size_t before = order_all.size();
                 if (k == 0 && !getenv("HX_POA_NO_XCD_MAP")) {
                     // Workgroups are handed to the 8 XCDs round-robin by index: put the members of one edge 8 indices apart so that they share an
@@ -660,13 +725,12 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             c->tick();
             HIPCHK(hipEventRecord(c->poa_ev[6], s));
             size_t opos = 0;
-            for (int k = 0; k < 6; k++) {
+            for (int k = 0; k < NCLS; k++) {
                 if (cls_list[k].empty()) continue;
+                const int sk = k < 6 ? k : k - 5;   // stream / event of the class
                 const uint32_t nt = k == 0 ? cl_lanes : (uint32_t)kClassNT[k];
-                const uint64_t row_bytes = (uint64_t)cls_cm[k] * (nt + 1) * 4;   // planes of nt + 1 words
-                const uint64_t lds_budget = nt >= 1024 ? 128 * 1024 : nt == 64 ? 32 * 1024 : 64 * 1024 * (nt / 128 > 2 ? 2 : 1);
-                uint64_t rows_fit = std::min<uint64_t>(lds_budget * 9 / 8, 140 * 1024) / row_bytes;   // ring slots + 1 scratch slot
-                uint32_t R = rows_fit >= 9 ? 8 : rows_fit >= 5 ? 4 : rows_fit >= 3 ? 2 : 0;   // power of two (slot = kept-row counter & (R-1))
+                uint64_t row_bytes;
+                const uint32_t R = ring_rows_of(nt, cls_cm[k], row_bytes);
                 // few edges: ask for enough LDS per workgroup that the dispatcher cannot stack them on a handful of CUs while others idle
                 // (a lone wave runs at twice the speed of two waves sharing a SIMD); many edges: request only what the ring needs
                 uint64_t lds_bytes = (uint64_t)(R ? R + 1 : 0) * row_bytes;   // R ring slots + the scratch slot of rows nobody keeps
@@ -674,21 +738,30 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
                     const uint64_t per_cu = (order_all.size() + 255) / 256;
                     if (per_cu < 8) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(144 * 1024, (156 * 1024) / per_cu - 6 * 1024));
                 }
-                HIPCHK(hipStreamWaitEvent(c->poa_streams[k], c->poa_ev[6], 0));
+                for (uint32_t e : cls_list[k]) c->dbg_cls[e] = (uint8_t)k;
+                c->dbg_ring[k] = R;
+                HIPCHK(hipStreamWaitEvent(c->poa_streams[sk], c->poa_ev[6], 0));
                 hxk::poa_run(d_edges.p, d_order.p + opos, (uint32_t)cls_blocks[k], d_seqs.p, c->packed.p, c->roff.p, c->rlen.p, pools, 0, pp->match, pp->mismatch,
-                             pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)nt, R, (uint32_t)lds_bytes, nt >= 1024 && cls_cm[k] > 8u, cls_dir[k], max_indeg, c->poa_streams[k]);
-                HIPCHK(hipEventRecord(c->poa_ev[k], c->poa_streams[k]));
-                HIPCHK(hipStreamWaitEvent(s, c->poa_ev[k], 0));
+                             pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)nt, R, (uint32_t)lds_bytes, nt >= 1024 && cls_cm[k] > 8u, k < 6, max_indeg, c->poa_streams[sk]);
+                HIPCHK(hipEventRecord(c->poa_ev[sk], c->poa_streams[sk]));
+                HIPCHK(hipStreamWaitEvent(s, c->poa_ev[sk], 0));
                 opos += cls_blocks[k];
             }
             c->tock(3);
             HIPCHK(hipGetLastError());
+            if (getenv("HX_DEBUG")) {
+                HIPCHK(hipStreamSynchronize(s));
+                fprintf(stderr, "[hx] POA batch: %zu edges, %.2f GB workspace, workgroups", batch.size(), bytes / 1e9);
+                for (int k = 0; k < NCLS; k++) if (k < 6 || cls_blocks[k]) fprintf(stderr, " %s%d:%zu(cm %u)", k == 0 ? "shared/" : k > 5 ? "matrix/" : "", k ? kClassNT[k] : (int)cl_lanes, cls_blocks[k], cls_cm[k]);
+                fprintf(stderr, ", %.1f ms since the call began\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count());
+            }
             std::vector<uint32_t> h_len(ne), h_status(ne);
             HIPCHK(hipMemcpy(h_len.data(), d_len.p, (size_t)ne * 4, hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(h_status.data(), d_status.p, (size_t)ne * 4, hipMemcpyDeviceToHost));
             std::vector<char> h_cns(co);
             if (co) HIPCHK(hipMemcpy(h_cns.data(), d_cns.p, co, hipMemcpyDeviceToHost));
             for (uint32_t e : batch) {
+                if (h_status[e] & HXE_POA_FARROWS) { if (far_full[e]) return fail("hx_poa_batch: internal error (far-row retry)"); far_full[e] = 1; retry_same.push_back(e); continue; }
                 if (h_status[e] & HXE_POA_NODIR) { if (force_nodir[e]) return fail("hx_poa_batch: internal error (direction-byte retry)"); force_nodir[e] = 1; retry_same.push_back(e); continue; }
                 if (h_status[e] & ~(uint32_t)HXE_POA_OVERFLOW) return fail("hx_poa_batch: internal error (kernel variant / column count mismatch)");
                 if (h_status[e] & HXE_POA_OVERFLOW) {
@@ -746,6 +819,11 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
                 fprintf(stderr, "[hx] top edge %u: lmax=%u nseq=%u cycles=%llu (dp %llu tb %llu graph %llu order %llu csr %llu) rows %llu\n", tt[k].second, c->dbg_lmax[tt[k].second], c->dbg_nseq[tt[k].second],
                         tt[k].first, q2[1], q2[2], q2[3], q2[4], q2[5], q2[6]);
             }
+        }
+        {   // per launch class: how often a row is read back from the LDS ring / from HBM
+            unsigned long long cr[12][4] = {};
+            for (size_t e = 0; e < ne; e++) { const int k = e < c->dbg_cls.size() ? c->dbg_cls[e] : 11; const unsigned long long* q3 = &c->poa_phase[e * 12]; cr[k][0] += q3[6]; cr[k][1] += q3[10]; cr[k][2] += q3[8]; cr[k][3] += q3[9]; }
+            for (int k = 0; k < 12; k++) if (cr[k][0]) fprintf(stderr, "[hx] class %d (ring %u): DP rows %llu, kept %.1f %%, ring refs %.1f %%, far refs %.2f %%\n", k, k < 11 ? c->dbg_ring[k] : 0, cr[k][0], 100.0 * cr[k][1] / cr[k][0], 100.0 * cr[k][2] / cr[k][0], 100.0 * cr[k][3] / cr[k][0]);
         }
         unsigned long long tot[6] = {0, 0, 0, 0, 0, 0};
         for (size_t e = 0; e < ne; e++) for (int k = 0; k < 6; k++) tot[k] += c->poa_phase[e * 12 + 6 + k];

@@ -74,7 +74,9 @@ struct PoaEdge {
     uint32_t seq_begin, seq_end;   // into the PoaSeq table
     uint32_t vcap, ecap, lmax, hrows;
     uint64_t node_off, edge_off;   // into the node / edge pools (elements)
-    uint64_t h_off;                // into the H pool (int32 cells)
+    uint64_t h_off;                // into the H pool (int32 cells): hrows rows of W. Direction-byte traceback: only the rows a far successor reads
+                                   // (hrows = an estimate, overflow -> retry); score-matrix traceback: all vcap + 1 rows
+    uint64_t d_off;                // into the direction-byte pool (bytes): vcap + 1 rows of W
     uint64_t seq_off;              // into the decoded-sequence pool (bytes, lmax per edge)
     uint64_t cns_off;              // into the consensus output (bytes, capacity vcap)
     uint64_t stack_off;            // into the toposort stack pool (4*(vcap+1) + ecap entries per edge)

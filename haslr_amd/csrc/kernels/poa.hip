@@ -588,6 +588,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     const unsigned long long* mb_in = cl.mbox + (uint64_t)(has_in ? cl.mem - 1 : 0) * cl.stride;
     unsigned long long* mb_out = cl.mbox + (uint64_t)cl.mem * cl.stride;
     int32_t* far_own = cl.farleft + (uint64_t)cl.mem * cl.stride;
+    const uint32_t* farslot = reinterpret_cast<const uint32_t*>(g.pred);      // per rank: row of H that holds the far-read row (consensus scratch, free during the DP)
     const uint32_t j0 = gt * CM;
     const bool live = j0 <= L;                       // the chunk holds at least one real column: only such chunks touch HBM
     const bool owns_last = live && L < j0 + CM;
@@ -638,7 +639,9 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             for (int k = 0; k < CM; k++) hp[k] = S[k * PW + 1];
             left = S[(CM - 1) * PW];
         } else if (live) {                 // kept row that fell out of the ring: HBM
-            const int32_t* Gp = H + (uint64_t)((ent & 0x0fffffffu) + 1) * W + j0;
+            // with direction bytes only the rows a far successor reads are in HBM, in the slots the CSR build gave them
+            const uint32_t hr = DIR ? farslot[ent & 0x0fffffffu] : (ent & 0x0fffffffu) + 1;
+            const int32_t* Gp = H + (uint64_t)hr * W + j0;
             load_chunk_i32<CM>(Gp, hp);
             left = j0 > 0 ? Gp[-1] : NEGK;
             if (!DIR) {                    // the score matrix holds plain scores
@@ -784,7 +787,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             DP_T(5);   // stores
             if (__builtin_expect((meta & (8u | 4u)) != 0, 0)) {
                 if (meta & 8u) {   // a far successor reads this row back from HBM (keys; with the score matrix it is there already)
-                    if (DIR && live) store_chunk_i32<CM>(hrow + j0, t);
+                    if (DIR && live) store_chunk_i32<CM>(H + (uint64_t)farslot[i - 1] * W + j0, t);
                     if (has_in && tid == 0) far_own[i] = left_prev;
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row has left this wave before any later row's barrier
                 }
@@ -838,7 +841,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         g.vcap = ED.vcap; g.ecap = ED.ecap;
     }
     int32_t* H = P.H + ED.h_off;
-    uint8_t* Dm = DIR ? P.dir + ED.h_off : nullptr;   // direction bytes share the score matrix' geometry
+    uint8_t* Dm = DIR ? P.dir + ED.d_off : nullptr;   // direction bytes: (vcap + 1) rows of W; with them H holds only ED.hrows far-read rows
     // ring geometry is a property of the edge (its longest sequence) and of the launch
     const uint32_t GM = ED.members;                  // workgroups sharing this edge's DP columns
     const uint32_t cme = (ED.lmax + 1 + GM * NT - 1) / (GM * NT);
@@ -1358,6 +1361,16 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                         if (np == 1 && loc != 15) atomicOr(&g.row_meta[r], (loc == 0 ? 1u : 2u) << 5);   // row type for the DP's dispatch (other lanes OR flags into this word)
                     }
                 }
+                if (DIR) {   // rows that a far successor reads back from HBM get consecutive rows of H (the score matrix is not kept with direction bytes)
+                    __syncthreads();
+                    uint32_t fc = 0;
+                    for (uint32_t r = r0; r < r1; r++) fc += (g.row_meta[r] >> 3) & 1u;
+                    uint32_t ftot;
+                    uint32_t fex = block_excl_scan_add(fc, lds_u, &ftot);
+                    uint32_t* farslot = reinterpret_cast<uint32_t*>(g.pred);
+                    for (uint32_t r = r0; r < r1; r++) if (g.row_meta[r] & 8u) farslot[r] = fex++;
+                    if (tid == 0 && ftot > ED.hrows && sOk == 1) sOk = 5;   // more far rows than the estimate: the host retries with a row per node
+                }
 #ifndef HX_DP_PROF
                 if (phase) {   // statistics of the rows the next DP will run over
                     if (st_multi) atomicAdd(&ph[7], (unsigned long long)st_multi);
@@ -1388,6 +1401,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         if (sOk == 2) { status[eidx] = HXE_SPOS_RANGE << 8; cns_len[eidx] = 0; }   // internal: kernel variant cannot hold this many columns per lane
         else if (!sOk) { status[eidx] = HXE_POA_OVERFLOW; cns_len[eidx] = 0; }
         else if (sOk == 4) { status[eidx] = HXE_POA_NODIR; cns_len[eidx] = 0; }
+        else if (sOk == 5) { status[eidx] = HXE_POA_FARROWS; cns_len[eidx] = 0; }
         else { status[eidx] = 0; cns_len[eidx] = !sV ? 0 : sCtl != NONE ? sCtl : consensus(g, sV, cns + ED.cns_off); atomicAdd(cells, sCells); }
         PHASE(3);
         if (phase) for (int k = 0; k < 12; k++) phase[(uint64_t)eidx * 12 + k] = ph[k];

@@ -24,7 +24,8 @@ def pytest_configure(config):
 def built():
     """Everything compiled in-tree (no-op when already built; the GPU box receives the built files)."""
     need = [os.path.join(ROOT, "haslr_amd", "lib", "libhaslr_host.so"), os.path.join(ROOT, "haslr_amd", "lib", "libhaslr_hip.so"),
-            os.path.join(ROOT, "haslr_amd", "bin", "haslr_assemble"), os.path.join(ROOT, "oracle", "liboracle.so"),
+            os.path.join(ROOT, "haslr_amd", "bin", "haslr_assemble"), os.path.join(ROOT, "haslr_amd", "bin", "minia_nooverlap"),
+            os.path.join(ROOT, "haslr_amd", "bin", "haslr.py"), os.path.join(ROOT, "oracle", "liboracle.so"),
             os.path.join(ROOT, "tools", "hxsim"), os.path.join(ROOT, "tools", "hxident")]
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__

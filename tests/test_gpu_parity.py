@@ -351,6 +351,38 @@ def test_in_degree_retry_with_score_matrix(sim, ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("far_rows,shape", [("0", {}), ("1", {}), ("0", {"HX_POA_CLUSTER_MIN": "300", "HX_POA_MEMBER_LANES": "128", "HX_POA_CLUSTER_MAX": "3"}),
+                                            ("2", {"HX_POA_WAVE_MAX": "4096"})])
+def test_far_row_estimate_overflow_is_retried(sim, ctx, far_rows, shape):
+    """with direction bytes H keeps only the rows that a successor reads after they left the LDS ring, in as many rows as the host
+    estimated; an edge that needs more comes back and is redone with room for every row. Forced here by an estimate of 0..2 rows
+    (long gaps with deep coverage produce far rows): results and cell counts stay those of the oracle"""
+    pre = sim("--genome-len", "150000", "--seed", "34", "--cov", "40", "--gap-median", "2500")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    prm = ds.params()
+    be = orclib.OracleBackend(ds, 8)
+    ro = host.Run(ds, prm, be.table, None)
+    ro.all()
+    ctx.upload(ds)
+    env = dict(shape, HX_POA_FAR_ROWS=far_rows)
+    old = {k: os.environ.get(k) for k in env}
+    try:
+        os.environ.update(env)
+        rg = host.Run(ds, prm, ctx.backend(), None)
+        rg.all()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert ro.cns_out() == rg.cns_out()
+    assert ro.cns_stats()["dp_cells"] == rg.cns_stats()["dp_cells"]
+    assert rg.n_edges > 0
+    rg.close(); ro.close(); be.close(); ds.close()
+
+
+@pytest.mark.gpu
 def test_cli_reuses_index_caches(sim, built, tmp_path):
     """like the reference (main.cpp:39-103) the binary leaves index.contig / index.longread in -d and a second run loads them instead of
     the text files (which may be gone): same outputs"""
