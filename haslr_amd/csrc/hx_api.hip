@@ -529,7 +529,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     if (!c->poa_budget) {   // measured once: later calls would count the context's own (persistent) workspace as used
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
-        c->poa_budget = (uint64_t)(free_b * 0.8);
+        c->poa_budget = (uint64_t)(free_b * 0.9);
     }
     const uint64_t budget = c->poa_budget;
     PoaPoolBufs& B = c->poa_pools;
@@ -539,7 +539,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     DV<unsigned long long>& d_phase = c->poa_phase_d;
     HIPCHK(d_phase.reserve((size_t)ne * 12));
     HIPCHK(hipMemsetAsync(d_phase.p, 0, std::max<size_t>(1, (size_t)ne * 12) * 8, s));
-    bool worst_case = false;
+    std::vector<uint8_t> grow(ne, 0);          // times an edge's graph outgrew its workspace: the node estimate doubles each time
     std::vector<uint8_t> force_nodir(ne, 0);   // edges whose in-degrees outgrew the direction bytes
     std::vector<uint8_t> full_h(ne, 0);        // edges that run with the score-matrix traceback
     const uint32_t max_indeg = getenv("HX_POA_MAX_INDEG") ? std::min<uint32_t>(16, (uint32_t)atoi(getenv("HX_POA_MAX_INDEG"))) : 16;   // (testing: forces the score-matrix retry earlier)
@@ -548,6 +548,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     const uint32_t cl_max = getenv("HX_POA_CLUSTER_MAX") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MAX")) : 8;          // members per edge at most
     const uint32_t cl_topk = getenv("HX_POA_CLUSTER_TOPK") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_TOPK")) : 96;            // shared edges per call at most (the costliest)
     const uint32_t cl_cols = getenv("HX_POA_CLUSTER_COLS") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_COLS")) : 4;            // columns per lane a member aims at
+    const uint64_t est_pct = getenv("HX_POA_NODE_EST_PCT") ? (uint64_t)std::max(1L, atol(getenv("HX_POA_NODE_EST_PCT"))) : 100;   // (testing: scales the node estimate)
     const long far_rows = getenv("HX_POA_FAR_ROWS") ? atol(getenv("HX_POA_FAR_ROWS")) : -1;   // (testing: rows of H per edge on the first attempt)
     if (cl_lanes != 64 && cl_lanes != 128 && cl_lanes != 256 && cl_lanes != 512 && cl_lanes != 1024) return fail("HX_POA_MEMBER_LANES must be 64, 128, 256, 512 or 1024");
     // lanes per edge. Gaps up to 2047 bases: ONE wavefront per edge (row in registers, no barriers, many edges per CU).
@@ -568,20 +569,24 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
         while (k > 1 && (uint64_t)kClassNT[k] * kMaxCm[k] < ncol) k--;
         return k;
     };
-    auto ring_rows_of = [](uint32_t nt, uint32_t cm, uint64_t& row_bytes) -> uint32_t {   // kept rows the LDS ring of a launch holds
+    auto ring_rows_of = [](uint32_t nt, uint32_t cm, uint64_t& row_bytes) -> uint32_t {   // kept rows the LDS ring holds; row_bytes returns the ring's LDS bytes
         row_bytes = (uint64_t)cm * (nt + 1) * 4;   // planes of nt + 1 words
         const uint64_t lds_budget = nt >= 1024 ? 128 * 1024 : nt == 64 ? 32 * 1024 : 64 * 1024 * (nt / 128 > 2 ? 2 : 1);
-        const uint64_t rows_fit = std::min<uint64_t>(lds_budget * 9 / 8, 140 * 1024) / row_bytes;   // ring slots + 1 scratch slot
-        return rows_fit >= 9 ? 8 : rows_fit >= 5 ? 4 : rows_fit >= 3 ? 2 : 0;   // power of two (slot = kept-row counter & (R-1))
+        const uint64_t rows_fit = std::min<uint64_t>(lds_budget * 9 / 8, 140 * 1024) / row_bytes;   // ring slots (+ 1 scratch slot when there is room)
+        const uint32_t R = rows_fit >= 8 ? 8 : rows_fit >= 4 ? 4 : rows_fit >= 2 ? 2 : 0;   // power of two (slot = kept-row counter & (R-1))
+        row_bytes *= R ? R + (rows_fit > R ? 1 : 0) : 0;                                    // -> LDS bytes of the ring
+        return R;
     };
     auto cm_round = [](uint32_t ncol, uint32_t lanes) -> uint32_t { uint32_t cm = (ncol + lanes - 1) / lanes, r = 4; while (r < cm) r <<= 1; return r; };
     std::vector<uint8_t> far_full(ne, 0);      // edges whose far rows outgrew the estimate
     while (!todo.empty()) {
-        // ---- workspace sizes; estimated graph capacity first, the proven worst case on retry
+        // ---- workspace sizes. Nodes of the finished graph: measured (nodes - L) / (L x sequences) on 13 %-error PacBio-like and 12 %-error
+        // Nanopore-like reads is 0.05-0.06 (median), 0.07-0.08 (99th percentile, small edges). The estimate allows 0.09 plus a fifth of L
+        // and doubles when a graph outgrows it, up to the proven bound (every base a node of its own).
         for (uint32_t e : todo) {
             hxk::PoaEdge& E = P.edges[e];
-            uint64_t est = (uint64_t)E.lmax * (3 + P.nseq[e] / 10) + 1024;
-            uint64_t vc = worst_case ? P.sumL[e] : std::min<uint64_t>(P.sumL[e], est);
+            const uint64_t est = std::max<uint64_t>(1, (((uint64_t)E.lmax * (120 + 9 * (uint64_t)P.nseq[e])) / 100 + 1024) * est_pct / 100) << std::min<uint32_t>(grow[e], 20);
+            const uint64_t vc = std::max<uint64_t>(std::min<uint64_t>(P.sumL[e], est), E.lmax);   // (never below one sequence: per-base scratch shares the node pools)
             if (vc >= 0x7fffffffULL) return fail("hx_poa_batch: POA graph too large");
             // DP cells are keys = 64 x score + 6 tie-break bits in an int32: |score| <= 8 * (nodes + columns) must stay below 2^24
             if (vc + E.lmax + 2 >= (1ull << 21)) return fail("hx_poa_batch: POA graph of an edge exceeds 2^21 nodes + columns (score keys would overflow)");
@@ -615,33 +620,51 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             const uint32_t ncol = E.lmax + 1, nt = E.members > 1 ? cl_lanes : (uint32_t)kClassNT[class_of(e)];
             uint64_t rb;
             const uint32_t Rp = ring_rows_of(nt, cm_round(ncol, E.members > 1 ? E.members * cl_lanes : nt), rb);
-            uint32_t est = far_rows >= 0 ? (uint32_t)far_rows : Rp >= 8 ? E.vcap / 16 + 256 : Rp >= 4 ? E.vcap / 4 + 256 : E.vcap + 1;
-            E.hrows = full_h[e] || far_full[e] || worst_case ? E.vcap + 1 : std::min<uint32_t>(E.vcap + 1, est);
+            // measured on PacBio-like data, rows read back from HBM per DP row: 0.15-0.4 % with 8 ring rows, 3-5 % with 4, 16-25 % on average
+            // with 2 (single edges: up to every kept row, ~60 % of the rows). Graphs fill ~70 % of the node estimate these are fractions of.
+            uint32_t est = far_rows >= 0 ? (uint32_t)far_rows : Rp >= 8 ? E.vcap / 32 + 256 : Rp >= 4 ? E.vcap / 8 + 256 : Rp >= 2 ? E.vcap / 2 + 256 : E.vcap + 1;
+            E.hrows = full_h[e] || far_full[e] ? E.vcap + 1 : std::min<uint32_t>(E.vcap + 1, est);
         }
         // largest first (block scheduling is in grid order): cost ~ rows x columns x sequences
         std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) {
             uint64_t ca = (uint64_t)P.edges[a].vcap * P.edges[a].lmax, cb = (uint64_t)P.edges[b].vcap * P.edges[b].lmax;
             return ca != cb ? ca > cb : a < b;
         });
-        // ---- batches that fit the memory budget
-        size_t pos = 0;
+        // ---- batches that fit the memory budget. When one batch cannot hold everything, the edges are DEALT to the batches in cost order
+        // (batch i takes edges i, i + B, i + 2B, ...): every batch then has its share of the large edges, whose serial dependence sets the
+        // batch's duration, and of the many small ones that keep the other CUs busy meanwhile. (Filling batch after batch in cost order
+        // would put the large edges alone into the first batches.)
+        auto edge_bytes = [&](uint32_t e, uint64_t& nn, uint64_t& dc, uint64_t& hc, uint64_t& cle) -> uint64_t {
+            const hxk::PoaEdge& E = P.edges[e];
+            const uint64_t rw = ((uint64_t)E.lmax + 1 + 31) & ~31ull;                 // rows padded to 32 columns (the widest lane chunk)
+            nn = (uint64_t)E.vcap + 1; dc = full_h[e] ? 0 : nn * rw; hc = (uint64_t)E.hrows * rw;
+            cle = E.members > 1 ? (uint64_t)E.members * nn : 0;
+            return nn * 86 + (uint64_t)E.ecap * 24 + hc * 4 + dc + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8 + cle * 12;
+        };
+        std::vector<std::vector<uint32_t>> batches;
+        {
+            uint64_t total = 0, biggest = 0, a1, a2, a3, a4;
+            for (uint32_t e : todo) { const uint64_t b = edge_bytes(e, a1, a2, a3, a4); total += b; biggest = std::max(biggest, b); }
+            if (biggest > budget) return fail("hx_poa_batch: a single edge needs more POA workspace than the device has free");
+            const size_t forced = getenv("HX_POA_BATCHES") ? (size_t)atol(getenv("HX_POA_BATCHES")) : 0;   // (testing)
+            for (size_t nb = std::max<size_t>(std::max<size_t>(1, forced), (size_t)((total + budget - 1) / budget));; nb++) {
+                nb = std::min(nb, std::max<size_t>(1, todo.size()));
+                batches.assign(nb, {});
+                std::vector<uint64_t> bb(nb, 0);
+                for (size_t i = 0; i < todo.size(); i++) { batches[i % nb].push_back(todo[i]); bb[i % nb] += edge_bytes(todo[i], a1, a2, a3, a4); }
+                if (*std::max_element(bb.begin(), bb.end()) <= budget || nb >= todo.size()) break;
+            }
+        }
         std::vector<uint32_t> retry, retry_same;   // retry with the worst-case workspace / with the score-matrix traceback
-        while (pos < todo.size()) {
+        for (const std::vector<uint32_t>& batch : batches) {
+            if (batch.empty()) continue;
             uint64_t no = 0, eo = 0, ho = 0, dro = 0, so = 0, co = 0, sto = 0, ao = 0, clo = 0, bytes = 0;
-            size_t end = pos;
-            std::vector<uint32_t> batch;
-            while (end < todo.size()) {
-                hxk::PoaEdge& E = P.edges[todo[end]];
-                const uint64_t rw = ((uint64_t)E.lmax + 1 + 31) & ~31ull;                 // rows padded to 32 columns (the widest lane chunk)
-                const uint64_t nn = (uint64_t)E.vcap + 1, dc = full_h[todo[end]] ? 0 : nn * rw, hc = (uint64_t)E.hrows * rw;
-                const uint64_t cle = E.members > 1 ? (uint64_t)E.members * nn : 0;
-                uint64_t b = nn * 86 + (uint64_t)E.ecap * 24 + hc * 4 + dc + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8 + cle * 12;
-                if (!batch.empty() && bytes + b > budget) break;
+            for (uint32_t e : batch) {
+                hxk::PoaEdge& E = P.edges[e];
+                uint64_t nn, dc, hc, cle;
+                bytes += edge_bytes(e, nn, dc, hc, cle);
                 E.node_off = no; E.edge_off = eo; E.h_off = ho; E.d_off = dro; E.seq_off = so; E.cns_off = co; E.stack_off = sto; E.aln_off = ao; E.cl_off = clo;
                 no += nn; eo += E.ecap; ho += hc; dro += dc; so += E.lmax; co += E.vcap; sto += 4 * nn + E.ecap; ao += nn + E.lmax + 2; clo += cle;
-                bytes += b;
-                batch.push_back(todo[end]);
-                end++;
             }
             if (bytes > budget) return fail("hx_poa_batch: a single edge needs more POA workspace than the device has free");
             // Pools grow and never shrink, each to the largest batch it has seen: after batches of different shapes (direction bytes for one,
@@ -729,11 +752,18 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
                 if (cls_list[k].empty()) continue;
                 const int sk = k < 6 ? k : k - 5;   // stream / event of the class
                 const uint32_t nt = k == 0 ? cl_lanes : (uint32_t)kClassNT[k];
-                uint64_t row_bytes;
-                const uint32_t R = ring_rows_of(nt, cls_cm[k], row_bytes);
+                // LDS of the launch: the largest ring any of its edges can use at its own row width (the kernel sizes every edge's ring by what it is given)
+                uint32_t R = 0;
+                uint64_t ring_need = 0;
+                for (uint32_t e : cls_list[k]) {
+                    uint64_t rb;
+                    const uint32_t ncol = P.edges[e].lmax + 1, Re = ring_rows_of(nt, cm_round(ncol, k == 0 ? P.edges[e].members * cl_lanes : nt), rb);
+                    R = std::max(R, Re);
+                    ring_need = std::max(ring_need, rb);
+                }
                 // few edges: ask for enough LDS per workgroup that the dispatcher cannot stack them on a handful of CUs while others idle
                 // (a lone wave runs at twice the speed of two waves sharing a SIMD); many edges: request only what the ring needs
-                uint64_t lds_bytes = (uint64_t)(R ? R + 1 : 0) * row_bytes;   // R ring slots + the scratch slot of rows nobody keeps
+                uint64_t lds_bytes = ring_need;   // ring slots + the scratch slot of rows nobody keeps
                 {
                     const uint64_t per_cu = (order_all.size() + 255) / 256;
                     if (per_cu < 8) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(144 * 1024, (156 * 1024) / per_cu - 6 * 1024));
@@ -760,21 +790,24 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             HIPCHK(hipMemcpy(h_status.data(), d_status.p, (size_t)ne * 4, hipMemcpyDeviceToHost));
             std::vector<char> h_cns(co);
             if (co) HIPCHK(hipMemcpy(h_cns.data(), d_cns.p, co, hipMemcpyDeviceToHost));
+            if (getenv("HX_DEBUG")) {
+                size_t n_far = 0, n_nodir = 0, n_over = 0;
+                for (uint32_t e : batch) { n_far += !!(h_status[e] & HXE_POA_FARROWS); n_nodir += !!(h_status[e] & HXE_POA_NODIR); n_over += !!(h_status[e] & HXE_POA_OVERFLOW); }
+                if (n_far + n_nodir + n_over) fprintf(stderr, "[hx] POA batch: to be redone: %zu (rows read back from HBM outgrew H), %zu (in-degree above the direction bytes' limit), %zu (graph outgrew its workspace)\n", n_far, n_nodir, n_over);
+            }
             for (uint32_t e : batch) {
                 if (h_status[e] & HXE_POA_FARROWS) { if (far_full[e]) return fail("hx_poa_batch: internal error (far-row retry)"); far_full[e] = 1; retry_same.push_back(e); continue; }
                 if (h_status[e] & HXE_POA_NODIR) { if (force_nodir[e]) return fail("hx_poa_batch: internal error (direction-byte retry)"); force_nodir[e] = 1; retry_same.push_back(e); continue; }
                 if (h_status[e] & ~(uint32_t)HXE_POA_OVERFLOW) return fail("hx_poa_batch: internal error (kernel variant / column count mismatch)");
                 if (h_status[e] & HXE_POA_OVERFLOW) {
-                    if (worst_case) return fail("hx_poa_batch: POA workspace overflow at worst-case size (internal error)");
+                    if (P.edges[e].vcap >= P.sumL[e]) return fail("hx_poa_batch: POA workspace overflow at worst-case size (internal error)");
+                    grow[e]++;
                     retry.push_back(e);
                 } else cns[e].assign(h_cns.data() + P.edges[e].cns_off, h_len[e]);
             }
-            pos = end;
         }
         todo.swap(retry);
-        if (!retry_same.empty() && todo.empty()) { todo.swap(retry_same); continue; }   // same workspace estimate, other traceback
         todo.insert(todo.end(), retry_same.begin(), retry_same.end());
-        worst_case = true;
     }
     unsigned long long cells = 0;
     HIPCHK(hipMemcpy(&cells, d_cells.p, 8, hipMemcpyDeviceToHost));
@@ -809,7 +842,7 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
     if (getenv("HX_DEBUG") && ne) {
         const unsigned long long* q = &c->poa_phase[(size_t)c->dbg_slowest * 12];
         fprintf(stderr, "[hx] slowest edge %u: lmax=%u nseq=%u | DP rows %llu (multi-pred %llu, ring refs %llu, far refs %llu, kept %llu) over %llu sequences\n", c->dbg_slowest,
-                c->dbg_lmax[c->dbg_slowest], c->dbg_nseq[c->dbg_slowest], q[6], q[7], q[8], q[9], q[10], q[11]);
+                c->dbg_lmax[c->dbg_slowest], c->dbg_nseq[c->dbg_slowest], q[6], q[7], q[8], q[9], q[10], q[11] & 0xffffffffull);
         {   // the five longest edges (critical-path candidates)
             std::vector<std::pair<unsigned long long, uint32_t>> tt;
             for (size_t e = 0; e < ne; e++) { unsigned long long t = 0; for (int k = 0; k < 6; k++) t += c->poa_phase[e * 12 + k]; tt.push_back({t, (uint32_t)e}); }
@@ -820,13 +853,26 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
                         tt[k].first, q2[1], q2[2], q2[3], q2[4], q2[5], q2[6]);
             }
         }
+        {   // finished graphs against the workspace estimate: nodes per base of the longest sequence, as a + b x sequences
+            std::vector<double> grow, fill;
+            for (size_t e = 0; e < ne; e++) {
+                const double V = (double)(c->poa_phase[e * 12 + 11] >> 32), L = c->dbg_lmax[e], S = c->dbg_nseq[e];
+                if (V <= 0 || L <= 0 || S <= 0) continue;
+                grow.push_back((V - L) / (L * S));
+                fill.push_back(V / (L * (3 + S / 10) + 1024));
+            }
+            std::sort(grow.begin(), grow.end()); std::sort(fill.begin(), fill.end());
+            auto pc = [](const std::vector<double>& v, double q) { return v.empty() ? 0.0 : v[std::min(v.size() - 1, (size_t)(q * v.size()))]; };
+            fprintf(stderr, "[hx] graph growth (nodes - L) / (L x sequences): median %.3f  p90 %.3f  p99 %.3f  max %.3f | nodes / estimate: median %.2f  p99 %.2f  max %.2f\n",
+                    pc(grow, 0.5), pc(grow, 0.9), pc(grow, 0.99), pc(grow, 1.0), pc(fill, 0.5), pc(fill, 0.99), pc(fill, 1.0));
+        }
         {   // per launch class: how often a row is read back from the LDS ring / from HBM
             unsigned long long cr[12][4] = {};
             for (size_t e = 0; e < ne; e++) { const int k = e < c->dbg_cls.size() ? c->dbg_cls[e] : 11; const unsigned long long* q3 = &c->poa_phase[e * 12]; cr[k][0] += q3[6]; cr[k][1] += q3[10]; cr[k][2] += q3[8]; cr[k][3] += q3[9]; }
             for (int k = 0; k < 12; k++) if (cr[k][0]) fprintf(stderr, "[hx] class %d (ring %u): DP rows %llu, kept %.1f %%, ring refs %.1f %%, far refs %.2f %%\n", k, k < 11 ? c->dbg_ring[k] : 0, cr[k][0], 100.0 * cr[k][1] / cr[k][0], 100.0 * cr[k][2] / cr[k][0], 100.0 * cr[k][3] / cr[k][0]);
         }
         unsigned long long tot[6] = {0, 0, 0, 0, 0, 0};
-        for (size_t e = 0; e < ne; e++) for (int k = 0; k < 6; k++) tot[k] += c->poa_phase[e * 12 + 6 + k];
+        for (size_t e = 0; e < ne; e++) for (int k = 0; k < 6; k++) tot[k] += k == 5 ? (c->poa_phase[e * 12 + 11] & 0xffffffffull) : c->poa_phase[e * 12 + 6 + k];
         fprintf(stderr, "[hx] all edges: DP rows %llu (multi-pred %llu, ring refs %llu, far refs %llu, kept %llu) over %llu sequences\n", tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]);
     }
     return (uint32_t)ne;

@@ -486,6 +486,7 @@ struct DpCl {
     uint32_t tag0;                    // tag of row i = tag0 + i (rows of all DPs of the edge numbered consecutively)
     unsigned long long* mbox;         // edge base
     int32_t* farleft;                 // edge base
+    bool ring_scratch;                // the LDS ring has a slot (index R) for the rows nobody keeps
     uint32_t* err;                    // device-visible error word of the edge (set when a poll gives up)
     int32_t* ringleft;                // LDS, 14 words: 64 x H[kept row][first column of the member - 1] per ring slot
 };
@@ -762,7 +763,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             left_prev = base - g64;               // 64 x H[i][j0-1]: the exclusive prefix already is the finished value left of this chunk
 #pragma unroll
             for (int k = 0; k < CM; k++) t[k] = m[k] & ~63;
-            if (R) {   // copy to the LDS ring: a kept row (a later row reads it as a non-adjacent predecessor) takes the next slot, any other row the scratch slot R
+            if (R && (cl.ring_scratch || (meta & 16u))) {   // copy to the LDS ring: a kept row (a later row reads it as a non-adjacent predecessor) takes the next slot, any other row the scratch slot R (if there is one)
                 const uint32_t kept = (meta >> 4) & 1u, slot = kept ? (nkept & (R - 1)) : R;
                 int32_t* S = ring + (size_t)slot * ring_w + tid;
 #pragma unroll
@@ -847,7 +848,17 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     const uint32_t cme = (ED.lmax + 1 + GM * NT - 1) / (GM * NT);
     const uint32_t cmr = cme <= 4 ? 4 : cme <= 8 ? 8 : cme <= 16 ? 16 : 32;
     const uint32_t ring_w = cmr * (NT + 1);   // planes of NT + 1 words (dp_rows)
-    const uint32_t R = ring_rows >= 2 ? ring_rows : 0;
+    // kept rows the LDS ring holds for THIS edge: what fits the launch's LDS at the edge's own row width (a launch serves edges of several
+    // widths; the host sizes the LDS for the widest), a power of two (slot = kept-row counter & (R - 1)), plus the scratch slot
+    // Rows nobody keeps go to a scratch slot so that the copy is unconditional; when the LDS holds exactly a power of two of rows the scratch
+    // slot is given up for twice the ring (wide rows: one branch per row is nothing against a row read back from HBM).
+    uint32_t R = 0;
+    bool ring_scratch = true;
+    if (ring_rows >= 2) {
+        const uint32_t fit = lds_bytes / (ring_w * 4u);
+        R = fit >= 8 ? 8 : fit >= 4 ? 4 : fit >= 2 ? 2 : 0;
+        ring_scratch = fit > R;
+    }
     uint8_t* seq = P.seq + ED.seq_off;
     const uint32_t W = (ED.lmax + 1 + 31) & ~31u;   // row stride: a multiple of the widest lane chunk (32 columns), so chunks are vector-aligned and stay inside their row
 
@@ -866,7 +877,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     int32_t* sinkbuf = P.sinkbuf + (uint64_t)eidx * (1 + 2 * SINK_CAP);
     DpCl cl;
     cl.mem = mem; cl.members = GM; cl.stride = ED.vcap + 1; cl.tag0 = 0;
-    cl.mbox = P.mbox + ED.cl_off; cl.farleft = P.farleft + ED.cl_off; cl.err = csy + 4; cl.ringleft = cl_ringleft;
+    cl.mbox = P.mbox + ED.cl_off; cl.farleft = P.farleft + ED.cl_off; cl.err = csy + 4; cl.ringleft = cl_ringleft; cl.ring_scratch = ring_scratch;
     constexpr uint32_t CL_ABORT = 0xffffffffu;
     auto cm_sel = [&](uint32_t Lq) -> uint32_t {   // columns per lane of the dp_rows instance that handles a sequence of Lq bases
         const uint32_t c = (Lq + 1 + GM * NT - 1) / (GM * NT);
@@ -1155,7 +1166,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
             const uint32_t V0 = sV, E0 = sE, na = sNaln;
             int32_t* anode = reinterpret_cast<int32_t*>(g.stack);   // node aligned to base p, -1 = none (horizontal move)
             uint32_t* eref = g.stack + L;                            // existing edge into base p's node, NONE = append one
-            const bool room = V0 + L <= g.vcap && E0 + L + 1 <= g.ecap;   // worst case: every base a new node / edge
+            const bool room = E0 + L + 1 <= g.ecap && L <= g.vcap;   // edges: worst case (every base a new edge); per-base scratch lives in node pools; nodes are counted exactly below
             if (!room) { if (tid == 0) sOk = 0; }
             else {
                 if (tid == 0) sNcand = 0;
@@ -1186,6 +1197,8 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                     }
                     uint32_t newV;
                     uint32_t nid = V0 + block_excl_scan_add(cnt, lds_u, &newV);
+                    if (V0 + newV > g.vcap) { if (tid == 0) sOk = 0; }   // the graph outgrows its workspace (same verdict on every lane): the host retries with more
+                    else {
                     for (uint32_t p = a0; p < a1; p++) {
                         if (path[p] != NONE) continue;
                         uint32_t vv = nid;
@@ -1222,6 +1235,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                         g.in_tail[t] = e;
                     }
                     if (tid == 0) { sV = V0 + newV; sE = E0 + newE; }
+                    }
                 }
             }
             PHASE(3);
@@ -1402,7 +1416,12 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         else if (!sOk) { status[eidx] = HXE_POA_OVERFLOW; cns_len[eidx] = 0; }
         else if (sOk == 4) { status[eidx] = HXE_POA_NODIR; cns_len[eidx] = 0; }
         else if (sOk == 5) { status[eidx] = HXE_POA_FARROWS; cns_len[eidx] = 0; }
-        else { status[eidx] = 0; cns_len[eidx] = !sV ? 0 : sCtl != NONE ? sCtl : consensus(g, sV, cns + ED.cns_off); atomicAdd(cells, sCells); }
+        else {
+            status[eidx] = 0; cns_len[eidx] = !sV ? 0 : sCtl != NONE ? sCtl : consensus(g, sV, cns + ED.cns_off); atomicAdd(cells, sCells);
+#ifndef HX_DP_PROF
+            if (phase) atomicAdd(&ph[11], (unsigned long long)sV << 32);   // statistics: nodes of the finished graph (high word)
+#endif
+        }
         PHASE(3);
         if (phase) for (int k = 0; k < 12; k++) phase[(uint64_t)eidx * 12 + k] = ph[k];
     }

@@ -352,11 +352,13 @@ def test_in_degree_retry_with_score_matrix(sim, ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("far_rows,shape", [("0", {}), ("1", {}), ("0", {"HX_POA_CLUSTER_MIN": "300", "HX_POA_MEMBER_LANES": "128", "HX_POA_CLUSTER_MAX": "3"}),
-                                            ("2", {"HX_POA_WAVE_MAX": "4096"})])
+                                            ("2", {"HX_POA_WAVE_MAX": "4096"}), ("1", {"HX_POA_BATCHES": "3"}),
+                                            ("-1", {"HX_POA_NODE_EST_PCT": "3"}), ("1", {"HX_POA_NODE_EST_PCT": "20", "HX_POA_BATCHES": "2"})])
 def test_far_row_estimate_overflow_is_retried(sim, ctx, far_rows, shape):
     """with direction bytes H keeps only the rows that a successor reads after they left the LDS ring, in as many rows as the host
     estimated; an edge that needs more comes back and is redone with room for every row. Forced here by an estimate of 0..2 rows
-    (long gaps with deep coverage produce far rows): results and cell counts stay those of the oracle"""
+    (long gaps with deep coverage produce far rows): results and cell counts stay those of the oracle. Likewise the node estimate: a graph
+    that outgrows it (forced by scaling the estimate to 3 % / 20 %) is redone with twice the room until it fits"""
     pre = sim("--genome-len", "150000", "--seed", "34", "--cov", "40", "--gap-median", "2500")
     ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
     prm = ds.params()

@@ -15,7 +15,7 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = hip.HipContext(0)
 os.makedirs('/tmp/fz', exist_ok=True)
 bad = 0
-KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS')
+KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS', 'HX_POA_BATCHES', 'HX_POA_NODE_EST_PCT')
 for it in range(n):
     big = os.environ.get('FUZZ_BIG') is not None   # long gaps at real sizes: the default launch shapes (512-lane cluster members) get real work
     glen = rng.choice([400000, 700000, 1000000]) if big else rng.choice([40000, 60000, 90000, 150000, 250000])
@@ -36,6 +36,10 @@ for it in range(n):
         ctx.set_poa_block(rng.choice([64, 128, 256, 512, 1024]))
     if rng.random() < 0.3:
         env['HX_POA_FAR_ROWS'] = str(rng.choice([0, 1, 4, 16]))
+    if rng.random() < 0.3:
+        env['HX_POA_BATCHES'] = str(rng.choice([2, 3, 7]))
+    if rng.random() < 0.25:
+        env['HX_POA_NODE_EST_PCT'] = str(rng.choice([2, 10, 30, 60]))
     os.environ.update(env)
     ds = host.Dataset('/tmp/fz/s.contigs.fa', '/tmp/fz/s.reads.fa', '/tmp/fz/s.paf')
     pk = dict(min_aln_block=rng.choice([250, 500, 500, 1000]), min_aln_sim=rng.choice([0.8, 0.85, 0.85, 0.9]), min_edge_sup=rng.choice([2, 3, 3, 5]), max_uniq_dev=rng.choice([0.15, 0.15, 0.3]))

@@ -77,6 +77,8 @@ def main():
         rg.consensus(); t4 = time.perf_counter()
         times.append(dict(chain=round(t1 - t0, 3), graph=round(t2 - t1, 3), coords=round(t3 - t2, 3), consensus=round(t4 - t3, 3), hot_path=round(t4 - t0, 3)))
         print("gpu pass", it, times[-1], file=sys.stderr, flush=True)
+        if os.environ.get("HX_DEBUG"):
+            ctx.poa_phase_cycles()                            # (prints the kernel's statistics of the last call)
     t0 = time.perf_counter()
     rg.assemble()
     lap("stitch_and_write_s", t0)
