@@ -487,6 +487,7 @@ extern "C" void hx_free_coords(hx_ctx*, hx_coords_out* o) {
 // ================================================================================================ K6
 
 extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out) {
+    const bool HX_COST_OLD = getenv("HX_COST_OLD") != nullptr;
     const auto dbg_t0 = std::chrono::steady_clock::now();
     memset(out, 0, sizeof(*out));
     if (!c->have_coords) return fail("hx_poa_batch: hx_edge_coords has not run");
@@ -579,6 +580,9 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     };
     auto cm_round = [](uint32_t ncol, uint32_t lanes) -> uint32_t { uint32_t cm = (ncol + lanes - 1) / lanes, r = 4; while (r < cm) r <<= 1; return r; };
     std::vector<uint8_t> far_full(ne, 0);      // edges whose far rows outgrew the estimate
+    // DP work of an edge ~ sum over its sequences of (nodes so far) x (length): with nodes growing linearly that is about half of
+    // (final nodes) x (longest sequence) x (sequences). vcap < 2^21, lmax < 2^16, nseq < 2^24: no overflow
+    auto edge_cost = [&](uint32_t e) -> uint64_t { return HX_COST_OLD ? (uint64_t)P.edges[e].vcap * P.edges[e].lmax : (uint64_t)P.edges[e].vcap * P.edges[e].lmax * std::max<uint32_t>(1, P.nseq[e]); };
     while (!todo.empty()) {
         // ---- workspace sizes. Nodes of the finished graph: measured (nodes - L) / (L x sequences) on 13 %-error PacBio-like and 12 %-error
         // Nanopore-like reads is 0.05-0.06 (median), 0.07-0.08 (99th percentile, small edges). The estimate allows 0.09 plus a fifth of L
@@ -593,12 +597,12 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             E.vcap = (uint32_t)vc; E.ecap = (uint32_t)(P.sumL[e] + P.nseq[e] + 1);
             // rows of H. The score-matrix traceback keeps every row; with direction bytes only rows that a successor reads after they left
             // the LDS ring go to HBM (about 1 row in 1000 on PacBio-like data): a sixteenth of the rows is the estimate, all of them the retry
-            full_h[e] = c->poa_no_dir || force_nodir[e] || P.nseq[e] > 63;   // (in-degree <= #sequences must fit the 6-bit predecessor slot)
+            full_h[e] = c->poa_no_dir || force_nodir[e];   // (any number of sequences: the kernel reports an in-degree the direction bytes cannot hold, see max_indeg)
 
             // long gaps: the DP columns of the edge are shared by several workgroups (one CU each), ~8 columns per lane
             E.members = 1;
             const uint32_t ncol = E.lmax + 1;
-            if (!c->poa_block && !c->poa_no_dir && !force_nodir[e] && P.nseq[e] <= 63 && ncol > cl_min) E.members = (uint32_t)std::min<uint64_t>(cl_max, (ncol + (uint64_t)cl_lanes * cl_cols - 1) / ((uint64_t)cl_lanes * cl_cols));
+            if (!c->poa_block && !c->poa_no_dir && !force_nodir[e] && ncol > cl_min) E.members = (uint32_t)std::min<uint64_t>(cl_max, (ncol + (uint64_t)cl_lanes * cl_cols - 1) / ((uint64_t)cl_lanes * cl_cols));
             if (E.members < 2 || ((uint64_t)ncol + (uint64_t)E.members * cl_lanes - 1) / ((uint64_t)E.members * cl_lanes) > 32) E.members = 1;   // (members too small for this gap: one workgroup)
         }
         // Sharing an edge among several CUs buys latency for the edge and costs throughput (the other members idle while member 0 walks
@@ -608,7 +612,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
             for (uint32_t e : todo) if (P.edges[e].members > 1) sh.push_back(e);
             if (sh.size() > cl_topk) {
                 std::sort(sh.begin(), sh.end(), [&](uint32_t a, uint32_t b) {
-                    uint64_t ca = (uint64_t)P.edges[a].vcap * P.edges[a].lmax, cb = (uint64_t)P.edges[b].vcap * P.edges[b].lmax;
+                    const uint64_t ca = edge_cost(a), cb = edge_cost(b);
                     return ca != cb ? ca > cb : a < b;
                 });
                 for (size_t q = cl_topk; q < sh.size(); q++) P.edges[sh[q]].members = 1;
@@ -627,7 +631,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
         }
         // largest first (block scheduling is in grid order): cost ~ rows x columns x sequences
         std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) {
-            uint64_t ca = (uint64_t)P.edges[a].vcap * P.edges[a].lmax, cb = (uint64_t)P.edges[b].vcap * P.edges[b].lmax;
+            const uint64_t ca = edge_cost(a), cb = edge_cost(b);
             return ca != cb ? ca > cb : a < b;
         });
         // ---- batches that fit the memory budget. When one batch cannot hold everything, the edges are DEALT to the batches in cost order
@@ -710,7 +714,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
                     cls_list[0].push_back(e);
                     continue;
                 }
-                if (ncol > 32768) return fail("hx_poa_batch: a gap longer than 32767 bases needs the shared (cluster) mode: <= 63 sequences, direction-byte traceback, automatic block size");
+                if (ncol > 32768) return fail("hx_poa_batch: a gap longer than 32767 bases needs the shared (cluster) mode: direction-byte traceback, automatic block size");
                 int k = class_of(e);
                 if (full_h[e]) k += 5;
                 cls_list[k].push_back(e);   // batch is cost-sorted, so every class list is too

@@ -616,6 +616,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
         store_chunk_i32<CM>(H + j0, pl);
     }
     uint32_t nkept = 0;                                 // kept rows produced so far (ring slot counter; mirrors the CSR build)
+    const uint32_t copy_if = cl.ring_scratch ? 0xffffffffu : 16u;   // rows copied to the ring: (nearly) all - a row nobody keeps goes to the scratch slot, where it is never read - or the kept rows only
     uint32_t nsink = 0;
     // row records of 64 rows per register, the next batch in flight
     uint32_t mC = 0, aC = 0, bC = 0, oC = 0, mN = 0, aN = 0, bN = 0, oN = 0;
@@ -763,7 +764,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             left_prev = base - g64;               // 64 x H[i][j0-1]: the exclusive prefix already is the finished value left of this chunk
 #pragma unroll
             for (int k = 0; k < CM; k++) t[k] = m[k] & ~63;
-            if (R && (cl.ring_scratch || (meta & 16u))) {   // copy to the LDS ring: a kept row (a later row reads it as a non-adjacent predecessor) takes the next slot, any other row the scratch slot R (if there is one)
+            if (R && (meta & copy_if)) {   // copy to the LDS ring: a kept row (a later row reads it as a non-adjacent predecessor) takes the next slot, any other row the scratch slot R (if there is one)
                 const uint32_t kept = (meta >> 4) & 1u, slot = kept ? (nkept & (R - 1)) : R;
                 int32_t* S = ring + (size_t)slot * ring_w + tid;
 #pragma unroll
