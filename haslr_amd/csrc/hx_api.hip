@@ -487,7 +487,6 @@ extern "C" void hx_free_coords(hx_ctx*, hx_coords_out* o) {
 // ================================================================================================ K6
 
 extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out) {
-    const bool HX_COST_OLD = getenv("HX_COST_OLD") != nullptr;
     const auto dbg_t0 = std::chrono::steady_clock::now();
     memset(out, 0, sizeof(*out));
     if (!c->have_coords) return fail("hx_poa_batch: hx_edge_coords has not run");
@@ -582,7 +581,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     std::vector<uint8_t> far_full(ne, 0);      // edges whose far rows outgrew the estimate
     // DP work of an edge ~ sum over its sequences of (nodes so far) x (length): with nodes growing linearly that is about half of
     // (final nodes) x (longest sequence) x (sequences). vcap < 2^21, lmax < 2^16, nseq < 2^24: no overflow
-    auto edge_cost = [&](uint32_t e) -> uint64_t { return HX_COST_OLD ? (uint64_t)P.edges[e].vcap * P.edges[e].lmax : (uint64_t)P.edges[e].vcap * P.edges[e].lmax * std::max<uint32_t>(1, P.nseq[e]); };
+    auto edge_cost = [&](uint32_t e) -> uint64_t { return (uint64_t)P.edges[e].vcap * P.edges[e].lmax * std::max<uint32_t>(1, P.nseq[e]); };
     while (!todo.empty()) {
         // ---- workspace sizes. Nodes of the finished graph: measured (nodes - L) / (L x sequences) on 13 %-error PacBio-like and 12 %-error
         // Nanopore-like reads is 0.05-0.06 (median), 0.07-0.08 (99th percentile, small edges). The estimate allows 0.09 plus a fifth of L
