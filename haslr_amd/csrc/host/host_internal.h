@@ -13,6 +13,18 @@ namespace hxh {
 
 extern thread_local std::string g_err;
 
+// Allocator for the big arenas (CIGAR op words, packed reads): resize() leaves new elements uninitialised, so growing an arena by
+// gigabytes neither zero-fills it on one thread nor touches its pages before the worker threads write them (first touch in parallel).
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+    template <class U> void construct(U* p) noexcept { ::new ((void*)p) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+using U32Arena = std::vector<uint32_t, NoInitAlloc<uint32_t>>;
+using U8Arena = std::vector<uint8_t, NoInitAlloc<uint8_t>>;
+
 struct Dataset {
     // contigs
     std::vector<uint32_t> contig_len, contig_kc;
@@ -23,13 +35,13 @@ struct Dataset {
     // reads
     std::vector<uint32_t> read_len;
     std::vector<uint64_t> read_off;
-    std::vector<uint8_t> read_packed;
+    U8Arena read_packed;
     uint64_t total_read_bases = 0;
     // raw PAF records
     std::vector<uint32_t> q_id, q_start, q_end, t_id, t_len, t_start, t_end, n_match, n_block;
     std::vector<uint8_t> is_rev, mapq;
     std::vector<uint64_t> cg_off;
-    std::vector<uint32_t> cg_ops;
+    U32Arena cg_ops;
     std::vector<uint64_t> read_hit_off;
     std::unordered_map<uint64_t, std::string> cg_text_odd;   // cg:Z: text of the records whose op words do not spell it (index.longread keeps the text)
 

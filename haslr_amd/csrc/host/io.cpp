@@ -10,6 +10,7 @@
 // sequences, FASTA or FASTQ); this reader implements the same record grammar on zlib's gzread.
 // The filters of load_alignment are NOT applied here: every PAF line becomes a raw record and the
 // predicate runs in the chain kernel.
+#include <chrono>
 #include "host_internal.h"
 
 #include <zlib.h>
@@ -99,16 +100,13 @@ bool read_seq_file(const std::string& path, const std::function<void(const std::
     return true;
 }
 
-inline uint8_t base_code(char c) {
-    switch (c) {
-        case 'C': case 'c': return 1;
-        case 'G': case 'g': return 2;
-        case 'T': case 't': return 3;
-        default: return 0;   // A, a, N and everything else (Compressed_sequence.cpp:10-19 with "& 3")
-    }
-}
+// 2-bit code of a base: C 1, G 2, T 3, and 0 for A, N and everything else (Compressed_sequence.cpp:10-19 with "& 3"). A table, not a
+// switch: the bases are random, so a compare chain mispredicts on every other character (measured: 10 ns per base against < 1 ns)
+struct BaseCodes { uint8_t v[256]; constexpr BaseCodes() : v() { v['C'] = v['c'] = 1; v['G'] = v['g'] = 2; v['T'] = v['t'] = 3; } };
+constexpr BaseCodes kBaseCodes;
+inline uint8_t base_code(char c) { return kBaseCodes.v[(uint8_t)c]; }
 
-void pack_into(std::vector<uint8_t>& dst, std::vector<uint64_t>& off, const std::string& s) {
+template <class Arena> void pack_into(Arena& dst, std::vector<uint64_t>& off, const std::string& s) {
     off.push_back(dst.size());
     size_t nbytes = ((s.size() + 15) / 16) * 4;   // whole dwords: every sequence starts 4-byte aligned
     size_t base = dst.size();
@@ -119,7 +117,7 @@ void pack_into(std::vector<uint8_t>& dst, std::vector<uint64_t>& off, const std:
 // CIGAR text -> op words, parsed like sscanf("%u%c") until it stops matching (Common.cpp:108-121). `odd` is set when the op words do
 // not spell the text again (letters other than M/I/D, zero lengths, leading zeros, trailing garbage): such a record keeps its text,
 // because index.longread stores the cg:Z: string as it was (index_cache.cpp).
-bool parse_cigar_text(const char* p, const char* end, std::vector<uint32_t>& ops, bool& odd, bool& too_long) {
+bool parse_cigar_text(const char* p, const char* end, U32Arena& ops, bool& odd, bool& too_long) {
     odd = false; too_long = false;
     while (p < end) {
         uint64_t len = 0;
@@ -164,6 +162,17 @@ struct Mapped {
     bool gz() const { return n >= 2 && (unsigned char)p[0] == 0x1f && (unsigned char)p[1] == 0x8b; }
 };
 
+struct IoLap {   // HASLR_IO_DEBUG=1: phase times of the parallel loaders on stderr
+    const char* who; bool on; std::chrono::steady_clock::time_point t0;
+    explicit IoLap(const char* w) : who(w), on(getenv("HASLR_IO_DEBUG") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void lap(const char* what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[io] %s: %s %.3f s\n", who, what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 template <class F> void run_parallel(unsigned threads, F&& f) {   // f(thread index)
     std::vector<std::thread> th;
     for (unsigned t = 1; t < threads; t++) th.emplace_back([&f, t]() { f(t); });
@@ -179,7 +188,8 @@ inline size_t next_line_start(const char* p, size_t n, size_t pos) {
 }
 
 struct PafPart {
-    std::vector<uint32_t> q_id, q_start, q_end, t_id, t_len, t_start, t_end, n_match, n_block, cg_ops;
+    std::vector<uint32_t> q_id, q_start, q_end, t_id, t_len, t_start, t_end, n_match, n_block;
+    U32Arena cg_ops;
     std::vector<uint8_t> is_rev, mapq;
     std::vector<uint64_t> cg_off;       // local offsets
     uint64_t lines = 0;                  // lines in this part (for global line numbers)
@@ -239,6 +249,7 @@ int load_paf_parallel(Dataset& d, const std::string& path, unsigned threads) {
     for (unsigned t = 0; t <= threads; t++) cut[t] = t == threads ? m.n : next_line_start(m.p, m.n, m.n / threads * t);
     std::vector<PafPart> parts(threads);
     const size_t n_reads = d.read_len.size(), n_contigs = d.contig_len.size();
+    IoLap lap("paf");
     run_parallel(threads, [&](unsigned t) {
         PafPart& P = parts[t];
         std::vector<std::pair<const char*, const char*>> f;
@@ -257,6 +268,7 @@ int load_paf_parallel(Dataset& d, const std::string& path, unsigned threads) {
             p = nl ? nl + 1 : pe;
         }
     });
+    lap.lap("parse");
     // errors in file order, including the ordering rule across part boundaries
     uint64_t line0 = 0;
     bool have_last = !d.q_id.empty();
@@ -269,12 +281,15 @@ int load_paf_parallel(Dataset& d, const std::string& path, unsigned threads) {
         if (!P.q_id.empty()) { have_last = true; last_q = P.q_id.back(); }
         line0 += P.lines;
     }
+    lap.lap("checks");
     // stitch
     std::vector<size_t> rec0(threads + 1, d.q_id.size()), op0(threads + 1, d.cg_ops.size());
     for (unsigned t = 0; t < threads; t++) { rec0[t + 1] = rec0[t] + parts[t].q_id.size(); op0[t + 1] = op0[t] + parts[t].cg_ops.size(); }
     const size_t nr = rec0[threads], no = op0[threads];
     d.q_id.resize(nr); d.q_start.resize(nr); d.q_end.resize(nr); d.t_id.resize(nr); d.t_len.resize(nr); d.t_start.resize(nr); d.t_end.resize(nr);
     d.n_match.resize(nr); d.n_block.resize(nr); d.is_rev.resize(nr); d.mapq.resize(nr); d.cg_off.resize(nr); d.cg_ops.resize(no);
+    if (lap.on) fprintf(stderr, "[io] paf: %zu records, %zu CIGAR ops\n", nr, no);
+    lap.lap("resize");
     run_parallel(threads, [&](unsigned t) {
         const PafPart& P = parts[t];
         const size_t r = rec0[t], k = P.q_id.size();
@@ -286,6 +301,7 @@ int load_paf_parallel(Dataset& d, const std::string& path, unsigned threads) {
         if (!P.cg_ops.empty()) memcpy(d.cg_ops.data() + op0[t], P.cg_ops.data(), P.cg_ops.size() * 4);
     });
     for (unsigned t = 0; t < threads; t++) for (auto& o : parts[t].odd) d.cg_text_odd[rec0[t] + o.first] = o.second;
+    lap.lap("stitch");
     return 1;
 }
 
@@ -298,6 +314,7 @@ int load_reads_parallel(Dataset& d, const std::string& path, unsigned threads) {
     for (unsigned t = 0; t <= threads; t++) cut[t] = t == threads ? m.n : next_line_start(m.p, m.n, m.n / threads * t);
     std::vector<std::vector<size_t>> starts(threads);
     std::vector<uint8_t> odd(threads, 0);
+    IoLap lap("reads");
     run_parallel(threads, [&](unsigned t) {   // record starts and a scan for anything FASTQ-like
         const char* p = m.p + cut[t];
         const char* pe = m.p + cut[t + 1];
@@ -308,6 +325,7 @@ int load_reads_parallel(Dataset& d, const std::string& path, unsigned threads) {
             p = nl ? nl + 1 : pe;
         }
     });
+    lap.lap("record starts");
     for (unsigned t = 0; t < threads; t++) if (odd[t]) return -1;
     std::vector<size_t> st;
     for (unsigned t = 0; t < threads; t++) st.insert(st.end(), starts[t].begin(), starts[t].end());
@@ -333,17 +351,21 @@ int load_reads_parallel(Dataset& d, const std::string& path, unsigned threads) {
     run_parallel(threads, [&](unsigned t) {
         for (size_t r = nrec * t / threads; r < nrec * (t + 1) / threads; r++) { size_t n = 0; for_seq(r, [&](char) { n++; }); d.read_len[r0 + r] = (uint32_t)n; }
     });
+    lap.lap("lengths");
     size_t base = d.read_packed.size();
     d.read_off.resize(r0 + nrec);
     for (size_t r = 0; r < nrec; r++) { d.read_off[r0 + r] = base; base += (((size_t)d.read_len[r0 + r] + 15) / 16) * 4; d.total_read_bases += d.read_len[r0 + r]; }
-    d.read_packed.resize(base, 0);
+    d.read_packed.resize(base);   // (not initialised: every dword is written below, by the thread that packs its record)
+    lap.lap("offsets");
     run_parallel(threads, [&](unsigned t) {
         for (size_t r = nrec * t / threads; r < nrec * (t + 1) / threads; r++) {
-            uint8_t* dst = d.read_packed.data() + d.read_off[r0 + r];
-            size_t i = 0;
-            for_seq(r, [&](char c) { dst[i >> 2] |= (uint8_t)(base_code(c) << ((i & 3) * 2)); i++; });
+            uint32_t* dst = reinterpret_cast<uint32_t*>(d.read_packed.data() + d.read_off[r0 + r]);   // records start 4-byte aligned and own whole dwords
+            uint32_t w = 0, k = 0;
+            for_seq(r, [&](char c) { w |= (uint32_t)base_code(c) << k; k += 2; if (k == 32) { *dst++ = w; w = 0; k = 0; } });
+            if (k) *dst = w;
         }
     });
+    lap.lap("pack");
     return 1;
 }
 

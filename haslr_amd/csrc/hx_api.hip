@@ -559,7 +559,10 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     constexpr int NCLS = 11;
     static const int kClassNT[NCLS] = {0, 1024, 512, 256, 128, 64, 1024, 512, 256, 128, 64};
     const uint32_t wave_max = getenv("HX_POA_WAVE_MAX") ? (uint32_t)atoi(getenv("HX_POA_WAVE_MAX")) : 512;   // columns handled by ONE wavefront per edge
-    const uint32_t cols_per_lane = getenv("HX_POA_COLS") ? (uint32_t)atoi(getenv("HX_POA_COLS")) : 4;
+    // columns per lane of the multi-wave classes: 4 while edges are few (more lanes = a shorter row for the edges that set the step time),
+    // 16 when thousands of edges keep every CU busy anyway (a row then costs fewer instructions in total: the per-row overhead is per wave).
+    // Measured: 1 846 edges 463 ms with 4 vs 482 ms with 16; 5 570 edges 1 166 vs 1 151 ms; 13 262 edges 4.17 vs 3.97 s.
+    const uint32_t cols_per_lane = getenv("HX_POA_COLS") ? (uint32_t)atoi(getenv("HX_POA_COLS")) : todo.size() > 4096 ? 16 : 4;
     auto class_of = [&](uint32_t e) -> int {   // launch class of an edge that is not shared (members == 1), direction-byte flavour
         static const uint32_t kMaxCm[6] = {0, 8, 16, 32, 32, 32};   // columns per lane each kernel variant keeps in registers
         const uint32_t ncol = P.edges[e].lmax + 1;
