@@ -79,20 +79,36 @@ int graph_remove_weak_edges(Graph& g, uint32_t min_edge_sup) {
     return removed;
 }
 
-void graph_write_gfa(const Graph& g, const Dataset& d, const std::string& path) {
+// the arcs in the order the GFA lists them (vertex ascending, key ascending): all a writer needs, so that the file can be written
+// while the cleaning passes go on changing the graph
+std::vector<std::pair<uint32_t, uint32_t>> graph_arc_list(const Graph& g) {
+    std::vector<std::pair<uint32_t, uint32_t>> arcs;
+    for (uint32_t v = 0; v < g.adj.size(); v++)
+        for (const Arc& a : g.adj[v]) arcs.push_back({v, a.key});
+    return arcs;
+}
+
+void graph_write_gfa_arcs(const std::vector<std::pair<uint32_t, uint32_t>>& arcs, const Dataset& d, const std::string& path) {
     FILE* fp = open_or_null(path, "w");
     if (!fp) return;
+    std::vector<char> iobuf(1 << 22);
+    setvbuf(fp, iobuf.data(), _IOFBF, iobuf.size());
     std::set<uint32_t> to_print;
-    for (uint32_t v = 0; v < g.adj.size(); v++)
-        for (const Arc& a : g.adj[v]) { to_print.insert(v >> 1); to_print.insert(a.key >> 1); }
+    for (const auto& a : arcs) { to_print.insert(a.first >> 1); to_print.insert(a.second >> 1); }
     for (uint32_t id : to_print) {
         std::string s = d.contig_seq(id);
-        fprintf(fp, "S\t%u\t%s\tLN:i:%zu\tKC:i:%u\n", id, s.c_str(), s.size(), d.contig_kc[id]);
+        fprintf(fp, "S\t%u\t", id);
+        fwrite(s.data(), 1, s.size(), fp);
+        fprintf(fp, "\tLN:i:%zu\tKC:i:%u\n", s.size(), d.contig_kc[id]);
     }
-    for (uint32_t v = 0; v < g.adj.size(); v++)
-        for (const Arc& a : g.adj[v])
-            fprintf(fp, "L\t%u\t%c\t%u\t%c\t0M\n", v >> 1, "+-"[v & 1], a.key >> 1, (a.key & 1) ? '-' : '+');
+    for (const auto& a : arcs)
+        fprintf(fp, "L\t%u\t%c\t%u\t%c\t0M\n", a.first >> 1, "+-"[a.first & 1], a.second >> 1, (a.second & 1) ? '-' : '+');
     fclose(fp);
+}
+
+void graph_write_gfa(const Graph& g, const Dataset& d, const std::string& path) {
+    if (path.empty()) return;
+    graph_write_gfa_arcs(graph_arc_list(g), d, path);
 }
 
 void graph_write_stats(const Graph& g, const Dataset& d, const std::string& path) {

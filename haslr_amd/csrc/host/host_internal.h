@@ -102,6 +102,8 @@ void graph_build(Graph& g, uint32_t n_nodes, const hx_edges_out& e);
 int graph_remove_weak_edges(Graph& g, uint32_t min_edge_sup);
 void graph_write_stats(const Graph& g, const Dataset& d, const std::string& path);
 void graph_write_gfa(const Graph& g, const Dataset& d, const std::string& path);
+std::vector<std::pair<uint32_t, uint32_t>> graph_arc_list(const Graph& g);
+void graph_write_gfa_arcs(const std::vector<std::pair<uint32_t, uint32_t>>& arcs, const Dataset& d, const std::string& path);
 void graph_report_branching(const Graph& g, const std::string& path);
 int clean_tips(Graph& g, int max_depth, const std::string& logpath);
 int clean_simple_bubbles(Graph& g, int max_depth, const std::string& logpath);

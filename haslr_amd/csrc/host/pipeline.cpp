@@ -8,6 +8,8 @@
 //   asm_extract_all_simple_paths   Assemble.cpp:757-810
 //   asm_assemble_single_path       Assemble.cpp:624-755  (asm.final.fa / asm.final.ann bytes)
 //   asm_get_assembly               Assemble.cpp:1045-1077
+#include <thread>
+#include <memory>
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -96,8 +98,23 @@ static int run_chain(Run& r) {
     return 0;
 }
 
+// the six GFA snapshots carry every contig sequence (6 x the assembly size of text): each is written by its own thread from a copy of
+// the arc list, while the cleaning passes go on; run_graph returns when all are on disk
+struct GfaWriters {
+    std::vector<std::thread> th;
+    void start(const Run& r, const char* name) {
+        if (r.out_dir.empty()) return;
+        auto arcs = std::make_shared<std::vector<std::pair<uint32_t, uint32_t>>>(graph_arc_list(r.g));
+        const Dataset* d = r.d;
+        const std::string path = r.path(name);
+        th.emplace_back([arcs, d, path]() { graph_write_gfa_arcs(*arcs, *d, path); });
+    }
+    ~GfaWriters() { for (auto& t : th) t.join(); }
+};
+
 static int run_graph(Run& r) {
     double t0 = now();
+    GfaWriters gfa;
     if (r.have_edges) r.be.free_edges(r.be.ctx, &r.edges), r.have_edges = false;
     if (r.be.edge_support(r.be.ctx, &r.prm, &r.edges) != 0) return backend_fail(r, "edge_support");
     r.have_edges = true;
@@ -105,30 +122,32 @@ static int run_graph(Run& r) {
     Graph& g = r.g;
     graph_build(g, (uint32_t)d.contig_len.size(), r.edges);
     graph_write_stats(g, d, r.path("backbone.01.init.stat"));
-    graph_write_gfa(g, d, r.path("backbone.01.init.gfa"));
+    gfa.start(r, "backbone.01.init.gfa");
     int nb = graph_remove_weak_edges(g, r.prm.min_edge_sup);
     if (!r.out_dir.empty()) fprintf(stderr, "       removed %d edges\n", nb);
     graph_write_stats(g, d, r.path("backbone.02.weakEdge.stat"));
-    graph_write_gfa(g, d, r.path("backbone.02.weakEdge.gfa"));
+    gfa.start(r, "backbone.02.weakEdge.gfa");
     nb = clean_tips(g, 1, r.path("backbone.03.tip.log"));
     nb += clean_tips(g, 2, r.path("backbone.03.tip.log"));
     nb += clean_tips(g, 3, r.path("backbone.03.tip.log"));
     if (!r.out_dir.empty()) fprintf(stderr, "       removed %d tips\n", nb);
     graph_write_stats(g, d, r.path("backbone.03.tip.stat"));
-    graph_write_gfa(g, d, r.path("backbone.03.tip.gfa"));
+    gfa.start(r, "backbone.03.tip.gfa");
     nb = clean_simple_bubbles(g, 4, r.path("backbone.04.simplebubble.log"));
     if (!r.out_dir.empty()) fprintf(stderr, "       removed %d simple bubbles\n", nb);
     graph_write_stats(g, d, r.path("backbone.04.simplebubble.stat"));
-    graph_write_gfa(g, d, r.path("backbone.04.simplebubble.gfa"));
+    gfa.start(r, "backbone.04.simplebubble.gfa");
     nb = clean_super_bubbles(g, r.path("backbone.05.superbubble.log"));
     if (!r.out_dir.empty()) fprintf(stderr, "       removed %d super bubbles\n", nb);
     graph_write_stats(g, d, r.path("backbone.05.superbubble.stat"));
-    graph_write_gfa(g, d, r.path("backbone.05.superbubble.gfa"));
+    gfa.start(r, "backbone.05.superbubble.gfa");
     nb = clean_small_bubbles(g, r.path("backbone.06.smallbubble.log"));
     if (!r.out_dir.empty()) fprintf(stderr, "       removed %d small bubbles\n", nb);
     graph_write_stats(g, d, r.path("backbone.06.smallbubble.stat"));
-    graph_write_gfa(g, d, r.path("backbone.06.smallbubble.gfa"));
+    gfa.start(r, "backbone.06.smallbubble.gfa");
     graph_report_branching(g, r.path("backbone.branching.log"));
+    for (auto& t : gfa.th) t.join();
+    gfa.th.clear();
     r.t[1] = now() - t0;
     return 0;
 }
