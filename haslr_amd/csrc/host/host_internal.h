@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -24,6 +25,14 @@ template <class T> struct NoInitAlloc : std::allocator<T> {
 };
 using U32Arena = std::vector<uint32_t, NoInitAlloc<uint32_t>>;
 using U8Arena = std::vector<uint8_t, NoInitAlloc<uint8_t>>;
+
+extern unsigned g_io_threads;   // threads of the loaders and the index writers (set by load_dataset: -t / HASLR_IO_THREADS / up to 16)
+template <class F> void run_parallel(unsigned threads, F&& f) {   // f(thread index) on `threads` threads, the caller being one of them
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < threads; t++) th.emplace_back([&f, t]() { f(t); });
+    f(0);
+    for (auto& x : th) x.join();
+}
 
 struct Dataset {
     // contigs
@@ -60,6 +69,7 @@ Dataset* load_dataset_cached(const char* index_dir, const char* contig_path, con
 void finish_contigs(Dataset& d);
 bool append_cigar(Dataset& d, const char* b, const char* e);
 std::string cigar_text(const Dataset& d, uint64_t rec);
+void append_cigar_text(const Dataset& d, uint64_t rec, std::string& out);
 bool write_contig_index(const Dataset& d, const std::string& path);
 bool write_longread_index(const Dataset& d, const hx_chain_out& chain, const std::string& path);
 bool read_contig_index(Dataset& d, const std::string& path);

@@ -30,15 +30,15 @@ inline uint32_t comp_len_of(uint32_t len) { return len / 4 + (len % 4 ? 1 : 0); 
 
 // own layout (base i at bits 2*(i%4) of byte i/4) -> reference layout
 void to_ref_codec(const uint8_t* mine, uint32_t len, uint8_t* dst) {
-    const uint32_t cl = comp_len_of(len), r = len % 4;
-    memset(dst, 0, cl);
-    for (uint32_t p = 0; p < len; p++) {
-        const uint8_t c = (mine[p >> 2] >> ((p & 3) * 2)) & 3;
-        uint32_t byte, sh;
-        if (p < r) { byte = cl - 1; sh = 2 * p; }
-        else { const uint32_t q = (p - r) / 4, j = (p - r) % 4; byte = cl - 1 - (r ? 1 : 0) - q; sh = 2 * j; }
-        dst[byte] |= (uint8_t)(c << sh);
-    }
+    // The reference's last byte holds the first len % 4 bases, the bytes before it (going backwards) the following groups of four, each
+    // with its first base in the low bits. Our arena is the plain little-endian 2-bit stream, so a group of four starting at base p is
+    // the 8 bits at bit 2p of the stream: one (unaligned) byte per output byte.
+    const uint32_t cl = comp_len_of(len), r = len % 4, sh = r * 2;
+    if (r) dst[cl - 1] = (uint8_t)(mine[0] & ((1u << sh) - 1));
+    uint8_t* out = dst + cl - 1 - (r ? 1 : 0);
+    const uint32_t groups = len / 4;
+    if (!sh) for (uint32_t g = 0; g < groups; g++) *out-- = mine[g];
+    else for (uint32_t g = 0; g < groups; g++) *out-- = (uint8_t)((mine[g] | ((uint32_t)mine[g + 1] << 8)) >> sh);
 }
 void from_ref_codec(const uint8_t* src, uint32_t len, uint8_t* mine /* zeroed, ((len+15)/16)*4 bytes */) {
     const uint32_t cl = comp_len_of(len), r = len % 4;
@@ -64,15 +64,25 @@ uint32_t get32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 
 }  // namespace
 
-std::string cigar_text(const Dataset& d, uint64_t rec) {
-    auto it = d.cg_text_odd.find(rec);
-    if (it != d.cg_text_odd.end()) return it->second;
-    std::string s;
+void append_cigar_text(const Dataset& d, uint64_t rec, std::string& s) {
+    if (!d.cg_text_odd.empty()) {
+        auto it = d.cg_text_odd.find(rec);
+        if (it != d.cg_text_odd.end()) { s += it->second; return; }
+    }
+    char buf[12];
     for (uint64_t k = d.cg_off[rec]; k < d.cg_off[rec + 1]; k++) {
         const uint32_t w = d.cg_ops[k];
-        s += std::to_string(HX_CG_LEN(w));
+        uint32_t v = HX_CG_LEN(w);
+        int n = 0;
+        do { buf[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+        while (n) s.push_back(buf[--n]);
         s.push_back("MID?"[w & 3u]);   // '?' never reaches a file: records with other letters keep their text in cg_text_odd
     }
+}
+
+std::string cigar_text(const Dataset& d, uint64_t rec) {
+    std::string s;
+    append_cigar_text(d, rec, s);
     return s;
 }
 
@@ -108,26 +118,38 @@ bool write_longread_index(const Dataset& d, const hx_chain_out& ch, const std::s
         put32(p + 24, (uint32_t)(ch.read_off[i + 1] - ch.read_off[i]));
         seqs += comp_len_of(d.read_len[i]);
     }
-    std::vector<uint8_t> sq(seqs);
-    uint64_t off = 0;
-    for (uint64_t i = 0; i < n; i++) { to_ref_codec(d.read_packed.data() + d.read_off[i], d.read_len[i], sq.data() + off); off += comp_len_of(d.read_len[i]); }
+    // both big blocks are independent per record: the reference codec of every read and the cg:Z: text of every kept alignment are made
+    // by the ingest threads (reads / alignments dealt in contiguous ranges), the texts are joined in alignment order afterwards
+    const unsigned T = std::max(1u, g_io_threads);
+    U8Arena sq;
+    sq.resize(seqs);
+    std::vector<uint64_t> sq_off(n + 1, 0);
+    for (uint64_t i = 0; i < n; i++) sq_off[i + 1] = sq_off[i] + comp_len_of(d.read_len[i]);
+    run_parallel(T, [&](unsigned t) {
+        for (uint64_t i = n * t / T; i < n * (t + 1) / T; i++) to_ref_codec(d.read_packed.data() + d.read_off[i], d.read_len[i], sq.data() + sq_off[i]);
+    });
     const uint64_t na = ch.n_aln;
     std::vector<uint8_t> al(na * 48, 0);
-    std::string cigars;
-    for (uint64_t a = 0; a < na; a++) {
-        const uint32_t h = ch.hit[a];
-        uint8_t* p = al.data() + a * 48;
-        put32(p, d.q_id[h]); put32(p + 4, d.q_start[h]); put32(p + 8, d.q_end[h]); put32(p + 12, d.t_id[h]);
-        put32(p + 16, d.t_start[h]); put32(p + 20, d.t_end[h]); put32(p + 24, d.n_match[h]); put32(p + 28, d.n_block[h]);
-        p[32] = d.is_rev[h]; p[33] = d.mapq[h]; p[34] = 0;
-        const std::string cg = cigar_text(d, h);
-        put32(p + 36, (uint32_t)cg.size());
-        cigars += cg;
-        cigars.push_back('\0');
-    }
-    const uint64_t cs = cigars.size();
-    if (!f.w(&n, 8) || !f.w(recs.data(), recs.size()) || !f.w(&seqs, 8) || !f.w(sq.data(), sq.size()) || !f.w(&na, 8) || !f.w(al.data(), al.size()) ||
-        !f.w(&cs, 8) || !f.w(cigars.data(), cs)) { g_err = "[ERROR] could not write " + path; return false; }
+    std::vector<std::string> part(T);
+    run_parallel(T, [&](unsigned t) {
+        std::string& out = part[t];
+        for (uint64_t a = na * t / T; a < na * (t + 1) / T; a++) {
+            const uint32_t h = ch.hit[a];
+            uint8_t* p = al.data() + a * 48;
+            put32(p, d.q_id[h]); put32(p + 4, d.q_start[h]); put32(p + 8, d.q_end[h]); put32(p + 12, d.t_id[h]);
+            put32(p + 16, d.t_start[h]); put32(p + 20, d.t_end[h]); put32(p + 24, d.n_match[h]); put32(p + 28, d.n_block[h]);
+            p[32] = d.is_rev[h]; p[33] = d.mapq[h]; p[34] = 0;
+            const size_t before = out.size();
+            append_cigar_text(d, h, out);
+            put32(p + 36, (uint32_t)(out.size() - before));
+            out.push_back('\0');
+        }
+    });
+    uint64_t cs = 0;
+    for (const std::string& x : part) cs += x.size();
+    bool ok = f.w(&n, 8) && f.w(recs.data(), recs.size()) && f.w(&seqs, 8) && f.w(sq.data(), sq.size()) && f.w(&na, 8) && f.w(al.data(), al.size()) && f.w(&cs, 8);
+    for (const std::string& x : part) ok = ok && (x.empty() || f.w(x.data(), x.size()));
+    if (!ok) { g_err = "[ERROR] could not write " + path; return false; }
     return true;
 }
 

@@ -173,13 +173,6 @@ struct IoLap {   // HASLR_IO_DEBUG=1: phase times of the parallel loaders on std
     }
 };
 
-template <class F> void run_parallel(unsigned threads, F&& f) {   // f(thread index)
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < threads; t++) th.emplace_back([&f, t]() { f(t); });
-    f(0);
-    for (auto& x : th) x.join();
-}
-
 // start of the line that contains or follows position `pos` ... i.e. first line start >= pos
 inline size_t next_line_start(const char* p, size_t n, size_t pos) {
     if (pos == 0) return 0;

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--no-oracle", action="store_true", help="skip the CPU oracle run (parity fields are null)")
     ap.add_argument("--no-identity", action="store_true", help="skip the placement of the assembly on the truth genome")
     ap.add_argument("--passes", type=int, default=2)
+    ap.add_argument("--cli", action="store_true", help="also run the haslr_assemble binary on the same files (wall time, same assembly)")
     ap.add_argument("--tmp", default="/tmp/full_size")
     a = ap.parse_args()
     cfg = dict(PRESETS[a.preset]) if a.preset else dict(genome_len=a.genome_len, model=a.model, cov=a.cov)
@@ -110,6 +111,15 @@ def main():
     else:
         res["parity"] = None
     rg.close(); ds.close()
+    if a.cli:
+        cli_out = os.path.join(a.tmp, name + ".cli")
+        subprocess.call(["rm", "-rf", cli_out])
+        t0 = time.perf_counter()
+        pr = subprocess.run([os.path.join(ROOT, "haslr_amd", "bin", "haslr_assemble"), "-t", str(min(32, os.cpu_count() or 1)), "-c", pre + ".contigs.fa", "-l", pre + ".reads.fa",
+                             "-m", pre + ".paf", "-d", cli_out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        lap("cli_wall_s", t0)
+        res["cli"] = {"rc": pr.returncode, "same_assembly": pr.returncode == 0 and open(os.path.join(cli_out, "asm.final.fa")).read() == asm,
+                      "stderr_tail": pr.stderr[-1500:]}
     line = json.dumps(res)
     print(line)
     god = os.path.join(ROOT, "gpurun_out")
