@@ -554,7 +554,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     // lanes per edge. Gaps up to 2047 bases: ONE wavefront per edge (row in registers, no barriers, many edges per CU).
     // Longer gaps: a multi-wave workgroup with ~8 columns per lane (256..1024 lanes). One launch per class, classes run concurrently.
     // Class 0 = edges shared by several workgroups (cluster members of cl_lanes lanes); classes 1..5 = one workgroup per edge.
-    // Classes 6..10 = classes 1..5 for the edges that need the score-matrix traceback (rare: more than 63 sequences, an in-degree
+    // Classes 6..10 = classes 1..5 for the edges that need the score-matrix traceback (rare: an in-degree
     // the direction bytes cannot hold, or the test switch), launched after their direction-byte twins on the same streams.
     constexpr int NCLS = 11;
     static const int kClassNT[NCLS] = {0, 1024, 512, 256, 128, 64, 1024, 512, 256, 128, 64};

@@ -74,7 +74,7 @@ uint32_t hx_poa_phase_cycles(hx_ctx*, uint64_t* sum6, uint64_t* max6);
 /* POA work-group size: 0 = automatic (64..256 lanes per edge, ~8 DP columns per lane; gaps > 2047 columns are shared by several
  * work-groups), or force one work-group of 64/128/256/512/1024 lanes per edge (gaps up to 32767 bases) */
 void hx_set_poa_block(hx_ctx*, int threads);
-/* traceback source: 1 (default) = 1-byte direction codes written by the DP (edges with <= 63 sequences), 0 = always re-derive the
+/* traceback source: 1 (default) = 1-byte direction codes written by the DP (an edge with a node of more than 16 in-edges is redone with 0), 0 = always re-derive the
  * moves from the int32 score matrix like the reference engine does (diagnostics / A-B comparison; results are identical) */
 void hx_set_poa_traceback(hx_ctx*, int use_direction_bytes);
 

@@ -1,8 +1,10 @@
 // hxident — length-weighted identity of assembled contigs against a truth genome (test/bench tool).
-// For every query record: locate it on the genome (either strand) by exact 24-mer seeds, then a banded
+// For every query record: choose the strand by a vote of exact 24-mer seeds of both orientations, place 20 kb windows by seed clusters, then a banded
 // global edit distance of the query against the implied genome window. Prints one line per record and a
 // summary `identity <weighted> aligned_bases <n> records <k> unplaced <u>`.
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -54,59 +56,90 @@ static long banded_ed(const std::string& q, const std::string& t, long B) {
     return best;
 }
 
+// identity of one record on one strand; hits = windows that found a placement
+struct StrandResult { long ed = 0, len = 0, bad = 0; };
+static StrandResult eval_strand(const std::string& q, const std::string& G, const std::unordered_map<std::string, long>& idx, int K, long B) {
+    StrandResult r;
+    const long WIN = 20000;
+    // windows are placed independently (seeded inside the window), so cumulative indel drift never leaves the band
+    for (long w0 = 0; w0 < (long)q.size(); w0 += WIN) {
+        long wl = std::min<long>(WIN, (long)q.size() - w0);
+        std::string win = q.substr(w0, wl);
+        // offset by majority vote of seeds spread over the window (a single seed may sit in a repeat copy or straddle an error)
+        std::vector<long> offs;
+        for (long i = 0; i + K <= wl; i += 31) {
+            auto it = idx.find(win.substr(i, K));
+            if (it != idx.end()) offs.push_back(it->second - i);
+        }
+        long off = -1000000000L;
+        if (!offs.empty()) {
+            std::sort(offs.begin(), offs.end());
+            size_t bi = 0, bc = 0;
+            for (size_t a2 = 0, b2 = 0; a2 < offs.size(); a2++) {       // densest cluster within +-150
+                while (b2 < offs.size() && offs[b2] - offs[a2] <= 300) b2++;
+                if (b2 - a2 > bc) { bc = b2 - a2; bi = a2; }
+            }
+            off = offs[bi];   // smallest offset of the cluster = alignment of the window start (insertions only push later seeds right)
+        }
+        if (off < -1000000 || wl < K) { r.bad++; r.ed += wl; r.len += wl; continue; }
+        long st = std::max(0L, off - 200);
+        std::string t = G.substr(st, std::min<long>((long)G.size() - st, wl + 400 + B / 2));
+        long ed = banded_ed(win, t, B);
+        r.ed += std::min(ed, wl); r.len += wl;
+    }
+    return r;
+}
+
 int main(int argc, char** argv) {
-    if (argc < 3) { fprintf(stderr, "usage: hxident genome.fa asm.fa [band]\n"); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: hxident genome.fa asm.fa [band [threads]]\n"); return 2; }
     auto g = read_fa(argv[1]);
     auto qs = read_fa(argv[2]);
     long B = argc > 3 ? atol(argv[3]) : 400;
+    unsigned T = argc > 4 ? (unsigned)atoi(argv[4]) : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
     if (g.empty()) return 2;
     const std::string& G = g[0].second;
     const int K = 24;
     std::unordered_map<std::string, long> idx;
     for (long i = 0; i + K <= (long)G.size(); i += 7) idx.emplace(G.substr(i, K), i);
+    // records are independent: dealt to threads, reported in file order
+    struct Out { std::string line; double ident = 0; long len = 0; bool placed = false; };
+    std::vector<Out> out(qs.size());
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= qs.size()) return;
+            const auto& rec = qs[k];
+            // strand: seeds of both orientations vote (a single seed may hit an inverted repeat); without any hit the record is unplaced
+            const std::string r = rc(rec.second);
+            long votes[2] = {0, 0};
+            for (int s2 = 0; s2 < 2; s2++) {
+                const std::string& q = s2 == 0 ? rec.second : r;
+                const long lim = std::min<long>((long)q.size(), 200000);
+                for (long i = 0; i + K <= lim; i += 13) votes[s2] += idx.count(q.substr(i, K));
+            }
+            char buf[256];
+            if (!votes[0] && !votes[1]) { snprintf(buf, sizeof buf, "%s\tlen=%zu\tUNPLACED\n", rec.first.c_str(), rec.second.size()); out[k].line = buf; continue; }
+            int strand = votes[1] > votes[0] ? 1 : 0;
+            StrandResult sr = eval_strand(strand ? r : rec.second, G, idx, K, B);
+            if (sr.len && (double)sr.ed / (double)sr.len > 0.5) {   // a vote decided by repeats: the other strand may be the real one
+                StrandResult o = eval_strand(strand ? rec.second : r, G, idx, K, B);
+                if (o.ed < sr.ed) { sr = o; strand ^= 1; }
+            }
+            const double ident = 1.0 - (double)sr.ed / (double)sr.len;
+            snprintf(buf, sizeof buf, "%s\tlen=%zu\t%c\ted=%ld\tunplaced_windows=%ld\tidentity=%.6f\n", rec.first.c_str(), rec.second.size(), strand ? '-' : '+', sr.ed, sr.bad, ident);
+            out[k].line = buf; out[k].ident = ident; out[k].len = sr.len; out[k].placed = true;
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; t++) th.emplace_back(worker);
+    worker();
+    for (auto& x : th) x.join();
     double wsum = 0; long wlen = 0; int unplaced = 0;
-    const long WIN = 20000;
-    for (auto& rec : qs) {
-        // strand: the one whose first placeable window hits
-        std::string r = rc(rec.second);
-        long total_ed = 0, total_len = 0, bad_win = 0;
-        int strand = -1;
-        for (int s2 = 0; s2 < 2 && strand < 0; s2++) {
-            const std::string& q = s2 == 0 ? rec.second : r;
-            for (long i = 0; i + K <= (long)q.size() && i < 50000; i++)
-                if (idx.count(q.substr(i, K))) { strand = s2; break; }
-        }
-        if (strand < 0) { unplaced++; printf("%s\tlen=%zu\tUNPLACED\n", rec.first.c_str(), rec.second.size()); continue; }
-        const std::string& q = strand == 0 ? rec.second : r;
-        // windows are placed independently (seeded inside the window), so cumulative indel drift never leaves the band
-        for (long w0 = 0; w0 < (long)q.size(); w0 += WIN) {
-            long wl = std::min<long>(WIN, (long)q.size() - w0);
-            std::string win = q.substr(w0, wl);
-            // offset by majority vote of seeds spread over the window (a single seed may sit in a repeat copy or straddle an error)
-            std::vector<long> offs;
-            for (long i = 0; i + K <= wl; i += 31) {
-                auto it = idx.find(win.substr(i, K));
-                if (it != idx.end()) offs.push_back(it->second - i);
-            }
-            long off = -1000000000L;
-            if (!offs.empty()) {
-                std::sort(offs.begin(), offs.end());
-                size_t bi = 0, bc = 0;
-                for (size_t a2 = 0, b2 = 0; a2 < offs.size(); a2++) {       // densest cluster within +-150
-                    while (b2 < offs.size() && offs[b2] - offs[a2] <= 300) b2++;
-                    if (b2 - a2 > bc) { bc = b2 - a2; bi = a2; }
-                }
-                off = offs[bi];   // smallest offset of the cluster = alignment of the window start (insertions only push later seeds right)
-            }
-            if (off < -1000000 || wl < K) { bad_win++; total_ed += wl; total_len += wl; continue; }
-            long st = std::max(0L, off - 200);
-            std::string t = G.substr(st, std::min<long>((long)G.size() - st, wl + 400 + B / 2));
-            long ed = banded_ed(win, t, B);
-            total_ed += std::min(ed, wl); total_len += wl;
-        }
-        double ident = 1.0 - (double)total_ed / (double)total_len;
-        printf("%s\tlen=%zu\t%c\ted=%ld\tunplaced_windows=%ld\tidentity=%.6f\n", rec.first.c_str(), rec.second.size(), strand ? '-' : '+', total_ed, bad_win, ident);
-        wsum += ident * total_len; wlen += total_len;
+    for (const Out& o : out) {
+        fputs(o.line.c_str(), stdout);
+        if (!o.placed) { unplaced++; continue; }
+        wsum += o.ident * o.len; wlen += o.len;
     }
     printf("identity %.6f aligned_bases %ld records %zu unplaced %d\n", wlen ? wsum / wlen : 0.0, wlen, qs.size(), unplaced);
     return 0;
