@@ -68,6 +68,7 @@ Dataset* load_dataset_cached(const char* index_dir, const char* contig_path, con
                              unsigned threads, int* used_contig_index, int* used_longread_index);
 void finish_contigs(Dataset& d);
 bool append_cigar(Dataset& d, const char* b, const char* e);
+bool parse_cigar_ops(const char* b, const char* e, U32Arena& ops, bool& odd, bool& too_long);   // cg:Z: text -> op words (io.cpp)
 std::string cigar_text(const Dataset& d, uint64_t rec);
 void append_cigar_text(const Dataset& d, uint64_t rec, std::string& out);
 bool write_contig_index(const Dataset& d, const std::string& path);

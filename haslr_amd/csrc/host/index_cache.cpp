@@ -40,15 +40,21 @@ void to_ref_codec(const uint8_t* mine, uint32_t len, uint8_t* dst) {
     if (!sh) for (uint32_t g = 0; g < groups; g++) *out-- = mine[g];
     else for (uint32_t g = 0; g < groups; g++) *out-- = (uint8_t)((mine[g] | ((uint32_t)mine[g + 1] << 8)) >> sh);
 }
-void from_ref_codec(const uint8_t* src, uint32_t len, uint8_t* mine /* zeroed, ((len+15)/16)*4 bytes */) {
-    const uint32_t cl = comp_len_of(len), r = len % 4;
-    for (uint32_t p = 0; p < len; p++) {
-        uint32_t byte, sh;
-        if (p < r) { byte = cl - 1; sh = 2 * p; }
-        else { const uint32_t q = (p - r) / 4, j = (p - r) % 4; byte = cl - 1 - (r ? 1 : 0) - q; sh = 2 * j; }
-        const uint8_t c = (src[byte] >> sh) & 3;
-        mine[p >> 2] |= (uint8_t)(c << ((p & 3) * 2));
+void from_ref_codec(const uint8_t* src, uint32_t len, uint8_t* mine /* ((len+15)/16)*4 bytes, all of them written */) {
+    // inverse of to_ref_codec: the first len % 4 bases come from the last byte, then one group of four per byte going backwards; the
+    // groups are appended to the little-endian 2-bit stream through a small bit accumulator
+    const uint32_t cl = comp_len_of(len), r = len % 4, groups = len / 4;
+    const size_t nbytes = (((size_t)len + 15) / 16) * 4;
+    uint32_t acc = r ? (uint32_t)(src[cl - 1] & ((1u << (2 * r)) - 1)) : 0, nb = 2 * r;
+    const uint8_t* in = src + cl - 1 - (r ? 1 : 0);
+    size_t o = 0;
+    for (uint32_t g = 0; g < groups; g++) {
+        acc |= (uint32_t)(*in--) << nb;
+        mine[o++] = (uint8_t)acc;
+        acc >>= 8;
     }
+    if (nb) mine[o++] = (uint8_t)acc;
+    while (o < nbytes) mine[o++] = 0;
 }
 
 struct File {
@@ -118,37 +124,63 @@ bool write_longread_index(const Dataset& d, const hx_chain_out& ch, const std::s
         put32(p + 24, (uint32_t)(ch.read_off[i + 1] - ch.read_off[i]));
         seqs += comp_len_of(d.read_len[i]);
     }
-    // both big blocks are independent per record: the reference codec of every read and the cg:Z: text of every kept alignment are made
-    // by the ingest threads (reads / alignments dealt in contiguous ranges), the texts are joined in alignment order afterwards
-    const unsigned T = std::max(1u, g_io_threads);
-    U8Arena sq;
-    sq.resize(seqs);
-    std::vector<uint64_t> sq_off(n + 1, 0);
-    for (uint64_t i = 0; i < n; i++) sq_off[i + 1] = sq_off[i] + comp_len_of(d.read_len[i]);
-    run_parallel(T, [&](unsigned t) {
-        for (uint64_t i = n * t / T; i < n * (t + 1) / T; i++) to_ref_codec(d.read_packed.data() + d.read_off[i], d.read_len[i], sq.data() + sq_off[i]);
-    });
+    // The two big blocks (every read re-coded, every kept CIGAR spelled out: gigabytes at full size) are produced and written in CHUNKS
+    // of a few dozen megabytes through buffers that are reused: the CLI runs this beside the GPU stages, and gigabytes of freshly
+    // faulted-in host memory there slowed the device allocations of the consensus stage by seconds. Within a chunk the records are
+    // dealt to a few threads. The alignment records carry the length of their text, so the lengths are counted first.
+    const unsigned T = std::max(1u, std::min(g_io_threads, 8u));
     const uint64_t na = ch.n_aln;
     std::vector<uint8_t> al(na * 48, 0);
-    std::vector<std::string> part(T);
+    std::vector<uint64_t> cgl_part(T, 0);
     run_parallel(T, [&](unsigned t) {
-        std::string& out = part[t];
         for (uint64_t a = na * t / T; a < na * (t + 1) / T; a++) {
             const uint32_t h = ch.hit[a];
             uint8_t* p = al.data() + a * 48;
             put32(p, d.q_id[h]); put32(p + 4, d.q_start[h]); put32(p + 8, d.q_end[h]); put32(p + 12, d.t_id[h]);
             put32(p + 16, d.t_start[h]); put32(p + 20, d.t_end[h]); put32(p + 24, d.n_match[h]); put32(p + 28, d.n_block[h]);
             p[32] = d.is_rev[h]; p[33] = d.mapq[h]; p[34] = 0;
-            const size_t before = out.size();
-            append_cigar_text(d, h, out);
-            put32(p + 36, (uint32_t)(out.size() - before));
-            out.push_back('\0');
+            uint64_t len = 0;
+            auto it = d.cg_text_odd.empty() ? d.cg_text_odd.end() : d.cg_text_odd.find(h);
+            if (it != d.cg_text_odd.end()) len = it->second.size();
+            else for (uint64_t k = d.cg_off[h]; k < d.cg_off[h + 1]; k++) { const uint32_t v = HX_CG_LEN(d.cg_ops[k]); len += 2 + (v >= 10) + (v >= 100) + (v >= 1000) + (v >= 10000) + (v >= 100000) + (v >= 1000000) + (v >= 10000000) + (v >= 100000000) + (v >= 1000000000); }
+            put32(p + 36, (uint32_t)len);
+            cgl_part[t] += len + 1;
         }
     });
     uint64_t cs = 0;
-    for (const std::string& x : part) cs += x.size();
-    bool ok = f.w(&n, 8) && f.w(recs.data(), recs.size()) && f.w(&seqs, 8) && f.w(sq.data(), sq.size()) && f.w(&na, 8) && f.w(al.data(), al.size()) && f.w(&cs, 8);
-    for (const std::string& x : part) ok = ok && (x.empty() || f.w(x.data(), x.size()));
+    for (uint64_t x : cgl_part) cs += x;
+    bool ok = f.w(&n, 8) && f.w(recs.data(), recs.size()) && f.w(&seqs, 8);
+    {   // sequences
+        const uint64_t CHUNK = 48ull << 20;
+        U8Arena buf;
+        std::vector<uint64_t> off;
+        for (uint64_t i0 = 0; ok && i0 < n;) {
+            uint64_t i1 = i0, bytes = 0;
+            off.clear();
+            while (i1 < n && (bytes < CHUNK || i1 == i0)) { off.push_back(bytes); bytes += comp_len_of(d.read_len[i1]); i1++; }
+            if (buf.size() < bytes) buf.resize(bytes);
+            const uint64_t m = i1 - i0;
+            run_parallel(T, [&](unsigned t) {
+                for (uint64_t k = m * t / T; k < m * (t + 1) / T; k++) to_ref_codec(d.read_packed.data() + d.read_off[i0 + k], d.read_len[i0 + k], buf.data() + off[k]);
+            });
+            ok = f.w(buf.data(), bytes);
+            i0 = i1;
+        }
+    }
+    ok = ok && f.w(&na, 8) && f.w(al.data(), al.size()) && f.w(&cs, 8);
+    {   // CIGAR texts, each followed by a NUL
+        const uint64_t PER = 16384;   // alignments per chunk
+        std::vector<std::string> part(T);
+        for (uint64_t a0 = 0; ok && a0 < na; a0 += PER) {
+            const uint64_t m = std::min<uint64_t>(PER, na - a0);
+            run_parallel(T, [&](unsigned t) {
+                std::string& out = part[t];
+                out.clear();
+                for (uint64_t k = m * t / T; k < m * (t + 1) / T; k++) { append_cigar_text(d, ch.hit[a0 + k], out); out.push_back('\0'); }
+            });
+            for (const std::string& x : part) ok = ok && (x.empty() || f.w(x.data(), x.size()));
+        }
+    }
     if (!ok) { g_err = "[ERROR] could not write " + path; return false; }
     return true;
 }
@@ -194,34 +226,68 @@ bool read_longread_index(Dataset& d, const std::string& path) {
     if (!f.r(al.data(), al.size()) || !f.r(&cs, 8)) return trunc();
     std::vector<char> cg(cs);
     if (!f.r(cg.data(), cs)) return trunc();
-    uint64_t off = 0, a = 0, coff = 0;
-    d.read_hit_off.assign(1, 0);
+    // serial: validate the record tables, lay out the arenas. parallel (reads / alignments dealt in contiguous ranges to the ingest
+    // threads): re-code every read, spell every CIGAR into op words (per-thread parts, stitched in order like the PAF loader's)
+    if (!d.read_len.empty() || !d.q_id.empty()) { g_err = "[ERROR] index.longread is loaded into an empty data set only"; return false; }
+    std::vector<uint64_t> sq_off(n + 1, 0), al0(n + 1, 0);
+    d.read_len.resize(n); d.read_off.resize(n + 1); d.read_hit_off.assign(n + 1, 0);
+    uint64_t base = 0;
     for (uint64_t i = 0; i < n; i++) {
         const uint8_t* p = recs.data() + i * 32;
         const uint32_t len = get32(p), cl = get32(p + 4), nal = get32(p + 24);
-        if (cl != comp_len_of(len) || off + cl > seqs || a + nal > na) return trunc();
-        d.read_len.push_back(len); d.total_read_bases += len;
-        d.read_off.push_back(d.read_packed.size());
-        const size_t base = d.read_packed.size();
-        d.read_packed.resize(base + (((size_t)len + 15) / 16) * 4, 0);
-        from_ref_codec(sq.data() + off, len, d.read_packed.data() + base);
-        off += cl;
-        for (uint32_t k = 0; k < nal; k++, a++) {
-            const uint8_t* q = al.data() + a * 48;
-            const uint32_t tid = get32(q + 12), cgl = get32(q + 36);
-            if (tid >= d.contig_len.size() || coff + cgl + 1 > cs) return trunc();
-            d.q_id.push_back(get32(q)); d.q_start.push_back(get32(q + 4)); d.q_end.push_back(get32(q + 8));
-            d.t_id.push_back(tid); d.t_len.push_back(d.contig_len[tid]); d.t_start.push_back(get32(q + 16)); d.t_end.push_back(get32(q + 20));
-            d.n_match.push_back(get32(q + 24)); d.n_block.push_back(get32(q + 28));
-            d.is_rev.push_back(q[32]); d.mapq.push_back(q[33]);
-            if (!append_cigar(d, cg.data() + coff, cg.data() + coff + cgl)) return false;
-            coff += cgl + 1;
-        }
-        d.read_hit_off.push_back(d.q_id.size());
+        if (cl != comp_len_of(len) || sq_off[i] + cl > seqs || al0[i] + nal > na) return trunc();
+        sq_off[i + 1] = sq_off[i] + cl; al0[i + 1] = al0[i] + nal;
+        d.read_len[i] = len; d.total_read_bases += len;
+        d.read_off[i] = base; base += (((size_t)len + 15) / 16) * 4;
+        d.read_hit_off[i + 1] = al0[i + 1];
     }
-    d.read_off.push_back(d.read_packed.size());
-    d.cg_off.push_back(d.cg_ops.size());
-    if (d.cg_ops.empty()) d.cg_ops.push_back(0);
+    d.read_off[n] = base;
+    const uint64_t nrec = al0[n];
+    std::vector<uint64_t> cg0(nrec + 1, 0);   // start of every alignment's text
+    for (uint64_t a = 0; a < nrec; a++) {
+        const uint32_t cgl = get32(al.data() + a * 48 + 36);
+        if (cg0[a] + cgl + 1 > cs || get32(al.data() + a * 48 + 12) >= d.contig_len.size()) return trunc();
+        cg0[a + 1] = cg0[a] + cgl + 1;
+    }
+    d.read_packed.resize(base);
+    d.q_id.resize(nrec); d.q_start.resize(nrec); d.q_end.resize(nrec); d.t_id.resize(nrec); d.t_len.resize(nrec); d.t_start.resize(nrec); d.t_end.resize(nrec);
+    d.n_match.resize(nrec); d.n_block.resize(nrec); d.is_rev.resize(nrec); d.mapq.resize(nrec); d.cg_off.resize(nrec + 1);
+    const unsigned T = std::max(1u, g_io_threads);
+    struct Part { U32Arena ops; std::vector<uint64_t> off; std::vector<std::pair<uint64_t, std::string>> odd; bool too_long = false; };
+    std::vector<Part> part(T);
+    run_parallel(T, [&](unsigned t) {
+        for (uint64_t i = n * t / T; i < n * (t + 1) / T; i++) from_ref_codec(sq.data() + sq_off[i], d.read_len[i], d.read_packed.data() + d.read_off[i]);
+        Part& P = part[t];
+        for (uint64_t a = nrec * t / T; a < nrec * (t + 1) / T; a++) {
+            const uint8_t* q = al.data() + a * 48;
+            const uint32_t tid = get32(q + 12);
+            d.q_id[a] = get32(q); d.q_start[a] = get32(q + 4); d.q_end[a] = get32(q + 8);
+            d.t_id[a] = tid; d.t_len[a] = d.contig_len[tid]; d.t_start[a] = get32(q + 16); d.t_end[a] = get32(q + 20);
+            d.n_match[a] = get32(q + 24); d.n_block[a] = get32(q + 28);
+            d.is_rev[a] = q[32]; d.mapq[a] = q[33];
+            P.off.push_back(P.ops.size());
+            bool odd, too_long;
+            const char* b = cg.data() + cg0[a];
+            const char* e = cg.data() + cg0[a + 1] - 1;
+            if (!parse_cigar_ops(b, e, P.ops, odd, too_long)) { P.too_long = true; return; }
+            if (odd) P.odd.push_back({a, std::string(b, e)});
+        }
+    });
+    std::vector<uint64_t> op0(T + 1, 0);
+    for (unsigned t = 0; t < T; t++) {
+        if (part[t].too_long) { g_err = "[ERROR] CIGAR operation longer than 2^30 in index.longread"; return false; }
+        op0[t + 1] = op0[t] + part[t].ops.size();
+    }
+    d.cg_ops.resize(std::max<uint64_t>(1, op0[T]));
+    if (!op0[T]) d.cg_ops[0] = 0;
+    run_parallel(T, [&](unsigned t) {
+        const Part& P = part[t];
+        const uint64_t a0 = nrec * t / T;
+        for (size_t k = 0; k < P.off.size(); k++) d.cg_off[a0 + k] = P.off[k] + op0[t];
+        if (!P.ops.empty()) memcpy(d.cg_ops.data() + op0[t], P.ops.data(), P.ops.size() * 4);
+    });
+    d.cg_off[nrec] = op0[T];
+    for (unsigned t = 0; t < T; t++) for (auto& o : part[t].odd) d.cg_text_odd[o.first] = o.second;
     return true;
 }
 

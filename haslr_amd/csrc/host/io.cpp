@@ -396,6 +396,8 @@ void finish_contigs(Dataset& d) {
 }
 
 // one alignment's CIGAR from text (index.longread): offsets, op words, and the text itself when the words do not spell it
+bool parse_cigar_ops(const char* b, const char* e, U32Arena& ops, bool& odd, bool& too_long) { return parse_cigar_text(b, e, ops, odd, too_long); }
+
 bool append_cigar(Dataset& d, const char* b, const char* e) {
     d.cg_off.push_back(d.cg_ops.size());
     bool odd, too_long;
