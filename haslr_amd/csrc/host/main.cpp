@@ -142,16 +142,29 @@ int main(int argc, char* argv[]) {
         {"[NOTE] calculating long read coordinates between anchors...", hxh_run_coords},
         {"[NOTE] calling consensus sequence between anchors...", hxh_run_consensus},
         {"[NOTE] generating the assembly from the cleaned backbone graph...", hxh_run_assemble}};
+    // index.longread: written when the filtered set is known, before the GPU stages go on, like the reference does. HASLR_INDEX_ASYNC=1
+    // writes it on a thread of its own beside the later stages instead (measured: see DESIGN.md 9.2; not the default).
+    std::thread index_writer;
+    std::string index_error;
+    auto finish_index = [&]() -> bool {
+        if (index_writer.joinable()) index_writer.join();
+        if (!index_error.empty()) { fprintf(stderr, "%s\n", index_error.c_str()); return false; }
+        return true;
+    };
     for (auto& st : stages) {
         fprintf(stderr, "%s\n", st.note);
-        if (st.fn(run) != 0) { fprintf(stderr, "[ERROR] %s\n", hxh_last_error()); return EXIT_FAILURE; }
-        // index.longread: the filtered set is known now. (Written here, before the GPU stages go on, like the reference does: on a thread
-        // of its own beside the consensus stage the 3 GB write of a 140 Mb-genome run cost that stage more than it takes alone.)
-        if (st.fn == hxh_run_chain && !used_li && hxh_run_write_longread_index(run, (out_dir + "/index.longread").c_str()) != 0) {
-            fprintf(stderr, "%s\n", hxh_last_error()); return EXIT_FAILURE;
+        if (st.fn(run) != 0) { fprintf(stderr, "[ERROR] %s\n", hxh_last_error()); finish_index(); return EXIT_FAILURE; }
+        if (st.fn == hxh_run_chain && !used_li) {
+            const std::string path = out_dir + "/index.longread";
+            if (getenv("HASLR_INDEX_ASYNC"))
+                index_writer = std::thread([run, path, &index_error]() {
+                    if (hxh_run_write_longread_index(run, path.c_str()) != 0) { index_error = hxh_last_error(); if (index_error.empty()) index_error = "[ERROR] could not write " + path; remove(path.c_str()); }
+                });
+            else if (hxh_run_write_longread_index(run, path.c_str()) != 0) { fprintf(stderr, "%s\n", hxh_last_error()); return EXIT_FAILURE; }
         }
         elapsed();
     }
+    if (!finish_index()) return EXIT_FAILURE;
     fprintf(stderr, "[NOTE] cleaning up the memory!\n");
     hxh_run_free(run);
     hxh_dataset_free(ds);
