@@ -111,6 +111,7 @@ def main():
     else:
         res["parity"] = None
     rg.close(); ds.close()
+    ctx.close()                                              # (the binary below needs the device memory this process held)
     if a.cli:
         cli_out = os.path.join(a.tmp, name + ".cli")
         subprocess.call(["rm", "-rf", cli_out])
