@@ -91,8 +91,12 @@ __device__ TrimRes trim_walk(const CgView& v, bool reversed, uint32_t lr, uint32
 
 __global__ void k_chain_reads(DevHits h, const uint64_t* __restrict__ rho, const uint8_t* __restrict__ cls, uint32_t n_contigs,
                               uint32_t lr_begin, uint32_t lr_end, uint32_t min_block, double min_sim, uint32_t min_mapq,
-                              ChainScratch sc, uint32_t* err) {
-    uint32_t r = lr_begin + blockIdx.x * blockDim.x + threadIdx.x;
+                              ChainScratch sc, uint32_t* err, uint32_t spread) {
+    // one lane per read; with few reads only every `spread`-th lane works, so that the reads are spread over more wavefronts (a wave takes
+    // as long as its slowest read, and 13 k reads on 64 per wave would leave four fifths of the SIMDs idle)
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gt % spread) return;
+    uint32_t r = lr_begin + gt / spread;
     if (r >= lr_end) return;
     const uint64_t raw_b = rho[r], raw_e = rho[r + 1];
     const uint64_t base = raw_b - rho[lr_begin];
@@ -232,7 +236,8 @@ __global__ void k_chain_compact(ChainScratch sc, const uint64_t* __restrict__ rh
 void chain_reads(const DevHits& h, const uint64_t* rho, const uint8_t* cls, uint32_t n_contigs, uint32_t lr_begin, uint32_t lr_end,
                  uint32_t min_aln_block, double min_aln_sim, uint32_t min_mapq, const ChainScratch& sc, uint32_t* err, hipStream_t s) {
     uint32_t n = lr_end - lr_begin;
-    if (n) k_chain_reads<<<(n + 63) / 64, 64, 0, s>>>(h, rho, cls, n_contigs, lr_begin, lr_end, min_aln_block, min_aln_sim, min_mapq, sc, err);
+    const uint32_t spread = n <= 16384 ? 4 : n <= 65536 ? 2 : 1;
+    if (n) k_chain_reads<<<(uint32_t)(((uint64_t)n * spread + 63) / 64), 64, 0, s>>>(h, rho, cls, n_contigs, lr_begin, lr_end, min_aln_block, min_aln_sim, min_mapq, sc, err, spread);
 }
 
 void chain_compact(const ChainScratch& sc, const uint64_t* rho, uint32_t lr_begin, uint32_t lr_end, const uint64_t* aln_off,
