@@ -110,8 +110,14 @@ template <class Arena> void pack_into(Arena& dst, std::vector<uint64_t>& off, co
     off.push_back(dst.size());
     size_t nbytes = ((s.size() + 15) / 16) * 4;   // whole dwords: every sequence starts 4-byte aligned
     size_t base = dst.size();
-    dst.resize(base + nbytes, 0);
-    for (size_t i = 0; i < s.size(); i++) dst[base + (i >> 2)] |= (uint8_t)(base_code(s[i]) << ((i & 3) * 2));
+    dst.resize(base + nbytes);
+    uint8_t* out = dst.data() + base;
+    uint32_t w = 0, k = 0;
+    for (const char c : s) {                      // 16 bases per dword, little-endian, first base in the low bits
+        w |= (uint32_t)base_code(c) << k; k += 2;
+        if (k == 32) { memcpy(out, &w, 4); out += 4; w = 0; k = 0; }
+    }
+    if (k) memcpy(out, &w, 4);
 }
 
 // CIGAR text -> op words, parsed like sscanf("%u%c") until it stops matching (Common.cpp:108-121). `odd` is set when the op words do
