@@ -14,7 +14,6 @@
 #include <map>
 #include <queue>
 #include <set>
-#include <stack>
 #include <tuple>
 #include <unordered_map>
 
@@ -244,61 +243,77 @@ int clean_simple_bubbles(Graph& g, int max_depth, const std::string& logpath) {
 
 namespace {
 
-// detect_super_bubble (Cleaning.cpp:488-562), miniasm-style; keeps the reference's arithmetic including the
-// division by (path length - 1) == 0 at the source, in IEEE doubles.
-bool detect_super_bubble(const Graph& g, uint32_t src_vertex, std::vector<uint32_t>& best_path, std::set<std::pair<uint32_t, uint32_t>>& bubble_edges) {
-    std::stack<uint32_t> S;
-    S.push(src_vertex);
-    std::unordered_map<uint32_t, int32_t> visited, gamma;
-    std::unordered_map<uint32_t, std::vector<uint32_t>> path;
-    std::unordered_map<uint32_t, uint32_t> support;
-    visited[src_vertex] = 1;
-    path[src_vertex].push_back(src_vertex);
-    support[src_vertex] = 0;
-    int p = 0;
-    while (!S.empty()) {
-        uint32_t v = S.top();
-        S.pop();
-        for (const Arc& a : g.adj[v]) {
-            bubble_edges.insert({v, a.key});
-            uint32_t w = a.key, next_supp = a.supp;
-            if ((w >> 1) == (v >> 1)) return false;
-            if (visited.count(w) == 0) { gamma[w] = (int32_t)g.adj[w ^ 1u].size(); visited[w] = 1; p++; }
-            if (support.count(w) == 0 ||
-                double(support[v] + next_supp) / path[v].size() > double(support[w]) / (path[v].size() - 1)) {
-                support[w] = support[v] + next_supp;
-                std::vector<uint32_t> np = path[v];
-                np.push_back(w);
-                path[w] = np;
+// Super bubbles (Cleaning.cpp:488-562 is miniasm's tour: a vertex is expanded once all of its in-arcs have been seen, and the
+// bubble closes when exactly one vertex waits and nothing else is open). State is kept per vertex in flat epoch-stamped tables
+// instead of hash maps, and the best path to a vertex as (parent, length, support): a vertex is final when it is expanded, so the
+// chain of parents at that moment is the path the reference stores by value.
+class BubbleTour {
+    struct Slot { uint32_t epoch = 0, waiting_in = 0, parent = 0, hops = 0, support = 0; };
+    std::vector<Slot> at_;
+    uint32_t epoch_ = 0;
+
+public:
+    std::vector<uint32_t> best;                              // source ... sink, as vertices
+    std::vector<std::pair<uint32_t, uint32_t>> touched;      // every arc looked at, (vertex, key), sorted, unique
+
+    bool close_from(const Graph& g, uint32_t source) {
+        if (at_.size() != g.adj.size()) at_.assign(g.adj.size(), Slot());
+        epoch_++;
+        best.clear(); touched.clear();
+        std::vector<uint32_t> ready{source};   // used as a stack
+        at_[source] = Slot{epoch_, 0, source, 1, 0};
+        int open = 0;                          // vertices seen but not yet ready
+        bool closed = false;
+        uint32_t sink = 0;
+        while (!ready.empty() && !closed) {
+            const uint32_t v = ready.back();
+            ready.pop_back();
+            const Slot from = at_[v];
+            for (const Arc& a : g.adj[v]) {
+                const uint32_t w = a.key;
+                touched.push_back({v, w});
+                if ((w >> 1) == (v >> 1)) return false;      // an arc back into the same contig: not a bubble
+                Slot& to = at_[w];
+                const bool first = to.epoch != epoch_;
+                if (first) { to = Slot{epoch_, (uint32_t)g.adj[w ^ 1u].size(), v, 0, 0}; open++; }
+                // the reference compares mean support per hop, dividing the old value by (hops of v) - 1: at the source that is a division
+                // by zero whose result (inf or NaN) never wins - IEEE doubles reproduce it
+                const double via_v = double(from.support + a.supp) / double(from.hops);
+                const double old = double(to.support) / double(from.hops - 1);
+                if (first || via_v > old) { to.parent = v; to.hops = from.hops + 1; to.support = from.support + a.supp; }
+                if (--to.waiting_in == 0 && !g.adj[w].empty()) { ready.push_back(w); open--; }
             }
-            gamma[w]--;
-            if (gamma[w] == 0 && !g.adj[w].empty()) { S.push(w); p--; }
+            if (ready.size() == 1 && open == 0) { closed = true; sink = ready.back(); }
         }
-        if (S.size() == 1 && p == 0) { best_path = path[S.top()]; return true; }
+        if (!closed) return false;
+        for (uint32_t v = sink;; v = at_[v].parent) { best.push_back(v); if (v == source) break; }
+        std::reverse(best.begin(), best.end());
+        std::sort(touched.begin(), touched.end());
+        touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+        return true;
     }
-    return false;
-}
+};
 
 }  // namespace
 
 int clean_super_bubbles(Graph& g, const std::string& logpath) {
     FILE* fp = open_or_null(logpath, "w");
     int removed = 0;
+    BubbleTour tour;
     for (uint32_t i = 0; i < g.n_nodes; i++) {
-        if (g.deg(i, 0) < 2 && g.deg(i, 1) < 2) continue;
         bool again = false;
         for (uint32_t side = 0; side < 2 && !again; side++) {
-            if (g.deg(i, side) < 2) continue;
-            std::vector<uint32_t> best;
-            std::set<std::pair<uint32_t, uint32_t>> be;
-            if (!detect_super_bubble(g, (i << 1) | side, best, be)) continue;
+            if (g.deg(i, side) < 2 || !tour.close_from(g, (i << 1) | side)) continue;
+            const std::vector<uint32_t>& best = tour.best;
             LOGF(fp, "bubble_src %u:%c\tbubble_sink %u:%c\n", i, "+-"[side], best.back() >> 1, "+-"[best.back() & 1]);
             LOGF(fp, "\tbest_path ");
             for (uint32_t v : best) LOGF(fp, "%u:%c ", v >> 1, "+-"[v & 1]);
-            LOGF(fp, "\n");
-            for (size_t j = 0; j + 1 < best.size(); j++) be.erase({best[j], best[j + 1]});
-            LOGF(fp, "\tremoved_edges:\n");
-            for (auto& e : be) {
+            LOGF(fp, "\n\tremoved_edges:\n");
+            std::vector<std::pair<uint32_t, uint32_t>> on_best;
+            for (size_t j = 0; j + 1 < best.size(); j++) on_best.push_back({best[j], best[j + 1]});
+            std::sort(on_best.begin(), on_best.end());
+            for (const auto& e : tour.touched) {   // every arc of the bubble that is not on the best path goes, in (vertex, key) order
+                if (std::binary_search(on_best.begin(), on_best.end(), e)) continue;
                 g.remove_edge(e.first >> 1, e.first & 1, e.second >> 1, e.second & 1);
                 LOGF(fp, "\t\t%u:%c -> %u:%c\n", e.first >> 1, "+-"[e.first & 1], e.second >> 1, "+-"[e.second & 1]);
             }
@@ -306,34 +321,39 @@ int clean_super_bubbles(Graph& g, const std::string& logpath) {
             removed++;
             again = true;
         }
-        if (again) i--;
+        if (again) i--;   // the node is looked at again (wraps at 0 and comes back with the loop increment, like the reference's uint32_t)
     }
     if (fp) fclose(fp);
     return removed;
 }
 
+namespace {
+// Small bubbles (Cleaning.cpp:7-57): a triangle p -> i -> s with the shortcut p -> s. `p` is the vertex that leaves the predecessor
+// towards i, `s` the key under which the successor is entered.
+struct Triangle { uint32_t p, s, direct, in, out; };
+
+bool first_triangle(const Graph& g, uint32_t i, Triangle& t) {
+    for (const Arc& back : g.adj[(i << 1) | 1])        // arcs leaving i through its 5' end = its predecessors, seen from the other side
+        for (const Arc& fwd : g.adj[i << 1]) {
+            const uint32_t p = back.key ^ 1u;
+            if (const Arc* d = g.find(p, fwd.key)) { t = Triangle{p, fwd.key, d->supp, back.supp, fwd.supp}; return true; }
+        }
+    return false;
+}
+}  // namespace
+
 int clean_small_bubbles(Graph& g, const std::string& logpath) {
     FILE* fp = open_or_null(logpath, "w");
     int removed = 0;
+    Triangle t;
     for (uint32_t i = 0; i < g.n_nodes; i++) {
-        if (!(g.deg(i, 1) > 0 && g.deg(i, 0) > 0)) continue;
-        bool done = false;
-        for (size_t ki = 0; ki < g.adj[(i << 1) | 1].size() && !done; ki++) {
-            for (size_t ko = 0; ko < g.adj[i << 1].size() && !done; ko++) {
-                const Arc ain = g.adj[(i << 1) | 1][ki], aout = g.adj[i << 1][ko];
-                uint32_t node1 = ain.key >> 1, rev1 = ain.key & 1, to = aout.key, node2 = to >> 1, rev2 = to & 1;
-                const Arc* direct = g.find((node1 << 1) | (1 - rev1), to);
-                if (!direct) continue;
-                double short_cov = direct->supp;
-                double long_cov = (ain.supp + aout.supp) / 2.0;
-                LOGF(fp, "small_bubble cov:%.2lf %u:%c -> %u:%c\n", short_cov, node1, "+-"[1 - rev1], node2, "+-"[rev2]);
-                LOGF(fp, "             cov:%.2lf %u:%c -> %u:%c -> %u:%c\n", long_cov, node1, "+-"[1 - rev1], i, "+-"[0], node2, "+-"[rev2]);
-                if (short_cov < long_cov) g.remove_edge(node1, 1 - rev1, node2, rev2);
-                else { g.remove_edge(node1, 1 - rev1, i, 0); g.remove_edge(i, 0, node2, rev2); }
-                removed++;
-                done = true;
-            }
-        }
+        if (!first_triangle(g, i, t)) continue;        // at most one per node and pass, and the node is not looked at again
+        const double shortcut = t.direct, detour = (t.in + t.out) / 2.0;
+        LOGF(fp, "small_bubble cov:%.2lf %u:%c -> %u:%c\n", shortcut, t.p >> 1, "+-"[t.p & 1], t.s >> 1, "+-"[t.s & 1]);
+        LOGF(fp, "             cov:%.2lf %u:%c -> %u:%c -> %u:%c\n", detour, t.p >> 1, "+-"[t.p & 1], i, '+', t.s >> 1, "+-"[t.s & 1]);
+        if (shortcut < detour) g.remove_edge(t.p >> 1, t.p & 1, t.s >> 1, t.s & 1);
+        else { g.remove_edge(t.p >> 1, t.p & 1, i, 0); g.remove_edge(i, 0, t.s >> 1, t.s & 1); }
+        removed++;
     }
     if (fp) fclose(fp);
     return removed;

@@ -58,9 +58,21 @@ typedef struct {
  * (bench timing of the compute path); otherwise every reference output file is produced. */
 hxh_run* hxh_run_create(const hxh_dataset*, const hx_params*, const hx_backend*, const char* out_dir);
 void hxh_run_free(hxh_run*);
-/* multi-GPU: this run computes coordinates + consensus only for its share of the surviving edges
- * (hxh_run_assemble is then meaningful only after the consensus strings have been gathered) */
+/* multi-GPU (one run per rank, every rank sees the same graph because hxh_run_graph works on the merged edge multiset):
+ *   hxh_run_set_edge_shard   this run computes coordinates + consensus only for its share of the work queue (Assemble.cpp:386-434); the
+ *                            queue is dealt by estimated DP cost, longest first, to the least loaded rank - the same on every rank
+ *   hxh_run_set_read_shard   first long read of the backend's read shard (read ids of hxh_run_compact_text)
+ *   hxh_run_results_export   head_end / tail_beg / supports / consensus of this run's share as one blob (valid until the next export)
+ *   hxh_run_results_import   the other ranks' blobs, in any order, singly or concatenated (own entries are skipped)
+ *   hxh_run_results_missing  queue entries without results: hxh_run_assemble fails unless it is 0 (the role of asm_cal_cns_seq_MT's
+ *                            join before asm_get_assembly, Assemble.cpp:580-605 -> :1045-1077)
+ *   hxh_run_compact_text     the compact_uniq.txt lines of the reads this run chained (a sharded run does not write the file itself) */
 void hxh_run_set_edge_shard(hxh_run*, uint32_t rank, uint32_t world);
+void hxh_run_set_read_shard(hxh_run*, uint32_t lr_begin);
+int hxh_run_results_export(hxh_run*, const uint8_t** buf, uint64_t* len);
+int hxh_run_results_import(hxh_run*, const uint8_t* buf, uint64_t len);
+uint64_t hxh_run_results_missing(const hxh_run*);
+const char* hxh_run_compact_text(hxh_run*, uint64_t* len);
 /* stages, in reference order; each returns 0 or <0 */
 int hxh_run_chain(hxh_run*);          /* fix_alignments + build_compact_longreads (+ compact_uniq.txt) */
 int hxh_run_graph(hxh_run*);          /* bbg_build_graph .. clean_small_bubbles + branching log (+ gfa/stat/log files) */
@@ -72,8 +84,9 @@ int hxh_run_all(hxh_run*);            /* all of the above */
 /* index.longread: the alignments that survived the chain stage's filters, with their raw fields (needs hxh_run_chain) */
 int hxh_run_write_longread_index(const hxh_run*, const char* path);
 void hxh_run_timings(const hxh_run*, double out[5]);
-/* results for tests: number of surviving undirected edges / their consensus */
+/* results for tests: number of surviving undirected edges this run processed (= all of them unless sharded) / in total; their consensus */
 uint32_t hxh_run_n_edges(const hxh_run*);
+uint32_t hxh_run_n_edges_total(const hxh_run*);
 const hx_chain_out* hxh_run_chain_out(const hxh_run*);
 const hx_edges_out* hxh_run_edges_out(const hxh_run*);
 const hx_coords_out* hxh_run_coords_out(const hxh_run*);

@@ -22,6 +22,15 @@ namespace hxh {
 
 #define LOGF(fp, ...) do { if (fp) fprintf(fp, __VA_ARGS__); } while (0)
 
+// what the two per-edge stages leave behind for one entry of the work queue; in a multi-GPU run the entries of the other ranks arrive
+// through hxh_run_results_import
+struct EdgeResult {
+    bool have_coords = false, have_cns = false;
+    uint32_t head_end = 0, tail_beg = 0;
+    std::vector<uint32_t> supp_lr, spos, epos;
+    std::string cns;
+};
+
 struct Run {
     const Dataset* d = nullptr;
     hx_params prm{};
@@ -33,12 +42,18 @@ struct Run {
     hx_cns_out cnsout{};
     bool have_chain = false, have_edges = false, have_coords = false, have_cns = false;
     Graph g;
-    // processed arcs in work-queue order: (vertex, key); index = position in coords / cnsout
+    // the work queue (Assemble.cpp:365-434): every surviving undirected edge once, as (vertex, key) of the direction that is processed
     std::vector<std::pair<uint32_t, uint32_t>> work;
+    std::vector<uint32_t> mine;     // entries of `work` this run computes (all of them unless the edges are sharded), ascending;
+                                    // position = index in coords / cnsout
+    std::vector<EdgeResult> res;    // per entry of `work`
     std::vector<std::string> cns;   // consensus strings; Arc::cns_id indexes this
     std::string fasta;
+    std::vector<uint8_t> blob;      // last hxh_run_results_export
+    std::string compact_text;       // last hxh_run_compact_text
     double t[5] = {0, 0, 0, 0, 0};
     uint32_t shard_rank = 0, shard_world = 1;   // multi-GPU: this run computes coordinates/consensus for its share of the edges
+    uint32_t lr_begin = 0;                      // multi-GPU: first long read of the backend's read shard (ids in compact_uniq.txt)
 
     std::string path(const char* name) const { return out_dir.empty() ? std::string() : out_dir + "/" + name; }
     void release() {
@@ -57,18 +72,28 @@ int backend_fail(Run& r, const char* what) {
     return -1;
 }
 
-void write_compact(const Run& r) {
-    FILE* fp = open_or_null(r.path("compact_uniq.txt"), "w");
-    if (!fp) return;
+// compact_uniq.txt lines (Longread.cpp:675-693) of the reads this run chained; read ids start at r.lr_begin
+std::string compact_lines(const Run& r) {
+    std::string out;
+    char buf[96];
     const hx_chain_out& c = r.chain;
     for (uint32_t i = 0; i < c.n_reads; i++) {
-        fprintf(fp, ">%u\t", i);
+        out.append(buf, snprintf(buf, sizeof(buf), ">%u\t", r.lr_begin + i));
         for (uint64_t j = c.cmp_off[i]; j < c.cmp_off[i + 1]; j++) {
             uint32_t a = c.cmp_aln[j], h = c.hit[a];
-            fprintf(fp, "%u-%u:%u:%c:%u-%u\t", c.q_start[a], c.q_end[a], r.d->t_id[h], r.d->is_rev[h] ? '-' : '+', c.t_start[a], c.t_end[a]);
+            out.append(buf, snprintf(buf, sizeof(buf), "%u-%u:%u:%c:%u-%u\t", c.q_start[a], c.q_end[a], r.d->t_id[h], r.d->is_rev[h] ? '-' : '+', c.t_start[a], c.t_end[a]));
         }
-        fprintf(fp, "\n");
+        out.push_back('\n');
     }
+    return out;
+}
+
+void write_compact(const Run& r) {
+    if (r.shard_world > 1) return;   // sharded reads: the launcher gathers hxh_run_compact_text of every rank and writes the file once
+    FILE* fp = open_or_null(r.path("compact_uniq.txt"), "w");
+    if (!fp) return;
+    const std::string t = compact_lines(r);
+    fwrite(t.data(), 1, t.size(), fp);
     fclose(fp);
 }
 
@@ -152,48 +177,127 @@ static int run_graph(Run& r) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Per-edge stages. Both work on the queue of Assemble.cpp:365-434; a run computes the entries in `mine`
+// and keeps what it learns in `res`, from where it is applied to the arcs (and, in a multi-GPU run,
+// exported to / imported from the other ranks).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// DP cost of an edge before its coordinates are known: sequences x longest gap x nodes of the finished graph, with the gap
+// taken from the read-space distance of the two anchors of every support and the graph growth hx_poa_batch plans with
+uint64_t edge_cost_estimate(const Run& r, uint32_t dev_edge) {
+    const hx_edges_out& e = r.edges;
+    uint64_t lmax = 1, n = 0;
+    for (uint64_t k = e.edge_off[dev_edge]; k < e.edge_off[dev_edge + 1]; k++, n++) {
+        const bool twin = e.lr[k] >> 31;   // a twin record's head is the later anchor on the read
+        const uint32_t from = twin ? e.tail.q_end[k] : e.head.q_end[k], to = twin ? e.head.q_start[k] : e.tail.q_start[k];
+        if (to > from) lmax = std::max<uint64_t>(lmax, (uint64_t)to - from + 1);
+    }
+    const uint64_t nodes = lmax * (120 + 9 * n) / 100 + 1024;
+    return nodes * lmax * std::max<uint64_t>(1, n);
+}
+
+// longest-processing-time dealing of the queue to the ranks: entries in descending cost, each to the rank with the least load so far
+std::vector<uint32_t> my_share(const Run& r) {
+    std::vector<uint32_t> all(r.work.size());
+    for (uint32_t i = 0; i < all.size(); i++) all[i] = i;
+    if (r.shard_world <= 1) return all;
+    std::vector<uint64_t> cost(all.size());
+    for (uint32_t i = 0; i < all.size(); i++) cost[i] = edge_cost_estimate(r, r.g.find(r.work[i].first, r.work[i].second)->dev_edge);
+    std::stable_sort(all.begin(), all.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    std::vector<uint64_t> load(r.shard_world, 0);
+    std::vector<uint32_t> mine;
+    for (uint32_t i : all) {
+        const uint32_t to = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
+        load[to] += cost[i];
+        if (to == r.shard_rank) mine.push_back(i);
+    }
+    std::sort(mine.begin(), mine.end());
+    return mine;
+}
+
+struct ArcPair { Arc* a; Arc* tw; };
+ArcPair arcs_of(Run& r, uint32_t gi) {
+    const uint32_t v = r.work[gi].first, key = r.work[gi].second;
+    return {r.g.find(v, key), r.g.find(Graph::twin_vertex(key), Graph::twin_key(v))};
+}
+
+void apply_coords(Run& r, uint32_t gi) {
+    const EdgeResult& x = r.res[gi];
+    const ArcPair p = arcs_of(r, gi);
+    const uint32_t n = (uint32_t)x.supp_lr.size();
+    p.a->head_end = x.head_end; p.a->tail_beg = x.tail_beg; p.a->n_cns_supp = n;
+    if (p.tw == p.a) p.a->head_end = p.a->tail_beg = x.tail_beg;   // self-twin (hairpin): edge1 and edge2 are one object in the reference,
+                                                                    // the second chained assignment wins (Assemble.cpp:351-352)
+    else if (p.tw) { p.tw->tail_beg = x.head_end; p.tw->head_end = x.tail_beg; p.tw->n_cns_supp = n; }
+}
+
+void apply_cns(Run& r, uint32_t gi) {
+    const EdgeResult& x = r.res[gi];
+    const ArcPair p = arcs_of(r, gi);
+    p.a->cns_id = (int32_t)r.cns.size();
+    r.cns.push_back(x.cns);
+    if (p.tw && p.tw != p.a) { p.tw->cns_id = (int32_t)r.cns.size(); r.cns.push_back(revcomp(x.cns)); }   // Assemble.cpp:555
+    else if (p.tw == p.a) r.cns.back() = revcomp(x.cns);   // self-twin (hairpin): the reference's edge2 assignment overwrites edge1's
+}
+
+// reduced forms of the reference's diagnostic logs (Assemble.cpp:176-362, :501-557), every entry of the queue in queue order
+void write_stage_logs(Run& r) {
+    FILE* fk = open_or_null(r.path("log_coordinate.txt"), "w");
+    FILE* fc = open_or_null(r.path("log_consensus.txt"), "w");
+    for (uint32_t gi = 0; gi < r.work.size() && (fk || fc); gi++) {
+        const uint32_t v = r.work[gi].first, key = r.work[gi].second;
+        const EdgeResult& x = r.res[gi];
+        const Arc* a = r.g.find(v, key);
+        if (fk && x.have_coords) {
+            fprintf(fk, "edge      %u:%c -> %u:%c\n", v >> 1, "+-"[v & 1], key >> 1, "+-"[key & 1]);
+            fprintf(fk, "edge_twin %u:%c -> %u:%c\n", key >> 1, "+-"[1 - (key & 1)], v >> 1, "+-"[1 - (v & 1)]);
+            fprintf(fk, "\tedge_supp size:%u\n", a->supp);
+            fprintf(fk, "coordinates contig1_pos: %u\tcontig2_pos: %u\n", a->head_end, a->tail_beg);
+            for (size_t k = 0; k < x.supp_lr.size(); k++)
+                fprintf(fk, "    +++ lr:%u strand:%c [coordinate] lr_start:%u lr_end:%u\n", x.supp_lr[k] & 0x7fffffffu, "+-"[x.supp_lr[k] >> 31], x.spos[k], x.epos[k]);
+            fprintf(fk, "\n");
+        }
+        if (fc && x.have_cns) {
+            fprintf(fc, "calc_cns %u:%c -> %u:%c\n", v >> 1, "+-"[v & 1], key >> 1, "+-"[key & 1]);
+            fprintf(fc, "[shared_region] head_end:%u\ttail_beg:%u\n", a->head_end, a->tail_beg);
+            fprintf(fc, ">CONSENSUS\n%s\n", x.cns.c_str());
+        }
+    }
+    if (fk) fclose(fk);
+    if (fc) fclose(fc);
+}
+
+size_t missing_results(const Run& r) {
+    size_t n = 0;
+    for (const EdgeResult& x : r.res) n += !(x.have_coords && x.have_cns);
+    return n;
+}
+
+}  // namespace
+
 static int run_coords(Run& r) {
     double t0 = now();
     r.work = work_queue(r.g, 11);
-    if (r.shard_world > 1) {   // deal the queue out by descending support count (a cost proxy), round-robin
-        std::vector<uint32_t> ord(r.work.size());
-        for (uint32_t i = 0; i < ord.size(); i++) ord[i] = i;
-        std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
-            return r.g.find(r.work[a].first, r.work[a].second)->supp > r.g.find(r.work[b].first, r.work[b].second)->supp;
-        });
-        std::vector<char> mine(r.work.size(), 0);
-        for (uint32_t k = 0; k < ord.size(); k++) if (k % r.shard_world == r.shard_rank) mine[ord[k]] = 1;
-        std::vector<std::pair<uint32_t, uint32_t>> w;
-        for (uint32_t i = 0; i < r.work.size(); i++) if (mine[i]) w.push_back(r.work[i]);
-        r.work.swap(w);
-    }
-    std::vector<uint32_t> sel(r.work.size());
-    for (size_t i = 0; i < r.work.size(); i++) sel[i] = r.g.find(r.work[i].first, r.work[i].second)->dev_edge;
+    r.res.assign(r.work.size(), EdgeResult());
+    r.cns.clear();
+    r.mine = my_share(r);
+    std::vector<uint32_t> sel(r.mine.size());
+    for (size_t i = 0; i < r.mine.size(); i++) sel[i] = r.g.find(r.work[r.mine[i]].first, r.work[r.mine[i]].second)->dev_edge;
     if (r.have_coords) r.be.free_coords(r.be.ctx, &r.coords), r.have_coords = false;
     if (r.be.edge_coords(r.be.ctx, (uint32_t)sel.size(), sel.data(), &r.coords) != 0) return backend_fail(r, "edge_coords");
     r.have_coords = true;
-    FILE* fp = open_or_null(r.path("log_coordinate.txt"), "w");
-    for (size_t i = 0; i < r.work.size(); i++) {
-        uint32_t v = r.work[i].first, key = r.work[i].second;
-        Arc* a = r.g.find(v, key);
-        Arc* tw = r.g.find(Graph::twin_vertex(key), Graph::twin_key(v));
-        uint32_t n = (uint32_t)(r.coords.supp_off[i + 1] - r.coords.supp_off[i]);
-        a->head_end = r.coords.head_end[i]; a->tail_beg = r.coords.tail_beg[i]; a->n_cns_supp = n;
-        if (tw == a) a->head_end = a->tail_beg = r.coords.tail_beg[i];   // self-twin (hairpin): edge1 and edge2 are one object in the
-                                                                          // reference, the second chained assignment wins (Assemble.cpp:351-352)
-        else if (tw) { tw->tail_beg = r.coords.head_end[i]; tw->head_end = r.coords.tail_beg[i]; tw->n_cns_supp = n; }
-        if (fp) {   // reduced form of the reference's diagnostic log (Assemble.cpp:176-362)
-            fprintf(fp, "edge      %u:%c -> %u:%c\n", v >> 1, "+-"[v & 1], key >> 1, "+-"[key & 1]);
-            fprintf(fp, "edge_twin %u:%c -> %u:%c\n", key >> 1, "+-"[1 - (key & 1)], v >> 1, "+-"[1 - (v & 1)]);
-            fprintf(fp, "\tedge_supp size:%u\n", a->supp);
-            fprintf(fp, "coordinates contig1_pos: %u\tcontig2_pos: %u\n", a->head_end, a->tail_beg);
-            for (uint64_t k = r.coords.supp_off[i]; k < r.coords.supp_off[i + 1]; k++)
-                fprintf(fp, "    +++ lr:%u strand:%c [coordinate] lr_start:%u lr_end:%u\n", r.coords.supp_lr[k] & 0x7fffffffu,
-                        "+-"[r.coords.supp_lr[k] >> 31], r.coords.spos[k], r.coords.epos[k]);
-            fprintf(fp, "\n");
-        }
+    for (size_t i = 0; i < r.mine.size(); i++) {
+        EdgeResult& x = r.res[r.mine[i]];
+        const uint64_t b = r.coords.supp_off[i], e = r.coords.supp_off[i + 1];
+        x.have_coords = true;
+        x.head_end = r.coords.head_end[i]; x.tail_beg = r.coords.tail_beg[i];
+        x.supp_lr.assign(r.coords.supp_lr + b, r.coords.supp_lr + e);
+        x.spos.assign(r.coords.spos + b, r.coords.spos + e);
+        x.epos.assign(r.coords.epos + b, r.coords.epos + e);
+        apply_coords(r, r.mine[i]);
     }
-    if (fp) fclose(fp);
     r.t[2] = now() - t0;
     return 0;
 }
@@ -201,153 +305,251 @@ static int run_coords(Run& r) {
 static int run_consensus(Run& r) {
     double t0 = now();
     // second pass of the work queue (flag 12) hands out the same arcs in the same order as the first
-    std::vector<std::pair<uint32_t, uint32_t>> again = work_queue(r.g, 12);
-    if (r.shard_world == 1 && again != r.work) { g_err = "internal: consensus work queue differs from coordinate work queue"; return -1; }
+    if (work_queue(r.g, 12) != r.work) { g_err = "internal: consensus work queue differs from coordinate work queue"; return -1; }
     hx_poa_params pp{5, -4, -8};   // Assemble.cpp:8-11
     if (r.have_cns) r.be.free_cns(r.be.ctx, &r.cnsout), r.have_cns = false;
     if (r.be.poa_batch(r.be.ctx, &pp, &r.cnsout) != 0) return backend_fail(r, "poa_batch");
     r.have_cns = true;
-    r.cns.clear();
-    r.cns.reserve(r.work.size() * 2);
-    FILE* fp = open_or_null(r.path("log_consensus.txt"), "w");
-    for (size_t i = 0; i < r.work.size(); i++) {
-        uint32_t v = r.work[i].first, key = r.work[i].second;
-        std::string c(r.cnsout.cns + r.cnsout.cns_off[i], r.cnsout.cns + r.cnsout.cns_off[i + 1]);
-        Arc* a = r.g.find(v, key);
-        Arc* tw = r.g.find(Graph::twin_vertex(key), Graph::twin_key(v));
-        a->cns_id = (int32_t)r.cns.size();
-        r.cns.push_back(c);
-        if (tw && tw != a) { tw->cns_id = (int32_t)r.cns.size(); r.cns.push_back(revcomp(c)); }   // Assemble.cpp:555
-        else if (tw == a) { r.cns.back() = revcomp(c); }   // self-twin (hairpin): the reference's edge2 assignment overwrites edge1's
-        if (fp) {
-            fprintf(fp, "calc_cns %u:%c -> %u:%c\n", v >> 1, "+-"[v & 1], key >> 1, "+-"[key & 1]);
-            fprintf(fp, "[shared_region] head_end:%u\ttail_beg:%u\n", a->head_end, a->tail_beg);
-            fprintf(fp, ">CONSENSUS\n%s\n", c.c_str());
-        }
+    if (r.cnsout.n_edge != r.mine.size()) { g_err = "internal: consensus count differs from this run's share of the work queue"; return -1; }
+    for (size_t i = 0; i < r.mine.size(); i++) {
+        EdgeResult& x = r.res[r.mine[i]];
+        x.cns.assign(r.cnsout.cns + r.cnsout.cns_off[i], r.cnsout.cns + r.cnsout.cns_off[i + 1]);
+        x.have_cns = true;
+        apply_cns(r, r.mine[i]);
     }
-    if (fp) fclose(fp);
+    if (r.shard_world == 1) write_stage_logs(r);
     r.t[3] = now() - t0;
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU: results of this run's share of the queue as one self-delimiting blob of 32-bit words
+//   { magic, n_items, words in the blob } then per item { queue index, head_end, tail_beg, n_supp, cns bytes,
+//   n_supp x (lr, spos, epos), consensus padded to a word }.
+// A rank imports the concatenation of every rank's blob (its own entries are skipped).
+// ---------------------------------------------------------------------------------------------
 namespace {
-struct PE { uint32_t strand, id; };
+constexpr uint32_t kBlobMagic = 0x31525848u;   // "HXR1"
 
-void assemble_path(Run& r, const std::deque<PE>& path, int& nb_ctg, FILE* fp_asm, FILE* fp_ann, FILE* fp_log) {
-    const Dataset& d = *r.d;
-    Graph& g = r.g;
-    auto emit = [&](uint32_t fs, uint32_t fstrand, uint32_t ts, uint32_t tstrand, const std::string& seq) {
-        LOGF(fp_log, ">%d from:%u:%c to:%u:%c\n%s\n\n", nb_ctg, fs, "+-"[fstrand], ts, "+-"[tstrand], seq.c_str());
-        char hdr[128];
-        int n = snprintf(hdr, sizeof(hdr), ">%d from:%u:%c to:%u:%c\n", nb_ctg, fs, "+-"[fstrand], ts, "+-"[tstrand]);
-        r.fasta.append(hdr, n); r.fasta += seq; r.fasta.push_back('\n');
-        if (fp_asm) { fputs(hdr, fp_asm); fputs(seq.c_str(), fp_asm); fputc('\n', fp_asm); }
-        nb_ctg++;
-    };
-    if (path.size() == 1) {
-        emit(path.front().id, path.front().strand, path.front().id, path.front().strand, d.contig_seq(path.front().id));
-        return;
+void export_results(Run& r) {
+    std::vector<uint32_t> w{kBlobMagic, (uint32_t)r.mine.size(), 0u};
+    for (uint32_t gi : r.mine) {
+        const EdgeResult& x = r.res[gi];
+        const uint32_t hdr[5] = {gi, x.head_end, x.tail_beg, (uint32_t)x.supp_lr.size(), (uint32_t)x.cns.size()};
+        w.insert(w.end(), hdr, hdr + 5);
+        for (size_t k = 0; k < x.supp_lr.size(); k++) { w.push_back(x.supp_lr[k]); w.push_back(x.spos[k]); w.push_back(x.epos[k]); }
+        const size_t at = w.size();
+        w.resize(at + (x.cns.size() + 3) / 4, 0u);
+        memcpy(w.data() + at, x.cns.data(), x.cns.size());
     }
-    std::string assembled;
-    uint32_t src = path[0].id, src_strand = path[0].strand;
-    uint32_t c1_start = src_strand == 0 ? 0 : d.contig_len[src] - 1;
-    uint32_t tgt = path.back().id, tgt_strand = path.back().strand;
-    size_t i;
-    for (i = 0; i + 1 < path.size(); i++) {
-        uint32_t c1 = path[i].id, s1 = path[i].strand, c2 = path[i + 1].id, s2 = path[i + 1].strand;
-        std::string c1s = d.contig_seq(c1);
-        Arc* e = g.find((c1 << 1) | s1, (c2 << 1) | s2);
-        std::string prefix;
-        if (e->n_cns_supp == 0) {   // break the assembly here (Assemble.cpp:682-706)
-            LOGF(fp_log, "[breaking] contig1_len:%zu    contig1_start:%u    prev_end:%u     next_beg:%u\n", c1s.size(), c1_start, e->head_end, e->tail_beg);
-            if (s1 == 0) {
-                prefix = c1s.substr(c1_start);
-                LOGF(fp_ann, "%d\t%zu\t%zu\tctg\t+\t%u\t%zu\t%u\t%zu\n", nb_ctg, assembled.size(), assembled.size() + prefix.size(), c1, c1s.size(), c1_start, c1s.size());
-            } else {
-                prefix = c1s.substr(0, c1_start + 1);
-                LOGF(fp_ann, "%d\t%zu\t%zu\tctg\t-\t%u\t%zu\t%u\t%u\n", nb_ctg, assembled.size(), assembled.size() + prefix.size(), c1, c1s.size(), 0, c1_start + 1);
-                prefix = revcomp(prefix);
+    w[2] = (uint32_t)w.size();
+    r.blob.resize(w.size() * 4);
+    memcpy(r.blob.data(), w.data(), r.blob.size());
+}
+
+int import_results(Run& r, const uint8_t* buf, uint64_t len) {
+    if (len % 4) { g_err = "results import: length is not a multiple of 4"; return -1; }
+    std::vector<uint32_t> w(len / 4);
+    memcpy(w.data(), buf, len);
+    size_t at = 0;
+    while (at < w.size()) {
+        if (w.size() - at < 3 || w[at] != kBlobMagic || w[at + 2] < 3 || w[at + 2] > w.size() - at) { g_err = "results import: malformed blob header"; return -1; }
+        const size_t end = at + w[at + 2];
+        const uint32_t n_items = w[at + 1];
+        at += 3;
+        for (uint32_t it = 0; it < n_items; it++) {
+            if (end - at < 5) { g_err = "results import: truncated item"; return -1; }
+            const uint32_t gi = w[at], ns = w[at + 3], nc = w[at + 4];
+            const size_t need = 5 + (size_t)ns * 3 + ((size_t)nc + 3) / 4;
+            if (gi >= r.work.size() || end - at < need) { g_err = "results import: item does not fit (different graph on the sending rank?)"; return -1; }
+            EdgeResult& x = r.res[gi];
+            if (!(x.have_coords && x.have_cns)) {   // (own entries and repeats are skipped)
+                x.head_end = w[at + 1]; x.tail_beg = w[at + 2];
+                x.supp_lr.resize(ns); x.spos.resize(ns); x.epos.resize(ns);
+                for (uint32_t k = 0; k < ns; k++) { x.supp_lr[k] = w[at + 5 + 3 * k]; x.spos[k] = w[at + 6 + 3 * k]; x.epos[k] = w[at + 7 + 3 * k]; }
+                x.cns.assign(reinterpret_cast<const char*>(w.data() + at + 5 + (size_t)ns * 3), nc);
+                x.have_coords = x.have_cns = true;
+                apply_coords(r, gi);
+                apply_cns(r, gi);
             }
-            assembled += prefix;
-            emit(src, src_strand, c1, s1, assembled);
-            assembled.clear();
-            src = c2; src_strand = s2;
-            c1_start = src_strand == 0 ? 0 : d.contig_len[src] - 1;
+            at += need;
+        }
+        if (at != end) { g_err = "results import: blob length does not match its items"; return -1; }
+    }
+    if (missing_results(r) == 0) write_stage_logs(r);
+    return 0;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Path extraction and stitching (Assemble.cpp:757-810, :624-755): a path of anchor contigs becomes one output
+// record, or several when an edge without consensus support breaks it. A record is planned as a list of
+// pieces (contig slices and consensus strings) and rendered once into asm.final.fa / .ann / log_asmfinal.txt.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Anchor { uint32_t strand, id; };
+
+struct Piece {
+    const std::string* cns = nullptr;   // a gap consensus ...
+    uint32_t n_supp = 0;
+    uint32_t contig = 0, strand = 0;    // ... or bases [lo, lo + n) of a contig, reverse-complemented on strand 1
+    uint64_t lo = 0, n = 0, ann_lo = 0, ann_hi = 0;
+};
+
+struct Record {
+    Anchor from{}, to{};
+    std::vector<Piece> pieces;
+    std::vector<std::string> notes;     // log_asmfinal.txt lines that precede the record
+};
+
+// what std::string::substr(pos, count) keeps of a string of `len` characters
+uint64_t kept(uint64_t len, uint64_t pos, uint64_t count) { return pos >= len ? 0 : std::min(count, len - pos); }
+
+std::string slice_text(const Dataset& d, const Piece& p) {
+    std::string s(p.n, 'A');
+    const uint8_t* q = d.contig_packed.data() + d.contig_off[p.contig];
+    if (p.strand == 0)
+        for (uint64_t i = 0; i < p.n; i++) { const uint64_t b = p.lo + i; s[i] = "ACGT"[(q[b >> 2] >> ((b & 3) * 2)) & 3]; }
+    else
+        for (uint64_t i = 0; i < p.n; i++) { const uint64_t b = p.lo + p.n - 1 - i; s[i] = "TGCA"[(q[b >> 2] >> ((b & 3) * 2)) & 3]; }
+    return s;
+}
+
+std::string note(const char* what, uint64_t len, uint32_t cursor, const Arc& e) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "[%s] contig1_len:%zu    contig1_start:%u    prev_end:%u     next_beg:%u\n", what, (size_t)len, cursor, e.head_end, e.tail_beg);
+    return buf;
+}
+
+// the rest of a contig from the cursor to the end it is left through (path orientation)
+Piece to_contig_end(const Dataset& d, Anchor c, uint32_t cursor) {
+    Piece p;
+    const uint64_t len = d.contig_len[c.id];
+    p.contig = c.id; p.strand = c.strand;
+    if (c.strand == 0) { p.lo = cursor; p.n = kept(len, cursor, UINT64_MAX); p.ann_lo = cursor; p.ann_hi = len; }
+    else { p.lo = 0; p.n = kept(len, 0, (uint64_t)cursor + 1); p.ann_lo = 0; p.ann_hi = (uint64_t)cursor + 1; }
+    return p;
+}
+
+// from the cursor up to the base where the edge's consensus takes over (head_end, inclusive); counts are 32-bit like the reference's
+Piece to_head_end(const Dataset& d, Anchor c, uint32_t cursor, const Arc& e) {
+    Piece p;
+    const uint64_t len = d.contig_len[c.id];
+    p.contig = c.id; p.strand = c.strand;
+    if (c.strand == 0) { p.lo = cursor; p.n = kept(len, cursor, (uint32_t)(e.head_end - cursor + 1)); }
+    else { p.lo = e.head_end; p.n = kept(len, e.head_end, (uint32_t)(cursor - e.head_end + 1)); }
+    p.ann_lo = p.lo; p.ann_hi = p.lo + p.n;
+    return p;
+}
+
+std::vector<Record> plan_path(Run& r, const std::deque<Anchor>& path) {
+    const Dataset& d = *r.d;
+    std::vector<Record> out;
+    auto entry = [&](Anchor a) { return a.strand == 0 ? 0u : d.contig_len[a.id] - 1; };   // where a contig is entered when nothing precedes it
+    Record cur;
+    cur.from = path.front();
+    uint32_t cursor = entry(path.front());
+    for (size_t i = 0; i + 1 < path.size(); i++) {
+        const Anchor c1 = path[i], c2 = path[i + 1];
+        const Arc& e = *r.g.find((c1.id << 1) | c1.strand, (c2.id << 1) | c2.strand);
+        if (e.n_cns_supp == 0) {   // no read bridges the gap: the record ends with the rest of c1, the next one starts at c2
+            cur.notes.push_back(note("breaking", d.contig_len[c1.id], cursor, e));
+            cur.pieces.push_back(to_contig_end(d, c1, cursor));
+            cur.to = c1;
+            out.push_back(std::move(cur));
+            cur = Record();
+            cur.from = c2;
+            cursor = entry(c2);
             if (!r.out_dir.empty())
-                fprintf(stderr, "[WARNING] breaking assembly for path %u:%c --> %u:%c between anchors %u:%c --> %u:%c\n", src, "+-"[src_strand], tgt, "+-"[tgt_strand], c1, "+-"[s1], c2, "+-"[s2]);
-        } else {                    // stitch contig piece + consensus (Assemble.cpp:708-731)
-            LOGF(fp_log, "[stitching] contig1_len:%zu    contig1_start:%u    prev_end:%u     next_beg:%u\n", c1s.size(), c1_start, e->head_end, e->tail_beg);
-            if (s1 == 0) {
-                prefix = c1s.substr(c1_start, e->head_end - c1_start + 1);
-                LOGF(fp_ann, "%d\t%zu\t%zu\tctg\t+\t%u\t%zu\t%u\t%zu\n", nb_ctg, assembled.size(), assembled.size() + prefix.size(), c1, c1s.size(), c1_start, c1_start + prefix.size());
-            } else {
-                prefix = c1s.substr(e->head_end, c1_start - e->head_end + 1);
-                LOGF(fp_ann, "%d\t%zu\t%zu\tctg\t-\t%u\t%zu\t%u\t%zu\n", nb_ctg, assembled.size(), assembled.size() + prefix.size(), c1, c1s.size(), e->head_end, e->head_end + prefix.size());
-                prefix = revcomp(prefix);
-            }
-            assembled += prefix;
-            const std::string& cs = r.cns[e->cns_id];
-            LOGF(fp_ann, "%d\t%zu\t%zu\tcns\t%zu\t%u\n", nb_ctg, assembled.size(), assembled.size() + cs.size(), cs.size(), e->n_cns_supp);
-            assembled += cs;
-            c1_start = e->tail_beg;
+                fprintf(stderr, "[WARNING] breaking assembly for path %u:%c --> %u:%c between anchors %u:%c --> %u:%c\n", c2.id, "+-"[c2.strand], path.back().id,
+                        "+-"[path.back().strand], c1.id, "+-"[c1.strand], c2.id, "+-"[c2.strand]);
+        } else {
+            cur.notes.push_back(note("stitching", d.contig_len[c1.id], cursor, e));
+            cur.pieces.push_back(to_head_end(d, c1, cursor, e));
+            Piece g;
+            g.cns = &r.cns[e.cns_id]; g.n_supp = e.n_cns_supp;
+            cur.pieces.push_back(g);
+            cursor = e.tail_beg;
         }
     }
-    uint32_t c2 = path[i].id, s2 = path[i].strand;
-    std::string c2s = d.contig_seq(c2), suffix;
-    if (s2 == 0) {
-        suffix = c2s.substr(c1_start);
-        LOGF(fp_ann, "%d\t%zu\t%zu\tctg\t+\t%u\t%zu\t%u\t%zu\n", nb_ctg, assembled.size(), assembled.size() + suffix.size(), c2, c2s.size(), c1_start, c2s.size());
-    } else {
-        suffix = c2s.substr(0, c1_start + 1);
-        LOGF(fp_ann, "%d\t%zu\t%zu\tctg\t-\t%u\t%zu\t%u\t%u\n", nb_ctg, assembled.size(), assembled.size() + suffix.size(), c2, c2s.size(), 0, c1_start + 1);
-        suffix = revcomp(suffix);
+    if (path.size() == 1) {   // a lone anchor is written as it is, whatever its strand in the path, and leaves no annotation
+        Piece whole;
+        whole.contig = path.front().id; whole.n = d.contig_len[whole.contig];
+        cur.pieces.push_back(whole);
+    } else cur.pieces.push_back(to_contig_end(d, path.back(), cursor));
+    cur.to = path.back();
+    out.push_back(std::move(cur));
+    return out;
+}
+
+void render(Run& r, const Record& rec, bool annotate, int id, FILE* fp_asm, FILE* fp_ann, FILE* fp_log) {
+    std::string seq;
+    for (const std::string& n : rec.notes) LOGF(fp_log, "%s", n.c_str());
+    for (const Piece& p : rec.pieces) {
+        const std::string text = p.cns ? *p.cns : slice_text(*r.d, p);
+        if (annotate && p.cns) LOGF(fp_ann, "%d\t%zu\t%zu\tcns\t%zu\t%u\n", id, seq.size(), seq.size() + text.size(), text.size(), p.n_supp);
+        else if (annotate)
+            LOGF(fp_ann, "%d\t%zu\t%zu\tctg\t%c\t%u\t%zu\t%zu\t%zu\n", id, seq.size(), seq.size() + text.size(), "+-"[p.strand], p.contig, (size_t)r.d->contig_len[p.contig],
+                 (size_t)p.ann_lo, (size_t)p.ann_hi);
+        seq += text;
     }
-    assembled += suffix;
-    emit(src, src_strand, c2, s2, assembled);
+    char hdr[128];
+    const int n = snprintf(hdr, sizeof(hdr), ">%d from:%u:%c to:%u:%c\n", id, rec.from.id, "+-"[rec.from.strand], rec.to.id, "+-"[rec.to.strand]);
+    LOGF(fp_log, "%s%s\n\n", hdr, seq.c_str());
+    r.fasta.append(hdr, n); r.fasta += seq; r.fasta.push_back('\n');
+    if (fp_asm) { fputs(hdr, fp_asm); fwrite(seq.data(), 1, seq.size(), fp_asm); fputc('\n', fp_asm); }
+}
+
+// asm_extract_all_simple_paths (Assemble.cpp:757-810): paths start at every node that is not a plain link (one arc on each side)
+std::vector<std::deque<Anchor>> simple_paths(Graph& g) {
+    const uint8_t seen = 21;
+    std::vector<std::deque<Anchor>> paths;
+    auto mark = [&](Anchor a, Anchor b) {
+        const uint32_t v = (a.id << 1) | a.strand, key = (b.id << 1) | b.strand;
+        if (Arc* x = g.find(v, key)) x->flag = seen;
+        if (Arc* x = g.find(Graph::twin_vertex(key), Graph::twin_key(v))) x->flag = seen;
+    };
+    for (uint32_t i = 0; i < g.n_nodes; i++) {
+        const size_t d0 = g.deg(i, 0), d1 = g.deg(i, 1);
+        if (d0 == 1 && d1 == 1) continue;
+        if (d0 > 1 && d1 > 1) paths.push_back({Anchor{0, i}});
+        for (uint32_t side = 0; side < 2; side++)
+            for (size_t k = 0; k < g.adj[(i << 1) | side].size(); k++) {
+                if (g.adj[(i << 1) | side][k].flag == seen) continue;
+                std::deque<Anchor> p{Anchor{side, i}};
+                for (uint32_t key = g.adj[(i << 1) | side][k].key;;) {   // asm_find_simple_path_from_source (Assemble.cpp:607-622)
+                    const Anchor at{key & 1, key >> 1};
+                    p.push_back(at);
+                    if (g.deg(at.id, at.strand) != 1 || g.deg(at.id, 1 - at.strand) > 1) break;
+                    key = g.adj[(at.id << 1) | at.strand][0].key;
+                }
+                for (size_t j = 0; j + 1 < p.size(); j++) mark(p[j], p[j + 1]);
+                if (g.deg(p.front().id, p.front().strand) > 1) p.pop_front();                  // a branching end belongs to no path
+                if (!p.empty() && g.deg(p.back().id, 1 - p.back().strand) > 1) p.pop_back();
+                if (!p.empty()) paths.push_back(std::move(p));
+            }
+    }
+    return paths;
 }
 }  // namespace
 
 static int run_assemble(Run& r) {
     double t0 = now();
-    Graph& g = r.g;
-    const uint8_t mark = 21;
-    std::vector<std::deque<PE>> paths;
-    for (uint32_t i = 0; i < g.n_nodes; i++) {
-        if (g.deg(i, 0) == 1 && g.deg(i, 1) == 1) continue;
-        if (g.deg(i, 0) > 1 && g.deg(i, 1) > 1) paths.push_back({PE{0, i}});
-        for (uint32_t side = 0; side < 2; side++) {
-            for (size_t k = 0; k < g.adj[(i << 1) | side].size(); k++) {
-                if (g.adj[(i << 1) | side][k].flag == mark) continue;
-                std::deque<PE> p;
-                p.push_back({side, i});
-                const Arc* it = &g.adj[(i << 1) | side][k];
-                uint32_t cn = it->key >> 1, cs = it->key & 1;
-                for (;;) {   // asm_find_simple_path_from_source (Assemble.cpp:607-622)
-                    p.push_back({cs, cn});
-                    if (g.deg(cn, cs) == 0) break;
-                    if (g.deg(cn, cs) > 1 || g.deg(cn, 1 - cs) > 1) break;
-                    it = &g.adj[(cn << 1) | cs][0];
-                    cn = it->key >> 1; cs = it->key & 1;
-                }
-                for (size_t j = 0; j + 1 < p.size(); j++) {
-                    uint32_t v = (p[j].id << 1) | p[j].strand, key = (p[j + 1].id << 1) | p[j + 1].strand;
-                    if (Arc* a = g.find(v, key)) a->flag = mark;
-                    if (Arc* tw = g.find(Graph::twin_vertex(key), Graph::twin_key(v))) tw->flag = mark;
-                }
-                if (g.deg(p.front().id, p.front().strand) > 1) p.pop_front();
-                if (!p.empty() && g.deg(p.back().id, 1 - p.back().strand) > 1) p.pop_back();
-                if (!p.empty()) paths.push_back(p);
-            }
-        }
+    if (const size_t miss = missing_results(r)) {
+        g_err = "assemble: " + std::to_string(miss) + " of " + std::to_string(r.res.size()) + " edges have no coordinates / consensus in this run" +
+                (r.shard_world > 1 ? " (multi-GPU: the other ranks' results must be imported first, hxh_run_results_import)" : " (coords and consensus stages must run first)");
+        return -1;
     }
+    const std::vector<std::deque<Anchor>> paths = simple_paths(r.g);
     FILE* fp_asm = open_or_null(r.path("asm.final.fa"), "w");
     FILE* fp_ann = open_or_null(r.path("asm.final.ann"), "w");
     FILE* fp_log = open_or_null(r.path("log_asmfinal.txt"), "w");
     for (size_t i = 0; i < paths.size(); i++)
         LOGF(fp_log, "simple_path %zu size:%zu\tfrom:%u:%c\tto:%u:%c\n", i, paths[i].size(), paths[i].front().id, "+-"[paths[i].front().strand], paths[i].back().id, "+-"[paths[i].back().strand]);
     r.fasta.clear();
-    int nb_ctg = 0;
-    for (auto& p : paths) assemble_path(r, p, nb_ctg, fp_asm, fp_ann, fp_log);
+    int n_out = 0;
+    for (const auto& p : paths)
+        for (const Record& rec : plan_path(r, p)) render(r, rec, p.size() > 1, n_out++, fp_asm, fp_ann, fp_log);
     if (fp_log) fclose(fp_log);
     if (fp_ann) fclose(fp_ann);
     if (fp_asm) fclose(fp_asm);
@@ -386,13 +588,30 @@ extern "C" void hxh_run_set_edge_shard(hxh_run* p, uint32_t rank, uint32_t world
     Run* r = reinterpret_cast<Run*>(p);
     r->shard_rank = rank; r->shard_world = world ? world : 1;
 }
+extern "C" void hxh_run_set_read_shard(hxh_run* p, uint32_t lr_begin) { reinterpret_cast<Run*>(p)->lr_begin = lr_begin; }
+extern "C" int hxh_run_results_export(hxh_run* p, const uint8_t** buf, uint64_t* len) {
+    Run* r = reinterpret_cast<Run*>(p);
+    for (uint32_t gi : r->mine) if (!(r->res[gi].have_coords && r->res[gi].have_cns)) { g_err = "results export: the coords and consensus stages have not run"; return -1; }
+    export_results(*r);
+    *buf = r->blob.data(); *len = r->blob.size();
+    return 0;
+}
+extern "C" int hxh_run_results_import(hxh_run* p, const uint8_t* buf, uint64_t len) { return import_results(*reinterpret_cast<Run*>(p), buf, len); }
+extern "C" uint64_t hxh_run_results_missing(const hxh_run* p) { return missing_results(*reinterpret_cast<const Run*>(p)); }
+extern "C" const char* hxh_run_compact_text(hxh_run* p, uint64_t* len) {
+    Run* r = reinterpret_cast<Run*>(p);
+    r->compact_text = r->have_chain ? compact_lines(*r) : std::string();
+    if (len) *len = r->compact_text.size();
+    return r->compact_text.c_str();
+}
 extern "C" int hxh_run_write_longread_index(const hxh_run* p, const char* path) {
     const Run* r = reinterpret_cast<const Run*>(p);
     if (!r->have_chain) { g_err = "index.longread needs the chain stage"; return -1; }
     return write_longread_index(*r->d, r->chain, path) ? 0 : -1;
 }
 extern "C" void hxh_run_timings(const hxh_run* p, double out[5]) { memcpy(out, reinterpret_cast<const Run*>(p)->t, sizeof(double) * 5); }
-extern "C" uint32_t hxh_run_n_edges(const hxh_run* p) { return (uint32_t)reinterpret_cast<const Run*>(p)->work.size(); }
+extern "C" uint32_t hxh_run_n_edges(const hxh_run* p) { return (uint32_t)reinterpret_cast<const Run*>(p)->mine.size(); }
+extern "C" uint32_t hxh_run_n_edges_total(const hxh_run* p) { return (uint32_t)reinterpret_cast<const Run*>(p)->work.size(); }
 extern "C" const hx_chain_out* hxh_run_chain_out(const hxh_run* p) { return &reinterpret_cast<const Run*>(p)->chain; }
 extern "C" const hx_edges_out* hxh_run_edges_out(const hxh_run* p) { return &reinterpret_cast<const Run*>(p)->edges; }
 extern "C" const hx_coords_out* hxh_run_coords_out(const hxh_run* p) { return &reinterpret_cast<const Run*>(p)->coords; }

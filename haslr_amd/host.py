@@ -41,6 +41,15 @@ def lib():
         for name in ("chain", "graph", "coords", "consensus", "assemble", "all"):
             getattr(L, "hxh_run_" + name).argtypes = [C.c_void_p]
         L.hxh_run_set_edge_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.hxh_run_set_read_shard.argtypes = [C.c_void_p, C.c_uint32]
+        L.hxh_run_results_export.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
+        L.hxh_run_results_import.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+        L.hxh_run_results_missing.argtypes = [C.c_void_p]
+        L.hxh_run_results_missing.restype = C.c_uint64
+        L.hxh_run_compact_text.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.hxh_run_compact_text.restype = C.POINTER(C.c_char)
+        L.hxh_run_n_edges_total.argtypes = [C.c_void_p]
+        L.hxh_run_n_edges_total.restype = C.c_uint32
         L.hxh_run_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double * 5)]
         L.hxh_run_n_edges.argtypes = [C.c_void_p]
         L.hxh_run_n_edges.restype = C.c_uint32
@@ -123,6 +132,31 @@ class Run:
 
     def set_edge_shard(self, rank, world):
         lib().hxh_run_set_edge_shard(self._h, rank, world)
+
+    def set_read_shard(self, lr_begin):
+        lib().hxh_run_set_read_shard(self._h, lr_begin)
+
+    def results_export(self):
+        """bytes: coordinates + consensus of this run's share of the edges (multi-GPU)"""
+        p, n = C.POINTER(C.c_uint8)(), C.c_uint64()
+        if lib().hxh_run_results_export(self._h, C.byref(p), C.byref(n)) != 0:
+            raise HostError(lib().hxh_last_error().decode())
+        return C.string_at(p, n.value)
+
+    def results_import(self, blob):
+        if lib().hxh_run_results_import(self._h, blob, len(blob)) != 0:
+            raise HostError(lib().hxh_last_error().decode())
+
+    @property
+    def results_missing(self): return lib().hxh_run_results_missing(self._h)
+
+    def compact_text(self):
+        n = C.c_uint64()
+        p = lib().hxh_run_compact_text(self._h, C.byref(n))
+        return C.string_at(p, n.value)
+
+    @property
+    def n_edges_total(self): return lib().hxh_run_n_edges_total(self._h)
 
     def write_longread_index(self, path):
         """index.longread (the reference's cache file): needs chain()"""
