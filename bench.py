@@ -3,21 +3,28 @@
 
 A step is one pass of the hot path over one resident batch of synthetic input:
     chain (filters/sort/dedup/trim/chain, K1-K3) -> edge-support multiset + sort (K4) -> host graph cleaning
-    -> edge coordinates (K5) -> POA consensus (K6)
+    -> edge coordinates (K5) -> POA consensus (K6) [-> N>1: all-gather of the per-edge results]
 i.e. reference stages main.cpp:115-208: from "inputs parsed and resident" to "all cns_seq
-computed". Inputs are uploaded to HBM before the timed region. `value` = long-read bases in the data set
-x steps / wall time (max over ranks).
+computed" (on every rank, when there are several). Inputs are uploaded to HBM before the timed region.
+`value` = long-read bases in the data set x steps / wall time (max over ranks).
 
-N=1 workload: BASELINE.json configs[1] — E. coli-size 4.6 Mb genome, PacBio-like 25x reads, synthetic
-(real E. coli reads cannot be fetched here; tools/hxsim generates contigs + reads + PAF from a seed).
-N>1 (weak scaling): genome of N x 4.6 Mb, reads sharded by id range, ONE all-gather of edge records (RCCL),
-edges sharded for coordinates + consensus.
+N=1 workload: BASELINE.json configs[2], the largest single-GPU configuration — S. cerevisiae-size 12 Mb genome,
+Nanopore-like 25x long reads + PAF against short-read contigs, synthetic (tools/hxsim, seed 0x4841534c + 2;
+there is no network for real reads). configs[1] (E. coli-size 4.6 Mb, PacBio-like 25x) is measured too and
+reported under "configs1" (`--workload ecoli` makes it the main line instead).
+N>1 (weak scaling): genome of N x 12 Mb, reads sharded by id range, ONE all-gather of edge records (RCCL),
+edges sharded by estimated DP cost for coordinates + consensus, one all-gather of the results; after the
+timed steps every rank stitches the assembly, the ranks' assemblies must be identical, and rank 0 repeats the
+pass on its GPU alone and requires the same assembly (`assembly.matches_single_gpu`).
 
 Extra objects on the JSON line: `roofline` for the dominant kernel (K6 POA; HBM bound named by the north
 star, algorithmic bytes per SURVEY.md 8d) with GCUPS as the secondary figure, and `cpu_baseline` (the
-CPU oracle = a port of the reference path, timed on this box's host cores on a bounded sample).
+CPU oracle = a port of the reference path with AVX2 row kernels, timed on this box's host cores on the SAME
+data set, 64 threads and all cores; its consensus must equal the GPU's).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import subprocess
@@ -28,61 +35,105 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before HIP initialises (see haslr_amd/hip.py)
 
-GENOME_PER_GPU = 4_600_000
-SEED = 0x4841534C + 1   # seed = 0x4841534c + config index
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SEED0 = 0x4841534C                                # seed = 0x4841534c + config index
+WORKLOADS = {
+    "yeast": dict(config=2, genome=12_000_000, model="nanopore", name="S. cerevisiae-size synthetic", variants="1.5"),
+    "ecoli": dict(config=1, genome=4_600_000, model="pacbio", name="E. coli-size synthetic", variants="1.5"),
+}
+HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9         # 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz (int32 VALU issue bound)
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def make_dataset(genome_len, seed, tag):
+def make_dataset(wl, genome_len, tag):
     d = os.environ.get("HASLR_BENCH_DIR", "/tmp/haslr_bench")
     os.makedirs(d, exist_ok=True)
-    pre = os.path.join(d, f"{tag}_g{genome_len}_s{seed:x}")
+    seed = SEED0 + wl["config"]
+    pre = os.path.join(d, f"{tag}_{wl['model']}_g{genome_len}_s{seed:x}")
     if not all(os.path.exists(pre + s) for s in (".contigs.fa", ".reads.fa", ".paf", ".done")):
         sim = os.path.join(ROOT, "tools", "hxsim")
         if not os.path.exists(sim):
             import __graft_entry__
             __graft_entry__.build()
-        subprocess.check_call([sim, "--genome-len", str(genome_len), "--seed", hex(seed), "--model", "pacbio", "--cov", "25",
-                               "--variant-per-mb", "1.5", "--out-prefix", pre], stderr=subprocess.DEVNULL)
+        subprocess.check_call([sim, "--genome-len", str(genome_len), "--seed", hex(seed), "--model", wl["model"], "--cov", "25",
+                               "--variant-per-mb", wl["variants"], "--out-prefix", pre], stderr=subprocess.DEVNULL)
         open(pre + ".done", "w").close()
     return pre
 
 
-def cpu_baseline(threads):
-    """The oracle (kind "port") on a bounded sample of the same workload: a 600 kb genome with the same
-    generator settings, all host threads, same timed region."""
+def cpu_baseline(ds, gpu_cns):
+    """The oracle (kind "port": the CPU restatement of the reference path, AVX2 row kernels where the host has them,
+    edges dealt to the threads costliest first) on the SAME data set and timed region as the GPU line, twice:
+    min(64, cores) threads - the thread count the north star quotes the reference at - and all cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from haslr_amd import host
     import orclib
-    glen = int(os.environ.get("HASLR_BENCH_CPU_GENOME", "600000"))
-    pre = make_dataset(glen, SEED, "cpu")
-    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
-    be = orclib.OracleBackend(ds, threads)
-    run = host.Run(ds, ds.params(), be.table, None)
+    ncpu = os.cpu_count() or 1
+    runs = []
+    for threads in sorted({min(64, ncpu), ncpu}):
+        be = orclib.OracleBackend(ds, threads)
+        run = host.Run(ds, ds.params(), be.table, None)
+        t0 = time.perf_counter()
+        run.chain(); run.graph(); run.coords(); run.consensus()
+        dt = time.perf_counter() - t0
+        st = run.cns_stats()
+        runs.append({"threads": threads, "seconds": dt, "value": ds.total_read_bases / dt, "gcups": st["dp_cells"] / dt / 1e9,
+                     "stage_s": run.timings(), "consensus_equals_gpu": run.cns_out() == gpu_cns})
+        n_edges = run.n_edges
+        run.close(); be.close()
+    main = runs[0]
+    return {"value": main["value"], "unit": "long-read bases/s", "cores": main["threads"], "kind": "port",
+            "sample": f"the whole data set of this line ({ds.reads.n} reads / {ds.total_read_bases} bases, {n_edges} edges), same timed region "
+                      f"(chain -> graph -> coordinates -> consensus); oracle/liboracle.so, POA row kernels {orclib.lib().orc_poa_kernel_name().decode()}, "
+                      f"{main['threads']} threads over edges (costliest first) in {main['seconds']:.2f} s",
+            "gcups": main["gcups"], "consensus_equals_gpu": all(r["consensus_equals_gpu"] for r in runs), "host_cores": ncpu, "runs": runs,
+            "note": "stand-in for '64-thread CPU haslr_assemble' (the reference cannot be built here: spoa 1.1.3 is not vendored); int32 AVX2 lanes, "
+                    "spoa's engine would use int16 lanes where scores fit"}
+
+
+def measure(ctx, ds, prm, table, steps, warmup, world, rank, sync, gather, lr_begin):
+    """`warmup` untimed + `steps` timed passes; returns (seconds, last run)."""
+    from haslr_amd import host
+
+    def step():
+        run = host.Run(ds, prm, table, None)
+        if world > 1:
+            run.set_edge_shard(rank, world)
+            run.set_read_shard(lr_begin)
+        run.chain(); run.graph(); run.coords(); run.consensus()
+        if world > 1:
+            gather(run)
+        return run
+
+    for _ in range(warmup):
+        step().close()
+    ctx.timing_reset()
+    sync()
     t0 = time.perf_counter()
-    run.chain(); run.graph(); run.coords(); run.consensus()
-    dt = time.perf_counter() - t0
-    st = run.cns_stats()
-    out = {"value": ds.total_read_bases / dt, "unit": "long-read bases/s", "cores": threads, "kind": "port",
-           "sample": f"synthetic {glen} bp genome, PacBio-like 25x, {ds.reads.n} reads / {ds.total_read_bases} bases, {run.n_edges} edges, "
-                     f"{st['dp_cells']} POA cells; oracle/liboracle.so (scalar C++ restatement, {threads} threads over edges) in {dt:.2f} s",
-           "gcups": st["dp_cells"] / dt / 1e9}
-    run.close(); be.close(); ds.close()
-    return out
+    last = None
+    for _ in range(steps):
+        if last is not None:
+            last.close()
+        ts = time.perf_counter()
+        last = step()
+        log(f"[rank {rank}] step {time.perf_counter() - ts:.3f} s  stages {last.timings()}")
+    sync()
+    return time.perf_counter() - t0, last
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="yeast")
     ap.add_argument("--genome-len", type=int, default=0, help="override the per-run genome length (testing)")
     ap.add_argument("--poa-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs1", action="store_true", help="skip the extra E. coli-size (configs[1]) measurement")
     args = ap.parse_args()
 
     import torch
@@ -92,24 +143,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
     torch.zeros(1, device="cuda")   # initialise torch's HIP context (streams, queues) now, not inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=device)
 
-    glen = args.genome_len or GENOME_PER_GPU * world
+    wl = WORKLOADS[args.workload]
+    glen = args.genome_len or wl["genome"] * world
     if rank == 0:
-        pre = make_dataset(glen, SEED, "gpu")
+        make_dataset(wl, glen, "gpu")
     if world > 1:
         dist.barrier()
-    pre = make_dataset(glen, SEED, "gpu")
+    pre = make_dataset(wl, glen, "gpu")
     t0 = time.perf_counter()
     ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")   # multi-threaded ingest, automatic thread count
     t_parse = time.perf_counter() - t0
@@ -123,14 +175,19 @@ def main():
     t_upload = time.perf_counter() - t1
     log(f"[rank {rank}] dataset {pre}: {ds.reads.n} reads, {ds.total_read_bases} bases, {ds.hits.n} PAF records; parse {t_parse:.2f} s ({in_bytes / 1e6 / t_parse:.0f} MB/s), upload {t_upload:.2f} s")
 
+    lr_begin, gathered = 0, [0]
     if world > 1:
         from haslr_amd import distributed as hd
         b = hd.shard_bounds(ds.read_hit_off, ds.reads.n, world)
         ctx.set_read_shard(b[rank], b[rank + 1])
-        backend = hd.ShardedBackend(ctx, prm)
+        lr_begin = b[rank]
+        backend = hd.ShardedBackend(ctx.backend(), hd.HipRecords(ctx, prm))
         table = backend.table
+
+        def gather(run):
+            gathered[0] = hd.gather_results(run, device)
     else:
-        table = ctx.backend()
+        table, gather = ctx.backend(), None
 
     def sync():
         torch.cuda.synchronize()
@@ -138,27 +195,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def step():
-        run = host.Run(ds, prm, table, None)
-        if world > 1:
-            run.set_edge_shard(rank, world)
-        run.chain(); run.graph(); run.coords(); run.consensus()
-        return run
-
-    for _ in range(args.warmup):
-        step().close()
-    ctx.timing_reset()
-    sync()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        if last is not None:
-            last.close()
-        ts = time.perf_counter()
-        last = step()
-        log(f"[rank {rank}] step {time.perf_counter() - ts:.3f} s  stages {last.timings()}")
-    sync()
-    dt = time.perf_counter() - t0
+    dt, last = measure(ctx, ds, prm, table, args.steps, args.warmup, world, rank, sync, gather, lr_begin)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -178,46 +215,93 @@ def main():
     cells, seq_bases, alg_bytes, n_edges = [float(x) for x in stats.tolist()]
     poa_ms = float(tms.item())
     achieved = alg_bytes / (poa_ms / 1e3) / 1e9 if poa_ms > 0 else 0.0
+    phase = ctx.poa_phase_cycles()
+    stage_ms = {k: v * 1e3 for k, v in last.timings().items()}
+    kernel_ms = {k: v["ms"] / max(1, v["launches"]) for k, v in tim.items()}
+
+    # ---- the assembly (outside the timed region): every rank stitches; N>1: identical on all ranks and equal to a single-GPU pass
+    last.assemble()
+    fasta = last.assembly_fasta()
+    sha = hashlib.sha256(fasta.encode()).hexdigest()
+    assembly = {"sha256": sha, "contigs": fasta.count(">"), "bases": sum(len(x) for x in fasta.split("\n") if x and x[0] != ">")}
+    if world > 1:
+        h = torch.frombuffer(bytearray(bytes.fromhex(sha)), dtype=torch.uint8).to(device)
+        hs = [torch.zeros(32, dtype=torch.uint8, device=device) for _ in range(world)]
+        dist.all_gather(hs, h)
+        assembly["same_on_all_ranks"] = all(bool(torch.equal(hs[0], x)) for x in hs)
+        assembly["results_gathered_bytes"] = gathered[0]
+        assembly["edge_record_exchange_bytes"] = backend.exchange_bytes
+        if rank == 0:
+            last.close()
+            ctx.set_read_shard(0, ds.reads.n)
+            t0 = time.perf_counter()
+            solo = host.Run(ds, prm, ctx.backend(), None)
+            solo.all()
+            assembly["single_gpu_pass_s"] = time.perf_counter() - t0
+            assembly["matches_single_gpu"] = hashlib.sha256(solo.assembly_fasta().encode()).hexdigest() == sha
+            last = solo
+        dist.barrier()
+        if not assembly["same_on_all_ranks"] or (rank == 0 and not assembly["matches_single_gpu"]):
+            raise SystemExit(f"[rank {rank}] multi-GPU assembly differs: {assembly}")
 
     # HBM traffic of the POA launch group: measured offline with rocprofv3 PMC passes for exactly this workload (profiles/*_traffic.json)
     traffic, traffic_src = None, None
     if world == 1 and not args.genome_len:
-        import glob
-        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-        if cand:
+        for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
             try:
-                traffic = json.load(open(cand[-1]))["hbm_bytes_raw"]
-                traffic_src = os.path.relpath(cand[-1], ROOT)
+                t = json.load(open(cand))
+                if t.get("bench_workload", "ecoli") == args.workload:
+                    traffic, traffic_src = t["hbm_bytes_raw"], os.path.relpath(cand, ROOT)
+                    break
             except Exception:  # noqa: BLE001
-                traffic = None
+                pass
     if rank == 0:
         value = ds.total_read_bases * args.steps / dt
+        gcups = cells / (poa_ms / 1e3) / 1e9 if poa_ms > 0 else 0.0
         line = {
             "metric": "long-read bases/sec through backbone+consensus; GFA match + FASTA %identity",
             "value": value, "unit": "long-read bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"E. coli-size synthetic: {glen} bp genome, PacBio-like 25x long reads + PAF vs short-read contigs "
-                                   f"(BASELINE.json configs[1]{' x%d, read-sharded' % world if world > 1 else ''})",
+            "config": {"workload": f"{wl['name']}: {glen} bp genome, {wl['model']}-like 25x long reads + PAF vs short-read contigs "
+                                   f"(BASELINE.json configs[{wl['config']}]{' x%d, read-sharded' % world if world > 1 else ''})",
                        "reads": ds.reads.n, "long_read_bases": ds.total_read_bases, "paf_records": ds.hits.n, "edges": int(n_edges),
-                       "poa_block_threads": args.poa_block or 256, "parallelism": f"reads+edges sharded x{world}, 1 all-gather" if world > 1 else "single GPU"},
+                       "poa_block_threads": args.poa_block or "auto", "parallelism": f"reads+edges sharded x{world}, 1 all-gather of edge records + 1 of results" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_poa (launch group: one kernel per lane-count class, concurrent)", "kernel_ms_per_launch": poa_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "gcups": cells / (poa_ms / 1e3) / 1e9 if poa_ms > 0 else 0.0, "dp_cells_per_launch": cells,
-                         "note": "POA is an O(L^2) integer DP over O(L) bytes: HBM fraction is low by construction (SURVEY.md 8d); GCUPS is the figure of merit"},
-            "stage_ms": {k: v * 1e3 for k, v in last.timings().items()},
-            "kernel_ms": {k: v["ms"] / max(1, v["launches"]) for k, v in tim.items()},
-            "poa_phase_cycles": ctx.poa_phase_cycles(),
+                         "gcups": gcups, "dp_cells_per_launch": cells, "valu_bound_gcups": VALU_PEAK_LANE_OPS / 10 / 1e9, "frac_of_valu_bound": gcups / (VALU_PEAK_LANE_OPS / 10 / 1e9),
+                         "note": "POA is an O(L^2) integer DP over O(L) bytes: HBM fraction is low by construction (SURVEY.md 8d); GCUPS against the int32 VALU issue bound (10 lane-ops per cell) is the figure of merit"},
+            "stage_ms": stage_ms, "kernel_ms": kernel_ms, "poa_phase_cycles": phase, "assembly": assembly,
             # outside the timed region (the metric starts with parsed, resident inputs): text ingest and the PCIe upload
             "ingest": {"seconds": t_parse, "input_mb": in_bytes / 1e6, "mb_per_s": in_bytes / 1e6 / t_parse, "threads": os.environ.get("HASLR_IO_THREADS", "auto (<= 16)"), "upload_seconds": t_upload},
         }
         if not args.no_cpu_baseline and world == 1:
             try:
-                line["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+                line["cpu_baseline"] = cpu_baseline(ds, cns)
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"error": str(e)}
+        if not args.no_configs1 and world == 1 and args.workload != "ecoli" and not args.genome_len:
+            # BASELINE.json configs[1] (the correctness-gate configuration) on the same GPU: short extra measurement
+            try:
+                last.close(); ds.close()
+                w1 = WORKLOADS["ecoli"]
+                pre1 = make_dataset(w1, w1["genome"], "gpu")
+                ds1 = host.Dataset(pre1 + ".contigs.fa", pre1 + ".reads.fa", pre1 + ".paf")
+                ctx.upload(ds1)
+                dt1, run1 = measure(ctx, ds1, ds1.params(), ctx.backend(), 3, 1, 1, 0, sync, None, 0)
+                tm1 = ctx.timing()
+                c1 = run1.cns_stats()["dp_cells"]
+                p1 = tm1["poa"]["ms"] / max(1, tm1["poa"]["launches"])
+                line["configs1"] = {"workload": f"{w1['name']}: {w1['genome']} bp genome, pacbio-like 25x (BASELINE.json configs[1])", "value": ds1.total_read_bases * 3 / dt1,
+                                    "ms_per_step": dt1 / 3 * 1e3, "steps": 3, "warmup": 1, "edges": run1.n_edges, "kernel_ms_per_launch": p1, "gcups": c1 / (p1 / 1e3) / 1e9,
+                                    "long_read_bases": ds1.total_read_bases}
+                run1.close(); ds1.close()
+                last = None
+            except Exception as e:  # noqa: BLE001
+                line["configs1"] = {"error": str(e)}
         print(json.dumps(line), flush=True)
-    last.close()
+    if last is not None:
+        last.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

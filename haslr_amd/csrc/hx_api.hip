@@ -411,6 +411,7 @@ extern "C" int hx_edge_records_export(hx_ctx* c, void* dst, uint64_t cap) {
 
 extern "C" int hx_edge_records_import(hx_ctx* c, const void* src, uint64_t n, hx_edges_out* out) {
     memset(out, 0, sizeof(*out));
+    if (n & 1) return fail("hx_edge_records_import: records come in (forward, twin) pairs, the count must be even");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(c->rec_un.reserve(n));
     hxk::edge_unpack((const uint32_t*)src, n, c->rec_un.view(), c->stream);
@@ -486,13 +487,25 @@ extern "C" void hx_free_coords(hx_ctx*, hx_coords_out* o) {
 
 // ================================================================================================ K6
 
-extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out) {
+namespace {
+// what the POA stage reads: the supports of every edge (the cns_supp lists of Assemble.cpp:503-543) and the read set they point into
+struct PoaInput {
+    uint32_t n_edge;
+    const uint64_t* supp_off;
+    const uint32_t *supp_lr, *spos, *epos;
+    const uint32_t* h_rlen;       // host copy of the read lengths
+    const uint8_t* d_packed;      // device: 2-bit reads, their byte offsets and lengths
+    const uint64_t* d_roff;
+    const uint32_t* d_rlen;
+};
+}  // namespace
+
+static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp, hx_cns_out* out) {
     const auto dbg_t0 = std::chrono::steady_clock::now();
     memset(out, 0, sizeof(*out));
-    if (!c->have_coords) return fail("hx_poa_batch: hx_edge_coords has not run");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    const uint32_t ne = c->n_sel;
+    const uint32_t ne = in.n_edge;
     // ---- plan: the sub-sequence rule of Assemble.cpp:530-537 (u32 wrap + substr clamp; empty ones skipped)
     PoaPlan P;
     P.edges.resize(ne); P.sumL.assign(ne, 0); P.nseq.assign(ne, 0);
@@ -501,9 +514,9 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
         hxk::PoaEdge& E = P.edges[e];
         memset(&E, 0, sizeof(E));
         E.seq_begin = (uint32_t)P.seqs.size();
-        for (uint64_t k = c->h_supp_off[e]; k < c->h_supp_off[e + 1]; k++) {
-            uint32_t rid = c->h_supp_lr[k] & 0x7fffffffu, strand = c->h_supp_lr[k] >> 31;
-            uint32_t rl = c->h_rlen[rid], sp = c->h_spos[k], ep = c->h_epos[k];
+        for (uint64_t k = in.supp_off[e]; k < in.supp_off[e + 1]; k++) {
+            uint32_t rid = in.supp_lr[k] & 0x7fffffffu, strand = in.supp_lr[k] >> 31;
+            uint32_t rl = in.h_rlen[rid], sp = in.spos[k], ep = in.epos[k];
             if (sp > rl) return fail("hx_poa_batch: consensus support starts beyond its read (the reference would throw std::out_of_range, Assemble.cpp:530)");
             uint32_t want = ep - sp + 1, n = std::min(want, rl - sp);
             if (n == 0) continue;
@@ -777,7 +790,7 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
                 for (uint32_t e : cls_list[k]) c->dbg_cls[e] = (uint8_t)k;
                 c->dbg_ring[k] = R;
                 HIPCHK(hipStreamWaitEvent(c->poa_streams[sk], c->poa_ev[6], 0));
-                hxk::poa_run(d_edges.p, d_order.p + opos, (uint32_t)cls_blocks[k], d_seqs.p, c->packed.p, c->roff.p, c->rlen.p, pools, 0, pp->match, pp->mismatch,
+                hxk::poa_run(d_edges.p, d_order.p + opos, (uint32_t)cls_blocks[k], d_seqs.p, in.d_packed, in.d_roff, in.d_rlen, pools, 0, pp->match, pp->mismatch,
                              pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)nt, R, (uint32_t)lds_bytes, nt >= 1024 && cls_cm[k] > 8u, k < 6, max_indeg, c->poa_streams[sk]);
                 HIPCHK(hipEventRecord(c->poa_ev[sk], c->poa_streams[sk]));
                 HIPCHK(hipStreamWaitEvent(s, c->poa_ev[sk], 0));
@@ -827,6 +840,51 @@ extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out)
     for (uint32_t e = 0; e < ne; e++) memcpy(out->cns + off[e], cns[e].data(), cns[e].size());
     out->dp_cells = cells; out->seq_bases = seq_bases; out->n_aligned = n_aligned;
     return 0;
+}
+
+extern "C" int hx_poa_batch(hx_ctx* c, const hx_poa_params* pp, hx_cns_out* out) {
+    memset(out, 0, sizeof(*out));
+    if (!c->have_coords) return fail("hx_poa_batch: hx_edge_coords has not run");
+    const PoaInput in{c->n_sel, c->h_supp_off.data(), c->h_supp_lr.data(), c->h_spos.data(), c->h_epos.data(), c->h_rlen.data(), c->packed.p, c->roff.p, c->rlen.p};
+    return poa_consensus(c, in, pp, out);
+}
+
+extern "C" int hx_poa_supports(hx_ctx* c, const hx_coords_out* sup, const hx_poa_params* pp, hx_cns_out* out) {
+    memset(out, 0, sizeof(*out));
+    if (!c->n_reads) return fail("hx_poa_supports: no reads are resident (hx_upload)");
+    for (uint64_t k = 0; k < sup->supp_off[sup->n_edge]; k++)
+        if ((sup->supp_lr[k] & 0x7fffffffu) >= c->n_reads) return fail("hx_poa_supports: long-read id out of range");
+    const PoaInput in{sup->n_edge, sup->supp_off, sup->supp_lr, sup->spos, sup->epos, c->h_rlen.data(), c->packed.p, c->roff.p, c->rlen.p};
+    return poa_consensus(c, in, pp, out);
+}
+
+extern "C" int hx_poa_sequences(hx_ctx* c, uint32_t n_sets, const uint64_t* set_off, const uint64_t* seq_off, const char* bases, const hx_poa_params* pp, hx_cns_out* out) {
+    memset(out, 0, sizeof(*out));
+    HIPCHK(hipSetDevice(c->device));
+    const uint64_t nseq = set_off[n_sets];
+    if (nseq >= 0x7fffffffULL) return fail("hx_poa_sequences: too many sequences");
+    // pack like the long reads (2 bits, A0 C1 G2 T3, anything else A; every sequence on a 4-byte boundary) and align them whole, forward
+    std::vector<uint32_t> len(nseq), lr(nseq), sp(nseq, 0), ep(nseq);
+    std::vector<uint64_t> off(nseq + 1, 0);
+    for (uint64_t i = 0; i < nseq; i++) {
+        const uint64_t L = seq_off[i + 1] - seq_off[i];
+        if (L >= 0xffffffffULL) return fail("hx_poa_sequences: sequence too long");
+        len[i] = (uint32_t)L; lr[i] = (uint32_t)i; ep[i] = (uint32_t)L - 1;   // an empty sequence gives epos = spos - 1: skipped, as in the reference (Assemble.cpp:537)
+        off[i + 1] = off[i] + ((L + 15) / 16) * 4;
+    }
+    std::vector<uint8_t> packed(std::max<uint64_t>(4, off[nseq]), 0);
+    for (uint64_t i = 0; i < nseq; i++)
+        for (uint32_t j = 0; j < len[i]; j++) {
+            const char ch = bases[seq_off[i] + j];
+            const uint8_t code = ch == 'C' || ch == 'c' ? 1 : ch == 'G' || ch == 'g' ? 2 : ch == 'T' || ch == 't' ? 3 : 0;
+            packed[off[i] + (j >> 2)] |= (uint8_t)(code << ((j & 3) * 2));
+        }
+    DV<uint8_t> d_packed; DV<uint64_t> d_off; DV<uint32_t> d_len;
+    if (up(d_packed, packed.data(), packed.size()) || up(d_off, off.data(), off.size()) || up(d_len, len.data(), std::max<size_t>(1, len.size()))) return -1;
+    const PoaInput in{n_sets, set_off, lr.data(), sp.data(), ep.data(), len.data(), d_packed.p, d_off.p, d_len.p};
+    const int rc = poa_consensus(c, in, pp, out);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return rc;
 }
 
 extern "C" void hx_free_cns(hx_ctx*, hx_cns_out* o) { free(o->cns_off); free(o->cns); memset(o, 0, sizeof(*o)); }

@@ -5,7 +5,7 @@
 // per-edge vectors inside std::map nodes; here they are written once to a flat SoA multiset, sorted by the
 // 64-bit edge key with a stable radix sort (emission order = read asc, pair asc, forward before twin, which
 // is exactly the reference's push order), and segmented into edges. Records carry a copy of both anchor
-// alignments so that they stay meaningful after the multi-GPU all-gather.
+// alignments so that they stay meaningful after the multi-GPU all-gather (the alignment table is per rank).
 #include "kernels.h"
 
 namespace hxk {
@@ -91,30 +91,43 @@ __global__ void k_segment_scatter(const uint64_t* __restrict__ key, const uint64
     if (i == n - 1) edge_off[fs[n]] = n;
 }
 
-// packed exchange layout (multi-GPU all-gather): 28 dwords per record
+// packed exchange layout (multi-GPU all-gather). Records are emitted in pairs (forward, twin) that hold the same two anchor alignments
+// with head and tail swapped, so a pair travels as ONE unit of 22 dwords = 44 bytes per record (the 112-byte record of round 1 carried
+// both copies, 64-bit CIGAR ends and a byte per dword):
+//   0-1  forward key (low = vertex entered at the tail anchor, high = vertex left at the head anchor)
+//   2    long-read id        3  compact indices, head | tail << 16 (a read has at most 10 000 chainable hits, Longread.cpp:529)
+//   4-12 head anchor, 13-21 tail anchor: q_start, q_end, t_start, t_end, cg_begin (64 bit), cg_end - cg_begin, skip_front, skip_back
+// is_rev of an anchor is the low bit of its key half. The twin's fields follow from the forward record's (Backbone_graph.cpp:10-25).
 __device__ __forceinline__ void pack_side(uint32_t* w, const DevSide& s, uint64_t i) {
-    w[0] = s.q_start[i]; w[1] = s.q_end[i]; w[2] = s.t_start[i]; w[3] = s.t_end[i]; w[4] = s.is_rev[i];
-    w[5] = (uint32_t)s.cg_begin[i]; w[6] = (uint32_t)(s.cg_begin[i] >> 32); w[7] = (uint32_t)s.cg_end[i]; w[8] = (uint32_t)(s.cg_end[i] >> 32);
-    w[9] = s.cg_skip_front[i]; w[10] = s.cg_skip_back[i];
+    w[0] = s.q_start[i]; w[1] = s.q_end[i]; w[2] = s.t_start[i]; w[3] = s.t_end[i];
+    w[4] = (uint32_t)s.cg_begin[i]; w[5] = (uint32_t)(s.cg_begin[i] >> 32); w[6] = (uint32_t)(s.cg_end[i] - s.cg_begin[i]);
+    w[7] = s.cg_skip_front[i]; w[8] = s.cg_skip_back[i];
 }
-__device__ __forceinline__ void unpack_side(const uint32_t* w, const DevSide& s, uint64_t i) {
-    s.q_start[i] = w[0]; s.q_end[i] = w[1]; s.t_start[i] = w[2]; s.t_end[i] = w[3]; s.is_rev[i] = (uint8_t)w[4];
-    s.cg_begin[i] = w[5] | ((uint64_t)w[6] << 32); s.cg_end[i] = w[7] | ((uint64_t)w[8] << 32);
-    s.cg_skip_front[i] = w[9]; s.cg_skip_back[i] = w[10];
+__device__ __forceinline__ void unpack_side(const uint32_t* w, uint32_t is_rev, const DevSide& s, uint64_t i) {
+    s.q_start[i] = w[0]; s.q_end[i] = w[1]; s.t_start[i] = w[2]; s.t_end[i] = w[3]; s.is_rev[i] = (uint8_t)is_rev;
+    const uint64_t cb = w[4] | ((uint64_t)w[5] << 32);
+    s.cg_begin[i] = cb; s.cg_end[i] = cb + w[6];
+    s.cg_skip_front[i] = w[7]; s.cg_skip_back[i] = w[8];
 }
-__global__ void k_edge_pack(EdgeRecs r, uint64_t n, uint32_t* dst) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t* w = dst + i * EDGE_REC_WORDS;
-    w[0] = (uint32_t)r.key[i]; w[1] = (uint32_t)(r.key[i] >> 32); w[2] = r.lr[i]; w[3] = r.cmp_head[i]; w[4] = r.cmp_tail[i]; w[5] = 0;
-    pack_side(w + 6, r.head, i); pack_side(w + 17, r.tail, i);
+__global__ void k_edge_pack(EdgeRecs r, uint64_t n_pairs, uint32_t* dst) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint64_t i = 2 * p;   // the forward record of the pair
+    uint32_t* w = dst + p * (2 * EDGE_REC_WORDS);
+    w[0] = (uint32_t)r.key[i]; w[1] = (uint32_t)(r.key[i] >> 32); w[2] = r.lr[i]; w[3] = r.cmp_head[i] | (r.cmp_tail[i] << 16);
+    pack_side(w + 4, r.head, i); pack_side(w + 13, r.tail, i);
 }
-__global__ void k_edge_unpack(const uint32_t* src, uint64_t n, EdgeRecs r) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t* w = src + i * EDGE_REC_WORDS;
-    r.key[i] = w[0] | ((uint64_t)w[1] << 32); r.lr[i] = w[2]; r.cmp_head[i] = w[3]; r.cmp_tail[i] = w[4];
-    unpack_side(w + 6, r.head, i); unpack_side(w + 17, r.tail, i);
+__global__ void k_edge_unpack(const uint32_t* src, uint64_t n_pairs, EdgeRecs r) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t* w = src + p * (2 * EDGE_REC_WORDS);
+    const uint32_t v2 = w[0], v1 = w[1], ih = w[3] & 0xffffu, it = w[3] >> 16;   // v1 = n1<<1|rev1 (head), v2 = n2<<1|rev2 (tail)
+    uint64_t i = 2 * p;
+    r.key[i] = ((uint64_t)v1 << 32) | v2; r.lr[i] = w[2]; r.cmp_head[i] = ih; r.cmp_tail[i] = it;
+    unpack_side(w + 4, v1 & 1u, r.head, i); unpack_side(w + 13, v2 & 1u, r.tail, i);
+    i++;                                                                          // the twin: leaves n2 by its other end, enters n1 reversed
+    r.key[i] = ((uint64_t)(v2 ^ 1u) << 32) | (v1 ^ 1u); r.lr[i] = w[2] | 0x80000000u; r.cmp_head[i] = it; r.cmp_tail[i] = ih;
+    unpack_side(w + 13, v2 & 1u, r.head, i); unpack_side(w + 4, v1 & 1u, r.tail, i);
 }
 
 inline unsigned grid_for(uint64_t n, int t) { return (unsigned)((n + t - 1) / t); }
@@ -132,8 +145,8 @@ void edge_emit(const DevHits& h, const uint8_t* cls, const ChainFinal& c, const 
 void edge_gather(const EdgeRecs& in, const uint32_t* perm, uint64_t n, const EdgeRecs& out, hipStream_t s) {
     if (n) k_edge_gather<<<grid_for(n, 256), 256, 0, s>>>(in, perm, n, out);
 }
-void edge_pack(const EdgeRecs& r, uint64_t n, uint32_t* dst, hipStream_t s) { if (n) k_edge_pack<<<grid_for(n, 256), 256, 0, s>>>(r, n, dst); }
-void edge_unpack(const uint32_t* src, uint64_t n, const EdgeRecs& r, hipStream_t s) { if (n) k_edge_unpack<<<grid_for(n, 256), 256, 0, s>>>(src, n, r); }
+void edge_pack(const EdgeRecs& r, uint64_t n, uint32_t* dst, hipStream_t s) { if (n) k_edge_pack<<<grid_for(n / 2, 256), 256, 0, s>>>(r, n / 2, dst); }
+void edge_unpack(const uint32_t* src, uint64_t n, const EdgeRecs& r, hipStream_t s) { if (n) k_edge_unpack<<<grid_for(n / 2, 256), 256, 0, s>>>(src, n / 2, r); }
 void iota_u32(uint32_t* p, uint64_t n, hipStream_t s) { if (n) k_iota<<<grid_for(n, 256), 256, 0, s>>>(p, n); }
 void segment_flags(const uint64_t* key, uint64_t n, uint32_t* flag, hipStream_t s) { if (n) k_segment_flags<<<grid_for(n, 256), 256, 0, s>>>(key, n, flag); }
 void segment_scatter(const uint64_t* key, const uint64_t* fs, uint64_t n, uint64_t* edge_key, uint64_t* edge_off, hipStream_t s) {

@@ -46,7 +46,7 @@ void edge_count(const DevHits& h, const uint8_t* cls, const ChainFinal& c, const
 void edge_emit(const DevHits& h, const uint8_t* cls, const ChainFinal& c, const uint64_t* cmp_off,
                uint32_t lr_begin, uint32_t lr_end, const uint64_t* pair_off, const EdgeRecs& out, hipStream_t s);
 void edge_gather(const EdgeRecs& in, const uint32_t* perm, uint64_t n, const EdgeRecs& out, hipStream_t s);
-constexpr int EDGE_REC_WORDS = 28;   // packed exchange record, dwords
+constexpr int EDGE_REC_WORDS = 11;   // packed exchange layout: dwords per record (a forward + twin pair travels as one unit of 22); n = records (even)
 void edge_pack(const EdgeRecs& r, uint64_t n, uint32_t* dst, hipStream_t s);
 void edge_unpack(const uint32_t* src, uint64_t n, const EdgeRecs& r, hipStream_t s);
 void iota_u32(uint32_t* p, uint64_t n, hipStream_t s);

@@ -1,13 +1,20 @@
 """Multi-GPU orchestration: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI).
 
-The path shards twice with ONE exchange in between:
+The path shards twice with ONE exchange of inputs in between:
   phase 1  long reads are split into contiguous id ranges balanced on raw-hit count; every rank filters /
            sorts / trims / chains its reads and emits their edge-support records
   exchange one all-gather of the packed records (ranks own ascending read ranges, so concatenation in rank
            order followed by the stable key sort reproduces the reference's per-edge support order)
   phase 2  every rank sorts + segments the full multiset and cleans the (small) graph redundantly, then
-           computes coordinates and POA consensus for its share of the surviving edges.
+           computes coordinates and POA consensus for its share of the surviving edges (dealt by estimated
+           DP cost, haslr_host.h hxh_run_set_edge_shard)
+  results  one all-gather of the per-edge results (coordinates, supports, consensus strings): every rank
+           can then stitch the assembly (asm_get_assembly needs all of them, Assemble.cpp:1045-1077)
 Raw inputs (CIGAR ops, packed reads) are replicated on every GPU, so records only carry indices.
+
+`ShardedBackend` is the compute-backend table of a rank; `run_sharded` drives one whole pass. Both take the
+record source as an object with emit() / export(buffer) / import_(buffer, n, out), so that the CPU tests can
+drive exactly this code over gloo with the test oracle in place of the HIP context.
 """
 import ctypes as C
 
@@ -33,49 +40,111 @@ def shard_bounds(read_hit_off, n_reads, world):
 
 def allgather_records(local: torch.Tensor, n_local: int, rec_bytes: int, group=None):
     """All-gather of variable-length packed record buffers (uint8 tensors of n_local*rec_bytes bytes).
-    Returns (merged tensor in rank order, total record count). One data collective (+ a count exchange)."""
+    Returns (merged tensor in rank order, total record count). One data collective (+ a count exchange):
+    every rank contributes its buffer padded to the largest, the padding is cut out afterwards."""
     world = dist.get_world_size(group)
     dev = local.device
-    counts = torch.zeros(world, dtype=torch.int64, device=dev)
     mine = torch.tensor([n_local], dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts, mine, group=group) if dev.type == "cuda" else dist.all_gather(list(counts.split(1)), mine, group=group)
-    counts_h = counts.cpu().tolist()
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, mine, group=group)
+    counts_h = [int(c.item()) for c in counts]
     cap = max(max(counts_h), 1) * rec_bytes
     padded = torch.zeros(cap, dtype=torch.uint8, device=dev)
     padded[: n_local * rec_bytes] = local[: n_local * rec_bytes]
-    gathered = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.all_gather(gathered, padded, group=group)
-    merged = torch.cat([g[: c * rec_bytes] for g, c in zip(gathered, counts_h)]) if sum(counts_h) else torch.zeros(0, dtype=torch.uint8, device=dev)
+    gathered = torch.empty(world * cap, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(gathered, padded, group=group)
+    if sum(counts_h) == 0:
+        return torch.zeros(0, dtype=torch.uint8, device=dev), 0
+    if all(c == counts_h[0] for c in counts_h):
+        return gathered, int(sum(counts_h))                       # no padding anywhere: the gather buffer is the result
+    merged = torch.cat([gathered[r * cap: r * cap + c * rec_bytes] for r, c in enumerate(counts_h)])
     return merged.contiguous(), int(sum(counts_h))
 
 
-class ShardedBackend:
-    """Backend table for the host pipeline in a multi-GPU run: chain/coords/POA are the context's own
-    operators (restricted to the read shard set on the context); edge_support = emit + all-gather + import."""
+def allgather_bytes(blob: bytes, device, group=None) -> bytes:
+    """Every rank's byte string, concatenated in rank order."""
+    local = torch.frombuffer(bytearray(blob) if blob else bytearray(1), dtype=torch.uint8).to(device)
+    merged, total = allgather_records(local, len(blob), 1, group)
+    return merged.cpu().numpy().tobytes()[:total]
 
-    def __init__(self, ctx, params, group=None):
+
+class HipRecords:
+    """Edge-support records of a rank's read shard on its HIP context (include/haslr_hip.h: hx_edge_emit / _export / _import)."""
+
+    def __init__(self, ctx, params):
         from . import hip
-        self.ctx, self.params, self.group = ctx, params, group
+        self.ctx, self.params = ctx, params
         self.rec_bytes = hip.records_bytes()
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def emit(self):
+        return self.ctx.edge_emit(self.params)
+
+    def export(self, n):
+        local = torch.empty(max(n, 1) * self.rec_bytes, dtype=torch.uint8, device=self.device)
+        self.ctx.edge_records_export(C.c_void_p(local.data_ptr()), n)
+        return local
+
+    def import_(self, merged, total, out):
+        from . import hip
+        torch.cuda.synchronize()
+        return hip.lib().hx_edge_records_import(self.ctx._h, C.c_void_p(merged.data_ptr()), total, out)
+
+
+class ShardedBackend:
+    """Backend table for the host pipeline in a multi-GPU run: chain/coords/POA are the rank's own operators
+    (restricted to its read shard / its share of the edges); edge_support = emit + all-gather + import."""
+
+    def __init__(self, table, records, group=None):
+        self.records, self.group = records, group
         self.table = T.Backend()
-        C.memmove(C.byref(self.table), C.byref(ctx.table), C.sizeof(T.Backend))
+        C.memmove(C.byref(self.table), C.byref(table), C.sizeof(T.Backend))
         proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(T.Params), C.POINTER(T.EdgesOut))
         self._cb = proto(self._edge_support)
         self.table.edge_support = C.cast(self._cb, C.c_void_p).value
         self.exchange_bytes = 0
+        self.error = None
 
-    def _edge_support(self, _ctx, prm, out):
-        from . import hip
+    def _edge_support(self, _ctx, _prm, out):
         try:
-            n = self.ctx.edge_emit(self.params)
-            dev = torch.device("cuda", torch.cuda.current_device())
-            local = torch.empty(max(n, 1) * self.rec_bytes, dtype=torch.uint8, device=dev)
-            self.ctx.edge_records_export(C.c_void_p(local.data_ptr()), n)
-            merged, total = allgather_records(local, n, self.rec_bytes, self.group)
-            self.exchange_bytes = total * self.rec_bytes
-            torch.cuda.synchronize()
-            rc = hip.lib().hx_edge_records_import(self.ctx._h, C.c_void_p(merged.data_ptr()), total, out)
-            return rc
+            n = self.records.emit()
+            local = self.records.export(n)
+            merged, total = allgather_records(local, n, self.records.rec_bytes, self.group)
+            self.exchange_bytes = total * self.records.rec_bytes
+            return self.records.import_(merged, total, out)
         except Exception as e:  # noqa: BLE001 - must not propagate through the C callback
+            self.error = e
             print(f"[ERROR] sharded edge_support: {e}", flush=True)
             return -1
+
+
+def gather_results(run, device, group=None):
+    """All ranks exchange the coordinates / supports / consensus of their share of the edges; afterwards every
+    rank's run holds all of them and can stitch. Returns the number of bytes gathered."""
+    merged = allgather_bytes(run.results_export(), device, group)
+    run.results_import(merged)
+    if run.results_missing:
+        raise RuntimeError(f"{run.results_missing} edges are without results after the gather")
+    return len(merged)
+
+
+def run_sharded(ds, params, backend: ShardedBackend, lr_begin, rank, world, device, group=None, out_dir=None, assemble=True):
+    """One pass of the stage on this rank: chain (own reads) -> merged graph -> coordinates + consensus (own edges)
+    -> gathered results -> assembly. Rank 0 passes out_dir to get the reference's output files."""
+    from . import host
+    run = host.Run(ds, params, backend.table, out_dir)
+    run.set_edge_shard(rank, world)
+    run.set_read_shard(lr_begin)
+    run.chain()
+    run.graph()
+    run.coords()
+    run.consensus()
+    gather_results(run, device, group)
+    if out_dir is not None or world > 1:
+        text = allgather_bytes(run.compact_text(), device, group)   # compact_uniq.txt lists every read: rank order = read order
+        if out_dir is not None:
+            with open(f"{out_dir}/compact_uniq.txt", "wb") as f:
+                f.write(text)
+    if assemble:
+        run.assemble()
+    return run

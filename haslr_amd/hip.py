@@ -15,7 +15,7 @@ _lib = None
 SYMBOLS = ["hx_last_error", "hx_device_count", "hx_ctx_create", "hx_ctx_destroy", "hx_upload", "hx_set_read_shard",
            "hx_chain_reads", "hx_edge_support", "hx_edge_coords", "hx_poa_batch", "hx_free_chain", "hx_free_edges",
            "hx_free_coords", "hx_free_cns", "hx_edge_emit", "hx_edge_records_bytes", "hx_edge_records_export",
-           "hx_edge_records_import", "hx_timing_reset", "hx_timing_get", "hx_set_poa_block", "hx_backend_fill", "hx_poa_phase_cycles", "hx_set_poa_traceback"]
+           "hx_edge_records_import", "hx_poa_supports", "hx_poa_sequences", "hx_timing_reset", "hx_timing_get", "hx_set_poa_block", "hx_backend_fill", "hx_poa_phase_cycles", "hx_set_poa_traceback"]
 
 
 class HipError(RuntimeError):
@@ -38,6 +38,8 @@ def lib():
         L.hx_edge_support.argtypes = [C.c_void_p, C.POINTER(T.Params), C.POINTER(T.EdgesOut)]
         L.hx_edge_coords.argtypes = [C.c_void_p, C.c_uint32, T.u32p, C.POINTER(T.CoordsOut)]
         L.hx_poa_batch.argtypes = [C.c_void_p, C.POINTER(T.PoaParams), C.POINTER(T.CnsOut)]
+        L.hx_poa_supports.argtypes = [C.c_void_p, C.POINTER(T.CoordsOut), C.POINTER(T.PoaParams), C.POINTER(T.CnsOut)]
+        L.hx_poa_sequences.argtypes = [C.c_void_p, C.c_uint32, T.u64p, T.u64p, C.c_char_p, C.POINTER(T.PoaParams), C.POINTER(T.CnsOut)]
         L.hx_free_chain.argtypes = [C.c_void_p, C.POINTER(T.ChainOut)]
         L.hx_free_edges.argtypes = [C.c_void_p, C.POINTER(T.EdgesOut)]
         L.hx_free_coords.argtypes = [C.c_void_p, C.POINTER(T.CoordsOut)]
@@ -134,6 +136,39 @@ class HipContext:
         pp = T.PoaParams(match, mismatch, gap)
         self._chk(lib().hx_poa_batch(self._h, C.byref(pp), C.byref(o)))
         r = T.cns_to_list(o), {"dp_cells": o.dp_cells, "seq_bases": o.seq_bases, "n_aligned": o.n_aligned}
+        lib().hx_free_cns(self._h, C.byref(o))
+        return r
+
+    def poa_supports(self, supports, match=5, mismatch=-4, gap=-8):
+        """consensus of caller-given edges: supports = list (one per edge) of (read id, strand, spos, epos) tuples into the resident reads"""
+        import numpy as np
+        off = np.zeros(len(supports) + 1, dtype=np.uint64)
+        flat = [t for e in supports for t in e]
+        for i, e in enumerate(supports):
+            off[i + 1] = off[i] + len(e)
+        lr = np.array([r | (s << 31) for r, s, _, _ in flat] or [0], dtype=np.uint32)
+        sp = np.array([t[2] & 0xffffffff for t in flat] or [0], dtype=np.uint32)
+        ep = np.array([t[3] & 0xffffffff for t in flat] or [0], dtype=np.uint32)
+        sup = T.CoordsOut(len(supports), None, None, off.ctypes.data_as(T.u64p), lr.ctypes.data_as(T.u32p), sp.ctypes.data_as(T.u32p), ep.ctypes.data_as(T.u32p))
+        o, pp = T.CnsOut(), T.PoaParams(match, mismatch, gap)
+        self._chk(lib().hx_poa_supports(self._h, C.byref(sup), C.byref(pp), C.byref(o)))
+        r = T.cns_to_list(o)
+        lib().hx_free_cns(self._h, C.byref(o))
+        return r
+
+    def poa_sequences(self, sets, match=5, mismatch=-4, gap=-8):
+        """consensus of every set of plain ACGT strings (aligned in the given order); nothing has to be resident"""
+        import numpy as np
+        set_off = np.zeros(len(sets) + 1, dtype=np.uint64)
+        seqs = [q for st in sets for q in st]
+        for i, st in enumerate(sets):
+            set_off[i + 1] = set_off[i] + len(st)
+        seq_off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        for i, q in enumerate(seqs):
+            seq_off[i + 1] = seq_off[i] + len(q)
+        o, pp = T.CnsOut(), T.PoaParams(match, mismatch, gap)
+        self._chk(lib().hx_poa_sequences(self._h, len(sets), set_off.ctypes.data_as(T.u64p), seq_off.ctypes.data_as(T.u64p), "".join(seqs).encode(), C.byref(pp), C.byref(o)))
+        r = T.cns_to_list(o)
         lib().hx_free_cns(self._h, C.byref(o))
         return r
 

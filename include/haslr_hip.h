@@ -48,6 +48,17 @@ int hx_chain_reads(hx_ctx*, const hx_params*, hx_chain_out* out);
 int hx_edge_support(hx_ctx*, const hx_params*, hx_edges_out* out);
 int hx_edge_coords(hx_ctx*, uint32_t n_sel, const uint32_t* sel_edge, hx_coords_out* out);
 int hx_poa_batch(hx_ctx*, const hx_poa_params*, hx_cns_out* out);
+/* The consensus operator on its own (what stands where the five SPOA calls stand, Assemble.cpp:499-554), for callers that hold the
+ * support lists themselves:
+ *   hx_poa_supports   consensus of caller-given edges: `sup` has hx_edge_coords' layout (n_edge, supp_off, supp_lr = read id |
+ *                     strand << 31, spos, epos; head_end / tail_beg are not read) and points into the resident reads. The sub-sequence
+ *                     rule is the reference's: epos - spos + 1 in 32 bits, clamped to the read like std::string::substr
+ *                     (Assemble.cpp:530-532), empty ones skipped (:537), no sequence at all -> empty consensus (:544-551).
+ *   hx_poa_sequences  consensus of caller-given sequence sets (plain ACGT text, set i = sequences [set_off[i], set_off[i+1]), sequence
+ *                     k = bases[seq_off[k] .. seq_off[k+1])), aligned in the given order; nothing has to be resident. This is the
+ *                     entry include/spoa_hx.hpp (the spoa.hpp-shaped C++ header over this library) calls. */
+int hx_poa_supports(hx_ctx*, const hx_coords_out* sup, const hx_poa_params*, hx_cns_out* out);
+int hx_poa_sequences(hx_ctx*, uint32_t n_sets, const uint64_t* set_off, const uint64_t* seq_off, const char* bases, const hx_poa_params*, hx_cns_out* out);
 void hx_free_chain(hx_ctx*, hx_chain_out*);
 void hx_free_edges(hx_ctx*, hx_edges_out*);
 void hx_free_coords(hx_ctx*, hx_coords_out*);
@@ -55,8 +66,9 @@ void hx_free_cns(hx_ctx*, hx_cns_out*);
 
 /* multi-GPU exchange of the edge-support multiset (one all-gather between hx_chain_reads and the sort):
  *   hx_edge_emit            emit this shard's records (unsorted) on the device, returns their number
- *   hx_edge_records_bytes   bytes per record in the packed exchange layout
- *   hx_edge_records_export  pack the local records into a caller-owned DEVICE buffer (n * bytes)
+ *   hx_edge_records_bytes   bytes per record in the packed exchange layout (44: a forward record and its twin travel as one
+ *                           88-byte unit - key, read id, compact indices and the two trimmed anchor alignments, once)
+ *   hx_edge_records_export  pack the local records into a caller-owned DEVICE buffer (n * bytes; n is even)
  *   hx_edge_records_import  replace the record set by n records unpacked from a DEVICE buffer (all ranks,
  *                           rank order), then sort + segment; fills `out` like hx_edge_support */
 int hx_edge_emit(hx_ctx*, const hx_params*, uint64_t* n_records);

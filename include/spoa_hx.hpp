@@ -1,0 +1,138 @@
+// spoa_hx.hpp — the per-edge POA operator of haslr_assemble behind the reference's own operator API.
+//
+// The reference computes every gap consensus with five calls of rvaser/spoa 1.1.3 (Assemble.cpp:499-554):
+//     auto alignment_engine = spoa::createAlignmentEngine(static_cast<spoa::AlignmentType>(1), 5, -4, -8);   // :499
+//     auto graph = spoa::createGraph();                                                                         // :500
+//     for every supporting sub-sequence, in stored order:
+//         auto alignment = alignment_engine->align_sequence_with_graph(seq, graph);                            // :539
+//         graph->add_alignment(alignment, seq);                                                                 // :540
+//     std::string consensus = graph->generate_consensus();                                                      // :554
+// This header declares exactly those symbols (namespace spoa, the same signatures and ownership: unique_ptr
+// engine + graph per edge, strings by const reference, consensus by value) over the C-ABI of haslr_hip.h, so that
+// the reference's Assemble.cpp compiles against it unchanged (`#include "spoa_hx.hpp"` in place of "spoa.hpp",
+// link -lhaslr_hip instead of libspoa.a) and its consensus runs on the MI355X.
+//
+// How it maps: a partial-order graph lives on the device only while it is being built, so the calls are recorded and
+// the work happens in generate_consensus(): align_sequence_with_graph() returns a token (an Alignment holding one
+// (-1, ticket) pair, not a list of node/position pairs), add_alignment() appends the sequence that goes with a token,
+// generate_consensus() sends the recorded sequences, in order, through hx_poa_sequences (global alignment, linear gap,
+// the engine's three scores, unit weights) and returns what spoa's generate_consensus returns for them.
+// What that supports is the reference's call pattern and nothing wider: AlignmentType::kNW only (createAlignmentEngine
+// throws std::invalid_argument otherwise), weight 1 only, every alignment added to the graph it was computed against,
+// in the order it was computed. spoa 1.1.3 exits on invalid input; this header throws std::runtime_error with the
+// library's message instead (there is no CPU fallback: without a HIP device every consensus fails loudly).
+//
+// Threads: the reference calls from gopt.num_threads pthreads, each with its own engine and graph. All of them share
+// one device context here (created on first use, device HASLR_DEVICE or 0), guarded by a mutex: correct, but one edge
+// at a time keeps a 256-CU GPU mostly idle. spoa::hx::consensus_batch() below is the entry to use from new code: all
+// edges in one call (that is what haslr_amd's own pipeline does through hx_poa_batch).
+//
+// This is product code. It is never used to build oracle/_ref (a reference build must not be made with stand-in
+// headers): tests/test_spoa_header.py compiles a small caller written against the five symbols, nothing else.
+#ifndef HASLR_SPOA_HX_HPP
+#define HASLR_SPOA_HX_HPP
+#include <cstdint>
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "haslr_hip.h"
+
+namespace spoa {
+
+enum class AlignmentType { kSW, kNW, kOV };   // values 0, 1, 2 as in spoa 1.1.3 (the reference passes 1)
+using Alignment = std::vector<std::pair<std::int32_t, std::int32_t>>;
+
+namespace hx {
+
+struct Device {
+    hx_ctx* ctx = nullptr;
+    std::mutex mu;
+    ~Device() { if (ctx) hx_ctx_destroy(ctx); }
+};
+inline Device& device() {
+    static Device d;
+    return d;
+}
+inline hx_ctx* context_locked(Device& d) {   // call with d.mu held
+    if (!d.ctx) {
+        const char* dev = std::getenv("HASLR_DEVICE");
+        if (hx_ctx_create(dev ? std::atoi(dev) : 0, nullptr, &d.ctx) != 0) throw std::runtime_error(std::string("spoa_hx: ") + hx_last_error());
+    }
+    return d.ctx;
+}
+
+// consensus of every set of sequences (set = the sub-sequences of one edge in alignment order) in ONE device call
+inline std::vector<std::string> consensus_batch(const std::vector<std::vector<std::string>>& sets, std::int8_t m = 5, std::int8_t n = -4, std::int8_t g = -8) {
+    std::vector<std::uint64_t> set_off{0}, seq_off{0};
+    std::string bases;
+    for (const auto& st : sets) {
+        for (const auto& s : st) { bases += s; seq_off.push_back(bases.size()); }
+        set_off.push_back(seq_off.size() - 1);
+    }
+    const hx_poa_params pp{m, n, g};
+    hx_cns_out out;
+    Device& d = device();
+    std::lock_guard<std::mutex> lock(d.mu);
+    hx_ctx* ctx = context_locked(d);
+    if (hx_poa_sequences(ctx, (std::uint32_t)sets.size(), set_off.data(), seq_off.data(), bases.c_str(), &pp, &out) != 0)
+        throw std::runtime_error(std::string("spoa_hx: ") + hx_last_error());
+    std::vector<std::string> res(sets.size());
+    for (std::size_t i = 0; i < sets.size(); i++) res[i].assign(out.cns + out.cns_off[i], out.cns + out.cns_off[i + 1]);
+    hx_free_cns(ctx, &out);
+    return res;
+}
+
+}  // namespace hx
+
+class Graph {
+public:
+    // spoa::Graph::add_alignment(alignment, sequence, weight = 1)
+    void add_alignment(const Alignment& alignment, const std::string& sequence, std::uint32_t weight = 1) {
+        if (weight != 1) throw std::invalid_argument("spoa_hx: only unit weights are supported (the reference uses the default)");
+        if (alignment.size() != 1 || alignment[0].first != -1 || (std::uint32_t)alignment[0].second != ticket_)
+            throw std::invalid_argument("spoa_hx: add_alignment needs the alignment that align_sequence_with_graph last returned for this graph");
+        ticket_++;
+        if (!sequence.empty()) sequences_.push_back(sequence);   // spoa ignores an empty sequence (the reference never passes one, Assemble.cpp:537)
+    }
+    // spoa::Graph::generate_consensus()
+    std::string generate_consensus() {
+        if (sequences_.empty()) return std::string();
+        return hx::consensus_batch({sequences_}, m_, n_, g_)[0];
+    }
+
+private:
+    friend class AlignmentEngine;
+    std::vector<std::string> sequences_;
+    std::uint32_t ticket_ = 0;
+    std::int8_t m_ = 5, n_ = -4, g_ = -8;
+};
+
+class AlignmentEngine {
+public:
+    // spoa::AlignmentEngine::align_sequence_with_graph(sequence, graph): a token for add_alignment (see the header comment)
+    Alignment align_sequence_with_graph(const std::string& /*sequence*/, const std::unique_ptr<Graph>& graph) {
+        graph->m_ = m_; graph->n_ = n_; graph->g_ = g_;
+        return Alignment{{-1, (std::int32_t)graph->ticket_}};
+    }
+
+private:
+    friend std::unique_ptr<AlignmentEngine> createAlignmentEngine(AlignmentType, std::int8_t, std::int8_t, std::int8_t);
+    AlignmentEngine(std::int8_t m, std::int8_t n, std::int8_t g) : m_(m), n_(n), g_(g) {}
+    std::int8_t m_, n_, g_;
+};
+
+// spoa::createAlignmentEngine(type, match, mismatch, gap) — linear gap penalties, as spoa 1.1.3 has them
+inline std::unique_ptr<AlignmentEngine> createAlignmentEngine(AlignmentType type, std::int8_t m, std::int8_t n, std::int8_t g) {
+    if (type != AlignmentType::kNW) throw std::invalid_argument("spoa_hx: only AlignmentType::kNW (global alignment, what the reference uses) is implemented");
+    if (g >= 0) throw std::invalid_argument("spoa_hx: the gap penalty must be negative");
+    return std::unique_ptr<AlignmentEngine>(new AlignmentEngine(m, n, g));
+}
+inline std::unique_ptr<Graph> createGraph() { return std::unique_ptr<Graph>(new Graph()); }
+
+}  // namespace spoa
+#endif

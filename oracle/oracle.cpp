@@ -15,6 +15,9 @@
 #include <string>
 #include <thread>
 #include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace {
 
@@ -580,6 +583,109 @@ struct PoaGraph {
     }
 };
 
+// ---- row kernels of the aligner. The scalar forms are the restatement; the AVX2 forms compute the same integers 8 columns at a
+// time (like spoa's SIMD engine does for this recurrence: element-wise maxima over the predecessor rows, then the horizontal
+// recurrence H[j] = max(T[j], H[j-1] + g) as a prefix-max scan inside a vector with a carry between vectors). They exist so that
+// bench.py's cpu_baseline is not a scalar straw man; selected at run time (the library is built for plain x86-64-v2).
+struct RowKernels {
+    // row[j] = max(pw[j-1] + pr[j], pw[j] + g)            for j in [1, W)   (first predecessor)
+    void (*first)(int32_t* row, const int32_t* pw, const int32_t* pr, int32_t g, size_t W);
+    // row[j] = max(row[j], pw[j-1] + pr[j], pw[j] + g)    for j in [1, W)   (further predecessors)
+    void (*more)(int32_t* row, const int32_t* pw, const int32_t* pr, int32_t g, size_t W);
+    // row[j] = max(row[j-1] + g, row[j])                  for j in [1, W)   (row[0] is final)
+    void (*horiz)(int32_t* row, int32_t g, size_t W);
+    // `first` and `horiz` in one pass (rows with a single predecessor)
+    void (*first_horiz)(int32_t* row, const int32_t* pw, const int32_t* pr, int32_t g, size_t W);
+    const char* name;
+};
+
+void row_first_scalar(int32_t* row, const int32_t* pw, const int32_t* pr, int32_t g, size_t W) {
+    for (size_t j = 1; j < W; j++) row[j] = std::max(pw[j - 1] + pr[j], pw[j] + g);
+}
+void row_more_scalar(int32_t* row, const int32_t* pw, const int32_t* pr, int32_t g, size_t W) {
+    for (size_t j = 1; j < W; j++) row[j] = std::max(pw[j - 1] + pr[j], std::max(row[j], pw[j] + g));
+}
+void row_horiz_scalar(int32_t* row, int32_t g, size_t W) {
+    for (size_t j = 1; j < W; j++) row[j] = std::max(row[j - 1] + g, row[j]);
+}
+
+void row_first_horiz_scalar(int32_t* row, const int32_t* pw, const int32_t* pr, int32_t g, size_t W) {
+    for (size_t j = 1; j < W; j++) row[j] = std::max(row[j - 1] + g, std::max(pw[j - 1] + pr[j], pw[j] + g));
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) void row_first_avx2(int32_t* row, const int32_t* pw, const int32_t* pr, int32_t g, size_t W) {
+    const __m256i vg = _mm256_set1_epi32(g);
+    size_t j = 1;
+    for (; j + 8 <= W; j += 8) {
+        const __m256i d = _mm256_add_epi32(_mm256_loadu_si256((const __m256i*)(pw + j - 1)), _mm256_loadu_si256((const __m256i*)(pr + j)));
+        const __m256i v = _mm256_add_epi32(_mm256_loadu_si256((const __m256i*)(pw + j)), vg);
+        _mm256_storeu_si256((__m256i*)(row + j), _mm256_max_epi32(d, v));
+    }
+    for (; j < W; j++) row[j] = std::max(pw[j - 1] + pr[j], pw[j] + g);
+}
+__attribute__((target("avx2"))) void row_more_avx2(int32_t* row, const int32_t* pw, const int32_t* pr, int32_t g, size_t W) {
+    const __m256i vg = _mm256_set1_epi32(g);
+    size_t j = 1;
+    for (; j + 8 <= W; j += 8) {
+        const __m256i d = _mm256_add_epi32(_mm256_loadu_si256((const __m256i*)(pw + j - 1)), _mm256_loadu_si256((const __m256i*)(pr + j)));
+        const __m256i v = _mm256_add_epi32(_mm256_loadu_si256((const __m256i*)(pw + j)), vg);
+        _mm256_storeu_si256((__m256i*)(row + j), _mm256_max_epi32(_mm256_loadu_si256((const __m256i*)(row + j)), _mm256_max_epi32(d, v)));
+    }
+    for (; j < W; j++) row[j] = std::max(pw[j - 1] + pr[j], std::max(row[j], pw[j] + g));
+}
+__attribute__((target("avx2"))) void row_horiz_avx2(int32_t* row, int32_t g, size_t W) {
+    // inside a vector: y[k] = max over i <= k of x[i] + (k - i) g  (three shift-and-max steps), then the carry of the columns before it
+    const __m256i neg = _mm256_set1_epi32(INT32_MIN / 2);
+    const __m256i s1 = _mm256_setr_epi32(0, 0, 1, 2, 3, 4, 5, 6), s2 = _mm256_setr_epi32(0, 0, 0, 1, 2, 3, 4, 5), s4 = _mm256_setr_epi32(0, 0, 0, 0, 0, 1, 2, 3);
+    const __m256i g1 = _mm256_set1_epi32(g), g2 = _mm256_set1_epi32(2 * g), g4 = _mm256_set1_epi32(4 * g);
+    const __m256i ramp = _mm256_mullo_epi32(_mm256_setr_epi32(1, 2, 3, 4, 5, 6, 7, 8), g1), last = _mm256_set1_epi32(7);
+    __m256i carry = _mm256_set1_epi32(row[0]);
+    size_t j = 1;
+    for (; j + 8 <= W; j += 8) {
+        __m256i x = _mm256_loadu_si256((const __m256i*)(row + j));
+        x = _mm256_max_epi32(x, _mm256_add_epi32(_mm256_blend_epi32(_mm256_permutevar8x32_epi32(x, s1), neg, 0x01), g1));
+        x = _mm256_max_epi32(x, _mm256_add_epi32(_mm256_blend_epi32(_mm256_permutevar8x32_epi32(x, s2), neg, 0x03), g2));
+        x = _mm256_max_epi32(x, _mm256_add_epi32(_mm256_blend_epi32(_mm256_permutevar8x32_epi32(x, s4), neg, 0x0f), g4));
+        x = _mm256_max_epi32(x, _mm256_add_epi32(carry, ramp));
+        _mm256_storeu_si256((__m256i*)(row + j), x);
+        carry = _mm256_permutevar8x32_epi32(x, last);
+    }
+    for (; j < W; j++) row[j] = std::max(row[j - 1] + g, row[j]);
+}
+__attribute__((target("avx2"))) void row_first_horiz_avx2(int32_t* row, const int32_t* pw, const int32_t* pr, int32_t g, size_t W) {
+    const __m256i neg = _mm256_set1_epi32(INT32_MIN / 2);
+    const __m256i s1 = _mm256_setr_epi32(0, 0, 1, 2, 3, 4, 5, 6), s2 = _mm256_setr_epi32(0, 0, 0, 1, 2, 3, 4, 5), s4 = _mm256_setr_epi32(0, 0, 0, 0, 0, 1, 2, 3);
+    const __m256i g1 = _mm256_set1_epi32(g), g2 = _mm256_set1_epi32(2 * g), g4 = _mm256_set1_epi32(4 * g);
+    const __m256i ramp = _mm256_mullo_epi32(_mm256_setr_epi32(1, 2, 3, 4, 5, 6, 7, 8), g1), last = _mm256_set1_epi32(7);
+    __m256i carry = _mm256_set1_epi32(row[0]);
+    size_t j = 1;
+    for (; j + 8 <= W; j += 8) {
+        const __m256i d = _mm256_add_epi32(_mm256_loadu_si256((const __m256i*)(pw + j - 1)), _mm256_loadu_si256((const __m256i*)(pr + j)));
+        __m256i x = _mm256_max_epi32(d, _mm256_add_epi32(_mm256_loadu_si256((const __m256i*)(pw + j)), g1));
+        x = _mm256_max_epi32(x, _mm256_add_epi32(_mm256_blend_epi32(_mm256_permutevar8x32_epi32(x, s1), neg, 0x01), g1));
+        x = _mm256_max_epi32(x, _mm256_add_epi32(_mm256_blend_epi32(_mm256_permutevar8x32_epi32(x, s2), neg, 0x03), g2));
+        x = _mm256_max_epi32(x, _mm256_add_epi32(_mm256_blend_epi32(_mm256_permutevar8x32_epi32(x, s4), neg, 0x0f), g4));
+        x = _mm256_max_epi32(x, _mm256_add_epi32(carry, ramp));
+        _mm256_storeu_si256((__m256i*)(row + j), x);
+        carry = _mm256_permutevar8x32_epi32(x, last);
+    }
+    for (; j < W; j++) row[j] = std::max(row[j - 1] + g, std::max(pw[j - 1] + pr[j], pw[j] + g));
+}
+#endif
+
+const RowKernels& row_kernels() {
+    static const RowKernels k = []() {
+        RowKernels r{row_first_scalar, row_more_scalar, row_horiz_scalar, row_first_horiz_scalar, "scalar"};
+#if defined(__x86_64__)
+        const char* force = getenv("ORC_POA_SCALAR");
+        if (!(force && force[0] == '1') && __builtin_cpu_supports("avx2")) r = RowKernels{row_first_avx2, row_more_avx2, row_horiz_avx2, row_first_horiz_avx2, "avx2 (8 x int32)"};
+#endif
+        return r;
+    }();
+    return k;
+}
+
 struct PoaAligner {
     int32_t m, x, g;
     std::vector<int32_t> H, prof;
@@ -608,18 +714,19 @@ struct PoaAligner {
             }
         }
         int32_t max_score = INT32_MIN + 1024; int64_t max_i = -1;
+        const RowKernels& K = row_kernels();
         for (size_t i = 1; i <= V; i++) {
             uint32_t n = G.rank2node[i - 1];
             const int32_t* pr = &prof[(size_t)G.code[n] * W];
             int32_t* row = &H[i * W];
             size_t pi = G.in[n].empty() ? 0 : node2rank[G.edges[G.in[n][0]].from] + 1;
             const int32_t* pw = &H[pi * W];
-            for (size_t j = 1; j < W; j++) row[j] = std::max(pw[j - 1] + pr[j], pw[j] + g);
-            for (size_t p = 1; p < G.in[n].size(); p++) {
-                pw = &H[(size_t)(node2rank[G.edges[G.in[n][p]].from] + 1) * W];
-                for (size_t j = 1; j < W; j++) row[j] = std::max(pw[j - 1] + pr[j], std::max(row[j], pw[j] + g));
+            if (G.in[n].size() <= 1) K.first_horiz(row, pw, pr, g, W);
+            else {
+                K.first(row, pw, pr, g, W);
+                for (size_t p = 1; p < G.in[n].size(); p++) K.more(row, &H[(size_t)(node2rank[G.edges[G.in[n][p]].from] + 1) * W], pr, g, W);
+                K.horiz(row, g, W);
             }
-            for (size_t j = 1; j < W; j++) row[j] = std::max(row[j - 1] + g, row[j]);
             if (G.outs[n].empty() && max_score < row[W - 1]) { max_score = row[W - 1]; max_i = (int64_t)i; }   // first max in rank order
         }
         // traceback: diagonal (in-edge order), then vertical (in-edge order), then horizontal
@@ -700,11 +807,22 @@ extern "C" int orc_poa_batch(const hx_reads* R, const hx_coords_out* C, const hx
     std::atomic<uint32_t> next{0};
     std::atomic<int> err{0};
     std::atomic<uint64_t> cells{0}, bases{0}, naln{0};
+    // edges are handed to the threads costliest first (supports x longest gap squared), so that the longest ones do not start last
+    std::vector<uint32_t> order(n);
+    std::vector<uint64_t> cost(n, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        order[i] = i;
+        uint64_t lmax = 0, ns = C->supp_off[i + 1] - C->supp_off[i];
+        for (uint64_t k = C->supp_off[i]; k < C->supp_off[i + 1]; k++) lmax = std::max<uint64_t>(lmax, (uint32_t)(C->epos[k] - C->spos[k] + 1) & 0xffffffu);
+        cost[i] = ns * lmax * lmax;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
     auto work = [&]() {
         uint64_t lc = 0, lb = 0, la = 0;
         for (;;) {
-            uint32_t s = next.fetch_add(1);
-            if (s >= n) break;
+            uint32_t q = next.fetch_add(1);
+            if (q >= n) break;
+            const uint32_t s = order[q];
             if (poa_edge(R, C, s, pp, cns[s], &lc, &lb, &la) != 0) err = 1;
         }
         cells += lc; bases += lb; naln += la;
@@ -724,6 +842,8 @@ extern "C" int orc_poa_batch(const hx_reads* R, const hx_coords_out* C, const hx
     out->dp_cells = cells; out->seq_bases = bases; out->n_aligned = naln;
     return 0;
 }
+
+extern "C" const char* orc_poa_kernel_name(void) { return row_kernels().name; }
 
 extern "C" void orc_free_cns(hx_cns_out* o) { free(o->cns_off); free(o->cns); memset(o, 0, sizeof(*o)); }
 

@@ -35,6 +35,8 @@ void orc_free_edges(hx_edges_out*);
 void orc_free_coords(hx_coords_out*);
 void orc_free_cns(hx_cns_out*);
 const char* orc_last_error(void);
+/* row kernels of the POA aligner in use: "avx2 (8 x int32)" when the CPU has AVX2 (same integers as the scalar restatement; ORC_POA_SCALAR=1 forces "scalar") */
+const char* orc_poa_kernel_name(void);
 
 /* single POA problem on plain ASCII sequences (known-answer tests): returns malloc'd consensus */
 char* orc_poa_consensus(const char* const* seqs, uint32_t n, const hx_poa_params* pp);

@@ -14,10 +14,14 @@ def lib():
     if _lib is None:
         L = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
         L.orc_last_error.restype = C.c_char_p
+        L.orc_poa_kernel_name.restype = C.c_char_p
         L.orc_ctx_create.restype = C.c_void_p
         L.orc_ctx_create.argtypes = [C.POINTER(T.Contigs), C.POINTER(T.Reads), C.POINTER(T.Hits), T.u64p, C.c_int]
         L.orc_ctx_destroy.argtypes = [C.c_void_p]
         L.orc_backend_fill.argtypes = [C.c_void_p, C.POINTER(T.Backend)]
+        L.orc_ctx_set_read_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.orc_ctx_shard_edges.argtypes = [C.c_void_p, C.POINTER(T.Params), C.c_uint32, C.c_uint32, C.POINTER(T.EdgesOut)]
+        L.orc_free_edges.argtypes = [C.POINTER(T.EdgesOut)]
         L.orc_poa_consensus.restype = C.c_void_p
         L.orc_poa_consensus.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(T.PoaParams)]
         L.orc_free_str.argtypes = [C.c_void_p]
@@ -33,6 +37,19 @@ class OracleBackend:
         self._ctx = lib().orc_ctx_create(C.byref(dataset.contigs), C.byref(dataset.reads), C.byref(dataset.hits), dataset.read_hit_off, n_threads)
         self.table = T.Backend()
         lib().orc_backend_fill(self._ctx, C.byref(self.table))
+
+    def set_read_shard(self, b, e):
+        """chain_reads shows the host pipeline the reads [b, e) only (what a rank of a multi-GPU run holds)"""
+        lib().orc_ctx_set_read_shard(self._ctx, b, e)
+
+    def shard_edges(self, params, b, e):
+        """edge-support records emitted by the reads [b, e), as a dict of arrays (key-sorted, stable)"""
+        o = T.EdgesOut()
+        if lib().orc_ctx_shard_edges(self._ctx, C.byref(params), b, e, C.byref(o)) != 0:
+            raise RuntimeError("oracle: shard_edges needs chain_reads first")
+        d = T.edges_to_dict(o, sides=False)
+        lib().orc_free_edges(C.byref(o))
+        return d
 
     def close(self):
         if self._ctx:

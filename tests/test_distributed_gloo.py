@@ -1,6 +1,10 @@
-"""world_size-2 CPU test (gloo) of the multi-GPU exchange logic: read sharding + all-gather of packed
-edge-support records in rank order + stable key sort == the unsharded multiset. The per-shard compute is done
-by the CPU oracle here (no GPU in this container); the collective code path is haslr_amd.distributed's."""
+"""world_size-2 CPU tests (gloo) of the multi-GPU path. The per-shard compute is done by the CPU oracle here (no GPU in
+this container); everything around it is the product's: haslr_amd.distributed (read shards, the record all-gather,
+ShardedBackend, the results all-gather, run_sharded) and the host pipeline's edge sharding / results export + import /
+stitching (libhaslr_host.so).
+  * the exchanged record multiset equals the unsharded one
+  * a whole sharded pass writes the same asm.final.fa / .ann, the same six GFAs, stats, logs and compact_uniq.txt as one rank
+  * stitching refuses to run while other ranks' results are missing"""
 import os
 import subprocess
 import sys
@@ -81,3 +85,101 @@ def test_shard_bounds_cover_all_reads(built):
     for world in (1, 2, 3, 4, 8):
         b = hd.shard_bounds(p, 7, world)
         assert b[0] == 0 and b[-1] == 7 and len(b) == world + 1 and all(x <= y for x, y in zip(b, b[1:]))
+
+
+FULL_WORKER = r'''
+import ctypes as C, hashlib, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from haslr_amd import host, distributed as hd, ctypes_defs as T
+import orclib
+pre, out = sys.argv[2], sys.argv[3]
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+prm = ds.params()
+ob = orclib.OracleBackend(ds, 4)
+b = hd.shard_bounds(ds.read_hit_off, ds.reads.n, world)
+ob.set_read_shard(b[rank], b[rank + 1])          # chain_reads hands the pipeline this rank's reads only, like a HIP context with a read shard
+
+
+class OracleRecords:
+    """the record source ShardedBackend drives (emit / export / import_), computed by the oracle: 32-byte records"""
+    rec_bytes = 32
+
+    def emit(self):
+        d = ob.shard_edges(prm, b[rank], b[rank + 1])
+        lr, tw = d["lr"] & 0x7fffffff, d["lr"] >> 31
+        pos = np.where(tw == 0, d["cmp_head"], d["cmp_tail"])
+        order = np.lexsort((tw, pos, lr))         # emission order: read asc, pair asc, forward before twin
+        self.rec = np.zeros((len(order), 4), dtype=np.uint64)
+        for k, name in enumerate(("key", "lr", "cmp_head", "cmp_tail")):
+            self.rec[:, k] = d[name][order]
+        return len(order)
+
+    def export(self, n):
+        return torch.from_numpy(self.rec.view(np.uint8).reshape(-1).copy()) if n else torch.zeros(1, dtype=torch.uint8)
+
+    def import_(self, merged, total, out):
+        m = merged.numpy().view(np.uint64).reshape(-1, 4)
+        assert m.shape[0] == total
+        m = m[np.argsort(m[:, 0], kind="stable")]
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(T.Params), C.POINTER(T.EdgesOut))
+        rc = proto(ob.table.edge_support)(ob.table.ctx, C.byref(prm), out)     # the oracle's own multiset of ALL reads ...
+        d = T.edges_to_dict(out.contents, sides=False)
+        for k, name in enumerate(("key", "lr", "cmp_head", "cmp_tail")):       # ... which the gathered shards must reproduce, order included
+            assert np.array_equal(m[:, k], d[name].astype(np.uint64)), name
+        return rc
+
+
+be = hd.ShardedBackend(ob.table, OracleRecords())
+dev = torch.device("cpu")
+run = hd.run_sharded(ds, prm, be, b[rank], rank, world, dev, out_dir=out if rank == 0 else None, assemble=False)
+assert be.error is None
+assert run.results_missing == 0 and run.n_edges_total > 4
+assert 0 < run.n_edges < run.n_edges_total, (run.n_edges, run.n_edges_total)   # every rank worked on a part of the queue only
+run.assemble()
+fa = run.assembly_fasta()
+# a run that has not been given the other ranks' results must refuse to stitch
+lone = host.Run(ds, prm, be.table, None)
+lone.set_edge_shard(rank, world); lone.set_read_shard(b[rank])
+lone.chain(); lone.graph(); lone.coords(); lone.consensus()
+assert lone.results_missing == run.n_edges_total - run.n_edges
+try:
+    lone.assemble()
+    raise SystemExit("assemble accepted an incomplete result set")
+except host.HostError as e:
+    assert "have no coordinates" in str(e), str(e)
+# all ranks stitched the same assembly
+h = torch.frombuffer(bytearray(hashlib.sha256(fa.encode()).digest()), dtype=torch.uint8)
+hs = [torch.zeros(32, dtype=torch.uint8) for _ in range(world)]
+dist.all_gather(hs, h)
+assert all(torch.equal(hs[0], x) for x in hs)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_pipeline_writes_the_single_rank_outputs(sim, built, tmp_path):
+    import orclib
+    import util
+    from haslr_amd import host
+    pre = sim("--genome-len", "150000", "--seed", "41", "--variant-per-mb", "60", "--cov", "9")
+    w = tmp_path / "worker_full.py"
+    w.write_text(FULL_WORKER)
+    out2 = str(tmp_path / "two_ranks")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29519", str(w), ROOT, pre, out2], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    ob = orclib.OracleBackend(ds, 4)
+    out1 = str(tmp_path / "one_rank")
+    run = host.Run(ds, ds.params(), ob.table, out1)
+    run.all()
+    names = sorted(os.listdir(out1))
+    assert "asm.final.fa" in names and "asm.final.ann" in names and "compact_uniq.txt" in names and sum(n.endswith(".gfa") for n in names) == 6
+    assert sorted(os.listdir(out2)) == names
+    assert util.compare_dirs(out1, out2) == []
+    assert len(run.assembly_fasta()) > 50000 and run.n_edges > 8
+    run.close(); ob.close(); ds.close()

@@ -84,7 +84,7 @@ def test_nondefault_parameters(sim, ctx, tmp_path):
     assert util.compare_dirs(str(tmp_path / "o"), str(tmp_path / "g")) == []
 
 
-@pytest.mark.parametrize("case", sorted(d for d in os.listdir(GOLD) if os.path.isfile(os.path.join(GOLD, d, "manifest.json")) and not d.startswith("committed")))
+@pytest.mark.parametrize("case", sorted(d for d in os.listdir(GOLD) if os.path.isfile(os.path.join(GOLD, d, "manifest.json"))))
 def test_golden_fixtures_through_hip(case, sim, ctx, tmp_path):
     """front-half outputs of the HIP path against the files the compiled reference produced"""
     import gzip
@@ -446,3 +446,139 @@ def test_random_data_sets_and_launch_shapes(sim, ctx, case):
     assert ro.cns_out() == rg.cns_out(), (shape, env, block, pk)
     assert ro.assembly_fasta() == rg.assembly_fasta()
     rg.close(); ro.close(); be.close(); ds.close()
+
+
+# ---------------------------------------------------------------------------------------------- round 2
+def test_edge_shards_merge_on_one_gpu(sim, ctx, tmp_path):
+    """multi-GPU phase 2 on one GPU: three runs take a third of the work queue each (dealt by estimated cost), exchange their results
+    blobs, and every one of them stitches the assembly of the unsharded run; before the exchange stitching is refused"""
+    pre = sim("--genome-len", "400000", "--seed", "61", "--variant-per-mb", "30", "--cov", "12")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    prm = ds.params()
+    ctx.upload(ds)
+    whole = host.Run(ds, prm, ctx.backend(), str(tmp_path / "whole"))
+    whole.all()
+    parts, blobs = [], []
+    for r in range(3):
+        run = host.Run(ds, prm, ctx.backend(), str(tmp_path / f"part{r}"))
+        run.set_edge_shard(r, 3)
+        run.chain(); run.graph(); run.coords(); run.consensus()
+        assert 0 < run.n_edges < whole.n_edges and run.n_edges_total == whole.n_edges
+        with pytest.raises(host.HostError):
+            run.assemble()
+        blobs.append(run.results_export())
+        parts.append(run)
+    assert sum(p.n_edges for p in parts) == whole.n_edges
+    for r, run in enumerate(parts):
+        run.results_import(b"".join(blobs))          # concatenation of every rank's blob, own included
+        assert run.results_missing == 0
+        run.assemble()
+        assert run.assembly_fasta() == whole.assembly_fasta()
+        assert util.compare_dirs(str(tmp_path / "whole"), str(tmp_path / f"part{r}")) == []
+
+
+def _full_size_against_oracle(sim, ctx, args, min_edges):
+    pre = sim(*args)
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    prm = ds.params()
+    ctx.upload(ds)
+    rg = host.Run(ds, prm, ctx.backend(), None)
+    rg.all()
+    ob = orclib.OracleBackend(ds, os.cpu_count() or 8)
+    ro = host.Run(ds, prm, ob.table, None)
+    ro.all()
+    assert rg.n_edges >= min_edges
+    assert_same_arrays(ro.chain_out(), rg.chain_out(), "chain")
+    assert_same_arrays(ro.edges_out(), rg.edges_out(), "edges")
+    assert_same_arrays(ro.coords_out(), rg.coords_out(), "coords")
+    assert ro.cns_out() == rg.cns_out()
+    assert ro.assembly_fasta() == rg.assembly_fasta()
+    rg.close(); ro.close(); ob.close(); ds.close()
+
+
+def test_configs2_full_size_against_oracle(sim, ctx):
+    """BASELINE configs[2] at full size (12 Mb genome, Nanopore-like 25x: bench.py's default data set): every stage and every consensus
+    identical to the oracle's"""
+    _full_size_against_oracle(sim, ctx, ("--genome-len", "12000000", "--seed", hex(0x4841534C + 2), "--model", "nanopore", "--cov", "25", "--variant-per-mb", "1.5"), 800)
+
+
+def test_configs1_bench_dataset_against_oracle(sim, ctx):
+    """BASELINE configs[1] at full size WITH the planted variants (bench.py's E. coli-size data set): identical to the oracle's"""
+    _full_size_against_oracle(sim, ctx, ("--genome-len", "4600000", "--seed", hex(0x4841534C + 1), "--model", "pacbio", "--cov", "25", "--variant-per-mb", "1.5"), 300)
+
+
+def test_hairpin_reads_through_hip(sim, ctx, tmp_path):
+    """missed-adapter reads (the palindrome rule of Longread.cpp:182-232 fires on every one of them): all stages identical to the oracle's"""
+    pre = sim("--genome-len", "200000", "--seed", "8", "--variant-per-mb", "30", "--cov", "14", "--hairpin-frac", "0.1")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    ro, rg, ob = both(ds, ctx, str(tmp_path / "o"), str(tmp_path / "g"))
+    assert_same_arrays(ro.chain_out(), rg.chain_out(), "chain")
+    assert_same_arrays(ro.edges_out(), rg.edges_out(), "edges")
+    assert ro.cns_out() == rg.cns_out() and ro.assembly_fasta() == rg.assembly_fasta()
+    assert util.compare_dirs(str(tmp_path / "o"), str(tmp_path / "g")) == []
+
+
+def _read_text(ds, rid, strand=0):
+    n = ds.reads.len[rid]
+    off = ds.reads.off[rid]
+    s = "".join("ACGT"[(ds.reads.packed[off + (i >> 2)] >> ((i & 3) * 2)) & 3] for i in range(n))
+    return s if strand == 0 else s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def test_poa_supports_edge_cases_through_hip(sim, ctx):
+    """the sub-sequence rule of Assemble.cpp:530-551 on the device: epos + 1 < spos wraps in 32 bits and takes the rest of the read,
+    epos + 1 == spos is an empty sequence and is skipped, an edge whose sequences are all empty has an empty consensus, spos beyond
+    the read is an error; every consensus equals the oracle's on the same substrings"""
+    pre = sim("--genome-len", "60000", "--seed", "26", "--variant-per-mb", "40", "--cov", "14")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    ctx.upload(ds)
+    lens = [ds.reads.len[i] for i in range(8)]
+    r0 = _read_text(ds, 0)
+    a, b = 100, 700
+    edges = [
+        [(0, 0, a, b - 1), (0, 0, a + 3, b + 5), (0, 0, a, b - 1)],                       # plain
+        [(0, 0, lens[0] - 400, lens[0] - 402), (0, 0, lens[0] - 400, lens[0] - 1)],       # wrap: epos + 1 < spos -> tail of the read from spos
+        [(0, 0, 50, 49), (1, 1, 10, 9)],                                                  # every sequence empty -> ""
+        [(0, 0, 50, 49), (0, 0, a, b - 1), (0, 1, 20, 19)],                               # empty ones skipped
+        [(0, 0, lens[0], 5)],                                                             # spos == length: empty after the clamp
+        [(0, 1, 30, 629), (0, 1, 30, 629)],                                               # reverse strand
+    ]
+    got = ctx.poa_supports(edges)
+    rc0 = _read_text(ds, 0, 1)
+    want = [orclib.poa_consensus([r0[a:b], r0[a + 3:b + 6], r0[a:b]]), orclib.poa_consensus([r0[lens[0] - 400:], r0[lens[0] - 400:]]), "",
+            orclib.poa_consensus([r0[a:b]]), "", orclib.poa_consensus([rc0[30:630]] * 2)]
+    assert got == want
+    assert got[1] == r0[lens[0] - 400:] and got[3] == r0[a:b]
+    with pytest.raises(hip.HipError):
+        ctx.poa_supports([[(0, 0, lens[0] + 1, lens[0] + 10)]])                           # the reference would throw std::out_of_range
+
+
+def test_poa_known_answers_through_hip(ctx):
+    """the known-answer sets of tests/test_poa_known_answers.py through the HIP kernel (hx_poa_sequences), and random noisy sets against the oracle"""
+    import random
+    s = "ACGTTGCAAGGCTTAACCGGTACGATCGATTAGC"
+    a = "ACGTACGTACGTTTGACCAGTACGGATCAAGGCT"
+    sub = a[:10] + ("A" if a[10] != "A" else "C") + a[11:]
+    dele, ins = a[:12] + a[15:], a[:12] + "GGG" + a[12:]
+    sets = [[s] * 5, [s], [], ["", ""], ["A"], ["", "ACGT", ""], [a, sub, a], [sub, a, a], [sub, sub, a], [a, dele, a, a], [dele, dele, a, dele],
+            [ins, a, a, a, ins], [ins, ins, a, ins]]
+    rnd = random.Random(9)
+    for _ in range(24):
+        L = rnd.choice([1, 2, 3, 30, 63, 64, 65, 300, 700, 1500])
+        t = "".join(rnd.choice("ACGT") for _ in range(L))
+
+        def noisy():
+            out = []
+            for ch in t:
+                r = rnd.random()
+                if r < 0.05:
+                    continue
+                out.append(rnd.choice("ACGT") if r < 0.09 else ch)
+                if rnd.random() < 0.04:
+                    out.append(rnd.choice("ACGT"))
+            return "".join(out)
+        sets.append([noisy() for _ in range(rnd.choice([1, 2, 3, 9, 25]))])
+    got = ctx.poa_sequences(sets)
+    want = [orclib.poa_consensus(st) for st in sets]
+    assert got == want
+    assert got[0] == s and got[2] == "" and got[6] == a and got[8] == sub and got[10] == dele and got[12] == ins

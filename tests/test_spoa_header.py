@@ -1,0 +1,51 @@
+"""include/spoa_hx.hpp — the spoa.hpp-shaped C++ header over libhaslr_hip.so: a caller written against the reference's
+five spoa symbols compiles and links against it (CPU), fails loudly without a device (no fallback), and on the GPU returns the oracle's
+consensus for every set, through the per-edge objects and through the batch entry."""
+import os
+import random
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def caller(built, tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("spoa") / "spoa_caller")
+    lib = os.path.join(ROOT, "haslr_amd", "lib")
+    subprocess.check_call(["g++", "-O2", "-std=c++11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "spoa_caller.cpp"), "-o", exe,
+                           "-L", lib, "-lhaslr_hip", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def sets():
+    rnd = random.Random(3)
+    out = [["ACGTACGTTTGACCA"] * 3, ["ACGTACGTACGTTTGACCAGTACGGATC", "ACGTACGTACATTTGACCAGTACGGATC", "ACGTACGTACGTTTGACCAGTACGGATC"], ["A"], ["-", "ACGT"]]
+    for L in (40, 333, 900):
+        t = "".join(rnd.choice("ACGT") for _ in range(L))
+        out.append(["".join(c for c in t if rnd.random() > 0.06) for _ in range(7)])
+    return out
+
+
+def text(ss):
+    return "\n\n".join("\n".join(st) for st in ss) + "\n"
+
+
+def test_caller_compiles_and_has_no_cpu_fallback(caller):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present: covered by the gpu test")
+    r = subprocess.run([caller], input=text(sets()), capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr, (r.returncode, r.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [[], ["--batch"]])
+def test_caller_returns_the_oracle_consensus(caller, mode):
+    import orclib
+    ss = sets()
+    r = subprocess.run([caller] + mode, input=text(ss), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = [orclib.poa_consensus([q for q in st if q != "-"]) for st in ss]
+    assert r.stdout.split("\n")[:-1] == want

@@ -96,6 +96,8 @@ struct Opts {
     int64_t read_cap = 120000;
     double variant_per_mb = 6.0;   // planted variant molecules per Mb, per kind
     bool variants = true;
+    double hairpin_frac = 0;       // fraction of reads that continue with the reverse complement of their own tail (missed-adapter reads:
+                                   // the same contigs hit twice on opposite strands, Longread.cpp:182-232's palindrome rule)
 };
 
 struct ErrModel { double ins, del, sub; };
@@ -120,6 +122,7 @@ int main(int argc, char** argv) {
         else if (a == "--read-median") o.read_median = atof(val("--read-median"));
         else if (a == "--variant-per-mb") o.variant_per_mb = atof(val("--variant-per-mb"));
         else if (a == "--no-variants") o.variants = false;
+        else if (a == "--hairpin-frac") o.hairpin_frac = atof(val("--hairpin-frac"));
         else { fprintf(stderr, "hxsim: unknown option %s\n", a.c_str()); return 2; }
     }
     ErrModel em{0.08, 0.03, 0.02};
@@ -398,8 +401,7 @@ int main(int argc, char** argv) {
                     int64_t g0 = os + (t0 - ((s - a) + (os - as))), g1 = g0 + (t1 - t0);   // axis coords of the aligned block
                     if (!P.rev) { h.ts = (uint32_t)(P.coff + (g0 - P.s)); h.te = (uint32_t)(P.coff + (g1 - P.s)); }
                     else { h.ts = (uint32_t)(P.coff - (g1 - 1 - P.s)); h.te = (uint32_t)(P.coff - (g0 - P.s) + 1); std::reverse(ops.begin(), ops.end()); }
-                    h.rev = read_rev != P.rev;
-                    if (read_rev) { h.qs = rlen - qe; h.qe = rlen - qs; } else { h.qs = qs; h.qe = qe; }
+                    h.rev = P.rev; h.qs = qs; h.qe = qe;      // in the orientation the read was synthesised in; flipped below with the read
                     h.tid = new_id[P.contig]; h.tlen = C.seq.size();
                     h.mapq = P.mapq_lo + (uint8_t)rng.below(P.mapq_hi - P.mapq_lo + 1);
                     // run-length CIGAR
@@ -413,6 +415,21 @@ int main(int argc, char** argv) {
                     hits.push_back(std::move(h));
                 }
             }
+            if (o.hairpin_frac > 0 && rng.uni() < o.hairpin_frac) {
+                // the polymerase went round the hairpin adapter: the read continues with the reverse complement of its last X bases, and
+                // every hit inside that stretch appears a second time, mirrored, on the other strand (same target interval, same CIGAR)
+                const uint32_t X = (uint32_t)(rlen * (0.3 + 0.6 * rng.uni()));
+                const size_t n0 = hits.size();
+                for (size_t k = 0; k < n0; k++) {
+                    if (hits[k].qs < rlen - X) continue;
+                    Hit m = hits[k];
+                    m.qs = 2 * rlen - hits[k].qe; m.qe = 2 * rlen - hits[k].qs; m.rev = !m.rev;
+                    hits.push_back(std::move(m));
+                }
+                rseq += revcomp(rseq.substr(rlen - X));
+                rlen = rseq.size();
+            }
+            if (read_rev) for (Hit& h : hits) { const uint32_t qs = h.qs; h.qs = rlen - h.qe; h.qe = rlen - qs; h.rev = !h.rev; }
             std::sort(hits.begin(), hits.end(), [](const Hit& x, const Hit& y) { return x.qs != y.qs ? x.qs < y.qs : x.qe < y.qe; });
             std::string out = read_rev ? revcomp(rseq) : rseq;
             fprintf(fr, ">%" PRIu64 "\n%s\n", read_id, out.c_str());
