@@ -147,13 +147,20 @@ def main():
         raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # HASLR_DIST_BACKEND=gloo (testing): the N>1 path on a box with fewer GPUs than ranks - ranks share devices, collectives go through host memory
+    backend_name = os.environ.get("HASLR_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend_name == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    comm_device = torch.device("cpu") if backend_name == "gloo" else device
     torch.zeros(1, device="cuda")   # initialise torch's HIP context (streams, queues) now, not inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend_name == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     wl = WORKLOADS[args.workload]
     glen = args.genome_len or wl["genome"] * world
@@ -167,7 +174,7 @@ def main():
     t_parse = time.perf_counter() - t0
     in_bytes = sum(os.path.getsize(pre + x) for x in (".contigs.fa", ".reads.fa", ".paf"))
     prm = ds.params()
-    ctx = hip.HipContext(local_rank)
+    ctx = hip.HipContext(dev_index)
     if args.poa_block:
         ctx.set_poa_block(args.poa_block)
     t1 = time.perf_counter()
@@ -181,11 +188,11 @@ def main():
         b = hd.shard_bounds(ds.read_hit_off, ds.reads.n, world)
         ctx.set_read_shard(b[rank], b[rank + 1])
         lr_begin = b[rank]
-        backend = hd.ShardedBackend(ctx.backend(), hd.HipRecords(ctx, prm))
+        backend = hd.ShardedBackend(ctx.backend(), hd.HipRecords(ctx, prm, comm_device))
         table = backend.table
 
         def gather(run):
-            gathered[0] = hd.gather_results(run, device)
+            gathered[0] = hd.gather_results(run, comm_device)
     else:
         table, gather = ctx.backend(), None
 
@@ -197,7 +204,7 @@ def main():
 
     dt, last = measure(ctx, ds, prm, table, args.steps, args.warmup, world, rank, sync, gather, lr_begin)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -207,8 +214,8 @@ def main():
     cns = last.cns_out()
     poa_ms = tim["poa"]["ms"] / max(1, tim["poa"]["launches"])
     alg_bytes = (st["seq_bases"] + 3) // 4 + sum(len(c) for c in cns)   # 2-bit gap bases read once + consensus written once
-    stats = torch.tensor([st["dp_cells"], st["seq_bases"], alg_bytes, last.n_edges], dtype=torch.float64, device="cuda")
-    tms = torch.tensor([poa_ms], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([st["dp_cells"], st["seq_bases"], alg_bytes, last.n_edges], dtype=torch.float64, device=comm_device)
+    tms = torch.tensor([poa_ms], dtype=torch.float64, device=comm_device)
     if world > 1:
         dist.all_reduce(stats)
         dist.all_reduce(tms, op=dist.ReduceOp.MAX)
@@ -225,8 +232,8 @@ def main():
     sha = hashlib.sha256(fasta.encode()).hexdigest()
     assembly = {"sha256": sha, "contigs": fasta.count(">"), "bases": sum(len(x) for x in fasta.split("\n") if x and x[0] != ">")}
     if world > 1:
-        h = torch.frombuffer(bytearray(bytes.fromhex(sha)), dtype=torch.uint8).to(device)
-        hs = [torch.zeros(32, dtype=torch.uint8, device=device) for _ in range(world)]
+        h = torch.frombuffer(bytearray(bytes.fromhex(sha)), dtype=torch.uint8).to(comm_device)
+        hs = [torch.zeros(32, dtype=torch.uint8, device=comm_device) for _ in range(world)]
         dist.all_gather(hs, h)
         assembly["same_on_all_ranks"] = all(bool(torch.equal(hs[0], x)) for x in hs)
         assembly["results_gathered_bytes"] = gathered[0]

@@ -71,11 +71,13 @@ def allgather_bytes(blob: bytes, device, group=None) -> bytes:
 class HipRecords:
     """Edge-support records of a rank's read shard on its HIP context (include/haslr_hip.h: hx_edge_emit / _export / _import)."""
 
-    def __init__(self, ctx, params):
+    def __init__(self, ctx, params, comm_device=None):
+        """comm_device: where the collective runs (the GPU for RCCL; torch.device("cpu") stages through host memory, for gloo)"""
         from . import hip
         self.ctx, self.params = ctx, params
         self.rec_bytes = hip.records_bytes()
         self.device = torch.device("cuda", torch.cuda.current_device())
+        self.comm_device = comm_device or self.device
 
     def emit(self):
         return self.ctx.edge_emit(self.params)
@@ -83,10 +85,11 @@ class HipRecords:
     def export(self, n):
         local = torch.empty(max(n, 1) * self.rec_bytes, dtype=torch.uint8, device=self.device)
         self.ctx.edge_records_export(C.c_void_p(local.data_ptr()), n)
-        return local
+        return local.to(self.comm_device)
 
     def import_(self, merged, total, out):
         from . import hip
+        merged = merged.to(self.device)
         torch.cuda.synchronize()
         return hip.lib().hx_edge_records_import(self.ctx._h, C.c_void_p(merged.data_ptr()), total, out)
 
