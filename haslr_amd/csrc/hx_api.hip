@@ -97,13 +97,13 @@ struct PoaPoolBufs {
     DV<uint32_t> row_meta, row_pred0, row_pred1;
     DV<uint4> nrec;
     DV<uint8_t> dir;
-    DV<unsigned long long> mbox; DV<int32_t> farleft, sinkbuf; DV<uint32_t> csync; DV<uint16_t> row_al;   // cluster mode (edges shared by several workgroups)
+    DV<unsigned long long> mbox; DV<int32_t> sinkbuf; DV<uint32_t> csync; DV<uint16_t> row_al;   // cluster mode (edges shared by several workgroups)
     void release_all() {
         code.release(); n_aligned.release(); mark.release(); check.release(); row_code.release(); row_sink.release(); seq.release();
         aligned.release(); in_head.release(); in_tail.release(); out_head.release(); out_tail.release(); rank2node.release(); node2rank.release();
         stack.release(); row_pred_off.release(); pred_rank.release(); e_from.release(); e_to.release(); e_next_in.release(); e_next_out.release();
         score.release(); pred.release(); e_w.release(); aln_node.release(); aln_pos.release(); H.release(); row_meta.release(); row_pred0.release();
-        row_pred1.release(); nrec.release(); dir.release(); mbox.release(); farleft.release(); sinkbuf.release(); csync.release(); row_al.release();
+        row_pred1.release(); nrec.release(); dir.release(); mbox.release(); sinkbuf.release(); csync.release(); row_al.release();
     }
 };
 }  // namespace
@@ -555,6 +555,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     std::vector<uint8_t> grow(ne, 0);          // times an edge's graph outgrew its workspace: the node estimate doubles each time
     std::vector<uint8_t> force_nodir(ne, 0);   // edges whose in-degrees outgrew the direction bytes
     std::vector<uint8_t> full_h(ne, 0);        // edges that run with the score-matrix traceback
+    std::vector<uint8_t> many_sinks(ne, 0);    // edges with more sink rows than the smaller kernels keep in LDS: one 1024-lane workgroup
     const uint32_t max_indeg = getenv("HX_POA_MAX_INDEG") ? std::min<uint32_t>(16, (uint32_t)atoi(getenv("HX_POA_MAX_INDEG"))) : 16;   // (testing: forces the score-matrix retry earlier)
     const uint32_t cl_lanes = getenv("HX_POA_MEMBER_LANES") ? (uint32_t)atoi(getenv("HX_POA_MEMBER_LANES")) : 512;   // lanes per cluster member
     const uint32_t cl_min = getenv("HX_POA_CLUSTER_MIN") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MIN")) : 2048;       // columns above which an edge is shared
@@ -570,25 +571,33 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     // Classes 6..10 = classes 1..5 for the edges that need the score-matrix traceback (rare: an in-degree
     // the direction bytes cannot hold, or the test switch), launched after their direction-byte twins on the same streams.
     constexpr int NCLS = 11;
+    static constexpr uint64_t kPoaLdsMax = 140 * 1024;   // dynamic LDS of a POA workgroup at most (160 KB per CU less the 1024-lane kernel's static 16.5 KB: sink lists, wave mailboxes)
     static const int kClassNT[NCLS] = {0, 1024, 512, 256, 128, 64, 1024, 512, 256, 128, 64};
     const uint32_t wave_max = getenv("HX_POA_WAVE_MAX") ? (uint32_t)atoi(getenv("HX_POA_WAVE_MAX")) : 512;   // columns handled by ONE wavefront per edge
     // columns per lane of the multi-wave classes: 4 while edges are few (more lanes = a shorter row for the edges that set the step time),
     // 16 when thousands of edges keep every CU busy anyway (a row then costs fewer instructions in total: the per-row overhead is per wave).
     // Measured: 1 846 edges 463 ms with 4 vs 482 ms with 16; 5 570 edges 1 166 vs 1 151 ms; 13 262 edges 4.17 vs 3.97 s.
-    const uint32_t cols_per_lane = getenv("HX_POA_COLS") ? (uint32_t)atoi(getenv("HX_POA_COLS")) : todo.size() > 4096 ? 16 : 4;
+    const uint32_t cols_per_lane = getenv("HX_POA_COLS") ? (uint32_t)atoi(getenv("HX_POA_COLS")) : todo.size() > 4096 ? 8 : 4;
     auto class_of = [&](uint32_t e) -> int {   // launch class of an edge that is not shared (members == 1), direction-byte flavour
         static const uint32_t kMaxCm[6] = {0, 8, 16, 32, 32, 32};   // columns per lane each kernel variant keeps in registers
         const uint32_t ncol = P.edges[e].lmax + 1;
         int k = 5;
+        if (many_sinks[e]) return 1;   // (the 1024-lane kernel keeps the full sink list)
         if (c->poa_block) { for (k = 1; k < 5 && kClassNT[k] > c->poa_block; k++) {} }
         else if (ncol > wave_max) { k = 4; while (k > 1 && (uint64_t)kClassNT[k] * cols_per_lane < ncol) k--; }
         while (k > 1 && (uint64_t)kClassNT[k] * kMaxCm[k] < ncol) k--;
         return k;
     };
-    auto ring_rows_of = [](uint32_t nt, uint32_t cm, uint64_t& row_bytes) -> uint32_t {   // kept rows the LDS ring holds; row_bytes returns the ring's LDS bytes
-        row_bytes = (uint64_t)cm * (nt + 1) * 4;   // planes of nt + 1 words
-        const uint64_t lds_budget = nt >= 1024 ? 128 * 1024 : nt == 64 ? 32 * 1024 : 64 * 1024 * (nt / 128 > 2 ? 2 : 1);
-        const uint64_t rows_fit = std::min<uint64_t>(lds_budget * 9 / 8, 140 * 1024) / row_bytes;   // ring slots (+ 1 scratch slot when there is room)
+    // LDS of the kept-row ring. Few edges (their longest sets the duration): as many kept rows as fit, so that hardly any row is read back
+    // from HBM. Thousands of edges (every CU busy): what counts is waves per SIMD - each wave spends most of its time waiting for its own
+    // dependent instructions - so the ring is cut to HX_POA_RING_KB per wave and several workgroups share a CU.
+    const bool many_edges = todo.size() > 4096;
+    const uint64_t ring_kb_wave = getenv("HX_POA_RING_KB") ? (uint64_t)std::max(1, atoi(getenv("HX_POA_RING_KB"))) : many_edges ? 9 : 0;   // 0 = no cut
+    auto ring_rows_of = [ring_kb_wave](uint32_t nt, uint32_t cm, uint64_t& row_bytes) -> uint32_t {   // kept rows the LDS ring holds; row_bytes returns the ring's LDS bytes
+        row_bytes = (uint64_t)cm * (nt / 64) * 65 * 4;   // planes of 65 words per wave
+        uint64_t lds_budget = nt >= 1024 ? 128 * 1024 : nt == 64 ? 32 * 1024 : 64 * 1024 * (nt / 128 > 2 ? 2 : 1);
+        if (ring_kb_wave) lds_budget = std::min<uint64_t>(lds_budget, std::max<uint64_t>(ring_kb_wave * 1024 * (nt / 64), 3 * row_bytes) * 8 / 9);
+        const uint64_t rows_fit = std::min<uint64_t>(lds_budget * 9 / 8, kPoaLdsMax) / row_bytes;   // ring slots (+ 1 scratch slot when there is room)
         const uint32_t R = rows_fit >= 8 ? 8 : rows_fit >= 4 ? 4 : rows_fit >= 2 ? 2 : 0;   // power of two (slot = kept-row counter & (R-1))
         row_bytes *= R ? R + (rows_fit > R ? 1 : 0) : 0;                                    // -> LDS bytes of the ring
         return R;
@@ -617,7 +626,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             // long gaps: the DP columns of the edge are shared by several workgroups (one CU each), ~8 columns per lane
             E.members = 1;
             const uint32_t ncol = E.lmax + 1;
-            if (!c->poa_block && !c->poa_no_dir && !force_nodir[e] && ncol > cl_min) E.members = (uint32_t)std::min<uint64_t>(cl_max, (ncol + (uint64_t)cl_lanes * cl_cols - 1) / ((uint64_t)cl_lanes * cl_cols));
+            if (!c->poa_block && !c->poa_no_dir && !force_nodir[e] && !many_sinks[e] && ncol > cl_min) E.members = (uint32_t)std::min<uint64_t>(cl_max, (ncol + (uint64_t)cl_lanes * cl_cols - 1) / ((uint64_t)cl_lanes * cl_cols));
             if (E.members < 2 || ((uint64_t)ncol + (uint64_t)E.members * cl_lanes - 1) / ((uint64_t)E.members * cl_lanes) > 32) E.members = 1;   // (members too small for this gap: one workgroup)
         }
         // Sharing an edge among several CUs buys latency for the edge and costs throughput (the other members idle while member 0 walks
@@ -656,9 +665,11 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
         auto edge_bytes = [&](uint32_t e, uint64_t& nn, uint64_t& dc, uint64_t& hc, uint64_t& cle) -> uint64_t {
             const hxk::PoaEdge& E = P.edges[e];
             const uint64_t rw = ((uint64_t)E.lmax + 1 + 31) & ~31ull;                 // rows padded to 32 columns (the widest lane chunk)
-            nn = (uint64_t)E.vcap + 1; dc = full_h[e] ? 0 : nn * rw; hc = (uint64_t)E.hrows * rw;
+            const uint64_t waves = (uint64_t)E.members * ((E.members > 1 ? cl_lanes : (uint32_t)kClassNT[class_of(e)]) / 64);
+            const uint64_t rwh = rw + (waves > 1 ? (waves + 3) & ~3ull : 0);       // rows of H end with one word per wave of the edge's pipeline
+            nn = (uint64_t)E.vcap + 1; dc = full_h[e] ? 0 : nn * rw; hc = (uint64_t)E.hrows * rwh;
             cle = E.members > 1 ? (uint64_t)E.members * nn : 0;
-            return nn * 86 + (uint64_t)E.ecap * 24 + hc * 4 + dc + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8 + cle * 12;
+            return nn * 86 + (uint64_t)E.ecap * 24 + hc * 4 + dc + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8 + cle * 8;
         };
         std::vector<std::vector<uint32_t>> batches;
         {
@@ -698,7 +709,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                 HX_RSV(B.node2rank, no); HX_RSV(B.row_pred_off, no); HX_RSV(B.score, no); HX_RSV(B.pred, no); HX_RSV(B.pred_rank, eo); HX_RSV(B.e_from, eo);
                 HX_RSV(B.e_to, eo); HX_RSV(B.e_next_in, eo); HX_RSV(B.e_next_out, eo); HX_RSV(B.e_w, eo); HX_RSV(B.stack, sto); HX_RSV(B.aln_node, ao); HX_RSV(B.aln_pos, ao);
                 HX_RSV(B.row_meta, no); HX_RSV(B.row_pred0, no); HX_RSV(B.row_pred1, no); HX_RSV(B.nrec, no); HX_RSV(B.seq, so); HX_RSV(d_cns, co);
-                HX_RSV(B.mbox, std::max<uint64_t>(1, clo)); HX_RSV(B.farleft, std::max<uint64_t>(1, clo));
+                HX_RSV(B.mbox, std::max<uint64_t>(1, clo));
                 HX_RSV(B.csync, (size_t)ne * 8); HX_RSV(B.sinkbuf, (size_t)ne * (1 + 2 * 1024));
 #undef HX_RSV
                 return hipSuccess;
@@ -714,47 +725,52 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             uint64_t n_blocks_total = 0;
             for (uint32_t e : batch) n_blocks_total += P.edges[e].members;
             HIPCHK(d_edges.reserve(ne)); HIPCHK(d_len.reserve(ne)); HIPCHK(d_status.reserve(ne));
-            std::vector<uint32_t> cls_list[NCLS];
-            uint32_t cls_cm[NCLS];
-            for (int k = 0; k < NCLS; k++) cls_cm[k] = 1;
+            // launch classes: (shared?, lanes per workgroup, columns per lane, traceback flavour) - one kernel instance each, so that every
+            // launch runs with the registers ITS row loop needs (kernels/poa.hip)
+            struct Cls { bool shared; uint32_t nt, cm; bool dir; std::vector<uint32_t> edges; size_t blocks = 0; };
+            std::vector<Cls> classes;
+            auto cls_of = [&](bool shared, uint32_t nt, uint32_t cm, bool dir) -> Cls& {
+                for (Cls& q : classes) if (q.shared == shared && q.nt == nt && q.cm == cm && q.dir == dir) return q;
+                classes.push_back(Cls{shared, nt, cm, dir, {}});
+                return classes.back();
+            };
             for (uint32_t e : batch) {
                 const uint32_t ncol = P.edges[e].lmax + 1;
                 if (ncol > 65536) return fail("hx_poa_batch: gap sub-sequence longer than 65535 bases is not supported by the POA kernel");
                 if (P.edges[e].members > 1) {
-                    const uint32_t lanes = P.edges[e].members * cl_lanes;
-                    uint32_t cm = (ncol + lanes - 1) / lanes, cmr = 4;
-                    while (cmr < cm) cmr <<= 1;
-                    if (cmr > 32) return fail("hx_poa_batch: gap too long for the configured cluster size (raise HX_POA_CLUSTER_MAX)");
-                    cls_cm[0] = std::max(cls_cm[0], cmr);
-                    cls_list[0].push_back(e);
+                    const uint32_t cmr = cm_round(ncol, P.edges[e].members * cl_lanes);
+                    if (cmr > (uint32_t)hxk::poa_kernel_max_cm((int)cl_lanes)) return fail("hx_poa_batch: gap too long for the configured cluster size (raise HX_POA_CLUSTER_MAX)");
+                    cls_of(true, cl_lanes, cmr, true).edges.push_back(e);   // batch is cost-sorted, so every class list is too
                     continue;
                 }
                 if (ncol > 32768) return fail("hx_poa_batch: a gap longer than 32767 bases needs the shared (cluster) mode: direction-byte traceback, automatic block size");
-                int k = class_of(e);
-                if (full_h[e]) k += 5;
-                cls_list[k].push_back(e);   // batch is cost-sorted, so every class list is too
-                uint32_t cm = (ncol + kClassNT[k] - 1) / kClassNT[k], cmr = 4;
-                while (cmr < cm) cmr <<= 1;
-                cls_cm[k] = std::max(cls_cm[k], cmr);
+                const uint32_t nt = (uint32_t)kClassNT[class_of(e)];
+                cls_of(false, nt, cm_round(ncol, nt), !full_h[e]).edges.push_back(e);
             }
+            // order of the launches: shared edges first (they set the duration), then by lanes; score-matrix launches after their direction-byte twins
+            std::stable_sort(classes.begin(), classes.end(), [](const Cls& a, const Cls& b) {
+                if (a.dir != b.dir) return a.dir;
+                if (a.shared != b.shared) return a.shared;
+                if (a.nt != b.nt) return a.nt > b.nt;
+                return a.cm > b.cm;
+            });
             std::vector<uint32_t> order_all;   // one entry per workgroup: edge | member << 24
-            size_t cls_blocks[NCLS];
-            for (int k = 0; k < NCLS; k++) {
+            for (Cls& q : classes) {
                 const size_t before = order_all.size();
-                if (k == 0 && !getenv("HX_POA_NO_XCD_MAP")) {
+                if (q.shared && !getenv("HX_POA_NO_XCD_MAP")) {
                     // Workgroups are handed to the 8 XCDs round-robin by index: put the members of one edge 8 indices apart so that they share an
                     // XCD (one L2 for the carries, the handshakes and the direction bytes member 0 walks back over). Holes are no-op workgroups.
-                    for (size_t g0 = 0; g0 < cls_list[0].size(); g0 += 8) {
-                        const size_t g1 = std::min(cls_list[0].size(), g0 + 8);
+                    for (size_t g0 = 0; g0 < q.edges.size(); g0 += 8) {
+                        const size_t g1 = std::min(q.edges.size(), g0 + 8);
                         uint32_t gmax = 0;
-                        for (size_t j = g0; j < g1; j++) gmax = std::max(gmax, P.edges[cls_list[0][j]].members);
+                        for (size_t j = g0; j < g1; j++) gmax = std::max(gmax, P.edges[q.edges[j]].members);
                         for (uint32_t m = 0; m < gmax; m++)
                             for (size_t j = g0; j < g0 + 8; j++)
-                                order_all.push_back(j < g1 && m < P.edges[cls_list[0][j]].members ? (cls_list[0][j] | (m << 24)) : 0x00ffffffu);
+                                order_all.push_back(j < g1 && m < P.edges[q.edges[j]].members ? (q.edges[j] | (m << 24)) : 0x00ffffffu);
                     }
                 } else
-                    for (uint32_t e : cls_list[k]) for (uint32_t m = 0; m < P.edges[e].members; m++) order_all.push_back(e | (m << 24));
-                cls_blocks[k] = order_all.size() - before;
+                    for (uint32_t e : q.edges) for (uint32_t m = 0; m < P.edges[e].members; m++) order_all.push_back(e | (m << 24));
+                q.blocks = order_all.size() - before;
             }
             if (ne >= (1u << 24)) return fail("hx_poa_batch: more than 2^24 edges in one call");
             HIPCHK(hipMemcpyAsync(d_edges.p, P.edges.data(), (size_t)ne * sizeof(hxk::PoaEdge), hipMemcpyHostToDevice, s));
@@ -763,45 +779,38 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             hxk::PoaPools pools{B.code.p, B.n_aligned.p, B.aligned.p, B.in_head.p, B.in_tail.p, B.out_head.p, B.out_tail.p, B.rank2node.p, B.node2rank.p,
                                 B.mark.p, B.check.p, B.stack.p, B.score.p, B.pred.p, B.row_code.p, B.row_sink.p, B.row_pred_off.p, B.pred_rank.p, B.row_meta.p, B.row_pred0.p, B.row_pred1.p, B.nrec.p,
                                 B.e_from.p, B.e_to.p, B.e_next_in.p, B.e_next_out.p, B.e_w.p, B.aln_node.p, B.aln_pos.p, B.H.p, B.dir.p, B.seq.p,
-                                B.mbox.p, B.farleft.p, B.csync.p, B.sinkbuf.p, B.row_al.p};
+                                B.mbox.p, B.csync.p, B.sinkbuf.p, B.row_al.p};
             c->tick();
             HIPCHK(hipEventRecord(c->poa_ev[6], s));
-            size_t opos = 0;
-            for (int k = 0; k < NCLS; k++) {
-                if (cls_list[k].empty()) continue;
-                const int sk = k < 6 ? k : k - 5;   // stream / event of the class
-                const uint32_t nt = k == 0 ? cl_lanes : (uint32_t)kClassNT[k];
-                // LDS of the launch: the largest ring any of its edges can use at its own row width (the kernel sizes every edge's ring by what it is given)
-                uint32_t R = 0;
+            size_t opos = 0, ci = 0;
+            for (const Cls& q : classes) {
+                const int sk = (int)(ci++ % 6);   // stream / event of the launch (launches that share a stream run one after the other)
+                // LDS of the launch: the ring its row width allows, a power of two of kept rows (+ a scratch slot for the rows nobody keeps)
                 uint64_t ring_need = 0;
-                for (uint32_t e : cls_list[k]) {
-                    uint64_t rb;
-                    const uint32_t ncol = P.edges[e].lmax + 1, Re = ring_rows_of(nt, cm_round(ncol, k == 0 ? P.edges[e].members * cl_lanes : nt), rb);
-                    R = std::max(R, Re);
-                    ring_need = std::max(ring_need, rb);
-                }
+                const uint32_t R = ring_rows_of(q.nt, q.cm, ring_need);
                 // few edges: ask for enough LDS per workgroup that the dispatcher cannot stack them on a handful of CUs while others idle
                 // (a lone wave runs at twice the speed of two waves sharing a SIMD); many edges: request only what the ring needs
-                uint64_t lds_bytes = ring_need;   // ring slots + the scratch slot of rows nobody keeps
+                uint64_t lds_bytes = ring_need;
                 {
                     const uint64_t per_cu = (order_all.size() + 255) / 256;
-                    if (per_cu < 8) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(144 * 1024, (156 * 1024) / per_cu - 6 * 1024));
+                    if (per_cu < 8) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(kPoaLdsMax, (158 * 1024) / per_cu - 18 * 1024));
                 }
-                for (uint32_t e : cls_list[k]) c->dbg_cls[e] = (uint8_t)k;
-                c->dbg_ring[k] = R;
+                const int dcls = q.shared ? 0 : q.nt >= 1024 ? 1 : q.nt >= 512 ? 2 : q.nt >= 256 ? 3 : q.nt >= 128 ? 4 : 5;
+                for (uint32_t e : q.edges) c->dbg_cls[e] = (uint8_t)(dcls + (q.dir ? 0 : 5));
+                c->dbg_ring[dcls + (q.dir ? 0 : 5)] = R;
                 HIPCHK(hipStreamWaitEvent(c->poa_streams[sk], c->poa_ev[6], 0));
-                hxk::poa_run(d_edges.p, d_order.p + opos, (uint32_t)cls_blocks[k], d_seqs.p, in.d_packed, in.d_roff, in.d_rlen, pools, 0, pp->match, pp->mismatch,
-                             pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)nt, R, (uint32_t)lds_bytes, nt >= 1024 && cls_cm[k] > 8u, k < 6, max_indeg, c->poa_streams[sk]);
+                hxk::poa_run(d_edges.p, d_order.p + opos, (uint32_t)q.blocks, d_seqs.p, in.d_packed, in.d_roff, in.d_rlen, pools, pp->match, pp->mismatch,
+                             pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)q.nt, (int)q.cm, R, (uint32_t)lds_bytes, q.dir, max_indeg, c->poa_streams[sk]);
                 HIPCHK(hipEventRecord(c->poa_ev[sk], c->poa_streams[sk]));
                 HIPCHK(hipStreamWaitEvent(s, c->poa_ev[sk], 0));
-                opos += cls_blocks[k];
+                opos += q.blocks;
             }
             c->tock(3);
             HIPCHK(hipGetLastError());
             if (getenv("HX_DEBUG")) {
                 HIPCHK(hipStreamSynchronize(s));
                 fprintf(stderr, "[hx] POA batch: %zu edges, %.2f GB workspace, workgroups", batch.size(), bytes / 1e9);
-                for (int k = 0; k < NCLS; k++) if (k < 6 || cls_blocks[k]) fprintf(stderr, " %s%d:%zu(cm %u)", k == 0 ? "shared/" : k > 5 ? "matrix/" : "", k ? kClassNT[k] : (int)cl_lanes, cls_blocks[k], cls_cm[k]);
+                for (const Cls& q : classes) fprintf(stderr, " %s%s%ux%u:%zu", q.shared ? "shared/" : "", q.dir ? "" : "matrix/", q.nt, q.cm, q.blocks);
                 fprintf(stderr, ", %.1f ms since the call began\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count());
             }
             std::vector<uint32_t> h_len(ne), h_status(ne);
@@ -816,6 +825,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             }
             for (uint32_t e : batch) {
                 if (h_status[e] & HXE_POA_FARROWS) { if (far_full[e]) return fail("hx_poa_batch: internal error (far-row retry)"); far_full[e] = 1; retry_same.push_back(e); continue; }
+                if (h_status[e] & HXE_POA_SINKS) { if (many_sinks[e]) return fail("hx_poa_batch: internal error (sink-list retry)"); many_sinks[e] = 1; retry_same.push_back(e); continue; }
                 if (h_status[e] & HXE_POA_NODIR) { if (force_nodir[e]) return fail("hx_poa_batch: internal error (direction-byte retry)"); force_nodir[e] = 1; retry_same.push_back(e); continue; }
                 if (h_status[e] & ~(uint32_t)HXE_POA_OVERFLOW) return fail("hx_poa_batch: internal error (kernel variant / column count mismatch)");
                 if (h_status[e] & HXE_POA_OVERFLOW) {

@@ -74,7 +74,7 @@ struct PoaEdge {
     uint32_t seq_begin, seq_end;   // into the PoaSeq table
     uint32_t vcap, ecap, lmax, hrows;
     uint64_t node_off, edge_off;   // into the node / edge pools (elements)
-    uint64_t h_off;                // into the H pool (int32 cells): hrows rows of W. Direction-byte traceback: only the rows a far successor reads
+    uint64_t h_off;                // into the H pool (int32 cells): hrows rows of W + one word per wave of the edge's pipeline. Direction-byte traceback: only the rows a far successor reads
                                    // (hrows = an estimate, overflow -> retry); score-matrix traceback: all vcap + 1 rows
     uint64_t d_off;                // into the direction-byte pool (bytes): vcap + 1 rows of W
     uint64_t seq_off;              // into the decoded-sequence pool (bytes, lmax per edge)
@@ -105,17 +105,19 @@ struct PoaPools {
     uint8_t* seq;
     // cluster mode (an edge's DP columns spread over several workgroups):
     unsigned long long* mbox;   // [member][row] = {tag, carry}: prefix maximum of the row through the member's last column (PoaEdge::cl_off)
-    int32_t* farleft;           // [member][row] = 64 x H[row][first column of the member - 1] of rows kept in HBM (PoaEdge::cl_off)
     uint32_t* csync;            // 8 words per edge: go, done, V, L, error
     int32_t* sinkbuf;           // 1 + 2*1024 words per edge: sink rows / scores when the last column lives in another member
     uint16_t* row_al;           // per rank: ranks of the node's aligned nodes in list order, 3 x 3 bits (rank delta + 4, 0 = none)
 };
+// kernel instance (largest workgroup it is compiled for) that serves workgroups of `block_threads` lanes, and the columns per lane it can be had with
+inline int poa_kernel_lanes(int block_threads) { return block_threads <= 64 ? 64 : block_threads <= 256 ? 256 : block_threads <= 512 ? 512 : 1024; }
+inline int poa_kernel_max_cm(int block_threads) { return block_threads <= 256 ? 32 : block_threads <= 512 ? 16 : 32; }
 void poa_run(const PoaEdge* edges, const uint32_t* order /* edge | member << 24, one entry per workgroup */, uint32_t n_blocks, const PoaSeq* seqs, const uint8_t* packed,
-             const uint64_t* read_off, const uint32_t* read_len, PoaPools pools, uint64_t stack_stride_unused,
+             const uint64_t* read_off, const uint32_t* read_len, PoaPools pools,
              int32_t match, int32_t mismatch, int32_t gap, char* cns, uint32_t* cns_len, uint32_t* status,
-             unsigned long long* cells, unsigned long long* phase_cycles /* 6 per edge or null */, int block_threads /* multiple of 64, <= 1024 */,
-             uint32_t ring_rows, uint32_t ring_bytes /* dynamic LDS: ring_rows x pow2ceil(ceil((lmax+1)/block)) x block x 4 */,
-             bool big /* some edge needs more than 16 columns per lane */,
+             unsigned long long* cells, unsigned long long* phase_cycles /* 12 per edge or null */, int block_threads /* multiple of 64, <= 1024 */,
+             int cm /* columns per lane of the launch: 4, 8, 16 or 32; every edge's longest sequence fits members x block_threads x cm columns */,
+             uint32_t ring_rows, uint32_t ring_bytes /* dynamic LDS */,
              bool use_dir /* direction-byte traceback (in-degrees <= max_indeg <= 16, else the edge comes back with HXE_POA_NODIR) */, uint32_t max_indeg, hipStream_t s);
 
 }  // namespace hxk

@@ -447,15 +447,24 @@ template <int CM> __device__ __forceinline__ void store_chunk_u8(uint8_t* p, con
 }
 
 // ---------------------------------------------------------------------------------------------------
-// DP over (rank, column) for one sequence against the current graph — rows live in registers.
+// DP over (rank, column) for one sequence against the current graph — rows live in registers, the waves of an edge form a pipeline.
 //
-// Lane t owns the CM contiguous columns [t*CM, t*CM+CM) and keeps the CURRENT row there. The common predecessor of
-// row i is row i-1: the lane's own registers, plus the value left of its first column, which falls out of the
-// prefix scan that row i-1 needed anyway. So the usual row costs no LDS row traffic and exactly ONE cross-lane
-// operation: the prefix-max scan of (chunk end - column*gap) that resolves the horizontal recurrence
-// H[j] = max(T[j], H[j-1]+g) — 64-lane DPP scan inside a wave, wave totals through LDS (double-buffered, one LDS-only
-// barrier per row) when the workgroup has several waves. A single-wave workgroup never synchronises; waves that own
-// no real column of this sequence only keep the barrier count.
+// Lane t of wave w owns the CM contiguous columns [(64 w + t) CM, (64 w + t + 1) CM) (w counts through all workgroups that share
+// the edge) and keeps the CURRENT row there. The common predecessor of row i is row i-1: the lane's own registers, plus the value left
+// of its first column, which falls out of the prefix scan that row i-1 needed anyway. So the usual row costs no LDS row traffic and
+// exactly ONE cross-lane operation: the 64-lane DPP prefix-max scan of (chunk end - column*gap) that resolves the horizontal
+// recurrence H[j] = max(T[j], H[j-1]+g) inside the wave.
+//
+// What crosses a wave boundary is one number per row: the prefix maximum through the wave's last column. Round 1 exchanged it with a
+// workgroup barrier per row (all waves in lock step: 65 % of the wave cycles were spent parked). Now every wave runs at its own pace
+// and is a stage of a pipeline: it publishes the carry of every finished row to a mailbox — a small tagged ring in LDS towards the
+// next wave of the workgroup, a tagged word per row in HBM towards the first wave of the next workgroup ("member") — and takes its
+// own carries from the wave on its left, 32 rows at a time (one coalesced read, lane r = row r of the batch, broadcast per row with
+// v_readlane like the row records). A wave therefore runs one batch behind its left neighbour, polls once per 32 rows and never meets
+// a barrier inside the DP. Tags (a row counter that runs through all DPs of the edge) make every entry self-validating; the consumer
+// reports how far it has read so that the producer never laps it.
+// Nothing else is shared: the LDS ring of kept rows and the rows kept in HBM are private to the wave (each with a copy of the value
+// left of its first column), so a wave that is ahead can never pull a row from under one that is behind.
 //
 // Cells are "keys": 64 x score + 6 low bits = move type * 16 + 15 - predecessor slot. The low bits make one max() do the
 // reference's tie-breaking: type 3 diagonal > 2 vertical > 1 horizontal (its traceback tries them in this order and takes a
@@ -465,36 +474,46 @@ template <int CM> __device__ __forceinline__ void store_chunk_u8(uint8_t* p, con
 // retries it with the score-matrix traceback).
 //
 // Rows that a later row needs as a NON-adjacent predecessor are flagged by the CSR build ("kept") and copied to an LDS
-// ring in the order they are produced (lane-transposed layout: column t*CM+k at word k*NT+t, conflict-free), or to
-// HBM when the ring has wrapped; predecessor references carry that location (0 registers, 1..14 ring slot+1, 15 HBM).
-// Row metadata travels in registers: every wave loads the records of 64 rows with one coalesced load (one batch ahead)
-// and broadcasts the current row's words with v_readlane.
+// ring in the order they are produced (per wave: CM planes of 65 words, column t*CM+k at word 65*CM*w + 65*k + 1 + t, conflict-free; word 0
+// of the wave's LAST plane holds the value left of the wave's first column, so "the column left of my chunk" is one load
+// at lane offset 0 for EVERY lane), or to HBM when the ring has wrapped; predecessor references carry that location (0 registers,
+// 1..14 ring slot+1, 15 HBM). Row metadata travels in registers: every wave loads the records of 64 rows with one coalesced load (one
+// batch ahead) and broadcasts the current row's words with v_readlane.
 // Columns beyond L are computed like real ones and never read by a real column, so the loop has no column predicates.
 // ---------------------------------------------------------------------------------------------------
 constexpr int32_t NEGK = -(1 << 30);   // "minus infinity" key
 constexpr int KD = 63, KV = 47, KH = 16;   // low 6 bits of a key = move type * 16 + 15 - predecessor slot: diagonal 3, vertical 2, horizontal 1
 
-// ---- cluster mode: the DP columns of one (large) edge are split over several workgroups ("members", one CU each, member m owns the
-// columns [m*NT*CM, (m+1)*NT*CM)). Rows stay the unit of work; what crosses a member boundary is one number per row, the prefix maximum
-// of the horizontal recurrence through the member's last column. It travels through a tagged 64-bit mailbox word per (member, row) in
-// HBM (relaxed device-scope atomics; the tag makes every word self-validating, so no fences are needed inside the DP). A member takes
-// the carries of 64 rows at a time (one coalesced load, lane r = row r of the batch, broadcast per row with v_readlane like the row
-// records), so it naturally runs one batch behind its left neighbour and polls once per 64 rows.
+constexpr uint32_t CARRY_BATCH = 32;       // rows whose carries a wave takes at a time (= how far it runs behind its left neighbour)
+constexpr uint32_t WAVE_MBOX = 64;         // entries of the LDS mailbox between two waves of a workgroup (a power of two >= 2 * CARRY_BATCH)
+constexpr uint32_t MAX_WAVES = 16;         // waves per workgroup at most
+
+template <int NWAVES> struct WaveMailT {   // LDS
+    unsigned long long box[(NWAVES > 1 ? NWAVES - 1 : 1) * WAVE_MBOX];   // boundary b (between waves b and b + 1): entry of row i at [b][i % WAVE_MBOX] = {tag, carry}
+    uint32_t consumed[NWAVES];                                           // boundary b: tag up to which wave b + 1 has taken the carries
+};
+using WaveMail = WaveMailT<MAX_WAVES>;     // (dp_rows addresses box[] and consumed[] through their own pointers: the layout of the largest serves all)
+
+// ---- an edge shared by several workgroups ("members", one CU each): member m owns the waves [m*NW, (m+1)*NW) of the pipeline; the carry
+// of its last wave travels through a tagged 64-bit word per row in HBM (relaxed device-scope atomics; the tag validates the word, no
+// fences inside the DP).
 struct DpCl {
     uint32_t mem, members;            // this member / members of the edge (1: no cluster)
-    uint32_t stride;                  // rows per member in mbox / farleft (vcap + 1)
+    uint32_t stride;                  // rows per member in mbox (vcap + 1)
     uint32_t tag0;                    // tag of row i = tag0 + i (rows of all DPs of the edge numbered consecutively)
     unsigned long long* mbox;         // edge base
-    int32_t* farleft;                 // edge base
     bool ring_scratch;                // the LDS ring has a slot (index R) for the rows nobody keeps
     uint32_t* err;                    // device-visible error word of the edge (set when a poll gives up)
-    int32_t* ringleft;                // LDS, 14 words: 64 x H[kept row][first column of the member - 1] per ring slot
 };
 constexpr uint32_t POLL_LIMIT = 1u << 24;   // polls before a waiter gives up and flags an error instead of hanging the GPU
 __device__ __forceinline__ uint32_t ld_dev(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_dev(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long ld_dev64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_dev64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_wg64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_wg64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t ld_wg(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_wg(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // inclusive prefix maximum over the 64 lanes of a wave: the classic DPP sequence with the max fused into the DPP instruction
 // (lanes without a source keep their value). s_nop 1 = the two wait states a DPP read needs after a VALU write of its source.
@@ -514,23 +533,6 @@ __device__ __forceinline__ int wave_incl_max(int v) {
         "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
         "s_nop 1\n\t"
         "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "=&v"(x) : "v"(v));
-    return x;
-}
-// the same inside every row of 16 lanes (wave totals: at most 16 waves)
-__device__ __forceinline__ int row16_incl_max(int v) {
-    int x;
-    asm volatile(
-        "v_mov_b32 %0, %1\n\t"
-        "s_nop 1\n\t"
-        "v_max_i32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_i32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_i32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
-        "s_nop 1\n\t"
-        "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
         "s_nop 1"
         : "=&v"(x) : "v"(v));
     return x;
@@ -567,33 +569,35 @@ template <int CM> __device__ __forceinline__ void store_dirs(uint8_t* p, const u
 // predecessor lives (registers / LDS ring / anything else), then straight-line code: rare events (row spilled to HBM, sink row) share
 // one not-taken branch, the kept-row copy to the LDS ring is unconditional (rows nobody keeps go to a scratch slot), selects are
 // arithmetic.
-template <int CM, bool DIR, bool MULTI>
-__device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, const uint32_t W, const uint8_t* __restrict__ seq, const uint32_t L,
-                        const uint32_t V, int32_t* ring, const uint32_t R, const uint32_t ring_w, const int match, const int mismatch, const int gap,
-                        int* lds_tot /* 2 x 16 */, uint32_t* sink_row, int* sink_score, uint32_t& nSinkOut, const DpCl& cl, unsigned long long* prof) {
+template <int CM, bool DIR>
+__device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, const uint32_t W, const uint32_t WH, const uint8_t* __restrict__ seq,
+                        const uint32_t L, const uint32_t V, int32_t* ring, const uint32_t R, const uint32_t ring_w, const int match, const int mismatch, const int gap,
+                        unsigned long long* wm_box, uint32_t* wm_cons, uint32_t* sink_row, int* sink_score, const uint32_t sink_cap, uint32_t& nSinkOut, const DpCl& cl, unsigned long long* prof) {
 #if defined(HX_DP_PROF) && !defined(HX_DP_PROF2)
     long long tprev = clock64();
 #endif
-    const uint32_t tid = threadIdx.x, NT = blockDim.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t tid = threadIdx.x, NT = blockDim.x, lane = tid & 63u, wv = tid >> 6, NW = NT >> 6;
     const uint32_t ncol = L + 1;
-    const uint32_t col0 = cl.mem * NT * CM;                                   // first column of this member
-    const uint32_t nwa = col0 >= ncol ? 0u : min(NT >> 6, (ncol - col0 + 64u * CM - 1) / (64u * CM));   // waves of this member that own a real column
-    if (nwa == 0) return;      // the whole member has nothing to do for this sequence (no barriers are counted then)
-    if (wv >= nwa) {   // nothing to compute: keep the workgroup's barrier count (one per row)
-        if (MULTI) for (uint32_t i = 1; i <= V; i++) barrier_lds_only();
-        return;
-    }
-    const uint32_t gt = cl.mem * NT + tid;                                    // lane index over all members
-    const bool has_in = cl.mem > 0;                                           // a member on the left feeds the horizontal carry
-    const bool has_out = cl.mem + 1 < cl.members && (cl.mem + 1) * NT * CM < ncol;   // a member on the right owns real columns
-    const unsigned long long* mb_in = cl.mbox + (uint64_t)(has_in ? cl.mem - 1 : 0) * cl.stride;
-    unsigned long long* mb_out = cl.mbox + (uint64_t)cl.mem * cl.stride;
-    int32_t* far_own = cl.farleft + (uint64_t)cl.mem * cl.stride;
+    const uint32_t gw = cl.mem * NW + wv;                                     // this wave's place in the edge's pipeline
+    if ((uint64_t)gw * 64u * CM >= ncol) return;                              // the wave owns no real column of this sequence
+    const uint32_t gt = gw * 64u + lane;                                      // lane index over all waves
+    const bool has_in = gw > 0;                                               // a wave on the left feeds the horizontal carry ...
+    const bool in_lds = wv > 0;                                               // ... through the workgroup's LDS mailbox, or (first wave of a member) through HBM
+    const bool has_out = (uint64_t)(gw + 1) * 64u * CM < ncol;                // a wave on the right owns real columns (the host sized the pipeline for the longest sequence)
+    const bool out_lds = wv + 1 < NW;
+    const unsigned long long* mb_in_h = cl.mbox + (uint64_t)(cl.mem ? cl.mem - 1 : 0) * cl.stride;
+    unsigned long long* mb_out_h = cl.mbox + (uint64_t)cl.mem * cl.stride;
+    const unsigned long long* mb_in_l = wm_box + (size_t)(wv ? wv - 1 : 0) * WAVE_MBOX;
+    unsigned long long* mb_out_l = wm_box + (size_t)wv * WAVE_MBOX;
+    uint32_t* cons_in = wm_cons + (wv ? wv - 1 : 0);                          // what this wave has taken from the boundary on its left
+    const uint32_t* cons_out = wm_cons + wv;                                  // what the wave on the right has taken from this wave's mailbox
+    if (has_in && in_lds && lane == 0) st_wg(cons_in, cl.tag0);               // everything of earlier DPs counts as taken (a wave may have sat out a short sequence)
     const uint32_t* farslot = reinterpret_cast<const uint32_t*>(g.pred);      // per rank: row of H that holds the far-read row (consensus scratch, free during the DP)
     const uint32_t j0 = gt * CM;
     const bool live = j0 <= L;                       // the chunk holds at least one real column: only such chunks touch HBM
     const bool owns_last = live && L < j0 + CM;
     const uint32_t klast = owns_last ? L - j0 : 0;
+    const uint32_t hleft = W + gw;                   // H rows end with one word per wave: the value left of the wave's first column (its own copy)
     // bases under the lane's columns, 2 bits per column (bit pair k); columns without a base (column 0, padding) never match
     using mask_t = typename std::conditional<(CM <= 16), uint32_t, unsigned long long>::type;
     static_assert(CM <= 32, "at most 32 columns per lane");
@@ -627,10 +631,11 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     fetch(0, mN, aN, bN, oN);
     int32_t* hrow = H;
     uint8_t* drow = D;
-    // ring rows, lane-transposed with one spare word per plane: column t*CM+k at word k*(NT+1) + 1 + t. Word 0 of the LAST plane holds the
-    // value left of the workgroup's first column, so "the column left of my chunk" is word (CM-1)*(NT+1) + t for EVERY lane: one load, no select
-    const uint32_t PW = NT + 1;
-    const int32_t* ring_me = ring + tid;
+    // ring rows, per wave: CM planes of 65 words, column t*CM+k at word 65*CM*wv + 65*k + 1 + t; word 0 of the wave's LAST plane holds the value
+    // left of the wave's first column, so "the column left of my chunk" is word 65*(CM-1) + t for EVERY lane: one load, no select. Plane
+    // offsets are compile-time constants: one address register per slot, the rest are instruction offsets.
+    constexpr uint32_t PW = 65u;
+    const int32_t* ring_me = ring + wv * (65u * CM) + lane;
     // f(row, left) on a predecessor row that is not the previous row
     auto with_far_pred = [&](const uint32_t ent, auto&& f) {
         const uint32_t loc = ent >> 28;
@@ -643,15 +648,14 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
         } else if (live) {                 // kept row that fell out of the ring: HBM
             // with direction bytes only the rows a far successor reads are in HBM, in the slots the CSR build gave them
             const uint32_t hr = DIR ? farslot[ent & 0x0fffffffu] : (ent & 0x0fffffffu) + 1;
-            const int32_t* Gp = H + (uint64_t)hr * W + j0;
+            const int32_t* Gp = H + (uint64_t)hr * WH + j0;
             load_chunk_i32<CM>(Gp, hp);
-            left = j0 > 0 ? Gp[-1] : NEGK;
+            left = lane > 0 ? Gp[-1] : has_in ? H[(uint64_t)hr * WH + hleft] : NEGK;   // (lane 0: the wave's own copy - the column belongs to a wave that may be far ahead)
             if (!DIR) {                    // the score matrix holds plain scores
 #pragma unroll
                 for (int k = 0; k < CM; k++) hp[k] <<= 6;
-                if (j0 > 0) left <<= 6;
+                if (gt > 0) left <<= 6;
             }
-            if (has_in && tid == 0) left = far_own[(ent & 0x0fffffffu) + 1];   // the column on the left belongs to another CU: own copy (keys)
         } else {
 #pragma unroll
             for (int k = 0; k < CM; k++) hp[k] = NEGK;
@@ -664,20 +668,35 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
         mC = mN; aC = aN; bC = bN; oC = oN;
         fetch(ib + 64, mN, aN, bN, oN);
         const uint32_t ie = min(64u, V - ib);
-        int cinV = NEGK;     // lane r: carry into this member for row ib + r + 1
-        if (has_in) {
-            const uint32_t row = ib + lane + 1;
-            for (uint32_t spin = 0;; spin++) {
-                unsigned long long v = 0;
-                bool ok = true;
-                if (lane < ie) { v = ld_dev64(mb_in + row); ok = (uint32_t)v == cl.tag0 + row; }
-                if (__ballot(ok) == ~0ull) { cinV = (int)(uint32_t)(v >> 32); break; }
-                if (spin > POLL_LIMIT) { if (lane == 0) st_dev(cl.err, 1u); break; }
-                __builtin_amdgcn_s_sleep(8);
-            }
-        }
+        int cinV = NEGK;     // lane r: carry into this wave for row ib + (ri & ~31) + r + 1
         for (uint32_t ri = 0; ri < ie; ri++) {
             const uint32_t i = ib + ri + 1;
+            if ((ri & (CARRY_BATCH - 1)) == 0) {
+                const uint32_t nb = min(CARRY_BATCH, ie - ri);        // rows of this carry batch: i .. i + nb - 1
+                if (has_in) {
+                    for (uint32_t spin = 0;; spin++) {
+                        unsigned long long v = 0;
+                        bool ok = true;
+                        if (lane < nb) {
+                            v = in_lds ? ld_wg64(mb_in_l + ((i + lane) & (WAVE_MBOX - 1))) : ld_dev64(mb_in_h + i + lane);
+                            ok = (uint32_t)v == cl.tag0 + i + lane;
+                        }
+                        if (__ballot(ok) == ~0ull) { cinV = (int)(uint32_t)(v >> 32); break; }
+                        if (spin > POLL_LIMIT) { if (lane == 0) st_dev(cl.err, 1u); break; }
+                        if (in_lds) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(8);
+                    }
+                    if (in_lds && lane == 0) st_wg(cons_in, cl.tag0 + i + nb - 1);   // the entries of these rows may be written again
+                }
+                if (has_out && out_lds) {   // the rows i .. i + nb - 1 overwrite the entries of the rows WAVE_MBOX earlier: the wave on the right must have taken those
+                    const uint32_t need = i + nb - 1 > WAVE_MBOX ? cl.tag0 + i + nb - 1 - WAVE_MBOX : 0;
+                    for (uint32_t spin = 0; need; spin++) {
+                        const uint32_t got = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_wg(cons_out));
+                        if ((int32_t)(got - need) >= 0) break;
+                        if (spin > POLL_LIMIT) { if (lane == 0) st_dev(cl.err, 1u); break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+            }
             const uint32_t meta = __builtin_amdgcn_readlane(mC, ri), p0 = __builtin_amdgcn_readlane(aC, ri);
             const uint32_t npred = meta >> 8;
             // mismatch bits of this row: bit 2k set <=> the base under column k differs from the row's letter
@@ -692,7 +711,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 else neg = 2 * k < 32 ? __builtin_amdgcn_sbfe((int)(uint32_t)mis, (2 * k) & 31, 1) : __builtin_amdgcn_sbfe((int)(uint32_t)(mis >> 32), (2 * k) & 31, 1);
                 return (m64 + KD) + ((mm64 - m64) & neg);
             };
-            hrow += W;
+            hrow += WH;
             if (DIR) drow += W;
             DP_T(0);   // row decode
             int m[CM];
@@ -745,19 +764,13 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             const int inc = wave_incl_max((m[CM - 1] & ~63) - (jg0 + (CM - 1) * g64));
             int ex = wave_shift_up1(inc, NEGK);
             DP_T(2);   // wave scan
-            const int cin = __builtin_amdgcn_readlane(cinV, ri);   // NEGK without a member on the left
-            if (MULTI) {
-                int* tot = lds_tot + (i & 1u) * 16;
-                if (lane == 63) tot[wv] = inc;
-                barrier_lds_only();   // one barrier per row
-                const uint32_t w16 = lane & 15u;
-                const int x = row16_incl_max(w16 < nwa ? tot[w16] : NEGK);
-                const int prev = __builtin_amdgcn_readlane(x, wv > 0 ? wv - 1 : 0);
-                ex = max(ex, wv > 0 ? prev : NEGK);
-                if (has_out && tid == 0) st_dev64(mb_out + i, (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, __builtin_amdgcn_readlane(x, nwa - 1)) << 32));
-            } else if (has_out && lane == 0) st_dev64(mb_out + i, (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, __builtin_amdgcn_readlane(inc, 63)) << 32));
+            const int cin = __builtin_amdgcn_readlane(cinV, ri & (CARRY_BATCH - 1));   // NEGK without a wave on the left
+            if (has_out && lane == 63) {   // the carry of this row for the wave on the right: the prefix maximum through this wave's last column
+                const unsigned long long e = (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, inc) << 32);
+                if (out_lds) st_wg64(mb_out_l + (i & (WAVE_MBOX - 1)), e); else st_dev64(mb_out_h + i, e);
+            }
             ex = max(ex, cin);
-            DP_T(3);   // cross-wave exchange
+            DP_T(3);   // carry in / out
             const int base = ex + jg0;            // 64 x (score reaching column j0 through a horizontal move from the left neighbour)
 #pragma unroll
             for (int k = 0; k < CM; k++) m[k] = max(m[k], base + (k * g64 + KH));
@@ -766,10 +779,10 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             for (int k = 0; k < CM; k++) t[k] = m[k] & ~63;
             if (R && (meta & copy_if)) {   // copy to the LDS ring: a kept row (a later row reads it as a non-adjacent predecessor) takes the next slot, any other row the scratch slot R (if there is one)
                 const uint32_t kept = (meta >> 4) & 1u, slot = kept ? (nkept & (R - 1)) : R;
-                int32_t* S = ring + (size_t)slot * ring_w + tid;
+                int32_t* S = ring + (size_t)slot * ring_w + wv * (65u * CM) + lane;
 #pragma unroll
                 for (int k = 0; k < CM; k++) S[k * PW + 1] = t[k];
-                if (tid == 0) S[(CM - 1) * PW] = left_prev;   // (first member: "minus infinity")
+                if (lane == 0) S[(CM - 1) * PW] = left_prev;   // (first wave of the edge: "minus infinity")
             }
             nkept += (meta >> 4) & 1u;
             DP_T(4);   // carry applied, kept-row copy
@@ -784,20 +797,24 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
 #pragma unroll
                     for (int k = 0; k < CM; k++) pl[k] = t[k] >> 6;
                     store_chunk_i32<CM>(hrow + j0, pl);
+                    if (lane == 0 && has_in) hrow[hleft] = left_prev >> 6;   // the wave's own copy of the column on its left
                 }
             }
             DP_T(5);   // stores
             if (__builtin_expect((meta & (8u | 4u)) != 0, 0)) {
                 if (meta & 8u) {   // a far successor reads this row back from HBM (keys; with the score matrix it is there already)
-                    if (DIR && live) store_chunk_i32<CM>(H + (uint64_t)farslot[i - 1] * W + j0, t);
-                    if (has_in && tid == 0) far_own[i] = left_prev;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row has left this wave before any later row's barrier
+                    if (DIR && live) {
+                        int32_t* F = H + (uint64_t)farslot[i - 1] * WH;
+                        store_chunk_i32<CM>(F + j0, t);
+                        if (lane == 0 && has_in) F[hleft] = left_prev;
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row has left this wave before a later row reads it back
                 }
                 if (owns_last && (meta & 4u)) {   // sink node: candidate end of the global alignment
                     int v = NEGK;
 #pragma unroll
                     for (int k = 0; k < CM; k++) if ((uint32_t)k == klast) v = t[k];
-                    if (nsink < SINK_CAP) { sink_row[nsink] = i; sink_score[nsink] = v >> 6; }
+                    if (nsink < sink_cap) { sink_row[nsink] = i; sink_score[nsink] = v >> 6; }
                     nsink++;
                 }
             }
@@ -806,7 +823,10 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     if (owns_last) nSinkOut = nsink;
 }
 
-template <int MAXNT, int CMMAX, bool DIR>
+// One kernel per (largest workgroup, columns per lane, traceback flavour): the register budget of a launch is that of ITS row loop, so the
+// many short gaps (one wavefront, 4-8 columns per lane) run with a fraction of the registers - and several times the waves per SIMD - of
+// the few long ones; sequences shorter than the edge's longest leave the upper lanes / waves of the pipeline idle.
+template <int MAXNT, int CM, bool DIR>
 __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges, const uint32_t* __restrict__ order, uint32_t n_edges,
                                             const PoaSeq* __restrict__ seqs, const uint8_t* __restrict__ packed, const uint64_t* __restrict__ read_off,
                                             const uint32_t* __restrict__ read_len, PoaPools P, int32_t match, int32_t mismatch, int32_t gap,
@@ -846,9 +866,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     uint8_t* Dm = DIR ? P.dir + ED.d_off : nullptr;   // direction bytes: (vcap + 1) rows of W; with them H holds only ED.hrows far-read rows
     // ring geometry is a property of the edge (its longest sequence) and of the launch
     const uint32_t GM = ED.members;                  // workgroups sharing this edge's DP columns
-    const uint32_t cme = (ED.lmax + 1 + GM * NT - 1) / (GM * NT);
-    const uint32_t cmr = cme <= 4 ? 4 : cme <= 8 ? 8 : cme <= 16 ? 16 : 32;
-    const uint32_t ring_w = cmr * (NT + 1);   // planes of NT + 1 words (dp_rows)
+    const uint32_t ring_w = CM * (NT >> 6) * 65u;    // CM planes of 65 words per wave (dp_rows)
     // kept rows the LDS ring holds for THIS edge: what fits the launch's LDS at the edge's own row width (a launch serves edges of several
     // widths; the host sizes the LDS for the widest), a power of two (slot = kept-row counter & (R - 1)), plus the scratch slot
     // Rows nobody keeps go to a scratch slot so that the copy is unconditional; when the LDS holds exactly a power of two of rows the scratch
@@ -862,36 +880,35 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     }
     uint8_t* seq = P.seq + ED.seq_off;
     const uint32_t W = (ED.lmax + 1 + 31) & ~31u;   // row stride: a multiple of the widest lane chunk (32 columns), so chunks are vector-aligned and stay inside their row
+    const uint32_t WH = W + (GM * (NT >> 6) > 1 ? (GM * (NT >> 6) + 3u) & ~3u : 0u);   // rows of H end with one word per wave of the edge's pipeline (dp_rows)
 
-    __shared__ int lds_i[32];
+    // static LDS is kept small for the launches that can share a CU: sink rows kept in LDS (an alignment ends in at most one sink per sequence
+    // aligned so far; an edge with more than 256 is redone by the 1024-lane kernel), wave mailboxes for the waves the launch can have
+    constexpr uint32_t SINK_LDS = MAXNT < 1024 ? 256 : SINK_CAP;
+    __shared__ WaveMailT<MAXNT / 64> wmail;
     __shared__ uint32_t lds_u[16];
     __shared__ uint32_t sV, sE, sNaln, sOk, sNsink, sNcand, sBestKey;
     __shared__ int sBestI;
-    __shared__ uint32_t sink_row[SINK_CAP];
-    __shared__ int sink_score[SINK_CAP];
-    __shared__ int32_t cl_ringleft[14];
+    __shared__ uint32_t sink_row[SINK_LDS];
+    __shared__ int sink_score[SINK_LDS];
     __shared__ uint32_t sCtl;
     __shared__ unsigned long long sCells;   // DP cells of this edge (reported only when the edge completes: retried edges count once)
     if (tid == 0) { sV = 0; sE = 0; sOk = 1; sCells = 0; }
+    if constexpr (MAXNT > 64) {
+        for (uint32_t q = tid; q < (MAXNT / 64 - 1) * WAVE_MBOX; q += NT) wmail.box[q] = 0ull;   // tag 0 = nothing published
+        if (tid < MAXNT / 64) wmail.consumed[tid] = 0u;
+    }
     __syncthreads();
     uint32_t* csy = P.csync + (uint64_t)eidx * 8;                 // go, done, V, L, error
     int32_t* sinkbuf = P.sinkbuf + (uint64_t)eidx * (1 + 2 * SINK_CAP);
     DpCl cl;
     cl.mem = mem; cl.members = GM; cl.stride = ED.vcap + 1; cl.tag0 = 0;
-    cl.mbox = P.mbox + ED.cl_off; cl.farleft = P.farleft + ED.cl_off; cl.err = csy + 4; cl.ringleft = cl_ringleft; cl.ring_scratch = ring_scratch;
+    cl.mbox = P.mbox + ED.cl_off; cl.err = csy + 4; cl.ring_scratch = ring_scratch;
     constexpr uint32_t CL_ABORT = 0xffffffffu;
-    auto cm_sel = [&](uint32_t Lq) -> uint32_t {   // columns per lane of the dp_rows instance that handles a sequence of Lq bases
-        const uint32_t c = (Lq + 1 + GM * NT - 1) / (GM * NT);
-        return c <= 4 ? 4u : c <= 8 ? 8u : c <= 16 ? 16u : 32u;
-    };
 #define HX_DP_DISPATCH(Lq, Vq, nsq) do { \
-        const uint32_t cm_ = ((Lq) + 1 + GM * NT - 1) / (GM * NT);     /* columns per lane for this sequence */ \
-        if (cm_ <= 4) HX_DP(4, Lq, Vq, nsq); else if (cm_ <= 8) HX_DP(8, Lq, Vq, nsq); \
-        else if (cm_ <= 16) { if constexpr (CMMAX >= 16) HX_DP(16, Lq, Vq, nsq); else sOk = 2; } \
-        else if (cm_ <= 32) { if constexpr (CMMAX >= 32) HX_DP(32, Lq, Vq, nsq); else sOk = 2; }   /* the host never asks a 16-column kernel for more */ \
+        if (((Lq) + 1 + GM * NT - 1) / (GM * NT) <= (uint32_t)CM)      /* the host puts an edge into a launch whose columns per lane hold its longest sequence */ \
+            dp_rows<CM, DIR>(g, H, Dm, W, WH, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, wmail.box, wmail.consumed, sink_row, sink_score, SINK_LDS, nsq, cl, ph + 6); \
         else sOk = 2; } while (0)
-#define HX_DP(CMV, Lq, Vq, nsq) do { if (NT > 64) dp_rows<CMV, DIR, true>(g, H, Dm, W, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, lds_i, sink_row, sink_score, nsq, cl, ph + 6); \
-                                      else dp_rows<CMV, DIR, false>(g, H, Dm, W, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, lds_i, sink_row, sink_score, nsq, cl, ph + 6); } while (0)
     // The reference's topological order (spoa's DFS, inherently serial) is needed in two places only: to break ties between equally scored
     // end nodes of an alignment, and for the heaviest-bundle traversal of the finished graph. The DP itself runs on a cheaper order that
     // is maintained incrementally (see "order update" below): row values do not depend on which valid topological order is used.
@@ -976,8 +993,8 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         }
         if (mem > 0) {
             __syncthreads();
-            if (V > 0 && L / (NT * cm_sel(L)) == mem) {   // this member owns the last column: hand the sink rows to member 0
-                const uint32_t nsk = min(sNsink, SINK_CAP);
+            if (V > 0 && L / (NT * (uint32_t)CM) == mem) {   // this member owns the last column: hand the sink rows to member 0
+                const uint32_t nsk = min(sNsink, SINK_LDS);
                 if (tid == 0) sinkbuf[0] = (int32_t)sNsink;
                 for (uint32_t q = tid; q < nsk; q += NT) { sinkbuf[1 + q] = (int32_t)sink_row[q]; sinkbuf[1 + SINK_CAP + q] = sink_score[q]; }
             }
@@ -1001,8 +1018,8 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                     }
                     __syncthreads();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    if (L / (NT * cm_sel(L)) != 0) {   // the last column lives in another member: fetch its sink rows
-                        const uint32_t nsk_all = (uint32_t)sinkbuf[0], nsk = min(nsk_all, SINK_CAP);
+                    if (L / (NT * (uint32_t)CM) != 0) {   // the last column lives in another member: fetch its sink rows
+                        const uint32_t nsk_all = (uint32_t)sinkbuf[0], nsk = min(nsk_all, SINK_LDS);
                         for (uint32_t q = tid; q < nsk; q += NT) { sink_row[q] = (uint32_t)sinkbuf[1 + q]; sink_score[q] = sinkbuf[1 + SINK_CAP + q]; }
                         if (tid == 0) sNsink = nsk_all;
                     }
@@ -1013,9 +1030,9 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
             SUBT(8);   // wait for the other members, sinks
             // ---- end node of the global alignment: the best-scoring sink; ties go to the smallest rank in the REFERENCE's order
             if (tid == 0) {
-                if (sNsink > SINK_CAP) sOk = 2;
+                if (sNsink > SINK_LDS) sOk = 6;   // more sink rows than the launch keeps: the host redoes the edge in a launch with the full list
                 int best = INT32_MIN + 1024; uint32_t ncand = 0, first = 0;
-                const uint32_t nsk = min(sNsink, SINK_CAP);
+                const uint32_t nsk = min(sNsink, SINK_LDS);
                 for (uint32_t q = 0; q < nsk; q++) if (sink_score[q] > best) best = sink_score[q];
                 for (uint32_t q = 0; q < nsk; q++) if (sink_score[q] == best) { if (!ncand) first = q; sink_row[ncand++] = sink_row[q]; }   // compact candidates to the front
                 (void)first;
@@ -1109,7 +1126,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                 sCells += (unsigned long long)V * L;
                 uint32_t i = (uint32_t)sBestI, j = L, na = 0;
                 while (!DIR && !(i == 0 && j == 0)) {
-                    const int hij = H[(uint64_t)i * W + j];
+                    const int hij = H[(uint64_t)i * WH + j];
                     uint32_t pi_ = i, pj_ = j;
                     bool found = false;
                     uint32_t po = 0, pe = 0;
@@ -1119,14 +1136,14 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                         if (po == pe) { if (hij == H[j - 1] + mc) { pi_ = 0; pj_ = j - 1; found = true; } }
                         else for (uint32_t p = po; p < pe && !found; p++) {
                             uint32_t pr = (g.pred_rank[p] & 0x0fffffffu) + 1;
-                            if (hij == H[(uint64_t)pr * W + j - 1] + mc) { pi_ = pr; pj_ = j - 1; found = true; }
+                            if (hij == H[(uint64_t)pr * WH + j - 1] + mc) { pi_ = pr; pj_ = j - 1; found = true; }
                         }
                     }
                     if (!found && i != 0) {
                         if (po == pe) { if (hij == H[j] + gap) { pi_ = 0; pj_ = j; found = true; } }
                         else for (uint32_t p = po; p < pe && !found; p++) {
                             uint32_t pr = (g.pred_rank[p] & 0x0fffffffu) + 1;
-                            if (hij == H[(uint64_t)pr * W + j] + gap) { pi_ = pr; pj_ = j; found = true; }
+                            if (hij == H[(uint64_t)pr * WH + j] + gap) { pi_ = pr; pj_ = j; found = true; }
                         }
                     }
                     if (!found) { pi_ = i; pj_ = j - 1; }
@@ -1417,6 +1434,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         else if (!sOk) { status[eidx] = HXE_POA_OVERFLOW; cns_len[eidx] = 0; }
         else if (sOk == 4) { status[eidx] = HXE_POA_NODIR; cns_len[eidx] = 0; }
         else if (sOk == 5) { status[eidx] = HXE_POA_FARROWS; cns_len[eidx] = 0; }
+        else if (sOk == 6) { status[eidx] = HXE_POA_SINKS; cns_len[eidx] = 0; }
         else {
             status[eidx] = 0; cns_len[eidx] = !sV ? 0 : sCtl != NONE ? sCtl : consensus(g, sV, cns + ED.cns_off); atomicAdd(cells, sCells);
 #ifndef HX_DP_PROF
@@ -1431,19 +1449,22 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
 }  // namespace
 
 void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_edges, const PoaSeq* seqs, const uint8_t* packed, const uint64_t* read_off,
-             const uint32_t* read_len, PoaPools pools, uint64_t, int32_t match, int32_t mismatch, int32_t gap, char* cns, uint32_t* cns_len,
-             uint32_t* status, unsigned long long* cells, unsigned long long* phase, int block_threads, uint32_t ring_rows, uint32_t ring_bytes, bool big,
+             const uint32_t* read_len, PoaPools pools, int32_t match, int32_t mismatch, int32_t gap, char* cns, uint32_t* cns_len,
+             uint32_t* status, unsigned long long* cells, unsigned long long* phase, int block_threads, int cm, uint32_t ring_rows, uint32_t ring_bytes,
              bool use_dir, uint32_t max_indeg, hipStream_t s) {
     if (!n_edges) return;
-#define HX_LAUNCH(MNT, CMX, DIRV) do { \
-        (void)hipFuncSetAttribute((const void*)k_poa<MNT, CMX, DIRV>, hipFuncAttributeMaxDynamicSharedMemorySize, 146 * 1024); \
-        k_poa<MNT, CMX, DIRV><<<n_edges, block_threads, ring_bytes, s>>>(edges, order, n_edges, seqs, packed, read_off, read_len, pools, match, mismatch, gap, \
+#define HX_LAUNCH(MNT, CMV, DIRV) do { \
+        (void)hipFuncSetAttribute((const void*)k_poa<MNT, CMV, DIRV>, hipFuncAttributeMaxDynamicSharedMemorySize, 142 * 1024); \
+        k_poa<MNT, CMV, DIRV><<<n_edges, block_threads, ring_bytes, s>>>(edges, order, n_edges, seqs, packed, read_off, read_len, pools, match, mismatch, gap, \
                                                                        cns, cns_len, status, cells, phase, ring_rows, ring_bytes, max_indeg); } while (0)
-    // one binary per register budget: <= 256 lanes may use 32-column chunks (256+ VGPRs per lane), 512/1024-lane workgroups 16 / 8
-    if (big) { if (use_dir) HX_LAUNCH(1024, 32, true); else HX_LAUNCH(1024, 32, false); }   // one workgroup for a gap of 8192..32767 bases: slow path (register spills), rare
-    else if (block_threads <= 256) { if (use_dir) HX_LAUNCH(256, 32, true); else HX_LAUNCH(256, 32, false); }
-    else if (block_threads <= 512) { if (use_dir) HX_LAUNCH(512, 16, true); else HX_LAUNCH(512, 16, false); }
-    else { if (use_dir) HX_LAUNCH(1024, 8, true); else HX_LAUNCH(1024, 8, false); }
+#define HX_LAUNCH_CM(MNT, CMV) do { if (use_dir) HX_LAUNCH(MNT, CMV, true); else HX_LAUNCH(MNT, CMV, false); } while (0)
+    // the instances the host's launch classes use (poa_kernel_lanes): workgroups up to 64 / 256 / 512 / 1024 lanes x 4, 8, 16 or 32 columns per lane
+    const int mnt = poa_kernel_lanes(block_threads);
+    if (mnt == 64) { if (cm <= 4) HX_LAUNCH_CM(64, 4); else if (cm <= 8) HX_LAUNCH_CM(64, 8); else if (cm <= 16) HX_LAUNCH_CM(64, 16); else HX_LAUNCH_CM(64, 32); }
+    else if (mnt == 256) { if (cm <= 4) HX_LAUNCH_CM(256, 4); else if (cm <= 8) HX_LAUNCH_CM(256, 8); else if (cm <= 16) HX_LAUNCH_CM(256, 16); else HX_LAUNCH_CM(256, 32); }
+    else if (mnt == 512) { if (cm <= 4) HX_LAUNCH_CM(512, 4); else if (cm <= 8) HX_LAUNCH_CM(512, 8); else HX_LAUNCH_CM(512, 16); }
+    else { if (cm <= 4) HX_LAUNCH_CM(1024, 4); else if (cm <= 8) HX_LAUNCH_CM(1024, 8); else if (cm <= 16) HX_LAUNCH_CM(1024, 16); else HX_LAUNCH_CM(1024, 32); }   // (1024 x 32: one workgroup for a gap of 8192..32767 bases: register spills, rare)
+#undef HX_LAUNCH_CM
 #undef HX_LAUNCH
 }
 

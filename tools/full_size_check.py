@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--passes", type=int, default=2)
     ap.add_argument("--cli", action="store_true", help="also run the haslr_assemble binary on the same files (wall time, same assembly)")
     ap.add_argument("--tmp", default="/tmp/full_size")
+    ap.add_argument("--reuse", action="store_true", help="keep the data set of an earlier run with the same name")
     a = ap.parse_args()
     cfg = dict(PRESETS[a.preset]) if a.preset else dict(genome_len=a.genome_len, model=a.model, cov=a.cov)
     name = a.name or a.preset or "custom"
@@ -49,8 +50,9 @@ def main():
         print(key, res[key], file=sys.stderr, flush=True)
 
     t0 = time.perf_counter()
-    subprocess.check_call([os.path.join(ROOT, "tools", "hxsim"), "--genome-len", str(cfg["genome_len"]), "--model", cfg["model"], "--cov", str(cfg["cov"]),
-                           "--seed", str(a.seed), "--out-prefix", pre], stderr=subprocess.DEVNULL)
+    if not (a.reuse and all(os.path.exists(pre + x) for x in (".contigs.fa", ".reads.fa", ".paf"))):
+        subprocess.check_call([os.path.join(ROOT, "tools", "hxsim"), "--genome-len", str(cfg["genome_len"]), "--model", cfg["model"], "--cov", str(cfg["cov"]),
+                               "--seed", str(a.seed), "--out-prefix", pre], stderr=subprocess.DEVNULL)
     lap("simulate_s", t0)
     res["input_bytes"] = {k: os.path.getsize(pre + "." + k) for k in ("contigs.fa", "reads.fa", "paf")}
 
