@@ -592,14 +592,14 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     // from HBM. Thousands of edges (every CU busy): what counts is waves per SIMD - each wave spends most of its time waiting for its own
     // dependent instructions - so the ring is cut to HX_POA_RING_KB per wave and several workgroups share a CU.
     const bool many_edges = todo.size() > 4096;
-    const uint64_t ring_kb_wave = getenv("HX_POA_RING_KB") ? (uint64_t)std::max(1, atoi(getenv("HX_POA_RING_KB"))) : many_edges ? 9 : 0;   // 0 = no cut
+    const uint64_t ring_kb_wave = getenv("HX_POA_RING_KB") ? (uint64_t)std::max(1, atoi(getenv("HX_POA_RING_KB"))) : many_edges ? 11 : 0;   // 0 = no cut
     auto ring_rows_of = [ring_kb_wave](uint32_t nt, uint32_t cm, uint64_t& row_bytes) -> uint32_t {   // kept rows the LDS ring holds; row_bytes returns the ring's LDS bytes
         row_bytes = (uint64_t)cm * (nt / 64) * 65 * 4;   // planes of 65 words per wave
         uint64_t lds_budget = nt >= 1024 ? 128 * 1024 : nt == 64 ? 32 * 1024 : 64 * 1024 * (nt / 128 > 2 ? 2 : 1);
         if (ring_kb_wave) lds_budget = std::min<uint64_t>(lds_budget, std::max<uint64_t>(ring_kb_wave * 1024 * (nt / 64), 3 * row_bytes) * 8 / 9);
         const uint64_t rows_fit = std::min<uint64_t>(lds_budget * 9 / 8, kPoaLdsMax) / row_bytes;   // ring slots (+ 1 scratch slot when there is room)
-        const uint32_t R = rows_fit >= 8 ? 8 : rows_fit >= 4 ? 4 : rows_fit >= 2 ? 2 : 0;   // power of two (slot = kept-row counter & (R-1))
-        row_bytes *= R ? R + (rows_fit > R ? 1 : 0) : 0;                                    // -> LDS bytes of the ring
+        const uint32_t R = rows_fit >= 9 ? 8 : rows_fit >= 5 ? 4 : rows_fit >= 3 ? 2 : 0;   // kept rows: a power of two (slot = kept-row counter & (R-1)); 0 = only the latest row
+        row_bytes *= R + 1;                                             // -> LDS bytes of the ring: one more slot for the latest row nobody keeps
         return R;
     };
     auto cm_round = [](uint32_t ncol, uint32_t lanes) -> uint32_t { uint32_t cm = (ncol + lanes - 1) / lanes, r = 4; while (r < cm) r <<= 1; return r; };
@@ -915,6 +915,7 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
     }
     if (getenv("HX_DEBUG") && ne) {
         const unsigned long long* q = &c->poa_phase[(size_t)c->dbg_slowest * 12];
+        if (getenv("HX_PROF3")) { for (int k = 6; k < 11; k++) fprintf(stderr, "[hx] prof3 bucket %d: rows %llu, cycles per row %.0f\n", k - 6, q[k] >> 40, (q[k] >> 40) ? (double)(q[k] & ((1ull << 40) - 1)) / (double)(q[k] >> 40) : 0.0); }
         fprintf(stderr, "[hx] slowest edge %u: lmax=%u nseq=%u | DP rows %llu (multi-pred %llu, ring refs %llu, far refs %llu, kept %llu) over %llu sequences\n", c->dbg_slowest,
                 c->dbg_lmax[c->dbg_slowest], c->dbg_nseq[c->dbg_slowest], q[6], q[7], q[8], q[9], q[10], q[11] & 0xffffffffull);
         {   // the five longest edges (critical-path candidates)

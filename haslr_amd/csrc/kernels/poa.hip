@@ -502,7 +502,6 @@ struct DpCl {
     uint32_t stride;                  // rows per member in mbox (vcap + 1)
     uint32_t tag0;                    // tag of row i = tag0 + i (rows of all DPs of the edge numbered consecutively)
     unsigned long long* mbox;         // edge base
-    bool ring_scratch;                // the LDS ring has a slot (index R) for the rows nobody keeps
     uint32_t* err;                    // device-visible error word of the edge (set when a poll gives up)
 };
 constexpr uint32_t POLL_LIMIT = 1u << 24;   // polls before a waiter gives up and flags an error instead of hanging the GPU
@@ -609,49 +608,56 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     }
     const int mm64 = mismatch * 64, g64 = gap * 64, m64 = match * 64;
     const int jg0 = (int)j0 * g64;
-    int t[CM];                                          // row i-1, then row i: 64 x score
-#pragma unroll
-    for (int k = 0; k < CM; k++) t[k] = jg0 + k * g64;  // row 0
-    int left_prev = gt > 0 ? jg0 - g64 : NEGK;          // 64 x H[i-1][j0-1]
+    // Every row a later row reads lives in the LDS ring: R slots for the kept rows (read by a non-adjacent successor) in the order they are
+    // produced, slot R for the latest row nobody keeps (only the next row can want it). A predecessor reference is a slot number
+    // (1 + slot, from the CSR build; 14 = the virtual row 0 that source nodes start from, 15 = a kept row that left the ring: HBM), so a
+    // row is straight-line code whatever its predecessors are: no dispatch on row types, no register path. Per wave: CM planes of 65 words, column t*CM+k at word 65*CM*wv + 65*k + 1 + t;
+    // word 0 of the wave's LAST plane holds the value left of the wave's first column, so "the column left of my chunk" is word
+    // 65*(CM-1) + t for EVERY lane: one load, no select. Plane offsets are instruction offsets of ONE address register per slot.
+    constexpr uint32_t PW = 65u;
+    int32_t* const ring_me = ring + wv * (65u * CM) + lane;
     if (!DIR && live) {                                 // the score-matrix traceback reads row 0 like any other row
         int pl[CM];
 #pragma unroll
-        for (int k = 0; k < CM; k++) pl[k] = t[k] >> 6;
+        for (int k = 0; k < CM; k++) pl[k] = (jg0 + k * g64) >> 6;
         store_chunk_i32<CM>(H + j0, pl);
     }
     uint32_t nkept = 0;                                 // kept rows produced so far (ring slot counter; mirrors the CSR build)
-    const uint32_t copy_if = cl.ring_scratch ? 0xffffffffu : 16u;   // rows copied to the ring: (nearly) all - a row nobody keeps goes to the scratch slot, where it is never read - or the kept rows only
     uint32_t nsink = 0;
-    // row records of 64 rows per register, the next batch in flight
-    uint32_t mC = 0, aC = 0, bC = 0, oC = 0, mN = 0, aN = 0, bN = 0, oN = 0;
+    // row records of 64 rows per register: the current batch (C), the next one (N, complete with the third and fourth predecessor entries
+    // of the rows that have them - a gather that needs the records first), and the one after it (F) in flight
+    uint32_t mC = 0, aC = 0, bC = 0, oC = 0, cC = 0, dC = 0, mN = 0, aN = 0, bN = 0, oN = 0, cN = 0, dN = 0, mF = 0, aF = 0, bF = 0, oF = 0;
     auto fetch = [&](uint32_t base, uint32_t& m, uint32_t& a, uint32_t& b, uint32_t& o) {
         const uint32_t r = base + lane;
         if (r < V) { m = g.row_meta[r]; a = g.row_pred0[r]; b = g.row_pred1[r]; o = g.row_pred_off[r]; }
     };
+    auto fetch_more = [&](uint32_t base, uint32_t m, uint32_t o, uint32_t& c, uint32_t& d) {
+        if (base + lane < V) { if ((m >> 8) > 2u) c = g.pred_rank[o + 2]; if ((m >> 8) > 3u) d = g.pred_rank[o + 3]; }
+    };
     fetch(0, mN, aN, bN, oN);
+    fetch(64, mF, aF, bF, oF);
+    fetch_more(0, mN, oN, cN, dN);
     int32_t* hrow = H;
     uint8_t* drow = D;
-    // ring rows, per wave: CM planes of 65 words, column t*CM+k at word 65*CM*wv + 65*k + 1 + t; word 0 of the wave's LAST plane holds the value
-    // left of the wave's first column, so "the column left of my chunk" is word 65*(CM-1) + t for EVERY lane: one load, no select. Plane
-    // offsets are compile-time constants: one address register per slot, the rest are instruction offsets.
-    constexpr uint32_t PW = 65u;
-    const int32_t* ring_me = ring + wv * (65u * CM) + lane;
-    // f(row, left) on a predecessor row that is not the previous row
-    auto with_far_pred = [&](const uint32_t ent, auto&& f) {
+    // predecessor row `ent` (slot << 28 | rank): its columns under this lane and the value left of them
+    auto pred_row = [&](const uint32_t ent, int (&hp)[CM], int& left) {
         const uint32_t loc = ent >> 28;
-        int hp[CM], left;
-        if (loc != 15) {                   // kept row in the LDS ring
+        if (__builtin_expect(loc < 14u, 1)) {    // in the LDS ring
             const int32_t* S = ring_me + (size_t)(loc - 1) * ring_w;
 #pragma unroll
             for (int k = 0; k < CM; k++) hp[k] = S[k * PW + 1];
             left = S[(CM - 1) * PW];
-        } else if (live) {                 // kept row that fell out of the ring: HBM
+        } else if (loc == 14u) {                 // a source node starts from the virtual row 0
+#pragma unroll
+            for (int k = 0; k < CM; k++) hp[k] = jg0 + k * g64;
+            left = gt > 0 ? jg0 - g64 : NEGK;
+        } else if (live) {                       // kept row that fell out of the ring: HBM
             // with direction bytes only the rows a far successor reads are in HBM, in the slots the CSR build gave them
             const uint32_t hr = DIR ? farslot[ent & 0x0fffffffu] : (ent & 0x0fffffffu) + 1;
             const int32_t* Gp = H + (uint64_t)hr * WH + j0;
             load_chunk_i32<CM>(Gp, hp);
             left = lane > 0 ? Gp[-1] : has_in ? H[(uint64_t)hr * WH + hleft] : NEGK;   // (lane 0: the wave's own copy - the column belongs to a wave that may be far ahead)
-            if (!DIR) {                    // the score matrix holds plain scores
+            if (!DIR) {                          // the score matrix holds plain scores
 #pragma unroll
                 for (int k = 0; k < CM; k++) hp[k] <<= 6;
                 if (gt > 0) left <<= 6;
@@ -661,161 +667,144 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             for (int k = 0; k < CM; k++) hp[k] = NEGK;
             left = NEGK;
         }
-        f(hp, left);
     };
     for (uint32_t ib = 0; ib < V; ib += 64) {
-        // the batch fetched 64 rows ago becomes current (the only wait for these loads), the next one goes in flight
-        mC = mN; aC = aN; bC = bN; oC = oN;
-        fetch(ib + 64, mN, aN, bN, oN);
+        // the batches move up (the only waits for these loads: everything was requested at least 64 rows ago), another one goes in flight
+        mC = mN; aC = aN; bC = bN; oC = oN; cC = cN; dC = dN;
+        mN = mF; aN = aF; bN = bF; oN = oF;
+        fetch(ib + 128, mF, aF, bF, oF);
+        fetch_more(ib + 64, mN, oN, cN, dN);
         const uint32_t ie = min(64u, V - ib);
-        int cinV = NEGK;     // lane r: carry into this wave for row ib + (ri & ~31) + r + 1
-        for (uint32_t ri = 0; ri < ie; ri++) {
-            const uint32_t i = ib + ri + 1;
-            if ((ri & (CARRY_BATCH - 1)) == 0) {
-                const uint32_t nb = min(CARRY_BATCH, ie - ri);        // rows of this carry batch: i .. i + nb - 1
-                if (has_in) {
-                    for (uint32_t spin = 0;; spin++) {
-                        unsigned long long v = 0;
-                        bool ok = true;
-                        if (lane < nb) {
-                            v = in_lds ? ld_wg64(mb_in_l + ((i + lane) & (WAVE_MBOX - 1))) : ld_dev64(mb_in_h + i + lane);
-                            ok = (uint32_t)v == cl.tag0 + i + lane;
-                        }
-                        if (__ballot(ok) == ~0ull) { cinV = (int)(uint32_t)(v >> 32); break; }
-                        if (spin > POLL_LIMIT) { if (lane == 0) st_dev(cl.err, 1u); break; }
-                        if (in_lds) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(8);
+        for (uint32_t rb = 0; rb < ie; rb += CARRY_BATCH) {
+            const uint32_t nb = min(CARRY_BATCH, ie - rb), i0 = ib + rb + 1;   // rows i0 .. i0 + nb - 1
+            int cinV = NEGK;     // lane r: carry into this wave for row i0 + r
+            if (has_in) {
+                for (uint32_t spin = 0;; spin++) {
+                    unsigned long long v = 0;
+                    bool ok = true;
+                    if (lane < nb) {
+                        v = in_lds ? ld_wg64(mb_in_l + ((i0 + lane) & (WAVE_MBOX - 1))) : ld_dev64(mb_in_h + i0 + lane);
+                        ok = (uint32_t)v == cl.tag0 + i0 + lane;
                     }
-                    if (in_lds && lane == 0) st_wg(cons_in, cl.tag0 + i + nb - 1);   // the entries of these rows may be written again
+                    if (__ballot(ok) == ~0ull) { cinV = (int)(uint32_t)(v >> 32); break; }
+                    if (spin > POLL_LIMIT) { if (lane == 0) st_dev(cl.err, 1u); break; }
+                    if (in_lds) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(8);
                 }
-                if (has_out && out_lds) {   // the rows i .. i + nb - 1 overwrite the entries of the rows WAVE_MBOX earlier: the wave on the right must have taken those
-                    const uint32_t need = i + nb - 1 > WAVE_MBOX ? cl.tag0 + i + nb - 1 - WAVE_MBOX : 0;
-                    for (uint32_t spin = 0; need; spin++) {
-                        const uint32_t got = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_wg(cons_out));
-                        if ((int32_t)(got - need) >= 0) break;
-                        if (spin > POLL_LIMIT) { if (lane == 0) st_dev(cl.err, 1u); break; }
-                        __builtin_amdgcn_s_sleep(2);
-                    }
+                if (in_lds && lane == 0) st_wg(cons_in, cl.tag0 + i0 + nb - 1);   // the entries of these rows may be written again
+            }
+            if (has_out && out_lds) {   // the rows of this batch overwrite the entries of the rows WAVE_MBOX earlier: the wave on the right must have taken those
+                const uint32_t need = i0 + nb - 1 > WAVE_MBOX ? cl.tag0 + i0 + nb - 1 - WAVE_MBOX : 0;
+                for (uint32_t spin = 0; need; spin++) {
+                    const uint32_t got = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_wg(cons_out));
+                    if ((int32_t)(got - need) >= 0) break;
+                    if (spin > POLL_LIMIT) { if (lane == 0) st_dev(cl.err, 1u); break; }
+                    __builtin_amdgcn_s_sleep(2);
                 }
             }
-            const uint32_t meta = __builtin_amdgcn_readlane(mC, ri), p0 = __builtin_amdgcn_readlane(aC, ri);
-            const uint32_t npred = meta >> 8;
-            // mismatch bits of this row: bit 2k set <=> the base under column k differs from the row's letter
-            mask_t mis;
-            {
-                const mask_t x = bases ^ ((mask_t)(meta & 3u) * (mask_t)0x5555555555555555ull);
-                mis = x | (x >> 1) | nobase;
-            }
-            auto score_of = [&](int k) -> int {   // 64 x substitution score of column k (+63: the diagonal move type)
-                int neg;   // -1 on a mismatch, 0 on a match
-                if constexpr (CM <= 16) neg = __builtin_amdgcn_sbfe((int)mis, 2 * k, 1);
-                else neg = 2 * k < 32 ? __builtin_amdgcn_sbfe((int)(uint32_t)mis, (2 * k) & 31, 1) : __builtin_amdgcn_sbfe((int)(uint32_t)(mis >> 32), (2 * k) & 31, 1);
-                return (m64 + KD) + ((mm64 - m64) & neg);
-            };
-            hrow += WH;
-            if (DIR) drow += W;
-            DP_T(0);   // row decode
-            int m[CM];
-            auto cells1 = [&](const int (&hp)[CM], const int left) {
-#pragma unroll
-                for (int k = 0; k < CM; k++) m[k] = max((k == 0 ? left : hp[k - 1]) + score_of(k), hp[k] + (g64 + KV));
-            };
-            const uint32_t loc0 = p0 >> 28;
-            const uint32_t rtype = (meta >> 5) & 7u;               // set by the CSR build: 1 previous row, 2 one ring row, 0 anything else
-            if (rtype == 1) cells1(t, left_prev);                  // the previous row: the lane's own registers
-            else if (rtype == 2) {                                 // one kept row in the LDS ring
-                int hp[CM], left;
-                const int32_t* S = ring_me + (size_t)(loc0 - 1) * ring_w;
-#pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] = S[k * PW + 1];
-                left = S[(CM - 1) * PW];
-                cells1(hp, left);
-            } else if (npred == 0) {                               // source node: the virtual row 0
-                int hp[CM];
-#pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] = jg0 + k * g64;
-                cells1(hp, gt > 0 ? jg0 - g64 : NEGK);
-            } else if (npred == 1) with_far_pred(p0, cells1);      // one row that left the ring
-            else {
-                const uint32_t p1 = __builtin_amdgcn_readlane(bC, ri), po = __builtin_amdgcn_readlane(oC, ri);
-                // the maximum over the predecessors: the low bits carry the move type and 15 - p, so ONE running maximum does it all
-                // (a diagonal beats a vertical move of the same score, the first predecessor in in-edge order beats the later ones)
-#pragma unroll
-                for (int k = 0; k < CM; k++) m[k] = NEGK;
-                auto acc_pred = [&](const uint32_t ent, const uint32_t p) {
-                    const int ps = DIR ? (int)p : 0;        // direction bytes exist only while in-degrees stay <= 16 (the CSR build checks)
-                    const int gc = g64 + KV - ps;
-                    auto acc = [&](const int (&hp)[CM], const int left) {
-#pragma unroll
-                        for (int k = 0; k < CM; k++) m[k] = max(m[k], max((k == 0 ? left : hp[k - 1]) + score_of(k) - ps, hp[k] + gc));
-                    };
-                    if ((ent >> 28) == 0) acc(t, left_prev); else with_far_pred(ent, acc);
+            for (uint32_t rj = 0; rj < nb; rj++) {
+                const uint32_t ri = rb + rj, i = ib + ri + 1;
+                const uint32_t meta = __builtin_amdgcn_readlane(mC, ri), p0 = __builtin_amdgcn_readlane(aC, ri);
+                const uint32_t npred = meta >> 8;
+                // mismatch bits of this row: bit 2k set <=> the base under column k differs from the row's letter
+                mask_t mis;
+                {
+                    const mask_t x = bases ^ ((mask_t)(meta & 3u) * (mask_t)0x5555555555555555ull);
+                    mis = x | (x >> 1) | nobase;
+                }
+                auto score_of = [&](int k) -> int {   // 64 x substitution score of column k (+63: the diagonal move type)
+                    int neg;   // -1 on a mismatch, 0 on a match
+                    if constexpr (CM <= 16) neg = __builtin_amdgcn_sbfe((int)mis, 2 * k, 1);
+                    else neg = 2 * k < 32 ? __builtin_amdgcn_sbfe((int)(uint32_t)mis, (2 * k) & 31, 1) : __builtin_amdgcn_sbfe((int)(uint32_t)(mis >> 32), (2 * k) & 31, 1);
+                    return (m64 + KD) + ((mm64 - m64) & neg);
                 };
-                // the first two predecessors come with the row record (registers); only a third and later ones are fetched — in their own
-                // loop, so that the common case never waits for a "possibly pending" global load (and with it for the previous rows' stores)
-                acc_pred(p0, 0);
-                acc_pred(p1, 1);
-                for (uint32_t p = 2; p < npred; p++) acc_pred((uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[po + p]), p);
-            }
-            // chunk-local horizontal recurrence (type 1 loses every tie)
+                hrow += WH;
+                if (DIR) drow += W;
+                DP_T(0);   // row decode
+                int m[CM];
+                {   // the first predecessor (or row 0): diagonal and vertical move
+                    int hp[CM], left;
+                    pred_row(p0, hp, left);
 #pragma unroll
-            for (int k = 1; k < CM; k++) m[k] = max(m[k], (m[k - 1] & ~63) + (g64 + KH));
-            DP_T(1);   // predecessor rows + cells + horizontal chain
-            // prefix maximum over the lanes to the left of (chunk end score - its column * gap)
-            const int inc = wave_incl_max((m[CM - 1] & ~63) - (jg0 + (CM - 1) * g64));
-            int ex = wave_shift_up1(inc, NEGK);
-            DP_T(2);   // wave scan
-            const int cin = __builtin_amdgcn_readlane(cinV, ri & (CARRY_BATCH - 1));   // NEGK without a wave on the left
-            if (has_out && lane == 63) {   // the carry of this row for the wave on the right: the prefix maximum through this wave's last column
-                const unsigned long long e = (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, inc) << 32);
-                if (out_lds) st_wg64(mb_out_l + (i & (WAVE_MBOX - 1)), e); else st_dev64(mb_out_h + i, e);
-            }
-            ex = max(ex, cin);
-            DP_T(3);   // carry in / out
-            const int base = ex + jg0;            // 64 x (score reaching column j0 through a horizontal move from the left neighbour)
-#pragma unroll
-            for (int k = 0; k < CM; k++) m[k] = max(m[k], base + (k * g64 + KH));
-            left_prev = base - g64;               // 64 x H[i][j0-1]: the exclusive prefix already is the finished value left of this chunk
-#pragma unroll
-            for (int k = 0; k < CM; k++) t[k] = m[k] & ~63;
-            if (R && (meta & copy_if)) {   // copy to the LDS ring: a kept row (a later row reads it as a non-adjacent predecessor) takes the next slot, any other row the scratch slot R (if there is one)
-                const uint32_t kept = (meta >> 4) & 1u, slot = kept ? (nkept & (R - 1)) : R;
-                int32_t* S = ring + (size_t)slot * ring_w + wv * (65u * CM) + lane;
-#pragma unroll
-                for (int k = 0; k < CM; k++) S[k * PW + 1] = t[k];
-                if (lane == 0) S[(CM - 1) * PW] = left_prev;   // (first wave of the edge: "minus infinity")
-            }
-            nkept += (meta >> 4) & 1u;
-            DP_T(4);   // carry applied, kept-row copy
-            if (live) {
-                if (DIR) {
-                    uint32_t dc[CM];
-#pragma unroll
-                    for (int k = 0; k < CM; k++) dc[k] = (uint32_t)m[k];
-                    store_dirs<CM>(drow + j0, dc, 0x3f3f3f3fu);   // the move code of every cell: type * 16 + 15 - predecessor slot
-                } else {
-                    int pl[CM];
-#pragma unroll
-                    for (int k = 0; k < CM; k++) pl[k] = t[k] >> 6;
-                    store_chunk_i32<CM>(hrow + j0, pl);
-                    if (lane == 0 && has_in) hrow[hleft] = left_prev >> 6;   // the wave's own copy of the column on its left
+                    for (int k = 0; k < CM; k++) m[k] = max((k == 0 ? left : hp[k - 1]) + score_of(k), hp[k] + (g64 + KV));
                 }
-            }
-            DP_T(5);   // stores
-            if (__builtin_expect((meta & (8u | 4u)) != 0, 0)) {
-                if (meta & 8u) {   // a far successor reads this row back from HBM (keys; with the score matrix it is there already)
-                    if (DIR && live) {
-                        int32_t* F = H + (uint64_t)farslot[i - 1] * WH;
-                        store_chunk_i32<CM>(F + j0, t);
-                        if (lane == 0 && has_in) F[hleft] = left_prev;
+                if (npred > 1) {
+                    // the maximum over the predecessors: the low bits carry the move type and 15 - p, so ONE running maximum does it all
+                    // (a diagonal beats a vertical move of the same score, the first predecessor in in-edge order beats the later ones)
+                    const uint32_t po = __builtin_amdgcn_readlane(oC, ri);
+                    for (uint32_t p = 1; p < npred; p++) {
+                        // the first four predecessors come with the row records (registers): only a fifth and later ones are fetched here
+                        const uint32_t ent = p == 1 ? __builtin_amdgcn_readlane(bC, ri) : p == 2 ? __builtin_amdgcn_readlane(cC, ri) : p == 3 ? __builtin_amdgcn_readlane(dC, ri)
+                                                    : (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[po + p]);
+                        const int ps = DIR ? (int)p : 0;        // direction bytes exist only while in-degrees stay <= 16 (the CSR build checks)
+                        int hp[CM], left;
+                        pred_row(ent, hp, left);
+#pragma unroll
+                        for (int k = 0; k < CM; k++) m[k] = max(m[k], max((k == 0 ? left : hp[k - 1]) + score_of(k) - ps, hp[k] + (g64 + KV - ps)));
                     }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row has left this wave before a later row reads it back
                 }
-                if (owns_last && (meta & 4u)) {   // sink node: candidate end of the global alignment
-                    int v = NEGK;
+                // chunk-local horizontal recurrence (type 1 loses every tie)
 #pragma unroll
-                    for (int k = 0; k < CM; k++) if ((uint32_t)k == klast) v = t[k];
-                    if (nsink < sink_cap) { sink_row[nsink] = i; sink_score[nsink] = v >> 6; }
-                    nsink++;
+                for (int k = 1; k < CM; k++) m[k] = max(m[k], (m[k - 1] & ~63) + (g64 + KH));
+                DP_T(1);   // predecessor rows + cells + horizontal chain
+                // prefix maximum over the lanes to the left of (chunk end score - its column * gap)
+                const int inc = wave_incl_max((m[CM - 1] & ~63) - (jg0 + (CM - 1) * g64));
+                int ex = wave_shift_up1(inc, NEGK);
+                DP_T(2);   // wave scan
+                const int cin = __builtin_amdgcn_readlane(cinV, rj);   // NEGK without a wave on the left
+                if (has_out) {   // the carry of this row for the wave on the right: the prefix maximum through this wave's last column (lane 63 holds it)
+                    const unsigned long long e = (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, inc) << 32);
+                    if (out_lds) { if (lane == 63) st_wg64(mb_out_l + (i & (WAVE_MBOX - 1)), e); }
+                    else if (lane == 63) st_dev64(mb_out_h + i, e);
+                }
+                ex = max(ex, cin);
+                DP_T(3);   // carry in / out
+                const int base = ex + jg0;            // 64 x (score reaching column j0 through a horizontal move from the left neighbour)
+#pragma unroll
+                for (int k = 0; k < CM; k++) m[k] = max(m[k], base + (k * g64 + KH));
+                int t[CM];
+#pragma unroll
+                for (int k = 0; k < CM; k++) t[k] = m[k] & ~63;
+                const int left_now = base - g64;      // 64 x H[i][j0-1]: the exclusive prefix already is the finished value left of this chunk
+                {   // to the ring: a kept row takes the next slot, any other row slot R
+                    const uint32_t kept = (meta >> 4) & 1u, slot = kept && R ? (nkept & (R - 1)) : R;
+                    int32_t* S = ring_me + (size_t)slot * ring_w;
+#pragma unroll
+                    for (int k = 0; k < CM; k++) S[k * PW + 1] = t[k];
+                    if (lane == 0) S[(CM - 1) * PW] = left_now;   // (first wave of the edge: "minus infinity")
+                    nkept += kept;
+                }
+                DP_T(4);   // carry applied, ring copy
+                if (__builtin_expect(live, 1)) {
+                    if (DIR) {
+                        uint32_t dc[CM];
+#pragma unroll
+                        for (int k = 0; k < CM; k++) dc[k] = (uint32_t)m[k];
+                        store_dirs<CM>(drow + j0, dc, 0x3f3f3f3fu);   // the move code of every cell: type * 16 + 15 - predecessor slot
+                    } else {
+                        int pl[CM];
+#pragma unroll
+                        for (int k = 0; k < CM; k++) pl[k] = t[k] >> 6;
+                        store_chunk_i32<CM>(hrow + j0, pl);
+                        if (lane == 0 && has_in) hrow[hleft] = left_now >> 6;   // the wave's own copy of the column on its left
+                    }
+                }
+                DP_T(5);   // stores
+                if (__builtin_expect((meta & (8u | 4u)) != 0, 0)) {
+                    if (meta & 8u) {   // a far successor reads this row back from HBM (keys; with the score matrix it is there already)
+                        if (DIR && live) {
+                            int32_t* F = H + (uint64_t)farslot[i - 1] * WH;
+                            store_chunk_i32<CM>(F + j0, t);
+                            if (lane == 0 && has_in) F[hleft] = left_now;
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row has left this wave before a later row reads it back
+                    }
+                    if (owns_last && (meta & 4u)) {   // sink node: candidate end of the global alignment
+                        int v = NEGK;
+#pragma unroll
+                        for (int k = 0; k < CM; k++) if ((uint32_t)k == klast) v = t[k];
+                        if (nsink < sink_cap) { sink_row[nsink] = i; sink_score[nsink] = v >> 6; }
+                        nsink++;
+                    }
                 }
             }
         }
@@ -872,12 +861,12 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     // Rows nobody keeps go to a scratch slot so that the copy is unconditional; when the LDS holds exactly a power of two of rows the scratch
     // slot is given up for twice the ring (wide rows: one branch per row is nothing against a row read back from HBM).
     uint32_t R = 0;
-    bool ring_scratch = true;
-    if (ring_rows >= 2) {
-        const uint32_t fit = lds_bytes / (ring_w * 4u);
-        R = fit >= 8 ? 8 : fit >= 4 ? 4 : fit >= 2 ? 2 : 0;
-        ring_scratch = fit > R;
+    {
+        const uint32_t fit = lds_bytes / (ring_w * 4u);   // slots: R kept rows + 1 for the latest row nobody keeps
+        R = fit >= 9 ? 8 : fit >= 5 ? 4 : fit >= 3 ? 2 : 0;   // (0: rows too wide for more than the latest one - every kept row is read back from HBM)
+        if (fit < 1) R = 0xffffffffu;
     }
+    (void)ring_rows;
     uint8_t* seq = P.seq + ED.seq_off;
     const uint32_t W = (ED.lmax + 1 + 31) & ~31u;   // row stride: a multiple of the widest lane chunk (32 columns), so chunks are vector-aligned and stay inside their row
     const uint32_t WH = W + (GM * (NT >> 6) > 1 ? (GM * (NT >> 6) + 3u) & ~3u : 0u);   // rows of H end with one word per wave of the edge's pipeline (dp_rows)
@@ -893,7 +882,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     __shared__ int sink_score[SINK_LDS];
     __shared__ uint32_t sCtl;
     __shared__ unsigned long long sCells;   // DP cells of this edge (reported only when the edge completes: retried edges count once)
-    if (tid == 0) { sV = 0; sE = 0; sOk = 1; sCells = 0; }
+    if (tid == 0) { sV = 0; sE = 0; sOk = R != 0xffffffffu ? 1 : 2; sCells = 0; }   // (the host gives every launch LDS for at least the latest row)
     if constexpr (MAXNT > 64) {
         for (uint32_t q = tid; q < (MAXNT / 64 - 1) * WAVE_MBOX; q += NT) wmail.box[q] = 0ull;   // tag 0 = nothing published
         if (tid < MAXNT / 64) wmail.consumed[tid] = 0u;
@@ -903,7 +892,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     int32_t* sinkbuf = P.sinkbuf + (uint64_t)eidx * (1 + 2 * SINK_CAP);
     DpCl cl;
     cl.mem = mem; cl.members = GM; cl.stride = ED.vcap + 1; cl.tag0 = 0;
-    cl.mbox = P.mbox + ED.cl_off; cl.err = csy + 4; cl.ring_scratch = ring_scratch;
+    cl.mbox = P.mbox + ED.cl_off; cl.err = csy + 4;
     constexpr uint32_t CL_ABORT = 0xffffffffu;
 #define HX_DP_DISPATCH(Lq, Vq, nsq) do { \
         if (((Lq) + 1 + GM * NT - 1) / (GM * NT) <= (uint32_t)CM)      /* the host puts an edge into a launch whose columns per lane hold its longest sequence */ \
@@ -1380,18 +1369,19 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                     st_multi += np >= 2;
                     for (uint32_t q = 0; q < np; q++) {
                         const uint32_t pr = g.pred_rank[po + q];
-                        uint32_t loc = 0;
-                        if (r - pr >= 2) {
+                        uint32_t loc;
+                        if (!((g.row_meta[pr] >> 4) & 1u) || (R == 0 && r - pr == 1)) loc = R + 1;   // nobody keeps it: it is the previous row and sits in the slot of the latest such row
+                        else {
                             const uint32_t live = (uint32_t)g.score[r] - (uint32_t)g.score[pr];   // kept rows produced in [pr, r), pr included
-                            if (R && live <= R) loc = 1 + ((uint32_t)g.score[pr] & (R - 1));
+                            if (live <= R) loc = 1 + ((uint32_t)g.score[pr] & (R - 1));
                             else { loc = 15; atomicOr(&g.row_meta[pr], 8u); }
                         }
                         const uint32_t ent = pr | (loc << 28);
-                        st_ring += loc != 0 && loc != 15; st_far += loc == 15;
+                        st_ring += r - pr >= 2 && loc != 15; st_far += loc == 15;
                         g.pred_rank[po + q] = ent;
                         if (q == 0) g.row_pred0[r] = ent; else if (q == 1) g.row_pred1[r] = ent;
-                        if (np == 1 && loc != 15) atomicOr(&g.row_meta[r], (loc == 0 ? 1u : 2u) << 5);   // row type for the DP's dispatch (other lanes OR flags into this word)
                     }
+                    if (np == 0) g.row_pred0[r] = 14u << 28;   // a source node: the virtual row 0
                 }
                 if (DIR) {   // rows that a far successor reads back from HBM get consecutive rows of H (the score matrix is not kept with direction bytes)
                     __syncthreads();
