@@ -1069,8 +1069,18 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                     const uint32_t ln = tid;
                     if (ln == 0) sCells += (unsigned long long)V * L;
                     uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane(sBestI), j = L, na = 0;
+                    // path entries are collected in two registers (entry n in lane n % 64, v_writelane) and leave 64 at a time with one
+                    // coalesced store each: a store per step cost more than the step itself
+                    int pn = 0, pp = 0;
+                    bool tail = false;
+                    auto flush = [&](uint32_t upto) {
+                        const uint32_t base = (upto - 1) & ~63u;
+                        if (ln < upto - base) { g.aln_node[base + ln] = pn; g.aln_pos[base + ln] = pp; }
+                    };
                     while (!(i == 0 && j == 0)) {
                         if (i == 0) {   // only horizontal moves are left in the virtual row
+                            if (na & 63u) flush(na);
+                            tail = true;
                             for (uint32_t q = ln; q < j; q += 64) { g.aln_node[na + q] = 0; g.aln_pos[na + q] = (int32_t)(j - 1 - q); }
                             na += j; j = 0;
                             break;
@@ -1101,12 +1111,18 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                             if (__builtin_expect(slot >= 2 && type != 1u, 0)) ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[(uint32_t)__builtin_amdgcn_readlane((int)qo, (int)dr) + slot]);
                             const uint32_t pv = np == 0 ? 0u : (ent & 0x0fffffffu) + 1;
                             const uint32_t pi_ = type == 1u ? i : pv, pj_ = type == 2u ? j : j - 1;
-                            if (ln == 0) { g.aln_node[na] = i == pi_ ? 0 : (int32_t)i; g.aln_pos[na] = j == pj_ ? -1 : (int32_t)(j - 1); }
+                            {
+                                const int en = __builtin_amdgcn_readfirstlane(i == pi_ ? 0 : (int)i), ep = __builtin_amdgcn_readfirstlane(j == pj_ ? -1 : (int)(j - 1));
+                                const int el = __builtin_amdgcn_readfirstlane((int)(na & 63u));
+                                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0" : "+v"(pn), "+v"(pp) : "s"(el), "s"(en), "s"(ep) : "m0");
+                            }
                             na++;
+                            if ((na & 63u) == 0) flush(na);
                             i = pi_; j = pj_;
                             if (i == 0 || ti - i >= 32 || tj - j >= 16) break;
                         }
                     }
+                    if (!tail && (na & 63u)) flush(na);   // (after a tail of horizontal moves everything has been written already)
                     if (ln == 0) sNaln = na;
                 }
                 __syncthreads();
