@@ -96,14 +96,14 @@ struct PoaPoolBufs {
     DV<int32_t> score, pred, e_w, aln_node, aln_pos, H;
     DV<uint32_t> row_meta, row_pred0, row_pred1;
     DV<uint4> nrec;
-    DV<uint8_t> dir;
+    DV<uint8_t> dir, dirw; DV<uint32_t> wslot;
     DV<unsigned long long> mbox; DV<int32_t> sinkbuf; DV<uint32_t> csync; DV<uint16_t> row_al;   // cluster mode (edges shared by several workgroups)
     void release_all() {
         code.release(); n_aligned.release(); mark.release(); check.release(); row_code.release(); row_sink.release(); seq.release();
         aligned.release(); in_head.release(); in_tail.release(); out_head.release(); out_tail.release(); rank2node.release(); node2rank.release();
         stack.release(); row_pred_off.release(); pred_rank.release(); e_from.release(); e_to.release(); e_next_in.release(); e_next_out.release();
         score.release(); pred.release(); e_w.release(); aln_node.release(); aln_pos.release(); H.release(); row_meta.release(); row_pred0.release();
-        row_pred1.release(); nrec.release(); dir.release(); mbox.release(); sinkbuf.release(); csync.release(); row_al.release();
+        row_pred1.release(); nrec.release(); dir.release(); dirw.release(); wslot.release(); mbox.release(); sinkbuf.release(); csync.release(); row_al.release();
     }
 };
 }  // namespace
@@ -555,6 +555,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     std::vector<uint8_t> grow(ne, 0);          // times an edge's graph outgrew its workspace: the node estimate doubles each time
     std::vector<uint8_t> force_nodir(ne, 0);   // edges whose in-degrees outgrew the direction bytes
     std::vector<uint8_t> full_h(ne, 0);        // edges that run with the score-matrix traceback
+    std::vector<uint8_t> wide_grow(ne, 0);     // times an edge had more rows with over 4 predecessors than its wide-row pool: the estimate quadruples each time
     std::vector<uint8_t> many_sinks(ne, 0);    // edges with more sink rows than the smaller kernels keep in LDS: one 1024-lane workgroup
     const uint32_t max_indeg = getenv("HX_POA_MAX_INDEG") ? std::min<uint32_t>(16, (uint32_t)atoi(getenv("HX_POA_MAX_INDEG"))) : 16;   // (testing: forces the score-matrix retry earlier)
     const uint32_t cl_lanes = getenv("HX_POA_MEMBER_LANES") ? (uint32_t)atoi(getenv("HX_POA_MEMBER_LANES")) : 256;   // lanes per cluster member
@@ -603,7 +604,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
         return R;
     };
     auto cm_round = [](uint32_t ncol, uint32_t lanes) -> uint32_t { uint32_t cm = (ncol + lanes - 1) / lanes, r = 4; while (r < cm) r <<= 1; return r; };
-    std::vector<uint8_t> far_full(ne, 0);      // edges whose far rows outgrew the estimate
+    std::vector<uint8_t> far_full(ne, 0);      // times an edge's far rows outgrew the estimate: four times the room each time
     // DP work of an edge ~ sum over its sequences of (nodes so far) x (length): with nodes growing linearly that is about half of
     // (final nodes) x (longest sequence) x (sequences). vcap < 2^21, lmax < 2^16, nseq < 2^24: no overflow
     auto edge_cost = [&](uint32_t e) -> uint64_t { return (uint64_t)P.edges[e].vcap * P.edges[e].lmax * std::max<uint32_t>(1, P.nseq[e]); };
@@ -651,7 +652,11 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             // measured on PacBio-like data, rows read back from HBM per DP row: 0.15-0.4 % with 8 ring rows, 3-5 % with 4, 16-25 % on average
             // with 2 (single edges: up to every kept row, ~60 % of the rows). Graphs fill ~70 % of the node estimate these are fractions of.
             uint32_t est = far_rows >= 0 ? (uint32_t)far_rows : Rp >= 8 ? E.vcap / 32 + 256 : Rp >= 4 ? E.vcap / 8 + 256 : Rp >= 2 ? E.vcap / 2 + 256 : E.vcap + 1;
-            E.hrows = full_h[e] || far_full[e] ? E.vcap + 1 : std::min<uint32_t>(E.vcap + 1, est);
+            E.hrows = full_h[e] || far_full[e] >= 3 ? E.vcap + 1 : (uint32_t)std::min<uint64_t>((uint64_t)E.vcap + 1, far_full[e] ? (uint64_t)std::max<uint32_t>(est, 256) << (2 * far_full[e]) : est);   // (a fourth attempt gets a row per node)
+            // rows with more than 4 predecessors (a move byte per cell instead of a nibble): 1-2 % of the rows the DPs of 25- to 45-fold edges run
+            // over, up to ~10 % of a finished deep graph; a 16th of the node estimate (graphs fill about a third of it) is the room, four times
+            // more after every overflow
+            E.wrows = wide_grow[e] >= 3 ? E.vcap + 1 : (uint32_t)std::min<uint64_t>((uint64_t)E.vcap + 1, ((uint64_t)E.vcap / 16 + 64) << (2 * wide_grow[e]));
         }
         // largest first (block scheduling is in grid order): cost ~ rows x columns x sequences
         std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) {
@@ -662,37 +667,38 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
         // (batch i takes edges i, i + B, i + 2B, ...): every batch then has its share of the large edges, whose serial dependence sets the
         // batch's duration, and of the many small ones that keep the other CUs busy meanwhile. (Filling batch after batch in cost order
         // would put the large edges alone into the first batches.)
-        auto edge_bytes = [&](uint32_t e, uint64_t& nn, uint64_t& dc, uint64_t& hc, uint64_t& cle) -> uint64_t {
+        auto edge_bytes = [&](uint32_t e, uint64_t& nn, uint64_t& dc, uint64_t& hc, uint64_t& cle, uint64_t& wc) -> uint64_t {
             const hxk::PoaEdge& E = P.edges[e];
             const uint64_t rw = ((uint64_t)E.lmax + 1 + 31) & ~31ull;                 // rows padded to 32 columns (the widest lane chunk)
             const uint64_t waves = (uint64_t)E.members * ((E.members > 1 ? cl_lanes : (uint32_t)kClassNT[class_of(e)]) / 64);
             const uint64_t rwh = rw + (waves > 1 ? (waves + 3) & ~3ull : 0);       // rows of H end with one word per wave of the edge's pipeline
-            nn = (uint64_t)E.vcap + 1; dc = full_h[e] ? 0 : nn * rw; hc = (uint64_t)E.hrows * rwh;
+            nn = (uint64_t)E.vcap + 1; dc = full_h[e] ? 0 : nn * (rw / 2); hc = (uint64_t)E.hrows * rwh; wc = full_h[e] ? 0 : (uint64_t)E.wrows * rw;
             cle = E.members > 1 ? (uint64_t)E.members * nn : 0;
-            return nn * 86 + (uint64_t)E.ecap * 24 + hc * 4 + dc + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8 + cle * 8;
+            return nn * 90 + (uint64_t)E.ecap * 24 + hc * 4 + dc + wc + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8 + cle * 8;
         };
         std::vector<std::vector<uint32_t>> batches;
         {
-            uint64_t total = 0, biggest = 0, a1, a2, a3, a4;
-            for (uint32_t e : todo) { const uint64_t b = edge_bytes(e, a1, a2, a3, a4); total += b; biggest = std::max(biggest, b); }
+            uint64_t total = 0, biggest = 0, a1, a2, a3, a4, a5;
+            for (uint32_t e : todo) { const uint64_t b = edge_bytes(e, a1, a2, a3, a4, a5); total += b; biggest = std::max(biggest, b); }
             if (biggest > budget) return fail("hx_poa_batch: a single edge needs more POA workspace than the device has free");
             const size_t forced = getenv("HX_POA_BATCHES") ? (size_t)atol(getenv("HX_POA_BATCHES")) : 0;   // (testing)
             for (size_t nb = std::max<size_t>(std::max<size_t>(1, forced), (size_t)((total + budget - 1) / budget));; nb++) {
                 nb = std::min(nb, std::max<size_t>(1, todo.size()));
                 batches.assign(nb, {});
                 std::vector<uint64_t> bb(nb, 0);
-                for (size_t i = 0; i < todo.size(); i++) { batches[i % nb].push_back(todo[i]); bb[i % nb] += edge_bytes(todo[i], a1, a2, a3, a4); }
+                for (size_t i = 0; i < todo.size(); i++) { batches[i % nb].push_back(todo[i]); bb[i % nb] += edge_bytes(todo[i], a1, a2, a3, a4, a5); }
                 if (*std::max_element(bb.begin(), bb.end()) <= budget || nb >= todo.size()) break;
             }
         }
         std::vector<uint32_t> retry, retry_same;   // retry with the worst-case workspace / with the score-matrix traceback
         for (const std::vector<uint32_t>& batch : batches) {
             if (batch.empty()) continue;
-            uint64_t no = 0, eo = 0, ho = 0, dro = 0, so = 0, co = 0, sto = 0, ao = 0, clo = 0, bytes = 0;
+            uint64_t no = 0, eo = 0, ho = 0, dro = 0, wo = 0, so = 0, co = 0, sto = 0, ao = 0, clo = 0, bytes = 0;
             for (uint32_t e : batch) {
                 hxk::PoaEdge& E = P.edges[e];
-                uint64_t nn, dc, hc, cle;
-                bytes += edge_bytes(e, nn, dc, hc, cle);
+                uint64_t nn, dc, hc, cle, wc;
+                bytes += edge_bytes(e, nn, dc, hc, cle, wc);
+                E.w_off = wo; wo += wc;
                 E.node_off = no; E.edge_off = eo; E.h_off = ho; E.d_off = dro; E.seq_off = so; E.cns_off = co; E.stack_off = sto; E.aln_off = ao; E.cl_off = clo;
                 no += nn; eo += E.ecap; ho += hc; dro += dc; so += E.lmax; co += E.vcap; sto += 4 * nn + E.ecap; ao += nn + E.lmax + 2; clo += cle;
             }
@@ -703,7 +709,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             auto reserve_pools = [&]() -> hipError_t {
                 hipError_t e;
 #define HX_RSV(buf, n) do { if ((e = (buf).reserve(n)) != hipSuccess) return e; } while (0)
-                HX_RSV(B.H, std::max<uint64_t>(1, ho)); HX_RSV(B.dir, std::max<uint64_t>(1, dro));
+                HX_RSV(B.H, std::max<uint64_t>(1, ho)); HX_RSV(B.dir, std::max<uint64_t>(1, dro)); HX_RSV(B.dirw, std::max<uint64_t>(1, wo)); HX_RSV(B.wslot, no);
                 HX_RSV(B.code, no); HX_RSV(B.n_aligned, no); HX_RSV(B.mark, no); HX_RSV(B.check, no); HX_RSV(B.row_code, no); HX_RSV(B.row_sink, no); HX_RSV(B.row_al, no);
                 HX_RSV(B.aligned, 3 * no); HX_RSV(B.in_head, no); HX_RSV(B.in_tail, no); HX_RSV(B.out_head, no); HX_RSV(B.out_tail, no); HX_RSV(B.rank2node, no);
                 HX_RSV(B.node2rank, no); HX_RSV(B.row_pred_off, no); HX_RSV(B.score, no); HX_RSV(B.pred, no); HX_RSV(B.pred_rank, eo); HX_RSV(B.e_from, eo);
@@ -778,7 +784,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             HIPCHK(hipMemcpyAsync(d_order.p, order_all.data(), order_all.size() * 4, hipMemcpyHostToDevice, s));
             hxk::PoaPools pools{B.code.p, B.n_aligned.p, B.aligned.p, B.in_head.p, B.in_tail.p, B.out_head.p, B.out_tail.p, B.rank2node.p, B.node2rank.p,
                                 B.mark.p, B.check.p, B.stack.p, B.score.p, B.pred.p, B.row_code.p, B.row_sink.p, B.row_pred_off.p, B.pred_rank.p, B.row_meta.p, B.row_pred0.p, B.row_pred1.p, B.nrec.p,
-                                B.e_from.p, B.e_to.p, B.e_next_in.p, B.e_next_out.p, B.e_w.p, B.aln_node.p, B.aln_pos.p, B.H.p, B.dir.p, B.seq.p,
+                                B.e_from.p, B.e_to.p, B.e_next_in.p, B.e_next_out.p, B.e_w.p, B.aln_node.p, B.aln_pos.p, B.H.p, B.dir.p, B.dirw.p, B.wslot.p, B.seq.p,
                                 B.mbox.p, B.csync.p, B.sinkbuf.p, B.row_al.p};
             c->tick();
             HIPCHK(hipEventRecord(c->poa_ev[6], s));
@@ -819,12 +825,13 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             std::vector<char> h_cns(co);
             if (co) HIPCHK(hipMemcpy(h_cns.data(), d_cns.p, co, hipMemcpyDeviceToHost));
             if (getenv("HX_DEBUG")) {
-                size_t n_far = 0, n_nodir = 0, n_over = 0;
-                for (uint32_t e : batch) { n_far += !!(h_status[e] & HXE_POA_FARROWS); n_nodir += !!(h_status[e] & HXE_POA_NODIR); n_over += !!(h_status[e] & HXE_POA_OVERFLOW); }
-                if (n_far + n_nodir + n_over) fprintf(stderr, "[hx] POA batch: to be redone: %zu (rows read back from HBM outgrew H), %zu (in-degree above the direction bytes' limit), %zu (graph outgrew its workspace)\n", n_far, n_nodir, n_over);
+                size_t n_far = 0, n_nodir = 0, n_over = 0, n_wide = 0, n_sinks = 0;
+                for (uint32_t e : batch) { n_far += !!(h_status[e] & HXE_POA_FARROWS); n_nodir += !!(h_status[e] & HXE_POA_NODIR); n_over += !!(h_status[e] & HXE_POA_OVERFLOW); n_wide += !!(h_status[e] & HXE_POA_WIDEROWS); n_sinks += !!(h_status[e] & HXE_POA_SINKS); }
+                if (n_far + n_nodir + n_over + n_wide + n_sinks) fprintf(stderr, "[hx] POA batch: to be redone: %zu (rows read back from HBM outgrew H), %zu (in-degree above the direction bytes' limit), %zu (graph outgrew its workspace), %zu (rows with more than 4 predecessors outgrew the wide-row pool), %zu (more sink rows than the launch keeps)\n", n_far, n_nodir, n_over, n_wide, n_sinks);
             }
             for (uint32_t e : batch) {
-                if (h_status[e] & HXE_POA_FARROWS) { if (far_full[e]) return fail("hx_poa_batch: internal error (far-row retry)"); far_full[e] = 1; retry_same.push_back(e); continue; }
+                if (h_status[e] & HXE_POA_FARROWS) { if (P.edges[e].hrows >= P.edges[e].vcap + 1) return fail("hx_poa_batch: internal error (far-row retry)"); far_full[e]++; retry_same.push_back(e); continue; }
+                if (h_status[e] & HXE_POA_WIDEROWS) { if (P.edges[e].wrows >= P.edges[e].vcap + 1) return fail("hx_poa_batch: internal error (wide-row retry)"); wide_grow[e]++; retry_same.push_back(e); continue; }
                 if (h_status[e] & HXE_POA_SINKS) { if (many_sinks[e]) return fail("hx_poa_batch: internal error (sink-list retry)"); many_sinks[e] = 1; retry_same.push_back(e); continue; }
                 if (h_status[e] & HXE_POA_NODIR) { if (force_nodir[e]) return fail("hx_poa_batch: internal error (direction-byte retry)"); force_nodir[e] = 1; retry_same.push_back(e); continue; }
                 if (h_status[e] & ~(uint32_t)HXE_POA_OVERFLOW) return fail("hx_poa_batch: internal error (kernel variant / column count mismatch)");

@@ -76,14 +76,15 @@ struct PoaEdge {
     uint64_t node_off, edge_off;   // into the node / edge pools (elements)
     uint64_t h_off;                // into the H pool (int32 cells): hrows rows of W + one word per wave of the edge's pipeline. Direction-byte traceback: only the rows a far successor reads
                                    // (hrows = an estimate, overflow -> retry); score-matrix traceback: all vcap + 1 rows
-    uint64_t d_off;                // into the direction-byte pool (bytes): vcap + 1 rows of W
+    uint64_t d_off;                // into the direction pool (bytes): vcap + 1 rows of W / 2 (a 4-bit move code per cell)
+    uint64_t w_off;                // into the wide-row pool (bytes): wrows rows of W (a move byte per cell of the rows with more than 4 predecessors)
     uint64_t seq_off;              // into the decoded-sequence pool (bytes, lmax per edge)
     uint64_t cns_off;              // into the consensus output (bytes, capacity vcap)
     uint64_t stack_off;            // into the toposort stack pool (4*(vcap+1) + ecap entries per edge)
     uint64_t aln_off;              // into the alignment pools (vcap + lmax + 2 entries per edge)
     uint64_t cl_off;               // into the cluster pools (members * (vcap+1) entries per edge), members > 1 only
     uint32_t members;              // workgroups ("members", one CU each) that share this edge's DP columns; 1 = the usual single workgroup
-    uint32_t pad_;
+    uint32_t wrows;                // rows of the wide-row pool (an estimate, overflow -> retry)
 };
 struct PoaPools {
     // per node (pool length = sum (vcap+1))
@@ -101,7 +102,9 @@ struct PoaPools {
     // alignment output of the traceback (node|-1, pos|-1), own pool, PoaEdge::aln_off
     int32_t* aln_node; int32_t* aln_pos;
     int32_t* H;
-    uint8_t* dir;   // traceback direction bytes, same geometry/offsets as H (used when every edge has <= 63 sequences)
+    uint8_t* dir;   // traceback move codes, 4 bits per cell (PoaEdge::d_off)
+    uint8_t* dirw;  // move bytes of the rows with more than 4 predecessors (PoaEdge::w_off)
+    uint32_t* wslot;   // per rank: row of the wide-row pool
     uint8_t* seq;
     // cluster mode (an edge's DP columns spread over several workgroups):
     unsigned long long* mbox;   // [member][row] = {tag, carry}: prefix maximum of the row through the member's last column (PoaEdge::cl_off)

@@ -37,6 +37,7 @@ struct G {   // per-edge views into the pools
     uint8_t *row_code, *row_sink; uint32_t *row_pred_off, *pred_rank;
     uint32_t *row_meta, *row_pred0, *row_pred1;   // per rank: code | sink<<2 | far<<3 | npred<<8 ; ranks of the first two predecessors
     uint16_t* row_al;                             // per rank: aligned nodes in list order as rank deltas (3 x 3 bits, delta + 4, 0 = none)
+    uint32_t* wslot;                              // per rank: row of the wide-row pool (rows with more than 4 predecessors: a direction byte per cell)
     uint4* nrec;   // per node, one 16-byte record for the serial graph walks: {1st in-edge source, 2nd in-edge source, 3 aligned ids (+1) x 21 bit, bit 63: more in-edges}
     uint32_t *e_from, *e_to, *e_next_in, *e_next_out; int32_t* e_w;
     int32_t *aln_node, *aln_pos;
@@ -558,6 +559,23 @@ template <int CM> __device__ __forceinline__ void store_dirs(uint8_t* p, const u
     }
 }
 
+// low nibble of CM registers -> CM / 2 bytes (cell k in the low half of byte k / 2 for even k, the high half for odd k)
+template <int CM> __device__ __forceinline__ void store_nibbles(uint8_t* p, const uint32_t (&v)[CM]) {
+    static_assert(CM >= 4 && CM % 4 == 0, "4, 8, 16 or 32 columns per lane");
+    uint32_t b[CM / 2];   // byte 0 of b[q] = the two cells 2q, 2q + 1 (higher bits are dropped by the byte packing)
+#pragma unroll
+    for (int q = 0; q < CM / 2; q++) b[q] = (v[2 * q] & 15u) | (v[2 * q + 1] << 4);
+    if constexpr (CM == 4) *reinterpret_cast<uint16_t*>(p) = (uint16_t)__builtin_amdgcn_perm(b[1], b[0], 0x0c0c0400u);
+    else {
+        uint32_t w[CM / 8];
+#pragma unroll
+        for (int q = 0; q < CM / 8; q++) w[q] = pack_b0(b[4 * q], b[4 * q + 1], b[4 * q + 2], b[4 * q + 3]);
+        if constexpr (CM == 8) *reinterpret_cast<uint32_t*>(p) = w[0];
+        else if constexpr (CM == 16) *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);
+        else *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 #if defined(HX_DP_PROF) && !defined(HX_DP_PROF2)
 #define DP_T(k) do { if (tid == 0) { const long long _n = clock64(); prof[k] += (unsigned long long)(_n - tprev); tprev = _n; } } while (0)
 #else
@@ -569,7 +587,7 @@ template <int CM> __device__ __forceinline__ void store_dirs(uint8_t* p, const u
 // one not-taken branch, the kept-row copy to the LDS ring is unconditional (rows nobody keeps go to a scratch slot), selects are
 // arithmetic.
 template <int CM, bool DIR>
-__device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, const uint32_t W, const uint32_t WH, const uint8_t* __restrict__ seq,
+__device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, uint8_t* __restrict__ Dwide, const uint32_t W, const uint32_t WH, const uint8_t* __restrict__ seq,
                         const uint32_t L, const uint32_t V, int32_t* ring, const uint32_t R, const uint32_t ring_w, const int match, const int mismatch, const int gap,
                         unsigned long long* wm_box, uint32_t* wm_cons, uint32_t* sink_row, int* sink_score, const uint32_t sink_cap, uint32_t& nSinkOut, const DpCl& cl, unsigned long long* prof) {
 #if defined(HX_DP_PROF) && !defined(HX_DP_PROF2)
@@ -592,6 +610,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     const uint32_t* cons_out = wm_cons + wv;                                  // what the wave on the right has taken from this wave's mailbox
     if (has_in && in_lds && lane == 0) st_wg(cons_in, cl.tag0);               // everything of earlier DPs counts as taken (a wave may have sat out a short sequence)
     const uint32_t* farslot = reinterpret_cast<const uint32_t*>(g.pred);      // per rank: row of H that holds the far-read row (consensus scratch, free during the DP)
+    const uint32_t* wideslot = g.wslot;                                       // per rank: row of the wide-row pool (rows with more than 4 predecessors)
     const uint32_t j0 = gt * CM;
     const bool live = j0 <= L;                       // the chunk holds at least one real column: only such chunks touch HBM
     const bool owns_last = live && L < j0 + CM;
@@ -711,21 +730,27 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                     const mask_t x = bases ^ ((mask_t)(meta & 3u) * (mask_t)0x5555555555555555ull);
                     mis = x | (x >> 1) | nobase;
                 }
-                auto score_of = [&](int k) -> int {   // 64 x substitution score of column k (+63: the diagonal move type)
+                // Move codes (the low 6 bits of a key while a row is computed; they are masked off before the row is used as a predecessor, so the
+                // format is the row's own). A row with at most 4 predecessors uses 4 bits - type * 4 + 3 - predecessor slot - which are its
+                // traceback nibble as they are; a "wide" row (rare) uses type * 16 + 15 - slot and stores a byte per cell in a side pool.
+                const bool wide = !DIR || (meta & 32u);
+                const int kd = wide ? KD : 15, kv = wide ? KV : 11, kh = wide ? KH : 4;
+                const int md = m64 + kd, gv = g64 + kv, gh = g64 + kh;
+                auto score_of = [&](int k) -> int {   // 64 x substitution score of column k + the diagonal move code
                     int neg;   // -1 on a mismatch, 0 on a match
                     if constexpr (CM <= 16) neg = __builtin_amdgcn_sbfe((int)mis, 2 * k, 1);
                     else neg = 2 * k < 32 ? __builtin_amdgcn_sbfe((int)(uint32_t)mis, (2 * k) & 31, 1) : __builtin_amdgcn_sbfe((int)(uint32_t)(mis >> 32), (2 * k) & 31, 1);
-                    return (m64 + KD) + ((mm64 - m64) & neg);
+                    return md + ((mm64 - m64) & neg);
                 };
                 hrow += WH;
-                if (DIR) drow += W;
+                if (DIR) drow += W >> 1;
                 DP_T(0);   // row decode
                 int m[CM];
                 {   // the first predecessor (or row 0): diagonal and vertical move
                     int hp[CM], left;
                     pred_row(p0, hp, left);
 #pragma unroll
-                    for (int k = 0; k < CM; k++) m[k] = max((k == 0 ? left : hp[k - 1]) + score_of(k), hp[k] + (g64 + KV));
+                    for (int k = 0; k < CM; k++) m[k] = max((k == 0 ? left : hp[k - 1]) + score_of(k), hp[k] + gv);
                 }
                 if (npred > 1) {
                     // the maximum over the predecessors: the low bits carry the move type and 15 - p, so ONE running maximum does it all
@@ -739,12 +764,12 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                         int hp[CM], left;
                         pred_row(ent, hp, left);
 #pragma unroll
-                        for (int k = 0; k < CM; k++) m[k] = max(m[k], max((k == 0 ? left : hp[k - 1]) + score_of(k) - ps, hp[k] + (g64 + KV - ps)));
+                        for (int k = 0; k < CM; k++) m[k] = max(m[k], max((k == 0 ? left : hp[k - 1]) + score_of(k) - ps, hp[k] + (gv - ps)));
                     }
                 }
                 // chunk-local horizontal recurrence (type 1 loses every tie)
 #pragma unroll
-                for (int k = 1; k < CM; k++) m[k] = max(m[k], (m[k - 1] & ~63) + (g64 + KH));
+                for (int k = 1; k < CM; k++) m[k] = max(m[k], (m[k - 1] & ~63) + gh);
                 DP_T(1);   // predecessor rows + cells + horizontal chain
                 // prefix maximum over the lanes to the left of (chunk end score - its column * gap)
                 const int inc = wave_incl_max((m[CM - 1] & ~63) - (jg0 + (CM - 1) * g64));
@@ -760,7 +785,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 DP_T(3);   // carry in / out
                 const int base = ex + jg0;            // 64 x (score reaching column j0 through a horizontal move from the left neighbour)
 #pragma unroll
-                for (int k = 0; k < CM; k++) m[k] = max(m[k], base + (k * g64 + KH));
+                for (int k = 0; k < CM; k++) m[k] = max(m[k], base + k * g64 + kh);
                 int t[CM];
 #pragma unroll
                 for (int k = 0; k < CM; k++) t[k] = m[k] & ~63;
@@ -779,7 +804,8 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                         uint32_t dc[CM];
 #pragma unroll
                         for (int k = 0; k < CM; k++) dc[k] = (uint32_t)m[k];
-                        store_dirs<CM>(drow + j0, dc, 0x3f3f3f3fu);   // the move code of every cell: type * 16 + 15 - predecessor slot
+                        store_nibbles<CM>(drow + (j0 >> 1), dc);      // the move code of every cell: type * 4 + 3 - predecessor slot
+                        if (__builtin_expect((meta & 32u) != 0, 0)) store_dirs<CM>(Dwide + (uint64_t)wideslot[i - 1] * W + j0, dc, 0x3f3f3f3fu);   // wide row: type * 16 + 15 - slot
                     } else {
                         int pl[CM];
 #pragma unroll
@@ -846,13 +872,14 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         g.rank2node = P.rank2node + no; g.node2rank = P.node2rank + no; g.mark = P.mark + no; g.check = P.check + no;
         g.stack = P.stack + ED.stack_off; g.score = P.score + no; g.pred = P.pred + no;
         g.row_code = P.row_code + no; g.row_sink = P.row_sink + no; g.row_pred_off = P.row_pred_off + no; g.pred_rank = P.pred_rank + eo;
-        g.row_meta = P.row_meta + no; g.row_pred0 = P.row_pred0 + no; g.row_pred1 = P.row_pred1 + no; g.nrec = P.nrec + no; g.row_al = P.row_al + no;
+        g.row_meta = P.row_meta + no; g.row_pred0 = P.row_pred0 + no; g.row_pred1 = P.row_pred1 + no; g.nrec = P.nrec + no; g.row_al = P.row_al + no; g.wslot = P.wslot + no;
         g.e_from = P.e_from + eo; g.e_to = P.e_to + eo; g.e_next_in = P.e_next_in + eo; g.e_next_out = P.e_next_out + eo; g.e_w = P.e_w + eo;
         g.aln_node = P.aln_node + ED.aln_off; g.aln_pos = P.aln_pos + ED.aln_off;
         g.vcap = ED.vcap; g.ecap = ED.ecap;
     }
     int32_t* H = P.H + ED.h_off;
-    uint8_t* Dm = DIR ? P.dir + ED.d_off : nullptr;   // direction bytes: (vcap + 1) rows of W; with them H holds only ED.hrows far-read rows
+    uint8_t* Dm = DIR ? P.dir + ED.d_off : nullptr;   // direction nibbles: (vcap + 1) rows of W / 2 bytes; with them H holds only ED.hrows far-read rows
+    uint8_t* Dw = DIR ? P.dirw + ED.w_off : nullptr;  // direction bytes of the rows with more than 4 predecessors: ED.wrows rows of W
     // ring geometry is a property of the edge (its longest sequence) and of the launch
     const uint32_t GM = ED.members;                  // workgroups sharing this edge's DP columns
     const uint32_t ring_w = CM * (NT >> 6) * 65u;    // CM planes of 65 words per wave (dp_rows)
@@ -896,7 +923,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     constexpr uint32_t CL_ABORT = 0xffffffffu;
 #define HX_DP_DISPATCH(Lq, Vq, nsq) do { \
         if (((Lq) + 1 + GM * NT - 1) / (GM * NT) <= (uint32_t)CM)      /* the host puts an edge into a launch whose columns per lane hold its longest sequence */ \
-            dp_rows<CM, DIR>(g, H, Dm, W, WH, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, wmail.box, wmail.consumed, sink_row, sink_score, SINK_LDS, nsq, cl, ph + 6); \
+            dp_rows<CM, DIR>(g, H, Dm, Dw, W, WH, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, wmail.box, wmail.consumed, sink_row, sink_score, SINK_LDS, nsq, cl, ph + 6); \
         else sOk = 2; } while (0)
     // The reference's topological order (spoa's DFS, inherently serial) is needed in two places only: to break ties between equally scored
     // end nodes of an alignment, and for the heaviest-bundle traversal of the finished graph. The DP itself runs on a cheaper order that
@@ -1085,27 +1112,30 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                             na += j; j = 0;
                             break;
                         }
-                        // tile: 32 rows (ranks ti .. ti-31) x 16 columns (tj .. tj-15); lane = (row, half): 8 bytes of one row in two registers
-                        const uint32_t ti = i, tj = j, r0 = ln >> 1, c0 = (ln & 1u) * 8;
-                        uint32_t w0 = 0, w1 = 0, mt = 0, q0 = 0, q1 = 0, qo = 0;
+                        // tile: 32 rows (ranks ti .. ti-31) x 16 columns (ct-15 .. ct, ct = tj made odd: whole bytes of two nibbles); lane = (row, half):
+                        // the 4 bytes = 8 columns of one row in one register
+                        const uint32_t ti = i, ct = j | 1u, r0 = ln >> 1, hf = ln & 1u;
+                        const int32_t bs = ((int32_t)ct - 15) >> 1;   // first byte of the tile in its rows (ct < 15: negative - bytes before the row, never looked at)
+                        uint32_t w0 = 0, mt = 0, q0 = 0, q1 = 0, qo = 0, qw = 0;
                         if (ti > r0) {
-                            // two unaligned dword loads per lane: bytes of columns tj-c0-3 .. tj-c0 and tj-c0-7 .. tj-c0-4 (columns below 0 read the
-                            // end of the previous row — row 0 exists — and are never looked at); byte-swapped so that byte q = column tj-c0-q
-                            const uint8_t* rowp = Dm + (uint64_t)(ti - r0) * W + tj - c0;
-                            uint32_t a, b;
-                            __builtin_memcpy(&a, rowp - 3, 4);
-                            __builtin_memcpy(&b, rowp - 7, 4);
-                            w0 = __builtin_bswap32(a); w1 = __builtin_bswap32(b);
+                            // one unaligned dword load per lane (bytes bs + 4 hf .. + 3 of the row; columns below 0 read the end of the previous row - row 0 exists)
+                            const uint8_t* rowp = Dm + (uint64_t)(ti - r0) * (W >> 1) + bs + 4 * (int32_t)hf;
+                            __builtin_memcpy(&w0, rowp, 4);
                         }
-                        if (ln < 32 && ti > ln) { const uint32_t rr = ti - 1 - ln; mt = g.row_meta[rr]; q0 = g.row_pred0[rr]; q1 = g.row_pred1[rr]; qo = g.row_pred_off[rr]; }
+                        if (ln < 32 && ti > ln) { const uint32_t rr = ti - 1 - ln; mt = g.row_meta[rr]; q0 = g.row_pred0[rr]; q1 = g.row_pred1[rr]; qo = g.row_pred_off[rr]; if (mt & 32u) qw = g.wslot[rr]; }
                         for (;;) {
-                            const uint32_t dr = ti - i, dcq = tj - j, idx = dr * 2 + (dcq >> 3);
-                            const uint32_t wsel = (dcq & 4u) ? (uint32_t)__builtin_amdgcn_readlane((int)w1, (int)idx) : (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)idx);
-                            const uint32_t d = (wsel >> (8 * (dcq & 3u))) & 0x3fu;
-                            // move code: type (3 diagonal / 2 vertical / 1 horizontal) * 16 + 15 - predecessor slot. Selects instead of branches:
-                            // a taken scalar branch costs as much as seven ALU instructions here
-                            const uint32_t type = d >> 4, slot = 15u - (d & 15u);
-                            const uint32_t np = (uint32_t)__builtin_amdgcn_readlane((int)mt, (int)dr) >> 8;
+                            const uint32_t dr = ti - i, off = (uint32_t)((int32_t)(j >> 1) - bs);   // byte of column j inside the tile row: 0..7
+                            const uint32_t wsel = (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)(dr * 2 + (off >> 2)));
+                            const uint32_t n4 = (wsel >> (8 * (off & 3u) + 4 * (j & 1u))) & 15u;
+                            const uint32_t rmeta = (uint32_t)__builtin_amdgcn_readlane((int)mt, (int)dr);
+                            // move code: type (3 diagonal / 2 vertical / 1 horizontal) * 4 + 3 - predecessor slot; a row with more than 4 predecessors
+                            // keeps type * 16 + 15 - slot in the wide-row pool. Selects instead of branches where it is cheap.
+                            uint32_t type = n4 >> 2, slot = 3u - (n4 & 3u);
+                            if (__builtin_expect((rmeta & 32u) != 0, 0)) {
+                                const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)Dw[(uint64_t)__builtin_amdgcn_readlane((int)qw, (int)dr) * W + j]);
+                                type = d >> 4; slot = 15u - (d & 15u);
+                            }
+                            const uint32_t np = rmeta >> 8;
                             const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)q0, (int)dr), e1 = (uint32_t)__builtin_amdgcn_readlane((int)q1, (int)dr);
                             uint32_t ent = slot == 0 ? e0 : e1;
                             if (__builtin_expect(slot >= 2 && type != 1u, 0)) ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[(uint32_t)__builtin_amdgcn_readlane((int)qo, (int)dr) + slot]);
@@ -1119,7 +1149,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                             na++;
                             if ((na & 63u) == 0) flush(na);
                             i = pi_; j = pj_;
-                            if (i == 0 || ti - i >= 32 || tj - j >= 16) break;
+                            if (i == 0 || ti - i >= 32 || ct - j >= 16) break;
                         }
                     }
                     if (!tail && (na & 63u)) flush(na);   // (after a tail of horizontal moves everything has been written already)
@@ -1359,7 +1389,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                     if (np == 0) q0 = pr; else if (np == 1) q1 = pr;
                     np++;
                 }
-                g.row_meta[r] = cd | (sink << 2) | (np << 8);
+                g.row_meta[r] = cd | (sink << 2) | (np > 4u ? 32u : 0u) | (np << 8);
                 if (DIR && np > max_indeg) sOk = 4;   // the direction bytes hold a 4-bit predecessor slot (max_indeg <= 16)
                 g.row_pred0[r] = q0; g.row_pred1[r] = q1;
             }
@@ -1408,6 +1438,13 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                     uint32_t* farslot = reinterpret_cast<uint32_t*>(g.pred);
                     for (uint32_t r = r0; r < r1; r++) if (g.row_meta[r] & 8u) farslot[r] = fex++;
                     if (tid == 0 && ftot > ED.hrows && sOk == 1) sOk = 5;   // more far rows than the estimate: the host retries with a row per node
+                    // rows with more than 4 predecessors keep a direction byte per cell in the wide-row pool
+                    uint32_t wc = 0;
+                    for (uint32_t r = r0; r < r1; r++) wc += (g.row_meta[r] >> 5) & 1u;
+                    uint32_t wtot;
+                    uint32_t wex = block_excl_scan_add(wc, lds_u, &wtot);
+                    for (uint32_t r = r0; r < r1; r++) if (g.row_meta[r] & 32u) g.wslot[r] = wex++;
+                    if (tid == 0 && wtot > ED.wrows && sOk == 1) sOk = 7;   // more of them than the estimate: the host retries with more
                 }
 #ifndef HX_DP_PROF
                 if (phase) {   // statistics of the rows the next DP will run over
@@ -1441,6 +1478,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         else if (sOk == 4) { status[eidx] = HXE_POA_NODIR; cns_len[eidx] = 0; }
         else if (sOk == 5) { status[eidx] = HXE_POA_FARROWS; cns_len[eidx] = 0; }
         else if (sOk == 6) { status[eidx] = HXE_POA_SINKS; cns_len[eidx] = 0; }
+        else if (sOk == 7) { status[eidx] = HXE_POA_WIDEROWS; cns_len[eidx] = 0; }
         else {
             status[eidx] = 0; cns_len[eidx] = !sV ? 0 : sCtl != NONE ? sCtl : consensus(g, sV, cns + ED.cns_off); atomicAdd(cells, sCells);
 #ifndef HX_DP_PROF
