@@ -611,6 +611,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     while (!todo.empty()) {
         // ---- workspace sizes. Nodes of the finished graph: measured (nodes - L) / (L x sequences) on 13 %-error PacBio-like and 12 %-error
         // Nanopore-like reads is 0.05-0.06 (median), 0.07-0.08 (99th percentile, small edges). The estimate allows 0.09 plus a fifth of L
+        // (a tighter one - 0.07 plus a twelfth - sent 7 of 13 230 edges of the 140 Mb data into a second attempt, which cost more than the memory was worth)
         // and doubles when a graph outgrows it, up to the proven bound (every base a node of its own).
         for (uint32_t e : todo) {
             hxk::PoaEdge& E = P.edges[e];
