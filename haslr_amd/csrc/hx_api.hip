@@ -153,6 +153,16 @@ struct hx_ctx {
     hipStream_t poa_streams[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t poa_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     Timer tm;
+    // scratch of the chain / edge / coordinate operators lives as long as the context too (grows, never shrinks): no allocation, free or
+    // synchronisation for temporaries in a call once the sizes have been seen
+    hxk::Workspace ws;
+    struct {
+        DV<uint32_t> hit, qs, qe, ts, te, nm, nb, skf, skb, dp, cmp, naln, ncmp;
+        DV<uint64_t> cb, ce;
+        DV<int32_t> from;
+    } sc_chain;
+    struct { DV<uint32_t> npairs, perm, perm_tmp, flag; DV<uint64_t> pair_off, key_tmp, fscan; } sc_edges;
+    struct { DV<uint32_t> sel, nsupp, t_lr, t_sp, t_ep, best_list; DV<uint64_t> cap, out_off, b1, e1, b2, e2; DV<uint8_t> cur; } sc_coords;
     // POA workspace lives as long as the context: allocating tens of GB per call costs more than the kernel
     PoaPoolBufs poa_pools;
     uint64_t poa_budget = 0;
@@ -279,9 +289,12 @@ extern "C" int hx_chain_reads(hx_ctx* c, const hx_params* prm, hx_chain_out* out
     HIPCHK(hipMemsetAsync(c->err.p, 0, 4, s));
     const double thr_load = prm->uniq_freq * (3 + prm->max_uniq_dev), thr_uniq = prm->uniq_freq * (1 + prm->max_uniq_dev);
     // scratch at raw-hit granularity
-    DV<uint32_t> s_hit, s_qs, s_qe, s_ts, s_te, s_nm, s_nb, s_skf, s_skb, s_dp, s_cmp, s_naln, s_ncmp;
-    DV<uint64_t> s_cb, s_ce;
-    DV<int32_t> s_from;
+    auto& S = c->sc_chain;
+    DV<uint32_t>&s_hit = S.hit, &s_qs = S.qs, &s_qe = S.qe, &s_ts = S.ts, &s_te = S.te, &s_nm = S.nm, &s_nb = S.nb, &s_skf = S.skf, &s_skb = S.skb, &s_dp = S.dp, &s_cmp = S.cmp,
+                &s_naln = S.naln, &s_ncmp = S.ncmp;
+    DV<uint64_t>&s_cb = S.cb, &s_ce = S.ce;
+    DV<int32_t>& s_from = S.from;
+    c->ws.reset(s);
     HIPCHK(s_hit.reserve(nraw)); HIPCHK(s_qs.reserve(nraw)); HIPCHK(s_qe.reserve(nraw)); HIPCHK(s_ts.reserve(nraw)); HIPCHK(s_te.reserve(nraw));
     HIPCHK(s_nm.reserve(nraw)); HIPCHK(s_nb.reserve(nraw)); HIPCHK(s_skf.reserve(nraw)); HIPCHK(s_skb.reserve(nraw)); HIPCHK(s_dp.reserve(nraw));
     HIPCHK(s_cmp.reserve(nraw)); HIPCHK(s_cb.reserve(nraw)); HIPCHK(s_ce.reserve(nraw)); HIPCHK(s_from.reserve(nraw));
@@ -291,8 +304,8 @@ extern "C" int hx_chain_reads(hx_ctx* c, const hx_params* prm, hx_chain_out* out
     c->tick();
     hxk::contig_class(c->km.p, c->n_contigs, thr_load, thr_uniq, c->cls.p, s);
     hxk::chain_reads(c->hits_view(), c->rho.p, c->cls.p, c->n_contigs, c->lr_begin, c->lr_end, prm->min_aln_block, prm->min_aln_sim, prm->min_aln_mapq, sc, c->err.p, s);
-    hxk::exclusive_scan_u32(s_naln.p, c->aln_off.p, nr, s);
-    hxk::exclusive_scan_u32(s_ncmp.p, c->cmp_off.p, nr, s);
+    hxk::exclusive_scan_u32(s_naln.p, c->aln_off.p, nr, s, c->ws);
+    hxk::exclusive_scan_u32(s_ncmp.p, c->cmp_off.p, nr, s, c->ws);
     uint64_t tot[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(&tot[0], c->aln_off.p + nr, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&tot[1], c->cmp_off.p + nr, 8, hipMemcpyDeviceToHost, s));
@@ -329,12 +342,13 @@ extern "C" int hx_edge_emit(hx_ctx* c, const hx_params*, uint64_t* n_records) {
     HIPCHK(hipSetDevice(c->device));
     const uint32_t nr = c->lr_end - c->lr_begin;
     hipStream_t s = c->stream;
-    DV<uint32_t> npairs;
-    DV<uint64_t> pair_off;
+    DV<uint32_t>& npairs = c->sc_edges.npairs;
+    DV<uint64_t>& pair_off = c->sc_edges.pair_off;
+    c->ws.reset(s);
     HIPCHK(npairs.reserve(nr)); HIPCHK(pair_off.reserve((size_t)nr + 1));
     c->tick();
     hxk::edge_count(c->hits_view(), c->cls.p, c->chain_view(), c->cmp_off.p, c->lr_begin, c->lr_end, npairs.p, s);
-    hxk::exclusive_scan_u32(npairs.p, pair_off.p, nr, s);
+    hxk::exclusive_scan_u32(npairs.p, pair_off.p, nr, s, c->ws);
     uint64_t tot = 0;
     HIPCHK(hipMemcpyAsync(&tot, pair_off.p + nr, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -359,17 +373,18 @@ static int finish_edges(hx_ctx* c, uint64_t n, hx_edges_out* out) {
     if (n >= 0xffffffffULL) return fail("hx_edge_support: more than 2^32-1 edge-support records");
     int bits = 1;
     while (bits < 32 && (1ull << bits) < 2ull * std::max<uint32_t>(1, c->n_contigs)) bits++;
-    DV<uint32_t> perm, perm_tmp, flag;
-    DV<uint64_t> key_tmp, fscan;
+    DV<uint32_t>&perm = c->sc_edges.perm, &perm_tmp = c->sc_edges.perm_tmp, &flag = c->sc_edges.flag;
+    DV<uint64_t>&key_tmp = c->sc_edges.key_tmp, &fscan = c->sc_edges.fscan;
+    c->ws.reset(s);
     HIPCHK(perm.reserve(n)); HIPCHK(perm_tmp.reserve(n)); HIPCHK(flag.reserve(n)); HIPCHK(key_tmp.reserve(n)); HIPCHK(fscan.reserve(n + 1));
     HIPCHK(c->rec.reserve(n));
     c->tick();
     hxk::iota_u32(perm.p, n, s);
-    hxk::radix_sort_pairs(c->rec_un.key.p, perm.p, key_tmp.p, perm_tmp.p, n, bits, bits, s);
+    hxk::radix_sort_pairs(c->rec_un.key.p, perm.p, key_tmp.p, perm_tmp.p, n, bits, bits, s, c->ws);
     if (n) HIPCHK(hipMemcpyAsync(c->rec.key.p, c->rec_un.key.p, n * 8, hipMemcpyDeviceToDevice, s));
     hxk::edge_gather(c->rec_un.view(), perm.p, n, c->rec.view(), s);
     hxk::segment_flags(c->rec.key.p, n, flag.p, s);
-    hxk::exclusive_scan_u32(flag.p, fscan.p, n, s);
+    hxk::exclusive_scan_u32(flag.p, fscan.p, n, s, c->ws);
     uint64_t ne = 0;
     HIPCHK(hipMemcpyAsync(&ne, fscan.p + n, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -441,9 +456,11 @@ extern "C" int hx_edge_coords(hx_ctx* c, uint32_t n_sel, const uint32_t* sel, hx
         cap_off[i + 1] = cap_off[i] + (hairpin ? 2 * n : n);
     }
     const uint64_t cap = cap_off[n_sel];
-    DV<uint32_t> d_sel, d_nsupp, t_lr, t_sp, t_ep, best_list;
-    DV<uint64_t> d_cap, d_out_off, b1, e1, b2, e2;
-    DV<uint8_t> cur;
+    auto& K = c->sc_coords;
+    DV<uint32_t>&d_sel = K.sel, &d_nsupp = K.nsupp, &t_lr = K.t_lr, &t_sp = K.t_sp, &t_ep = K.t_ep, &best_list = K.best_list;
+    DV<uint64_t>&d_cap = K.cap, &d_out_off = K.out_off, &b1 = K.b1, &e1 = K.e1, &b2 = K.b2, &e2 = K.e2;
+    DV<uint8_t>& cur = K.cur;
+    c->ws.reset(s);
     HIPCHK(d_sel.reserve(n_sel)); HIPCHK(d_nsupp.reserve(n_sel)); HIPCHK(t_lr.reserve(cap)); HIPCHK(t_sp.reserve(cap)); HIPCHK(t_ep.reserve(cap));
     HIPCHK(best_list.reserve(cap)); HIPCHK(d_cap.reserve((size_t)n_sel + 1)); HIPCHK(d_out_off.reserve((size_t)n_sel + 1));
     HIPCHK(b1.reserve(cap)); HIPCHK(e1.reserve(cap)); HIPCHK(b2.reserve(cap)); HIPCHK(e2.reserve(cap)); HIPCHK(cur.reserve(cap));
@@ -454,7 +471,7 @@ extern "C" int hx_edge_coords(hx_ctx* c, uint32_t n_sel, const uint32_t* sel, hx
     c->tick();
     hxk::edge_coords(c->rec.view(), c->edge_key.p, c->edge_off.p, c->cg_ops.p, c->clen.p, c->rlen.p, n_sel, d_sel.p, d_cap.p, sc,
                      c->k_head_end.p, c->k_tail_beg.p, d_nsupp.p, t_lr.p, t_sp.p, t_ep.p, s);
-    hxk::exclusive_scan_u32(d_nsupp.p, d_out_off.p, n_sel, s);
+    hxk::exclusive_scan_u32(d_nsupp.p, d_out_off.p, n_sel, s, c->ws);
     uint64_t tot = 0;
     HIPCHK(hipMemcpyAsync(&tot, d_out_off.p + n_sel, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -556,7 +573,9 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     std::vector<uint8_t> force_nodir(ne, 0);   // edges whose in-degrees outgrew the direction bytes
     std::vector<uint8_t> full_h(ne, 0);        // edges that run with the score-matrix traceback
     std::vector<uint8_t> wide_grow(ne, 0);     // times an edge had more rows with over 4 predecessors than its wide-row pool: the estimate quadruples each time
+    std::vector<uint8_t> no_share(ne, 0);      // edges whose members did not get through together: one workgroup from now on
     std::vector<uint8_t> many_sinks(ne, 0);    // edges with more sink rows than the smaller kernels keep in LDS: one 1024-lane workgroup
+    const uint32_t poll_limit = getenv("HX_POA_POLL_LIMIT") ? (uint32_t)atol(getenv("HX_POA_POLL_LIMIT")) : 1u << 24;   // (testing: forces the unshared retry)
     const uint32_t max_indeg = getenv("HX_POA_MAX_INDEG") ? std::min<uint32_t>(16, (uint32_t)atoi(getenv("HX_POA_MAX_INDEG"))) : 16;   // (testing: forces the score-matrix retry earlier)
     const uint32_t cl_lanes = getenv("HX_POA_MEMBER_LANES") ? (uint32_t)atoi(getenv("HX_POA_MEMBER_LANES")) : 256;   // lanes per cluster member
     const uint32_t cl_min = getenv("HX_POA_CLUSTER_MIN") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MIN")) : 2048;       // columns above which an edge is shared
@@ -598,6 +617,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
         row_bytes = (uint64_t)cm * (nt / 64) * 65 * 4;   // planes of 65 words per wave
         uint64_t lds_budget = nt >= 1024 ? 128 * 1024 : nt == 64 ? 32 * 1024 : 64 * 1024 * (nt / 128 > 2 ? 2 : 1);
         if (ring_kb_wave) lds_budget = std::min<uint64_t>(lds_budget, std::max<uint64_t>(ring_kb_wave * 1024 * (nt / 64), 3 * row_bytes) * 8 / 9);
+        if (3 * row_bytes > lds_budget * 9 / 8) lds_budget = kPoaLdsMax * 8 / 9;   // wide rows: whatever the CU has, for at least two kept rows beside the latest
         const uint64_t rows_fit = std::min<uint64_t>(lds_budget * 9 / 8, kPoaLdsMax) / row_bytes;   // ring slots (+ 1 scratch slot when there is room)
         const uint32_t R = rows_fit >= 9 ? 8 : rows_fit >= 5 ? 4 : rows_fit >= 3 ? 2 : 0;   // kept rows: a power of two (slot = kept-row counter & (R-1)); 0 = only the latest row
         row_bytes *= R + 1;                                             // -> LDS bytes of the ring: one more slot for the latest row nobody keeps
@@ -628,7 +648,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             // long gaps: the DP columns of the edge are shared by several workgroups (one CU each), ~8 columns per lane
             E.members = 1;
             const uint32_t ncol = E.lmax + 1;
-            if (!c->poa_block && !c->poa_no_dir && !force_nodir[e] && !many_sinks[e] && ncol > cl_min) E.members = (uint32_t)std::min<uint64_t>(cl_max, (ncol + (uint64_t)cl_lanes * cl_cols - 1) / ((uint64_t)cl_lanes * cl_cols));
+            if (!c->poa_block && !c->poa_no_dir && !force_nodir[e] && !many_sinks[e] && !no_share[e] && ncol > cl_min) E.members = (uint32_t)std::min<uint64_t>(cl_max, (ncol + (uint64_t)cl_lanes * cl_cols - 1) / ((uint64_t)cl_lanes * cl_cols));
             if (E.members < 2 || ((uint64_t)ncol + (uint64_t)E.members * cl_lanes - 1) / ((uint64_t)E.members * cl_lanes) > 32) E.members = 1;   // (members too small for this gap: one workgroup)
         }
         // Sharing an edge among several CUs buys latency for the edge and costs throughput (the other members idle while member 0 walks
@@ -641,7 +661,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                     const uint64_t ca = edge_cost(a), cb = edge_cost(b);
                     return ca != cb ? ca > cb : a < b;
                 });
-                for (size_t q = cl_topk; q < sh.size(); q++) P.edges[sh[q]].members = 1;
+                for (size_t q = cl_topk; q < sh.size(); q++) if (P.edges[sh[q]].lmax + 1 <= 8192) P.edges[sh[q]].members = 1;   // (longer gaps than a 1024-lane workgroup holds with its ring stay shared)
             }
         }
         // rows of H (see full_h above): how many rows leave the LDS ring before their last reader depends on how many the ring holds
@@ -743,7 +763,9 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             };
             for (uint32_t e : batch) {
                 const uint32_t ncol = P.edges[e].lmax + 1;
-                if (ncol > 65536) return fail("hx_poa_batch: gap sub-sequence longer than 65535 bases is not supported by the POA kernel");
+                if (ncol > (uint64_t)cl_max * cl_lanes * hxk::poa_kernel_max_cm((int)cl_lanes) || ncol >= (1u << 20))
+                    return fail("hx_poa_batch: a gap sub-sequence of " + std::to_string(ncol - 1) + " bases is longer than the POA kernel's shared mode holds (" +
+                                std::to_string((uint64_t)cl_max * cl_lanes * hxk::poa_kernel_max_cm((int)cl_lanes) - 1) + " with HX_POA_CLUSTER_MAX x HX_POA_MEMBER_LANES x 32 columns per lane)");
                 if (P.edges[e].members > 1) {
                     const uint32_t cmr = cm_round(ncol, P.edges[e].members * cl_lanes);
                     if (cmr > (uint32_t)hxk::poa_kernel_max_cm((int)cl_lanes)) return fail("hx_poa_batch: gap too long for the configured cluster size (raise HX_POA_CLUSTER_MAX)");
@@ -807,7 +829,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                 c->dbg_ring[dcls + (q.dir ? 0 : 5)] = R;
                 HIPCHK(hipStreamWaitEvent(c->poa_streams[sk], c->poa_ev[6], 0));
                 hxk::poa_run(d_edges.p, d_order.p + opos, (uint32_t)q.blocks, d_seqs.p, in.d_packed, in.d_roff, in.d_rlen, pools, pp->match, pp->mismatch,
-                             pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)q.nt, (int)q.cm, R, (uint32_t)lds_bytes, q.dir, max_indeg, c->poa_streams[sk]);
+                             pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)q.nt, (int)q.cm, poll_limit, (uint32_t)lds_bytes, q.dir, max_indeg, c->poa_streams[sk]);
                 HIPCHK(hipEventRecord(c->poa_ev[sk], c->poa_streams[sk]));
                 HIPCHK(hipStreamWaitEvent(s, c->poa_ev[sk], 0));
                 opos += q.blocks;
@@ -832,6 +854,10 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             }
             for (uint32_t e : batch) {
                 if (h_status[e] & HXE_POA_FARROWS) { if (P.edges[e].hrows >= P.edges[e].vcap + 1) return fail("hx_poa_batch: internal error (far-row retry)"); far_full[e]++; retry_same.push_back(e); continue; }
+                if (h_status[e] & HXE_POA_STALLED) {
+                    if (P.edges[e].members < 2) return fail("hx_poa_batch: internal error (a wave of an unshared edge gave up waiting)");
+                    no_share[e] = 1; retry_same.push_back(e); continue;
+                }
                 if (h_status[e] & HXE_POA_WIDEROWS) { if (P.edges[e].wrows >= P.edges[e].vcap + 1) return fail("hx_poa_batch: internal error (wide-row retry)"); wide_grow[e]++; retry_same.push_back(e); continue; }
                 if (h_status[e] & HXE_POA_SINKS) { if (many_sinks[e]) return fail("hx_poa_batch: internal error (sink-list retry)"); many_sinks[e] = 1; retry_same.push_back(e); continue; }
                 if (h_status[e] & HXE_POA_NODIR) { if (force_nodir[e]) return fail("hx_poa_batch: internal error (direction-byte retry)"); force_nodir[e] = 1; retry_same.push_back(e); continue; }

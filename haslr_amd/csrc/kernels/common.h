@@ -18,6 +18,7 @@ enum {
     HXE_POA_NODIR = 32,       // a POA node gained more than 16 in-edges: the 4-bit predecessor slot of the direction bytes is too small (host retries with the score-matrix traceback)
     HXE_POA_SINKS = 128,      // more sink rows than a one-wavefront launch keeps in LDS (host retries the edge with a multi-wave workgroup, which keeps 1024)
     HXE_POA_WIDEROWS = 256,   // more rows with over 4 predecessors than the wide-row pool has rows for (host retries this edge with more)
+    HXE_POA_STALLED = 512,    // a wave of a shared edge gave up waiting for another workgroup's carry (host retries the edge with one workgroup)
     HXE_POA_FARROWS = 64,     // more rows left the LDS ring and were read back than H has rows for (host retries this edge with a row of H for every node)
 };
 

@@ -3,16 +3,29 @@
 // or are allocated internally where noted.
 #ifndef HX_KERNELS_H
 #define HX_KERNELS_H
+#include <vector>
+
 #include "common.h"
 
 namespace hxk {
 
 // ---- primitives.hip
+// Scratch of the launchers: bump allocation from device blocks that live as long as their owner (the context), so that no operator
+// allocates, frees or synchronises for its temporaries. Everything is handed out in stream order on ONE stream; reset() declares all of it
+// free again for the work enqueued afterwards.
+struct Workspace {
+    struct Block { char* p; size_t cap, used; };
+    std::vector<Block> blocks;
+    void* take(size_t bytes);       // 256-byte aligned; nullptr when the device is out of memory
+    void reset(hipStream_t s);      // (several blocks are merged into one of their total size, after the stream has drained)
+    void release();
+    ~Workspace() { release(); }
+};
 // out[i] = sum(in[0..i)), out[n] = total.  (n+1 outputs)
-void exclusive_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, hipStream_t s);
+void exclusive_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, hipStream_t s, Workspace& ws);
 // stable LSD radix sort of (key, val) pairs on bits [0,bits_lo) and [32,32+bits_hi) of the key
 void radix_sort_pairs(uint64_t* key, uint32_t* val, uint64_t* key_tmp, uint32_t* val_tmp, uint64_t n,
-                      int bits_lo, int bits_hi, hipStream_t s);
+                      int bits_lo, int bits_hi, hipStream_t s, Workspace& ws);
 
 // ---- chain.hip (K0-K3)
 struct ChainScratch {   // all sized by the number of raw hits in the shard (+1)
@@ -120,7 +133,7 @@ void poa_run(const PoaEdge* edges, const uint32_t* order /* edge | member << 24,
              int32_t match, int32_t mismatch, int32_t gap, char* cns, uint32_t* cns_len, uint32_t* status,
              unsigned long long* cells, unsigned long long* phase_cycles /* 12 per edge or null */, int block_threads /* multiple of 64, <= 1024 */,
              int cm /* columns per lane of the launch: 4, 8, 16 or 32; every edge's longest sequence fits members x block_threads x cm columns */,
-             uint32_t ring_rows, uint32_t ring_bytes /* dynamic LDS */,
+             uint32_t poll_limit /* polls before a wave gives up waiting for another (-> HXE_POA_STALLED) */, uint32_t ring_bytes /* dynamic LDS */,
              bool use_dir /* direction-byte traceback (in-degrees <= max_indeg <= 16, else the edge comes back with HXE_POA_NODIR) */, uint32_t max_indeg, hipStream_t s);
 
 }  // namespace hxk

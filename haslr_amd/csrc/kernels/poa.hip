@@ -488,6 +488,7 @@ constexpr int KD = 63, KV = 47, KH = 16;   // low 6 bits of a key = move type * 
 constexpr uint32_t CARRY_BATCH = 32;       // rows whose carries a wave takes at a time (= how far it runs behind its left neighbour)
 constexpr uint32_t WAVE_MBOX = 64;         // entries of the LDS mailbox between two waves of a workgroup (a power of two >= 2 * CARRY_BATCH)
 constexpr uint32_t MAX_WAVES = 16;         // waves per workgroup at most
+constexpr uint32_t WG_POLL_LIMIT = 1u << 24;   // polls of a wave for another wave of its own workgroup (resident by construction) before it flags an internal error
 
 template <int NWAVES> struct WaveMailT {   // LDS
     unsigned long long box[(NWAVES > 1 ? NWAVES - 1 : 1) * WAVE_MBOX];   // boundary b (between waves b and b + 1): entry of row i at [b][i % WAVE_MBOX] = {tag, carry}
@@ -504,8 +505,8 @@ struct DpCl {
     uint32_t tag0;                    // tag of row i = tag0 + i (rows of all DPs of the edge numbered consecutively)
     unsigned long long* mbox;         // edge base
     uint32_t* err;                    // device-visible error word of the edge (set when a poll gives up)
+    uint32_t poll_limit;              // polls before a waiter gives up and flags the edge instead of hanging the GPU (the host then redoes it unshared)
 };
-constexpr uint32_t POLL_LIMIT = 1u << 24;   // polls before a waiter gives up and flags an error instead of hanging the GPU
 __device__ __forceinline__ uint32_t ld_dev(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_dev(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long ld_dev64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -706,7 +707,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                         ok = (uint32_t)v == cl.tag0 + i0 + lane;
                     }
                     if (__ballot(ok) == ~0ull) { cinV = (int)(uint32_t)(v >> 32); break; }
-                    if (spin > POLL_LIMIT) { if (lane == 0) st_dev(cl.err, 1u); break; }
+                    if (spin > (in_lds ? WG_POLL_LIMIT : cl.poll_limit)) { if (lane == 0) st_dev(cl.err, in_lds ? 2u : 1u); break; }
                     if (in_lds) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(8);
                 }
                 if (in_lds && lane == 0) st_wg(cons_in, cl.tag0 + i0 + nb - 1);   // the entries of these rows may be written again
@@ -716,7 +717,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 for (uint32_t spin = 0; need; spin++) {
                     const uint32_t got = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_wg(cons_out));
                     if ((int32_t)(got - need) >= 0) break;
-                    if (spin > POLL_LIMIT) { if (lane == 0) st_dev(cl.err, 1u); break; }
+                    if (spin > WG_POLL_LIMIT) { if (lane == 0) st_dev(cl.err, 2u); break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
             }
@@ -846,7 +847,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                                             const PoaSeq* __restrict__ seqs, const uint8_t* __restrict__ packed, const uint64_t* __restrict__ read_off,
                                             const uint32_t* __restrict__ read_len, PoaPools P, int32_t match, int32_t mismatch, int32_t gap,
                                             char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells, unsigned long long* phase,
-                                            uint32_t ring_rows, uint32_t lds_bytes, uint32_t max_indeg) {
+                                            uint32_t poll_limit, uint32_t lds_bytes, uint32_t max_indeg) {
     const uint32_t eidx = order[blockIdx.x] & 0x00ffffffu, mem = order[blockIdx.x] >> 24;   // edge, member of its cluster (0 unless the edge is shared)
     if (eidx == 0x00ffffffu) return;                  // hole in the XCD-aligned cluster grid
     __shared__ unsigned long long ph[12];            // lane-0 cycle counts: decode, dp, traceback, graph update, toposort, csr; then row statistics
@@ -893,7 +894,6 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         R = fit >= 9 ? 8 : fit >= 5 ? 4 : fit >= 3 ? 2 : 0;   // (0: rows too wide for more than the latest one - every kept row is read back from HBM)
         if (fit < 1) R = 0xffffffffu;
     }
-    (void)ring_rows;
     uint8_t* seq = P.seq + ED.seq_off;
     const uint32_t W = (ED.lmax + 1 + 31) & ~31u;   // row stride: a multiple of the widest lane chunk (32 columns), so chunks are vector-aligned and stay inside their row
     const uint32_t WH = W + (GM * (NT >> 6) > 1 ? (GM * (NT >> 6) + 3u) & ~3u : 0u);   // rows of H end with one word per wave of the edge's pipeline (dp_rows)
@@ -919,7 +919,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     int32_t* sinkbuf = P.sinkbuf + (uint64_t)eidx * (1 + 2 * SINK_CAP);
     DpCl cl;
     cl.mem = mem; cl.members = GM; cl.stride = ED.vcap + 1; cl.tag0 = 0;
-    cl.mbox = P.mbox + ED.cl_off; cl.err = csy + 4;
+    cl.mbox = P.mbox + ED.cl_off; cl.err = csy + 4; cl.poll_limit = poll_limit;
     constexpr uint32_t CL_ABORT = 0xffffffffu;
 #define HX_DP_DISPATCH(Lq, Vq, nsq) do { \
         if (((Lq) + 1 + GM * NT - 1) / (GM * NT) <= (uint32_t)CM)      /* the host puts an edge into a launch whose columns per lane hold its longest sequence */ \
@@ -989,7 +989,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                 for (uint32_t spin = 0;; spin++) {
                     v = ld_dev(csy + 0);
                     if (v == CL_ABORT || v >= k - ED.seq_begin + 1) break;
-                    if (spin > POLL_LIMIT) { st_dev(csy + 4, 1u); v = CL_ABORT; break; }
+                    if (spin > poll_limit) { st_dev(csy + 4, 1u); v = CL_ABORT; break; }
                     __builtin_amdgcn_s_sleep(32);
                 }
                 sCtl = v;
@@ -1028,7 +1028,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                         const uint32_t need = (GM - 1) * (k - ED.seq_begin + 1);
                         for (uint32_t spin = 0;; spin++) {
                             if (ld_dev(csy + 1) >= need) break;
-                            if (spin > POLL_LIMIT) { st_dev(csy + 4, 1u); break; }
+                            if (spin > poll_limit) { st_dev(csy + 4, 1u); break; }
                             __builtin_amdgcn_s_sleep(32);
                         }
                     }
@@ -1039,10 +1039,13 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                         for (uint32_t q = tid; q < nsk; q += NT) { sink_row[q] = (uint32_t)sinkbuf[1 + q]; sink_score[q] = sinkbuf[1 + SINK_CAP + q]; }
                         if (tid == 0) sNsink = nsk_all;
                     }
-                    if (tid == 0 && ld_dev(csy + 4)) sOk = 2;
                 }
             }
             __syncthreads();
+            if (tid == 0 && ld_dev(csy + 4) && sOk == 1) sOk = ld_dev(csy + 4) == 2u ? 2 : 8;   // a wave gave up waiting for a carry (never seen within one workgroup; between workgroups
+                                                                    // when the members of an edge are not resident together): the host redoes the edge unshared
+            __syncthreads();
+            if (sOk != 1) break;                                    // (the matrix of this sequence is not to be walked)
             SUBT(8);   // wait for the other members, sinks
             // ---- end node of the global alignment: the best-scoring sink; ties go to the smallest rank in the REFERENCE's order
             if (tid == 0) {
@@ -1197,7 +1200,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                     const uint32_t need = (GM - 1) * (k - ED.seq_begin + 1);
                     for (uint32_t spin = 0;; spin++) {
                         if (ld_dev(csy + 1) >= need) break;
-                        if (spin > POLL_LIMIT) { st_dev(csy + 4, 1u); break; }
+                        if (spin > poll_limit) { st_dev(csy + 4, 1u); break; }
                         __builtin_amdgcn_s_sleep(32);
                     }
                 }
@@ -1479,6 +1482,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
         else if (sOk == 5) { status[eidx] = HXE_POA_FARROWS; cns_len[eidx] = 0; }
         else if (sOk == 6) { status[eidx] = HXE_POA_SINKS; cns_len[eidx] = 0; }
         else if (sOk == 7) { status[eidx] = HXE_POA_WIDEROWS; cns_len[eidx] = 0; }
+        else if (sOk == 8) { status[eidx] = HXE_POA_STALLED; cns_len[eidx] = 0; }
         else {
             status[eidx] = 0; cns_len[eidx] = !sV ? 0 : sCtl != NONE ? sCtl : consensus(g, sV, cns + ED.cns_off); atomicAdd(cells, sCells);
 #ifndef HX_DP_PROF
@@ -1494,13 +1498,13 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
 
 void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_edges, const PoaSeq* seqs, const uint8_t* packed, const uint64_t* read_off,
              const uint32_t* read_len, PoaPools pools, int32_t match, int32_t mismatch, int32_t gap, char* cns, uint32_t* cns_len,
-             uint32_t* status, unsigned long long* cells, unsigned long long* phase, int block_threads, int cm, uint32_t ring_rows, uint32_t ring_bytes,
+             uint32_t* status, unsigned long long* cells, unsigned long long* phase, int block_threads, int cm, uint32_t poll_limit, uint32_t ring_bytes,
              bool use_dir, uint32_t max_indeg, hipStream_t s) {
     if (!n_edges) return;
 #define HX_LAUNCH(MNT, CMV, DIRV) do { \
         (void)hipFuncSetAttribute((const void*)k_poa<MNT, CMV, DIRV>, hipFuncAttributeMaxDynamicSharedMemorySize, 142 * 1024); \
         k_poa<MNT, CMV, DIRV><<<n_edges, block_threads, ring_bytes, s>>>(edges, order, n_edges, seqs, packed, read_off, read_len, pools, match, mismatch, gap, \
-                                                                       cns, cns_len, status, cells, phase, ring_rows, ring_bytes, max_indeg); } while (0)
+                                                                       cns, cns_len, status, cells, phase, poll_limit, ring_bytes, max_indeg); } while (0)
 #define HX_LAUNCH_CM(MNT, CMV) do { if (use_dir) HX_LAUNCH(MNT, CMV, true); else HX_LAUNCH(MNT, CMV, false); } while (0)
     // the instances the host's launch classes use (poa_kernel_lanes): workgroups up to 64 / 256 / 512 / 1024 lanes x 4, 8, 16 or 32 columns per lane
     const int mnt = poa_kernel_lanes(block_threads);

@@ -1,5 +1,7 @@
 // primitives.hip — device-wide exclusive scan and a stable LSD radix sort, hand-written for wave64.
 // (rocPRIM/hipCUB are deliberately not used on the product path.)
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace hxk {
@@ -60,26 +62,52 @@ __global__ void scan_apply(const TIN* in, uint64_t n, const uint64_t* block_pref
 }
 
 template <typename TIN>
-void scan_impl(const TIN* in, uint64_t* out, uint64_t n, hipStream_t s) {
+void scan_impl(const TIN* in, uint64_t* out, uint64_t n, hipStream_t s, Workspace& ws) {
     if (n == 0) { hipMemsetAsync(out, 0, sizeof(uint64_t), s); return; }
     uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nb == 1) {
         scan_apply<TIN><<<1, SCAN_T, 0, s>>>(in, n, nullptr, out);
         return;
     }
-    uint64_t *sums, *prefix;
-    hipMalloc(&sums, nb * sizeof(uint64_t));
-    hipMalloc(&prefix, (nb + 1) * sizeof(uint64_t));
+    uint64_t* sums = (uint64_t*)ws.take(nb * sizeof(uint64_t));
+    uint64_t* prefix = (uint64_t*)ws.take((nb + 1) * sizeof(uint64_t));
+    if (!sums || !prefix) return;   // (out of device memory: the caller's next HIP call reports it)
     scan_block_sums<TIN><<<(unsigned)nb, SCAN_T, 0, s>>>(in, n, sums);
-    scan_impl<uint64_t>(sums, prefix, nb, s);
+    scan_impl<uint64_t>(sums, prefix, nb, s, ws);
     scan_apply<TIN><<<(unsigned)nb, SCAN_T, 0, s>>>(in, n, prefix, out);
-    hipStreamSynchronize(s);
-    hipFree(sums);
-    hipFree(prefix);
 }
 }  // namespace
 
-void exclusive_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, hipStream_t s) { scan_impl<uint32_t>(in, out, n, s); }
+void exclusive_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, hipStream_t s, Workspace& ws) { scan_impl<uint32_t>(in, out, n, s, ws); }
+
+void* Workspace::take(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (!blocks.empty() && blocks.back().cap - blocks.back().used >= bytes) {
+        void* r = blocks.back().p + blocks.back().used;
+        blocks.back().used += bytes;
+        return r;
+    }
+    size_t cap = std::max<size_t>(bytes, blocks.empty() ? (size_t)1 << 20 : blocks.back().cap * 2);
+    char* p = nullptr;
+    if (hipMalloc((void**)&p, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    blocks.push_back(Block{p, cap, bytes});
+    return p;
+}
+void Workspace::reset(hipStream_t s) {
+    if (blocks.size() > 1) {   // grew during the last use: one block of the total size from now on
+        size_t total = 0;
+        for (const Block& b : blocks) total += b.cap;
+        (void)hipStreamSynchronize(s);
+        release();
+        char* p = nullptr;
+        if (hipMalloc((void**)&p, total) == hipSuccess) blocks.push_back(Block{p, total, 0}); else (void)hipGetLastError();
+    }
+    for (Block& b : blocks) b.used = 0;
+}
+void Workspace::release() {
+    for (Block& b : blocks) (void)hipFree(b.p);
+    blocks.clear();
+}
 
 // ------------------------------------------------------------------------------------------------
 // Stable LSD radix sort, 8 bits per pass. Each block owns a tile of RS_TILE consecutive elements.
@@ -149,13 +177,12 @@ __global__ void rs_scatter(const uint64_t* key, const uint32_t* val, uint64_t n,
 }
 }  // namespace
 
-void radix_sort_pairs(uint64_t* key, uint32_t* val, uint64_t* key_tmp, uint32_t* val_tmp, uint64_t n, int bits_lo, int bits_hi, hipStream_t s) {
+void radix_sort_pairs(uint64_t* key, uint32_t* val, uint64_t* key_tmp, uint32_t* val_tmp, uint64_t n, int bits_lo, int bits_hi, hipStream_t s, Workspace& ws) {
     if (n == 0) return;
     uint32_t nblocks = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
-    uint32_t* hist;
-    uint64_t* base;
-    hipMalloc(&hist, (uint64_t)256 * nblocks * sizeof(uint32_t));
-    hipMalloc(&base, ((uint64_t)256 * nblocks + 1) * sizeof(uint64_t));
+    uint32_t* hist = (uint32_t*)ws.take((uint64_t)256 * nblocks * sizeof(uint32_t));
+    uint64_t* base = (uint64_t*)ws.take(((uint64_t)256 * nblocks + 1) * sizeof(uint64_t));
+    if (!hist || !base) return;
     uint64_t *ki = key, *ko = key_tmp;
     uint32_t *vi = val, *vo = val_tmp;
     int shifts[16], ns = 0;
@@ -163,7 +190,7 @@ void radix_sort_pairs(uint64_t* key, uint32_t* val, uint64_t* key_tmp, uint32_t*
     for (int b = 0; b < bits_hi; b += 8) shifts[ns++] = 32 + b;
     for (int p = 0; p < ns; p++) {
         rs_hist<<<nblocks, RS_T, 0, s>>>(ki, n, shifts[p], hist, nblocks);
-        exclusive_scan_u32(hist, base, (uint64_t)256 * nblocks, s);
+        exclusive_scan_u32(hist, base, (uint64_t)256 * nblocks, s, ws);
         rs_scatter<<<nblocks, RS_T, 0, s>>>(ki, vi, n, shifts[p], base, nblocks, ko, vo);
         uint64_t* tk = ki; ki = ko; ko = tk;
         uint32_t* tv = vi; vi = vo; vo = tv;
@@ -172,9 +199,6 @@ void radix_sort_pairs(uint64_t* key, uint32_t* val, uint64_t* key_tmp, uint32_t*
         hipMemcpyAsync(key, ki, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
         hipMemcpyAsync(val, vi, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
     }
-    hipStreamSynchronize(s);
-    hipFree(hist);
-    hipFree(base);
 }
 
 }  // namespace hxk

@@ -582,3 +582,41 @@ def test_poa_known_answers_through_hip(ctx):
     want = [orclib.poa_consensus(st) for st in sets]
     assert got == want
     assert got[0] == s and got[2] == "" and got[6] == a and got[8] == sub and got[10] == dele and got[12] == ins
+
+
+def test_shared_edge_that_stalls_is_redone_unshared(sim, ctx):
+    """a wave of a shared edge that gives up waiting for another workgroup's carry (forced here: HX_POA_POLL_LIMIT=0 makes every first poll a
+    time-out) flags its edge; the host redoes exactly those edges with one workgroup each and the call succeeds with the oracle's consensus"""
+    pre = sim("--genome-len", "150000", "--seed", "31", "--variant-per-mb", "15")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    knobs = {"HX_POA_CLUSTER_MIN": "300", "HX_POA_MEMBER_LANES": "64", "HX_POA_CLUSTER_COLS": "4", "HX_POA_CLUSTER_MAX": "8", "HX_POA_POLL_LIMIT": "0"}
+    old = {k: os.environ.get(k) for k in knobs}
+    try:
+        os.environ.update(knobs)
+        ro, rg, ob = both(ds, ctx, None, None)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert ro.cns_out() == rg.cns_out() and ro.assembly_fasta() == rg.assembly_fasta()
+
+
+def test_gap_longer_than_65535_columns(ctx):
+    """a 70 000-base gap (shared by 16 workgroups, 32 columns per lane): three copies of one random sequence, two of them with sparse private
+    substitutions - the consensus is the sequence itself (majority in every column)"""
+    import random
+    rnd = random.Random(70)
+    L = 70000
+    a = [rnd.choice("ACGT") for _ in range(L)]
+    b, c = list(a), list(a)
+    for k in range(0, L, 997):
+        b[k] = "ACGT"[("ACGT".index(a[k]) + 1) % 4]
+    for k in range(500, L, 1009):
+        c[k] = "ACGT"[("ACGT".index(a[k]) + 2) % 4]
+    a = "".join(a)
+    got = ctx.poa_sequences([[a, "".join(b), "".join(c)], [a[:300]] * 2])
+    assert got[0] == a and got[1] == a[:300]
+    with pytest.raises(hip.HipError, match="longer than the POA kernel"):
+        ctx.poa_sequences([["A" * 140000, "A" * 140000]])
