@@ -59,10 +59,27 @@ void from_ref_codec(const uint8_t* src, uint32_t len, uint8_t* mine /* ((len+15)
 
 struct File {
     FILE* fp;
-    File(const std::string& path, const char* mode) : fp(fopen(path.c_str(), mode)) {}
-    ~File() { if (fp) fclose(fp); }
+    uint64_t size = 0, pos = 0;   // (readers: a count that promises more bytes than the file has left is refused before anything is allocated for it)
+    std::string final_path, part_path;
+    File(const std::string& path, const char* mode) : fp(nullptr) {
+        if (mode[0] == 'w') {   // writers fill "<path>.part"; commit() renames it, so a run that is killed half way leaves no cache file that looks complete
+            final_path = path; part_path = path + ".part";
+            fp = fopen(part_path.c_str(), mode);
+        } else {
+            fp = fopen(path.c_str(), mode);
+            if (fp && fseeko(fp, 0, SEEK_END) == 0) { size = (uint64_t)ftello(fp); fseeko(fp, 0, SEEK_SET); }
+        }
+    }
+    ~File() { if (fp) fclose(fp); if (!part_path.empty()) remove(part_path.c_str()); }
     bool w(const void* p, size_t n) { return n == 0 || fwrite(p, 1, n, fp) == n; }
-    bool r(void* p, size_t n) { return n == 0 || fread(p, 1, n, fp) == n; }
+    bool r(void* p, size_t n) { if (n == 0) return true; if (fread(p, 1, n, fp) != n) return false; pos += n; return true; }
+    bool has(uint64_t count, uint64_t each) const { return each == 0 || count <= (size - pos) / each; }
+    bool commit() {
+        const bool ok = fclose(fp) == 0;
+        fp = nullptr;
+        if (ok && rename(part_path.c_str(), final_path.c_str()) == 0) { part_path.clear(); return true; }
+        return false;
+    }
 };
 
 void put32(uint8_t* p, uint32_t v) { memcpy(p, &v, 4); }
@@ -107,7 +124,7 @@ bool write_contig_index(const Dataset& d, const std::string& path) {
     std::vector<uint8_t> blk(block);
     uint64_t off = 0;
     for (uint64_t i = 0; i < n; i++) { to_ref_codec(d.contig_packed.data() + d.contig_off[i], d.contig_len[i], blk.data() + off); off += comp_len_of(d.contig_len[i]); }
-    if (!f.w(&n, 8) || !f.w(recs.data(), recs.size()) || !f.w(&block, 8) || !f.w(blk.data(), blk.size())) { g_err = "[ERROR] could not write " + path; return false; }
+    if (!f.w(&n, 8) || !f.w(recs.data(), recs.size()) || !f.w(&block, 8) || !f.w(blk.data(), blk.size()) || !f.commit()) { g_err = "[ERROR] could not write " + path; return false; }
     return true;
 }
 
@@ -181,7 +198,7 @@ bool write_longread_index(const Dataset& d, const hx_chain_out& ch, const std::s
             for (const std::string& x : part) ok = ok && (x.empty() || f.w(x.data(), x.size()));
         }
     }
-    if (!ok) { g_err = "[ERROR] could not write " + path; return false; }
+    if (!ok || !f.commit()) { g_err = "[ERROR] could not write " + path; return false; }
     return true;
 }
 
@@ -189,9 +206,9 @@ bool read_contig_index(Dataset& d, const std::string& path) {
     File f(path, "rb");
     if (!f.fp) { g_err = "[ERROR] (Contig::read_contig_index) could not open file: " + path; return false; }
     uint64_t n = 0, block = 0;
-    if (!f.r(&n, 8)) { g_err = "[ERROR] truncated " + path; return false; }
+    if (!f.r(&n, 8) || !f.has(n, 32)) { g_err = "[ERROR] truncated " + path; return false; }
     std::vector<uint8_t> recs(n * 32);
-    if (!f.r(recs.data(), recs.size()) || !f.r(&block, 8)) { g_err = "[ERROR] truncated " + path; return false; }
+    if (!f.r(recs.data(), recs.size()) || !f.r(&block, 8) || !f.has(block, 1)) { g_err = "[ERROR] truncated " + path; return false; }
     std::vector<uint8_t> blk(block);
     if (!f.r(blk.data(), block)) { g_err = "[ERROR] truncated " + path; return false; }
     uint64_t off = 0;
@@ -217,13 +234,13 @@ bool read_longread_index(Dataset& d, const std::string& path) {
     if (!f.fp) { g_err = "[ERROR] (Longread::read_longread_index) could not open file: " + path; return false; }
     auto trunc = [&]() { g_err = "[ERROR] truncated or inconsistent " + path; return false; };
     uint64_t n = 0, seqs = 0, na = 0, cs = 0;
-    if (!f.r(&n, 8)) return trunc();
+    if (!f.r(&n, 8) || !f.has(n, 32) || n >= 0xffffffffull) return trunc();
     std::vector<uint8_t> recs(n * 32);
-    if (!f.r(recs.data(), recs.size()) || !f.r(&seqs, 8)) return trunc();
+    if (!f.r(recs.data(), recs.size()) || !f.r(&seqs, 8) || !f.has(seqs, 1)) return trunc();
     std::vector<uint8_t> sq(seqs);
-    if (!f.r(sq.data(), seqs) || !f.r(&na, 8)) return trunc();
+    if (!f.r(sq.data(), seqs) || !f.r(&na, 8) || !f.has(na, 48)) return trunc();
     std::vector<uint8_t> al(na * 48);
-    if (!f.r(al.data(), al.size()) || !f.r(&cs, 8)) return trunc();
+    if (!f.r(al.data(), al.size()) || !f.r(&cs, 8) || !f.has(cs, 1)) return trunc();
     std::vector<char> cg(cs);
     if (!f.r(cg.data(), cs)) return trunc();
     // serial: validate the record tables, lay out the arenas. parallel (reads / alignments dealt in contiguous ranges to the ingest

@@ -536,12 +536,18 @@ extern "C" hxh_dataset* hxh_dataset_load_mt(const char* contig_path, const char*
 }
 extern "C" hxh_dataset* hxh_dataset_load_cached(const char* index_dir, const char* contig_path, const char* long_path, int long_fofn, const char* mapping_path,
                                                 int mapping_fofn, unsigned threads, int* used_contig_index, int* used_longread_index) {
-    return reinterpret_cast<hxh_dataset*>(load_dataset_cached(index_dir, contig_path, long_path, long_fofn != 0, mapping_path, mapping_fofn != 0, threads,
-                                                              used_contig_index, used_longread_index));
+    try {   // (no exception may cross the C boundary: a corrupt cache file or an exhausted host becomes an [ERROR] like any other)
+        return reinterpret_cast<hxh_dataset*>(load_dataset_cached(index_dir, contig_path, long_path, long_fofn != 0, mapping_path, mapping_fofn != 0, threads,
+                                                                  used_contig_index, used_longread_index));
+    } catch (const std::exception& e) { g_err = std::string("[ERROR] loading the inputs: ") + e.what(); return nullptr; }
 }
-extern "C" int hxh_dataset_write_contig_index(const hxh_dataset* p, const char* path) { return write_contig_index(*reinterpret_cast<const Dataset*>(p), path) ? 0 : -1; }
+extern "C" int hxh_dataset_write_contig_index(const hxh_dataset* p, const char* path) {
+    try { return write_contig_index(*reinterpret_cast<const Dataset*>(p), path) ? 0 : -1; }
+    catch (const std::exception& e) { g_err = std::string("[ERROR] writing index.contig: ") + e.what(); return -1; }
+}
 extern "C" hxh_dataset* hxh_dataset_load(const char* contig_path, const char* long_path, int long_fofn, const char* mapping_path, int mapping_fofn) {
-    return reinterpret_cast<hxh_dataset*>(load_dataset(contig_path, long_path, long_fofn != 0, mapping_path, mapping_fofn != 0, 0));   // automatic thread count
+    try { return reinterpret_cast<hxh_dataset*>(load_dataset(contig_path, long_path, long_fofn != 0, mapping_path, mapping_fofn != 0, 0)); }   // automatic thread count
+    catch (const std::exception& e) { g_err = std::string("[ERROR] loading the inputs: ") + e.what(); return nullptr; }
 }
 extern "C" void hxh_dataset_free(hxh_dataset* p) { delete reinterpret_cast<Dataset*>(p); }
 extern "C" double hxh_dataset_uniq_freq(const hxh_dataset* p) { return reinterpret_cast<const Dataset*>(p)->uniq_freq; }

@@ -8,8 +8,9 @@
 // `[ERROR] ...` on stderr + EXIT_FAILURE otherwise, progress on stderr, outputs inside -d.
 // Build-only additions: --device INT (HIP device, default 0), --poa-block INT.
 // -t is accepted and clamped like the reference's, but the per-read / per-edge work runs on the GPU.
-// index.contig / index.longread (raw struct dumps with process pointers, Contig.cpp:119-159,
-// Longread.cpp:322-372) are not written: they are caches of the reference's own memory layout.
+// index.contig / index.longread (the reference's cache files, Contig.cpp:119-159, Longread.cpp:322-372) are written into -d and loaded
+// instead of the text inputs when they exist, like main.cpp:39-103 does (host/index_cache.cpp; records read back from index.longread are
+// the filtered set and go straight to trim + chain).
 #include <getopt.h>
 #include <sys/resource.h>
 #include <sys/stat.h>
@@ -127,11 +128,13 @@ int main(int argc, char* argv[]) {
     if (!used_ci && hxh_dataset_write_contig_index(ds, (out_dir + "/index.contig").c_str()) != 0) { fprintf(stderr, "%s\n", hxh_last_error()); return EXIT_FAILURE; }
     hx_contigs vc; hx_reads vr; hx_hits vh; const uint64_t* rho;
     hxh_dataset_views(ds, &vc, &vr, &vh, &rho);
-    fprintf(stderr, "       loaded %u contigs\n       loaded %u long reads\n       loaded %lu alignments\n", vc.n, vr.n, (unsigned long)vh.n);
+    fprintf(stderr, "       loaded %u contigs\n       loaded %u long reads\n       loaded %lu alignment records%s\n", vc.n, vr.n, (unsigned long)vh.n,
+            used_li ? "" : " (before the filters; the alignments that survive them are counted after the next stage)");
     prm.uniq_freq = hxh_dataset_uniq_freq(ds);
     fprintf(stderr, "[NOTE] calculating kmer frequency of unique contigs\n       mean: %.2lf\n", prm.uniq_freq);
     elapsed();
     if (hx_upload(ctx, &vc, &vr, &vh, rho) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
+    hx_set_prefiltered(ctx, used_li);
 
     hx_backend be;
     hx_backend_fill(ctx, &be);
@@ -154,6 +157,7 @@ int main(int argc, char* argv[]) {
     for (auto& st : stages) {
         fprintf(stderr, "%s\n", st.note);
         if (st.fn(run) != 0) { fprintf(stderr, "[ERROR] %s\n", hxh_last_error()); finish_index(); return EXIT_FAILURE; }
+        if (st.fn == hxh_run_chain) fprintf(stderr, "       loaded %lu alignments\n", (unsigned long)hxh_run_chain_out(run)->n_aln);   // (the count the reference prints at load time)
         if (st.fn == hxh_run_chain && !used_li) {
             const std::string path = out_dir + "/index.longread";
             if (getenv("HASLR_INDEX_ASYNC"))

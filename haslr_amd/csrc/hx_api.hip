@@ -127,6 +127,7 @@ struct hx_ctx {
     std::vector<uint32_t> h_rlen;
     std::vector<uint64_t> h_rho;
     uint32_t lr_begin = 0, lr_end = 0;
+    bool prefiltered = false;   // the resident records are the filtered set of an index.longread
     DV<uint32_t> err;
     // chain results
     DV<uint32_t> c_hit, c_qs, c_qe, c_ts, c_te, c_nm, c_nb, c_skf, c_skb, c_cmp;
@@ -257,9 +258,12 @@ extern "C" int hx_upload(hx_ctx* c, const hx_contigs* ctg, const hx_reads* rd, c
     c->h_rlen.assign(rd->len, rd->len + rd->n);
     c->h_rho.assign(rho, rho + rd->n + 1);
     c->lr_begin = 0; c->lr_end = rd->n;
+    c->prefiltered = false;
     c->have_chain = c->have_edges = c->have_coords = false;
     return 0;
 }
+
+extern "C" void hx_set_prefiltered(hx_ctx* c, int on) { c->prefiltered = on != 0; }
 
 extern "C" int hx_set_read_shard(hx_ctx* c, uint32_t b, uint32_t e) {
     if (b > e || e > c->n_reads) return fail("hx_set_read_shard: bad range");
@@ -303,7 +307,7 @@ extern "C" int hx_chain_reads(hx_ctx* c, const hx_params* prm, hx_chain_out* out
     HIPCHK(c->aln_off.reserve((size_t)nr + 1)); HIPCHK(c->cmp_off.reserve((size_t)nr + 1));
     c->tick();
     hxk::contig_class(c->km.p, c->n_contigs, thr_load, thr_uniq, c->cls.p, s);
-    hxk::chain_reads(c->hits_view(), c->rho.p, c->cls.p, c->n_contigs, c->lr_begin, c->lr_end, prm->min_aln_block, prm->min_aln_sim, prm->min_aln_mapq, sc, c->err.p, s);
+    hxk::chain_reads(c->hits_view(), c->rho.p, c->cls.p, c->n_contigs, c->lr_begin, c->lr_end, prm->min_aln_block, prm->min_aln_sim, prm->min_aln_mapq, sc, c->err.p, c->prefiltered, s);
     hxk::exclusive_scan_u32(s_naln.p, c->aln_off.p, nr, s, c->ws);
     hxk::exclusive_scan_u32(s_ncmp.p, c->cmp_off.p, nr, s, c->ws);
     uint64_t tot[2] = {0, 0};

@@ -91,7 +91,7 @@ __device__ TrimRes trim_walk(const CgView& v, bool reversed, uint32_t lr, uint32
 
 __global__ void k_chain_reads(DevHits h, const uint64_t* __restrict__ rho, const uint8_t* __restrict__ cls, uint32_t n_contigs,
                               uint32_t lr_begin, uint32_t lr_end, uint32_t min_block, double min_sim, uint32_t min_mapq,
-                              ChainScratch sc, uint32_t* err, uint32_t spread) {
+                              ChainScratch sc, uint32_t* err, uint32_t spread, const bool prefiltered) {
     // one lane per read; with few reads only every `spread`-th lane works, so that the reads are spread over more wavefronts (a wave takes
     // as long as its slowest read, and 13 k reads on 64 per wave would leave four fifths of the SIMDs idle)
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
@@ -106,6 +106,7 @@ __global__ void k_chain_reads(DevHits h, const uint64_t* __restrict__ rho, const
     for (uint64_t i = raw_b; i < raw_e; i++) {
         uint32_t tid = h.t_id[i];
         if (tid >= n_contigs) { atomicOr(err, (uint32_t)HXE_BAD_TID); continue; }
+        if (prefiltered) { L[n++] = (uint32_t)i; continue; }   // the filtered set of an index.longread: taken as it is (main.cpp:90-116)
         if (h.n_block[i] < min_block) continue;
         if ((double)h.n_match[i] / (double)h.n_block[i] < min_sim) continue;
         if (h.mapq[i] < min_mapq) continue;
@@ -113,7 +114,7 @@ __global__ void k_chain_reads(DevHits h, const uint64_t* __restrict__ rho, const
         L[n++] = (uint32_t)i;
     }
     // ---- stable insertion sort by (q_end, q_start); ties keep PAF order
-    for (uint32_t i = 1; i < n; i++) {
+    for (uint32_t i = 1; i < n && !prefiltered; i++) {
         uint32_t x = L[i];
         uint32_t xe = h.q_end[x], xs = h.q_start[x];
         uint32_t j = i;
@@ -127,10 +128,10 @@ __global__ void k_chain_reads(DevHits h, const uint64_t* __restrict__ rho, const
         L[j] = x;
     }
     uint32_t n_aln = 0, n_cmp = 0;
-    if (n > 1) {
+    if (n > (prefiltered ? 0u : 1u)) {
         // ---- palindrome rule: truncate at the second hit of a unique contig
         uint32_t keep = n;
-        for (uint32_t i = 0; i < keep; i++) {
+        for (uint32_t i = 0; i < keep && !prefiltered; i++) {
             uint32_t tid = h.t_id[L[i]];
             if (!(cls[tid] & HXC_UNIQUE)) continue;
             for (uint32_t k = 0; k < i; k++)
@@ -139,7 +140,7 @@ __global__ void k_chain_reads(DevHits h, const uint64_t* __restrict__ rho, const
         // ---- filter 5 (interior hits covering < 0.8 of the contig) + materialise the alignment rows in place
         for (uint32_t i = 0; i < keep; i++) {
             uint32_t x = L[i];
-            if (i > 0 && i + 1 < keep && (h.t_end[x] - h.t_start[x]) / (double)h.t_len[x] < 0.8) continue;
+            if (!prefiltered && i > 0 && i + 1 < keep && (h.t_end[x] - h.t_start[x]) / (double)h.t_len[x] < 0.8) continue;
             uint64_t o = base + n_aln;
             sc.hit[o] = x;   // o <= base+i: never overwrites an unread entry of L
             sc.qs[o] = h.q_start[x]; sc.qe[o] = h.q_end[x]; sc.ts[o] = h.t_start[x]; sc.te[o] = h.t_end[x];
@@ -234,10 +235,10 @@ __global__ void k_chain_compact(ChainScratch sc, const uint64_t* __restrict__ rh
 }  // namespace
 
 void chain_reads(const DevHits& h, const uint64_t* rho, const uint8_t* cls, uint32_t n_contigs, uint32_t lr_begin, uint32_t lr_end,
-                 uint32_t min_aln_block, double min_aln_sim, uint32_t min_mapq, const ChainScratch& sc, uint32_t* err, hipStream_t s) {
+                 uint32_t min_aln_block, double min_aln_sim, uint32_t min_mapq, const ChainScratch& sc, uint32_t* err, bool prefiltered, hipStream_t s) {
     uint32_t n = lr_end - lr_begin;
     const uint32_t spread = n <= 16384 ? 4 : n <= 65536 ? 2 : 1;
-    if (n) k_chain_reads<<<(uint32_t)(((uint64_t)n * spread + 63) / 64), 64, 0, s>>>(h, rho, cls, n_contigs, lr_begin, lr_end, min_aln_block, min_aln_sim, min_mapq, sc, err, spread);
+    if (n) k_chain_reads<<<(uint32_t)(((uint64_t)n * spread + 63) / 64), 64, 0, s>>>(h, rho, cls, n_contigs, lr_begin, lr_end, min_aln_block, min_aln_sim, min_mapq, sc, err, spread, prefiltered);
 }
 
 void chain_compact(const ChainScratch& sc, const uint64_t* rho, uint32_t lr_begin, uint32_t lr_end, const uint64_t* aln_off,

@@ -39,7 +39,7 @@ struct ChainScratch {   // all sized by the number of raw hits in the shard (+1)
 void contig_class(const double* mean_kmer, uint32_t n, double thr_load, double thr_uniq, uint8_t* cls, hipStream_t s);
 void chain_reads(const DevHits& h, const uint64_t* read_hit_off, const uint8_t* cls, uint32_t n_contigs,
                  uint32_t lr_begin, uint32_t lr_end, uint32_t min_aln_block, double min_aln_sim, uint32_t min_mapq,
-                 const ChainScratch& sc, uint32_t* err, hipStream_t s);
+                 const ChainScratch& sc, uint32_t* err, bool prefiltered /* records of an index.longread: no filters, sort or group rule */, hipStream_t s);
 struct ChainFinal {
     uint32_t *hit, *qs, *qe, *ts, *te, *nm, *nb, *skf, *skb;
     uint64_t *cb, *ce;

@@ -12,7 +12,7 @@ from . import ctypes_defs as T
 _LIBDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 _lib = None
 
-SYMBOLS = ["hx_last_error", "hx_device_count", "hx_ctx_create", "hx_ctx_destroy", "hx_upload", "hx_set_read_shard",
+SYMBOLS = ["hx_last_error", "hx_device_count", "hx_ctx_create", "hx_ctx_destroy", "hx_upload", "hx_set_read_shard", "hx_set_prefiltered",
            "hx_chain_reads", "hx_edge_support", "hx_edge_coords", "hx_poa_batch", "hx_free_chain", "hx_free_edges",
            "hx_free_coords", "hx_free_cns", "hx_edge_emit", "hx_edge_records_bytes", "hx_edge_records_export",
            "hx_edge_records_import", "hx_poa_supports", "hx_poa_sequences", "hx_timing_reset", "hx_timing_get", "hx_set_poa_block", "hx_backend_fill", "hx_poa_phase_cycles", "hx_set_poa_traceback"]
@@ -34,6 +34,7 @@ def lib():
         L.hx_ctx_destroy.argtypes = [C.c_void_p]
         L.hx_upload.argtypes = [C.c_void_p, C.POINTER(T.Contigs), C.POINTER(T.Reads), C.POINTER(T.Hits), T.u64p]
         L.hx_set_read_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.hx_set_prefiltered.argtypes = [C.c_void_p, C.c_int]
         L.hx_chain_reads.argtypes = [C.c_void_p, C.POINTER(T.Params), C.POINTER(T.ChainOut)]
         L.hx_edge_support.argtypes = [C.c_void_p, C.POINTER(T.Params), C.POINTER(T.EdgesOut)]
         L.hx_edge_coords.argtypes = [C.c_void_p, C.c_uint32, T.u32p, C.POINTER(T.CoordsOut)]
@@ -79,6 +80,7 @@ class HipContext:
     def upload(self, dataset):
         self._ds = dataset
         self._chk(lib().hx_upload(self._h, C.byref(dataset.contigs), C.byref(dataset.reads), C.byref(dataset.hits), dataset.read_hit_off))
+        lib().hx_set_prefiltered(self._h, int(getattr(dataset, "used_longread_index", False)))   # records of an index.longread are taken as they are
 
     def set_read_shard(self, b, e):
         self._chk(lib().hx_set_read_shard(self._h, b, e))

@@ -43,6 +43,10 @@ void hx_ctx_destroy(hx_ctx*);
  * multi-GPU run). Read shard defaults to all reads. */
 int hx_upload(hx_ctx*, const hx_contigs*, const hx_reads*, const hx_hits*, const uint64_t* read_hit_off);
 int hx_set_read_shard(hx_ctx*, uint32_t lr_begin, uint32_t lr_end);
+/* the uploaded records are the reference's FILTERED set, read back from an index.longread (Longread.cpp:341-372): hx_chain_reads then takes
+ * them as they are - no filters 1-5, no sort, no group / palindrome rule - and goes straight to trim + chain, like main.cpp:90-116 does
+ * after read_longread_index. Reset by hx_upload. */
+void hx_set_prefiltered(hx_ctx*, int on);
 
 int hx_chain_reads(hx_ctx*, const hx_params*, hx_chain_out* out);
 int hx_edge_support(hx_ctx*, const hx_params*, hx_edges_out* out);

@@ -141,8 +141,16 @@ extern "C" const char* orc_last_error(void) { return g_err.c_str(); }
 // =====================================================================================================
 // a1-a5: filters, per-read sort, palindrome rule, filter 5, overlap trim, chaining
 // =====================================================================================================
+extern "C" int orc_chain_reads_ex(const hx_contigs* ctg, const hx_hits* h, const uint64_t* read_hit_off,
+                                  uint32_t n_reads, const hx_params* prm, int prefiltered, hx_chain_out* out);
 extern "C" int orc_chain_reads(const hx_contigs* ctg, const hx_hits* h, const uint64_t* read_hit_off,
                                uint32_t n_reads, const hx_params* prm, hx_chain_out* out) {
+    return orc_chain_reads_ex(ctg, h, read_hit_off, n_reads, prm, 0, out);
+}
+// prefiltered: the records are the reference's filtered set read back from index.longread (Longread.cpp:341-372): main() goes straight to
+// fix_alignments with them (main.cpp:90-116) - no filters, no sort, no group rule
+extern "C" int orc_chain_reads_ex(const hx_contigs* ctg, const hx_hits* h, const uint64_t* read_hit_off,
+                                  uint32_t n_reads, const hx_params* prm, int prefiltered, hx_chain_out* out) {
     memset(out, 0, sizeof(*out));
     const double thr_load = prm->uniq_freq * (3 + prm->max_uniq_dev);   // Longread.cpp:272
     const double thr_uniq = prm->uniq_freq * (1 + prm->max_uniq_dev);   // Longread.cpp:191, :539 (copy_count = 1)
@@ -159,6 +167,7 @@ extern "C" int orc_chain_reads(const hx_contigs* ctg, const hx_hits* h, const ui
         for (uint64_t i = read_hit_off[r]; i < read_hit_off[r + 1]; i++) {
             if (h->q_id[i] != r) return fail("orc_chain_reads: PAF not grouped by ascending query id");
             if (h->t_id[i] >= ctg->n) return fail("orc_chain_reads: contig id out of range");
+            if (prefiltered) { grp.push_back((uint32_t)i); continue; }
             if (h->n_block[i] < prm->min_aln_block) continue;
             if ((double)h->n_match[i] / (double)h->n_block[i] < prm->min_aln_sim) continue;
             if (h->mapq[i] < prm->min_aln_mapq) continue;
@@ -167,14 +176,14 @@ extern "C" int orc_chain_reads(const hx_contigs* ctg, const hx_hits* h, const ui
         }
         // ---- sort by (q_end, q_start) (Longread.cpp:52-55,256). The reference's std::sort leaves ties on
         // both keys in implementation order; the restatement fixes them to PAF order (stable).
-        std::stable_sort(grp.begin(), grp.end(), [&](uint32_t a, uint32_t b) {
+        if (!prefiltered) std::stable_sort(grp.begin(), grp.end(), [&](uint32_t a, uint32_t b) {
             return h->q_end[a] < h->q_end[b] || (h->q_end[a] == h->q_end[b] && h->q_start[a] < h->q_start[b]);
         });
-        if (grp.size() <= 1) continue;  // Longread.cpp:184
+        if (!prefiltered && grp.size() <= 1) continue;  // Longread.cpp:184
         // ---- palindrome rule (Longread.cpp:187-202): truncate at the second hit of a unique contig
         seen_tid.clear();
         size_t keep = grp.size();
-        for (size_t i = 0; i < keep; i++) {
+        for (size_t i = 0; i < keep && !prefiltered; i++) {
             uint32_t tid = h->t_id[grp[i]];
             if (ctg->mean_kmer[tid] < thr_uniq) {
                 if (std::find(seen_tid.begin(), seen_tid.end(), tid) != seen_tid.end()) keep = i;
@@ -185,7 +194,7 @@ extern "C" int orc_chain_reads(const hx_contigs* ctg, const hx_hits* h, const ui
         // ---- filter 5 (Longread.cpp:207) + append (:216-230)
         for (size_t i = 0; i < grp.size(); i++) {
             uint32_t x = grp[i];
-            if (i > 0 && i + 1 < grp.size() && (h->t_end[x] - h->t_start[x]) / (double)h->t_len[x] < 0.8) continue;
+            if (!prefiltered && i > 0 && i + 1 < grp.size() && (h->t_end[x] - h->t_start[x]) / (double)h->t_len[x] < 0.8) continue;
             alns.push_back({x, h->q_start[x], h->q_end[x], h->t_start[x], h->t_end[x], h->n_match[x], h->n_block[x],
                             h->cg_off[x], h->cg_off[x + 1], 0, 0});
         }

@@ -24,6 +24,9 @@ extern "C" {
  * the reference's precondition, Longread.cpp:57-84,253). Returns 0, or <0 with orc_last_error(). */
 int orc_chain_reads(const hx_contigs* contigs, const hx_hits* hits, const uint64_t* read_hit_off,
                     uint32_t n_reads, const hx_params* prm, hx_chain_out* out);
+/* prefiltered != 0: the records are the filtered set of an index.longread (no filters, sort or group rule: straight to trim + chain) */
+int orc_chain_reads_ex(const hx_contigs* contigs, const hx_hits* hits, const uint64_t* read_hit_off,
+                       uint32_t n_reads, const hx_params* prm, int prefiltered, hx_chain_out* out);
 int orc_edge_support(const hx_contigs* contigs, const hx_hits* hits, const hx_params* prm,
                      const hx_chain_out* chain, uint32_t lr_begin, uint32_t lr_end, hx_edges_out* out);
 int orc_edge_coords(const hx_contigs* contigs, const uint32_t* read_len, const hx_hits* hits,

@@ -20,6 +20,7 @@ struct orc_ctx {
     uint32_t lr_begin, lr_end;   // read shard shown to the host pipeline by chain_reads (multi-rank tests); 0, 0 = all reads
     hx_chain_out full_chain;     // the chain output of ALL reads, which the later stages work on (kept when a shard is shown)
     bool sliced;
+    int prefiltered;             // the records come from an index.longread
 };
 
 template <class T> static T* dup_range(const T* p, uint64_t b, uint64_t e) {
@@ -45,7 +46,7 @@ static void slice_chain(const hx_chain_out& f, uint32_t b, uint32_t e, hx_chain_
 
 static int be_chain(void* p, const hx_params* prm, hx_chain_out* out) {
     orc_ctx* c = (orc_ctx*)p;
-    int rc = orc_chain_reads(&c->contigs, &c->hits, c->read_hit_off, c->reads.n, prm, out);
+    int rc = orc_chain_reads_ex(&c->contigs, &c->hits, c->read_hit_off, c->reads.n, prm, c->prefiltered, out);
     if (rc) return rc;
     c->chain = *out; c->have_chain = true; c->sliced = false;
     if (c->lr_end > c->lr_begin || c->lr_begin) {   // show the host pipeline this rank's reads only; edges / coords go on using the full table
@@ -89,6 +90,7 @@ extern "C" orc_ctx* orc_ctx_create(const hx_contigs* c, const hx_reads* r, const
     return x;
 }
 extern "C" void orc_ctx_destroy(orc_ctx* x) { free(x); }
+extern "C" void orc_ctx_set_prefiltered(orc_ctx* x, int on) { x->prefiltered = on; }
 extern "C" void orc_ctx_set_read_shard(orc_ctx* x, uint32_t b, uint32_t e) { x->lr_begin = b; x->lr_end = e; }
 /* the emission of one read shard (multi-rank tests): records of reads [b, e) from the full chain table, key-sorted like orc_edge_support returns them */
 extern "C" int orc_ctx_shard_edges(orc_ctx* c, const hx_params* prm, uint32_t b, uint32_t e, hx_edges_out* out) {

@@ -19,6 +19,7 @@ def lib():
         L.orc_ctx_create.argtypes = [C.POINTER(T.Contigs), C.POINTER(T.Reads), C.POINTER(T.Hits), T.u64p, C.c_int]
         L.orc_ctx_destroy.argtypes = [C.c_void_p]
         L.orc_backend_fill.argtypes = [C.c_void_p, C.POINTER(T.Backend)]
+        L.orc_ctx_set_prefiltered.argtypes = [C.c_void_p, C.c_int]
         L.orc_ctx_set_read_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.orc_ctx_shard_edges.argtypes = [C.c_void_p, C.POINTER(T.Params), C.c_uint32, C.c_uint32, C.POINTER(T.EdgesOut)]
         L.orc_free_edges.argtypes = [C.POINTER(T.EdgesOut)]
@@ -37,6 +38,7 @@ class OracleBackend:
         self._ctx = lib().orc_ctx_create(C.byref(dataset.contigs), C.byref(dataset.reads), C.byref(dataset.hits), dataset.read_hit_off, n_threads)
         self.table = T.Backend()
         lib().orc_backend_fill(self._ctx, C.byref(self.table))
+        lib().orc_ctx_set_prefiltered(self._ctx, int(getattr(dataset, "used_longread_index", False)))   # records of an index.longread are taken as they are
 
     def set_read_shard(self, b, e):
         """chain_reads shows the host pipeline the reads [b, e) only (what a rank of a multi-GPU run holds)"""

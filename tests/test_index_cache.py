@@ -139,3 +139,36 @@ def test_odd_cigar_text_is_kept(sim, ref_front, tmp_path):
     for f in ("alignments.loaded.paf", "alignments.fixed.paf", "compact_uniq.txt", "edge_supp.06.txt"):
         assert open(os.path.join(a, f), "rb").read() == open(os.path.join(b, f), "rb").read(), f
     run.close(); be.close(); ds.close()
+
+
+def test_rerun_from_the_index_is_idempotent(sim, ref_front, tmp_path):
+    """reads cut down to ONE alignment by the palindrome rule (missed-adapter reads) keep it in index.longread; a rerun that loads the index
+    must not put the records through the filters again (the '<= 1 hit' rule would drop them): compact_uniq.txt, the trimmed alignments and
+    the assembly of the rerun equal those of the text run and the reference's own rerun from the same cache"""
+    pre = sim("--genome-len", "150000", "--seed", "19", "--variant-per-mb", "20", "--cov", "14", "--hairpin-frac", "0.15")
+    a, b = str(tmp_path / "text"), str(tmp_path / "rerun")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    be = orclib.OracleBackend(ds, 4)
+    run = host.Run(ds, ds.params(), be.table, a)
+    run.all()
+    ch = run.chain_out()
+    n_single = int(np.sum(np.diff(ch["read_off"]) == 1))
+    assert n_single > 0, "the fixture must hold reads that the palindrome rule cuts to one alignment"
+    ds.write_contig_index(os.path.join(a, "index.contig"))
+    run.write_longread_index(os.path.join(a, "index.longread"))
+    ds2 = host.Dataset("/nonexistent/c.fa", "/nonexistent/r.fa", "/nonexistent/m.paf", index_dir=a)
+    assert ds2.used_contig_index and ds2.used_longread_index
+    be2 = orclib.OracleBackend(ds2, 4)
+    run2 = host.Run(ds2, ds2.params(), be2.table, b)
+    run2.all()
+    ch2 = run2.chain_out()
+    for k in ("q_start", "q_end", "t_start", "t_end", "n_match", "n_block", "read_off", "cmp_off", "cmp_aln"):
+        assert np.array_equal(ch[k], ch2[k]), k
+    for f in ("compact_uniq.txt", "asm.final.fa", "backbone.06.smallbubble.gfa"):
+        assert open(os.path.join(a, f), "rb").read() == open(os.path.join(b, f), "rb").read(), f
+    # the reference, rerun from the same cache, writes the same compact_uniq.txt
+    r = str(tmp_path / "ref")
+    run_ref(ref_front, pre, r, {"REF_FRONT_FROM_INDEX": a})
+    assert open(os.path.join(r, "compact_uniq.txt"), "rb").read() == open(os.path.join(a, "compact_uniq.txt"), "rb").read()
+    for x in (run, run2, be, be2, ds, ds2):
+        x.close()
