@@ -89,15 +89,10 @@ __device__ TrimRes trim_walk(const CgView& v, bool reversed, uint32_t lr, uint32
     return r;
 }
 
-__global__ void k_chain_reads(DevHits h, const uint64_t* __restrict__ rho, const uint8_t* __restrict__ cls, uint32_t n_contigs,
-                              uint32_t lr_begin, uint32_t lr_end, uint32_t min_block, double min_sim, uint32_t min_mapq,
-                              ChainScratch sc, uint32_t* err, uint32_t spread, const bool prefiltered) {
-    // one lane per read; with few reads only every `spread`-th lane works, so that the reads are spread over more wavefronts (a wave takes
-    // as long as its slowest read, and 13 k reads on 64 per wave would leave four fifths of the SIMDs idle)
-    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gt % spread) return;
-    uint32_t r = lr_begin + gt / spread;
-    if (r >= lr_end) return;
+// One read, start to end, on ONE lane (the round-1 mapping): kept for the reads with more raw hits than a wavefront has lanes.
+__device__ void chain_read_serial(const DevHits& h, const uint64_t* __restrict__ rho, const uint8_t* __restrict__ cls, uint32_t n_contigs,
+                                  uint32_t lr_begin, uint32_t r, uint32_t min_block, double min_sim, uint32_t min_mapq,
+                                  const ChainScratch& sc, uint32_t* err, const bool prefiltered) {
     const uint64_t raw_b = rho[r], raw_e = rho[r + 1];
     const uint64_t base = raw_b - rho[lr_begin];
     uint32_t* L = sc.hit + base;   // the read's working list of raw-hit indices
@@ -217,6 +212,253 @@ __global__ void k_chain_reads(DevHits h, const uint64_t* __restrict__ rho, const
     sc.n_cmp[r - lr_begin] = n_cmp;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// One WAVEFRONT per read (reads with at most 64 raw hits - in practice all of them).
+//   * lane i loads raw hit i of the read: 64 consecutive records of every column, coalesced; the filters are one ballot
+//   * sort by (q_end, q_start): every surviving lane counts the survivors that precede it (a loop over the set bits of the ballot with
+//     v_readlane broadcasts), the rank is its place; ties keep PAF order like the serial insertion sort
+//   * palindrome rule and filter 5: ballots over the sorted lanes; rows move to their final places through ds_bpermute
+//   * overlap trim: pairs left to right (a hit can be cut on both sides by two successive pairs), but the CIGAR walk of a cut - thousands of
+//     run-length ops for a 10 kb alignment, the serial kernel's whole cost - is shared by the 64 lanes: every lane sums a slice of the ops,
+//     a wave prefix sum gives each slice its start state, one ballot finds the op where the walk stops (trim_walk_wave)
+//   * chaining: the latest compatible predecessor of every candidate in parallel, the O(n) recurrence itself on wave-uniform values
+// Rows of the read live in LDS while they change and are written once, coalesced.
+// ---------------------------------------------------------------------------------------------------
+struct WaveRows {
+    uint32_t hit[64], qs[64], qe[64], ts[64], te[64], nm[64], nb[64], skf[64], skb[64], perm[64], cand[64], jprev[64], sol[64];
+    uint64_t cb[64], ce[64];
+};
+
+__device__ __forceinline__ uint32_t wave_excl_add(uint32_t v, uint32_t lane) {
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(x, d, 64); if ((int)lane >= d) x += o; }
+    return x - v;
+}
+
+// trim_walk with the ops of the view dealt to the 64 lanes; every lane returns the same result
+__device__ TrimRes trim_walk_wave(const CgView& v, bool reversed, uint32_t lr0, uint32_t c0, int lstep, int cstep, uint32_t lr_pos, uint32_t lane) {
+    TrimRes r;
+    r.ok = false; r.lr = r.c = r.kept = r.nmatch = r.kept_in_last = 0; r.last_run = 0;
+    const uint64_t n = v.e - v.b;
+    const uint64_t C = (n + 63) / 64, k0 = std::min<uint64_t>(n, (uint64_t)lane * C), k1 = std::min<uint64_t>(n, k0 + C);
+    const uint32_t D0 = lstep > 0 ? lr_pos - lr0 : lr0 - lr_pos;   // read bases to go (32-bit like the serial walk: a target behind the start is never reached)
+    // pass 1: what the lane's slice adds to the walk's counters
+    uint32_t sRead = 0, sM = 0, sIdx = 0, sCon = 0, sOth = 0;
+    for (uint64_t k = k0; k < k1; k++) {
+        const uint64_t g = reversed ? v.e - 1 - k : v.b + k;
+        const uint32_t len = v.eff(g), code = HX_CG_OP(v.ops[g]);
+        sIdx += len;
+        if (code == HX_CG_M) { sRead += len; sM += len; sCon += len; }
+        else if (code == HX_CG_I) sRead += len;
+        else { sCon += len; if (code == HX_CG_OTHER) sOth += len; }
+    }
+    const uint32_t bRead = wave_excl_add(sRead, lane), bM = wave_excl_add(sM, lane), bIdx = wave_excl_add(sIdx, lane), bCon = wave_excl_add(sCon, lane),
+                   bOth = wave_excl_add(sOth, lane);
+    // pass 2: the first op of the slice at which the serial walk would stop, and the last M run before it
+    uint32_t cr = bRead, cm = bM, ci = bIdx, cc = bCon, co = bOth;
+    bool stop = false, stopM = false;
+    uint32_t st_d = 0, st_read = 0, st_m = 0, st_idx = 0, st_con = 0, st_oth = 0; uint64_t st_g = 0;
+    bool haveM = false;
+    uint32_t m_read = 0, m_m = 0, m_idx = 0, m_con = 0, m_len = 0, m_othAfter = 0; uint64_t m_g = 0;
+    for (uint64_t k = k0; k < k1 && !stop; k++) {
+        const uint64_t g = reversed ? v.e - 1 - k : v.b + k;
+        const uint32_t len = v.eff(g);
+        if (len == 0) continue;
+        const uint32_t code = HX_CG_OP(v.ops[g]);
+        const uint32_t d = D0 - cr;
+        if (code == HX_CG_M || code == HX_CG_I) {
+            if (d < len) { stop = true; stopM = code == HX_CG_M; st_d = d; st_read = cr; st_m = cm; st_idx = ci; st_con = cc; st_oth = co; st_g = g; break; }
+            if (code == HX_CG_M) { haveM = true; m_read = cr; m_m = cm; m_idx = ci; m_con = cc; m_len = len; m_g = g; m_othAfter = co; cm += len; cc += len; }
+            cr += len;
+        } else {
+            if (d == 0) { stop = true; stopM = false; st_d = 0; st_read = cr; st_m = cm; st_idx = ci; st_con = cc; st_oth = co; st_g = g; break; }
+            cc += len;
+            if (code == HX_CG_OTHER) co += len;
+        }
+        ci += len;
+    }
+    const unsigned long long stopMask = __ballot(stop);
+    const int fl = stopMask ? __builtin_ctzll(stopMask) : 64;                 // the lane whose slice holds the stop (64: the ops ran out)
+    if (fl < 64 && __shfl((int)stopM, fl, 64)) {                              // stopped inside an M run: the cut
+        const uint32_t d = __shfl(st_d, fl, 64), rd = __shfl(st_read, fl, 64), mm = __shfl(st_m, fl, 64), ix = __shfl(st_idx, fl, 64), cn = __shfl(st_con, fl, 64);
+        const uint32_t glo = __shfl((uint32_t)st_g, fl, 64), ghi = __shfl((uint32_t)(st_g >> 32), fl, 64);
+        r.ok = true;
+        r.lr = lr0 + (rd + d) * (uint32_t)lstep; r.c = c0 + (cn + d) * (uint32_t)cstep;
+        r.kept = ix + d + 1; r.nmatch = mm + d + 1;
+        r.last_run = (uint64_t)glo | ((uint64_t)ghi << 32); r.kept_in_last = d + 1;
+        return r;
+    }
+    // not on an M: back to the last M run before the stop (lanes beyond the stopping one do not count)
+    const unsigned long long mMask = __ballot(haveM && (int)lane <= fl);
+    if (!mMask) return r;
+    const int ml = 63 - __builtin_clzll(mMask);
+    const uint32_t othStop = fl < 64 ? __shfl(st_oth, fl, 64) : __shfl(bOth + sOth, 63, 64);   // OTHER bases before the stop
+    const uint32_t rd = __shfl(m_read, ml, 64), mm = __shfl(m_m, ml, 64), ix = __shfl(m_idx, ml, 64), cn = __shfl(m_con, ml, 64), ln = __shfl(m_len, ml, 64),
+                   oa = __shfl(m_othAfter, ml, 64);
+    const uint32_t glo = __shfl((uint32_t)m_g, ml, 64), ghi = __shfl((uint32_t)(m_g >> 32), ml, 64);
+    const uint32_t other_extra = othStop - oa;
+    r.ok = true;
+    r.lr = lr0 + (rd + ln - 1) * (uint32_t)lstep;
+    r.c = c0 + (cn + ln - 1) * (uint32_t)cstep + other_extra * (uint32_t)cstep;
+    r.kept = ix + ln; r.nmatch = mm + ln;
+    r.last_run = (uint64_t)glo | ((uint64_t)ghi << 32); r.kept_in_last = ln;
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_chain_reads_wave(DevHits h, const uint64_t* __restrict__ rho, const uint8_t* __restrict__ cls, uint32_t n_contigs,
+                                                           uint32_t lr_begin, uint32_t lr_end, uint32_t min_block, double min_sim, uint32_t min_mapq,
+                                                           ChainScratch sc, uint32_t* err, const bool prefiltered) {
+    __shared__ WaveRows rows_all[4];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t r = lr_begin + blockIdx.x * 4u + wv;
+    if (r >= lr_end) return;
+    const uint64_t raw_b = rho[r], raw_e = rho[r + 1];
+    const uint32_t nraw = (uint32_t)(raw_e - raw_b);
+    if (raw_e - raw_b > 64) {   // more hits than lanes: the one-lane path
+        if (lane == 0) chain_read_serial(h, rho, cls, n_contigs, lr_begin, r, min_block, min_sim, min_mapq, sc, err, prefiltered);
+        return;
+    }
+    WaveRows& R = rows_all[wv];
+    const uint64_t base = raw_b - rho[lr_begin];
+    // ---- lane i = raw hit i: filters 1-4
+    const uint64_t x = raw_b + lane;
+    uint32_t tid = 0, qs = 0, qe = 0, ts = 0, te = 0, nm = 0, nb = 0, tl = 1;
+    bool pass = false;
+    if (lane < nraw) {
+        tid = h.t_id[x]; qs = h.q_start[x]; qe = h.q_end[x]; ts = h.t_start[x]; te = h.t_end[x]; nm = h.n_match[x]; nb = h.n_block[x]; tl = h.t_len[x];
+        if (tid >= n_contigs) atomicOr(err, (uint32_t)HXE_BAD_TID);
+        else pass = prefiltered || (nb >= min_block && !((double)nm / (double)nb < min_sim) && h.mapq[x] >= min_mapq && !(cls[tid] & HXC_DROP_LOAD));
+    }
+    const unsigned long long mpass = __ballot(pass);
+    uint32_t n = (uint32_t)__popcll(mpass);
+    uint32_t n_aln = 0, n_cmp = 0;
+    if (n > (prefiltered ? 0u : 1u)) {
+        // ---- rank among the survivors by (q_end, q_start), ties in PAF order (= lane order); an index.longread is in that order already
+        uint32_t rank = (uint32_t)__popcll(mpass & ((1ull << lane) - 1ull));
+        if (!prefiltered) {
+            rank = 0;
+            for (unsigned long long m = mpass; m; m &= m - 1) {
+                const int j = __builtin_ctzll(m);
+                const uint32_t je = (uint32_t)__builtin_amdgcn_readlane((int)qe, j), js = (uint32_t)__builtin_amdgcn_readlane((int)qs, j);
+                rank += (je < qe || (je == qe && (js < qs || (js == qs && (uint32_t)j < lane)))) ? 1u : 0u;
+            }
+        }
+        if (pass) R.perm[rank] = lane;
+        __builtin_amdgcn_wave_barrier();
+        // sorted lane p takes the row of the lane that ranked p
+        const int src = lane < n ? (int)R.perm[lane] : 0;
+        const uint32_t hx = (uint32_t)raw_b + (uint32_t)src;   // (low word; the row keeps the full raw index below)
+        tid = __shfl(tid, src, 64); qs = __shfl(qs, src, 64); qe = __shfl(qe, src, 64); ts = __shfl(ts, src, 64); te = __shfl(te, src, 64);
+        nm = __shfl(nm, src, 64); nb = __shfl(nb, src, 64); tl = __shfl(tl, src, 64);
+        (void)hx;
+        const bool in = lane < n;
+        // ---- palindrome rule: cut at the second hit of a unique contig
+        uint32_t keep = n;
+        if (!prefiltered) {
+            const bool uniq = in && (cls[tid] & HXC_UNIQUE);
+            bool dup = false;
+            for (uint32_t k = 0; k + 1 < n; k++) { const uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)tid, (int)k); dup = dup || (uniq && lane > k && tk == tid); }
+            const unsigned long long dm = __ballot(dup);
+            if (dm) keep = (uint32_t)__builtin_ctzll(dm);
+        }
+        // ---- filter 5: interior hits that cover less than 0.8 of their contig
+        const bool kept_row = lane < keep && !(!prefiltered && lane > 0 && lane + 1 < keep && (te - ts) / (double)tl < 0.8);
+        const unsigned long long km = __ballot(kept_row);
+        n_aln = (uint32_t)__popcll(km);
+        if (kept_row) {
+            const uint32_t o = (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+            const uint64_t raw = raw_b + (uint32_t)src;
+            R.hit[o] = (uint32_t)raw; R.qs[o] = qs; R.qe[o] = qe; R.ts[o] = ts; R.te[o] = te; R.nm[o] = nm; R.nb[o] = nb;
+            R.cb[o] = h.cg_off[raw]; R.ce[o] = h.cg_off[raw + 1]; R.skf[o] = 0; R.skb[o] = 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- overlap trim, left to right: both walks of a pair on all lanes, the row updates on lane 0
+        for (uint32_t i = 0; i + 1 < n_aln; i++) {
+            const uint32_t a = i, b = i + 1;
+            const uint32_t qe_a = R.qe[a], qs_b = R.qs[b];
+            if (!(qe_a > qs_b)) continue;
+            const long long ov = (long long)qe_a - (long long)qs_b;
+            {
+                const CgView v{h.cg_ops, R.cb[a], R.ce[a], R.skf[a], R.skb[a]};
+                const bool rev = h.is_rev[R.hit[a]];
+                const uint32_t target = (uint32_t)((long long)qe_a - ov / 2 - 1);
+                const TrimRes t = rev ? trim_walk_wave(v, true, R.qs[a], R.te[a] - 1, +1, -1, target, lane) : trim_walk_wave(v, false, R.qs[a], R.ts[a], +1, +1, target, lane);
+                if (!t.ok) { if (lane == 0) atomicOr(err, (uint32_t)HXE_TRIM_NO_M); continue; }
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) {
+                    R.qe[a] = t.lr + 1;
+                    if (rev) R.ts[a] = t.c; else R.te[a] = t.c + 1;
+                    R.nb[a] = t.kept; R.nm[a] = t.nmatch;
+                    const uint32_t raw = HX_CG_LEN(h.cg_ops[t.last_run]);
+                    if (!rev) { R.skb[a] = raw - (t.last_run == R.cb[a] ? R.skf[a] : 0) - t.kept_in_last; R.ce[a] = t.last_run + 1; }
+                    else      { R.skf[a] = raw - (t.last_run + 1 == R.ce[a] ? R.skb[a] : 0) - t.kept_in_last; R.cb[a] = t.last_run; }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            {
+                const CgView v{h.cg_ops, R.cb[b], R.ce[b], R.skf[b], R.skb[b]};
+                const bool rev = h.is_rev[R.hit[b]];
+                const uint32_t target = (uint32_t)((long long)qs_b + (ov - ov / 2));
+                const TrimRes t = rev ? trim_walk_wave(v, false, R.qe[b] - 1, R.ts[b], -1, +1, target, lane) : trim_walk_wave(v, true, R.qe[b] - 1, R.te[b] - 1, -1, -1, target, lane);
+                if (!t.ok) { if (lane == 0) atomicOr(err, (uint32_t)HXE_TRIM_NO_M); continue; }
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) {
+                    R.qs[b] = t.lr;
+                    if (rev) R.te[b] = t.c + 1; else R.ts[b] = t.c;
+                    R.nb[b] = t.kept; R.nm[b] = t.nmatch;
+                    const uint32_t raw = HX_CG_LEN(h.cg_ops[t.last_run]);
+                    if (rev) { R.skb[b] = raw - (t.last_run == R.cb[b] ? R.skf[b] : 0) - t.kept_in_last; R.ce[b] = t.last_run + 1; }
+                    else     { R.skf[b] = raw - (t.last_run + 1 == R.ce[b] ? R.skb[b] : 0) - t.kept_in_last; R.cb[b] = t.last_run; }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        // ---- chaining: weighted interval scheduling over the hits that pass Longread.cpp:535 and :539
+        const bool is_c = lane < n_aln && R.nb[lane] >= min_block && !(cls[h.t_id[R.hit[lane]]] & HXC_DROP_CHAIN);
+        const unsigned long long cmask = __ballot(is_c);
+        const uint32_t nu = (uint32_t)__popcll(cmask);
+        if (is_c) R.cand[__popcll(cmask & ((1ull << lane) - 1ull))] = lane;
+        __builtin_amdgcn_wave_barrier();
+        if (nu > 0) {
+            // candidate u = lane u: its row, and the latest candidate k < u that ends where u starts or before
+            const uint32_t row = lane < nu ? R.cand[lane] : 0;
+            const uint32_t uqs = R.qs[row], uqe = R.qe[row], unm = R.nm[row];
+            int32_t jp = -1;
+            for (uint32_t k = 0; k + 1 < nu; k++) { const uint32_t ke = (uint32_t)__builtin_amdgcn_readlane((int)uqe, (int)k); if (lane > k && ke <= uqs) jp = (int32_t)k; }
+            // the recurrence, on wave-uniform values: take u iff its weight plus the best before its predecessor beats the best without it (strict)
+            uint32_t dpv = 0;     // lane u: dp[u]
+            uint32_t take = 0;    // lane u: 1 = u is in the solution that ends at or before u
+            uint32_t best = 0;
+            for (uint32_t u = 0; u < nu; u++) {
+                const int32_t j = __builtin_amdgcn_readlane(jp, (int)u);
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)unm, (int)u) + (j >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)dpv, j) : 0u);
+                const bool tk = u == 0 || w > best;
+                if (tk) best = w;
+                if (lane == u) { dpv = best; take = tk ? 1u : 0u; }
+            }
+            // walk back from the last candidate
+            uint32_t cnt = 0;
+            for (int32_t u = (int32_t)nu - 1; u >= 0;) {
+                if (!__builtin_amdgcn_readlane((int)take, u)) { u--; continue; }
+                if (lane == 0) R.sol[cnt] = (uint32_t)__builtin_amdgcn_readlane((int)row, u);
+                cnt++;
+                u = __builtin_amdgcn_readlane(jp, u);
+            }
+            n_cmp = cnt;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < cnt) sc.cmp[base + lane] = R.sol[cnt - 1 - lane];   // (found last to first)
+        }
+        // ---- the rows, once, coalesced
+        if (lane < n_aln) {
+            const uint64_t o = base + lane;
+            sc.hit[o] = R.hit[lane]; sc.qs[o] = R.qs[lane]; sc.qe[o] = R.qe[lane]; sc.ts[o] = R.ts[lane]; sc.te[o] = R.te[lane];
+            sc.nm[o] = R.nm[lane]; sc.nb[o] = R.nb[lane]; sc.cb[o] = R.cb[lane]; sc.ce[o] = R.ce[lane]; sc.skf[o] = R.skf[lane]; sc.skb[o] = R.skb[lane];
+        }
+    }
+    if (lane == 0) { sc.n_aln[r - lr_begin] = n_aln; sc.n_cmp[r - lr_begin] = n_cmp; }
+}
+
 __global__ void k_chain_compact(ChainScratch sc, const uint64_t* __restrict__ rho, uint32_t lr_begin, uint32_t lr_end,
                                 const uint64_t* __restrict__ aln_off, const uint64_t* __restrict__ cmp_off, ChainFinal out) {
     uint32_t r = lr_begin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -237,8 +479,7 @@ __global__ void k_chain_compact(ChainScratch sc, const uint64_t* __restrict__ rh
 void chain_reads(const DevHits& h, const uint64_t* rho, const uint8_t* cls, uint32_t n_contigs, uint32_t lr_begin, uint32_t lr_end,
                  uint32_t min_aln_block, double min_aln_sim, uint32_t min_mapq, const ChainScratch& sc, uint32_t* err, bool prefiltered, hipStream_t s) {
     uint32_t n = lr_end - lr_begin;
-    const uint32_t spread = n <= 16384 ? 4 : n <= 65536 ? 2 : 1;
-    if (n) k_chain_reads<<<(uint32_t)(((uint64_t)n * spread + 63) / 64), 64, 0, s>>>(h, rho, cls, n_contigs, lr_begin, lr_end, min_aln_block, min_aln_sim, min_mapq, sc, err, spread, prefiltered);
+    if (n) k_chain_reads_wave<<<(n + 3) / 4, 256, 0, s>>>(h, rho, cls, n_contigs, lr_begin, lr_end, min_aln_block, min_aln_sim, min_mapq, sc, err, prefiltered);
 }
 
 void chain_compact(const ChainScratch& sc, const uint64_t* rho, uint32_t lr_begin, uint32_t lr_end, const uint64_t* aln_off,
