@@ -139,40 +139,58 @@ struct GfaWriters {
 
 static int run_graph(Run& r) {
     double t0 = now();
+    // HASLR_GRAPH_DEBUG=1: where the host graph stage spends its time (stderr)
+    const bool dbg = getenv("HASLR_GRAPH_DEBUG") != nullptr;
+    double tl = t0;
+    auto lap = [&](const char* what) { if (dbg) { const double t = now(); fprintf(stderr, "[hxh] graph stage: %-28s %7.1f ms\n", what, (t - tl) * 1e3); tl = t; } };
     GfaWriters gfa;
     if (r.have_edges) r.be.free_edges(r.be.ctx, &r.edges), r.have_edges = false;
     if (r.be.edge_support(r.be.ctx, &r.prm, &r.edges) != 0) return backend_fail(r, "edge_support");
     r.have_edges = true;
+    lap("edge_support (backend)");
     const Dataset& d = *r.d;
     Graph& g = r.g;
     graph_build(g, (uint32_t)d.contig_len.size(), r.edges);
+    lap("build");
     graph_write_stats(g, d, r.path("backbone.01.init.stat"));
     gfa.start(r, "backbone.01.init.gfa");
+    lap("stat + gfa 01");
     int nb = graph_remove_weak_edges(g, r.prm.min_edge_sup);
     if (!r.out_dir.empty()) fprintf(stderr, "       removed %d edges\n", nb);
+    lap("weak edges");
     graph_write_stats(g, d, r.path("backbone.02.weakEdge.stat"));
     gfa.start(r, "backbone.02.weakEdge.gfa");
+    lap("stat + gfa 02");
     nb = clean_tips(g, 1, r.path("backbone.03.tip.log"));
     nb += clean_tips(g, 2, r.path("backbone.03.tip.log"));
     nb += clean_tips(g, 3, r.path("backbone.03.tip.log"));
     if (!r.out_dir.empty()) fprintf(stderr, "       removed %d tips\n", nb);
+    lap("tips x3");
     graph_write_stats(g, d, r.path("backbone.03.tip.stat"));
     gfa.start(r, "backbone.03.tip.gfa");
+    lap("stat + gfa 03");
     nb = clean_simple_bubbles(g, 4, r.path("backbone.04.simplebubble.log"));
     if (!r.out_dir.empty()) fprintf(stderr, "       removed %d simple bubbles\n", nb);
+    lap("simple bubbles");
     graph_write_stats(g, d, r.path("backbone.04.simplebubble.stat"));
     gfa.start(r, "backbone.04.simplebubble.gfa");
+    lap("stat + gfa 04");
     nb = clean_super_bubbles(g, r.path("backbone.05.superbubble.log"));
     if (!r.out_dir.empty()) fprintf(stderr, "       removed %d super bubbles\n", nb);
+    lap("super bubbles");
     graph_write_stats(g, d, r.path("backbone.05.superbubble.stat"));
     gfa.start(r, "backbone.05.superbubble.gfa");
+    lap("stat + gfa 05");
     nb = clean_small_bubbles(g, r.path("backbone.06.smallbubble.log"));
     if (!r.out_dir.empty()) fprintf(stderr, "       removed %d small bubbles\n", nb);
+    lap("small bubbles");
     graph_write_stats(g, d, r.path("backbone.06.smallbubble.stat"));
     gfa.start(r, "backbone.06.smallbubble.gfa");
     graph_report_branching(g, r.path("backbone.branching.log"));
+    lap("stat + gfa 06 + branching");
     for (auto& t : gfa.th) t.join();
     gfa.th.clear();
+    lap("gfa writers joined");
     r.t[1] = now() - t0;
     return 0;
 }

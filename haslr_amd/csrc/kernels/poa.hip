@@ -682,6 +682,11 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 for (int k = 0; k < CM; k++) hp[k] <<= 6;
                 if (gt > 0) left <<= 6;
             }
+            // the loaded values are consumed HERE: otherwise the wait for them is placed where the three sources of a predecessor row
+            // join - on the path of every row - and waits for the previous rows' direction stores as well (vmcnt counts them)
+#pragma unroll
+            for (int k = 0; k < CM; k++) asm volatile("" : "+v"(hp[k]));
+            asm volatile("" : "+v"(left));
         } else {
 #pragma unroll
             for (int k = 0; k < CM; k++) hp[k] = NEGK;
