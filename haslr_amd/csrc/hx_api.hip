@@ -983,6 +983,13 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
             unsigned long long cr[12][4] = {};
             for (size_t e = 0; e < ne; e++) { const int k = e < c->dbg_cls.size() ? c->dbg_cls[e] : 11; const unsigned long long* q3 = &c->poa_phase[e * 12]; cr[k][0] += q3[6]; cr[k][1] += q3[10]; cr[k][2] += q3[8]; cr[k][3] += q3[9]; }
             for (int k = 0; k < 12; k++) if (cr[k][0]) fprintf(stderr, "[hx] class %d (ring %u): DP rows %llu, kept %.1f %%, ring refs %.1f %%, far refs %.2f %%\n", k, k < 11 ? c->dbg_ring[k] : 0, cr[k][0], 100.0 * cr[k][1] / cr[k][0], 100.0 * cr[k][2] / cr[k][0], 100.0 * cr[k][3] / cr[k][0]);
+            unsigned long long cy[12][4] = {};   // edges, all cycles, DP cycles, longest edge
+            for (size_t e = 0; e < ne; e++) {
+                const int k = e < c->dbg_cls.size() ? c->dbg_cls[e] : 11; const unsigned long long* q3 = &c->poa_phase[e * 12];
+                unsigned long long t = 0; for (int j = 0; j < 6; j++) t += q3[j];
+                cy[k][0]++; cy[k][1] += t; cy[k][2] += q3[1]; cy[k][3] = std::max(cy[k][3], t);
+            }
+            for (int k = 0; k < 12; k++) if (cy[k][0]) fprintf(stderr, "[hx] class %d: %llu workgroups, %.3e cycles in all (DP %.0f %%), longest %.3e, DP cycles per row %.0f\n", k, cy[k][0], (double)cy[k][1], 100.0 * cy[k][2] / cy[k][1], (double)cy[k][3], cr[k][0] ? (double)cy[k][2] / cr[k][0] : 0.0);
         }
         unsigned long long tot[6] = {0, 0, 0, 0, 0, 0};
         for (size_t e = 0; e < ne; e++) for (int k = 0; k < 6; k++) tot[k] += k == 5 ? (c->poa_phase[e * 12 + 11] & 0xffffffffull) : c->poa_phase[e * 12 + 6 + k];

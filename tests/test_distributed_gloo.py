@@ -1,10 +1,11 @@
-"""world_size-2 CPU tests (gloo) of the multi-GPU path. The per-shard compute is done by the CPU oracle here (no GPU in
+"""world_size-2 (and one world_size-4) CPU tests (gloo) of the multi-GPU path. The per-shard compute is done by the CPU oracle here (no GPU in
 this container); everything around it is the product's: haslr_amd.distributed (read shards, the record all-gather,
 ShardedBackend, the results all-gather, run_sharded) and the host pipeline's edge sharding / results export + import /
 stitching (libhaslr_host.so).
   * the exchanged record multiset equals the unsharded one
   * a whole sharded pass writes the same asm.final.fa / .ann, the same six GFAs, stats, logs and compact_uniq.txt as one rank
-  * stitching refuses to run while other ranks' results are missing"""
+  * stitching refuses to run while other ranks' results are missing
+  * more ranks than edges: ranks without work still take part in both all-gathers and stitch the same assembly"""
 import os
 import subprocess
 import sys
@@ -136,8 +137,15 @@ be = hd.ShardedBackend(ob.table, OracleRecords())
 dev = torch.device("cpu")
 run = hd.run_sharded(ds, prm, be, b[rank], rank, world, dev, out_dir=out if rank == 0 else None, assemble=False)
 assert be.error is None
-assert run.results_missing == 0 and run.n_edges_total > 4
-assert 0 < run.n_edges < run.n_edges_total, (run.n_edges, run.n_edges_total)   # every rank worked on a part of the queue only
+loose = os.environ.get("HASLR_TEST_IDLE_RANKS") is not None     # more ranks than edges: some ranks have nothing to compute
+assert run.results_missing == 0 and run.n_edges_total > (0 if loose else 4)
+if not loose:
+    assert 0 < run.n_edges < run.n_edges_total, (run.n_edges, run.n_edges_total)   # every rank worked on a part of the queue only
+counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+dist.all_gather(counts, torch.tensor([run.n_edges], dtype=torch.int64))
+assert sum(int(c) for c in counts) == run.n_edges_total               # the shares partition the work queue
+if loose:
+    assert min(int(c) for c in counts) == 0, [int(c) for c in counts]
 run.assemble()
 fa = run.assembly_fasta()
 # a run that has not been given the other ranks' results must refuse to stitch
@@ -145,11 +153,12 @@ lone = host.Run(ds, prm, be.table, None)
 lone.set_edge_shard(rank, world); lone.set_read_shard(b[rank])
 lone.chain(); lone.graph(); lone.coords(); lone.consensus()
 assert lone.results_missing == run.n_edges_total - run.n_edges
-try:
-    lone.assemble()
-    raise SystemExit("assemble accepted an incomplete result set")
-except host.HostError as e:
-    assert "have no coordinates" in str(e), str(e)
+if lone.results_missing:
+    try:
+        lone.assemble()
+        raise SystemExit("assemble accepted an incomplete result set")
+    except host.HostError as e:
+        assert "have no coordinates" in str(e), str(e)
 # all ranks stitched the same assembly
 h = torch.frombuffer(bytearray(hashlib.sha256(fa.encode()).digest()), dtype=torch.uint8)
 hs = [torch.zeros(32, dtype=torch.uint8) for _ in range(world)]
@@ -182,4 +191,28 @@ def test_two_rank_pipeline_writes_the_single_rank_outputs(sim, built, tmp_path):
     assert sorted(os.listdir(out2)) == names
     assert util.compare_dirs(out1, out2) == []
     assert len(run.assembly_fasta()) > 50000 and run.n_edges > 8
+    run.close(); ob.close(); ds.close()
+
+
+def test_four_ranks_some_without_edges(sim, built, tmp_path):
+    """A data set with fewer surviving edges than ranks: the idle ranks contribute empty result blobs (and possibly no
+    records), every rank still ends with the single-rank assembly."""
+    import orclib
+    import util
+    from haslr_amd import host
+    pre = sim("--genome-len", "26000", "--seed", "12", "--cov", "7", "--gap-median", "400")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    ob = orclib.OracleBackend(ds, 2)
+    out1 = str(tmp_path / "one_rank")
+    run = host.Run(ds, ds.params(), ob.table, out1)
+    run.all()
+    assert 0 < run.n_edges < 4, run.n_edges        # (the point of the case; pick another seed if the simulator changes)
+    w = tmp_path / "worker_full.py"
+    w.write_text(FULL_WORKER)
+    out4 = str(tmp_path / "four_ranks")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HASLR_TEST_IDLE_RANKS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+                        "--master-port", "29523", str(w), ROOT, pre, out4], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert util.compare_dirs(out1, out4) == []
     run.close(); ob.close(); ds.close()

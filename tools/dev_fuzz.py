@@ -15,12 +15,14 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = hip.HipContext(0)
 os.makedirs('/tmp/fz', exist_ok=True)
 bad = 0
-KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS', 'HX_POA_BATCHES', 'HX_POA_NODE_EST_PCT')
+KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS', 'HX_POA_BATCHES', 'HX_POA_NODE_EST_PCT', 'HX_POA_RING_KB', 'HX_POA_COLS', 'HX_POA_CLUSTER_TOPK')
 for it in range(n):
     big = os.environ.get('FUZZ_BIG') is not None   # long gaps at real sizes: the default launch shapes (512-lane cluster members) get real work
     glen = rng.choice([400000, 700000, 1000000]) if big else rng.choice([40000, 60000, 90000, 150000, 250000])
     args = ['--genome-len', str(glen), '--seed', str(rng.randrange(1, 10**6)), '--model', rng.choice(['pacbio', 'nanopore', 'pacbio']), '--cov', str(rng.choice([8, 15, 25, 40, 70])),
             '--variant-per-mb', str(rng.choice([0, 5, 30])), '--gap-median', str(rng.choice([2500, 4000, 6000]) if big else rng.choice([300, 600, 1500, 3000])), '--out-prefix', '/tmp/fz/s']
+    if rng.random() < 0.3:
+        args[-2:-2] = ['--hairpin-frac', str(rng.choice([0.02, 0.1]))]
     subprocess.check_call([ROOT + '/tools/hxsim'] + args, stderr=subprocess.DEVNULL)
     env = {}
     shape = rng.choice(['default', 'default', 'small-members', 'block']) if big else rng.choice(['default', 'small-members', 'one-wave', 'block'])
@@ -38,6 +40,12 @@ for it in range(n):
         env['HX_POA_FAR_ROWS'] = str(rng.choice([0, 1, 4, 16]))
     if rng.random() < 0.3:
         env['HX_POA_BATCHES'] = str(rng.choice([2, 3, 7]))
+    if rng.random() < 0.3:
+        env['HX_POA_RING_KB'] = str(rng.choice([1, 3, 7, 11]))      # small LDS rings: many far rows, rings without kept rows
+    if rng.random() < 0.3:
+        env['HX_POA_COLS'] = str(rng.choice([4, 8, 16]))
+    if rng.random() < 0.2:
+        env['HX_POA_CLUSTER_TOPK'] = str(rng.choice([0, 2, 1000]))
     if rng.random() < 0.25:
         env['HX_POA_NODE_EST_PCT'] = str(rng.choice([2, 10, 30, 60]))
     os.environ.update(env)
