@@ -767,9 +767,11 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             };
             for (uint32_t e : batch) {
                 const uint32_t ncol = P.edges[e].lmax + 1;
-                if (ncol > (uint64_t)cl_max * cl_lanes * hxk::poa_kernel_max_cm((int)cl_lanes) || ncol >= (1u << 20))
-                    return fail("hx_poa_batch: a gap sub-sequence of " + std::to_string(ncol - 1) + " bases is longer than the POA kernel's shared mode holds (" +
-                                std::to_string((uint64_t)cl_max * cl_lanes * hxk::poa_kernel_max_cm((int)cl_lanes) - 1) + " with HX_POA_CLUSTER_MAX x HX_POA_MEMBER_LANES x 32 columns per lane)");
+                // widest row: the shared mode (members x lanes x columns per lane), or one 1024-lane workgroup when the members were made small
+                const uint64_t col_cap = std::max<uint64_t>((uint64_t)cl_max * cl_lanes * hxk::poa_kernel_max_cm((int)cl_lanes), 1024ull * hxk::poa_kernel_max_cm(1024));
+                if (ncol > col_cap || ncol >= (1u << 20))
+                    return fail("hx_poa_batch: a gap sub-sequence of " + std::to_string(ncol - 1) + " bases is longer than the POA kernel holds (" +
+                                std::to_string(col_cap - 1) + " with HX_POA_CLUSTER_MAX x HX_POA_MEMBER_LANES x 32 columns per lane)");
                 if (P.edges[e].members > 1) {
                     const uint32_t cmr = cm_round(ncol, P.edges[e].members * cl_lanes);
                     if (cmr > (uint32_t)hxk::poa_kernel_max_cm((int)cl_lanes)) return fail("hx_poa_batch: gap too long for the configured cluster size (raise HX_POA_CLUSTER_MAX)");
@@ -946,6 +948,7 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
     for (int k = 0; k < 6; k++) { sum6[k] = 0; max6[k] = 0; }
     unsigned long long best = 0;
     size_t ne = c->poa_phase.size() / 12;
+    for (size_t e = 0; e < ne; e++) for (int k = 0; k < 6; k++) if ((long long)c->poa_phase[e * 12 + k] < 0) c->poa_phase[e * 12 + k] = 0;   // (a phase that began and ended on different waves' clocks)
     for (size_t e = 0; e < ne; e++) {
         unsigned long long t = 0;
         for (int k = 0; k < 6; k++) { sum6[k] += c->poa_phase[e * 12 + k]; t += c->poa_phase[e * 12 + k]; }
