@@ -646,21 +646,32 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     uint32_t nsink = 0;
     // row records of 64 rows per register: the current batch (C), the next one (N, complete with the third and fourth predecessor entries
     // of the rows that have them - a gather that needs the records first), and the one after it (F) in flight
-    uint32_t mC = 0, aC = 0, bC = 0, oC = 0, cC = 0, dC = 0, mN = 0, aN = 0, bN = 0, oN = 0, cN = 0, dN = 0, mF = 0, aF = 0, bF = 0, oF = 0;
+    uint32_t mC = 0, aC = 0, bC = 0, oC = 0, cC = 0, dC = 0, fC = 0, mN = 0, aN = 0, bN = 0, oN = 0, cN = 0, dN = 0, fN = 0, mF = 0, aF = 0, bF = 0, oF = 0;
     auto fetch = [&](uint32_t base, uint32_t& m, uint32_t& a, uint32_t& b, uint32_t& o) {
         const uint32_t r = base + lane;
         if (r < V) { m = g.row_meta[r]; a = g.row_pred0[r]; b = g.row_pred1[r]; o = g.row_pred_off[r]; }
     };
-    auto fetch_more = [&](uint32_t base, uint32_t m, uint32_t o, uint32_t& c, uint32_t& d) {
-        if (base + lane < V) { if ((m >> 8) > 2u) c = g.pred_rank[o + 2]; if ((m >> 8) > 3u) d = g.pred_rank[o + 3]; }
+    // Second stage, a batch ahead of its use. Everything that would otherwise be a DEPENDENT load on the row's own path is gathered here:
+    // the third and fourth predecessor entries, and (direction-byte flavour) the H slots of far rows - a far first / second predecessor
+    // entry gets its slot in place of the rank (the row loop never needs the rank), a row that is stored for a far reader its own slot.
+    auto fetch_more = [&](uint32_t base, uint32_t m, uint32_t o, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d, uint32_t& f) {
+        if (base + lane < V) {
+            if ((m >> 8) > 2u) c = g.pred_rank[o + 2];
+            if ((m >> 8) > 3u) d = g.pred_rank[o + 3];
+            if (DIR) {
+                if ((a >> 28) == 15u) a = 0xf0000000u | farslot[a & 0x0fffffffu];
+                if ((b >> 28) == 15u && (m >> 8) > 1u) b = 0xf0000000u | farslot[b & 0x0fffffffu];
+                if (m & 8u) f = farslot[base + lane];
+            }
+        }
     };
     fetch(0, mN, aN, bN, oN);
     fetch(64, mF, aF, bF, oF);
-    fetch_more(0, mN, oN, cN, dN);
+    fetch_more(0, mN, oN, aN, bN, cN, dN, fN);
     int32_t* hrow = H;
     uint8_t* drow = D;
     // predecessor row `ent` (slot << 28 | rank): its columns under this lane and the value left of them
-    auto pred_row = [&](const uint32_t ent, int (&hp)[CM], int& left) {
+    auto pred_row = [&](const uint32_t ent, int (&hp)[CM], int& left, const bool slot_known) {
         const uint32_t loc = ent >> 28;
         if (__builtin_expect(loc < 14u, 1)) {    // in the LDS ring
             const int32_t* S = ring_me + (size_t)(loc - 1) * ring_w;
@@ -673,10 +684,10 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             left = gt > 0 ? jg0 - g64 : NEGK;
         } else if (live) {                       // kept row that fell out of the ring: HBM
             // with direction bytes only the rows a far successor reads are in HBM, in the slots the CSR build gave them
-            const uint32_t hr = DIR ? farslot[ent & 0x0fffffffu] : (ent & 0x0fffffffu) + 1;
+            const uint32_t hr = DIR ? (slot_known ? ent & 0x0fffffffu : farslot[ent & 0x0fffffffu]) : (ent & 0x0fffffffu) + 1;
             const int32_t* Gp = H + (uint64_t)hr * WH + j0;
             load_chunk_i32<CM>(Gp, hp);
-            left = lane > 0 ? Gp[-1] : has_in ? H[(uint64_t)hr * WH + hleft] : NEGK;   // (lane 0: the wave's own copy - the column belongs to a wave that may be far ahead)
+            left = lane > 0 ? Gp[-1] : has_in ? Gp[(int64_t)hleft - (int64_t)j0] : NEGK;   // (lane 0: the wave's own copy - the column belongs to a wave that may be far ahead)
             if (!DIR) {                          // the score matrix holds plain scores
 #pragma unroll
                 for (int k = 0; k < CM; k++) hp[k] <<= 6;
@@ -695,10 +706,10 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     };
     for (uint32_t ib = 0; ib < V; ib += 64) {
         // the batches move up (the only waits for these loads: everything was requested at least 64 rows ago), another one goes in flight
-        mC = mN; aC = aN; bC = bN; oC = oN; cC = cN; dC = dN;
+        mC = mN; aC = aN; bC = bN; oC = oN; cC = cN; dC = dN; fC = fN;
         mN = mF; aN = aF; bN = bF; oN = oF;
         fetch(ib + 128, mF, aF, bF, oF);
-        fetch_more(ib + 64, mN, oN, cN, dN);
+        fetch_more(ib + 64, mN, oN, aN, bN, cN, dN, fN);
         const uint32_t ie = min(64u, V - ib);
         for (uint32_t rb = 0; rb < ie; rb += CARRY_BATCH) {
             const uint32_t nb = min(CARRY_BATCH, ie - rb), i0 = ib + rb + 1;   // rows i0 .. i0 + nb - 1
@@ -754,7 +765,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 int m[CM];
                 {   // the first predecessor (or row 0): diagonal and vertical move
                     int hp[CM], left;
-                    pred_row(p0, hp, left);
+                    pred_row(p0, hp, left, true);
 #pragma unroll
                     for (int k = 0; k < CM; k++) m[k] = max((k == 0 ? left : hp[k - 1]) + score_of(k), hp[k] + gv);
                 }
@@ -768,7 +779,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                                                     : (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[po + p]);
                         const int ps = DIR ? (int)p : 0;        // direction bytes exist only while in-degrees stay <= 16 (the CSR build checks)
                         int hp[CM], left;
-                        pred_row(ent, hp, left);
+                        pred_row(ent, hp, left, p == 1);
 #pragma unroll
                         for (int k = 0; k < CM; k++) m[k] = max(m[k], max((k == 0 ? left : hp[k - 1]) + score_of(k) - ps, hp[k] + (gv - ps)));
                     }
@@ -824,11 +835,11 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 if (__builtin_expect((meta & (8u | 4u)) != 0, 0)) {
                     if (meta & 8u) {   // a far successor reads this row back from HBM (keys; with the score matrix it is there already)
                         if (DIR && live) {
-                            int32_t* F = H + (uint64_t)farslot[i - 1] * WH;
+                            int32_t* F = H + (uint64_t)__builtin_amdgcn_readlane(fC, ri) * WH;
                             store_chunk_i32<CM>(F + j0, t);
                             if (lane == 0 && has_in) F[hleft] = left_now;
                         }
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row has left this wave before a later row reads it back
+                        // (no wait: only this wave reads these words back, and a wave's memory instructions reach the cache in program order)
                     }
                     if (owns_last && (meta & 4u)) {   // sink node: candidate end of the global alignment
                         int v = NEGK;
