@@ -39,6 +39,7 @@ SEED0 = 0x4841534C                                # seed = 0x48415
 WORKLOADS = {
     "yeast": dict(config=2, genome=12_000_000, model="nanopore", name="S. cerevisiae-size synthetic", variants="1.5"),
     "ecoli": dict(config=1, genome=4_600_000, model="pacbio", name="E. coli-size synthetic", variants="1.5"),
+    "fly": dict(config=3, genome=140_000_000, model="pacbio", name="D. melanogaster-size synthetic", variants="1.5"),
 }
 HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9         # 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz (int32 VALU issue bound)
@@ -238,6 +239,15 @@ def main():
         assembly["same_on_all_ranks"] = all(bool(torch.equal(hs[0], x)) for x in hs)
         assembly["results_gathered_bytes"] = gathered[0]
         assembly["edge_record_exchange_bytes"] = backend.exchange_bytes
+        if backend_name == "gloo" and dist.get_world_size() > 1:
+            # rehearsal mode (all ranks on one device): the single-GPU pass needs the memory the other ranks' workspaces hold
+            last.close()
+            ctx.close()
+            torch.cuda.empty_cache()
+            dist.barrier()
+            if rank == 0:
+                ctx = hip.HipContext(dev_index)
+                ctx.upload(ds)
         if rank == 0:
             last.close()
             ctx.set_read_shard(0, ds.reads.n)
