@@ -29,13 +29,14 @@ namespace {
 constexpr uint32_t NONE = 0xffffffffu;
 constexpr int32_t NEG = -(1 << 29);
 
+constexpr uint32_t META_SLOT = 8, META_NP = 12;   // row record: ring slot the row is written to (4 bits; 15 = not written), number of predecessors
 struct G {   // per-edge views into the pools
     uint8_t *code, *n_aligned; uint32_t* aligned;
     uint32_t *in_head, *in_tail, *out_head, *out_tail, *rank2node, *node2rank;
     uint8_t *mark, *check; uint32_t* stack;
     int32_t *score, *pred;
     uint8_t *row_code, *row_sink; uint32_t *row_pred_off, *pred_rank;
-    uint32_t *row_meta, *row_pred0, *row_pred1;   // per rank: code | sink<<2 | far<<3 | npred<<8 ; ranks of the first two predecessors
+    uint32_t *row_meta, *row_pred0, *row_pred1;   // per rank: code | sink<<2 | far<<3 | kept<<4 | wide<<5 | own ring slot<<8 | npred<<12 (META_SLOT, META_NP) ; ranks of the first two predecessors
     uint16_t* row_al;                             // per rank: aligned nodes in list order as rank deltas (3 x 3 bits, delta + 4, 0 = none)
     uint32_t* wslot;                              // per rank: row of the wide-row pool (rows with more than 4 predecessors: a direction byte per cell)
     uint4* nrec;   // per node, one 16-byte record for the serial graph walks: {1st in-edge source, 2nd in-edge source, 3 aligned ids (+1) x 21 bit, bit 63: more in-edges}
@@ -229,7 +230,7 @@ __device__ void toposort_rank(G& g, const uint32_t V, uint8_t* st /* by rank */,
                 if (lane == 0) tags[slot] = line;
             }
             const uint4 rv = cache[slot * 16 + (n & 15u)];
-            const uint32_t npred = (uint32_t)__builtin_amdgcn_readfirstlane((int)rv.x) >> 8;
+            const uint32_t npred = (uint32_t)__builtin_amdgcn_readfirstlane((int)rv.x) >> META_NP;
             const uint32_t alp = (uint32_t)__builtin_amdgcn_readfirstlane((int)rv.w);
             const bool chk = sn & 4u;
             const uint32_t spb = sp;
@@ -589,12 +590,16 @@ template <int CM> __device__ __forceinline__ void store_nibbles(uint8_t* p, cons
 // arithmetic.
 template <int CM, bool DIR>
 __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, uint8_t* __restrict__ Dwide, const uint32_t W, const uint32_t WH, const uint8_t* __restrict__ seq,
-                        const uint32_t L, const uint32_t V, int32_t* ring, const uint32_t R, const uint32_t ring_w, const int match, const int mismatch, const int gap,
+                        const uint32_t L_, const uint32_t V_, int32_t* ring, const uint32_t R_, const uint32_t ring_w_, const int match, const int mismatch, const int gap,
                         unsigned long long* wm_box, uint32_t* wm_cons, uint32_t* sink_row, int* sink_score, const uint32_t sink_cap, uint32_t& nSinkOut, const DpCl& cl, unsigned long long* prof) {
 #if defined(HX_DP_PROF) && !defined(HX_DP_PROF2)
     long long tprev = clock64();
 #endif
-    const uint32_t tid = threadIdx.x, NT = blockDim.x, lane = tid & 63u, wv = tid >> 6, NW = NT >> 6;
+    // wave-uniform values the compiler cannot know to be uniform (they come through LDS / integer division / the thread index): in scalar
+    // registers they turn the loop control, the ring slot arithmetic and the carry hand-over into scalar instructions and branches
+    const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)L_), V = (uint32_t)__builtin_amdgcn_readfirstlane((int)V_);
+    const uint32_t R = (uint32_t)__builtin_amdgcn_readfirstlane((int)R_), ring_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)ring_w_);
+    const uint32_t tid = threadIdx.x, NT = blockDim.x, lane = tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), NW = NT >> 6;
     const uint32_t ncol = L + 1;
     const uint32_t gw = cl.mem * NW + wv;                                     // this wave's place in the edge's pipeline
     if ((uint64_t)gw * 64u * CM >= ncol) return;                              // the wave owns no real column of this sequence
@@ -628,10 +633,11 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     }
     const int mm64 = mismatch * 64, g64 = gap * 64, m64 = match * 64;
     const int jg0 = (int)j0 * g64;
-    // Every row a later row reads lives in the LDS ring: R slots for the kept rows (read by a non-adjacent successor) in the order they are
-    // produced, slot R for the latest row nobody keeps (only the next row can want it). A predecessor reference is a slot number
-    // (1 + slot, from the CSR build; 14 = the virtual row 0 that source nodes start from, 15 = a kept row that left the ring: HBM), so a
-    // row is straight-line code whatever its predecessors are: no dispatch on row types, no register path. Per wave: CM planes of 65 words, column t*CM+k at word 65*CM*wv + 65*k + 1 + t;
+    // The previous row is still in the registers of the lanes that own its columns (tp, lnp): a successor that follows it immediately
+    // reads it there - no LDS round trip on the most common dependency. Every row a NON-adjacent successor reads ("kept") lives in the LDS
+    // ring, R slots in the order they are produced; rows nobody else reads are not written at all. A predecessor reference is a code from
+    // the CSR build (1 + ring slot; 13 = the previous row; 14 = the virtual row 0 that source nodes start from; 15 = a kept row that left
+    // the ring: HBM), the row's own slot sits in its record. Per wave: CM planes of 65 words, column t*CM+k at word 65*CM*wv + 65*k + 1 + t;
     // word 0 of the wave's LAST plane holds the value left of the wave's first column, so "the column left of my chunk" is word
     // 65*(CM-1) + t for EVERY lane: one load, no select. Plane offsets are instruction offsets of ONE address register per slot.
     constexpr uint32_t PW = 65u;
@@ -642,7 +648,6 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
         for (int k = 0; k < CM; k++) pl[k] = (jg0 + k * g64) >> 6;
         store_chunk_i32<CM>(H + j0, pl);
     }
-    uint32_t nkept = 0;                                 // kept rows produced so far (ring slot counter; mirrors the CSR build)
     uint32_t nsink = 0;
     // row records of 64 rows per register: the current batch (C), the next one (N, complete with the third and fourth predecessor entries
     // of the rows that have them - a gather that needs the records first), and the one after it (F) in flight
@@ -656,11 +661,11 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     // entry gets its slot in place of the rank (the row loop never needs the rank), a row that is stored for a far reader its own slot.
     auto fetch_more = [&](uint32_t base, uint32_t m, uint32_t o, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d, uint32_t& f) {
         if (base + lane < V) {
-            if ((m >> 8) > 2u) c = g.pred_rank[o + 2];
-            if ((m >> 8) > 3u) d = g.pred_rank[o + 3];
+            if ((m >> META_NP) > 2u) c = g.pred_rank[o + 2];
+            if ((m >> META_NP) > 3u) d = g.pred_rank[o + 3];
             if (DIR) {
                 if ((a >> 28) == 15u) a = 0xf0000000u | farslot[a & 0x0fffffffu];
-                if ((b >> 28) == 15u && (m >> 8) > 1u) b = 0xf0000000u | farslot[b & 0x0fffffffu];
+                if ((b >> 28) == 15u && (m >> META_NP) > 1u) b = 0xf0000000u | farslot[b & 0x0fffffffu];
                 if (m & 8u) f = farslot[base + lane];
             }
         }
@@ -671,9 +676,16 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     int32_t* hrow = H;
     uint8_t* drow = D;
     // predecessor row `ent` (slot << 28 | rank): its columns under this lane and the value left of them
+    int tp[CM], lnp = NEGK;                  // the previous row's finished keys under this lane, and the key left of the wave's first column (lane 0's is used)
+#pragma unroll
+    for (int k = 0; k < CM; k++) tp[k] = NEGK;
     auto pred_row = [&](const uint32_t ent, int (&hp)[CM], int& left, const bool slot_known) {
         const uint32_t loc = ent >> 28;
-        if (__builtin_expect(loc < 14u, 1)) {    // in the LDS ring
+        if (loc == 13u) {                        // the previous row: registers
+#pragma unroll
+            for (int k = 0; k < CM; k++) hp[k] = tp[k];
+            left = wave_shift_up1(tp[CM - 1], lnp);
+        } else if (__builtin_expect(loc < 13u, 1)) {    // in the LDS ring
             const int32_t* S = ring_me + (size_t)(loc - 1) * ring_w;
 #pragma unroll
             for (int k = 0; k < CM; k++) hp[k] = S[k * PW + 1];
@@ -740,7 +752,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             for (uint32_t rj = 0; rj < nb; rj++) {
                 const uint32_t ri = rb + rj, i = ib + ri + 1;
                 const uint32_t meta = __builtin_amdgcn_readlane(mC, ri), p0 = __builtin_amdgcn_readlane(aC, ri);
-                const uint32_t npred = meta >> 8;
+                const uint32_t npred = meta >> META_NP;
                 // mismatch bits of this row: bit 2k set <=> the base under column k differs from the row's letter
                 mask_t mis;
                 {
@@ -807,14 +819,16 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
 #pragma unroll
                 for (int k = 0; k < CM; k++) t[k] = m[k] & ~63;
                 const int left_now = base - g64;      // 64 x H[i][j0-1]: the exclusive prefix already is the finished value left of this chunk
-                {   // to the ring: a kept row takes the next slot, any other row slot R
-                    const uint32_t kept = (meta >> 4) & 1u, slot = kept && R ? (nkept & (R - 1)) : R;
-                    int32_t* S = ring_me + (size_t)slot * ring_w;
+                const uint32_t slot = (meta >> META_SLOT) & 15u;   // (the CSR build counted the kept rows)
+                if (slot != 15u) {   // a kept row goes to its ring slot
+                    int32_t* S = ring_me + slot * ring_w;
 #pragma unroll
                     for (int k = 0; k < CM; k++) S[k * PW + 1] = t[k];
                     if (lane == 0) S[(CM - 1) * PW] = left_now;   // (first wave of the edge: "minus infinity")
-                    nkept += kept;
                 }
+#pragma unroll
+                for (int k = 0; k < CM; k++) tp[k] = t[k];
+                lnp = left_now;
                 DP_T(4);   // carry applied, ring copy
                 if (__builtin_expect(live, 1)) {
                     if (DIR) {
@@ -1154,7 +1168,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                                 const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)Dw[(uint64_t)__builtin_amdgcn_readlane((int)qw, (int)dr) * W + j]);
                                 type = d >> 4; slot = 15u - (d & 15u);
                             }
-                            const uint32_t np = rmeta >> 8;
+                            const uint32_t np = rmeta >> META_NP;
                             const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)q0, (int)dr), e1 = (uint32_t)__builtin_amdgcn_readlane((int)q1, (int)dr);
                             uint32_t ent = slot == 0 ? e0 : e1;
                             if (__builtin_expect(slot >= 2 && type != 1u, 0)) ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[(uint32_t)__builtin_amdgcn_readlane((int)qo, (int)dr) + slot]);
@@ -1408,7 +1422,7 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
                     if (np == 0) q0 = pr; else if (np == 1) q1 = pr;
                     np++;
                 }
-                g.row_meta[r] = cd | (sink << 2) | (np > 4u ? 32u : 0u) | (np << 8);
+                g.row_meta[r] = cd | (sink << 2) | (np > 4u ? 32u : 0u) | (np << META_NP);
                 if (DIR && np > max_indeg) sOk = 4;   // the direction bytes hold a 4-bit predecessor slot (max_indeg <= 16)
                 g.row_pred0[r] = q0; g.row_pred1[r] = q1;
             }
@@ -1417,25 +1431,30 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
             {
                 // Wave kernel: a row lives in the owning lanes' registers for exactly one more row. Rows with a NON-adjacent successor
                 // are "kept": they get ring slots in the order they are produced (slot = #kept rows before it, mod R), and every
-                // predecessor reference is tagged with where the DP will find the row: 0 registers, 1..14 ring slot + 1, 15 HBM.
+                // predecessor reference is tagged with where the DP will find the row: 1..R ring slot + 1, 13 the previous row (registers), 14 the virtual row 0, 15 HBM.
                 for (uint32_t r = r0; r < r1; r++)
-                    for (uint32_t q = g.row_pred_off[r], qe = q + (g.row_meta[r] >> 8); q < qe; q++)
+                    for (uint32_t q = g.row_pred_off[r], qe = q + (g.row_meta[r] >> META_NP); q < qe; q++)
                         if (r - g.pred_rank[q] >= 2) atomicOr(&g.row_meta[g.pred_rank[q]], 16u);
                 __syncthreads();
                 uint32_t kc = 0;
                 for (uint32_t r = r0; r < r1; r++) kc += (g.row_meta[r] >> 4) & 1u;
                 uint32_t ktot;
                 uint32_t kex = block_excl_scan_add(kc, lds_u, &ktot);
-                for (uint32_t r = r0; r < r1; r++) { g.score[r] = (int32_t)kex; kex += (g.row_meta[r] >> 4) & 1u; }   // kept rows before r
+                for (uint32_t r = r0; r < r1; r++) {   // kept rows before r; the row's own ring slot goes into its record (own rows only: nobody else writes these words in this phase)
+                    const uint32_t kept = (g.row_meta[r] >> 4) & 1u;
+                    g.score[r] = (int32_t)kex;
+                    g.row_meta[r] |= (kept && R ? (kex & (R - 1)) : 15u) << META_SLOT;   // 15: no non-adjacent reader (or no ring at all) - the row is not written to the ring
+                    kex += kept;
+                }
                 __syncthreads();
                 uint32_t st_multi = 0, st_ring = 0, st_far = 0;
                 for (uint32_t r = r0; r < r1; r++) {
-                    const uint32_t po = g.row_pred_off[r], np = g.row_meta[r] >> 8;
+                    const uint32_t po = g.row_pred_off[r], np = g.row_meta[r] >> META_NP;
                     st_multi += np >= 2;
                     for (uint32_t q = 0; q < np; q++) {
                         const uint32_t pr = g.pred_rank[po + q];
                         uint32_t loc;
-                        if (!((g.row_meta[pr] >> 4) & 1u) || (R == 0 && r - pr == 1)) loc = R + 1;   // nobody keeps it: it is the previous row and sits in the slot of the latest such row
+                        if (r - pr == 1) loc = 13;   // the previous row: still in the registers of the lanes that own its columns
                         else {
                             const uint32_t live = (uint32_t)g.score[r] - (uint32_t)g.score[pr];   // kept rows produced in [pr, r), pr included
                             if (live <= R) loc = 1 + ((uint32_t)g.score[pr] & (R - 1));
