@@ -620,11 +620,11 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     auto ring_rows_of = [ring_kb_wave](uint32_t nt, uint32_t cm, uint64_t& row_bytes) -> uint32_t {   // kept rows the LDS ring holds; row_bytes returns the ring's LDS bytes
         row_bytes = (uint64_t)cm * (nt / 64) * 65 * 4;   // planes of 65 words per wave
         uint64_t lds_budget = nt >= 1024 ? 128 * 1024 : nt == 64 ? 32 * 1024 : 64 * 1024 * (nt / 128 > 2 ? 2 : 1);
-        if (ring_kb_wave) lds_budget = std::min<uint64_t>(lds_budget, std::max<uint64_t>(ring_kb_wave * 1024 * (nt / 64), 3 * row_bytes) * 8 / 9);
-        if (3 * row_bytes > lds_budget * 9 / 8) lds_budget = kPoaLdsMax * 8 / 9;   // wide rows: whatever the CU has, for at least two kept rows beside the latest
-        const uint64_t rows_fit = std::min<uint64_t>(lds_budget * 9 / 8, kPoaLdsMax) / row_bytes;   // ring slots (+ 1 scratch slot when there is room)
-        const uint32_t R = rows_fit >= 9 ? 8 : rows_fit >= 5 ? 4 : rows_fit >= 3 ? 2 : 0;   // kept rows: a power of two (slot = kept-row counter & (R-1)); 0 = only the latest row
-        row_bytes *= R + 1;                                             // -> LDS bytes of the ring: one more slot for the latest row nobody keeps
+        if (ring_kb_wave) lds_budget = std::min<uint64_t>(lds_budget, std::max<uint64_t>(ring_kb_wave * 1024 * (nt / 64), 2 * row_bytes));
+        if (2 * row_bytes > lds_budget) lds_budget = kPoaLdsMax;   // wide rows: whatever the CU has
+        const uint64_t rows_fit = std::min<uint64_t>(lds_budget, kPoaLdsMax) / row_bytes;
+        const uint32_t R = rows_fit >= 8 ? 8 : rows_fit >= 4 ? 4 : rows_fit >= 2 ? 2 : 0;   // kept rows: a power of two (slot = kept-row counter & (R-1)); 0 = every kept row goes through HBM
+        row_bytes *= std::max<uint32_t>(R, 1);                          // -> LDS bytes of the ring (at least one row's worth: the kernel's other phases use the space too)
         return R;
     };
     auto cm_round = [](uint32_t ncol, uint32_t lanes) -> uint32_t { uint32_t cm = (ncol + lanes - 1) / lanes, r = 4; while (r < cm) r <<= 1; return r; };
@@ -829,6 +829,9 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                 {
                     const uint64_t per_cu = (order_all.size() + 255) / 256;
                     if (per_cu < 8) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(kPoaLdsMax, (158 * 1024) / per_cu - 18 * 1024));
+                    // hundreds of edges: the longest ones set the duration, and their waves run faster with two neighbours on a SIMD than with
+                    // three - 10 KB of LDS per wave keeps a CU at 12 waves (thousands of edges: 16, the ring alone is 8.3 KB per wave)
+                    if (!many_edges) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(kPoaLdsMax, 10 * 1024 * (uint64_t)(q.nt / 64)));
                 }
                 const int dcls = q.shared ? 0 : q.nt >= 1024 ? 1 : q.nt >= 512 ? 2 : q.nt >= 256 ? 3 : q.nt >= 128 ? 4 : 5;
                 for (uint32_t e : q.edges) c->dbg_cls[e] = (uint8_t)(dcls + (q.dir ? 0 : 5));

@@ -873,7 +873,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
 // many short gaps (one wavefront, 4-8 columns per lane) run with a fraction of the registers - and several times the waves per SIMD - of
 // the few long ones; sequences shorter than the edge's longest leave the upper lanes / waves of the pipeline idle.
 template <int MAXNT, int CM, bool DIR>
-__global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges, const uint32_t* __restrict__ order, uint32_t n_edges,
+__global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const PoaEdge* __restrict__ edges, const uint32_t* __restrict__ order, uint32_t n_edges,
                                             const PoaSeq* __restrict__ seqs, const uint8_t* __restrict__ packed, const uint64_t* __restrict__ read_off,
                                             const uint32_t* __restrict__ read_len, PoaPools P, int32_t match, int32_t mismatch, int32_t gap,
                                             char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells, unsigned long long* phase,
@@ -915,13 +915,12 @@ __global__ void __launch_bounds__(MAXNT) k_poa(const PoaEdge* __restrict__ edges
     const uint32_t GM = ED.members;                  // workgroups sharing this edge's DP columns
     const uint32_t ring_w = CM * (NT >> 6) * 65u;    // CM planes of 65 words per wave (dp_rows)
     // kept rows the LDS ring holds for THIS edge: what fits the launch's LDS at the edge's own row width (a launch serves edges of several
-    // widths; the host sizes the LDS for the widest), a power of two (slot = kept-row counter & (R - 1)), plus the scratch slot
-    // Rows nobody keeps go to a scratch slot so that the copy is unconditional; when the LDS holds exactly a power of two of rows the scratch
-    // slot is given up for twice the ring (wide rows: one branch per row is nothing against a row read back from HBM).
+    // widths; the host sizes the LDS for the widest), a power of two (slot = kept-row counter & (R - 1)). Only rows with a non-adjacent
+    // reader go there (the previous row is read from registers), so every slot holds a kept row.
     uint32_t R = 0;
     {
-        const uint32_t fit = lds_bytes / (ring_w * 4u);   // slots: R kept rows + 1 for the latest row nobody keeps
-        R = fit >= 9 ? 8 : fit >= 5 ? 4 : fit >= 3 ? 2 : 0;   // (0: rows too wide for more than the latest one - every kept row is read back from HBM)
+        const uint32_t fit = lds_bytes / (ring_w * 4u);
+        R = fit >= 8 ? 8 : fit >= 4 ? 4 : fit >= 2 ? 2 : 0;   // (0: rows too wide for two of them - every kept row is read back from HBM)
         if (fit < 1) R = 0xffffffffu;
     }
     uint8_t* seq = P.seq + ED.seq_off;
