@@ -9,6 +9,7 @@
 //   bbg_find_simple_path_from_source :378-402             clean_tips Cleaning.cpp:59-96
 //   clean_simple_bubbles_old Cleaning.cpp:98-184          detect_super_bubble/clean_super_bubbles :488-648
 //   clean_small_bubbles Cleaning.cpp:7-57
+#include <cstring>
 #include <algorithm>
 #include <cstdio>
 #include <map>
@@ -31,11 +32,13 @@ FILE* open_or_null(const std::string& path, const char* mode) {
 }
 
 std::string revcomp(const std::string& s) {
-    std::string r(s.size(), 'N');
-    for (size_t i = 0; i < s.size(); i++) {
-        char c = s[s.size() - 1 - i];
-        r[i] = c == 'A' || c == 'a' ? 'T' : c == 'C' || c == 'c' ? 'G' : c == 'G' || c == 'g' ? 'C' : c == 'T' || c == 't' ? 'A' : 'N';
-    }
+    // complement by table (anything but ACGT / acgt becomes N), written back to front
+    static const struct Tab { char c[256]; Tab() { memset(c, 'N', 256); c['A'] = c['a'] = 'T'; c['C'] = c['c'] = 'G'; c['G'] = c['g'] = 'C'; c['T'] = c['t'] = 'A'; } } tab;
+    const size_t n = s.size();
+    std::string r(n, 'N');
+    const unsigned char* in = reinterpret_cast<const unsigned char*>(s.data());
+    char* out = &r[0];
+    for (size_t i = 0; i < n; i++) out[n - 1 - i] = tab.c[in[i]];
     return r;
 }
 

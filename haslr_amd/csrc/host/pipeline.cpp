@@ -327,6 +327,7 @@ static int run_consensus(Run& r) {
     hx_poa_params pp{5, -4, -8};   // Assemble.cpp:8-11
     if (r.have_cns) r.be.free_cns(r.be.ctx, &r.cnsout), r.have_cns = false;
     if (r.be.poa_batch(r.be.ctx, &pp, &r.cnsout) != 0) return backend_fail(r, "poa_batch");
+    const double t_poa = now();
     r.have_cns = true;
     if (r.cnsout.n_edge != r.mine.size()) { g_err = "internal: consensus count differs from this run's share of the work queue"; return -1; }
     for (size_t i = 0; i < r.mine.size(); i++) {
@@ -335,8 +336,10 @@ static int run_consensus(Run& r) {
         x.have_cns = true;
         apply_cns(r, r.mine[i]);
     }
+    const double t_apply = now();
     if (r.shard_world == 1) write_stage_logs(r);
     r.t[3] = now() - t0;
+    if (getenv("HASLR_GRAPH_DEBUG")) fprintf(stderr, "[consensus] queue check + backend %.2f ms, results applied %.2f ms, stage logs %.2f ms\n", (t_poa - t0) * 1e3, (t_apply - t_poa) * 1e3, (now() - t_apply) * 1e3);
     return 0;
 }
 
