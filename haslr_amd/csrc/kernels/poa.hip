@@ -1128,19 +1128,18 @@ __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const P
                     const uint32_t ln = tid;
                     if (ln == 0) sCells += (unsigned long long)V * L;
                     uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane(sBestI), j = L, na = 0;
-                    // path entries are collected in two registers (entry n in lane n % 64, v_writelane) and leave 64 at a time with one
-                    // coalesced store each: a store per step cost more than the step itself
+                    // The walk records the cell it stands on, (rank, column), before every move: entry n in lane n % 64 of two registers
+                    // (v_writelane), 64 entries leave with one coalesced store each. What the alignment wants - "node or nothing, position or
+                    // nothing" - is a comparison of neighbouring entries and is made by all lanes afterwards.
                     int pn = 0, pp = 0;
+                    uint32_t nwalk = 0, iend = 0, jend = 0;   // entries of the walk proper, and where it stopped
                     bool tail = false;
-                    auto flush = [&](uint32_t upto) {
-                        const uint32_t base = (upto - 1) & ~63u;
-                        if (ln < upto - base) { g.aln_node[base + ln] = pn; g.aln_pos[base + ln] = pp; }
-                    };
                     while (!(i == 0 && j == 0)) {
-                        if (i == 0) {   // only horizontal moves are left in the virtual row
-                            if (na & 63u) flush(na);
+                        if (i == 0) {   // only horizontal moves are left in the virtual row: written in their final form
+                            if (na & 63u) { const uint32_t base = na & ~63u; if (ln < na - base) { g.aln_node[base + ln] = pn; g.aln_pos[base + ln] = pp; } }
                             tail = true;
-                            for (uint32_t q = ln; q < j; q += 64) { g.aln_node[na + q] = 0; g.aln_pos[na + q] = (int32_t)(j - 1 - q); }
+                            nwalk = na; iend = 0; jend = j;
+                            for (uint32_t q = ln; q < j; q += 64) { g.aln_node[na + q] = -1; g.aln_pos[na + q] = (int32_t)(j - 1 - q); }
                             na += j; j = 0;
                             break;
                         }
@@ -1148,47 +1147,68 @@ __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const P
                         // the 4 bytes = 8 columns of one row in one register
                         const uint32_t ti = i, ct = j | 1u, r0 = ln >> 1, hf = ln & 1u;
                         const int32_t bs = ((int32_t)ct - 15) >> 1;   // first byte of the tile in its rows (ct < 15: negative - bytes before the row, never looked at)
-                        uint32_t w0 = 0, mt = 0, q0 = 0, q1 = 0, qo = 0, qw = 0;
+                        uint32_t w0 = 0, mt = 0, pv0 = 0, pv1 = 0, qo = 0, qw = 0;
                         if (ti > r0) {
                             // one unaligned dword load per lane (bytes bs + 4 hf .. + 3 of the row; columns below 0 read the end of the previous row - row 0 exists)
                             const uint8_t* rowp = Dm + (uint64_t)(ti - r0) * (W >> 1) + bs + 4 * (int32_t)hf;
                             __builtin_memcpy(&w0, rowp, 4);
                         }
-                        if (ln < 32 && ti > ln) { const uint32_t rr = ti - 1 - ln; mt = g.row_meta[rr]; q0 = g.row_pred0[rr]; q1 = g.row_pred1[rr]; qo = g.row_pred_off[rr]; if (mt & 32u) qw = g.wslot[rr]; }
+                        if (ln < 32 && ti > ln) {   // the records of the tile's rows: where a move into the first / second predecessor leads (lanes = rows)
+                            const uint32_t rr = ti - 1 - ln;
+                            mt = g.row_meta[rr]; qo = g.row_pred_off[rr]; if (mt & 32u) qw = g.wslot[rr];
+                            pv0 = (mt >> META_NP) == 0 ? 0u : (g.row_pred0[rr] & 0x0fffffffu) + 1;   // (a source node continues in the virtual row 0)
+                            pv1 = (g.row_pred1[rr] & 0x0fffffffu) + 1;
+                        }
+                        const uint32_t ilo = ti > 31u ? ti - 31u : 1u;                 // the walk goes on while i >= ilo (rows of the tile, never row 0) ...
+                        const int32_t jb0 = 2 * bs;                                  // ... and j >= first column of the tile
                         for (;;) {
-                            const uint32_t dr = ti - i, off = (uint32_t)((int32_t)(j >> 1) - bs);   // byte of column j inside the tile row: 0..7
-                            const uint32_t wsel = (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)(dr * 2 + (off >> 2)));
-                            const uint32_t n4 = (wsel >> (8 * (off & 3u) + 4 * (j & 1u))) & 15u;
+                            const uint32_t dr = ti - i, jb = (uint32_t)((int32_t)j - jb0);   // row and column inside the tile (0..31, 0..15)
+                            const uint32_t wsel = (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)(dr * 2 + (jb >> 3)));
+                            const uint32_t n4 = (wsel >> (4 * (jb & 7u))) & 15u;
                             const uint32_t rmeta = (uint32_t)__builtin_amdgcn_readlane((int)mt, (int)dr);
                             // move code: type (3 diagonal / 2 vertical / 1 horizontal) * 4 + 3 - predecessor slot; a row with more than 4 predecessors
-                            // keeps type * 16 + 15 - slot in the wide-row pool. Selects instead of branches where it is cheap.
-                            uint32_t type = n4 >> 2, slot = 3u - (n4 & 3u);
+                            // keeps type * 16 + 15 - slot in the wide-row pool
+                            // (a move into the third or a later predecessor - codes 8, 9, 12, 13 of a 4-bit row - has to fetch that predecessor's rank)
+                            uint32_t type = n4 >> 2, slot = 3u - (n4 & 3u), later = (0x3300u >> n4) & 1u;
                             if (__builtin_expect((rmeta & 32u) != 0, 0)) {
                                 const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)Dw[(uint64_t)__builtin_amdgcn_readlane((int)qw, (int)dr) * W + j]);
-                                type = d >> 4; slot = 15u - (d & 15u);
+                                type = d >> 4; slot = 15u - (d & 15u); later = slot >= 2 && type != 1u;
                             }
-                            const uint32_t np = rmeta >> META_NP;
-                            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)q0, (int)dr), e1 = (uint32_t)__builtin_amdgcn_readlane((int)q1, (int)dr);
-                            uint32_t ent = slot == 0 ? e0 : e1;
-                            if (__builtin_expect(slot >= 2 && type != 1u, 0)) ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[(uint32_t)__builtin_amdgcn_readlane((int)qo, (int)dr) + slot]);
-                            const uint32_t pv = np == 0 ? 0u : (ent & 0x0fffffffu) + 1;
-                            const uint32_t pi_ = type == 1u ? i : pv, pj_ = type == 2u ? j : j - 1;
+                            uint32_t pv = slot == 0 ? (uint32_t)__builtin_amdgcn_readlane((int)pv0, (int)dr) : (uint32_t)__builtin_amdgcn_readlane((int)pv1, (int)dr);
+                            if (__builtin_expect(later != 0, 0))
+                                pv = ((uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[(uint32_t)__builtin_amdgcn_readlane((int)qo, (int)dr) + slot]) & 0x0fffffffu) + 1;
                             {
-                                const int en = __builtin_amdgcn_readfirstlane(i == pi_ ? 0 : (int)i), ep = __builtin_amdgcn_readfirstlane(j == pj_ ? -1 : (int)(j - 1));
-                                const int el = __builtin_amdgcn_readfirstlane((int)(na & 63u));
-                                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0" : "+v"(pn), "+v"(pp) : "s"(el), "s"(en), "s"(ep) : "m0");
+                                const int el = (int)(na & 63u);
+                                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0" : "+v"(pn), "+v"(pp) : "s"(el), "s"(i), "s"(j) : "m0");
                             }
                             na++;
-                            if ((na & 63u) == 0) flush(na);
-                            i = pi_; j = pj_;
-                            if (i == 0 || ti - i >= 32 || ct - j >= 16) break;
+                            if (type != 1u) i = pv;
+                            j -= type & 1u;   // (types 1 and 3 move a column to the left, type 2 does not)
+                            if (__builtin_expect((na & 63u) == 0, 0)) {   // 64 entries: out they go (a store per step cost more than the step itself)
+                                asm volatile("" ::: "memory");
+                                g.aln_node[na - 64 + ln] = pn; g.aln_pos[na - 64 + ln] = pp;
+                            }
+                            if ((int32_t)((i - ilo) | (uint32_t)((int32_t)j - jb0)) < 0) break;   // left the tile's rows or columns
                         }
                     }
-                    if (!tail && (na & 63u)) flush(na);   // (after a tail of horizontal moves everything has been written already)
-                    if (ln == 0) sNaln = na;
+                    if (!tail) {
+                        if (na & 63u) { const uint32_t base = na & ~63u; if (ln < na - base) { g.aln_node[base + ln] = pn; g.aln_pos[base + ln] = pp; } }
+                        nwalk = na; iend = 0; jend = 0;
+                    }
+                    if (ln == 0) { sNaln = na; lds_u[0] = nwalk; lds_u[1] = iend; lds_u[2] = jend; }
                 }
                 __syncthreads();
-                for (uint32_t k = tid, nk = sNaln; k < nk; k += NT) { const int32_t r = g.aln_node[k]; g.aln_node[k] = r == 0 ? -1 : (int32_t)g.rank2node[r - 1]; }
+                {   // entry k of the walk: the node of its row unless the move stayed in the row, its column unless the move stayed in the column
+                    const uint32_t nw = lds_u[0], ie = lds_u[1], je = lds_u[2];
+                    for (uint32_t base = 0; base < nw; base += NT) {
+                        const uint32_t k = base + tid;
+                        int32_t r = 0, c = 0, r2 = 0, c2 = 0;
+                        if (k < nw) { r = g.aln_node[k]; c = g.aln_pos[k]; if (k + 1 < nw) { r2 = g.aln_node[k + 1]; c2 = g.aln_pos[k + 1]; } else { r2 = (int32_t)ie; c2 = (int32_t)je; } }
+                        __syncthreads();   // (entry k + 1 is another thread's to rewrite)
+                        if (k < nw) { g.aln_node[k] = r == r2 ? -1 : (int32_t)g.rank2node[r - 1]; g.aln_pos[k] = c == c2 ? -1 : c - 1; }
+                    }
+                }
+                __syncthreads();
             } else if (tid == 0) {
                 sCells += (unsigned long long)V * L;
                 uint32_t i = (uint32_t)sBestI, j = L, na = 0;
