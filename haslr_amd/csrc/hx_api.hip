@@ -820,7 +820,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             size_t opos = 0, ci = 0;
             for (const Cls& q : classes) {
                 const int sk = (int)(ci++ % 6);   // stream / event of the launch (launches that share a stream run one after the other)
-                // LDS of the launch: the ring its row width allows, a power of two of kept rows (+ a scratch slot for the rows nobody keeps)
+                // LDS of the launch: the ring its row width allows, a power of two of kept rows
                 uint64_t ring_need = 0;
                 const uint32_t R = ring_rows_of(q.nt, q.cm, ring_need);
                 // few edges: ask for enough LDS per workgroup that the dispatcher cannot stack them on a handful of CUs while others idle

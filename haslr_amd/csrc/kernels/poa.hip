@@ -586,7 +586,7 @@ template <int CM> __device__ __forceinline__ void store_nibbles(uint8_t* p, cons
 // The row loop is written for a lone wavefront's latency: on this hardware a VALU instruction costs ~5 cycles whether or not it depends
 // on its predecessor, a taken scalar branch ~35, an LDS round trip ~75, the DPP scan ~90. So a row is ONE dispatch on where its
 // predecessor lives (registers / LDS ring / anything else), then straight-line code: rare events (row spilled to HBM, sink row) share
-// one not-taken branch, the kept-row copy to the LDS ring is unconditional (rows nobody keeps go to a scratch slot), selects are
+// one not-taken branch, only rows with a non-adjacent reader are copied to the LDS ring (slot from the row's record), selects are
 // arithmetic.
 template <int CM, bool DIR>
 __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, uint8_t* __restrict__ Dwide, const uint32_t W, const uint32_t WH, const uint8_t* __restrict__ seq,
