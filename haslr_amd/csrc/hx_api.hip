@@ -583,8 +583,13 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     const uint32_t max_indeg = getenv("HX_POA_MAX_INDEG") ? std::min<uint32_t>(16, (uint32_t)atoi(getenv("HX_POA_MAX_INDEG"))) : 16;   // (testing: forces the score-matrix retry earlier)
     const uint32_t cl_lanes = getenv("HX_POA_MEMBER_LANES") ? (uint32_t)atoi(getenv("HX_POA_MEMBER_LANES")) : 256;   // lanes per cluster member
     const uint32_t cl_min = getenv("HX_POA_CLUSTER_MIN") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MIN")) : 2048;       // columns above which an edge is shared
-    const uint32_t cl_max = getenv("HX_POA_CLUSTER_MAX") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MAX")) : 16;         // members per edge at most
-    const uint32_t cl_topk = getenv("HX_POA_CLUSTER_TOPK") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_TOPK")) : 192;           // shared edges per call at most (the costliest)
+    // Sharing an edge buys latency for that edge and costs throughput. Hundreds of edges (the longest is the step): up to 16 members, the
+    // 192 costliest shared. Thousands (every CU busy anyway): 8 members (more only where a gap needs them to fit), the 32 costliest - measured on 13 262 edges: 2.10 s with 16 x 192,
+    // 1.98 s with 8 x 32, 2.29 s without sharing (the largest edges then run on after everything else has finished).
+    const bool many_edges_in = ne > 4096;
+    const uint32_t cl_max = getenv("HX_POA_CLUSTER_MAX") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MAX")) : 16;                              // members per edge at most
+    const uint32_t cl_pref = getenv("HX_POA_CLUSTER_MAX") ? cl_max : many_edges_in ? 8 : 16;                                                  // ... unless the gap needs more to fit at all
+    const uint32_t cl_topk = getenv("HX_POA_CLUSTER_TOPK") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_TOPK")) : many_edges_in ? 32 : 192;    // shared edges per call at most (the costliest)
     const uint32_t cl_cols = getenv("HX_POA_CLUSTER_COLS") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_COLS")) : 4;            // columns per lane a member aims at
     const uint64_t est_pct = getenv("HX_POA_NODE_EST_PCT") ? (uint64_t)std::max(1L, atol(getenv("HX_POA_NODE_EST_PCT"))) : 100;   // (testing: scales the node estimate)
     const long far_rows = getenv("HX_POA_FAR_ROWS") ? atol(getenv("HX_POA_FAR_ROWS")) : -1;   // (testing: rows of H per edge on the first attempt)
@@ -652,7 +657,8 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             // long gaps: the DP columns of the edge are shared by several workgroups (one CU each), ~8 columns per lane
             E.members = 1;
             const uint32_t ncol = E.lmax + 1;
-            if (!c->poa_block && !c->poa_no_dir && !force_nodir[e] && !many_sinks[e] && !no_share[e] && ncol > cl_min) E.members = (uint32_t)std::min<uint64_t>(cl_max, (ncol + (uint64_t)cl_lanes * cl_cols - 1) / ((uint64_t)cl_lanes * cl_cols));
+            if (!c->poa_block && !c->poa_no_dir && !force_nodir[e] && !many_sinks[e] && !no_share[e] && ncol > cl_min) E.members = (uint32_t)std::min<uint64_t>(cl_max, std::max<uint64_t>(std::min<uint64_t>(cl_pref, (ncol + (uint64_t)cl_lanes * cl_cols - 1) / ((uint64_t)cl_lanes * cl_cols)),
+                                                                                                                                                                                       (ncol + (uint64_t)cl_lanes * 32 - 1) / ((uint64_t)cl_lanes * 32)));
             if (E.members < 2 || ((uint64_t)ncol + (uint64_t)E.members * cl_lanes - 1) / ((uint64_t)E.members * cl_lanes) > 32) E.members = 1;   // (members too small for this gap: one workgroup)
         }
         // Sharing an edge among several CUs buys latency for the edge and costs throughput (the other members idle while member 0 walks
