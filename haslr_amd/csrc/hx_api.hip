@@ -586,7 +586,9 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     // Sharing an edge buys latency for that edge and costs throughput. Hundreds of edges (the longest is the step): up to 16 members, the
     // 192 costliest shared. Thousands (every CU busy anyway): 8 members (more only where a gap needs them to fit), the 32 costliest - measured on 13 262 edges: 2.10 s with 16 x 192,
     // 1.98 s with 8 x 32, 2.29 s without sharing (the largest edges then run on after everything else has finished).
-    const bool many_edges_in = ne > 4096;
+    // (the two launch shapes cross between 2 200 and 3 300 edges: 292 against 313 ms at 2 214 edges, 390-400 against 374 ms at 3 294)
+    constexpr size_t kManyEdges = 3000;
+    const bool many_edges_in = ne > kManyEdges;
     const uint32_t cl_max = getenv("HX_POA_CLUSTER_MAX") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MAX")) : 16;                              // members per edge at most
     const uint32_t cl_pref = getenv("HX_POA_CLUSTER_MAX") ? cl_max : many_edges_in ? 8 : 16;                                                  // ... unless the gap needs more to fit at all
     const uint32_t cl_topk = getenv("HX_POA_CLUSTER_TOPK") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_TOPK")) : many_edges_in ? 32 : 192;    // shared edges per call at most (the costliest)
@@ -606,7 +608,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     // columns per lane of the multi-wave classes: 4 while edges are few (more lanes = a shorter row for the edges that set the step time),
     // 16 when thousands of edges keep every CU busy anyway (a row then costs fewer instructions in total: the per-row overhead is per wave).
     // Measured: 1 846 edges 463 ms with 4 vs 482 ms with 16; 5 570 edges 1 166 vs 1 151 ms; 13 262 edges 4.17 vs 3.97 s.
-    const uint32_t cols_per_lane = getenv("HX_POA_COLS") ? (uint32_t)atoi(getenv("HX_POA_COLS")) : todo.size() > 4096 ? 8 : 4;
+    const uint32_t cols_per_lane = getenv("HX_POA_COLS") ? (uint32_t)atoi(getenv("HX_POA_COLS")) : todo.size() > kManyEdges ? 8 : 4;
     auto class_of = [&](uint32_t e) -> int {   // launch class of an edge that is not shared (members == 1), direction-byte flavour
         static const uint32_t kMaxCm[6] = {0, 8, 16, 32, 32, 32};   // columns per lane each kernel variant keeps in registers
         const uint32_t ncol = P.edges[e].lmax + 1;
@@ -620,7 +622,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     // LDS of the kept-row ring. Few edges (their longest sets the duration): as many kept rows as fit, so that hardly any row is read back
     // from HBM. Thousands of edges (every CU busy): what counts is waves per SIMD - each wave spends most of its time waiting for its own
     // dependent instructions - so the ring is cut to HX_POA_RING_KB per wave and several workgroups share a CU.
-    const bool many_edges = todo.size() > 4096;
+    const bool many_edges = todo.size() > kManyEdges;
     const uint64_t ring_kb_wave = getenv("HX_POA_RING_KB") ? (uint64_t)std::max(1, atoi(getenv("HX_POA_RING_KB"))) : many_edges ? 11 : 0;   // 0 = no cut
     auto ring_rows_of = [ring_kb_wave](uint32_t nt, uint32_t cm, uint64_t& row_bytes) -> uint32_t {   // kept rows the LDS ring holds; row_bytes returns the ring's LDS bytes
         row_bytes = (uint64_t)cm * (nt / 64) * 65 * 4;   // planes of 65 words per wave
