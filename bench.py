@@ -42,7 +42,9 @@ WORKLOADS = {
     "fly": dict(config=3, genome=140_000_000, model="pacbio", name="D. melanogaster-size synthetic", variants="1.5"),
 }
 HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9         # 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz (int32 VALU issue bound)
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9         # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 (a wave64 VALU op issues in 2 cycles) x 2.4 GHz = 7.86e13 lane-ops/s
+SHADER_CLOCK_HZ = 2.4e9                           # clock the kernel's cycle counters are converted with (critical_path_ms)
+VALU_OPS_PER_CELL_MODEL = 10                      # ~10 lane-ops per DP cell is the model the VALU bound is quoted for
 
 
 def log(*a):
@@ -65,7 +67,13 @@ def make_dataset(wl, genome_len, tag):
     return pre
 
 
-def cpu_baseline(ds, gpu_cns):
+def gfa_digest(out_dir):
+    """sha256 of each of the six backbone.0x.*.gfa files of a run directory (the metric's "GFA match")"""
+    files = sorted(glob.glob(os.path.join(out_dir, "backbone.0[1-6].*.gfa")))
+    return {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest() for f in files}
+
+
+def cpu_baseline(ds, gpu_cns, gpu_gfa=None, work_dir=None):
     """The oracle (kind "port": the CPU restatement of the reference path, AVX2 row kernels where the host has them,
     edges dealt to the threads costliest first) on the SAME data set and timed region as the GPU line, twice:
     min(64, cores) threads - the thread count the north star quotes the reference at - and all cores."""
@@ -84,13 +92,20 @@ def cpu_baseline(ds, gpu_cns):
         runs.append({"threads": threads, "seconds": dt, "value": ds.total_read_bases / dt, "gcups": st["dp_cells"] / dt / 1e9,
                      "stage_s": run.timings(), "consensus_equals_gpu": run.cns_out() == gpu_cns})
         n_edges = run.n_edges
-        run.close(); be.close()
+        run.close()
+        if gpu_gfa is not None and "gfa" not in runs[0]:   # untimed: chain + graph once more with an output directory, for the six GFA snapshots
+            d = os.path.join(work_dir, "cpu_gfa")
+            r2 = host.Run(ds, ds.params(), be.table, d)
+            r2.chain(); r2.graph(); r2.close()
+            runs[0]["gfa"] = gfa_digest(d)
+        be.close()
     main = runs[0]
+    gfa_equal = None if gpu_gfa is None else (len(gpu_gfa) == 6 and main.get("gfa") == gpu_gfa)
     return {"value": main["value"], "unit": "long-read bases/s", "cores": main["threads"], "kind": "port",
             "sample": f"the whole data set of this line ({ds.reads.n} reads / {ds.total_read_bases} bases, {n_edges} edges), same timed region "
                       f"(chain -> graph -> coordinates -> consensus); oracle/liboracle.so, POA row kernels {orclib.lib().orc_poa_kernel_name().decode()}, "
                       f"{main['threads']} threads over edges (costliest first) in {main['seconds']:.2f} s",
-            "gcups": main["gcups"], "consensus_equals_gpu": all(r["consensus_equals_gpu"] for r in runs), "host_cores": ncpu, "runs": runs,
+            "gcups": main["gcups"], "consensus_equals_gpu": all(r["consensus_equals_gpu"] for r in runs), "gfa_equals_gpu": gfa_equal, "host_cores": ncpu, "runs": runs,
             "note": "stand-in for '64-thread CPU haslr_assemble' (the reference cannot be built here: spoa 1.1.3 is not vendored); int32 AVX2 lanes, "
                     "spoa's engine would use int16 lanes where scores fit"}
 
@@ -130,7 +145,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="yeast")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None,
+                    help="default: yeast (BASELINE configs[2]; x N for N = 2, 8), fly (configs[3] as BASELINE names it: 140 Mb on 4 GPUs) at N = 4")
     ap.add_argument("--genome-len", type=int, default=0, help="override the per-run genome length (testing)")
     ap.add_argument("--poa-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -163,8 +179,11 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
+    if args.workload is None:
+        args.workload = "fly" if world == 4 else "yeast"   # BASELINE.json configs[3] is quoted on 4 GPUs; N = 2, 8: the yeast-size genome x N (weak scaling)
     wl = WORKLOADS[args.workload]
-    glen = args.genome_len or wl["genome"] * world
+    as_named = args.workload == "fly" and world == 4       # the configuration exactly as BASELINE names it: no x N
+    glen = args.genome_len or (wl["genome"] if as_named else wl["genome"] * world)
     if rank == 0:
         make_dataset(wl, glen, "gpu")
     if world > 1:
@@ -275,26 +294,59 @@ def main():
     if rank == 0:
         value = ds.total_read_bases * args.steps / dt
         gcups = cells / (poa_ms / 1e3) / 1e9 if poa_ms > 0 else 0.0
+        valu_bound = VALU_PEAK_LANE_OPS / VALU_OPS_PER_CELL_MODEL / 1e9
+        # the longest edge's serial chain of {decode, DP, traceback, graph update, order update, CSR rebuild}: lane-0 cycle counters of the kernel
+        critical_ms = sum(phase["slowest_edge"].values()) / SHADER_CLOCK_HZ * 1e3
+        # SQ counters of the POA launch group, collected offline for exactly this workload (profiles/*_sq_counters.json: separate --pmc passes)
+        sq, sq_src = {}, None
+        if world == 1 and not args.genome_len:
+            for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")), reverse=True):
+                try:
+                    t = json.load(open(cand))
+                    if t.get("bench_workload", "yeast") == args.workload:
+                        sq, sq_src = t["counters_summed_over_k_poa_dispatches"], os.path.relpath(cand, ROOT)
+                        break
+                except Exception:  # noqa: BLE001
+                    pass
+        sq_fig = {}
+        if sq.get("SQ_INSTS_VALU") and cells:
+            # profiled cells = this line's cells (same workload, same data set); a wave64 VALU instruction = 64 lane-ops, 2 cycles of a SIMD-32
+            prof_ms = sq.get("profiled_kernel_ms", poa_ms)
+            sq_fig = {"valu_lane_ops_per_cell": sq["SQ_INSTS_VALU"] * 64 / cells,
+                      "valu_issue_util": sq["SQ_INSTS_VALU"] * 2 / (256 * 4 * SHADER_CLOCK_HZ * prof_ms / 1e3),
+                      "wait_share": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"] if sq.get("SQ_WAVE_CYCLES") else None,
+                      "sq_counters_source": sq_src}
+        gfa_gpu = None
+        if world == 1:   # the metric's "GFA match": the six backbone.0x.*.gfa snapshots of a GPU pass (untimed) against the CPU leg's, byte for byte
+            work_dir = os.path.join(os.environ.get("HASLR_BENCH_DIR", "/tmp/haslr_bench"), "gfa_%s" % args.workload)
+            r2 = host.Run(ds, prm, ctx.backend(), os.path.join(work_dir, "gpu_gfa"))
+            r2.chain(); r2.graph(); r2.close()
+            gfa_gpu = gfa_digest(os.path.join(work_dir, "gpu_gfa"))
         line = {
             "metric": "long-read bases/sec through backbone+consensus; GFA match + FASTA %identity",
             "value": value, "unit": "long-read bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{wl['name']}: {glen} bp genome, {wl['model']}-like 25x long reads + PAF vs short-read contigs "
-                                   f"(BASELINE.json configs[{wl['config']}]{' x%d, read-sharded' % world if world > 1 else ''})",
+                                   f"(BASELINE.json configs[{wl['config']}]{(', read-sharded over %d GPUs as BASELINE names it' % world) if as_named else (' x%d, read-sharded' % world if world > 1 else '')})",
                        "reads": ds.reads.n, "long_read_bases": ds.total_read_bases, "paf_records": ds.hits.n, "edges": int(n_edges),
                        "poa_block_threads": args.poa_block or "auto", "parallelism": f"reads+edges sharded x{world}, 1 all-gather of edge records + 1 of results" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_poa (launch group: one kernel per lane-count class, concurrent)", "kernel_ms_per_launch": poa_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "gcups": gcups, "dp_cells_per_launch": cells, "valu_bound_gcups": VALU_PEAK_LANE_OPS / 10 / 1e9, "frac_of_valu_bound": gcups / (VALU_PEAK_LANE_OPS / 10 / 1e9),
-                         "note": "POA is an O(L^2) integer DP over O(L) bytes: HBM fraction is low by construction (SURVEY.md 8d); GCUPS against the int32 VALU issue bound (10 lane-ops per cell) is the figure of merit"},
-            "stage_ms": stage_ms, "kernel_ms": kernel_ms, "poa_phase_cycles": phase, "assembly": assembly,
+                         "gcups": gcups, "dp_cells_per_launch": cells, "valu_bound_gcups": valu_bound, "frac_of_valu_bound": gcups / valu_bound,
+                         "valu_peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "valu_ops_per_cell_model": VALU_OPS_PER_CELL_MODEL, **sq_fig,
+                         "critical_path_ms": critical_ms, "critical_path_share_of_launch": critical_ms / poa_ms if poa_ms > 0 else None,
+                         "note": "POA is an O(L^2) integer DP over O(L) bytes: HBM fraction is low by construction (SURVEY.md 8d); GCUPS against the VALU issue bound "
+                                 "(256 CU x 4 SIMD-32 x 2.4 GHz lane-ops/s / 10 lane-ops per cell) is the figure of merit; valu_lane_ops_per_cell / valu_issue_util / wait_share are "
+                                 "what the SQ counters of the committed profile say the kernel really issues; critical_path_ms = the slowest edge's serial chain (its lane-0 cycle counters / 2.4 GHz)"},
+            "stage_ms": stage_ms, "kernel_ms": kernel_ms, "poa_phase_cycles": phase, "assembly": assembly, "gfa": gfa_gpu,
             # outside the timed region (the metric starts with parsed, resident inputs): text ingest and the PCIe upload
             "ingest": {"seconds": t_parse, "input_mb": in_bytes / 1e6, "mb_per_s": in_bytes / 1e6 / t_parse, "threads": os.environ.get("HASLR_IO_THREADS", "auto (<= 16)"), "upload_seconds": t_upload},
         }
         if not args.no_cpu_baseline and world == 1:
             try:
-                line["cpu_baseline"] = cpu_baseline(ds, cns)
+                line["cpu_baseline"] = cpu_baseline(ds, cns, gfa_gpu, work_dir)
+                line["gfa_equals_cpu_baseline"] = line["cpu_baseline"]["gfa_equals_gpu"]   # six files, byte for byte (the CPU leg = the oracle, pinned to the compiled reference for the GFAs)
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"error": str(e)}
         if not args.no_configs1 and world == 1 and args.workload != "ecoli" and not args.genome_len:

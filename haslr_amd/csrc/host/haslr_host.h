@@ -80,6 +80,10 @@ int hxh_run_coords(hxh_run*);         /* asm_calc_edge_coordinates_MT */
 int hxh_run_consensus(hxh_run*);      /* asm_cal_cns_seq_MT */
 int hxh_run_assemble(hxh_run*);       /* asm_get_assembly: asm.final.fa / .ann / log_asmfinal.txt */
 int hxh_run_all(hxh_run*);            /* all of the above */
+/* on: hxh_run_graph returns while its six GFA snapshots are still being written by their threads - beside the coordinate and consensus
+ * stages, which need only the cleaned graph; hxh_run_assemble (and hxh_run_free) waits for them. Off (default): a graph stage called on
+ * its own returns when the files are complete. hxh_run_all always overlaps. */
+void hxh_run_set_async_writers(hxh_run*, int on);
 /* wall seconds of the last call of each stage: chain, graph(host), coords, consensus, assemble */
 /* index.longread: the alignments that survived the chain stage's filters, with their raw fields (needs hxh_run_chain) */
 int hxh_run_write_longread_index(const hxh_run*, const char* path);

@@ -114,6 +114,7 @@ int main(int argc, char* argv[]) {
     const double c0 = cpu_time(), r0 = real_time();
     auto elapsed = [&]() { fprintf(stderr, "       elapsed time %.2lf CPU seconds (%.2lf real seconds)\n\n", cpu_time() - c0, real_time() - r0); };
 
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);   // before HIP initialises: the POA launch classes overlap on separate hardware queues (include/haslr_hip.h)
     hx_ctx* ctx = nullptr;
     if (hx_ctx_create(device, nullptr, &ctx) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
     if (poa_block) hx_set_poa_block(ctx, poa_block);
@@ -129,8 +130,10 @@ int main(int argc, char* argv[]) {
     if (!used_ci && hxh_dataset_write_contig_index(ds, (out_dir + "/index.contig").c_str()) != 0) { fprintf(stderr, "%s\n", hxh_last_error()); return EXIT_FAILURE; }
     hx_contigs vc; hx_reads vr; hx_hits vh; const uint64_t* rho;
     hxh_dataset_views(ds, &vc, &vr, &vh, &rho);
-    fprintf(stderr, "       loaded %u contigs\n       loaded %u long reads\n       loaded %lu alignment records%s\n", vc.n, vr.n, (unsigned long)vh.n,
-            used_li ? "" : " (before the filters; the alignments that survive them are counted after the next stage)");
+    // the reference prints ONE "loaded N alignments" line, N = the records that survive the load-time filters (main.cpp:70,103). From an
+    // index.longread that is the record count; from a PAF the filters run on the GPU in the next stage, which prints the line then.
+    fprintf(stderr, "       loaded %u contigs\n       loaded %u long reads\n", vc.n, vr.n);
+    if (used_li) fprintf(stderr, "       loaded %lu alignments\n", (unsigned long)vh.n);
     prm.uniq_freq = hxh_dataset_uniq_freq(ds);
     fprintf(stderr, "[NOTE] calculating kmer frequency of unique contigs\n       mean: %.2lf\n", prm.uniq_freq);
     elapsed();
@@ -140,6 +143,7 @@ int main(int argc, char* argv[]) {
     hx_backend be;
     hx_backend_fill(ctx, &be);
     hxh_run* run = hxh_run_create(ds, &prm, &be, out_dir.c_str());
+    hxh_run_set_async_writers(run, 1);   // the GFA snapshots are written beside the GPU stages; the last stage waits for them
     struct { const char* note; int (*fn)(hxh_run*); } stages[] = {
         {"[NOTE] fixing overlapping alignments and building compact long reads...", hxh_run_chain},
         {"[NOTE] building and cleaning the backbone graph...", hxh_run_graph},
@@ -158,7 +162,7 @@ int main(int argc, char* argv[]) {
     for (auto& st : stages) {
         fprintf(stderr, "%s\n", st.note);
         if (st.fn(run) != 0) { fprintf(stderr, "[ERROR] %s\n", hxh_last_error()); finish_index(); return EXIT_FAILURE; }
-        if (st.fn == hxh_run_chain) fprintf(stderr, "       loaded %lu alignments\n", (unsigned long)hxh_run_chain_out(run)->n_aln);   // (the count the reference prints at load time)
+        if (st.fn == hxh_run_chain && !used_li) fprintf(stderr, "       loaded %lu alignments\n", (unsigned long)hxh_run_chain_out(run)->n_aln);   // (the count the reference prints at load time)
         if (st.fn == hxh_run_chain && !used_li) {
             const std::string path = out_dir + "/index.longread";
             if (getenv("HASLR_INDEX_ASYNC"))
@@ -171,7 +175,12 @@ int main(int argc, char* argv[]) {
     }
     if (!finish_index()) return EXIT_FAILURE;
     fprintf(stderr, "[NOTE] cleaning up the memory!\n");
-    if (!getenv("HASLR_FULL_TEARDOWN")) {   // everything is written and closed: the release of up to ~250 GB of device memory and of the host arrays is left
+    // tools that write their data from atexit handlers / static destructors (rocprofv3, roctracer, gcov, sanitizers) need the ordinary exit
+    bool tooling = false;
+    for (const char* v : {"HASLR_FULL_TEARDOWN", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB", "ROCTRACER_DOMAIN", "GCOV_PREFIX", "ASAN_OPTIONS", "LSAN_OPTIONS", "TSAN_OPTIONS", "UBSAN_OPTIONS"})
+        if (getenv(v)) tooling = true;
+    if (const char* pre = getenv("LD_PRELOAD")) if (strstr(pre, "rocprof") || strstr(pre, "roctracer") || strstr(pre, "asan")) tooling = true;
+    if (!tooling) {   // everything is written and closed: the release of up to ~250 GB of device memory and of the host arrays is left
                                             // to the end of the process (1.5-2 s of a 10 s run at 140 Mb); HASLR_FULL_TEARDOWN=1 frees object by object (leak checks)
         fprintf(stderr, "[NOTE] elapsed time %.2lf CPU seconds (%.2lf real seconds)\n\n*** BYE ***\n\n", cpu_time() - c0, real_time() - r0);
         fflush(nullptr);

@@ -52,11 +52,15 @@ struct Run {
     std::vector<uint8_t> blob;      // last hxh_run_results_export
     std::string compact_text;       // last hxh_run_compact_text
     double t[5] = {0, 0, 0, 0, 0};
+    bool async_writers = false;                 // hxh_run_set_async_writers / hxh_run_all: the graph stage returns while its GFA snapshots are still being written
+    std::vector<std::thread> gfa_writers;       // the six GFA snapshots are written beside the per-edge stages; joined before the assembly is written (and on free)
+    void join_writers() { for (auto& th : gfa_writers) if (th.joinable()) th.join(); gfa_writers.clear(); }
     uint32_t shard_rank = 0, shard_world = 1;   // multi-GPU: this run computes coordinates/consensus for its share of the edges
     uint32_t lr_begin = 0;                      // multi-GPU: first long read of the backend's read shard (ids in compact_uniq.txt)
 
     std::string path(const char* name) const { return out_dir.empty() ? std::string() : out_dir + "/" + name; }
     void release() {
+        join_writers();
         if (have_cns) be.free_cns(be.ctx, &cnsout), have_cns = false;
         if (have_coords) be.free_coords(be.ctx, &coords), have_coords = false;
         if (have_edges) be.free_edges(be.ctx, &edges), have_edges = false;
@@ -124,17 +128,19 @@ static int run_chain(Run& r) {
 }
 
 // the six GFA snapshots carry every contig sequence (6 x the assembly size of text): each is written by its own thread from a copy of
-// the arc list, while the cleaning passes go on; run_graph returns when all are on disk
+// the arc list, while the cleaning passes AND the per-edge GPU stages (coordinates, consensus) go on - they depend only on the cleaned
+// graph. They are joined before the assembly is written (run_assemble), when the stage is repeated, and when the run is freed.
+// That overlap is what the pipeline as a whole does (hxh_run_all, the CLI: Run::async_writers); a graph stage called on its own returns
+// when all six are on disk. HASLR_GFA_SYNC=1 forces that everywhere (A/B timing).
 struct GfaWriters {
-    std::vector<std::thread> th;
-    void start(const Run& r, const char* name) {
+    Run& r;
+    void start(const char* name) {
         if (r.out_dir.empty()) return;
         auto arcs = std::make_shared<std::vector<std::pair<uint32_t, uint32_t>>>(graph_arc_list(r.g));
         const Dataset* d = r.d;
         const std::string path = r.path(name);
-        th.emplace_back([arcs, d, path]() { graph_write_gfa_arcs(*arcs, *d, path); });
+        r.gfa_writers.emplace_back([arcs, d, path]() { graph_write_gfa_arcs(*arcs, *d, path); });
     }
-    ~GfaWriters() { for (auto& t : th) t.join(); }
 };
 
 static int run_graph(Run& r) {
@@ -143,7 +149,8 @@ static int run_graph(Run& r) {
     const bool dbg = getenv("HASLR_GRAPH_DEBUG") != nullptr;
     double tl = t0;
     auto lap = [&](const char* what) { if (dbg) { const double t = now(); fprintf(stderr, "[hxh] graph stage: %-28s %7.1f ms\n", what, (t - tl) * 1e3); tl = t; } };
-    GfaWriters gfa;
+    r.join_writers();
+    GfaWriters gfa{r};
     if (r.have_edges) r.be.free_edges(r.be.ctx, &r.edges), r.have_edges = false;
     if (r.be.edge_support(r.be.ctx, &r.prm, &r.edges) != 0) return backend_fail(r, "edge_support");
     r.have_edges = true;
@@ -153,13 +160,13 @@ static int run_graph(Run& r) {
     graph_build(g, (uint32_t)d.contig_len.size(), r.edges);
     lap("build");
     graph_write_stats(g, d, r.path("backbone.01.init.stat"));
-    gfa.start(r, "backbone.01.init.gfa");
+    gfa.start("backbone.01.init.gfa");
     lap("stat + gfa 01");
     int nb = graph_remove_weak_edges(g, r.prm.min_edge_sup);
     if (!r.out_dir.empty()) fprintf(stderr, "       removed %d edges\n", nb);
     lap("weak edges");
     graph_write_stats(g, d, r.path("backbone.02.weakEdge.stat"));
-    gfa.start(r, "backbone.02.weakEdge.gfa");
+    gfa.start("backbone.02.weakEdge.gfa");
     lap("stat + gfa 02");
     nb = clean_tips(g, 1, r.path("backbone.03.tip.log"));
     nb += clean_tips(g, 2, r.path("backbone.03.tip.log"));
@@ -167,30 +174,28 @@ static int run_graph(Run& r) {
     if (!r.out_dir.empty()) fprintf(stderr, "       removed %d tips\n", nb);
     lap("tips x3");
     graph_write_stats(g, d, r.path("backbone.03.tip.stat"));
-    gfa.start(r, "backbone.03.tip.gfa");
+    gfa.start("backbone.03.tip.gfa");
     lap("stat + gfa 03");
     nb = clean_simple_bubbles(g, 4, r.path("backbone.04.simplebubble.log"));
     if (!r.out_dir.empty()) fprintf(stderr, "       removed %d simple bubbles\n", nb);
     lap("simple bubbles");
     graph_write_stats(g, d, r.path("backbone.04.simplebubble.stat"));
-    gfa.start(r, "backbone.04.simplebubble.gfa");
+    gfa.start("backbone.04.simplebubble.gfa");
     lap("stat + gfa 04");
     nb = clean_super_bubbles(g, r.path("backbone.05.superbubble.log"));
     if (!r.out_dir.empty()) fprintf(stderr, "       removed %d super bubbles\n", nb);
     lap("super bubbles");
     graph_write_stats(g, d, r.path("backbone.05.superbubble.stat"));
-    gfa.start(r, "backbone.05.superbubble.gfa");
+    gfa.start("backbone.05.superbubble.gfa");
     lap("stat + gfa 05");
     nb = clean_small_bubbles(g, r.path("backbone.06.smallbubble.log"));
     if (!r.out_dir.empty()) fprintf(stderr, "       removed %d small bubbles\n", nb);
     lap("small bubbles");
     graph_write_stats(g, d, r.path("backbone.06.smallbubble.stat"));
-    gfa.start(r, "backbone.06.smallbubble.gfa");
+    gfa.start("backbone.06.smallbubble.gfa");
     graph_report_branching(g, r.path("backbone.branching.log"));
     lap("stat + gfa 06 + branching");
-    for (auto& t : gfa.th) t.join();
-    gfa.th.clear();
-    lap("gfa writers joined");
+    if (!r.async_writers || getenv("HASLR_GFA_SYNC")) { r.join_writers(); lap("gfa writers joined"); }
     r.t[1] = now() - t0;
     return 0;
 }
@@ -326,6 +331,11 @@ static int run_consensus(Run& r) {
     if (work_queue(r.g, 12) != r.work) { g_err = "internal: consensus work queue differs from coordinate work queue"; return -1; }
     hx_poa_params pp{5, -4, -8};   // Assemble.cpp:8-11
     if (r.have_cns) r.be.free_cns(r.be.ctx, &r.cnsout), r.have_cns = false;
+    if (!r.cns.empty()) {   // a repeated call: the strings of the earlier one go, those imported from other ranks are applied again
+        r.cns.clear();
+        for (uint32_t gi : r.mine) r.res[gi].have_cns = false;
+        for (uint32_t gi = 0; gi < r.res.size(); gi++) if (r.res[gi].have_cns) apply_cns(r, gi);
+    }
     if (r.be.poa_batch(r.be.ctx, &pp, &r.cnsout) != 0) return backend_fail(r, "poa_batch");
     const double t_poa = now();
     r.have_cns = true;
@@ -352,7 +362,7 @@ static int run_consensus(Run& r) {
 namespace {
 constexpr uint32_t kBlobMagic = 0x31525848u;   // "HXR1"
 
-void export_results(Run& r) {
+int export_results(Run& r) {
     std::vector<uint32_t> w{kBlobMagic, (uint32_t)r.mine.size(), 0u};
     for (uint32_t gi : r.mine) {
         const EdgeResult& x = r.res[gi];
@@ -363,9 +373,11 @@ void export_results(Run& r) {
         w.resize(at + (x.cns.size() + 3) / 4, 0u);
         memcpy(w.data() + at, x.cns.data(), x.cns.size());
     }
+    if (w.size() > 0xffffffffull) { g_err = "results export: this rank's share exceeds 2^32 words (the blob's length field is 32 bits)"; return -1; }
     w[2] = (uint32_t)w.size();
     r.blob.resize(w.size() * 4);
     memcpy(r.blob.data(), w.data(), r.blob.size());
+    return 0;
 }
 
 int import_results(Run& r, const uint8_t* buf, uint64_t len) {
@@ -556,6 +568,7 @@ std::vector<std::deque<Anchor>> simple_paths(Graph& g) {
 
 static int run_assemble(Run& r) {
     double t0 = now();
+    r.join_writers();   // the GFA snapshots are complete before the stage's last outputs appear
     if (const size_t miss = missing_results(r)) {
         g_err = "assemble: " + std::to_string(miss) + " of " + std::to_string(r.res.size()) + " edges have no coordinates / consensus in this run" +
                 (r.shard_world > 1 ? " (multi-GPU: the other ranks' results must be imported first, hxh_run_results_import)" : " (coords and consensus stages must run first)");
@@ -596,8 +609,11 @@ extern "C" int hxh_run_graph(hxh_run* p) { return run_graph(*reinterpret_cast<Ru
 extern "C" int hxh_run_coords(hxh_run* p) { return run_coords(*reinterpret_cast<Run*>(p)); }
 extern "C" int hxh_run_consensus(hxh_run* p) { return run_consensus(*reinterpret_cast<Run*>(p)); }
 extern "C" int hxh_run_assemble(hxh_run* p) { return run_assemble(*reinterpret_cast<Run*>(p)); }
+extern "C" void hxh_run_set_async_writers(hxh_run* p, int on) { reinterpret_cast<Run*>(p)->async_writers = on != 0; }
 extern "C" int hxh_run_all(hxh_run* p) {
     Run& r = *reinterpret_cast<Run*>(p);
+    struct Async { Run& r; bool was; ~Async() { r.async_writers = was; } } guard{r, r.async_writers};
+    r.async_writers = true;   // (run_assemble joins the writers)
     int rc;
     if ((rc = run_chain(r))) return rc;
     if ((rc = run_graph(r))) return rc;
@@ -613,7 +629,7 @@ extern "C" void hxh_run_set_read_shard(hxh_run* p, uint32_t lr_begin) { reinterp
 extern "C" int hxh_run_results_export(hxh_run* p, const uint8_t** buf, uint64_t* len) {
     Run* r = reinterpret_cast<Run*>(p);
     for (uint32_t gi : r->mine) if (!(r->res[gi].have_coords && r->res[gi].have_cns)) { g_err = "results export: the coords and consensus stages have not run"; return -1; }
-    export_results(*r);
+    if (export_results(*r) != 0) return -1;
     *buf = r->blob.data(); *len = r->blob.size();
     return 0;
 }

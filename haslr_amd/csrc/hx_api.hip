@@ -198,9 +198,8 @@ extern "C" int hx_device_count(void) {
 
 extern "C" int hx_ctx_create(int device, void* stream, hx_ctx** out) {
     *out = nullptr;
-    // the POA classes are launched on separate streams and must really overlap: ask the runtime for enough hardware queues
-    // (only effective if HIP has not been initialised in this process yet; haslr_amd/hip.py and bench.py set it before importing torch)
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    // (the POA launch classes go to separate streams and overlap only with enough hardware queues: the APPLICATION sets GPU_MAX_HW_QUEUES >= 8
+    //  before HIP initialises - haslr_assemble, haslr_amd/hip.py and bench.py do; the library does not touch the process environment)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail("hx_ctx_create: no HIP device available (libhaslr_hip.so has no CPU fallback)");
     if (device < 0 || device >= n) return fail("hx_ctx_create: device index out of range");
@@ -271,7 +270,15 @@ extern "C" int hx_set_read_shard(hx_ctx* c, uint32_t b, uint32_t e) {
     return 0;
 }
 
+// the scan / sort launchers skip their work when their scratch cannot be allocated (Workspace::oom): nothing they were to write may be read
+static int ws_ok(hx_ctx* c, const char* who) {
+    if (!c->ws.oom) return 0;
+    c->ws.oom = false;
+    return fail(std::string(who) + ": out of device memory for scan / sort scratch");
+}
+
 static int check_err(hx_ctx* c, const char* who) {
+    if (ws_ok(c, who)) return -1;
     uint32_t e = 0;
     HIPCHK(hipMemcpy(&e, c->err.p, 4, hipMemcpyDeviceToHost));
     if (!e) return 0;
@@ -310,6 +317,7 @@ extern "C" int hx_chain_reads(hx_ctx* c, const hx_params* prm, hx_chain_out* out
     hxk::chain_reads(c->hits_view(), c->rho.p, c->cls.p, c->n_contigs, c->lr_begin, c->lr_end, prm->min_aln_block, prm->min_aln_sim, prm->min_aln_mapq, sc, c->err.p, c->prefiltered, s);
     hxk::exclusive_scan_u32(s_naln.p, c->aln_off.p, nr, s, c->ws);
     hxk::exclusive_scan_u32(s_ncmp.p, c->cmp_off.p, nr, s, c->ws);
+    if (ws_ok(c, "hx_chain_reads")) return -1;
     uint64_t tot[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(&tot[0], c->aln_off.p + nr, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&tot[1], c->cmp_off.p + nr, 8, hipMemcpyDeviceToHost, s));
@@ -353,6 +361,7 @@ extern "C" int hx_edge_emit(hx_ctx* c, const hx_params*, uint64_t* n_records) {
     c->tick();
     hxk::edge_count(c->hits_view(), c->cls.p, c->chain_view(), c->cmp_off.p, c->lr_begin, c->lr_end, npairs.p, s);
     hxk::exclusive_scan_u32(npairs.p, pair_off.p, nr, s, c->ws);
+    if (ws_ok(c, "hx_edge_emit")) return -1;
     uint64_t tot = 0;
     HIPCHK(hipMemcpyAsync(&tot, pair_off.p + nr, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -389,6 +398,7 @@ static int finish_edges(hx_ctx* c, uint64_t n, hx_edges_out* out) {
     hxk::edge_gather(c->rec_un.view(), perm.p, n, c->rec.view(), s);
     hxk::segment_flags(c->rec.key.p, n, flag.p, s);
     hxk::exclusive_scan_u32(flag.p, fscan.p, n, s, c->ws);
+    if (ws_ok(c, "hx_edge_support")) return -1;
     uint64_t ne = 0;
     HIPCHK(hipMemcpyAsync(&ne, fscan.p + n, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -476,6 +486,7 @@ extern "C" int hx_edge_coords(hx_ctx* c, uint32_t n_sel, const uint32_t* sel, hx
     hxk::edge_coords(c->rec.view(), c->edge_key.p, c->edge_off.p, c->cg_ops.p, c->clen.p, c->rlen.p, n_sel, d_sel.p, d_cap.p, sc,
                      c->k_head_end.p, c->k_tail_beg.p, d_nsupp.p, t_lr.p, t_sp.p, t_ep.p, s);
     hxk::exclusive_scan_u32(d_nsupp.p, d_out_off.p, n_sel, s, c->ws);
+    if (ws_ok(c, "hx_edge_coords")) return -1;
     uint64_t tot = 0;
     HIPCHK(hipMemcpyAsync(&tot, d_out_off.p + n_sel, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

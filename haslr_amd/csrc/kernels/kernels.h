@@ -16,7 +16,8 @@ namespace hxk {
 struct Workspace {
     struct Block { char* p; size_t cap, used; };
     std::vector<Block> blocks;
-    void* take(size_t bytes);       // 256-byte aligned; nullptr when the device is out of memory
+    bool oom = false;               // sticky: an allocation failed since the owner last looked (the launchers then skip their work; the operator must report it)
+    void* take(size_t bytes);       // 256-byte aligned; nullptr when the device is out of memory (and oom is set)
     void reset(hipStream_t s);      // (several blocks are merged into one of their total size, after the stream has drained)
     void release();
     ~Workspace() { release(); }

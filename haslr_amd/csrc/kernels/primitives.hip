@@ -71,7 +71,7 @@ void scan_impl(const TIN* in, uint64_t* out, uint64_t n, hipStream_t s, Workspac
     }
     uint64_t* sums = (uint64_t*)ws.take(nb * sizeof(uint64_t));
     uint64_t* prefix = (uint64_t*)ws.take((nb + 1) * sizeof(uint64_t));
-    if (!sums || !prefix) return;   // (out of device memory: the caller's next HIP call reports it)
+    if (!sums || !prefix) return;   // (out of device memory: Workspace::oom is set, the operator reports it before it reads any result)
     scan_block_sums<TIN><<<(unsigned)nb, SCAN_T, 0, s>>>(in, n, sums);
     scan_impl<uint64_t>(sums, prefix, nb, s, ws);
     scan_apply<TIN><<<(unsigned)nb, SCAN_T, 0, s>>>(in, n, prefix, out);
@@ -89,7 +89,7 @@ void* Workspace::take(size_t bytes) {
     }
     size_t cap = std::max<size_t>(bytes, blocks.empty() ? (size_t)1 << 20 : blocks.back().cap * 2);
     char* p = nullptr;
-    if (hipMalloc((void**)&p, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMalloc((void**)&p, cap) != hipSuccess) { (void)hipGetLastError(); oom = true; return nullptr; }
     blocks.push_back(Block{p, cap, bytes});
     return p;
 }
@@ -100,7 +100,7 @@ void Workspace::reset(hipStream_t s) {
         (void)hipStreamSynchronize(s);
         release();
         char* p = nullptr;
-        if (hipMalloc((void**)&p, total) == hipSuccess) blocks.push_back(Block{p, total, 0}); else (void)hipGetLastError();
+        if (hipMalloc((void**)&p, total) == hipSuccess) blocks.push_back(Block{p, total, 0}); else { (void)hipGetLastError(); oom = true; }
     }
     for (Block& b : blocks) b.used = 0;
 }

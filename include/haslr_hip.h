@@ -35,7 +35,11 @@ typedef struct hx_ctx hx_ctx;
 const char* hx_last_error(void);
 int hx_device_count(void); /* number of HIP devices, <0 on error */
 
-/* stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL to create one */
+/* stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL to create one.
+ * Process environment: the library never modifies it. hx_poa_batch launches its lane-count classes on separate streams; they run side
+ * by side only if the HIP runtime was initialised with GPU_MAX_HW_QUEUES >= 8 (the runtime's default is 4), so an application that wants
+ * the measured POA throughput exports that variable before its first HIP call (haslr_assemble, haslr_amd/hip.py and bench.py do).
+ * Results do not depend on it. */
 int hx_ctx_create(int device, void* stream, hx_ctx** out);
 void hx_ctx_destroy(hx_ctx*);
 

@@ -52,7 +52,8 @@ namespace hx {
 struct Device {
     hx_ctx* ctx = nullptr;
     std::mutex mu;
-    ~Device() { if (ctx) hx_ctx_destroy(ctx); }
+    // (no destructor: this object is destroyed during static destruction, possibly after the HIP runtime has torn itself down -
+    //  the context and its device memory are left to the end of the process)
 };
 inline Device& device() {
     static Device d;

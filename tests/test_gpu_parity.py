@@ -507,6 +507,72 @@ def test_configs1_bench_dataset_against_oracle(sim, ctx):
     _full_size_against_oracle(sim, ctx, ("--genome-len", "4600000", "--seed", hex(0x4841534C + 1), "--model", "pacbio", "--cov", "25", "--variant-per-mb", "1.5"), 300)
 
 
+def _drop_sim_files(pre):
+    """the multi-GB inputs of the full-size tests do not stay on the box's disk for the rest of the session"""
+    for suffix in (".contigs.fa", ".reads.fa", ".paf", ".genome.fa", ".truth.tsv"):
+        try:
+            os.remove(pre + suffix)
+        except OSError:
+            pass
+
+
+huge = pytest.mark.skipif(bool(os.environ.get("HASLR_SKIP_HUGE")), reason="HASLR_SKIP_HUGE is set (developer runs: the 140 Mb / 400 Mb tests take ~10 min together)")
+
+
+@huge
+def test_configs3_full_size_against_oracle(sim, ctx):
+    """BASELINE configs[3] at full size on ONE GPU (140 Mb genome, PacBio-like 25x, seed 0x4841534c + 3: bench.py --workload fly, the N = 4
+    default): every stage array, every consensus and the assembly identical to the oracle's (all host cores; ~60 s simulate + ~2.5 min oracle)"""
+    args = ("--genome-len", "140000000", "--seed", hex(0x4841534C + 3), "--model", "pacbio", "--cov", "25", "--variant-per-mb", "1.5")
+    try:
+        _full_size_against_oracle(sim, ctx, args, 10000)
+    finally:
+        _drop_sim_files(sim(*args))
+
+
+@huge
+def test_configs4_share_full_size_properties(sim, ctx, tmp_path):
+    """One GPU's share of BASELINE configs[4] (3.1 Gb / 8 GPUs = a 400 Mb genome, PacBio-like 25x, seed 0x4841534c + 4) on one MI355X. Too
+    big for the oracle inside a test (405 s on 256 threads), so the size-independent properties: twin symmetry of the edge multiset,
+    sortedness, non-overlapping chains, idempotence of a second pass, identity of the assembly against the truth genome."""
+    args = ("--genome-len", "400000000", "--seed", hex(0x4841534C + 4), "--model", "pacbio", "--cov", "25", "--no-variants")
+    pre = sim(*args)
+    try:
+        ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf", threads=min(32, os.cpu_count() or 1))
+        ctx.upload(ds)
+        prm = ds.params()
+        out = str(tmp_path / "g")
+        run = host.Run(ds, prm, ctx.backend(), out)
+        run.all()
+        assert run.n_edges >= 30000
+        e = run.edges_out(sides=False)
+        assert np.all(e["key"][1:] >= e["key"][:-1])
+        ek = e["edge_key"]
+        twin = ((ek & np.uint64(0xffffffff)) ^ np.uint64(1)) << np.uint64(32) | ((ek >> np.uint64(32)) ^ np.uint64(1))
+        cnt = np.diff(e["edge_off"])
+        pos = np.searchsorted(ek, twin)                      # edge keys are sorted and unique
+        assert np.all(pos < ek.size) and np.array_equal(ek[pos], twin) and np.array_equal(cnt[pos], cnt)   # every edge has a twin with the same support
+        c = run.chain_out()
+        a = c["cmp_aln"]
+        inner = np.ones(a.size, dtype=bool)
+        starts = c["cmp_off"][:-1]
+        inner[starts[starts < a.size].astype(np.int64)] = False                                # first element of every compact read
+        assert np.all(c["q_end"][a[:-1]][inner[1:]] <= c["q_start"][a[1:]][inner[1:]])        # chained hits never overlap on the read
+        fasta1, cns1 = run.assembly_fasta(), run.cns_out()
+        run.close()
+        run2 = host.Run(ds, prm, ctx.backend(), None)
+        run2.all()
+        assert run2.cns_out() == cns1 and run2.assembly_fasta() == fasta1                   # idempotent / deterministic at this size
+        run2.close()
+        o = subprocess.check_output([os.path.join(ROOT, "tools", "hxident"), pre + ".genome.fa", os.path.join(out, "asm.final.fa")], text=True)
+        ident = float(o.strip().split("\n")[-1].split()[1])
+        # identity against the SYNTHETIC TRUTH (not against the reference's output, which cannot be produced here: SPOA 1.1.3 is not in the image)
+        assert ident >= 0.997, o[-500:]
+        ds.close()
+    finally:
+        _drop_sim_files(pre)
+
+
 def test_hairpin_reads_through_hip(sim, ctx, tmp_path):
     """missed-adapter reads (the palindrome rule of Longread.cpp:182-232 fires on every one of them): all stages identical to the oracle's"""
     pre = sim("--genome-len", "200000", "--seed", "8", "--variant-per-mb", "30", "--cov", "14", "--hairpin-frac", "0.1")
