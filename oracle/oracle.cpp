@@ -799,7 +799,27 @@ int poa_edge(const hx_reads* R, const hx_coords_out* C, uint32_t s, const hx_poa
         uint32_t lmax = 0; uint64_t sum = 0; uint32_t ns = 0;
         for (uint64_t k = C->supp_off[s]; k < C->supp_off[s + 1]; k++) { uint32_t rl = R->len[C->supp_lr[k] & 0x7fffffffu]; uint32_t w = C->epos[k] - C->spos[k] + 1; uint32_t n = std::min(w, rl - C->spos[k]); lmax = std::max(lmax, n); sum += n; ns++; }
         size_t maxin = 0; for (auto& v : G.in) maxin = std::max(maxin, v.size());
-        fprintf(stderr, "POASTAT nseq=%u lmax=%u sumL=%lu V=%zu E=%zu maxin=%zu\n", ns, lmax, (unsigned long)sum, G.code.size(), G.edges.size(), maxin);
+        // columns (aligned groups) and predecessor lags in columns: what an anti-diagonal schedule of the DP would see (tools/dev_skewbench.hip)
+        size_t ncol = 0, lag1 = 0, lag6 = 0, lagfar = 0, np2 = 0, np3 = 0, np5 = 0;
+        {
+            G.toposort();
+            std::vector<uint32_t> colof(G.code.size(), 0);
+            uint32_t c = 0;
+            std::vector<uint8_t> seen(G.code.size(), 0);
+            for (uint32_t n : G.rank2node) {
+                if (seen[n]) continue;
+                seen[n] = 1; colof[n] = c;
+                for (uint32_t a : G.aligned[n]) { seen[a] = 1; colof[a] = c; }
+                c++;
+            }
+            ncol = c;
+            for (size_t n = 0; n < G.code.size(); n++) {
+                np2 += G.in[n].size() >= 2; np3 += G.in[n].size() >= 3; np5 += G.in[n].size() >= 5;
+                for (uint32_t e : G.in[n]) { const uint32_t d = colof[n] - colof[G.edges[e].from]; lag1 += d == 1; lag6 += d <= 6; lagfar += d > 6; }
+            }
+        }
+        fprintf(stderr, "POASTAT nseq=%u lmax=%u sumL=%lu V=%zu E=%zu maxin=%zu cols=%zu lag1=%zu lag<=6=%zu lag>6=%zu np>=2=%zu np>=3=%zu np>=5=%zu\n", ns, lmax, (unsigned long)sum, G.code.size(), G.edges.size(), maxin,
+                ncol, lag1, lag6, lagfar, np2, np3, np5);
     }
     cns.clear();
     if (non_empty == 0) return 0;   // :544-551
