@@ -68,6 +68,17 @@ void hxh_run_free(hxh_run*);
  *                            join before asm_get_assembly, Assemble.cpp:580-605 -> :1045-1077)
  *   hxh_run_compact_text     the compact_uniq.txt lines of the reads this run chained (a sharded run does not write the file itself) */
 void hxh_run_set_edge_shard(hxh_run*, uint32_t rank, uint32_t world);
+/* the same inside ONE process (one host thread per rank; the multi-GPU mode of the haslr_assemble binary):
+ *   hxh_shard_bounds        n + 1 boundaries of contiguous read-id ranges with about equal numbers of raw PAF records
+ *   hxh_runs_all_sharded    the whole stage over runs[0..n): runs[r] was created on rank r's backend table (include/haslr_hip.h
+ *                           hx_group_backend_fill: its edge_support is the collective hx_edge_merge), runs[0] owns the output directory. One
+ *                           thread per rank: chain (own reads) -> graph (merged multiset, cleaned redundantly) -> coordinates + consensus (own
+ *                           share of the queue) -> results exchanged through the process's memory -> rank 0 writes compact_uniq.txt and the
+ *                           assembly. The ranks agree on success after every stage: an error on one rank ends all of them, none waits
+ *                           forever. on_stage (may be NULL) is called on rank 0's thread at the begin (1) / end (0) of stage 0..4
+ *                           (chain, graph, coords, consensus, assemble). */
+void hxh_shard_bounds(const hxh_dataset*, uint32_t n, uint32_t* bounds);
+int hxh_runs_all_sharded(hxh_run** runs, uint32_t n, const uint32_t* read_begin, void (*on_stage)(int stage, int begin, void* user), void* user);
 void hxh_run_set_read_shard(hxh_run*, uint32_t lr_begin);
 int hxh_run_results_export(hxh_run*, const uint8_t** buf, uint64_t* len);
 int hxh_run_results_import(hxh_run*, const uint8_t* buf, uint64_t len);

@@ -6,7 +6,8 @@
 //                  [--long-fofn] [--mapping-fofn] [--version] [-h]
 // and the same conventions: exit 0 on success and for -h / --version (haslr.py's check_program relies on it),
 // `[ERROR] ...` on stderr + EXIT_FAILURE otherwise, progress on stderr, outputs inside -d.
-// Build-only additions: --device INT (HIP device, default 0), --poa-block INT.
+// Build-only additions: --device INT (HIP device, default 0), --poa-block INT, --gpus INT (the GPUs of this node the per-read and per-edge work
+// is spread over: one host thread and one RCCL rank per GPU inside this process, ONE all-gather of the edge-support records; default 1).
 // -t is accepted and clamped like the reference's, but the per-read / per-edge work runs on the GPU.
 // index.contig / index.longread (the reference's cache files, Contig.cpp:119-159, Longread.cpp:322-372) are written into -d and loaded
 // instead of the text inputs when they exist, like main.cpp:39-103 does (host/index_cache.cpp; records read back from index.longread are
@@ -23,6 +24,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "../../../include/haslr_hip.h"
 #include "haslr_host.h"
@@ -59,6 +61,7 @@ static void help(const hx_params& p) {
     fprintf(stderr, "    --long-fofn       The file passed by -l is fofn\n");
     fprintf(stderr, "    --mapping-fofn    The file passed by -m is fofn\n");
     fprintf(stderr, "    --device INT      HIP device to run on [0]\n");
+    fprintf(stderr, "    --gpus INT        Number of GPUs of this node to use, devices 0..INT-1 [1]\n");
     fprintf(stderr, "    --version         Prints version (%s)\n", kVersion);
     fprintf(stderr, "    -h                Prints this help message (also --help)\n\n");
 }
@@ -68,13 +71,13 @@ int main(int argc, char* argv[]) {
     std::string contig_path, long_path, mapping_path, out_dir;
     bool long_fofn = false, mapping_fofn = false;
     unsigned num_threads = 1;
-    int device = 0, poa_block = 0;
+    int device = 0, poa_block = 0, gpus = 1;
     if (argc == 1) { help_short(); return EXIT_FAILURE; }
     static struct option lo[] = {{"contig", required_argument, 0, 'c'}, {"long", required_argument, 0, 'l'}, {"mapping", required_argument, 0, 'm'},
                                  {"dir", required_argument, 0, 'd'}, {"help", no_argument, 0, 'h'}, {"threads", required_argument, 0, 't'},
                                  {"version", no_argument, 0, 0}, {"long-fofn", no_argument, 0, 0}, {"mapping-fofn", no_argument, 0, 0},
                                  {"aln-block", required_argument, 0, 0}, {"aln-sim", required_argument, 0, 0}, {"uniq-dev", required_argument, 0, 0},
-                                 {"edge-sup", required_argument, 0, 0}, {"device", required_argument, 0, 0}, {"poa-block", required_argument, 0, 0}, {0, 0, 0, 0}};
+                                 {"edge-sup", required_argument, 0, 0}, {"device", required_argument, 0, 0}, {"poa-block", required_argument, 0, 0}, {"gpus", required_argument, 0, 0}, {0, 0, 0, 0}};
     int ch, li;
     while ((ch = getopt_long(argc, argv, "c:l:m:d:t:h", lo, &li)) != -1) {
         switch (ch) {
@@ -98,6 +101,7 @@ int main(int argc, char* argv[]) {
                 else if (li == 12) { int v = atoi(optarg); prm.min_edge_sup = v < 0 ? 3 : (uint32_t)v; }
                 else if (li == 13) device = atoi(optarg);
                 else if (li == 14) poa_block = atoi(optarg);
+                else if (li == 15) { gpus = atoi(optarg); if (gpus < 1) gpus = 1; }
                 else { help_short(); return EXIT_FAILURE; }
                 break;
             default: help_short(); return EXIT_FAILURE;
@@ -115,9 +119,19 @@ int main(int argc, char* argv[]) {
     auto elapsed = [&]() { fprintf(stderr, "       elapsed time %.2lf CPU seconds (%.2lf real seconds)\n\n", cpu_time() - c0, real_time() - r0); };
 
     setenv("GPU_MAX_HW_QUEUES", "8", 0);   // before HIP initialises: the POA launch classes overlap on separate hardware queues (include/haslr_hip.h)
+    // --gpus N > 1 (or HASLR_FORCE_GROUP=1, which sends one GPU through the same code): a group of contexts, one rank per GPU
+    const bool grouped = gpus > 1 || getenv("HASLR_FORCE_GROUP");
     hx_ctx* ctx = nullptr;
-    if (hx_ctx_create(device, nullptr, &ctx) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
-    if (poa_block) hx_set_poa_block(ctx, poa_block);
+    hx_group* group = nullptr;
+    if (grouped) {
+        if (hx_group_create(gpus, nullptr, &group) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
+        fprintf(stderr, "[NOTE] %d GPU ranks in this process, edge-record exchange over %s\n\n", gpus, hx_group_transport(group));
+        ctx = hx_group_ctx(group, 0);
+        if (poa_block) for (int r = 0; r < gpus; r++) hx_set_poa_block(hx_group_ctx(group, r), poa_block);
+    } else {
+        if (hx_ctx_create(device, nullptr, &ctx) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
+        if (poa_block) hx_set_poa_block(ctx, poa_block);
+    }
 
     fprintf(stderr, "[NOTE] loading contig sequences, long read sequences and alignments...\n");
     // index.contig / index.longread of the output directory are loaded when they exist, written when they do not (main.cpp:39-103)
@@ -137,6 +151,46 @@ int main(int argc, char* argv[]) {
     prm.uniq_freq = hxh_dataset_uniq_freq(ds);
     fprintf(stderr, "[NOTE] calculating kmer frequency of unique contigs\n       mean: %.2lf\n", prm.uniq_freq);
     elapsed();
+    if (grouped) {
+        // inputs are replicated on every GPU (they fit: DESIGN.md 3); reads are sharded by id range, edges by estimated DP cost
+        std::vector<uint32_t> bounds((size_t)gpus + 1);
+        hxh_shard_bounds(ds, (uint32_t)gpus, bounds.data());
+        std::vector<std::string> uerr((size_t)gpus);
+        std::vector<std::thread> up;
+        for (int r = 0; r < gpus; r++)
+            up.emplace_back([&, r]() {
+                hx_ctx* c = hx_group_ctx(group, r);
+                if (hx_upload(c, &vc, &vr, &vh, rho) != 0 || hx_set_read_shard(c, bounds[r], bounds[r + 1]) != 0) uerr[r] = hx_last_error();
+                hx_set_prefiltered(c, used_li);
+            });
+        for (auto& t : up) t.join();
+        for (int r = 0; r < gpus; r++) if (!uerr[r].empty()) { fprintf(stderr, "[ERROR] rank %d: %s\n", r, uerr[r].c_str()); return EXIT_FAILURE; }
+        std::vector<hx_backend> tables((size_t)gpus);
+        std::vector<hxh_run*> runs((size_t)gpus);
+        for (int r = 0; r < gpus; r++) {
+            hx_group_backend_fill(group, r, &tables[r]);
+            runs[r] = hxh_run_create(ds, &prm, &tables[r], r == 0 ? out_dir.c_str() : nullptr);
+        }
+        static const char* notes[5] = {"[NOTE] fixing overlapping alignments and building compact long reads...", "[NOTE] building and cleaning the backbone graph...",
+                                       "[NOTE] calculating long read coordinates between anchors...", "[NOTE] calling consensus sequence between anchors...",
+                                       "[NOTE] generating the assembly from the cleaned backbone graph..."};
+        struct Cb { decltype(elapsed)* el; hx_group* g; } cb{&elapsed, group};
+        auto on_stage = [](int s, int begin, void* u) {
+            Cb* c = (Cb*)u;
+            if (begin) fprintf(stderr, "%s\n", notes[s]);
+            else {
+                if (s == 1) { uint64_t by = 0; double ms = 0; hx_group_exchange_stats(c->g, &by, &ms); fprintf(stderr, "       exchanged %lu bytes of edge records in %.2f ms (%s)\n", (unsigned long)by, ms, hx_group_transport(c->g)); }
+                (*c->el)();
+            }
+        };
+        if (hxh_runs_all_sharded(runs.data(), (uint32_t)gpus, bounds.data(), on_stage, &cb) != 0) { fprintf(stderr, "[ERROR] %s\n", hxh_last_error()); return EXIT_FAILURE; }
+        // (index.longread is not written by a sharded run: every rank holds only its own reads' filtered alignments; a later run parses the PAF again)
+        fprintf(stderr, "[NOTE] cleaning up the memory!\n");
+        fprintf(stderr, "[NOTE] elapsed time %.2lf CPU seconds (%.2lf real seconds)\n\n*** BYE ***\n\n", cpu_time() - c0, real_time() - r0);
+        fflush(nullptr);
+        if (getenv("HASLR_FULL_TEARDOWN")) { for (hxh_run* r : runs) hxh_run_free(r); hxh_dataset_free(ds); hx_group_destroy(group); return EXIT_SUCCESS; }
+        _exit(EXIT_SUCCESS);
+    }
     if (hx_upload(ctx, &vc, &vr, &vh, rho) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
     hx_set_prefiltered(ctx, used_li);
 

@@ -9,6 +9,8 @@
 //   asm_assemble_single_path       Assemble.cpp:624-755  (asm.final.fa / asm.final.ann bytes)
 //   asm_get_assembly               Assemble.cpp:1045-1077
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <memory>
 #include <algorithm>
 #include <chrono>
@@ -657,4 +659,94 @@ extern "C" const char* hxh_run_assembly_fasta(const hxh_run* p, uint64_t* len) {
     const Run* r = reinterpret_cast<const Run*>(p);
     if (len) *len = r->fasta.size();
     return r->fasta.c_str();
+}
+
+// ---------------------------------------------------------------------------------------------
+// The whole stage over n ranks INSIDE one process (one host thread per rank, one GPU per rank behind the ranks' backend tables): what the
+// reference's worker threads are to asm_calc_edge_coordinates_MT / asm_cal_cns_seq_MT (Assemble.cpp:453-477, :580-605), with the reads
+// sharded as well. Between the stages the ranks agree on success - a rank that failed never leaves the others waiting inside the
+// edge-record collective - and the per-edge results travel through the process's memory (export -> import), no second collective.
+// ---------------------------------------------------------------------------------------------
+extern "C" void hxh_shard_bounds(const hxh_dataset* p, uint32_t n, uint32_t* bounds) {
+    // contiguous read-id ranges with about equal numbers of raw PAF records (SURVEY.md 8e phase 1)
+    const Dataset* d = reinterpret_cast<const Dataset*>(p);
+    const std::vector<uint64_t>& rho = d->read_hit_off;
+    const uint32_t nr = (uint32_t)rho.size() - 1;
+    const uint64_t total = rho[nr];
+    bounds[0] = 0;
+    for (uint32_t r = 1; r < n; r++) {
+        const uint64_t want = total / n * r + total % n * r / n;
+        bounds[r] = std::max<uint32_t>(bounds[r - 1], (uint32_t)(std::lower_bound(rho.begin(), rho.end(), want) - rho.begin()));
+        if (bounds[r] > nr) bounds[r] = nr;
+    }
+    bounds[n] = nr;
+}
+
+namespace {
+struct RankBarrier {   // everybody arrives with a status, everybody leaves with the worst one
+    std::mutex mu; std::condition_variable cv;
+    uint32_t n, arrived = 0; int worst = 0, agreed = 0; uint64_t gen = 0;
+    explicit RankBarrier(uint32_t n_) : n(n_) {}
+    int meet(int status) {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t g = gen;
+        worst = std::max(worst, status);
+        if (++arrived == n) { agreed = worst; worst = 0; arrived = 0; gen++; cv.notify_all(); return agreed; }
+        cv.wait(lk, [&] { return gen != g; });
+        return agreed;
+    }
+};
+}  // namespace
+
+extern "C" int hxh_runs_all_sharded(hxh_run** runs, uint32_t n, const uint32_t* read_begin, void (*on_stage)(int stage, int begin, void* user), void* user) {
+    if (n == 0) { g_err = "sharded run: no ranks"; return -1; }
+    std::vector<Run*> R(n);
+    for (uint32_t r = 0; r < n; r++) R[r] = reinterpret_cast<Run*>(runs[r]);
+    RankBarrier bar(n);
+    std::vector<std::string> errs(n);
+    std::vector<int> rcs(n, 0);
+    auto body = [&](uint32_t r) {
+        Run& me = *R[r];
+        me.shard_rank = r; me.shard_world = n; me.lr_begin = read_begin[r];
+        me.async_writers = true;
+        int (*stages[4])(Run&) = {run_chain, run_graph, run_coords, run_consensus};
+        for (int s = 0; s < 4; s++) {
+            if (r == 0 && on_stage) on_stage(s, 1, user);
+            int rc = stages[s](me);
+            if (rc) errs[r] = g_err;
+            if (bar.meet(rc != 0)) { rcs[r] = -1; if (errs[r].empty()) errs[r] = "another rank failed"; return; }
+            if (r == 0 && on_stage) on_stage(s, 0, user);
+        }
+        // results: every rank publishes its share, every rank takes the others'
+        int rc = export_results(me);
+        if (rc) errs[r] = g_err;
+        if (bar.meet(rc != 0)) { rcs[r] = -1; if (errs[r].empty()) errs[r] = "another rank failed"; return; }
+        for (uint32_t q = 0; q < n && !rc; q++)
+            if (q != r && import_results(me, R[q]->blob.data(), R[q]->blob.size()) != 0) { rc = -1; errs[r] = g_err; }
+        if (!rc && missing_results(me)) { rc = -1; errs[r] = std::to_string(missing_results(me)) + " edges are without results after the exchange"; }
+        if (bar.meet(rc != 0)) { rcs[r] = -1; if (errs[r].empty()) errs[r] = "another rank failed"; return; }
+        if (r == 0) {
+            if (on_stage) on_stage(4, 1, user);
+            // compact_uniq.txt lists every read: the ranks' lines in rank order = read order
+            if (FILE* fp = open_or_null(me.path("compact_uniq.txt"), "w")) {
+                for (uint32_t q = 0; q < n; q++) { const std::string t = compact_lines(*R[q]); fwrite(t.data(), 1, t.size(), fp); }
+                fclose(fp);
+            }
+            if (run_assemble(me) != 0) { rcs[r] = -1; errs[r] = g_err; }
+            if (on_stage) on_stage(4, 0, user);
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t r = 1; r < n; r++) th.emplace_back(body, r);
+    body(0);
+    for (auto& t : th) t.join();
+    for (uint32_t r = 0; r < n; r++) R[r]->join_writers();
+    for (uint32_t r = 0; r < n; r++)
+        if (rcs[r]) {   // the first rank with an error of its own tells what went wrong
+            uint32_t w = r;
+            for (uint32_t q = 0; q < n; q++) if (rcs[q] && errs[q] != "another rank failed") { w = q; break; }
+            g_err = "rank " + std::to_string(w) + ": " + errs[w];
+            return -1;
+        }
+    return 0;
 }

@@ -1039,3 +1039,180 @@ extern "C" void hx_backend_fill(hx_ctx* c, void* table) {
     b->ctx = c; b->chain_reads = be_chain; b->edge_support = be_edges; b->edge_coords = be_coords; b->poa_batch = be_poa;
     b->free_chain = be_fc; b->free_edges = be_fe; b->free_coords = be_fk; b->free_cns = be_fn; b->last_error = hx_last_error;
 }
+
+// ================================================================================================ multi-GPU inside one process
+// What asm_calc_edge_coordinates_MT / asm_cal_cns_seq_MT (Assemble.cpp:453-477, :580-605; called from main.cpp:203-208) are to the reference -
+// a fan-out of the per-read / per-edge work over the threads of ONE process - this is to the GPUs of one node: a group of contexts (one per
+// device, one host thread each) with one RCCL communicator each (ncclCommInitAll), and ONE collective on the data path: the all-gather of
+// the packed edge-support records between the chain stage and the key sort (hx_edge_merge). librccl is looked up at run time (it is half a
+// gigabyte: a single-GPU run never maps it). HASLR_GROUP_TRANSPORT=host stages the exchange through host memory instead, which also allows
+// several ranks on one device (rehearsal of the multi-GPU logic on a one-GPU box).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+
+namespace {
+struct GroupRank { hx_group* g; int rank; };
+}
+struct hx_group {
+    int n = 0;
+    std::vector<hx_ctx*> ctx;
+    std::vector<int> dev;
+    std::vector<GroupRank> self;             // opaque `ctx` of the ranks' backend tables
+    bool rccl = false;
+    void* lib = nullptr;
+    std::vector<ncclComm_t> comm;
+    ncclResult_t (*p_init_all)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*p_all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*p_destroy)(ncclComm_t) = nullptr;
+    const char* (*p_errstr)(ncclResult_t) = nullptr;
+    // rendezvous of the rank threads: everybody arrives with a status, everybody leaves with the worst one (so that no rank enters a
+    // collective the others will never join)
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0, worst = 0, agreed = 0;
+    uint64_t generation = 0;
+    std::vector<uint64_t> counts;
+    std::vector<std::unique_ptr<DV<uint8_t>>> sendb, recvb, merged;
+    std::vector<std::vector<uint8_t>> stage;      // host transport
+    uint64_t last_bytes = 0;
+    double last_ms = 0;
+
+    int rendezvous(int status) {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t gen = generation;
+        worst = std::max(worst, status);
+        if (++arrived == n) { agreed = worst; worst = 0; arrived = 0; generation++; cv.notify_all(); return agreed; }
+        cv.wait(lk, [&] { return generation != gen; });
+        return agreed;
+    }
+};
+
+extern "C" int hx_group_create(int n, const int* devices, hx_group** out) {
+    *out = nullptr;
+    int ndev = 0;
+    if (n < 1) return fail("hx_group_create: at least one rank");
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail("hx_group_create: no HIP device available (no CPU fallback)");
+    std::unique_ptr<hx_group> g(new hx_group);
+    g->n = n;
+    const char* tr = getenv("HASLR_GROUP_TRANSPORT");
+    bool distinct = true;
+    for (int r = 0; r < n; r++) {
+        const int d = devices ? devices[r] : (tr && !strcmp(tr, "host") ? r % ndev : r);
+        if (d < 0 || d >= ndev) return fail("hx_group_create: rank " + std::to_string(r) + " asks for device " + std::to_string(d) + " of " + std::to_string(ndev) +
+                                            " (one device per rank over RCCL; HASLR_GROUP_TRANSPORT=host lets ranks share devices)");
+        for (int q : g->dev) distinct = distinct && q != d;
+        g->dev.push_back(d);
+    }
+    if (tr && strcmp(tr, "host") && strcmp(tr, "rccl")) return fail("HASLR_GROUP_TRANSPORT must be rccl or host");
+    g->rccl = tr ? !strcmp(tr, "rccl") : distinct;
+    if (g->rccl && !distinct) return fail("hx_group_create: RCCL needs one device per rank");
+    g->ctx.assign(n, nullptr);
+    for (int r = 0; r < n; r++)
+        if (hx_ctx_create(g->dev[r], nullptr, &g->ctx[r]) != 0) { for (hx_ctx* c : g->ctx) hx_ctx_destroy(c); return -1; }
+    g->self.resize(n);
+    for (int r = 0; r < n; r++) g->self[r] = GroupRank{g.get(), r};
+    g->counts.assign(n, 0); g->stage.resize(n);
+    for (int r = 0; r < n; r++) { g->sendb.emplace_back(new DV<uint8_t>); g->recvb.emplace_back(new DV<uint8_t>); g->merged.emplace_back(new DV<uint8_t>); }
+    if (g->rccl) {
+        g->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!g->lib) g->lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!g->lib) g->lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!g->lib) { const std::string m = std::string("hx_group_create: cannot load librccl: ") + dlerror(); for (hx_ctx* c : g->ctx) hx_ctx_destroy(c); return fail(m); }
+        g->p_init_all = (decltype(g->p_init_all))dlsym(g->lib, "ncclCommInitAll");
+        g->p_all_gather = (decltype(g->p_all_gather))dlsym(g->lib, "ncclAllGather");
+        g->p_destroy = (decltype(g->p_destroy))dlsym(g->lib, "ncclCommDestroy");
+        g->p_errstr = (decltype(g->p_errstr))dlsym(g->lib, "ncclGetErrorString");
+        if (!g->p_init_all || !g->p_all_gather || !g->p_destroy || !g->p_errstr) { for (hx_ctx* c : g->ctx) hx_ctx_destroy(c); return fail("hx_group_create: librccl lacks ncclCommInitAll / ncclAllGather"); }
+        g->comm.assign(n, nullptr);
+        const ncclResult_t rc = g->p_init_all(g->comm.data(), n, g->dev.data());
+        if (rc != ncclSuccess) { const std::string m = std::string("ncclCommInitAll: ") + g->p_errstr(rc); for (hx_ctx* c : g->ctx) hx_ctx_destroy(c); return fail(m); }
+    }
+    *out = g.release();
+    return 0;
+}
+
+extern "C" void hx_group_destroy(hx_group* g) {
+    if (!g) return;
+    if (g->rccl) for (int r = 0; r < g->n; r++) if (g->comm[r]) { (void)hipSetDevice(g->dev[r]); (void)g->p_destroy(g->comm[r]); }
+    for (int r = 0; r < g->n; r++) { (void)hipSetDevice(g->dev[r]); g->sendb[r]->release(); g->recvb[r]->release(); g->merged[r]->release(); }
+    for (hx_ctx* c : g->ctx) hx_ctx_destroy(c);
+    // (librccl stays mapped: unloading it while the HIP runtime is alive buys nothing)
+    delete g;
+}
+extern "C" int hx_group_size(const hx_group* g) { return g->n; }
+extern "C" hx_ctx* hx_group_ctx(hx_group* g, int rank) { return rank >= 0 && rank < g->n ? g->ctx[rank] : nullptr; }
+extern "C" const char* hx_group_transport(const hx_group* g) { return g->rccl ? "rccl" : "host"; }
+extern "C" void hx_group_exchange_stats(const hx_group* g, uint64_t* bytes, double* ms) { *bytes = g->last_bytes; *ms = g->last_ms; }
+
+extern "C" int hx_edge_merge(hx_group* g, int rank, const hx_params* prm, hx_edges_out* out) {
+    memset(out, 0, sizeof(*out));
+    if (rank < 0 || rank >= g->n) return fail("hx_edge_merge: rank out of range");
+    hx_ctx* c = g->ctx[rank];
+    const uint32_t rb = hx_edge_records_bytes();
+    uint64_t n = 0;
+    int rc = hx_edge_emit(c, prm, &n);
+    g->counts[rank] = rc == 0 ? n : 0;
+    std::string own_err = rc ? g_err : std::string();
+    if (g->rendezvous(rc != 0)) return fail(rc ? own_err : "hx_edge_merge: another rank failed to emit its edge records");
+    uint64_t cap_rec = 1, total = 0;
+    bool equal = true;
+    for (int r = 0; r < g->n; r++) { cap_rec = std::max(cap_rec, g->counts[r]); total += g->counts[r]; equal = equal && g->counts[r] == g->counts[0]; }
+    const uint64_t cap = cap_rec * rb;
+    DV<uint8_t>&sb = *g->sendb[rank], &rv = *g->recvb[rank];
+    rc = 0;
+    if (hipSetDevice(c->device) != hipSuccess || sb.reserve(cap) != hipSuccess || rv.reserve(cap * g->n) != hipSuccess) { rc = -1; own_err = "hx_edge_merge: out of device memory for the exchange buffers"; }
+    if (!rc && hx_edge_records_export(c, sb.p, cap_rec) != 0) { rc = -1; own_err = g_err; }
+    if (g->rendezvous(rc != 0)) return fail(rc ? own_err : "hx_edge_merge: another rank failed before the exchange");
+    const auto t0 = std::chrono::steady_clock::now();
+    if (g->rccl) {
+        // THE collective of the path: every rank contributes its packed records padded to the largest shard (counts travelled through the
+        // process's memory above: the ranks are threads of one process)
+        const ncclResult_t nr = g->p_all_gather(sb.p, rv.p, cap, ncclUint8, g->comm[rank], c->stream);
+        if (nr != ncclSuccess) { rc = -1; own_err = std::string("ncclAllGather: ") + g->p_errstr(nr); }
+        else if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = -1; own_err = "hx_edge_merge: all-gather failed on the stream"; }
+    } else {
+        g->stage[rank].resize(cap);
+        if (hipMemcpy(g->stage[rank].data(), sb.p, cap, hipMemcpyDeviceToHost) != hipSuccess) { rc = -1; own_err = "hx_edge_merge: copy to the host staging buffer failed"; }
+        if (g->rendezvous(rc != 0)) return fail(rc ? own_err : "hx_edge_merge: another rank failed in the exchange");
+        for (int r = 0; r < g->n && !rc; r++)
+            if (hipMemcpy(rv.p + (uint64_t)r * cap, g->stage[r].data(), cap, hipMemcpyHostToDevice) != hipSuccess) { rc = -1; own_err = "hx_edge_merge: copy from the host staging buffer failed"; }
+    }
+    if (g->rendezvous(rc != 0)) return fail(rc ? own_err : "hx_edge_merge: another rank failed in the exchange");
+    if (rank == 0) { g->last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); g->last_bytes = total * rb; }
+    const uint8_t* src = rv.p;
+    if (!equal) {   // cut the padding out: rank order = ascending read ids, which the stable key sort relies on
+        DV<uint8_t>& mg = *g->merged[rank];
+        if (mg.reserve(std::max<uint64_t>(1, total * rb)) != hipSuccess) { rc = -1; own_err = "hx_edge_merge: out of device memory for the merged records"; }
+        uint64_t off = 0;
+        for (int r = 0; r < g->n && !rc; r++) {
+            if (g->counts[r] && hipMemcpyAsync(mg.p + off, rv.p + (uint64_t)r * cap, g->counts[r] * rb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) { rc = -1; own_err = "hx_edge_merge: compaction failed"; }
+            off += g->counts[r] * rb;
+        }
+        if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) { rc = -1; own_err = "hx_edge_merge: compaction failed"; }
+        src = mg.p;
+    }
+    if (!rc && hx_edge_records_import(c, src, total, out) != 0) { rc = -1; own_err = g_err; }
+    if (g->rendezvous(rc != 0)) { if (!rc) hx_free_edges(c, out); return fail(rc ? own_err : "hx_edge_merge: another rank failed to import the merged records"); }
+    return 0;
+}
+
+static int gb_chain(void* p, const hx_params* a, hx_chain_out* o) { GroupRank* q = (GroupRank*)p; return hx_chain_reads(q->g->ctx[q->rank], a, o); }
+static int gb_edges(void* p, const hx_params* a, hx_edges_out* o) { GroupRank* q = (GroupRank*)p; return hx_edge_merge(q->g, q->rank, a, o); }
+static int gb_coords(void* p, uint32_t n, const uint32_t* s, hx_coords_out* o) { GroupRank* q = (GroupRank*)p; return hx_edge_coords(q->g->ctx[q->rank], n, s, o); }
+static int gb_poa(void* p, const hx_poa_params* a, hx_cns_out* o) { GroupRank* q = (GroupRank*)p; return hx_poa_batch(q->g->ctx[q->rank], a, o); }
+static void gb_fc(void* p, hx_chain_out* o) { GroupRank* q = (GroupRank*)p; hx_free_chain(q->g->ctx[q->rank], o); }
+static void gb_fe(void* p, hx_edges_out* o) { GroupRank* q = (GroupRank*)p; hx_free_edges(q->g->ctx[q->rank], o); }
+static void gb_fk(void* p, hx_coords_out* o) { GroupRank* q = (GroupRank*)p; hx_free_coords(q->g->ctx[q->rank], o); }
+static void gb_fn(void* p, hx_cns_out* o) { GroupRank* q = (GroupRank*)p; hx_free_cns(q->g->ctx[q->rank], o); }
+
+extern "C" int hx_group_backend_fill(hx_group* g, int rank, void* table) {
+    if (rank < 0 || rank >= g->n) return fail("hx_group_backend_fill: rank out of range");
+    hx_backend* b = (hx_backend*)table;
+    b->ctx = &g->self[rank]; b->chain_reads = gb_chain; b->edge_support = gb_edges; b->edge_coords = gb_coords; b->poa_batch = gb_poa;
+    b->free_chain = gb_fc; b->free_edges = gb_fe; b->free_coords = gb_fk; b->free_cns = gb_fn; b->last_error = hx_last_error;
+    return 0;
+}

@@ -57,6 +57,9 @@ def lib():
             f = getattr(L, "hxh_run_" + name)
             f.argtypes = [C.c_void_p]
             f.restype = C.POINTER(ty)
+        L.hxh_shard_bounds.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.hxh_runs_all_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
+        L.hxh_run_set_async_writers.argtypes = [C.c_void_p, C.c_int]
         L.hxh_run_assembly_fasta.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.hxh_run_assembly_fasta.restype = C.POINTER(C.c_char)
         _lib = L
@@ -108,6 +111,22 @@ class Dataset:
             self.close()
         except Exception:
             pass
+
+
+def shard_bounds(dataset, n):
+    """n + 1 boundaries of contiguous read-id ranges with about equal numbers of raw PAF records (hxh_shard_bounds)"""
+    b = (C.c_uint32 * (n + 1))()
+    lib().hxh_shard_bounds(dataset._h, n, b)
+    return list(b)
+
+
+def runs_all_sharded(runs, read_begin):
+    """The whole stage over `runs` inside this process, one host thread per rank (hxh_runs_all_sharded: what haslr_assemble --gpus N runs).
+    runs[r] sits on rank r's backend table; runs[0] owns the output directory."""
+    hs = (C.c_void_p * len(runs))(*[r._h for r in runs])
+    rb = (C.c_uint32 * len(runs))(*read_begin[:len(runs)])
+    if lib().hxh_runs_all_sharded(hs, len(runs), rb, None, None) != 0:
+        raise HostError(lib().hxh_last_error().decode())
 
 
 class Run:

@@ -84,6 +84,30 @@ uint32_t hx_edge_records_bytes(void);
 int hx_edge_records_export(hx_ctx*, void* dst_device, uint64_t capacity_records);
 int hx_edge_records_import(hx_ctx*, const void* src_device, uint64_t n_records, hx_edges_out* out);
 
+/* Multi-GPU inside ONE process: the GPUs of a node behind the same binary, like the reference's worker threads behind asm_calc_edge_coordinates_MT
+ * / asm_cal_cns_seq_MT (Assemble.cpp:453-477, :580-605, called from main.cpp:203-208). A group holds one context per rank (one host thread
+ * each) and one RCCL communicator per rank (ncclCommInitAll; librccl is loaded at run time, only by this call).
+ *   hx_group_create        n ranks on `devices` (NULL: ranks 0..n-1 on devices 0..n-1). Transport: RCCL over xGMI when every rank has its own
+ *                          device; HASLR_GROUP_TRANSPORT=host stages the exchange through host memory and lets ranks share devices (a rehearsal
+ *                          of the multi-GPU logic on a box with fewer GPUs than ranks).
+ *   hx_group_ctx           the rank's context: hx_upload (inputs are replicated), hx_set_read_shard, hx_set_prefiltered per rank as usual
+ *   hx_edge_merge          COLLECTIVE - every rank's thread calls it once per pass, after hx_chain_reads on its read shard: emits the shard's
+ *                          edge-support records, all-gathers the packed records (ONE ncclAllGather, padded to the largest shard; counts are
+ *                          exchanged through the process's memory), imports the concatenation (rank order = read order), sorts and segments:
+ *                          `out` like hx_edge_support, identical on every rank (bbg_build_graph's multiset, Backbone_graph.cpp:148-171).
+ *                          The ranks agree on failure before the collective: if one fails, all return an error, none hangs.
+ *   hx_group_backend_fill  the rank's hx_backend table: its own chain / coordinate / consensus operators, hx_edge_merge as edge_support
+ *   hx_group_exchange_stats  bytes of records exchanged by the last hx_edge_merge and its wall time in ms */
+typedef struct hx_group hx_group;
+int hx_group_create(int n_ranks, const int* devices, hx_group** out);
+void hx_group_destroy(hx_group*);
+int hx_group_size(const hx_group*);
+hx_ctx* hx_group_ctx(hx_group*, int rank);
+const char* hx_group_transport(const hx_group*); /* "rccl" or "host" */
+int hx_edge_merge(hx_group*, int rank, const hx_params*, hx_edges_out* out);
+int hx_group_backend_fill(hx_group*, int rank, void* backend_table);
+void hx_group_exchange_stats(const hx_group*, uint64_t* bytes, double* ms);
+
 /* kernel timing measured with hipEvents on the context's stream, accumulated per kernel family since the
  * last reset: 0 chain, 1 edges (emit+sort+segment), 2 coords, 3 poa. ms[] and launches[] have 4 entries. */
 void hx_timing_reset(hx_ctx*);

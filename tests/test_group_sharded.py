@@ -1,0 +1,163 @@
+"""The multi-GPU mode of the drop-in binary (haslr_assemble --gpus N): N ranks INSIDE one process, one host thread per rank
+(libhaslr_host.so hxh_runs_all_sharded over the ranks' backend tables; on the device side include/haslr_hip.h hx_group_* / hx_edge_merge,
+one RCCL all-gather of the edge-support records). Replaces the reference's worker threads behind asm_calc_edge_coordinates_MT /
+asm_cal_cns_seq_MT (Assemble.cpp:453-477, :580-605; main.cpp:203-208).
+  CPU: the host orchestration over oracle backends - every output file equal to a single rank's; an error on one rank ends all ranks.
+  GPU: the binary with --gpus 2 on one device (host-staged exchange), and --gpus 1 through the group path over RCCL (ncclCommInitAll +
+       ncclAllGather really execute), both byte-equal to the plain single-GPU run."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+import orclib
+import util
+from haslr_amd import ctypes_defs as T
+from haslr_amd import host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "haslr_amd", "bin", "haslr_assemble")
+
+
+def _sharded_oracle_pass(ds, n, out, threads=2):
+    b = host.shard_bounds(ds, n)
+    backs, runs = [], []
+    for r in range(n):
+        ob = orclib.OracleBackend(ds, threads)
+        ob.set_read_shard(b[r], b[r + 1])      # the rank chains its own reads only; the oracle's edge_support still returns the merged multiset
+        backs.append(ob)
+        runs.append(host.Run(ds, ds.params(), ob.table, out if r == 0 else None))
+    host.runs_all_sharded(runs, b)
+    return b, backs, runs
+
+
+@pytest.mark.parametrize("n", [2, 3, 5])
+def test_in_process_ranks_write_the_single_rank_outputs(n, sim, tmp_path):
+    pre = sim("--genome-len", "150000", "--seed", "61", "--variant-per-mb", "30", "--cov", "14")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    one = orclib.OracleBackend(ds, 4)
+    lone = host.Run(ds, ds.params(), one.table, str(tmp_path / "one"))
+    lone.all()
+    b, backs, runs = _sharded_oracle_pass(ds, n, str(tmp_path / "many"))
+    assert b[0] == 0 and b[-1] == ds.reads.n and sorted(b) == b
+    assert util.compare_dirs(str(tmp_path / "one"), str(tmp_path / "many")) == []          # GFAs, stats, logs, compact_uniq.txt, asm.final.*
+    assert runs[0].assembly_fasta() == lone.assembly_fasta() and len(lone.assembly_fasta()) > 1000
+    shares = [r.n_edges for r in runs]
+    assert sum(shares) == runs[0].n_edges_total and runs[0].results_missing == 0            # the shares partition the work queue
+    if n <= 3:
+        assert all(0 < s < runs[0].n_edges_total for s in shares), shares
+    for r in runs + [lone]:      # (runs before their backends: a run hands its stage outputs back to the backend that made them)
+        r.close()
+    for ob in backs + [one]:
+        ob.close()
+    ds.close()
+
+
+def test_error_on_one_rank_ends_all_ranks(sim, tmp_path):
+    """a failing stage on one rank: every rank stops after that stage (nobody is left waiting), the error names the rank"""
+    pre = sim("--genome-len", "100000", "--seed", "62", "--variant-per-mb", "30", "--cov", "12")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    b = host.shard_bounds(ds, 3)
+    backs = [orclib.OracleBackend(ds, 1) for _ in range(3)]
+    for r, ob in enumerate(backs):
+        ob.set_read_shard(b[r], b[r + 1])
+    calls = []
+    proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(T.CoordsOut))
+
+    def broken_coords(_ctx, _n, _sel, _out):
+        calls.append(1)
+        return -1
+
+    cb = proto(broken_coords)
+    table = T.Backend()
+    C.memmove(C.byref(table), C.byref(backs[1].table), C.sizeof(T.Backend))
+    table.edge_coords = C.cast(cb, C.c_void_p).value
+    runs = [host.Run(ds, ds.params(), table if r == 1 else backs[r].table, None) for r in range(3)]
+    with pytest.raises(host.HostError, match="rank 1"):
+        host.runs_all_sharded(runs, b)
+    assert calls == [1]
+    for r in runs:
+        r.close()
+    for ob in backs:
+        ob.close()
+
+
+def _cli(args, env=None):
+    return subprocess.run([BIN] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, **(env or {})), timeout=600)
+
+
+@pytest.mark.gpu
+def test_binary_with_two_ranks_on_one_gpu_and_one_rank_over_rccl(sim, built, tmp_path):
+    pre = sim("--genome-len", "400000", "--seed", "63", "--variant-per-mb", "20", "--cov", "20")
+    base = ["-t", "8", "-c", pre + ".contigs.fa", "-l", pre + ".reads.fa", "-m", pre + ".paf"]
+    one = _cli(base + ["-d", str(tmp_path / "one")])
+    assert one.returncode == 0, one.stderr[-2000:]
+    # two ranks, both on device 0, records exchanged through host memory: the sharding / merge / results exchange / stitching logic
+    two = _cli(base + ["-d", str(tmp_path / "two"), "--gpus", "2"], {"HASLR_GROUP_TRANSPORT": "host"})
+    assert two.returncode == 0, two.stderr[-2000:]
+    assert "2 GPU ranks in this process, edge-record exchange over host" in two.stderr and "exchanged" in two.stderr
+    # one rank through the group path over RCCL: ncclCommInitAll and ncclAllGather execute on the hardware
+    rc1 = _cli(base + ["-d", str(tmp_path / "rccl1"), "--gpus", "1"], {"HASLR_FORCE_GROUP": "1"})
+    assert rc1.returncode == 0, rc1.stderr[-2000:]
+    assert "edge-record exchange over rccl" in rc1.stderr
+    skip = {"index.longread"}                                     # (a sharded run does not write the filtered-alignment cache)
+    for other in ("two", "rccl1"):
+        diff = [d for d in util.compare_dirs(str(tmp_path / "one"), str(tmp_path / other)) if not any(s in d for s in skip)]
+        assert diff == [], (other, diff)
+    assert os.path.getsize(tmp_path / "one" / "asm.final.fa") > 100000
+    # more ranks than devices over RCCL is refused, loudly
+    bad = _cli(base + ["-d", str(tmp_path / "bad"), "--gpus", "64"], {"HASLR_GROUP_TRANSPORT": "rccl"})
+    assert bad.returncode != 0 and "[ERROR]" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_edge_merge_through_the_c_abi_equals_edge_support(sim, built):
+    """hx_group_create / hx_edge_merge / hx_group_backend_fill through ctypes: three ranks on one device (host-staged exchange), one Python
+    thread per rank; every rank's merged multiset equals the unsharded hx_edge_support"""
+    import threading
+
+    import numpy as np
+    from haslr_amd import hip
+    pre = sim("--genome-len", "150000", "--seed", "21", "--variant-per-mb", "30")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    prm = ds.params()
+    ctx = hip.HipContext(0)
+    ctx.upload(ds)
+    ctx.chain_reads(prm)
+    whole = ctx.edge_support(prm)
+    ctx.close()
+    L = hip.lib()
+    os.environ["HASLR_GROUP_TRANSPORT"] = "host"
+    try:
+        g = C.c_void_p()
+        assert L.hx_group_create(3, None, C.byref(g)) == 0, L.hx_last_error()
+    finally:
+        del os.environ["HASLR_GROUP_TRANSPORT"]
+    assert L.hx_group_size(g) == 3 and L.hx_group_transport(g) == b"host"
+    b = host.shard_bounds(ds, 3)
+    got, errs = [None] * 3, []
+
+    def rank(r):
+        try:
+            c = L.hx_group_ctx(g, r)
+            assert L.hx_upload(c, C.byref(ds.contigs), C.byref(ds.reads), C.byref(ds.hits), ds.read_hit_off) == 0
+            assert L.hx_set_read_shard(c, b[r], b[r + 1]) == 0
+            ch = T.ChainOut()
+            assert L.hx_chain_reads(c, C.byref(prm), C.byref(ch)) == 0
+            L.hx_free_chain(c, C.byref(ch))
+            e = T.EdgesOut()
+            assert L.hx_edge_merge(g, r, C.byref(prm), C.byref(e)) == 0, L.hx_last_error()
+            got[r] = T.edges_to_dict(e, sides=True)
+            L.hx_free_edges(c, C.byref(e))
+        except Exception as ex:  # noqa: BLE001
+            errs.append((r, ex))
+
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for r in range(3):
+        for k in whole:
+            assert np.array_equal(whole[k], got[r][k]), (r, k)
+    L.hx_group_destroy(g)
