@@ -333,7 +333,7 @@ def main():
                        "poa_block_threads": args.poa_block or "auto", "parallelism": f"reads+edges sharded x{world}, 1 all-gather of edge records + 1 of results" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_poa (launch group: one kernel per lane-count class, concurrent)", "kernel_ms_per_launch": poa_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "gcups": gcups, "dp_cells_per_launch": cells, "valu_bound_gcups": valu_bound, "frac_of_valu_bound": gcups / valu_bound,
+                         "gcups": gcups, "dp_cells_per_launch": cells, "poa_workspace_bytes": ctx.poa_workspace_bytes(), "valu_bound_gcups": valu_bound, "frac_of_valu_bound": gcups / valu_bound,
                          "valu_peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "valu_ops_per_cell_model": VALU_OPS_PER_CELL_MODEL, **sq_fig,
                          "critical_path_ms": critical_ms, "critical_path_share_of_launch": critical_ms / poa_ms if poa_ms > 0 else None,
                          "note": "POA is an O(L^2) integer DP over O(L) bytes: HBM fraction is low by construction (SURVEY.md 8d); GCUPS against the VALU issue bound "

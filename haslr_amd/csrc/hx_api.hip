@@ -151,8 +151,8 @@ struct hx_ctx {
     std::vector<uint8_t> dbg_cls; uint32_t dbg_ring[11] = {};
     bool poa_no_dir = false;   // diagnostics: force the score-matrix traceback
     int poa_block = 0;   // 0 = automatic (lanes per edge chosen from the gap length)
-    hipStream_t poa_streams[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t poa_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t poa_streams[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t poa_ev[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     Timer tm;
     // scratch of the chain / edge / coordinate operators lives as long as the context too (grows, never shrinks): no allocation, free or
     // synchronisation for temporaries in a call once the sizes have been seen
@@ -169,7 +169,9 @@ struct hx_ctx {
     uint64_t poa_budget = 0;
     DV<hxk::PoaEdge> poa_edges;
     DV<hxk::PoaSeq> poa_seqs;
-    DV<uint32_t> poa_order, poa_len, poa_status;
+    DV<uint32_t> poa_order, poa_len, poa_status, poa_counters;
+    DV<hxk::PoaSlot> poa_slots;
+    uint64_t poa_workspace_bytes = 0;   // largest POA workspace (pools) a call of this context has used
     DV<char> poa_cns;
     DV<unsigned long long> poa_phase_d, poa_cells_d;
     std::vector<unsigned long long> poa_phase;   // per edge x 6, cycles of the last hx_poa_batch
@@ -213,12 +215,12 @@ extern "C" int hx_ctx_create(int device, void* stream, hx_ctx** out) {
     {   // distinct priorities map to distinct hardware queues, so the lane-count classes really run side by side
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least priority (largest number), hi = greatest
-        for (int i = 0; i < 6; i++) {
+        for (int i = 0; i < 8; i++) {
             int pr = hi + i; if (pr > lo) pr = lo;
             HIPCHK(hipStreamCreateWithPriority(&c->poa_streams[i], hipStreamNonBlocking, pr));
         }
     }
-    for (int i = 0; i < 7; i++) HIPCHK(hipEventCreateWithFlags(&c->poa_ev[i], hipEventDisableTiming));
+    for (int i = 0; i < 9; i++) HIPCHK(hipEventCreateWithFlags(&c->poa_ev[i], hipEventDisableTiming));
     HIPCHK(c->err.reserve(1));
     *out = c;
     return 0;
@@ -230,8 +232,8 @@ extern "C" void hx_ctx_destroy(hx_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->tm.a) (void)hipEventDestroy(c->tm.a);
     if (c->tm.b) (void)hipEventDestroy(c->tm.b);
-    for (int i = 0; i < 6; i++) if (c->poa_streams[i]) (void)hipStreamDestroy(c->poa_streams[i]);
-    for (int i = 0; i < 7; i++) if (c->poa_ev[i]) (void)hipEventDestroy(c->poa_ev[i]);
+    for (int i = 0; i < 8; i++) if (c->poa_streams[i]) (void)hipStreamDestroy(c->poa_streams[i]);
+    for (int i = 0; i < 9; i++) if (c->poa_ev[i]) (void)hipEventDestroy(c->poa_ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -576,7 +578,10 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         c->poa_budget = (uint64_t)(free_b * 0.9);
     }
-    const uint64_t budget = c->poa_budget;
+    // HX_POA_WORKSPACE_GB: cap of the POA workspace (default: 90 % of what was free when the context first ran a consensus). The workgroups in
+    // flight per launch class are scaled down until the slots fit. Measured at 140 Mb (13 230 edges): 257 GB 2.0-2.1 s, 138 GB 2.10-2.13 s (and
+    // the first call, which allocates the pools, 4.1 instead of 5-7.6 s), 39 GB 4.6 s, 22 GB 8.5 s; a 400 Mb genome (37 608 edges): 148 GB 6.7 s.
+    const uint64_t budget = getenv("HX_POA_WORKSPACE_GB") ? (uint64_t)(atof(getenv("HX_POA_WORKSPACE_GB")) * 1e9) : c->poa_budget;
     PoaPoolBufs& B = c->poa_pools;
     DV<hxk::PoaEdge>& d_edges = c->poa_edges;
     DV<uint32_t>&d_order = c->poa_order, &d_len = c->poa_len, &d_status = c->poa_status;
@@ -707,78 +712,30 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             const uint64_t ca = edge_cost(a), cb = edge_cost(b);
             return ca != cb ? ca > cb : a < b;
         });
-        // ---- batches that fit the memory budget. When one batch cannot hold everything, the edges are DEALT to the batches in cost order
-        // (batch i takes edges i, i + B, i + 2B, ...): every batch then has its share of the large edges, whose serial dependence sets the
-        // batch's duration, and of the many small ones that keep the other CUs busy meanwhile. (Filling batch after batch in cost order
-        // would put the large edges alone into the first batches.)
-        auto edge_bytes = [&](uint32_t e, uint64_t& nn, uint64_t& dc, uint64_t& hc, uint64_t& cle, uint64_t& wc) -> uint64_t {
+        // ---- workspace. An edge that is shared by several workgroups owns a workspace slot for the call; every other launch class is PERSISTENT:
+        // a number of slots, each sized for the class's largest edge, each owned by one workgroup that pulls edges (costliest first) from the class's
+        // list (kernels/poa.hip). The workspace of a call is slots x largest edge, not the sum over its edges: 140 Mb on one GPU took 241 GB per
+        // edge, a 400 Mb genome three batches. When even that does not fit the budget the slot counts are halved (fewer workgroups in flight); when a
+        // class's slots alone do not fit, the edges are dealt to several batches in cost order as before.
+        struct Need { uint64_t nn, ec, hc, dc, wc, lm, st, al; };
+        auto need_of = [&](uint32_t e) -> Need {
             const hxk::PoaEdge& E = P.edges[e];
             const uint64_t rw = ((uint64_t)E.lmax + 1 + 31) & ~31ull;                 // rows padded to 32 columns (the widest lane chunk)
             const uint64_t waves = (uint64_t)E.members * ((E.members > 1 ? cl_lanes : (uint32_t)kClassNT[class_of(e)]) / 64);
             const uint64_t rwh = rw + (waves > 1 ? (waves + 3) & ~3ull : 0);       // rows of H end with one word per wave of the edge's pipeline
-            nn = (uint64_t)E.vcap + 1; dc = full_h[e] ? 0 : nn * (rw / 2); hc = (uint64_t)E.hrows * rwh; wc = full_h[e] ? 0 : (uint64_t)E.wrows * rw;
-            cle = E.members > 1 ? (uint64_t)E.members * nn : 0;
-            return nn * 90 + (uint64_t)E.ecap * 24 + hc * 4 + dc + wc + E.lmax + E.vcap + (4 * nn + E.ecap) * 4 + (nn + E.lmax + 2) * 8 + cle * 8;
+            Need n;
+            n.nn = (uint64_t)E.vcap + 1; n.ec = E.ecap; n.dc = full_h[e] ? 0 : n.nn * (rw / 2); n.hc = (uint64_t)E.hrows * rwh; n.wc = full_h[e] ? 0 : (uint64_t)E.wrows * rw;
+            n.lm = E.lmax; n.st = 4 * n.nn + E.ecap; n.al = n.nn + E.lmax + 2;
+            return n;
         };
-        std::vector<std::vector<uint32_t>> batches;
-        {
-            uint64_t total = 0, biggest = 0, a1, a2, a3, a4, a5;
-            for (uint32_t e : todo) { const uint64_t b = edge_bytes(e, a1, a2, a3, a4, a5); total += b; biggest = std::max(biggest, b); }
-            if (biggest > budget) return fail("hx_poa_batch: a single edge needs more POA workspace than the device has free");
-            const size_t forced = getenv("HX_POA_BATCHES") ? (size_t)atol(getenv("HX_POA_BATCHES")) : 0;   // (testing)
-            for (size_t nb = std::max<size_t>(std::max<size_t>(1, forced), (size_t)((total + budget - 1) / budget));; nb++) {
-                nb = std::min(nb, std::max<size_t>(1, todo.size()));
-                batches.assign(nb, {});
-                std::vector<uint64_t> bb(nb, 0);
-                for (size_t i = 0; i < todo.size(); i++) { batches[i % nb].push_back(todo[i]); bb[i % nb] += edge_bytes(todo[i], a1, a2, a3, a4, a5); }
-                if (*std::max_element(bb.begin(), bb.end()) <= budget || nb >= todo.size()) break;
-            }
-        }
-        std::vector<uint32_t> retry, retry_same;   // retry with the worst-case workspace / with the score-matrix traceback
-        for (const std::vector<uint32_t>& batch : batches) {
-            if (batch.empty()) continue;
-            uint64_t no = 0, eo = 0, ho = 0, dro = 0, wo = 0, so = 0, co = 0, sto = 0, ao = 0, clo = 0, bytes = 0;
-            for (uint32_t e : batch) {
-                hxk::PoaEdge& E = P.edges[e];
-                uint64_t nn, dc, hc, cle, wc;
-                bytes += edge_bytes(e, nn, dc, hc, cle, wc);
-                E.w_off = wo; wo += wc;
-                E.node_off = no; E.edge_off = eo; E.h_off = ho; E.d_off = dro; E.seq_off = so; E.cns_off = co; E.stack_off = sto; E.aln_off = ao; E.cl_off = clo;
-                no += nn; eo += E.ecap; ho += hc; dro += dc; so += E.lmax; co += E.vcap; sto += 4 * nn + E.ecap; ao += nn + E.lmax + 2; clo += cle;
-            }
-            if (bytes > budget) return fail("hx_poa_batch: a single edge needs more POA workspace than the device has free");
-            // Pools grow and never shrink, each to the largest batch it has seen: after batches of different shapes (direction bytes for one,
-            // the whole score matrix for a retry) the capacities together can exceed the device although this batch alone fits the budget.
-            // Then everything is released and reserved again at this batch's sizes.
-            auto reserve_pools = [&]() -> hipError_t {
-                hipError_t e;
-#define HX_RSV(buf, n) do { if ((e = (buf).reserve(n)) != hipSuccess) return e; } while (0)
-                HX_RSV(B.H, std::max<uint64_t>(1, ho)); HX_RSV(B.dir, std::max<uint64_t>(1, dro)); HX_RSV(B.dirw, std::max<uint64_t>(1, wo)); HX_RSV(B.wslot, no);
-                HX_RSV(B.code, no); HX_RSV(B.n_aligned, no); HX_RSV(B.mark, no); HX_RSV(B.check, no); HX_RSV(B.row_code, no); HX_RSV(B.row_sink, no); HX_RSV(B.row_al, no);
-                HX_RSV(B.aligned, 3 * no); HX_RSV(B.in_head, no); HX_RSV(B.in_tail, no); HX_RSV(B.out_head, no); HX_RSV(B.out_tail, no); HX_RSV(B.rank2node, no);
-                HX_RSV(B.node2rank, no); HX_RSV(B.row_pred_off, no); HX_RSV(B.score, no); HX_RSV(B.pred, no); HX_RSV(B.pred_rank, eo); HX_RSV(B.e_from, eo);
-                HX_RSV(B.e_to, eo); HX_RSV(B.e_next_in, eo); HX_RSV(B.e_next_out, eo); HX_RSV(B.e_w, eo); HX_RSV(B.stack, sto); HX_RSV(B.aln_node, ao); HX_RSV(B.aln_pos, ao);
-                HX_RSV(B.row_meta, no); HX_RSV(B.row_pred0, no); HX_RSV(B.row_pred1, no); HX_RSV(B.nrec, no); HX_RSV(B.seq, so); HX_RSV(d_cns, co);
-                HX_RSV(B.mbox, std::max<uint64_t>(1, clo));
-                HX_RSV(B.csync, (size_t)ne * 8); HX_RSV(B.sinkbuf, (size_t)ne * (1 + 2 * 1024));
-#undef HX_RSV
-                return hipSuccess;
-            };
-            if (reserve_pools() != hipSuccess) {
-                (void)hipGetLastError();
-                HIPCHK(hipStreamSynchronize(s));
-                B.release_all(); d_cns.release();
-                HIPCHK(reserve_pools());
-            }
-            HIPCHK(hipMemsetAsync(B.csync.p, 0, (size_t)ne * 8 * 4, s));
-            if (clo) HIPCHK(hipMemsetAsync(B.mbox.p, 0, clo * 8, s));   // tag 0 = nothing published
-            uint64_t n_blocks_total = 0;
-            for (uint32_t e : batch) n_blocks_total += P.edges[e].members;
-            HIPCHK(d_edges.reserve(ne)); HIPCHK(d_len.reserve(ne)); HIPCHK(d_status.reserve(ne));
-            // launch classes: (shared?, lanes per workgroup, columns per lane, traceback flavour) - one kernel instance each, so that every
-            // launch runs with the registers ITS row loop needs (kernels/poa.hip)
-            struct Cls { bool shared; uint32_t nt, cm; bool dir; std::vector<uint32_t> edges; size_t blocks = 0; };
-            std::vector<Cls> classes;
+        auto need_max = [](Need& a, const Need& b) { a.nn = std::max(a.nn, b.nn); a.ec = std::max(a.ec, b.ec); a.hc = std::max(a.hc, b.hc); a.dc = std::max(a.dc, b.dc); a.wc = std::max(a.wc, b.wc);
+                                                       a.lm = std::max(a.lm, b.lm); a.st = std::max(a.st, b.st); a.al = std::max(a.al, b.al); };
+        auto need_bytes = [](const Need& n) -> uint64_t { return n.nn * 90 + n.ec * 24 + n.hc * 4 + n.dc + n.wc + n.lm + n.st * 4 + n.al * 8; };
+        // launch classes: (shared?, lanes per workgroup, columns per lane, traceback flavour) - one kernel instance each, so that every
+        // launch runs with the registers ITS row loop needs (kernels/poa.hip)
+        struct Cls { bool shared; uint32_t nt, cm; bool dir; std::vector<uint32_t> edges; size_t blocks = 0, order_at = 0, slot_at = 0, n_slots = 0; Need need{}; bool persistent = false; };
+        auto build_classes = [&](const std::vector<uint32_t>& batch, std::vector<Cls>& classes) -> int {
+            classes.clear();
             auto cls_of = [&](bool shared, uint32_t nt, uint32_t cm, bool dir) -> Cls& {
                 for (Cls& q : classes) if (q.shared == shared && q.nt == nt && q.cm == cm && q.dir == dir) return q;
                 classes.push_back(Cls{shared, nt, cm, dir, {}});
@@ -808,9 +765,129 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                 if (a.nt != b.nt) return a.nt > b.nt;
                 return a.cm > b.cm;
             });
-            std::vector<uint32_t> order_all;   // one entry per workgroup: edge | member << 24
             for (Cls& q : classes) {
-                const size_t before = order_all.size();
+                q.need = Need{};
+                for (uint32_t e : q.edges) need_max(q.need, need_of(e));
+            }
+            return 0;
+        };
+        // Slots of a persistent class: as many workgroups as the chip holds of that size at 16 waves per CU (all classes share the CUs, but when the
+        // others have finished, what is left of this one still finds the whole chip: measured at 140 Mb, 1.95 s against 2.12 s with slots in
+        // proportion to the classes' shares), at most one per edge. `shrink` scales the number down (memory budget).
+        const uint32_t slot_scale = getenv("HX_POA_SLOTS_PCT") ? (uint32_t)std::max(1, atoi(getenv("HX_POA_SLOTS_PCT"))) : 100;   // (testing: fewer slots = more edges per workgroup)
+        const size_t slot_abs = getenv("HX_POA_SLOTS") ? (size_t)std::max(1, atoi(getenv("HX_POA_SLOTS"))) : 0;
+        auto slots_wanted = [&](const Cls& q, uint32_t shrink) -> size_t {
+            if (q.shared) return q.edges.size();
+            size_t cap = std::max<size_t>(1, ((size_t)4096 / (q.nt / 64)) * slot_scale / 100 * shrink / 1000);   // (`shrink`: per mille of the full count)
+            if (slot_abs) cap = slot_abs;                                        // (testing: HX_POA_SLOTS workgroups per class, many edges each)
+            return std::min(q.edges.size(), cap);
+        };
+        // A class runs persistent when it has more edges than slots: its list stays in DP-cost order (costliest first, taken by whoever is free) and
+        // every slot is sized for the class's largest edge. (Tried: the slots' first edges = the edges with the largest workspace need, slot b sized
+        // for its own first edge and the largest of the rest - 148 GB instead of 257 GB at 140 Mb, but 2.32-2.42 s against 2.03-2.09 s in the same
+        // call: need and cost do not agree well enough - a gap aligned by 60 reads costs 20 times one aligned by 3 at the same need - and the
+        // costliest edges then start late. Memory is saved by halving the slot counts instead: HX_POA_WORKSPACE_GB.)
+        auto arrange = [&](Cls& q, uint32_t shrink) {
+            q.n_slots = slots_wanted(q, shrink);
+            q.persistent = !q.shared && q.n_slots < q.edges.size() && hxk::poa_persistent_ok(q.dir);
+            if (!q.persistent) q.n_slots = q.edges.size();
+        };
+        auto slot_needs = [&](const Cls& q) -> std::vector<Need> {   // per slot: the edge's own need, or (persistent) the largest of the class
+            std::vector<Need> v(q.n_slots);
+            for (size_t b = 0; b < q.n_slots; b++) v[b] = q.persistent ? q.need : need_of(q.edges[b]);
+            return v;
+        };
+        auto total_bytes = [&](std::vector<Cls>& classes, uint32_t shrink) -> uint64_t {
+            uint64_t t = 0;
+            for (Cls& q : classes) {
+                arrange(q, shrink);
+                for (const Need& n : slot_needs(q)) t += need_bytes(n);
+                for (uint32_t e : q.edges) t += P.edges[e].vcap + (q.shared ? (uint64_t)P.edges[e].members * ((uint64_t)P.edges[e].vcap + 1) * 8 : 0);   // consensus output, cluster mailboxes
+            }
+            return t;
+        };
+        std::vector<std::vector<uint32_t>> batches(1, todo);
+        std::vector<uint32_t> batch_shrink(1, 1000);
+        {
+            const size_t forced = getenv("HX_POA_BATCHES") ? (size_t)atol(getenv("HX_POA_BATCHES")) : 0;   // (testing)
+            for (size_t nb = std::max<size_t>(1, forced);; nb++) {
+                nb = std::min(nb, std::max<size_t>(1, todo.size()));
+                batches.assign(nb, {}); batch_shrink.assign(nb, 1000);
+                for (size_t i = 0; i < todo.size(); i++) batches[i % nb].push_back(todo[i]);   // dealt in cost order: every batch has its share of the large edges
+                bool fits = true;
+                for (size_t bi = 0; bi < nb && fits; bi++) {
+                    std::vector<Cls> cl;
+                    if (build_classes(batches[bi], cl)) return -1;
+                    uint32_t sh = 1000;   // per mille of the full slot counts: the largest that fits (down to 1 %: below that, more batches)
+                    if (total_bytes(cl, sh) > budget) {
+                        uint32_t lo = 10, hi = 1000;
+                        while (hi - lo > 10) { const uint32_t mid = (lo + hi) / 2; if (total_bytes(cl, mid) <= budget) lo = mid; else hi = mid; }
+                        sh = lo;
+                    }
+                    batch_shrink[bi] = sh;
+                    fits = total_bytes(cl, sh) <= budget;
+                }
+                if (fits) break;
+                if (nb >= todo.size()) return fail("hx_poa_batch: a single edge needs more POA workspace than the device has free");
+            }
+        }
+        std::vector<uint32_t> retry, retry_same;   // retry with the worst-case workspace / with the score-matrix traceback
+        for (size_t bi = 0; bi < batches.size(); bi++) {
+            const std::vector<uint32_t>& batch = batches[bi];
+            if (batch.empty()) continue;
+            std::vector<Cls> classes;
+            if (build_classes(batch, classes)) return -1;
+            // ---- slots and their offsets into the pools
+            std::vector<hxk::PoaSlot> h_slots;
+            uint64_t no = 0, eo = 0, ho = 0, dro = 0, wo = 0, so = 0, co = 0, sto = 0, ao = 0, clo = 0;
+            auto add_slot = [&](const Need& n) {
+                h_slots.push_back(hxk::PoaSlot{no, eo, ho, dro, wo, so, sto, ao});
+                no += n.nn; eo += n.ec; ho += n.hc; dro += n.dc; wo += n.wc; so += n.lm; sto += n.st; ao += n.al;
+            };
+            for (Cls& q : classes) {
+                arrange(q, batch_shrink[bi]);
+                q.slot_at = h_slots.size();
+                const std::vector<Need> sn = slot_needs(q);
+                for (size_t k = 0; k < q.n_slots; k++) {
+                    if (!q.persistent) P.edges[q.edges[k]].slot = (uint32_t)h_slots.size();   // one workgroup (or cluster) per edge: the edge's own slot
+                    add_slot(sn[k]);
+                }
+                for (uint32_t e : q.edges) {
+                    P.edges[e].cns_off = co; co += P.edges[e].vcap;
+                    if (q.shared) { P.edges[e].cl_off = clo; clo += (uint64_t)P.edges[e].members * ((uint64_t)P.edges[e].vcap + 1); }
+                }
+            }
+            const uint64_t bytes = no * 90 + eo * 24 + ho * 4 + dro + wo + so + sto * 4 + ao * 8 + clo * 8 + co;
+            // Pools grow and never shrink, each to the largest batch it has seen: after batches of different shapes (direction bytes for one,
+            // the whole score matrix for a retry) the capacities together can exceed the device although this batch alone fits the budget.
+            // Then everything is released and reserved again at this batch's sizes.
+            auto reserve_pools = [&]() -> hipError_t {
+                hipError_t e;
+#define HX_RSV(buf, n) do { if ((e = (buf).reserve(n)) != hipSuccess) return e; } while (0)
+                HX_RSV(B.H, std::max<uint64_t>(1, ho)); HX_RSV(B.dir, std::max<uint64_t>(1, dro)); HX_RSV(B.dirw, std::max<uint64_t>(1, wo)); HX_RSV(B.wslot, no);
+                HX_RSV(B.code, no); HX_RSV(B.n_aligned, no); HX_RSV(B.mark, no); HX_RSV(B.check, no); HX_RSV(B.row_code, no); HX_RSV(B.row_sink, no); HX_RSV(B.row_al, no);
+                HX_RSV(B.aligned, 3 * no); HX_RSV(B.in_head, no); HX_RSV(B.in_tail, no); HX_RSV(B.out_head, no); HX_RSV(B.out_tail, no); HX_RSV(B.rank2node, no);
+                HX_RSV(B.node2rank, no); HX_RSV(B.row_pred_off, no); HX_RSV(B.score, no); HX_RSV(B.pred, no); HX_RSV(B.pred_rank, eo); HX_RSV(B.e_from, eo);
+                HX_RSV(B.e_to, eo); HX_RSV(B.e_next_in, eo); HX_RSV(B.e_next_out, eo); HX_RSV(B.e_w, eo); HX_RSV(B.stack, sto); HX_RSV(B.aln_node, ao); HX_RSV(B.aln_pos, ao);
+                HX_RSV(B.row_meta, no); HX_RSV(B.row_pred0, no); HX_RSV(B.row_pred1, no); HX_RSV(B.nrec, no); HX_RSV(B.seq, so); HX_RSV(d_cns, co);
+                HX_RSV(B.mbox, std::max<uint64_t>(1, clo));
+                HX_RSV(B.csync, (size_t)ne * 8); HX_RSV(B.sinkbuf, (size_t)ne * (1 + 2 * 1024));
+#undef HX_RSV
+                return hipSuccess;
+            };
+            if (reserve_pools() != hipSuccess) {
+                (void)hipGetLastError();
+                HIPCHK(hipStreamSynchronize(s));
+                B.release_all(); d_cns.release();
+                HIPCHK(reserve_pools());
+            }
+            c->poa_workspace_bytes = std::max<uint64_t>(c->poa_workspace_bytes, bytes);
+            HIPCHK(hipMemsetAsync(B.csync.p, 0, (size_t)ne * 8 * 4, s));
+            if (clo) HIPCHK(hipMemsetAsync(B.mbox.p, 0, clo * 8, s));   // tag 0 = nothing published
+            HIPCHK(d_edges.reserve(ne)); HIPCHK(d_len.reserve(ne)); HIPCHK(d_status.reserve(ne));
+            std::vector<uint32_t> order_all;   // shared launches: one entry per workgroup (edge | member << 24); persistent launches: the class's edges, costliest first
+            for (Cls& q : classes) {
+                q.order_at = order_all.size();
                 if (q.shared && !getenv("HX_POA_NO_XCD_MAP")) {
                     // Workgroups are handed to the 8 XCDs round-robin by index: put the members of one edge 8 indices apart so that they share an
                     // XCD (one L2 for the carries, the handshakes and the direction bytes member 0 walks back over). Holes are no-op workgroups.
@@ -822,23 +899,32 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                             for (size_t j = g0; j < g0 + 8; j++)
                                 order_all.push_back(j < g1 && m < P.edges[q.edges[j]].members ? (q.edges[j] | (m << 24)) : 0x00ffffffu);
                     }
-                } else
+                } else if (q.shared)
                     for (uint32_t e : q.edges) for (uint32_t m = 0; m < P.edges[e].members; m++) order_all.push_back(e | (m << 24));
-                q.blocks = order_all.size() - before;
+                else
+                    for (uint32_t e : q.edges) order_all.push_back(e);
+                q.blocks = q.shared ? order_all.size() - q.order_at : q.n_slots;   // (not shared: one workgroup per slot - per edge unless persistent)
             }
             if (ne >= (1u << 24)) return fail("hx_poa_batch: more than 2^24 edges in one call");
             HIPCHK(hipMemcpyAsync(d_edges.p, P.edges.data(), (size_t)ne * sizeof(hxk::PoaEdge), hipMemcpyHostToDevice, s));
             HIPCHK(d_order.reserve(order_all.size()));
             HIPCHK(hipMemcpyAsync(d_order.p, order_all.data(), order_all.size() * 4, hipMemcpyHostToDevice, s));
+            HIPCHK(c->poa_slots.reserve(h_slots.size()));
+            HIPCHK(hipMemcpyAsync(c->poa_slots.p, h_slots.data(), h_slots.size() * sizeof(hxk::PoaSlot), hipMemcpyHostToDevice, s));
+            HIPCHK(c->poa_counters.reserve(classes.size()));
+            HIPCHK(hipMemsetAsync(c->poa_counters.p, 0, classes.size() * 4, s));
             hxk::PoaPools pools{B.code.p, B.n_aligned.p, B.aligned.p, B.in_head.p, B.in_tail.p, B.out_head.p, B.out_tail.p, B.rank2node.p, B.node2rank.p,
                                 B.mark.p, B.check.p, B.stack.p, B.score.p, B.pred.p, B.row_code.p, B.row_sink.p, B.row_pred_off.p, B.pred_rank.p, B.row_meta.p, B.row_pred0.p, B.row_pred1.p, B.nrec.p,
                                 B.e_from.p, B.e_to.p, B.e_next_in.p, B.e_next_out.p, B.e_w.p, B.aln_node.p, B.aln_pos.p, B.H.p, B.dir.p, B.dirw.p, B.wslot.p, B.seq.p,
                                 B.mbox.p, B.csync.p, B.sinkbuf.p, B.row_al.p};
+            const size_t n_streams = getenv("HX_POA_STREAMS") ? (size_t)std::min(8, std::max(1, atoi(getenv("HX_POA_STREAMS")))) : 6;
+            size_t wg_total = 0;
+            for (const Cls& q : classes) wg_total += q.blocks;
             c->tick();
-            HIPCHK(hipEventRecord(c->poa_ev[6], s));
-            size_t opos = 0, ci = 0;
+            HIPCHK(hipEventRecord(c->poa_ev[8], s));
+            size_t ci = 0;
             for (const Cls& q : classes) {
-                const int sk = (int)(ci++ % 6);   // stream / event of the launch (launches that share a stream run one after the other)
+                const int sk = (int)(ci % n_streams);   // stream / event of the launch (launches that share a stream run one after the other)
                 // LDS of the launch: the ring its row width allows, a power of two of kept rows
                 uint64_t ring_need = 0;
                 const uint32_t R = ring_rows_of(q.nt, q.cm, ring_need);
@@ -846,7 +932,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                 // (a lone wave runs at twice the speed of two waves sharing a SIMD); many edges: request only what the ring needs
                 uint64_t lds_bytes = ring_need;
                 {
-                    const uint64_t per_cu = (order_all.size() + 255) / 256;
+                    const uint64_t per_cu = (wg_total + 255) / 256;
                     if (per_cu < 8) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(kPoaLdsMax, (158 * 1024) / per_cu - 18 * 1024));
                     // hundreds of edges: the longest ones set the duration, and their waves run faster with two neighbours on a SIMD than with
                     // three - 10 KB of LDS per wave keeps a CU at 12 waves (thousands of edges: 16, the ring alone is 8.3 KB per wave)
@@ -855,19 +941,20 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                 const int dcls = q.shared ? 0 : q.nt >= 1024 ? 1 : q.nt >= 512 ? 2 : q.nt >= 256 ? 3 : q.nt >= 128 ? 4 : 5;
                 for (uint32_t e : q.edges) c->dbg_cls[e] = (uint8_t)(dcls + (q.dir ? 0 : 5));
                 c->dbg_ring[dcls + (q.dir ? 0 : 5)] = R;
-                HIPCHK(hipStreamWaitEvent(c->poa_streams[sk], c->poa_ev[6], 0));
-                hxk::poa_run(d_edges.p, d_order.p + opos, (uint32_t)q.blocks, d_seqs.p, in.d_packed, in.d_roff, in.d_rlen, pools, pp->match, pp->mismatch,
+                HIPCHK(hipStreamWaitEvent(c->poa_streams[sk], c->poa_ev[8], 0));
+                hxk::poa_run(d_edges.p, d_order.p + q.order_at, q.persistent ? (uint32_t)q.edges.size() : (uint32_t)q.blocks, c->poa_slots.p + (q.persistent ? q.slot_at : 0), q.persistent ? c->poa_counters.p + ci : nullptr,
+                             (uint32_t)q.blocks, d_seqs.p, in.d_packed, in.d_roff, in.d_rlen, pools, pp->match, pp->mismatch,
                              pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)q.nt, (int)q.cm, poll_limit, (uint32_t)lds_bytes, q.dir, max_indeg, c->poa_streams[sk]);
                 HIPCHK(hipEventRecord(c->poa_ev[sk], c->poa_streams[sk]));
                 HIPCHK(hipStreamWaitEvent(s, c->poa_ev[sk], 0));
-                opos += q.blocks;
+                ci++;
             }
             c->tock(3);
             HIPCHK(hipGetLastError());
             if (getenv("HX_DEBUG")) {
                 HIPCHK(hipStreamSynchronize(s));
                 fprintf(stderr, "[hx] POA batch: %zu edges, %.2f GB workspace, workgroups", batch.size(), bytes / 1e9);
-                for (const Cls& q : classes) fprintf(stderr, " %s%s%ux%u:%zu", q.shared ? "shared/" : "", q.dir ? "" : "matrix/", q.nt, q.cm, q.blocks);
+                for (const Cls& q : classes) fprintf(stderr, " %s%s%s%ux%u:%zu(%zu edges, largest %.1f MB)", q.shared ? "shared/" : "", q.persistent ? "persistent/" : "", q.dir ? "" : "matrix/", q.nt, q.cm, q.blocks, q.edges.size(), need_bytes(q.need) / 1e6);
                 fprintf(stderr, ", %.1f ms since the call began\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count());
             }
             std::vector<uint32_t> h_len(ne), h_status(ne);
@@ -1022,6 +1109,7 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
     }
     return (uint32_t)ne;
 }
+extern "C" uint64_t hx_poa_workspace_bytes(const hx_ctx* c) { return c->poa_workspace_bytes; }
 extern "C" void hx_set_poa_traceback(hx_ctx* c, int use_direction_bytes) { c->poa_no_dir = !use_direction_bytes; }
 extern "C" void hx_set_poa_block(hx_ctx* c, int t) { c->poa_block = t <= 0 ? 0 : t >= 1024 ? 1024 : t >= 512 ? 512 : t >= 256 ? 256 : t >= 128 ? 128 : 64; }
 

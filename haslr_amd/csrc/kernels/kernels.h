@@ -86,19 +86,25 @@ void coords_compact(const uint64_t* cap_off, const uint64_t* out_off, uint32_t n
 struct PoaSeq { uint32_t rid; uint32_t strand; uint32_t spos; uint32_t len; };
 struct PoaEdge {
     uint32_t seq_begin, seq_end;   // into the PoaSeq table
-    uint32_t vcap, ecap, lmax, hrows;
+    uint32_t vcap, ecap, lmax, hrows;   // capacities the kernel checks this edge against (all within its workspace slot)
+    uint64_t cns_off;              // into the consensus output (bytes, capacity vcap): per edge, it outlives the workspace
+    uint64_t cl_off;               // into the cluster pools (members * (vcap+1) entries per edge), members > 1 only
+    uint32_t members;              // workgroups ("members", one CU each) that share this edge's DP columns; 1 = the usual single workgroup
+    uint32_t wrows;                // rows of the wide-row pool (an estimate, overflow -> retry)
+    uint32_t slot;                 // workspace slot of a shared edge (members > 1); other edges run in the slot of the workgroup that pulls them
+    uint32_t pad_;
+};
+// A workspace slot: offsets into the pools. A persistent workgroup owns one for its lifetime (sized for the largest edge of its launch), a shared
+// edge owns one for the call.
+struct PoaSlot {
     uint64_t node_off, edge_off;   // into the node / edge pools (elements)
     uint64_t h_off;                // into the H pool (int32 cells): hrows rows of W + one word per wave of the edge's pipeline. Direction-byte traceback: only the rows a far successor reads
                                    // (hrows = an estimate, overflow -> retry); score-matrix traceback: all vcap + 1 rows
     uint64_t d_off;                // into the direction pool (bytes): vcap + 1 rows of W / 2 (a 4-bit move code per cell)
     uint64_t w_off;                // into the wide-row pool (bytes): wrows rows of W (a move byte per cell of the rows with more than 4 predecessors)
     uint64_t seq_off;              // into the decoded-sequence pool (bytes, lmax per edge)
-    uint64_t cns_off;              // into the consensus output (bytes, capacity vcap)
     uint64_t stack_off;            // into the toposort stack pool (4*(vcap+1) + ecap entries per edge)
     uint64_t aln_off;              // into the alignment pools (vcap + lmax + 2 entries per edge)
-    uint64_t cl_off;               // into the cluster pools (members * (vcap+1) entries per edge), members > 1 only
-    uint32_t members;              // workgroups ("members", one CU each) that share this edge's DP columns; 1 = the usual single workgroup
-    uint32_t wrows;                // rows of the wide-row pool (an estimate, overflow -> retry)
 };
 struct PoaPools {
     // per node (pool length = sum (vcap+1))
@@ -129,7 +135,10 @@ struct PoaPools {
 // kernel instance (largest workgroup it is compiled for) that serves workgroups of `block_threads` lanes, and the columns per lane it can be had with
 inline int poa_kernel_lanes(int block_threads) { return block_threads <= 64 ? 64 : block_threads <= 256 ? 256 : block_threads <= 512 ? 512 : 1024; }
 inline int poa_kernel_max_cm(int block_threads) { return block_threads <= 256 ? 32 : block_threads <= 512 ? 16 : 32; }
-void poa_run(const PoaEdge* edges, const uint32_t* order /* edge | member << 24, one entry per workgroup */, uint32_t n_blocks, const PoaSeq* seqs, const uint8_t* packed,
+inline bool poa_persistent_ok(bool use_dir) { return use_dir; }   // launches that can run persistent (the score-matrix flavour is rare: one workgroup per edge)
+// One launch of a class. counter == nullptr: one workgroup per entry of `order` (edge | member << 24; shared edges, each in its own slot
+// PoaEdge::slot); else PERSISTENT: n_blocks workgroups, workgroup b owns slots[b] and pulls the n_items edges of `order` through *counter.
+void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_items, const PoaSlot* slots, uint32_t* counter, uint32_t n_blocks, const PoaSeq* seqs, const uint8_t* packed,
              const uint64_t* read_off, const uint32_t* read_len, PoaPools pools,
              int32_t match, int32_t mismatch, int32_t gap, char* cns, uint32_t* cns_len, uint32_t* status,
              unsigned long long* cells, unsigned long long* phase_cycles /* 12 per edge or null */, int block_threads /* multiple of 64, <= 1024 */,

@@ -873,13 +873,11 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
 // many short gaps (one wavefront, 4-8 columns per lane) run with a fraction of the registers - and several times the waves per SIMD - of
 // the few long ones; sequences shorter than the edge's longest leave the upper lanes / waves of the pipeline idle.
 template <int MAXNT, int CM, bool DIR>
-__global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const PoaEdge* __restrict__ edges, const uint32_t* __restrict__ order, uint32_t n_edges,
-                                            const PoaSeq* __restrict__ seqs, const uint8_t* __restrict__ packed, const uint64_t* __restrict__ read_off,
-                                            const uint32_t* __restrict__ read_len, PoaPools P, int32_t match, int32_t mismatch, int32_t gap,
-                                            char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells, unsigned long long* phase,
-                                            uint32_t poll_limit, uint32_t lds_bytes, uint32_t max_indeg) {
-    const uint32_t eidx = order[blockIdx.x] & 0x00ffffffu, mem = order[blockIdx.x] >> 24;   // edge, member of its cluster (0 unless the edge is shared)
-    if (eidx == 0x00ffffffu) return;                  // hole in the XCD-aligned cluster grid
+__device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem, const PoaSlot SL, const PoaEdge* __restrict__ edges,
+                                         const PoaSeq* __restrict__ seqs, const uint8_t* __restrict__ packed, const uint64_t* __restrict__ read_off,
+                                         const uint32_t* __restrict__ read_len, const PoaPools& P, int32_t match, int32_t mismatch, int32_t gap,
+                                         char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells, unsigned long long* phase,
+                                         uint32_t poll_limit, uint32_t lds_bytes, uint32_t max_indeg) {
     __shared__ unsigned long long ph[12];            // lane-0 cycle counts: decode, dp, traceback, graph update, toposort, csr; then row statistics
     __shared__ long long tc;
     if (threadIdx.x == 0) { for (int k = 0; k < 12; k++) ph[k] = 0; tc = clock64(); }
@@ -897,20 +895,20 @@ __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const P
     extern __shared__ int32_t ring[];
     G g;
     {
-        const uint64_t no = ED.node_off, eo = ED.edge_off;
+        const uint64_t no = SL.node_off, eo = SL.edge_off;
         g.code = P.code + no; g.n_aligned = P.n_aligned + no; g.aligned = P.aligned + 3 * no;
         g.in_head = P.in_head + no; g.in_tail = P.in_tail + no; g.out_head = P.out_head + no; g.out_tail = P.out_tail + no;
         g.rank2node = P.rank2node + no; g.node2rank = P.node2rank + no; g.mark = P.mark + no; g.check = P.check + no;
-        g.stack = P.stack + ED.stack_off; g.score = P.score + no; g.pred = P.pred + no;
+        g.stack = P.stack + SL.stack_off; g.score = P.score + no; g.pred = P.pred + no;
         g.row_code = P.row_code + no; g.row_sink = P.row_sink + no; g.row_pred_off = P.row_pred_off + no; g.pred_rank = P.pred_rank + eo;
         g.row_meta = P.row_meta + no; g.row_pred0 = P.row_pred0 + no; g.row_pred1 = P.row_pred1 + no; g.nrec = P.nrec + no; g.row_al = P.row_al + no; g.wslot = P.wslot + no;
         g.e_from = P.e_from + eo; g.e_to = P.e_to + eo; g.e_next_in = P.e_next_in + eo; g.e_next_out = P.e_next_out + eo; g.e_w = P.e_w + eo;
-        g.aln_node = P.aln_node + ED.aln_off; g.aln_pos = P.aln_pos + ED.aln_off;
+        g.aln_node = P.aln_node + SL.aln_off; g.aln_pos = P.aln_pos + SL.aln_off;
         g.vcap = ED.vcap; g.ecap = ED.ecap;
     }
-    int32_t* H = P.H + ED.h_off;
-    uint8_t* Dm = DIR ? P.dir + ED.d_off : nullptr;   // direction nibbles: (vcap + 1) rows of W / 2 bytes; with them H holds only ED.hrows far-read rows
-    uint8_t* Dw = DIR ? P.dirw + ED.w_off : nullptr;  // direction bytes of the rows with more than 4 predecessors: ED.wrows rows of W
+    int32_t* H = P.H + SL.h_off;
+    uint8_t* Dm = DIR ? P.dir + SL.d_off : nullptr;   // direction nibbles: (vcap + 1) rows of W / 2 bytes; with them H holds only ED.hrows far-read rows
+    uint8_t* Dw = DIR ? P.dirw + SL.w_off : nullptr;  // direction bytes of the rows with more than 4 predecessors: ED.wrows rows of W
     // ring geometry is a property of the edge (its longest sequence) and of the launch
     const uint32_t GM = ED.members;                  // workgroups sharing this edge's DP columns
     const uint32_t ring_w = CM * (NT >> 6) * 65u;    // CM planes of 65 words per wave (dp_rows)
@@ -923,7 +921,7 @@ __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const P
         R = fit >= 8 ? 8 : fit >= 4 ? 4 : fit >= 2 ? 2 : 0;   // (0: rows too wide for two of them - every kept row is read back from HBM)
         if (fit < 1) R = 0xffffffffu;
     }
-    uint8_t* seq = P.seq + ED.seq_off;
+    uint8_t* seq = P.seq + SL.seq_off;
     const uint32_t W = (ED.lmax + 1 + 31) & ~31u;   // row stride: a multiple of the widest lane chunk (32 columns), so chunks are vector-aligned and stay inside their row
     const uint32_t WH = W + (GM * (NT >> 6) > 1 ? (GM * (NT >> 6) + 3u) & ~3u : 0u);   // rows of H end with one word per wave of the edge's pipeline (dp_rows)
 
@@ -1548,18 +1546,61 @@ __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const P
     }
 }
 
+// The launch. An edge that is shared by several workgroups gets one workgroup per member and a workspace slot of its own (`order` entry =
+// edge | member << 24, the slot is the edge's PoaEdge::slot). Everything else runs PERSISTENT: the grid is a number of workspace slots, each
+// workgroup owns slot blockIdx.x - sized for the largest edge of the launch - and works through the launch's list (costliest first): entry
+// blockIdx.x first, then whatever comes next off an atomic counter. The workspace of a call is (workgroups in flight) x (largest edge of
+// the class), not the sum over all its edges.
+// (two instances per shape: the plain one keeps the register allocation of a kernel that runs one edge - the loop of the persistent one costs
+// 8-12 VGPRs, which takes the 4-column kernels from 4 to 3 waves per SIMD - and is what the few-edge regime launches)
+template <int MAXNT, int CM, bool DIR, bool PERSIST>
+__global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const PoaEdge* __restrict__ edges, const uint32_t* __restrict__ order, uint32_t n_items,
+                                            const PoaSlot* __restrict__ slots, uint32_t* __restrict__ counter /* null: one workgroup per entry of `order` */,
+                                            const PoaSeq* __restrict__ seqs, const uint8_t* __restrict__ packed, const uint64_t* __restrict__ read_off,
+                                            const uint32_t* __restrict__ read_len, PoaPools P, int32_t match, int32_t mismatch, int32_t gap,
+                                            char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells, unsigned long long* phase,
+                                            uint32_t poll_limit, uint32_t lds_bytes, uint32_t max_indeg) {
+    __shared__ uint32_t sNext;
+    for (uint32_t round = 0;; round++) {   // (one call site of the edge body for both kinds of launch)
+        uint32_t eidx, mem = 0;
+        PoaSlot SL;
+        if (!PERSIST) {
+            eidx = order[blockIdx.x] & 0x00ffffffu; mem = order[blockIdx.x] >> 24;   // edge, member of its cluster
+            if (eidx == 0x00ffffffu) return;              // hole in the XCD-aligned cluster grid
+            SL = slots[edges[eidx].slot];
+        } else {
+            // the list is in DP-cost order, costliest first: the first edge of workgroup b is entry b, the others come through the counter - whoever
+            // is free takes the next one; every slot is sized for the largest edge of the list
+            uint32_t idx = blockIdx.x;
+            if (round) {
+                __syncthreads();                          // (the previous edge has left the LDS)
+                if (threadIdx.x == 0) sNext = gridDim.x + atomicAdd(counter, 1u);
+                __syncthreads();
+                idx = sNext;
+            }
+            if (idx >= n_items) return;
+            eidx = order[idx] & 0x00ffffffu;
+            SL = slots[blockIdx.x];
+        }
+        poa_edge<MAXNT, CM, DIR>(eidx, mem, SL, edges, seqs, packed, read_off, read_len, P, match, mismatch, gap, cns, cns_len, status, cells, phase, poll_limit, lds_bytes, max_indeg);
+        if (!PERSIST) return;
+    }
+}
+
 }  // namespace
 
-void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_edges, const PoaSeq* seqs, const uint8_t* packed, const uint64_t* read_off,
-             const uint32_t* read_len, PoaPools pools, int32_t match, int32_t mismatch, int32_t gap, char* cns, uint32_t* cns_len,
+void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_items, const PoaSlot* slots, uint32_t* counter, uint32_t n_blocks, const PoaSeq* seqs, const uint8_t* packed,
+             const uint64_t* read_off, const uint32_t* read_len, PoaPools pools, int32_t match, int32_t mismatch, int32_t gap, char* cns, uint32_t* cns_len,
              uint32_t* status, unsigned long long* cells, unsigned long long* phase, int block_threads, int cm, uint32_t poll_limit, uint32_t ring_bytes,
              bool use_dir, uint32_t max_indeg, hipStream_t s) {
-    if (!n_edges) return;
-#define HX_LAUNCH(MNT, CMV, DIRV) do { \
-        (void)hipFuncSetAttribute((const void*)k_poa<MNT, CMV, DIRV>, hipFuncAttributeMaxDynamicSharedMemorySize, 142 * 1024); \
-        k_poa<MNT, CMV, DIRV><<<n_edges, block_threads, ring_bytes, s>>>(edges, order, n_edges, seqs, packed, read_off, read_len, pools, match, mismatch, gap, \
+    if (!n_blocks || !n_items) return;
+    if (counter && !use_dir) return;   // (the host never asks for it: poa_persistent_ok)
+#define HX_LAUNCH(MNT, CMV, DIRV, PERS) do { \
+        (void)hipFuncSetAttribute((const void*)k_poa<MNT, CMV, DIRV, PERS>, hipFuncAttributeMaxDynamicSharedMemorySize, 142 * 1024); \
+        k_poa<MNT, CMV, DIRV, PERS><<<n_blocks, block_threads, ring_bytes, s>>>(edges, order, n_items, slots, counter, seqs, packed, read_off, read_len, pools, match, mismatch, gap, \
                                                                        cns, cns_len, status, cells, phase, poll_limit, ring_bytes, max_indeg); } while (0)
-#define HX_LAUNCH_CM(MNT, CMV) do { if (use_dir) HX_LAUNCH(MNT, CMV, true); else HX_LAUNCH(MNT, CMV, false); } while (0)
+    // (persistent instances exist for the direction-byte flavour only: poa_persistent_ok)
+#define HX_LAUNCH_CM(MNT, CMV) do { if (use_dir && counter) HX_LAUNCH(MNT, CMV, true, true); else if (use_dir) HX_LAUNCH(MNT, CMV, true, false); else HX_LAUNCH(MNT, CMV, false, false); } while (0)
     // the instances the host's launch classes use (poa_kernel_lanes): workgroups up to 64 / 256 / 512 / 1024 lanes x 4, 8, 16 or 32 columns per lane
     const int mnt = poa_kernel_lanes(block_threads);
     if (mnt == 64) { if (cm <= 4) HX_LAUNCH_CM(64, 4); else if (cm <= 8) HX_LAUNCH_CM(64, 8); else if (cm <= 16) HX_LAUNCH_CM(64, 16); else HX_LAUNCH_CM(64, 32); }

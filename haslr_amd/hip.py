@@ -15,7 +15,7 @@ _lib = None
 SYMBOLS = ["hx_last_error", "hx_device_count", "hx_ctx_create", "hx_ctx_destroy", "hx_upload", "hx_set_read_shard", "hx_set_prefiltered",
            "hx_chain_reads", "hx_edge_support", "hx_edge_coords", "hx_poa_batch", "hx_free_chain", "hx_free_edges",
            "hx_free_coords", "hx_free_cns", "hx_edge_emit", "hx_edge_records_bytes", "hx_edge_records_export",
-           "hx_edge_records_import", "hx_poa_supports", "hx_poa_sequences", "hx_timing_reset", "hx_timing_get", "hx_set_poa_block", "hx_backend_fill", "hx_poa_phase_cycles", "hx_set_poa_traceback",
+           "hx_edge_records_import", "hx_poa_supports", "hx_poa_sequences", "hx_timing_reset", "hx_timing_get", "hx_set_poa_block", "hx_backend_fill", "hx_poa_phase_cycles", "hx_set_poa_traceback", "hx_poa_workspace_bytes",
            "hx_group_create", "hx_group_destroy", "hx_group_size", "hx_group_ctx", "hx_group_transport", "hx_edge_merge", "hx_group_backend_fill", "hx_group_exchange_stats"]
 
 
@@ -57,6 +57,8 @@ def lib():
         L.hx_poa_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 6), C.POINTER(C.c_uint64 * 6)]
         L.hx_poa_phase_cycles.restype = C.c_uint32
         L.hx_backend_fill.argtypes = [C.c_void_p, C.POINTER(T.Backend)]
+        L.hx_poa_workspace_bytes.argtypes = [C.c_void_p]
+        L.hx_poa_workspace_bytes.restype = C.c_uint64
         # multi-GPU inside one process (one thread per rank): hx_group_*
         L.hx_group_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
         L.hx_group_destroy.argtypes = [C.c_void_p]
@@ -191,6 +193,9 @@ class HipContext:
         n = lib().hx_poa_phase_cycles(self._h, C.byref(a), C.byref(b))
         names = ("decode", "dp", "traceback", "graph_update", "toposort", "csr")
         return {"edges": n, "sum": dict(zip(names, a)), "slowest_edge": dict(zip(names, b))}
+
+    def poa_workspace_bytes(self):
+        return int(lib().hx_poa_workspace_bytes(self._h))
 
     def timing_reset(self):
         lib().hx_timing_reset(self._h)

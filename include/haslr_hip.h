@@ -115,6 +115,9 @@ void hx_timing_get(hx_ctx*, double* ms, uint64_t* launches);
 /* diagnostics of the last hx_poa_batch: shader-clock cycles spent by lane 0 per phase [decode, dp, traceback,
  * graph update + consensus, toposort, csr], summed over edges (sum6) and for the slowest edge (max6); returns #edges */
 uint32_t hx_poa_phase_cycles(hx_ctx*, uint64_t* sum6, uint64_t* max6);
+/* bytes of POA workspace (all pools) the largest hx_poa_batch of this context has needed: (resident work-groups) x (largest edge of a launch
+ * class) + the shared edges' own slots - not the sum over the edges of the call */
+uint64_t hx_poa_workspace_bytes(const hx_ctx*);
 /* POA work-group size: 0 = automatic (64..256 lanes per edge, ~8 DP columns per lane; gaps > 2047 columns are shared by several
  * work-groups), or force one work-group of 64/128/256/512/1024 lanes per edge (gaps up to 32767 bases) */
 void hx_set_poa_block(hx_ctx*, int threads);

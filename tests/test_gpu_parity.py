@@ -353,7 +353,10 @@ def test_in_degree_retry_with_score_matrix(sim, ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("far_rows,shape", [("0", {}), ("1", {}), ("0", {"HX_POA_CLUSTER_MIN": "300", "HX_POA_MEMBER_LANES": "128", "HX_POA_CLUSTER_MAX": "3"}),
                                             ("2", {"HX_POA_WAVE_MAX": "4096"}), ("1", {"HX_POA_BATCHES": "3"}),
-                                            ("-1", {"HX_POA_NODE_EST_PCT": "3"}), ("1", {"HX_POA_NODE_EST_PCT": "20", "HX_POA_BATCHES": "2"})])
+                                            ("-1", {"HX_POA_NODE_EST_PCT": "3"}), ("1", {"HX_POA_NODE_EST_PCT": "20", "HX_POA_BATCHES": "2"}),
+                                            # persistent workgroups (what thousands of edges get): 1-3 workspace slots per launch class, every workgroup works through many edges
+                                            ("-1", {"HX_POA_SLOTS": "1"}), ("1", {"HX_POA_SLOTS": "2"}), ("0", {"HX_POA_SLOTS": "3", "HX_POA_NODE_EST_PCT": "20"}),
+                                            ("-1", {"HX_POA_SLOTS": "2", "HX_POA_CLUSTER_MIN": "100000", "HX_POA_COLS": "8"})])
 def test_far_row_estimate_overflow_is_retried(sim, ctx, far_rows, shape):
     """with direction bytes H keeps only the rows that a successor reads after they left the LDS ring, in as many rows as the host
     estimated; an edge that needs more comes back and is redone with room for every row. Forced here by an estimate of 0..2 rows
@@ -381,6 +384,35 @@ def test_far_row_estimate_overflow_is_retried(sim, ctx, far_rows, shape):
     assert ro.cns_out() == rg.cns_out()
     assert ro.cns_stats()["dp_cells"] == rg.cns_stats()["dp_cells"]
     assert rg.n_edges > 0
+    rg.close(); ro.close(); be.close(); ds.close()
+
+
+@pytest.mark.gpu
+def test_persistent_workgroups_on_many_edges(sim, ctx):
+    """hundreds of edges through 4 persistent workgroups per launch class (the mode of the 140 Mb / 400 Mb runs, forced at test size): slots sized for
+    their first edge and the largest of the rest, edges pulled through the class's counter - every consensus the oracle's"""
+    pre = sim("--genome-len", "1200000", "--seed", "58", "--variant-per-mb", "10", "--cov", "22")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    prm = ds.params()
+    be = orclib.OracleBackend(ds, os.cpu_count() or 8)
+    ro = host.Run(ds, prm, be.table, None)
+    ro.all()
+    ctx.upload(ds)
+    old = os.environ.get("HX_POA_SLOTS")
+    try:
+        os.environ["HX_POA_SLOTS"] = "4"
+        rg = host.Run(ds, prm, ctx.backend(), None)
+        rg.all()
+        ws_few = ctx.poa_workspace_bytes()
+    finally:
+        if old is None:
+            os.environ.pop("HX_POA_SLOTS", None)
+        else:
+            os.environ["HX_POA_SLOTS"] = old
+    assert rg.n_edges > 60
+    assert ro.cns_out() == rg.cns_out() and ro.assembly_fasta() == rg.assembly_fasta()
+    assert ro.cns_stats()["dp_cells"] == rg.cns_stats()["dp_cells"]
+    assert ws_few > 0
     rg.close(); ro.close(); be.close(); ds.close()
 
 

@@ -57,6 +57,8 @@ def main():
     res["input_bytes"] = {k: os.path.getsize(pre + "." + k) for k in ("contigs.fa", "reads.fa", "paf")}
 
     from haslr_amd import hip, host
+    if os.environ.get("HASLR_DEV_LIBDIR"):                       # (development: A/B against another build of libhaslr_hip.so)
+        hip._LIBDIR = os.environ["HASLR_DEV_LIBDIR"]
     t0 = time.perf_counter()
     ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf", threads=min(32, os.cpu_count() or 1))
     lap("ingest_s", t0)
