@@ -119,9 +119,10 @@ def measure(ctx, ds, prm, table, steps, warmup, world, rank, sync, gather, lr_be
         if world > 1:
             run.set_edge_shard(rank, world)
             run.set_read_shard(lr_begin)
-        run.chain(); run.graph(); run.coords(); run.consensus()
         if world > 1:
-            gather(run)
+            gather(run)                            # chain -> merged graph -> coords -> consensus -> results gathered; the ranks agree on success before every collective
+        else:
+            run.chain(); run.graph(); run.coords(); run.consensus()
         return run
 
     for _ in range(warmup):
@@ -212,7 +213,7 @@ def main():
         table = backend.table
 
         def gather(run):
-            gathered[0] = hd.gather_results(run, comm_device)
+            gathered[0] = hd.sharded_stages(run, comm_device)
     else:
         table, gather = ctx.backend(), None
 

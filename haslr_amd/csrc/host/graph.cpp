@@ -10,6 +10,8 @@
 //   clean_simple_bubbles_old Cleaning.cpp:98-184          detect_super_bubble/clean_super_bubbles :488-648
 //   clean_small_bubbles Cleaning.cpp:7-57
 #include <cstring>
+#include <cstdlib>
+#include <thread>
 #include <algorithm>
 #include <cstdio>
 #include <map>
@@ -164,6 +166,58 @@ void graph_report_branching(const Graph& g, const std::string& path) {
 
 namespace {
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Parallel formulation of the four cleaning passes (Cleaning.cpp:7-184, :488-648). Each pass of the reference walks the
+// nodes in ascending order and, at almost every node, does nothing: a cheap test of the node's own adjacency sends it on. Edits only ever
+// REMOVE edges. So a pass is split into
+//   (1) the test for every node on the graph as the pass finds it - read-only, independent per node: all host threads, a bit per node;
+//   (2) the reference's loop over the nodes whose bit is set, in ascending order, deciding on the CURRENT graph exactly like the reference;
+//       every removal sets the bits of the two nodes it touches, so a node whose test only became true through an earlier removal of this
+//       pass (a degree that fell to the tested value) is visited as well, at its place in the order.
+// A node the reference would have acted on is never skipped - its test was true at the start or became true by a removal next to it - and a
+// node visited without need takes the reference's own early exit: the edits, their order and the logs are the serial algorithm's, whatever
+// the thread count. (The small-bubble test - "has a triangle" - can only turn false by removals, so its set needs no additions.)
+// ---------------------------------------------------------------------------------------------------------------------------
+unsigned clean_threads(uint32_t n_nodes) {
+    if (const char* e = getenv("HASLR_CLEAN_THREADS")) return (unsigned)std::max(1, atoi(e));
+    if (n_nodes < 200000) return 1;                   // (below that the scan is microseconds: threads would cost more than they save)
+    return std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+}
+
+template <class Pred>
+std::vector<uint64_t> candidate_bits(const Graph& g, Pred pred) {
+    const uint32_t n = g.n_nodes, words = (n + 63) / 64;
+    std::vector<uint64_t> bits(words + 1, 0);
+    const unsigned T = clean_threads(n);
+    auto work = [&](uint32_t w0, uint32_t w1) {
+        for (uint32_t w = w0; w < w1; w++) {
+            uint64_t b = 0;
+            for (uint32_t k = 0; k < 64 && w * 64 + k < n; k++) if (pred(w * 64 + k)) b |= 1ull << k;
+            bits[w] = b;
+        }
+    };
+    if (T <= 1) { work(0, words); return bits; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; t++) th.emplace_back(work, (uint32_t)((uint64_t)words * t / T), (uint32_t)((uint64_t)words * (t + 1) / T));
+    for (auto& x : th) x.join();
+    return bits;
+}
+
+// the loop of a pass over the set bits, ascending; `body(i)` returns true when the reference would look at node i again (its `i--; continue`)
+template <class Body>
+void for_candidates(Graph& g, std::vector<uint64_t>& bits, Body body) {
+    g.touched = &bits;
+    for (uint32_t w = 0; w + 1 < bits.size(); w++)
+        while (bits[w]) {                             // (a removal may set bits of this very word: lower ones are behind us and are cleared unseen)
+            const uint32_t k = (uint32_t)__builtin_ctzll(bits[w]);
+            const uint32_t i = w * 64 + k;
+            bits[w] &= ~((2ull << k) - 1);            // this bit and everything below it
+            while (body(i)) {}
+            bits[w] &= ~((2ull << k) - 1);            // (the node's own removals set its bit again: it has just been looked at)
+        }
+    g.touched = nullptr;
+}
+
 struct PathElem { uint32_t strand, id; };
 
 // bbg_find_simple_path_from_source: follow the arc at index `k` of vertex (src,side) while nodes are 1-in 1-out.
@@ -197,20 +251,22 @@ void remove_path(Graph& g, const std::vector<PathElem>& p) {
 int clean_tips(Graph& g, int max_depth, const std::string& logpath) {
     FILE* fp = open_or_null(logpath, max_depth == 1 ? "w" : "a");
     int removed = 0;
-    for (uint32_t i = 0; i < g.n_nodes; i++) {
+    std::vector<uint64_t> cand = candidate_bits(g, [&](uint32_t i) { return g.deg(i, 0) + g.deg(i, 1) == 1; });   // a dead end: one arc on one side, none on the other
+    for_candidates(g, cand, [&](uint32_t i) -> bool {
         uint32_t side;
         if (g.deg(i, 1) == 0 && g.deg(i, 0) == 1) side = 0;
         else if (g.deg(i, 1) == 1 && g.deg(i, 0) == 0) side = 1;
-        else continue;
+        else return false;
         std::vector<PathElem> p;
         float cov;
         if (simple_path_from(g, i, side, 0, max_depth, p, cov)) {
-            if (g.deg(p.back().id, p.back().strand) == 0) continue;
+            if (g.deg(p.back().id, p.back().strand) == 0) return false;
             LOGF(fp, "tip_len:%zu\t%u:%c -> %u:%c\n", p.size() - 1, p.front().id, "+-"[p.front().strand], p.back().id, "+-"[p.back().strand]);
             remove_path(g, p);
             removed++;
         }
-    }
+        return false;
+    });
     if (fp) fclose(fp);
     return removed;
 }
@@ -218,8 +274,9 @@ int clean_tips(Graph& g, int max_depth, const std::string& logpath) {
 int clean_simple_bubbles(Graph& g, int max_depth, const std::string& logpath) {
     FILE* fp = open_or_null(logpath, "w");
     int removed = 0;
-    for (uint32_t i = 0; i < g.n_nodes; i++) {
-        if (g.deg(i, 0) < 2 && g.deg(i, 1) < 2) continue;
+    std::vector<uint64_t> cand = candidate_bits(g, [&](uint32_t i) { return g.deg(i, 0) >= 2 || g.deg(i, 1) >= 2; });
+    for_candidates(g, cand, [&](uint32_t i) -> bool {
+        if (g.deg(i, 0) < 2 && g.deg(i, 1) < 2) return false;
         bool again = false;
         for (uint32_t side = 0; side < 2 && !again; side++) {
             if (g.deg(i, side) != 2) continue;
@@ -238,8 +295,8 @@ int clean_simple_bubbles(Graph& g, int max_depth, const std::string& logpath) {
                 again = true;   // the reference re-examines the same node (i--; continue)
             }
         }
-        if (again) i--;   // wraps at 0 and comes back with the loop increment, like the reference's uint32_t
-    }
+        return again;
+    });
     if (fp) fclose(fp);
     return removed;
 }
@@ -303,7 +360,8 @@ int clean_super_bubbles(Graph& g, const std::string& logpath) {
     FILE* fp = open_or_null(logpath, "w");
     int removed = 0;
     BubbleTour tour;
-    for (uint32_t i = 0; i < g.n_nodes; i++) {
+    std::vector<uint64_t> cand = candidate_bits(g, [&](uint32_t i) { return g.deg(i, 0) >= 2 || g.deg(i, 1) >= 2; });
+    for_candidates(g, cand, [&](uint32_t i) -> bool {
         bool again = false;
         for (uint32_t side = 0; side < 2 && !again; side++) {
             if (g.deg(i, side) < 2 || !tour.close_from(g, (i << 1) | side)) continue;
@@ -322,10 +380,10 @@ int clean_super_bubbles(Graph& g, const std::string& logpath) {
             }
             LOGF(fp, "\n");
             removed++;
-            again = true;
+            again = true;   // the node is looked at again, like the reference's i--
         }
-        if (again) i--;   // the node is looked at again (wraps at 0 and comes back with the loop increment, like the reference's uint32_t)
-    }
+        return again;
+    });
     if (fp) fclose(fp);
     return removed;
 }
@@ -349,15 +407,17 @@ int clean_small_bubbles(Graph& g, const std::string& logpath) {
     FILE* fp = open_or_null(logpath, "w");
     int removed = 0;
     Triangle t;
-    for (uint32_t i = 0; i < g.n_nodes; i++) {
-        if (!first_triangle(g, i, t)) continue;        // at most one per node and pass, and the node is not looked at again
+    std::vector<uint64_t> cand = candidate_bits(g, [&](uint32_t i) { Triangle x; return first_triangle(g, i, x); });   // (removals only destroy triangles: no additions)
+    for_candidates(g, cand, [&](uint32_t i) -> bool {
+        if (!first_triangle(g, i, t)) return false;    // at most one per node and pass, and the node is not looked at again
         const double shortcut = t.direct, detour = (t.in + t.out) / 2.0;
         LOGF(fp, "small_bubble cov:%.2lf %u:%c -> %u:%c\n", shortcut, t.p >> 1, "+-"[t.p & 1], t.s >> 1, "+-"[t.s & 1]);
         LOGF(fp, "             cov:%.2lf %u:%c -> %u:%c -> %u:%c\n", detour, t.p >> 1, "+-"[t.p & 1], i, '+', t.s >> 1, "+-"[t.s & 1]);
         if (shortcut < detour) g.remove_edge(t.p >> 1, t.p & 1, t.s >> 1, t.s & 1);
         else { g.remove_edge(t.p >> 1, t.p & 1, i, 0); g.remove_edge(i, 0, t.s >> 1, t.s & 1); }
         removed++;
-    }
+        return false;
+    });
     if (fp) fclose(fp);
     return removed;
 }

@@ -101,10 +101,13 @@ struct Graph {
     Arc* find(uint32_t v, uint32_t key);
     const Arc* find(uint32_t v, uint32_t key) const { return const_cast<Graph*>(this)->find(v, key); }
     void erase_arc(uint32_t v, uint32_t key);
+    // nodes whose adjacency changed while a cleaning pass runs (a bit per node; null outside a pass): the pass looks at them again
+    std::vector<uint64_t>* touched = nullptr;
     // bbg_remove_edge (Backbone_graph.cpp:45-51)
     void remove_edge(uint32_t node1, uint32_t rev1, uint32_t node2, uint32_t rev2) {
         erase_arc((node1 << 1) | rev1, (node2 << 1) | rev2);
         erase_arc((node2 << 1) | (1 - rev2), (node1 << 1) | (1 - rev1));
+        if (touched) { (*touched)[node1 >> 6] |= 1ull << (node1 & 63); (*touched)[node2 >> 6] |= 1ull << (node2 & 63); }
     }
     size_t deg(uint32_t node, uint32_t side) const { return adj[(node << 1) | side].size(); }
 };

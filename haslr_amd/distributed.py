@@ -68,6 +68,15 @@ def allgather_bytes(blob: bytes, device, group=None) -> bytes:
     return merged.cpu().numpy().tobytes()[:total]
 
 
+def agree(ok: bool, device, group=None, what="stage"):
+    """Every rank arrives with its own verdict, every rank leaves with the worst one: a rank that failed never leaves the others waiting in
+    the next collective (one 1-element all-reduce). Raises on every rank when any rank failed."""
+    t = torch.tensor([0 if ok else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    if int(t.item()):
+        raise RuntimeError(f"{what} failed on {'this rank' if not ok else 'another rank'} (all ranks stop)")
+
+
 class HipRecords:
     """Edge-support records of a rank's read shard on its HIP context (include/haslr_hip.h: hx_edge_emit / _export / _import)."""
 
@@ -110,8 +119,13 @@ class ShardedBackend:
 
     def _edge_support(self, _ctx, _prm, out):
         try:
-            n = self.records.emit()
-            local = self.records.export(n)
+            n, local = 0, None
+            try:
+                n = self.records.emit()
+                local = self.records.export(n)
+            except Exception as e:  # noqa: BLE001
+                self.error = e
+            agree(local is not None, getattr(self.records, "comm_device", torch.device("cpu")), self.group, "edge-record emission")   # before the all-gather: all or nobody
             merged, total = allgather_records(local, n, self.records.rec_bytes, self.group)
             self.exchange_bytes = total * self.records.rec_bytes
             return self.records.import_(merged, total, out)
@@ -124,11 +138,36 @@ class ShardedBackend:
 def gather_results(run, device, group=None):
     """All ranks exchange the coordinates / supports / consensus of their share of the edges; afterwards every
     rank's run holds all of them and can stitch. Returns the number of bytes gathered."""
-    merged = allgather_bytes(run.results_export(), device, group)
+    blob, err = None, None
+    try:
+        blob = run.results_export()
+    except Exception as e:  # noqa: BLE001
+        err = e
+    agree(blob is not None, device, group, f"results export ({err})" if err else "results export")
+    merged = allgather_bytes(blob, device, group)
     run.results_import(merged)
     if run.results_missing:
         raise RuntimeError(f"{run.results_missing} edges are without results after the gather")
     return len(merged)
+
+
+def sharded_stages(run, device, group=None):
+    """chain -> graph (the record all-gather happens inside, behind its own agreement) -> coords -> consensus -> gathered results, with the ranks
+    agreeing on success after the stages that are followed by a collective. Returns the bytes of results gathered."""
+    def stage(fn, name):
+        err = None
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001
+            err = e
+        try:
+            agree(err is None, device, group, name)
+        except RuntimeError as a:
+            raise (err or a)
+    stage(run.chain, "chain stage")
+    run.graph()                                   # (fails on every rank together: agreement inside the backend's edge_support)
+    stage(lambda: (run.coords(), run.consensus()), "coordinate / consensus stage")
+    return gather_results(run, device, group)
 
 
 def run_sharded(ds, params, backend: ShardedBackend, lr_begin, rank, world, device, group=None, out_dir=None, assemble=True):
@@ -138,11 +177,7 @@ def run_sharded(ds, params, backend: ShardedBackend, lr_begin, rank, world, devi
     run = host.Run(ds, params, backend.table, out_dir)
     run.set_edge_shard(rank, world)
     run.set_read_shard(lr_begin)
-    run.chain()
-    run.graph()
-    run.coords()
-    run.consensus()
-    gather_results(run, device, group)
+    sharded_stages(run, device, group)
     if out_dir is not None or world > 1:
         text = allgather_bytes(run.compact_text(), device, group)   # compact_uniq.txt lists every read: rank order = read order
         if out_dir is not None:

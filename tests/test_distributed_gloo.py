@@ -216,3 +216,64 @@ def test_four_ranks_some_without_edges(sim, built, tmp_path):
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert util.compare_dirs(out1, out4) == []
     run.close(); ob.close(); ds.close()
+
+
+FAIL_WORKER = r'''
+import ctypes as C, os, sys, time
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from haslr_amd import host, distributed as hd, ctypes_defs as T
+import orclib
+pre = sys.argv[2]
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+prm = ds.params()
+ob = orclib.OracleBackend(ds, 2)
+b = hd.shard_bounds(ds.read_hit_off, ds.reads.n, world)
+ob.set_read_shard(b[rank], b[rank + 1])
+table = T.Backend()
+C.memmove(C.byref(table), C.byref(ob.table), C.sizeof(T.Backend))
+proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(T.CoordsOut))
+cb = proto(lambda *_: -1)
+if rank == 1:
+    table.edge_coords = C.cast(cb, C.c_void_p).value      # this rank's coordinate operator fails
+
+
+class Rec:                                              # the oracle's edge_support already returns the merged multiset: nothing to exchange
+    rec_bytes = 32
+    def emit(self): return 0
+    def export(self, n): return torch.zeros(1, dtype=torch.uint8)
+    def import_(self, merged, total, out):
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(T.Params), C.POINTER(T.EdgesOut))
+        return proto(ob.table.edge_support)(ob.table.ctx, C.byref(prm), out)
+
+
+be = hd.ShardedBackend(table, Rec())
+t0 = time.time()
+try:
+    hd.run_sharded(ds, prm, be, b[rank], rank, world, torch.device("cpu"), out_dir=None, assemble=False)
+    print(f"rank {rank}: NO ERROR", flush=True)
+    code = 0
+except Exception as e:
+    print(f"rank {rank}: stopped after {time.time() - t0:.1f} s: {e}", flush=True)
+    code = 7
+os._exit(code)
+'''
+
+
+def test_failure_on_one_rank_stops_every_rank(sim, built, tmp_path):
+    """a rank whose coordinate stage fails: the ranks agree before the results all-gather, so every rank raises within seconds instead of
+    waiting in the collective for the gloo / RCCL watchdog"""
+    pre = sim("--genome-len", "120000", "--seed", "77", "--variant-per-mb", "30", "--cov", "12")
+    w = tmp_path / "worker_fail.py"
+    w.write_text(FAIL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+                        "--master-port", "29527", str(w), ROOT, pre], env=env, capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0
+    for k in range(3):
+        assert f"rank {k}: stopped after" in out, out[-3000:]
+    assert "NO ERROR" not in out
+    assert "rank 0: stopped" in out and "another rank" in out

@@ -48,3 +48,33 @@ def test_nondefault_parameters(sim, ref_front, tmp_path):
     run.chain()
     run.graph()
     assert util.compare_dirs(str(rd), str(od)) == []
+
+
+@pytest.mark.parametrize("threads", ["1", "3", "16"])
+def test_parallel_cleaning_passes_equal_the_reference(threads, sim, ref_front, tmp_path):
+    """the four cleaning passes with their per-node tests evaluated by several host threads and the edits committed in the
+    reference's node order (host/graph.cpp) - every GFA, stat and log byte-equal to the compiled reference's (Cleaning.cpp:7-184, :488-648),
+    on a graph where every pass fires (tips, simple / super / small bubbles, weak edges), whatever the thread count"""
+    pre = sim("--genome-len", "1500000", "--seed", "5", "--variant-per-mb", "60", "--cov", "16", "--model", "nanopore", "--hairpin-frac", "0.06")
+    rd, od = tmp_path / "ref", tmp_path / "orc"
+    rd.mkdir()
+    subprocess.check_call([ref_front, "-c", pre + ".contigs.fa", "-l", pre + ".reads.fa", "-m", pre + ".paf", "-d", str(rd)],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    be = orclib.OracleBackend(ds, 8)
+    old = os.environ.get("HASLR_CLEAN_THREADS")
+    try:
+        os.environ["HASLR_CLEAN_THREADS"] = threads
+        run = host.Run(ds, ds.params(), be.table, str(od))
+        run.chain()
+        run.graph()
+    finally:
+        if old is None:
+            os.environ.pop("HASLR_CLEAN_THREADS", None)
+        else:
+            os.environ["HASLR_CLEAN_THREADS"] = old
+    assert util.compare_dirs(str(rd), str(od)) == []
+    logs = {f: open(od / f).read() for f in os.listdir(od) if f.endswith(".log")}
+    assert logs["backbone.03.tip.log"].count("tip_len") >= 20 and "bubble_src" in logs["backbone.05.superbubble.log"]
+    assert "simple_bubble" in logs["backbone.04.simplebubble.log"] and logs["backbone.06.smallbubble.log"].count("small_bubble") >= 10
+    run.close(); be.close(); ds.close()
