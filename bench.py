@@ -12,13 +12,17 @@ N=1 workload: BASELINE.json configs[2], the largest single-GPU configuration —
 Nanopore-like 25x long reads + PAF against short-read contigs, synthetic (tools/hxsim, seed 0x4841534c + 2;
 there is no network for real reads). configs[1] (E. coli-size 4.6 Mb, PacBio-like 25x) is measured too and
 reported under "configs1" (`--workload ecoli` makes it the main line instead).
-N>1 (weak scaling): genome of N x 12 Mb, reads sharded by id range, ONE all-gather of edge records (RCCL),
-edges sharded by estimated DP cost for coordinates + consensus, one all-gather of the results; after the
-timed steps every rank stitches the assembly, the ranks' assemblies must be identical, and rank 0 repeats the
-pass on its GPU alone and requires the same assembly (`assembly.matches_single_gpu`).
+N>1: reads sharded by id range, ONE all-gather of edge records (RCCL), edges sharded by estimated DP cost for
+coordinates + consensus, one all-gather of the results; the ranks agree on success before every collective.
+N = 4 runs BASELINE.json configs[3] as it is named (140 Mb PacBio-like, read-sharded over 4 GPUs); N = 2, 8 scale the
+12 Mb genome x N (weak scaling; `config.workload` says which). After the timed steps every rank stitches the
+assembly, the ranks' assemblies must be identical, and rank 0 repeats the pass on its GPU alone and requires the
+same assembly (`assembly.matches_single_gpu`).
 
 Extra objects on the JSON line: `roofline` for the dominant kernel (K6 POA; HBM bound named by the north
-star, algorithmic bytes per SURVEY.md 8d) with GCUPS as the secondary figure, and `cpu_baseline` (the
+star, algorithmic bytes per SURVEY.md 8d) with GCUPS against the VALU issue bound (256 CU x 4 SIMD-32 x 2.4 GHz),
+the SQ-counter figures of the committed profile, the critical path and the POA workspace; `gfa` +
+`gfa_equals_cpu_baseline` (the metric's "GFA match": six files, byte for byte); and `cpu_baseline` (the
 CPU oracle = a port of the reference path with AVX2 row kernels, timed on this box's host cores on the SAME
 data set, 64 threads and all cores; its consensus must equal the GPU's).
 """
