@@ -112,6 +112,22 @@ def test_binary_with_two_ranks_on_one_gpu_and_one_rank_over_rccl(sim, built, tmp
 
 
 @pytest.mark.gpu
+def test_binary_with_more_ranks_than_edges(sim, built, tmp_path):
+    """fewer surviving edges than ranks: the idle ranks call hx_edge_coords with no edge and hx_poa_batch with nothing to align, still take part
+    in the record exchange and the results exchange, and the outputs are the single-GPU run's"""
+    pre = sim("--genome-len", "26000", "--seed", "12", "--cov", "7", "--gap-median", "400")
+    base = ["-t", "4", "-c", pre + ".contigs.fa", "-l", pre + ".reads.fa", "-m", pre + ".paf"]
+    one = _cli(base + ["-d", str(tmp_path / "one")])
+    assert one.returncode == 0, one.stderr[-2000:]
+    many = _cli(base + ["-d", str(tmp_path / "many"), "--gpus", "5"], {"HASLR_GROUP_TRANSPORT": "host"})
+    assert many.returncode == 0, many.stderr[-2000:]
+    diff = [d for d in util.compare_dirs(str(tmp_path / "one"), str(tmp_path / "many")) if "index.longread" not in d]
+    assert diff == [], diff
+    n_links = sum(1 for ln in open(tmp_path / "one" / "backbone.06.smallbubble.gfa") if ln.startswith("L"))
+    assert 0 < n_links // 2 < 5, n_links        # (the point of the case: fewer edges than ranks)
+
+
+@pytest.mark.gpu
 def test_edge_merge_through_the_c_abi_equals_edge_support(sim, built):
     """hx_group_create / hx_edge_merge / hx_group_backend_fill through ctypes: three ranks on one device (host-staged exchange), one Python
     thread per rank; every rank's merged multiset equals the unsharded hx_edge_support"""
