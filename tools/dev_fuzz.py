@@ -15,7 +15,7 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = hip.HipContext(0)
 os.makedirs('/tmp/fz', exist_ok=True)
 bad = 0
-KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS', 'HX_POA_BATCHES', 'HX_POA_NODE_EST_PCT', 'HX_POA_RING_KB', 'HX_POA_COLS', 'HX_POA_CLUSTER_TOPK')
+KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS', 'HX_POA_BATCHES', 'HX_POA_NODE_EST_PCT', 'HX_POA_RING_KB', 'HX_POA_COLS', 'HX_POA_CLUSTER_TOPK', 'HX_POA_SLOTS', 'HX_POA_WORKSPACE_GB')
 for it in range(n):
     big = os.environ.get('FUZZ_BIG') is not None   # long gaps at real sizes: the default launch shapes (512-lane cluster members) get real work
     glen = rng.choice([400000, 700000, 1000000]) if big else rng.choice([40000, 60000, 90000, 150000, 250000])
@@ -46,6 +46,10 @@ for it in range(n):
         env['HX_POA_COLS'] = str(rng.choice([4, 8, 16]))
     if rng.random() < 0.2:
         env['HX_POA_CLUSTER_TOPK'] = str(rng.choice([0, 2, 1000]))
+    if rng.random() < 0.4:
+        env['HX_POA_SLOTS'] = str(rng.choice([1, 2, 3, 7]))          # persistent workgroups: a few workspace slots per launch class, many edges each (round 3)
+    if rng.random() < 0.15:
+        env['HX_POA_WORKSPACE_GB'] = str(rng.choice([1, 2, 4]))   # a small workspace cap: fewer slots, or several batches
     if rng.random() < 0.25:
         env['HX_POA_NODE_EST_PCT'] = str(rng.choice([2, 10, 30, 60]))
     os.environ.update(env)
