@@ -79,6 +79,9 @@ void hxh_run_set_edge_shard(hxh_run*, uint32_t rank, uint32_t world);
  *                           (chain, graph, coords, consensus, assemble). */
 void hxh_shard_bounds(const hxh_dataset*, uint32_t n, uint32_t* bounds);
 int hxh_runs_all_sharded(hxh_run** runs, uint32_t n, const uint32_t* read_begin, void (*on_stage)(int stage, int begin, void* user), void* user);
+/* index.longread of a sharded pass (after hxh_runs_all_sharded, or at least the chain stage of every rank): the ranks' filtered alignments in
+ * rank order = read order, same bytes as the single-rank file */
+int hxh_runs_write_longread_index(hxh_run* const* runs, uint32_t n, const char* path);
 void hxh_run_set_read_shard(hxh_run*, uint32_t lr_begin);
 int hxh_run_results_export(hxh_run*, const uint8_t** buf, uint64_t* len);
 int hxh_run_results_import(hxh_run*, const uint8_t* buf, uint64_t len);

@@ -184,7 +184,8 @@ int main(int argc, char* argv[]) {
             }
         };
         if (hxh_runs_all_sharded(runs.data(), (uint32_t)gpus, bounds.data(), on_stage, &cb) != 0) { fprintf(stderr, "[ERROR] %s\n", hxh_last_error()); return EXIT_FAILURE; }
-        // (index.longread is not written by a sharded run: every rank holds only its own reads' filtered alignments; a later run parses the PAF again)
+        // index.longread: the ranks' filtered alignments in rank order (written after the stages here: every rank's chain output is still held)
+        if (!used_li && hxh_runs_write_longread_index(runs.data(), (uint32_t)gpus, (out_dir + "/index.longread").c_str()) != 0) { fprintf(stderr, "%s\n", hxh_last_error()); return EXIT_FAILURE; }
         fprintf(stderr, "[NOTE] cleaning up the memory!\n");
         fprintf(stderr, "[NOTE] elapsed time %.2lf CPU seconds (%.2lf real seconds)\n\n*** BYE ***\n\n", cpu_time() - c0, real_time() - r0);
         fflush(nullptr);

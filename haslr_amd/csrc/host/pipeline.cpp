@@ -750,3 +750,24 @@ extern "C" int hxh_runs_all_sharded(hxh_run** runs, uint32_t n, const uint32_t* 
         }
     return 0;
 }
+
+// index.longread of a sharded pass: the filtered alignments of ALL reads = the ranks' chain outputs in rank order (ranks own ascending read
+// ranges). The writer looks at the per-read alignment counts and the PAF record of every alignment only (Longread.cpp:322-339).
+extern "C" int hxh_runs_write_longread_index(hxh_run* const* runs, uint32_t n, const char* path) {
+    if (n == 0) { g_err = "index.longread: no ranks"; return -1; }
+    std::vector<uint32_t> hit;
+    std::vector<uint64_t> read_off{0};
+    const Dataset* d = reinterpret_cast<const Run*>(runs[0])->d;
+    for (uint32_t r = 0; r < n; r++) {
+        const Run* R = reinterpret_cast<const Run*>(runs[r]);
+        if (!R->have_chain) { g_err = "index.longread needs the chain stage of every rank"; return -1; }
+        const hx_chain_out& c = R->chain;
+        const uint64_t base = hit.size();
+        hit.insert(hit.end(), c.hit, c.hit + c.n_aln);
+        for (uint32_t i = 0; i < c.n_reads; i++) read_off.push_back(base + c.read_off[i + 1]);
+    }
+    hx_chain_out all{};
+    all.n_reads = (uint32_t)(read_off.size() - 1); all.n_aln = hit.size();
+    all.hit = hit.data(); all.read_off = read_off.data();
+    return write_longread_index(*d, all, path) ? 0 : -1;
+}

@@ -101,10 +101,9 @@ def test_binary_with_two_ranks_on_one_gpu_and_one_rank_over_rccl(sim, built, tmp
     rc1 = _cli(base + ["-d", str(tmp_path / "rccl1"), "--gpus", "1"], {"HASLR_FORCE_GROUP": "1"})
     assert rc1.returncode == 0, rc1.stderr[-2000:]
     assert "edge-record exchange over rccl" in rc1.stderr
-    skip = {"index.longread"}                                     # (a sharded run does not write the filtered-alignment cache)
-    for other in ("two", "rccl1"):
-        diff = [d for d in util.compare_dirs(str(tmp_path / "one"), str(tmp_path / other)) if not any(s in d for s in skip)]
-        assert diff == [], (other, diff)
+    for other in ("two", "rccl1"):                                # every output file, index.contig / index.longread included
+        assert util.compare_dirs(str(tmp_path / "one"), str(tmp_path / other)) == [], other
+        assert open(tmp_path / "one" / "index.longread", "rb").read() == open(tmp_path / other / "index.longread", "rb").read()
     assert os.path.getsize(tmp_path / "one" / "asm.final.fa") > 100000
     # more ranks than devices over RCCL is refused, loudly
     bad = _cli(base + ["-d", str(tmp_path / "bad"), "--gpus", "64"], {"HASLR_GROUP_TRANSPORT": "rccl"})
@@ -121,8 +120,8 @@ def test_binary_with_more_ranks_than_edges(sim, built, tmp_path):
     assert one.returncode == 0, one.stderr[-2000:]
     many = _cli(base + ["-d", str(tmp_path / "many"), "--gpus", "5"], {"HASLR_GROUP_TRANSPORT": "host"})
     assert many.returncode == 0, many.stderr[-2000:]
-    diff = [d for d in util.compare_dirs(str(tmp_path / "one"), str(tmp_path / "many")) if "index.longread" not in d]
-    assert diff == [], diff
+    assert util.compare_dirs(str(tmp_path / "one"), str(tmp_path / "many")) == []
+    assert open(tmp_path / "one" / "index.longread", "rb").read() == open(tmp_path / "many" / "index.longread", "rb").read()
     n_links = sum(1 for ln in open(tmp_path / "one" / "backbone.06.smallbubble.gfa") if ln.startswith("L"))
     assert 0 < n_links // 2 < 5, n_links        # (the point of the case: fewer edges than ranks)
 
