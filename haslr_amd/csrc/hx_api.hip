@@ -93,7 +93,7 @@ struct PoaPlan {
 struct PoaPoolBufs {
     DV<uint8_t> code, n_aligned, mark, check, row_code, row_sink, seq;
     DV<uint32_t> aligned, in_head, in_tail, out_head, out_tail, rank2node, node2rank, stack, row_pred_off, pred_rank, e_from, e_to, e_next_in, e_next_out;
-    DV<int32_t> score, pred, e_w, aln_node, aln_pos, H;
+    DV<int32_t> score, pred, e_w, aln_node, aln_pos, H, pred_w;
     DV<uint32_t> row_meta, row_pred0, row_pred1;
     DV<uint4> nrec;
     DV<uint8_t> dir, dirw; DV<uint32_t> wslot;
@@ -103,7 +103,7 @@ struct PoaPoolBufs {
         aligned.release(); in_head.release(); in_tail.release(); out_head.release(); out_tail.release(); rank2node.release(); node2rank.release();
         stack.release(); row_pred_off.release(); pred_rank.release(); e_from.release(); e_to.release(); e_next_in.release(); e_next_out.release();
         score.release(); pred.release(); e_w.release(); aln_node.release(); aln_pos.release(); H.release(); row_meta.release(); row_pred0.release();
-        row_pred1.release(); nrec.release(); dir.release(); dirw.release(); wslot.release(); mbox.release(); sinkbuf.release(); csync.release(); row_al.release();
+        row_pred1.release(); nrec.release(); pred_w.release(); dir.release(); dirw.release(); wslot.release(); mbox.release(); sinkbuf.release(); csync.release(); row_al.release();
     }
 };
 }  // namespace
@@ -730,7 +730,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
         };
         auto need_max = [](Need& a, const Need& b) { a.nn = std::max(a.nn, b.nn); a.ec = std::max(a.ec, b.ec); a.hc = std::max(a.hc, b.hc); a.dc = std::max(a.dc, b.dc); a.wc = std::max(a.wc, b.wc);
                                                        a.lm = std::max(a.lm, b.lm); a.st = std::max(a.st, b.st); a.al = std::max(a.al, b.al); };
-        auto need_bytes = [](const Need& n) -> uint64_t { return n.nn * 90 + n.ec * 24 + n.hc * 4 + n.dc + n.wc + n.lm + n.st * 4 + n.al * 8; };
+        auto need_bytes = [](const Need& n) -> uint64_t { return n.nn * 90 + n.ec * 28 + n.hc * 4 + n.dc + n.wc + n.lm + n.st * 4 + n.al * 8; };
         // launch classes: (shared?, lanes per workgroup, columns per lane, traceback flavour) - one kernel instance each, so that every
         // launch runs with the registers ITS row loop needs (kernels/poa.hip)
         struct Cls { bool shared; uint32_t nt, cm; bool dir; std::vector<uint32_t> edges; size_t blocks = 0, order_at = 0, slot_at = 0, n_slots = 0; Need need{}; bool persistent = false; };
@@ -857,7 +857,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                     if (q.shared) { P.edges[e].cl_off = clo; clo += (uint64_t)P.edges[e].members * ((uint64_t)P.edges[e].vcap + 1); }
                 }
             }
-            const uint64_t bytes = no * 90 + eo * 24 + ho * 4 + dro + wo + so + sto * 4 + ao * 8 + clo * 8 + co;
+            const uint64_t bytes = no * 90 + eo * 28 + ho * 4 + dro + wo + so + sto * 4 + ao * 8 + clo * 8 + co;
             // Pools grow and never shrink, each to the largest batch it has seen: after batches of different shapes (direction bytes for one,
             // the whole score matrix for a retry) the capacities together can exceed the device although this batch alone fits the budget.
             // Then everything is released and reserved again at this batch's sizes.
@@ -867,7 +867,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                 HX_RSV(B.H, std::max<uint64_t>(1, ho)); HX_RSV(B.dir, std::max<uint64_t>(1, dro)); HX_RSV(B.dirw, std::max<uint64_t>(1, wo)); HX_RSV(B.wslot, no);
                 HX_RSV(B.code, no); HX_RSV(B.n_aligned, no); HX_RSV(B.mark, no); HX_RSV(B.check, no); HX_RSV(B.row_code, no); HX_RSV(B.row_sink, no); HX_RSV(B.row_al, no);
                 HX_RSV(B.aligned, 3 * no); HX_RSV(B.in_head, no); HX_RSV(B.in_tail, no); HX_RSV(B.out_head, no); HX_RSV(B.out_tail, no); HX_RSV(B.rank2node, no);
-                HX_RSV(B.node2rank, no); HX_RSV(B.row_pred_off, no); HX_RSV(B.score, no); HX_RSV(B.pred, no); HX_RSV(B.pred_rank, eo); HX_RSV(B.e_from, eo);
+                HX_RSV(B.node2rank, no); HX_RSV(B.row_pred_off, no); HX_RSV(B.score, no); HX_RSV(B.pred, no); HX_RSV(B.pred_rank, eo); HX_RSV(B.pred_w, eo); HX_RSV(B.e_from, eo);
                 HX_RSV(B.e_to, eo); HX_RSV(B.e_next_in, eo); HX_RSV(B.e_next_out, eo); HX_RSV(B.e_w, eo); HX_RSV(B.stack, sto); HX_RSV(B.aln_node, ao); HX_RSV(B.aln_pos, ao);
                 HX_RSV(B.row_meta, no); HX_RSV(B.row_pred0, no); HX_RSV(B.row_pred1, no); HX_RSV(B.nrec, no); HX_RSV(B.seq, so); HX_RSV(d_cns, co);
                 HX_RSV(B.mbox, std::max<uint64_t>(1, clo));
@@ -916,7 +916,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             hxk::PoaPools pools{B.code.p, B.n_aligned.p, B.aligned.p, B.in_head.p, B.in_tail.p, B.out_head.p, B.out_tail.p, B.rank2node.p, B.node2rank.p,
                                 B.mark.p, B.check.p, B.stack.p, B.score.p, B.pred.p, B.row_code.p, B.row_sink.p, B.row_pred_off.p, B.pred_rank.p, B.row_meta.p, B.row_pred0.p, B.row_pred1.p, B.nrec.p,
                                 B.e_from.p, B.e_to.p, B.e_next_in.p, B.e_next_out.p, B.e_w.p, B.aln_node.p, B.aln_pos.p, B.H.p, B.dir.p, B.dirw.p, B.wslot.p, B.seq.p,
-                                B.mbox.p, B.csync.p, B.sinkbuf.p, B.row_al.p};
+                                B.mbox.p, B.csync.p, B.sinkbuf.p, B.row_al.p, B.pred_w.p};
             const size_t n_streams = getenv("HX_POA_STREAMS") ? (size_t)std::min(8, std::max(1, atoi(getenv("HX_POA_STREAMS")))) : 6;
             size_t wg_total = 0;
             for (const Cls& q : classes) wg_total += q.blocks;

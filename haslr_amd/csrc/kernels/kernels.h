@@ -131,6 +131,7 @@ struct PoaPools {
     uint32_t* csync;            // 8 words per edge: go, done, V, L, error
     int32_t* sinkbuf;           // 1 + 2*1024 words per edge: sink rows / scores when the last column lives in another member
     uint16_t* row_al;           // per rank: ranks of the node's aligned nodes in list order, 3 x 3 bits (rank delta + 4, 0 = none)
+    int32_t* pred_w;            // per entry of pred_rank: the weight of that in-edge (the heaviest bundle runs on the rank-ordered rows)
 };
 // kernel instance (largest workgroup it is compiled for) that serves workgroups of `block_threads` lanes, and the columns per lane it can be had with
 inline int poa_kernel_lanes(int block_threads) { return block_threads <= 64 ? 64 : block_threads <= 256 ? 256 : block_threads <= 512 ? 512 : 1024; }

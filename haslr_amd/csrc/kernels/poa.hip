@@ -39,6 +39,7 @@ struct G {   // per-edge views into the pools
     uint32_t *row_meta, *row_pred0, *row_pred1;   // per rank: code | sink<<2 | far<<3 | kept<<4 | wide<<5 | own ring slot<<8 | npred<<12 (META_SLOT, META_NP) ; ranks of the first two predecessors
     uint16_t* row_al;                             // per rank: aligned nodes in list order as rank deltas (3 x 3 bits, delta + 4, 0 = none)
     uint32_t* wslot;                              // per rank: row of the wide-row pool (rows with more than 4 predecessors: a direction byte per cell)
+    int32_t* pred_w;                              // per entry of pred_rank: weight of that in-edge
     uint4* nrec;   // per node, one 16-byte record for the serial graph walks: {1st in-edge source, 2nd in-edge source, 3 aligned ids (+1) x 21 bit, bit 63: more in-edges}
     uint32_t *e_from, *e_to, *e_next_in, *e_next_out; int32_t* e_w;
     int32_t *aln_node, *aln_pos;
@@ -320,31 +321,64 @@ __device__ bool add_alignment(G& g, uint32_t& V, uint32_t& E, uint32_t n_aln, co
 }
 
 // The forward pass of the heaviest bundle on ANY valid topological order gives the same scores and predecessors (a node looks only at its
-// in-edges, in in-edge order). The order matters in two places: which of several equally heavy nodes is taken as the end ("first in
-// rank order"), and the branch completion that follows when that node is not a sink. So: run the pass on the order the DP maintains;
-// if the heaviest node is unique and a sink, the walk back from it IS the reference's consensus. Otherwise return NONE and let the
-// caller sort the graph the reference's way. lane 0 only.
-__device__ uint32_t consensus_fast(G& g, uint32_t V, char* out) {
-    for (uint32_t i = 0; i < V; i++) { g.pred[i] = -1; g.score[i] = -1; }
+// in-edges, in in-edge order). The order matters in two places: which of several equally heavy nodes is taken as the end ("first in rank order"),
+// and the branch completion that follows when that node is not a sink. So: run the pass on the order the DP maintains; if the heaviest node is
+// unique and a sink, the walk back from it IS the reference's consensus. Otherwise return NONE and let the caller sort the graph the reference's way.
+// It is made by one whole wavefront on the rank-ordered rows of the last CSR build (row_pred_off / row_pred0 / row_pred1 / pred_rank, pred_w):
+// a single lane walking the node lists pays 5-6 dependent HBM round trips per node (25-50 M cycles on a 20 000-node graph: 4-8 % of the longest edges). Here 64
+// consecutive ranks are taken at a time: every lane fetches its row and folds the predecessors that lie BEFORE the chunk (their scores are final:
+// independent loads, one round trip for the chunk), then the chunk is finished rank by rank with the scores of the predecessors inside it read from
+// a register (ds_bpermute). The fold "take the edge if it is heavier, or as heavy and its source scores at least as much" (spoa's <=: the later
+// in-edge wins a tie) is the maximum of (weight, source score, position in the in-edge list), so the two halves can be folded in any order.
+// Returns the consensus length, or NONE when the heaviest node is not a unique sink (the caller then sorts the graph the reference's way).
+__device__ uint32_t consensus_fast_wave(G& g, const uint32_t V, char* out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    int32_t* sc_r = g.score;          // by rank
+    int32_t* pr_r = g.pred;           // by rank: rank of the chosen predecessor, -1 = none
     uint32_t best = NONE, nbest = 0;
     int32_t bscore = 0;
-    for (uint32_t r = 0; r < V; r++) {
-        const uint32_t n = g.rank2node[r];
-        for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) {
-            const uint32_t f = g.e_from[e]; const int32_t w = g.e_w[e];
-            if (g.score[n] < w || (g.score[n] == w && g.score[g.pred[n]] <= g.score[f])) { g.score[n] = w; g.pred[n] = (int32_t)f; }
+    for (uint32_t r0 = 0; r0 < V; r0 += 64) {
+        const uint32_t r = r0 + lane;
+        const bool valid = r < V;
+        const uint32_t np = valid ? g.row_meta[r] >> META_NP : 0u, off = valid ? g.row_pred_off[r] : 0u;
+        // the first four in-edges in registers (rank, weight); more than four: the list is walked again where needed (rare)
+        uint32_t ep[4]; int32_t ew[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { ep[k] = (uint32_t)k < np ? g.pred_rank[off + k] & 0x0fffffffu : NONE; ew[k] = (uint32_t)k < np ? g.pred_w[off + k] : 0; }
+        int32_t bw = -1, bs = 0, bp = -1; uint32_t bk = 0;     // best candidate so far: weight, its source's score, its source's rank, its position
+        auto take = [&](int32_t w, int32_t s, uint32_t p, uint32_t k) { if (w > bw || (w == bw && (s > bs || (s == bs && k >= bk)))) { bw = w; bs = s; bp = (int32_t)p; bk = k; } };
+        for (uint32_t k = 0; k < np; k++) {                     // predecessors before the chunk
+            const uint32_t p = k < 4 ? ep[k] : g.pred_rank[off + k] & 0x0fffffffu;
+            if (p < r0) take(k < 4 ? ew[k] : g.pred_w[off + k], sc_r[p], p, k);
         }
-        if (g.pred[n] != -1) g.score[n] += g.score[g.pred[n]];
-        const int32_t sc = g.score[n];
-        if (best == NONE || sc > bscore) { best = n; bscore = sc; nbest = 1; }
-        else if (sc == bscore) nbest++;
+        int32_t sc = -1;
+        const uint32_t nv = min(64u, V - r0);
+        for (uint32_t l = 0; l < nv; l++) {                     // the chunk, rank by rank (wave-uniform loop; lane l is the one that finishes)
+            const uint32_t npl = (uint32_t)__builtin_amdgcn_readlane((int)np, (int)l);
+            for (uint32_t k = 0; k < npl; k++) {
+                uint32_t p = NONE; int32_t w = 0;
+                if (lane == l) { p = k < 4 ? ep[k < 4 ? k : 0] : g.pred_rank[off + k] & 0x0fffffffu; w = k < 4 ? ew[k < 4 ? k : 0] : g.pred_w[off + k]; }
+                const bool inside = lane == l && p >= r0 && p != NONE;
+                const int32_t s = __shfl(sc, inside ? (int)(p - r0) : 0);   // (every lane takes part in the exchange)
+                if (inside) take(w, s, p, k);
+            }
+            if (lane == l) sc = bp == -1 ? -1 : bw + bs;
+            const int32_t sl = __builtin_amdgcn_readlane(sc, (int)l);
+            if (best == NONE || sl > bscore) { best = r0 + l; bscore = sl; nbest = 1; }
+            else if (sl == bscore) nbest++;
+        }
+        if (valid) { sc_r[r] = sc; pr_r[r] = bp; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
-    if (nbest != 1 || g.out_head[best] != NONE) return NONE;
+    if (nbest != 1 || !(g.row_meta[best] & 4u)) return NONE;    // (bit 2 of a row record: the node has no out-edge)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     uint32_t len = 0;
-    for (uint32_t n = best;; n = (uint32_t)g.pred[n]) { len++; if (g.pred[n] == -1) break; }
-    uint32_t w = len;
-    for (uint32_t n = best;; n = (uint32_t)g.pred[n]) { out[--w] = "ACGT"[g.code[n]]; if (g.pred[n] == -1) break; }
-    return len;
+    if (lane == 0) {
+        for (int32_t r = (int32_t)best; r != -1; r = pr_r[r]) len++;
+        uint32_t w = len;
+        for (int32_t r = (int32_t)best; r != -1; r = pr_r[r]) out[--w] = "ACGT"[g.row_meta[r] & 3u];
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
 }
 
 // spoa Graph::traverse_heaviest_bundle + branch_completion; lane 0 only. Writes the consensus, returns its length.
@@ -900,7 +934,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
         g.in_head = P.in_head + no; g.in_tail = P.in_tail + no; g.out_head = P.out_head + no; g.out_tail = P.out_tail + no;
         g.rank2node = P.rank2node + no; g.node2rank = P.node2rank + no; g.mark = P.mark + no; g.check = P.check + no;
         g.stack = P.stack + SL.stack_off; g.score = P.score + no; g.pred = P.pred + no;
-        g.row_code = P.row_code + no; g.row_sink = P.row_sink + no; g.row_pred_off = P.row_pred_off + no; g.pred_rank = P.pred_rank + eo;
+        g.row_code = P.row_code + no; g.row_sink = P.row_sink + no; g.row_pred_off = P.row_pred_off + no; g.pred_rank = P.pred_rank + eo; g.pred_w = P.pred_w + eo;
         g.row_meta = P.row_meta + no; g.row_pred0 = P.row_pred0 + no; g.row_pred1 = P.row_pred1 + no; g.nrec = P.nrec + no; g.row_al = P.row_al + no; g.wslot = P.wslot + no;
         g.e_from = P.e_from + eo; g.e_to = P.e_to + eo; g.e_next_in = P.e_next_in + eo; g.e_next_out = P.e_next_out + eo; g.e_w = P.e_w + eo;
         g.aln_node = P.aln_node + SL.aln_off; g.aln_pos = P.aln_pos + SL.aln_off;
@@ -1435,6 +1469,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                 uint32_t np = 0, q0 = 0, q1 = 0;
                 for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) {
                     const uint32_t pr = g.node2rank[g.e_from[e]];
+                    g.pred_w[off] = g.e_w[e];
                     g.pred_rank[off++] = pr;
                     if (np == 0) q0 = pr; else if (np == 1) q1 = pr;
                     np++;
@@ -1519,7 +1554,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     if (sOk == 1 && sV) {
         // heaviest bundle: first on the maintained order (exact whenever the heaviest node is unique and a sink); else on the reference's
         // topological order of the finished graph
-        if (tid == 0) sCtl = consensus_fast(g, sV, cns + ED.cns_off);
+        if (tid < 64) { const uint32_t cl_ = consensus_fast_wave(g, sV, cns + ED.cns_off); if (tid == 0) sCtl = cl_; }
         __syncthreads();
         if (sCtl == NONE) {
             exact_order(sV, g.rank2node);
