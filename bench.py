@@ -263,6 +263,7 @@ def main():
         assembly["same_on_all_ranks"] = all(bool(torch.equal(hs[0], x)) for x in hs)
         assembly["results_gathered_bytes"] = gathered[0]
         assembly["edge_record_exchange_bytes"] = backend.exchange_bytes
+        assembly["edge_record_exchange_ms"] = backend.exchange_ms      # wall time of the record all-gather of the last step on this rank (over xGMI with RCCL; SURVEY 8e expects 10-15 ms at CHM1 scale)
         if backend_name == "gloo" and dist.get_world_size() > 1:
             # rehearsal mode (all ranks on one device): the single-GPU pass needs the memory the other ranks' workspaces hold
             last.close()

@@ -596,7 +596,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     std::vector<uint8_t> no_share(ne, 0);      // edges whose members did not get through together: one workgroup from now on
     std::vector<uint8_t> many_sinks(ne, 0);    // edges with more sink rows than the smaller kernels keep in LDS: one 1024-lane workgroup
     const uint32_t poll_limit = getenv("HX_POA_POLL_LIMIT") ? (uint32_t)atol(getenv("HX_POA_POLL_LIMIT")) : 1u << 24;   // (testing: forces the unshared retry)
-    const uint32_t max_indeg = getenv("HX_POA_MAX_INDEG") ? std::min<uint32_t>(16, (uint32_t)atoi(getenv("HX_POA_MAX_INDEG"))) : 16;   // (testing: forces the score-matrix retry earlier)
+    const uint32_t max_indeg = (getenv("HX_POA_MAX_INDEG") ? std::min<uint32_t>(16, (uint32_t)atoi(getenv("HX_POA_MAX_INDEG"))) : 16);   // (testing: forces the score-matrix retry earlier)
     const uint32_t cl_lanes = getenv("HX_POA_MEMBER_LANES") ? (uint32_t)atoi(getenv("HX_POA_MEMBER_LANES")) : 256;   // lanes per cluster member
     const uint32_t cl_min = getenv("HX_POA_CLUSTER_MIN") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MIN")) : 2048;       // columns above which an edge is shared
     // Sharing an edge buys latency for that edge and costs throughput. Hundreds of edges (the longest is the step): up to 16 members, the
@@ -646,7 +646,8 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
         if (ring_kb_wave) lds_budget = std::min<uint64_t>(lds_budget, std::max<uint64_t>(ring_kb_wave * 1024 * (nt / 64), 2 * row_bytes));
         if (2 * row_bytes > lds_budget) lds_budget = kPoaLdsMax;   // wide rows: whatever the CU has
         const uint64_t rows_fit = std::min<uint64_t>(lds_budget, kPoaLdsMax) / row_bytes;
-        const uint32_t R = rows_fit >= 8 ? 8 : rows_fit >= 4 ? 4 : rows_fit >= 2 ? 2 : 0;   // kept rows: a power of two (slot = kept-row counter & (R-1)); 0 = every kept row goes through HBM
+        uint32_t R = rows_fit >= 8 ? 8 : rows_fit >= 4 ? 4 : rows_fit >= 2 ? 2 : 0;   // kept rows: a power of two (slot = kept-row counter & (R-1)); 0 = every kept row goes through HBM
+        if (getenv("HX_POA_RING_ZERO")) R = 0;                          // (testing: the ring-less mode that otherwise only gaps above 16 383 columns in ONE workgroup reach)
         row_bytes *= std::max<uint32_t>(R, 1);                          // -> LDS bytes of the ring (at least one row's worth: the kernel's other phases use the space too)
         return R;
     };
@@ -756,7 +757,9 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                 }
                 if (ncol > 32768) return fail("hx_poa_batch: a gap longer than 32767 bases needs the shared (cluster) mode: direction-byte traceback, automatic block size");
                 const uint32_t nt = (uint32_t)kClassNT[class_of(e)];
-                cls_of(false, nt, cm_round(ncol, nt), !full_h[e]).edges.push_back(e);
+                uint32_t cmq = cm_round(ncol, nt);
+                if (const char* fc = getenv("HX_POA_FORCE_CM")) cmq = std::max<uint32_t>(cmq, std::min<uint32_t>((uint32_t)atoi(fc), (uint32_t)hxk::poa_kernel_max_cm((int)nt)));   // (testing: a wider kernel instance than the gap needs)
+                cls_of(false, nt, cmq, !full_h[e]).edges.push_back(e);
             }
             // order of the launches: shared edges first (they set the duration), then by lanes; score-matrix launches after their direction-byte twins
             std::stable_sort(classes.begin(), classes.end(), [](const Cls& a, const Cls& b) {
@@ -937,6 +940,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                     // hundreds of edges: the longest ones set the duration, and their waves run faster with two neighbours on a SIMD than with
                     // three - 10 KB of LDS per wave keeps a CU at 12 waves (thousands of edges: 16, the ring alone is 8.3 KB per wave)
                     if (!many_edges) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(kPoaLdsMax, 10 * 1024 * (uint64_t)(q.nt / 64)));
+                    if (getenv("HX_POA_RING_ZERO")) lds_bytes = ring_need;   // (one row's worth: the kernel then finds room for no kept row either)
                 }
                 const int dcls = q.shared ? 0 : q.nt >= 1024 ? 1 : q.nt >= 512 ? 2 : q.nt >= 256 ? 3 : q.nt >= 128 ? 4 : 5;
                 for (uint32_t e : q.edges) c->dbg_cls[e] = (uint8_t)(dcls + (q.dir ? 0 : 5));

@@ -441,7 +441,8 @@ __global__ void __launch_bounds__(256) k_chain_reads_wave(DevHits h, const uint6
             uint32_t cnt = 0;
             for (int32_t u = (int32_t)nu - 1; u >= 0;) {
                 if (!__builtin_amdgcn_readlane((int)take, u)) { u--; continue; }
-                if (lane == 0) R.sol[cnt] = (uint32_t)__builtin_amdgcn_readlane((int)row, u);
+                const uint32_t row_u = (uint32_t)__builtin_amdgcn_readlane((int)row, u);   // (cross-lane reads stay outside divergent blocks)
+                if (lane == 0) R.sol[cnt] = row_u;
                 cnt++;
                 u = __builtin_amdgcn_readlane(jp, u);
             }

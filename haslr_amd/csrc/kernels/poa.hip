@@ -331,49 +331,60 @@ __device__ bool add_alignment(G& g, uint32_t& V, uint32_t& E, uint32_t n_aln, co
 // a register (ds_bpermute). The fold "take the edge if it is heavier, or as heavy and its source scores at least as much" (spoa's <=: the later
 // in-edge wins a tie) is the maximum of (weight, source score, position in the in-edge list), so the two halves can be folded in any order.
 // Returns the consensus length, or NONE when the heaviest node is not a unique sink (the caller then sorts the graph the reference's way).
-__device__ uint32_t consensus_fast_wave(G& g, const uint32_t V, char* out) {
+// One forward pass over the ranks [r_begin, V) of the rank-ordered rows, by one wavefront. `restricted` = the pass of spoa's branch completion:
+// in-edges from nodes whose score is -1 do not count. Returns through best / nbest the first rank whose score exceeds `floor_score` and every
+// later maximum (strictly greater moves it, equal counts it).
+__device__ void bundle_pass(G& g, const uint32_t V, const uint32_t r_begin, const bool restricted, const int32_t floor_score, uint32_t& best, uint32_t& nbest) {
     const uint32_t lane = threadIdx.x & 63u;
     int32_t* sc_r = g.score;          // by rank
     int32_t* pr_r = g.pred;           // by rank: rank of the chosen predecessor, -1 = none
-    uint32_t best = NONE, nbest = 0;
-    int32_t bscore = 0;
-    for (uint32_t r0 = 0; r0 < V; r0 += 64) {
+    best = NONE; nbest = 0;
+    int32_t bscore = floor_score;
+    for (uint32_t r0 = r_begin & ~63u; r0 < V; r0 += 64) {
         const uint32_t r = r0 + lane;
-        const bool valid = r < V;
+        const uint32_t lim = max(r0, r_begin);                  // predecessors below this rank are final: their scores come from memory
+        const bool valid = r < V && r >= r_begin;
         const uint32_t np = valid ? g.row_meta[r] >> META_NP : 0u, off = valid ? g.row_pred_off[r] : 0u;
         // the first four in-edges in registers (rank, weight); more than four: the list is walked again where needed (rare)
         uint32_t ep[4]; int32_t ew[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) { ep[k] = (uint32_t)k < np ? g.pred_rank[off + k] & 0x0fffffffu : NONE; ew[k] = (uint32_t)k < np ? g.pred_w[off + k] : 0; }
         int32_t bw = -1, bs = 0, bp = -1; uint32_t bk = 0;     // best candidate so far: weight, its source's score, its source's rank, its position
-        auto take = [&](int32_t w, int32_t s, uint32_t p, uint32_t k) { if (w > bw || (w == bw && (s > bs || (s == bs && k >= bk)))) { bw = w; bs = s; bp = (int32_t)p; bk = k; } };
+        auto take = [&](int32_t w, int32_t s, uint32_t p, uint32_t k) {
+            if (restricted && s == -1) return;
+            if (w > bw || (w == bw && (s > bs || (s == bs && k >= bk)))) { bw = w; bs = s; bp = (int32_t)p; bk = k; }
+        };
         for (uint32_t k = 0; k < np; k++) {                     // predecessors before the chunk
             const uint32_t p = k < 4 ? ep[k] : g.pred_rank[off + k] & 0x0fffffffu;
-            if (p < r0) take(k < 4 ? ew[k] : g.pred_w[off + k], sc_r[p], p, k);
+            if (p < lim) take(k < 4 ? ew[k] : g.pred_w[off + k], sc_r[p], p, k);
         }
         int32_t sc = -1;
-        const uint32_t nv = min(64u, V - r0);
-        for (uint32_t l = 0; l < nv; l++) {                     // the chunk, rank by rank (wave-uniform loop; lane l is the one that finishes)
+        const uint32_t l0 = lim - r0, nv = min(64u, V - r0);
+        for (uint32_t l = l0; l < nv; l++) {                    // the chunk, rank by rank (wave-uniform loop; lane l is the one that finishes)
             const uint32_t npl = (uint32_t)__builtin_amdgcn_readlane((int)np, (int)l);
             for (uint32_t k = 0; k < npl; k++) {
                 uint32_t p = NONE; int32_t w = 0;
                 if (lane == l) { p = k < 4 ? ep[k < 4 ? k : 0] : g.pred_rank[off + k] & 0x0fffffffu; w = k < 4 ? ew[k < 4 ? k : 0] : g.pred_w[off + k]; }
-                const bool inside = lane == l && p >= r0 && p != NONE;
+                const bool inside = lane == l && p >= lim && p != NONE;
                 const int32_t s = __shfl(sc, inside ? (int)(p - r0) : 0);   // (every lane takes part in the exchange)
                 if (inside) take(w, s, p, k);
             }
             if (lane == l) sc = bp == -1 ? -1 : bw + bs;
             const int32_t sl = __builtin_amdgcn_readlane(sc, (int)l);
-            if (best == NONE || sl > bscore) { best = r0 + l; bscore = sl; nbest = 1; }
+            if (sl > bscore) { best = r0 + l; bscore = sl; nbest = 1; }
             else if (sl == bscore) nbest++;
         }
         if (valid) { sc_r[r] = sc; pr_r[r] = bp; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    if (nbest != 1 || !(g.row_meta[best] & 4u)) return NONE;    // (bit 2 of a row record: the node has no out-edge)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// the walk back from rank `best` along the chosen predecessors; lane 0 writes, every lane gets the length
+__device__ uint32_t bundle_backtrack(G& g, const uint32_t best, char* out) {
+    const int32_t* pr_r = g.pred;
     uint32_t len = 0;
-    if (lane == 0) {
+    if ((threadIdx.x & 63u) == 0) {
         for (int32_t r = (int32_t)best; r != -1; r = pr_r[r]) len++;
         uint32_t w = len;
         for (int32_t r = (int32_t)best; r != -1; r = pr_r[r]) out[--w] = "ACGT"[g.row_meta[r] & 3u];
@@ -381,43 +392,34 @@ __device__ uint32_t consensus_fast_wave(G& g, const uint32_t V, char* out) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
 }
 
-// spoa Graph::traverse_heaviest_bundle + branch_completion; lane 0 only. Writes the consensus, returns its length.
-__device__ uint32_t consensus(G& g, uint32_t V, char* out) {
-    for (uint32_t i = 0; i < V; i++) { g.pred[i] = -1; g.score[i] = -1; }
-    uint32_t best = 0;
-    for (uint32_t r = 0; r < V; r++) {
-        uint32_t n = g.rank2node[r];
-        for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) {
-            uint32_t f = g.e_from[e]; int32_t w = g.e_w[e];
-            if (g.score[n] < w || (g.score[n] == w && g.score[g.pred[n]] <= g.score[f])) { g.score[n] = w; g.pred[n] = (int32_t)f; }
-        }
-        if (g.pred[n] != -1) g.score[n] += g.score[g.pred[n]];
-        if (g.score[best] < g.score[n]) best = n;
+__device__ uint32_t consensus_fast_wave(G& g, const uint32_t V, char* out) {
+    uint32_t best, nbest;
+    bundle_pass(g, V, 0, false, -2, best, nbest);               // (every score is >= -1: the first rank opens the maximum)
+    if (best == NONE || nbest != 1 || !(g.row_meta[best] & 4u)) return NONE;    // (bit 2 of a row record: the node has no out-edge)
+    return bundle_backtrack(g, best, out);
+}
+
+// spoa Graph::traverse_heaviest_bundle + branch_completion on the REFERENCE's topological order (rank2node / node2rank hold it, the rank-ordered
+// rows have been rebuilt for it: k_poa's bundle_rows), by one wavefront. The reference starts with best = node 0 and moves it to every node that
+// scores strictly more, in rank order; its branch completion does the same from (0, node 0).
+__device__ uint32_t consensus_wave(G& g, const uint32_t V, char* out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t best, nbest;
+    bundle_pass(g, V, 0, false, -1, best, nbest);
+    if (best == NONE) best = g.node2rank[0];
+    for (uint32_t round = 0; !(g.row_meta[best] & 4u) && round <= V; round++) {   // branch completion (the bound only guards against a cycle the reference would hang in)
+        const uint32_t n0 = g.rank2node[best];
+        if (lane == 0)
+            for (uint32_t e = g.out_head[n0]; e != NONE; e = g.e_next_out[e])
+                for (uint32_t oe = g.in_head[g.e_to[e]]; oe != NONE; oe = g.e_next_in[oe])
+                    if (g.e_from[oe] != n0) g.score[g.node2rank[g.e_from[oe]]] = -1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        uint32_t nb;
+        bundle_pass(g, V, best + 1, true, 0, nb, nbest);
+        best = nb == NONE ? g.node2rank[0] : nb;
     }
-    while (g.out_head[best] != NONE) {   // branch completion
-        uint32_t n0 = best;
-        for (uint32_t e = g.out_head[n0]; e != NONE; e = g.e_next_out[e])
-            for (uint32_t oe = g.in_head[g.e_to[e]]; oe != NONE; oe = g.e_next_in[oe])
-                if (g.e_from[oe] != n0) g.score[g.e_from[oe]] = -1;
-        int32_t mx = 0; uint32_t mxid = 0;
-        for (uint32_t r = g.node2rank[n0] + 1; r < V; r++) {
-            uint32_t n = g.rank2node[r];
-            g.score[n] = -1; g.pred[n] = -1;
-            for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) {
-                uint32_t f = g.e_from[e]; int32_t w = g.e_w[e];
-                if (g.score[f] == -1) continue;
-                if (g.score[n] < w || (g.score[n] == w && g.score[g.pred[n]] <= g.score[f])) { g.score[n] = w; g.pred[n] = (int32_t)f; }
-            }
-            if (g.pred[n] != -1) g.score[n] += g.score[g.pred[n]];
-            if (mx < g.score[n]) { mx = g.score[n]; mxid = n; }
-        }
-        best = mxid;
-    }
-    uint32_t len = 0;
-    for (uint32_t n = best;; n = (uint32_t)g.pred[n]) { len++; if (g.pred[n] == -1) break; }
-    uint32_t w = len;
-    for (uint32_t n = best;; n = (uint32_t)g.pred[n]) { out[--w] = "ACGT"[g.code[n]]; if (g.pred[n] == -1) break; }
-    return len;
+    return bundle_backtrack(g, best, out);
 }
 
 __device__ __forceinline__ int block_excl_scan_max(int v, int* lds /* blockDim/64 */) {
@@ -728,7 +730,8 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
 #pragma unroll
             for (int k = 0; k < CM; k++) hp[k] = jg0 + k * g64;
             left = gt > 0 ? jg0 - g64 : NEGK;
-        } else if (live) {                       // kept row that fell out of the ring: HBM
+        } else if (live
+                   ) {                       // kept row that fell out of the ring: HBM
             // with direction bytes only the rows a far successor reads are in HBM, in the slots the CSR build gave them
             const uint32_t hr = DIR ? (slot_known ? ent & 0x0fffffffu : farslot[ent & 0x0fffffffu]) : (ent & 0x0fffffffu) + 1;
             const int32_t* Gp = H + (uint64_t)hr * WH + j0;
@@ -882,8 +885,12 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 DP_T(5);   // stores
                 if (__builtin_expect((meta & (8u | 4u)) != 0, 0)) {
                     if (meta & 8u) {   // a far successor reads this row back from HBM (keys; with the score matrix it is there already)
-                        if (DIR && live) {
-                            int32_t* F = H + (uint64_t)__builtin_amdgcn_readlane(fC, ri) * WH;
+                        // (the slot is read out of its lane HERE, where every lane is active: inside the divergent block below a register
+                        // that was spilled is reloaded for the active lanes only, and lane ri need not be one of them)
+                        const uint32_t fslot = DIR ? __builtin_amdgcn_readlane(fC, ri) : 0u;
+                        if (DIR && live
+                            ) {
+                            int32_t* F = H + (uint64_t)fslot * WH;
                             store_chunk_i32<CM>(F + j0, t);
                             if (lane == 0 && has_in) F[hleft] = left_now;
                         }
@@ -1211,7 +1218,12 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                                 pv = ((uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[(uint32_t)__builtin_amdgcn_readlane((int)qo, (int)dr) + slot]) & 0x0fffffffu) + 1;
                             {
                                 const int el = (int)(na & 63u);
-                                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0" : "+v"(pn), "+v"(pp) : "s"(el), "s"(i), "s"(j) : "m0");
+                                // (M0 is saved and restored around the two v_writelane: the compiler reserves it - an earlier version that listed it as a
+                                //  clobber broke the one kernel instance that spills heavily, k_poa<1024, 32, true>: memory faults / wrong consensus for
+                                //  gaps above 16 383 columns in ONE workgroup, found by the round-3 fuzz)
+                                int m0_keep;
+                                asm volatile("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\ts_mov_b32 m0, %2"
+                                             : "+v"(pn), "+v"(pp), "=&s"(m0_keep) : "s"(el), "s"(i), "s"(j));
                             }
                             na++;
                             if (type != 1u) i = pv;
@@ -1560,6 +1572,25 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
             exact_order(sV, g.rank2node);
             for (uint32_t r = tid; r < sV; r += NT) g.node2rank[g.rank2node[r]] = r;
             __syncthreads();
+            {   // bundle_rows: the rank-ordered in-edge rows (predecessor ranks, weights, letter, sink flag) of THIS order, all lanes
+                const uint32_t V2 = sV, CH = (V2 + NT - 1) / NT, r0 = min(tid * CH, V2), r1 = min(r0 + CH, V2);
+                uint32_t cnt = 0;
+                for (uint32_t r = r0; r < r1; r++) for (uint32_t e = g.in_head[g.rank2node[r]]; e != NONE; e = g.e_next_in[e]) cnt++;
+                uint32_t tot;
+                uint32_t off = block_excl_scan_add(cnt, lds_u, &tot);
+                for (uint32_t r = r0; r < r1; r++) {
+                    const uint32_t n = g.rank2node[r];
+                    g.row_pred_off[r] = off;
+                    uint32_t np = 0;
+                    for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) { g.pred_rank[off] = g.node2rank[g.e_from[e]]; g.pred_w[off] = g.e_w[e]; off++; np++; }
+                    g.row_meta[r] = (uint32_t)g.code[n] | (g.out_head[n] == NONE ? 4u : 0u) | (np << META_NP);
+                }
+                if (tid == NT - 1) g.row_pred_off[V2] = tot;
+                __threadfence_block();
+                __syncthreads();
+            }
+            if (tid < 64) { const uint32_t cl_ = consensus_wave(g, sV, cns + ED.cns_off); if (tid == 0) sCtl = cl_; }
+            __syncthreads();
         }
     }
     if (tid == 0) {
@@ -1571,7 +1602,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
         else if (sOk == 7) { status[eidx] = HXE_POA_WIDEROWS; cns_len[eidx] = 0; }
         else if (sOk == 8) { status[eidx] = HXE_POA_STALLED; cns_len[eidx] = 0; }
         else {
-            status[eidx] = 0; cns_len[eidx] = !sV ? 0 : sCtl != NONE ? sCtl : consensus(g, sV, cns + ED.cns_off); atomicAdd(cells, sCells);
+            status[eidx] = 0; cns_len[eidx] = !sV ? 0 : sCtl; atomicAdd(cells, sCells);
 #ifndef HX_DP_PROF
             if (phase) atomicAdd(&ph[11], (unsigned long long)sV << 32);   // statistics: nodes of the finished graph (high word)
 #endif

@@ -17,6 +17,7 @@ record source as an object with emit() / export(buffer) / import_(buffer, n, out
 drive exactly this code over gloo with the test oracle in place of the HIP context.
 """
 import ctypes as C
+import time
 
 import numpy as np
 import torch
@@ -115,6 +116,7 @@ class ShardedBackend:
         self._cb = proto(self._edge_support)
         self.table.edge_support = C.cast(self._cb, C.c_void_p).value
         self.exchange_bytes = 0
+        self.exchange_ms = 0.0
         self.error = None
 
     def _edge_support(self, _ctx, _prm, out):
@@ -126,7 +128,11 @@ class ShardedBackend:
             except Exception as e:  # noqa: BLE001
                 self.error = e
             agree(local is not None, getattr(self.records, "comm_device", torch.device("cpu")), self.group, "edge-record emission")   # before the all-gather: all or nobody
+            t0 = time.perf_counter()
             merged, total = allgather_records(local, n, self.records.rec_bytes, self.group)
+            if merged.is_cuda:
+                torch.cuda.synchronize()
+            self.exchange_ms = (time.perf_counter() - t0) * 1e3       # counts exchange + the padded all-gather of the records (+ the cut of the padding)
             self.exchange_bytes = total * self.records.rec_bytes
             return self.records.import_(merged, total, out)
         except Exception as e:  # noqa: BLE001 - must not propagate through the C callback

@@ -718,3 +718,43 @@ def test_gap_longer_than_65535_columns(ctx):
     assert got[0] == a and got[1] == a[:300]
     with pytest.raises(hip.HipError, match="longer than the POA kernel"):
         ctx.poa_sequences([["A" * 140000, "A" * 140000]])
+
+
+@pytest.mark.parametrize("length,force_cm", [(3000, "32"), (17000, None)])
+def test_one_workgroup_with_32_columns_per_lane(ctx, length, force_cm):
+    """the 1024-lane, 32-columns-per-lane kernel on a BRANCHED graph (noisy copies: kept rows that leave the ring are read back from HBM):
+    gaps of 16 384 to 32 767 columns in one workgroup reach it (forced here with the block size; HX_POA_FORCE_CM reaches it at any length).
+    Its row loop spills registers; a cross-lane read of a row record inside a divergent block once picked up a lane the reload had skipped
+    (round 3: wrong far-row slot -> wrong consensus or a memory fault) - found by tools/dev_fuzz.py, kept here."""
+    import random
+    rnd = random.Random(7 + length)
+
+    def noisy(t, ins=0.06, dele=0.04, sub=0.03):
+        out = []
+        for ch in t:
+            r = rnd.random()
+            if r < dele:
+                continue
+            out.append(rnd.choice("ACGT") if r < dele + sub else ch)
+            while rnd.random() < ins:
+                out.append(rnd.choice("ACGT"))
+        return "".join(out)
+
+    tmpl = "".join(rnd.choice("ACGT") for _ in range(length))
+    groups = [[noisy(tmpl) for _ in range(n)] for n in (3, 5)]
+    want = [orclib.poa_consensus(g) for g in groups]
+    old = os.environ.get("HX_POA_FORCE_CM")
+    try:
+        if force_cm:
+            os.environ["HX_POA_FORCE_CM"] = force_cm
+        for dirb in (1, 0):
+            ctx.set_poa_block(1024)
+            hip.lib().hx_set_poa_traceback(ctx._h, dirb)
+            assert ctx.poa_sequences(groups) == want, "traceback flavour %d" % dirb
+    finally:
+        ctx.set_poa_block(0)
+        hip.lib().hx_set_poa_traceback(ctx._h, 1)
+        if old is None:
+            os.environ.pop("HX_POA_FORCE_CM", None)
+        else:
+            os.environ["HX_POA_FORCE_CM"] = old

@@ -15,7 +15,7 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = hip.HipContext(0)
 os.makedirs('/tmp/fz', exist_ok=True)
 bad = 0
-KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS', 'HX_POA_BATCHES', 'HX_POA_NODE_EST_PCT', 'HX_POA_RING_KB', 'HX_POA_COLS', 'HX_POA_CLUSTER_TOPK', 'HX_POA_SLOTS', 'HX_POA_WORKSPACE_GB')
+KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS', 'HX_POA_BATCHES', 'HX_POA_NODE_EST_PCT', 'HX_POA_RING_KB', 'HX_POA_COLS', 'HX_POA_CLUSTER_TOPK', 'HX_POA_SLOTS', 'HX_POA_WORKSPACE_GB', 'HX_POA_FORCE_CM', 'HX_POA_RING_ZERO')
 for it in range(n):
     big = os.environ.get('FUZZ_BIG') is not None   # long gaps at real sizes: the default launch shapes (512-lane cluster members) get real work
     glen = rng.choice([400000, 700000, 1000000]) if big else rng.choice([40000, 60000, 90000, 150000, 250000])
@@ -50,6 +50,10 @@ for it in range(n):
         env['HX_POA_SLOTS'] = str(rng.choice([1, 2, 3, 7]))          # persistent workgroups: a few workspace slots per launch class, many edges each (round 3)
     if rng.random() < 0.15:
         env['HX_POA_WORKSPACE_GB'] = str(rng.choice([1, 2, 4]))   # a small workspace cap: fewer slots, or several batches
+    if rng.random() < 0.2:
+        env['HX_POA_FORCE_CM'] = str(rng.choice([16, 32]))          # a wider kernel instance than the gap lengths ask for (spill-heavy row loops)
+    if rng.random() < 0.1:
+        env['HX_POA_RING_ZERO'] = '1'                               # no LDS ring: every kept row is read back from HBM
     if rng.random() < 0.25:
         env['HX_POA_NODE_EST_PCT'] = str(rng.choice([2, 10, 30, 60]))
     os.environ.update(env)
@@ -61,7 +65,16 @@ for it in range(n):
     ro.all()
     ctx.upload(ds)
     rg = host.Run(ds, ds.params(**pk), ctx.backend(), None)
-    rg.all()
+    try:
+        rg.all()
+    except host.HostError as e:
+        if 'HX_POA_WORKSPACE_GB' not in os.environ or 'more POA workspace' not in str(e):
+            raise
+        print(it, 'workspace cap too small for the largest edge (loud error, as it should be): again without the cap', flush=True)
+        os.environ.pop('HX_POA_WORKSPACE_GB')
+        rg.close()
+        rg = host.Run(ds, ds.params(**pk), ctx.backend(), None)
+        rg.all()
     ok = ro.cns_out() == rg.cns_out() and ro.assembly_fasta() == rg.assembly_fasta()
     print(it, 'OK' if ok else 'DIFF', ' '.join(args[:-2]), shape, env, 'edges', rg.n_edges, flush=True)
     bad += not ok
