@@ -717,7 +717,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     for (int k = 0; k < CM; k++) tp[k] = NEGK;
     auto pred_row = [&](const uint32_t ent, int (&hp)[CM], int& left, const bool slot_known) {
         const uint32_t loc = ent >> 28;
-        if (loc == 13u) {                        // the previous row: registers
+        if (__builtin_expect(loc == 13u, 1)) {   // the previous row: registers (the likely case falls through: a taken scalar branch costs a lone wave ~35 cycles)
 #pragma unroll
             for (int k = 0; k < CM; k++) hp[k] = tp[k];
             left = wave_shift_up1(tp[CM - 1], lnp);
@@ -818,7 +818,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
 #pragma unroll
                     for (int k = 0; k < CM; k++) m[k] = max((k == 0 ? left : hp[k - 1]) + score_of(k), hp[k] + gv);
                 }
-                if (npred > 1) {
+                if (__builtin_expect(npred > 1, 0)) {
                     // the maximum over the predecessors: the low bits carry the move type and 15 - p, so ONE running maximum does it all
                     // (a diagonal beats a vertical move of the same score, the first predecessor in in-edge order beats the later ones)
                     const uint32_t po = __builtin_amdgcn_readlane(oC, ri);
