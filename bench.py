@@ -114,16 +114,19 @@ def cpu_baseline(ds, gpu_cns, gpu_gfa=None, work_dir=None):
                     "spoa's engine would use int16 lanes where scores fit"}
 
 
-def measure(ctx, ds, prm, table, steps, warmup, world, rank, sync, gather, lr_begin):
+def measure(ctx, ds, prm, table, steps, warmup, world, rank, sync, gather, lr_begin, sharded=None):
     """`warmup` untimed + `steps` timed passes; returns (seconds, last run)."""
     from haslr_amd import host
 
+    if sharded is None:
+        sharded = world > 1
+
     def step():
         run = host.Run(ds, prm, table, None)
-        if world > 1:
+        if sharded:
             run.set_edge_shard(rank, world)
             run.set_read_shard(lr_begin)
-        if world > 1:
+        if sharded:
             gather(run)                            # chain -> merged graph -> coords -> consensus -> results gathered; the ranks agree on success before every collective
         else:
             run.chain(); run.graph(); run.coords(); run.consensus()
@@ -165,6 +168,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # HASLR_BENCH_FORCE_DIST=1 (testing): the N>1 code path - process group, record all-gather, results exchange - with whatever world size the launcher
+    # gave, also 1: a one-GPU box then executes the RCCL collectives of the multi-GPU path for real
+    dist_on = world > 1 or os.environ.get("HASLR_BENCH_FORCE_DIST") == "1"
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
@@ -177,7 +183,7 @@ def main():
     comm_device = torch.device("cpu") if backend_name == "gloo" else device
     torch.zeros(1, device="cuda")   # initialise torch's HIP context (streams, queues) now, not inside the timed region
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend_name == "gloo":
             dist.init_process_group("gloo")
@@ -191,7 +197,7 @@ def main():
     glen = args.genome_len or (wl["genome"] if as_named else wl["genome"] * world)
     if rank == 0:
         make_dataset(wl, glen, "gpu")
-    if world > 1:
+    if dist_on:
         dist.barrier()
     pre = make_dataset(wl, glen, "gpu")
     t0 = time.perf_counter()
@@ -208,7 +214,7 @@ def main():
     log(f"[rank {rank}] dataset {pre}: {ds.reads.n} reads, {ds.total_read_bases} bases, {ds.hits.n} PAF records; parse {t_parse:.2f} s ({in_bytes / 1e6 / t_parse:.0f} MB/s), upload {t_upload:.2f} s")
 
     lr_begin, gathered = 0, [0]
-    if world > 1:
+    if dist_on:
         from haslr_amd import distributed as hd
         b = hd.shard_bounds(ds.read_hit_off, ds.reads.n, world)
         ctx.set_read_shard(b[rank], b[rank + 1])
@@ -223,12 +229,12 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
-    dt, last = measure(ctx, ds, prm, table, args.steps, args.warmup, world, rank, sync, gather, lr_begin)
-    if world > 1:
+    dt, last = measure(ctx, ds, prm, table, args.steps, args.warmup, world, rank, sync, gather, lr_begin, sharded=dist_on)
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -241,7 +247,7 @@ def main():
     alg_bytes = (st["seq_bases"] + 3) // 4 + sum(len(c) for c in cns)   # 2-bit gap bases read once + consensus written once
     stats = torch.tensor([st["dp_cells"], st["seq_bases"], alg_bytes, last.n_edges], dtype=torch.float64, device=comm_device)
     tms = torch.tensor([poa_ms], dtype=torch.float64, device=comm_device)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(stats)
         dist.all_reduce(tms, op=dist.ReduceOp.MAX)
     cells, seq_bases, alg_bytes, n_edges = [float(x) for x in stats.tolist()]
@@ -256,7 +262,7 @@ def main():
     fasta = last.assembly_fasta()
     sha = hashlib.sha256(fasta.encode()).hexdigest()
     assembly = {"sha256": sha, "contigs": fasta.count(">"), "bases": sum(len(x) for x in fasta.split("\n") if x and x[0] != ">")}
-    if world > 1:
+    if dist_on:
         h = torch.frombuffer(bytearray(bytes.fromhex(sha)), dtype=torch.uint8).to(comm_device)
         hs = [torch.zeros(32, dtype=torch.uint8, device=comm_device) for _ in range(world)]
         dist.all_gather(hs, h)
@@ -377,7 +383,7 @@ def main():
         print(json.dumps(line), flush=True)
     if last is not None:
         last.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
