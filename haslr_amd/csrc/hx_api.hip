@@ -608,6 +608,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     const uint32_t cl_max = getenv("HX_POA_CLUSTER_MAX") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MAX")) : 16;                              // members per edge at most
     const uint32_t cl_pref = getenv("HX_POA_CLUSTER_MAX") ? cl_max : many_edges_in ? 8 : 16;                                                  // ... unless the gap needs more to fit at all
     const uint32_t cl_topk = getenv("HX_POA_CLUSTER_TOPK") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_TOPK")) : many_edges_in ? 32 : 192;    // shared edges per call at most (the costliest)
+    const uint32_t wide_k = getenv("HX_POA_WIDE_MEMBERS") ? (uint32_t)atoi(getenv("HX_POA_WIDE_MEMBERS")) : many_edges_in ? 0 : 4;   // shared edges per call (the costliest) whose members are 1024-lane workgroups
     const uint32_t cl_cols = getenv("HX_POA_CLUSTER_COLS") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_COLS")) : 4;            // columns per lane a member aims at
     const uint64_t est_pct = getenv("HX_POA_NODE_EST_PCT") ? (uint64_t)std::max(1L, atol(getenv("HX_POA_NODE_EST_PCT"))) : 100;   // (testing: scales the node estimate)
     const long far_rows = getenv("HX_POA_FAR_ROWS") ? atol(getenv("HX_POA_FAR_ROWS")) : -1;   // (testing: rows of H per edge on the first attempt)
@@ -734,14 +735,15 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
         auto need_bytes = [](const Need& n) -> uint64_t { return n.nn * 90 + n.ec * 28 + n.hc * 4 + n.dc + n.wc + n.lm + n.st * 4 + n.al * 8; };
         // launch classes: (shared?, lanes per workgroup, columns per lane, traceback flavour) - one kernel instance each, so that every
         // launch runs with the registers ITS row loop needs (kernels/poa.hip)
-        struct Cls { bool shared; uint32_t nt, cm; bool dir; std::vector<uint32_t> edges; size_t blocks = 0, order_at = 0, slot_at = 0, n_slots = 0; Need need{}; bool persistent = false; };
+        struct Cls { bool shared; uint32_t nt, cm; bool dir; uint32_t dpl = 0 /* lanes in the DP when the workgroups are wider (wide cluster members), else 0 */; std::vector<uint32_t> edges; size_t blocks = 0, order_at = 0, slot_at = 0, n_slots = 0; Need need{}; bool persistent = false; };
         auto build_classes = [&](const std::vector<uint32_t>& batch, std::vector<Cls>& classes) -> int {
             classes.clear();
-            auto cls_of = [&](bool shared, uint32_t nt, uint32_t cm, bool dir) -> Cls& {
-                for (Cls& q : classes) if (q.shared == shared && q.nt == nt && q.cm == cm && q.dir == dir) return q;
-                classes.push_back(Cls{shared, nt, cm, dir, {}});
+            auto cls_of = [&](bool shared, uint32_t nt, uint32_t cm, bool dir, uint32_t dpl = 0) -> Cls& {
+                for (Cls& q : classes) if (q.shared == shared && q.nt == nt && q.cm == cm && q.dir == dir && q.dpl == dpl) return q;
+                classes.push_back(Cls{shared, nt, cm, dir, dpl, {}});
                 return classes.back();
             };
+            uint32_t n_wide = 0;
             for (uint32_t e : batch) {
                 const uint32_t ncol = P.edges[e].lmax + 1;
                 // widest row: the shared mode (members x lanes x columns per lane), or one 1024-lane workgroup when the members were made small
@@ -752,6 +754,10 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                 if (P.edges[e].members > 1) {
                     const uint32_t cmr = cm_round(ncol, P.edges[e].members * cl_lanes);
                     if (cmr > (uint32_t)hxk::poa_kernel_max_cm((int)cl_lanes)) return fail("hx_poa_batch: gap too long for the configured cluster size (raise HX_POA_CLUSTER_MAX)");
+                    // the costliest shared edges run with WIDE members: workgroups of 1024 lanes of which the first cl_lanes take part in the DP (one
+                    // wave per SIMD, as before) and all sixteen waves in the graph phases of member 0 (graph update, CSR build, orders: latency-bound
+                    // loops over the nodes that want lanes). Such a workgroup has a CU to itself, so only a few edges get them.
+                    if (n_wide < wide_k && cl_lanes < 1024 && cmr <= 8) { n_wide++; cls_of(true, 1024, cmr, true, cl_lanes).edges.push_back(e); continue; }
                     cls_of(true, cl_lanes, cmr, true).edges.push_back(e);   // batch is cost-sorted, so every class list is too
                     continue;
                 }
@@ -930,7 +936,8 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                 const int sk = (int)(ci % n_streams);   // stream / event of the launch (launches that share a stream run one after the other)
                 // LDS of the launch: the ring its row width allows, a power of two of kept rows
                 uint64_t ring_need = 0;
-                const uint32_t R = ring_rows_of(q.nt, q.cm, ring_need);
+                const uint32_t dp_nt = q.dpl ? q.dpl : q.nt;   // lanes in the DP
+                const uint32_t R = ring_rows_of(dp_nt, q.cm, ring_need);
                 // few edges: ask for enough LDS per workgroup that the dispatcher cannot stack them on a handful of CUs while others idle
                 // (a lone wave runs at twice the speed of two waves sharing a SIMD); many edges: request only what the ring needs
                 uint64_t lds_bytes = ring_need;
@@ -939,7 +946,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                     if (per_cu < 8) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(kPoaLdsMax, (158 * 1024) / per_cu - 18 * 1024));
                     // hundreds of edges: the longest ones set the duration, and their waves run faster with two neighbours on a SIMD than with
                     // three - 10 KB of LDS per wave keeps a CU at 12 waves (thousands of edges: 16, the ring alone is 8.3 KB per wave)
-                    if (!many_edges) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(kPoaLdsMax, 10 * 1024 * (uint64_t)(q.nt / 64)));
+                    if (!many_edges) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(kPoaLdsMax, 10 * 1024 * (uint64_t)(dp_nt / 64)));
                     if (getenv("HX_POA_RING_ZERO")) lds_bytes = ring_need;   // (one row's worth: the kernel then finds room for no kept row either)
                 }
                 const int dcls = q.shared ? 0 : q.nt >= 1024 ? 1 : q.nt >= 512 ? 2 : q.nt >= 256 ? 3 : q.nt >= 128 ? 4 : 5;
@@ -948,9 +955,17 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                 HIPCHK(hipStreamWaitEvent(c->poa_streams[sk], c->poa_ev[8], 0));
                 hxk::poa_run(d_edges.p, d_order.p + q.order_at, q.persistent ? (uint32_t)q.edges.size() : (uint32_t)q.blocks, c->poa_slots.p + (q.persistent ? q.slot_at : 0), q.persistent ? c->poa_counters.p + ci : nullptr,
                              (uint32_t)q.blocks, d_seqs.p, in.d_packed, in.d_roff, in.d_rlen, pools, pp->match, pp->mismatch,
-                             pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)q.nt, (int)q.cm, poll_limit, (uint32_t)lds_bytes, q.dir, max_indeg, c->poa_streams[sk]);
+                             pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)q.nt, (int)q.cm, poll_limit, (uint32_t)lds_bytes, q.dir, max_indeg, q.dpl, c->poa_streams[sk]);
                 HIPCHK(hipEventRecord(c->poa_ev[sk], c->poa_streams[sk]));
                 HIPCHK(hipStreamWaitEvent(s, c->poa_ev[sk], 0));
+                if (q.dpl) {
+                    // a 1024-lane workgroup needs an EMPTY CU: give the dispatcher a head start before the other launches fill the chip with small
+                    // workgroups (once they have, a CU only empties when its longest resident workgroup ends)
+                    static const int wide_us = getenv("HX_POA_WIDE_DELAY_US") ? atoi(getenv("HX_POA_WIDE_DELAY_US")) : 60;
+                    HIPCHK(hipEventSynchronize(c->poa_ev[8]));   // (what precedes the launches on `s` is done: the wide launch is starting)
+                    const auto t0 = std::chrono::steady_clock::now();
+                    while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < wide_us) { }
+                }
                 ci++;
             }
             c->tock(3);

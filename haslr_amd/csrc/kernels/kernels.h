@@ -145,7 +145,7 @@ void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_items, cons
              unsigned long long* cells, unsigned long long* phase_cycles /* 12 per edge or null */, int block_threads /* multiple of 64, <= 1024 */,
              int cm /* columns per lane of the launch: 4, 8, 16 or 32; every edge's longest sequence fits members x block_threads x cm columns */,
              uint32_t poll_limit /* polls before a wave gives up waiting for another (-> HXE_POA_STALLED) */, uint32_t ring_bytes /* dynamic LDS */,
-             bool use_dir /* direction-byte traceback (in-degrees <= max_indeg <= 16, else the edge comes back with HXE_POA_NODIR) */, uint32_t max_indeg, hipStream_t s);
+             bool use_dir /* direction-byte traceback (in-degrees <= max_indeg <= 16, else the edge comes back with HXE_POA_NODIR) */, uint32_t max_indeg, uint32_t dp_lanes /* 0: every lane of the workgroup; else the lanes that take part in the DP (a wide cluster member) */, hipStream_t s);
 
 }  // namespace hxk
 #endif

@@ -543,6 +543,7 @@ struct DpCl {
     unsigned long long* mbox;         // edge base
     uint32_t* err;                    // device-visible error word of the edge (set when a poll gives up)
     uint32_t poll_limit;              // polls before a waiter gives up and flags the edge instead of hanging the GPU (the host then redoes it unshared)
+    uint32_t lanes;                   // lanes of the workgroup that take part in the DP (a "wide" member has more: they work in the graph phases only)
 };
 __device__ __forceinline__ uint32_t ld_dev(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_dev(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -635,7 +636,8 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     // registers they turn the loop control, the ring slot arithmetic and the carry hand-over into scalar instructions and branches
     const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)L_), V = (uint32_t)__builtin_amdgcn_readfirstlane((int)V_);
     const uint32_t R = (uint32_t)__builtin_amdgcn_readfirstlane((int)R_), ring_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)ring_w_);
-    const uint32_t tid = threadIdx.x, NT = blockDim.x, lane = tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), NW = NT >> 6;
+    const uint32_t tid = threadIdx.x, NT = blockDim.x, lane = tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), NW = cl.lanes >> 6;
+    if (wv >= NW) return;                                                     // (a wave of a wide member that sits the DP out)
     const uint32_t ncol = L + 1;
     const uint32_t gw = cl.mem * NW + wv;                                     // this wave's place in the edge's pipeline
     if ((uint64_t)gw * 64u * CM >= ncol) return;                              // the wave owns no real column of this sequence
@@ -918,7 +920,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                                          const PoaSeq* __restrict__ seqs, const uint8_t* __restrict__ packed, const uint64_t* __restrict__ read_off,
                                          const uint32_t* __restrict__ read_len, const PoaPools& P, int32_t match, int32_t mismatch, int32_t gap,
                                          char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells, unsigned long long* phase,
-                                         uint32_t poll_limit, uint32_t lds_bytes, uint32_t max_indeg) {
+                                         uint32_t poll_limit, uint32_t lds_bytes, uint32_t max_indeg, uint32_t dp_lanes) {
     __shared__ unsigned long long ph[12];            // lane-0 cycle counts: decode, dp, traceback, graph update, toposort, csr; then row statistics
     __shared__ long long tc;
     if (threadIdx.x == 0) { for (int k = 0; k < 12; k++) ph[k] = 0; tc = clock64(); }
@@ -933,6 +935,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
 #endif
     const PoaEdge ED = edges[eidx];
     const uint32_t tid = threadIdx.x, NT = blockDim.x;
+    const uint32_t DL = dp_lanes ? dp_lanes : NT;   // lanes in the DP: the whole workgroup, or the first waves of a "wide" cluster member (one wave per SIMD in the DP, sixteen in the graph phases)
     extern __shared__ int32_t ring[];
     G g;
     {
@@ -952,7 +955,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     uint8_t* Dw = DIR ? P.dirw + SL.w_off : nullptr;  // direction bytes of the rows with more than 4 predecessors: ED.wrows rows of W
     // ring geometry is a property of the edge (its longest sequence) and of the launch
     const uint32_t GM = ED.members;                  // workgroups sharing this edge's DP columns
-    const uint32_t ring_w = CM * (NT >> 6) * 65u;    // CM planes of 65 words per wave (dp_rows)
+    const uint32_t ring_w = CM * (DL >> 6) * 65u;    // CM planes of 65 words per wave (dp_rows)
     // kept rows the LDS ring holds for THIS edge: what fits the launch's LDS at the edge's own row width (a launch serves edges of several
     // widths; the host sizes the LDS for the widest), a power of two (slot = kept-row counter & (R - 1)). Only rows with a non-adjacent
     // reader go there (the previous row is read from registers), so every slot holds a kept row.
@@ -964,7 +967,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     }
     uint8_t* seq = P.seq + SL.seq_off;
     const uint32_t W = (ED.lmax + 1 + 31) & ~31u;   // row stride: a multiple of the widest lane chunk (32 columns), so chunks are vector-aligned and stay inside their row
-    const uint32_t WH = W + (GM * (NT >> 6) > 1 ? (GM * (NT >> 6) + 3u) & ~3u : 0u);   // rows of H end with one word per wave of the edge's pipeline (dp_rows)
+    const uint32_t WH = W + (GM * (DL >> 6) > 1 ? (GM * (DL >> 6) + 3u) & ~3u : 0u);   // rows of H end with one word per wave of the edge's pipeline (dp_rows)
 
     // static LDS is kept small for the launches that can share a CU: sink rows kept in LDS (an alignment ends in at most one sink per sequence
     // aligned so far; an edge with more than 256 is redone by the 1024-lane kernel), wave mailboxes for the waves the launch can have
@@ -987,10 +990,10 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     int32_t* sinkbuf = P.sinkbuf + (uint64_t)eidx * (1 + 2 * SINK_CAP);
     DpCl cl;
     cl.mem = mem; cl.members = GM; cl.stride = ED.vcap + 1; cl.tag0 = 0;
-    cl.mbox = P.mbox + ED.cl_off; cl.err = csy + 4; cl.poll_limit = poll_limit;
+    cl.mbox = P.mbox + ED.cl_off; cl.err = csy + 4; cl.poll_limit = poll_limit; cl.lanes = DL;
     constexpr uint32_t CL_ABORT = 0xffffffffu;
 #define HX_DP_DISPATCH(Lq, Vq, nsq) do { \
-        if (((Lq) + 1 + GM * NT - 1) / (GM * NT) <= (uint32_t)CM)      /* the host puts an edge into a launch whose columns per lane hold its longest sequence */ \
+        if (((Lq) + 1 + GM * DL - 1) / (GM * DL) <= (uint32_t)CM)      /* the host puts an edge into a launch whose columns per lane hold its longest sequence */ \
             dp_rows<CM, DIR>(g, H, Dm, Dw, W, WH, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, wmail.box, wmail.consumed, sink_row, sink_score, SINK_LDS, nsq, cl, ph + 6); \
         else sOk = 2; } while (0)
     // The reference's topological order (spoa's DFS, inherently serial) is needed in two places only: to break ties between equally scored
@@ -1077,7 +1080,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
         }
         if (mem > 0) {
             __syncthreads();
-            if (V > 0 && L / (NT * (uint32_t)CM) == mem) {   // this member owns the last column: hand the sink rows to member 0
+            if (V > 0 && L / (DL * (uint32_t)CM) == mem) {   // this member owns the last column: hand the sink rows to member 0
                 const uint32_t nsk = min(sNsink, SINK_LDS);
                 if (tid == 0) sinkbuf[0] = (int32_t)sNsink;
                 for (uint32_t q = tid; q < nsk; q += NT) { sinkbuf[1 + q] = (int32_t)sink_row[q]; sinkbuf[1 + SINK_CAP + q] = sink_score[q]; }
@@ -1102,7 +1105,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                     }
                     __syncthreads();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    if (L / (NT * (uint32_t)CM) != 0) {   // the last column lives in another member: fetch its sink rows
+                    if (L / (DL * (uint32_t)CM) != 0) {   // the last column lives in another member: fetch its sink rows
                         const uint32_t nsk_all = (uint32_t)sinkbuf[0], nsk = min(nsk_all, SINK_LDS);
                         for (uint32_t q = tid; q < nsk; q += NT) { sink_row[q] = (uint32_t)sinkbuf[1 + q]; sink_score[q] = sinkbuf[1 + SINK_CAP + q]; }
                         if (tid == 0) sNsink = nsk_all;
@@ -1625,7 +1628,7 @@ __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const P
                                             const PoaSeq* __restrict__ seqs, const uint8_t* __restrict__ packed, const uint64_t* __restrict__ read_off,
                                             const uint32_t* __restrict__ read_len, PoaPools P, int32_t match, int32_t mismatch, int32_t gap,
                                             char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells, unsigned long long* phase,
-                                            uint32_t poll_limit, uint32_t lds_bytes, uint32_t max_indeg) {
+                                            uint32_t poll_limit, uint32_t lds_bytes, uint32_t max_indeg, uint32_t dp_lanes) {
     __shared__ uint32_t sNext;
     for (uint32_t round = 0;; round++) {   // (one call site of the edge body for both kinds of launch)
         uint32_t eidx, mem = 0;
@@ -1648,7 +1651,7 @@ __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const P
             eidx = order[idx] & 0x00ffffffu;
             SL = slots[blockIdx.x];
         }
-        poa_edge<MAXNT, CM, DIR>(eidx, mem, SL, edges, seqs, packed, read_off, read_len, P, match, mismatch, gap, cns, cns_len, status, cells, phase, poll_limit, lds_bytes, max_indeg);
+        poa_edge<MAXNT, CM, DIR>(eidx, mem, SL, edges, seqs, packed, read_off, read_len, P, match, mismatch, gap, cns, cns_len, status, cells, phase, poll_limit, lds_bytes, max_indeg, dp_lanes);
         if (!PERSIST) return;
     }
 }
@@ -1658,13 +1661,13 @@ __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const P
 void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_items, const PoaSlot* slots, uint32_t* counter, uint32_t n_blocks, const PoaSeq* seqs, const uint8_t* packed,
              const uint64_t* read_off, const uint32_t* read_len, PoaPools pools, int32_t match, int32_t mismatch, int32_t gap, char* cns, uint32_t* cns_len,
              uint32_t* status, unsigned long long* cells, unsigned long long* phase, int block_threads, int cm, uint32_t poll_limit, uint32_t ring_bytes,
-             bool use_dir, uint32_t max_indeg, hipStream_t s) {
+             bool use_dir, uint32_t max_indeg, uint32_t dp_lanes, hipStream_t s) {
     if (!n_blocks || !n_items) return;
     if (counter && !use_dir) return;   // (the host never asks for it: poa_persistent_ok)
 #define HX_LAUNCH(MNT, CMV, DIRV, PERS) do { \
         (void)hipFuncSetAttribute((const void*)k_poa<MNT, CMV, DIRV, PERS>, hipFuncAttributeMaxDynamicSharedMemorySize, 142 * 1024); \
         k_poa<MNT, CMV, DIRV, PERS><<<n_blocks, block_threads, ring_bytes, s>>>(edges, order, n_items, slots, counter, seqs, packed, read_off, read_len, pools, match, mismatch, gap, \
-                                                                       cns, cns_len, status, cells, phase, poll_limit, ring_bytes, max_indeg); } while (0)
+                                                                       cns, cns_len, status, cells, phase, poll_limit, ring_bytes, max_indeg, dp_lanes); } while (0)
     // (persistent instances exist for the direction-byte flavour only: poa_persistent_ok)
 #define HX_LAUNCH_CM(MNT, CMV) do { if (use_dir && counter) HX_LAUNCH(MNT, CMV, true, true); else if (use_dir) HX_LAUNCH(MNT, CMV, true, false); else HX_LAUNCH(MNT, CMV, false, false); } while (0)
     // the instances the host's launch classes use (poa_kernel_lanes): workgroups up to 64 / 256 / 512 / 1024 lanes x 4, 8, 16 or 32 columns per lane

@@ -291,11 +291,13 @@ def test_score_matrix_traceback_matches_direction_bytes(sim, ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [("300", "64", "8", "8"), ("300", "64", "4", "3"), ("500", "128", "4", "4"), ("400", "256", "8", "8")])
+@pytest.mark.parametrize("cfg", [("300", "64", "8", "8", "0"), ("300", "64", "4", "3", "100"), ("500", "128", "4", "4", "2"), ("400", "256", "8", "8", "100"),
+                                 ("300", "64", "4", "3", "0"), ("400", "256", "8", "8", "0")])
 def test_shared_edges_cluster_mode(sim, ctx, cfg):
     """cluster mode: the DP columns of an edge spread over several workgroups (forced here on short gaps with small members, so that
     every variant — single-wave members, multi-wave members, members without columns for a short read, sink rows in another member —
-    is exercised) gives the consensus of the oracle, bit for bit"""
+    is exercised) gives the consensus of the oracle, bit for bit. Last knob: how many of the costliest shared edges run with WIDE members
+    (1024-lane workgroups whose first waves do the DP and all of whose waves work in member 0's graph phases): none, some, all"""
     import os
     pre = sim("--genome-len", "150000", "--seed", "31", "--variant-per-mb", "15")
     ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
@@ -304,7 +306,7 @@ def test_shared_edges_cluster_mode(sim, ctx, cfg):
     ro = host.Run(ds, prm, be.table, None)
     ro.all()
     ctx.upload(ds)
-    keys = ("HX_POA_CLUSTER_MIN", "HX_POA_MEMBER_LANES", "HX_POA_CLUSTER_COLS", "HX_POA_CLUSTER_MAX")
+    keys = ("HX_POA_CLUSTER_MIN", "HX_POA_MEMBER_LANES", "HX_POA_CLUSTER_COLS", "HX_POA_CLUSTER_MAX", "HX_POA_WIDE_MEMBERS")
     old = {k: os.environ.get(k) for k in keys}
     try:
         for k, v in zip(keys, cfg):
