@@ -608,7 +608,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     const uint32_t cl_max = getenv("HX_POA_CLUSTER_MAX") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MAX")) : 16;                              // members per edge at most
     const uint32_t cl_pref = getenv("HX_POA_CLUSTER_MAX") ? cl_max : many_edges_in ? 8 : 16;                                                  // ... unless the gap needs more to fit at all
     const uint32_t cl_topk = getenv("HX_POA_CLUSTER_TOPK") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_TOPK")) : many_edges_in ? 32 : 192;    // shared edges per call at most (the costliest)
-    const uint32_t wide_k = getenv("HX_POA_WIDE_MEMBERS") ? (uint32_t)atoi(getenv("HX_POA_WIDE_MEMBERS")) : many_edges_in ? 0 : 4;   // shared edges per call (the costliest) whose members are 1024-lane workgroups
+    uint32_t wide_k = getenv("HX_POA_WIDE_MEMBERS") ? (uint32_t)atoi(getenv("HX_POA_WIDE_MEMBERS")) : 0;   // shared edges per call (the costliest) whose members are 1024-lane workgroups (default: below)
     const uint32_t cl_cols = getenv("HX_POA_CLUSTER_COLS") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_COLS")) : 4;            // columns per lane a member aims at
     const uint64_t est_pct = getenv("HX_POA_NODE_EST_PCT") ? (uint64_t)std::max(1L, atol(getenv("HX_POA_NODE_EST_PCT"))) : 100;   // (testing: scales the node estimate)
     const long far_rows = getenv("HX_POA_FAR_ROWS") ? atol(getenv("HX_POA_FAR_ROWS")) : -1;   // (testing: rows of H per edge on the first attempt)
@@ -693,6 +693,17 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                 });
                 for (size_t q = cl_topk; q < sh.size(); q++) if (P.edges[sh[q]].lmax + 1 <= 8192) P.edges[sh[q]].members = 1;   // (longer gaps than a 1024-lane workgroup holds with its ring stay shared)
             }
+        }
+        // Wide members (build_classes) pay when ONE edge's serial chain is what the call waits for, and cost when the chip is busy anyway (every wide
+        // workgroup has a CU to itself): time of the longest chain ~ its DP rows (nodes x sequences) x ~1 750 cycles, time of everything ~ DP cells
+        // / throughput. Measured (Nanopore-like 25x): 4.6 Mb / 12 Mb genomes (423 / 1 079 edges) 0.190 -> 0.177 s and 0.248 -> 0.230 s with them, but 20 Mb
+        // (1 864 edges, a chain 1.75 x longer) 0.426 -> 0.454 s and 30 Mb (2 737 edges) 0.327 -> 0.351 s: from ~1 500 edges on the chip is busy whatever the
+        // longest chain does, so the edge count decides and the chain / work ratio only keeps calls without a dominant edge out.
+        if (!getenv("HX_POA_WIDE_MEMBERS")) {
+            uint64_t top_rows = 0, sum_cost = 0;
+            for (uint32_t e : todo) { top_rows = std::max<uint64_t>(top_rows, (uint64_t)P.edges[e].vcap * std::max<uint32_t>(1, P.nseq[e])); sum_cost += edge_cost(e); }
+            wide_k = ne <= 1500 && (double)top_rows * 5e5 > (double)sum_cost ? 4 : 0;
+            if (getenv("HX_DEBUG")) fprintf(stderr, "[hx] wide members: longest chain %.3g node-sequences, all edges %.3g cost units -> %u\n", (double)top_rows, (double)sum_cost, wide_k);
         }
         // rows of H (see full_h above): how many rows leave the LDS ring before their last reader depends on how many the ring holds
         for (uint32_t e : todo) {
