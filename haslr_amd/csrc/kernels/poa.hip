@@ -1127,6 +1127,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                 for (uint32_t q = 0; q < nsk; q++) if (sink_score[q] == best) { if (!ncand) first = q; sink_row[ncand++] = sink_row[q]; }   // compact candidates to the front
                 (void)first;
                 sNcand = ncand; sBestI = ncand ? (int)sink_row[0] : -1; sBestKey = 0xffffffffu;
+                lds_u[8] = 0; lds_u[9] = 0; lds_u[10] = 0;   // (traceback helper: nowhere yet, not done)
                 // Ties, the usual case: all candidates sit in ONE column (aligned group) whose members are all sinks, e.g. the letters seen
                 // at the end of the gap. Such a column is entered by the reference's DFS only through its oldest member (roots are taken in
                 // node-id order, a sink is nobody's predecessor), which emits itself and then its aligned list; every later member was
@@ -1188,6 +1189,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                         // tile: 32 rows (ranks ti .. ti-31) x 16 columns (ct-15 .. ct, ct = tj made odd: whole bytes of two nibbles); lane = (row, half):
                         // the 4 bytes = 8 columns of one row in one register
                         const uint32_t ti = i, ct = j | 1u, r0 = ln >> 1, hf = ln & 1u;
+                        if (NT > 64 && ln == 0) { st_wg(&lds_u[8], ti); st_wg(&lds_u[9], ct); }   // (where the walk is: the helper wave fetches ahead of it)
                         const int32_t bs = ((int32_t)ct - 15) >> 1;   // first byte of the tile in its rows (ct < 15: negative - bytes before the row, never looked at)
                         uint32_t w0 = 0, mt = 0, pv0 = 0, pv1 = 0, qo = 0, qw = 0;
                         if (ti > r0) {
@@ -1242,7 +1244,33 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                         if (na & 63u) { const uint32_t base = na & ~63u; if (ln < na - base) { g.aln_node[base + ln] = pn; g.aln_pos[base + ln] = pp; } }
                         nwalk = na; iend = 0; jend = 0;
                     }
-                    if (ln == 0) { sNaln = na; lds_u[0] = nwalk; lds_u[1] = iend; lds_u[2] = jend; }
+                    if (ln == 0) { sNaln = na; lds_u[0] = nwalk; lds_u[1] = iend; lds_u[2] = jend; st_wg(&lds_u[10], 1u); }
+                } else if (tid < 128) {
+                    // Helper wavefront of the walk (any workgroup with a second wave; it sits on another SIMD): touches what the walk reaches in the
+                    // next one to three tiles - the nibble rows around the path's expected column (graphs have ~2 ranks per column), the rows'
+                    // records, the later predecessor entries of rows with more than two and the move bytes of wide rows - so that the walk's
+                    // tile fetches and its rare dependent loads find their lines in the CU's vector cache instead of the L2. Nothing it loads is used.
+                    const uint32_t hl = tid - 64u;
+                    uint32_t last_i = 0xffffffffu, sink = 0;
+                    for (uint32_t spin = 0; spin < (1u << 26); spin++) {
+                        if (ld_wg(&lds_u[10])) break;
+                        const uint32_t pi_ = ld_wg(&lds_u[8]), pc = ld_wg(&lds_u[9]);
+                        if (pi_ == last_i) { __builtin_amdgcn_s_sleep(8); continue; }
+                        last_i = pi_;
+                        const uint32_t d = 32u + hl;                              // rows pi_ - 32 .. pi_ - 95
+                        if (pi_ > d) {
+                            const uint32_t r = pi_ - d, rr = r - 1;
+                            const uint8_t* rowp = Dm + (uint64_t)r * (W >> 1);
+                            const uint32_t c_lo = pc > d ? pc - d : 0u, c_hi = pc > d / 3u ? pc - d / 3u : 0u;
+                            uint32_t a0, a1;
+                            __builtin_memcpy(&a0, rowp + ((c_lo >> 1) & ~3u), 4); __builtin_memcpy(&a1, rowp + ((c_hi >> 1) & ~3u), 4);
+                            const uint32_t mt = g.row_meta[rr], qo = g.row_pred_off[rr];
+                            sink ^= a0 ^ a1 ^ g.row_pred0[rr] ^ g.row_pred1[rr];
+                            if ((mt >> META_NP) > 2u) sink ^= g.pred_rank[qo + 2] ^ g.pred_rank[qo + (mt >> META_NP) - 1];
+                            if (mt & 32u) { const uint8_t* wp = Dw + (uint64_t)g.wslot[rr] * W; sink ^= wp[c_lo] ^ wp[(c_lo + c_hi) >> 1] ^ wp[c_hi]; }
+                        }
+                    }
+                    asm volatile("" :: "v"(sink));
                 }
                 __syncthreads();
                 {   // entry k of the walk: the node of its row unless the move stayed in the row, its column unless the move stayed in the column
