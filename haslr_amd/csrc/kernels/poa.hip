@@ -1250,6 +1250,8 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                     // next one to three tiles - the nibble rows around the path's expected column (graphs have ~2 ranks per column), the rows'
                     // records, the later predecessor entries of rows with more than two and the move bytes of wide rows - so that the walk's
                     // tile fetches and its rare dependent loads find their lines in the CU's vector cache instead of the L2. Nothing it loads is used.
+                    // (measured on the longest 12 Mb edge, cycles of the traceback phase: no helper 92 M, 64 rows ahead 76 M, 128 rows 70-72 M, 192 rows 74 M,
+                    //  256 rows 78 M; two or three helper waves 83-87 M; polling four times as often 80 M)
                     const uint32_t hl = tid - 64u;
                     uint32_t last_i = 0xffffffffu, sink = 0;
                     for (uint32_t spin = 0; spin < (1u << 26); spin++) {
@@ -1257,7 +1259,8 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                         const uint32_t pi_ = ld_wg(&lds_u[8]), pc = ld_wg(&lds_u[9]);
                         if (pi_ == last_i) { __builtin_amdgcn_s_sleep(8); continue; }
                         last_i = pi_;
-                        const uint32_t d = 32u + hl;                              // rows pi_ - 32 .. pi_ - 95
+                        for (uint32_t hk = 0; hk < 2; hk++) {                        // rows pi_ - 32 .. pi_ - 159, 64 at a time
+                        const uint32_t d = 32u + hl + 64u * hk;
                         if (pi_ > d) {
                             const uint32_t r = pi_ - d, rr = r - 1;
                             const uint8_t* rowp = Dm + (uint64_t)r * (W >> 1);
@@ -1268,6 +1271,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                             sink ^= a0 ^ a1 ^ g.row_pred0[rr] ^ g.row_pred1[rr];
                             if ((mt >> META_NP) > 2u) sink ^= g.pred_rank[qo + 2] ^ g.pred_rank[qo + (mt >> META_NP) - 1];
                             if (mt & 32u) { const uint8_t* wp = Dw + (uint64_t)g.wslot[rr] * W; sink ^= wp[c_lo] ^ wp[(c_lo + c_hi) >> 1] ^ wp[c_hi]; }
+                        }
                         }
                     }
                     asm volatile("" :: "v"(sink));
