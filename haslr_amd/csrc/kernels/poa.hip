@@ -637,20 +637,55 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)L_), V = (uint32_t)__builtin_amdgcn_readfirstlane((int)V_);
     const uint32_t R = (uint32_t)__builtin_amdgcn_readfirstlane((int)R_), ring_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)ring_w_);
     const uint32_t tid = threadIdx.x, NT = blockDim.x, lane = tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), NW = cl.lanes >> 6;
-    if (wv >= NW) return;                                                     // (a wave of a wide member that sits the DP out)
     const uint32_t ncol = L + 1;
+    // A wide member (1024 lanes, NW of its 16 waves in the DP) other than the first lets a spare wave RELAY the carries that arrive through HBM
+    // into an LDS mailbox: its first DP wave then takes them like any wave takes its left neighbour's (an LDS round trip per batch of rows
+    // instead of a device-scope load, ~1.7 us, that it would sit through - and the pipeline runs at the speed of its slowest wave).
+    constexpr uint32_t RELAY_BOX = MAX_WAVES - 2;                             // mailbox / consumed word of the relay (the 1024-lane instances have them; boundaries 0 .. NW-2 are the DP's)
+    const bool relay_mode = NT == 1024u && NW + 2u <= 16u && cl.mem > 0;
+    if (wv >= NW) {                                                           // (a wave of a wide member that sits the DP out)
+        if (relay_mode && wv == NW + 1u && (uint64_t)(cl.mem * NW) * 64u * CM < ncol) {   // (wave NW + 1: not the SIMD of the wave it feeds)
+            const unsigned long long* src = cl.mbox + (uint64_t)(cl.mem - 1) * cl.stride;
+            unsigned long long* dst = wm_box + (size_t)RELAY_BOX * WAVE_MBOX;
+            const uint32_t* cons = wm_cons + RELAY_BOX;
+            bool dead = false;
+            for (uint32_t ib = 0; ib < V; ib += 64) {
+                const uint32_t ie = min(64u, V - ib);
+                for (uint32_t rb = 0; rb < ie; rb += CARRY_BATCH) {
+                    const uint32_t nb = min(CARRY_BATCH, ie - rb), i0 = ib + rb + 1;
+                    unsigned long long v = (unsigned long long)(cl.tag0 + i0 + lane);   // (a relay that gave up still hands out tagged entries: the edge is flagged and redone)
+                    for (uint32_t spin = 0; !dead; spin++) {
+                        bool ok = true;
+                        if (lane < nb) { v = ld_dev64(src + i0 + lane); ok = (uint32_t)v == cl.tag0 + i0 + lane; }
+                        if (__ballot(ok) == ~0ull) break;
+                        if (spin > cl.poll_limit) { if (lane == 0) st_dev(cl.err, 1u); dead = true; v = (unsigned long long)(cl.tag0 + i0 + lane); break; }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    const uint32_t need = i0 + nb - 1 > WAVE_MBOX ? cl.tag0 + i0 + nb - 1 - WAVE_MBOX : 0;   // the entries overwritten must have been taken
+                    for (uint32_t spin = 0; need; spin++) {
+                        const uint32_t got = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_wg(cons));
+                        if ((int32_t)(got - need) >= 0) break;
+                        if (spin > WG_POLL_LIMIT) { if (lane == 0) st_dev(cl.err, 2u); break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (lane < nb) st_wg64(dst + ((i0 + lane) & (WAVE_MBOX - 1)), v);
+                }
+            }
+        }
+        return;
+    }
     const uint32_t gw = cl.mem * NW + wv;                                     // this wave's place in the edge's pipeline
     if ((uint64_t)gw * 64u * CM >= ncol) return;                              // the wave owns no real column of this sequence
     const uint32_t gt = gw * 64u + lane;                                      // lane index over all waves
     const bool has_in = gw > 0;                                               // a wave on the left feeds the horizontal carry ...
-    const bool in_lds = wv > 0;                                               // ... through the workgroup's LDS mailbox, or (first wave of a member) through HBM
+    const bool in_lds = wv > 0 || relay_mode;                                 // ... through the workgroup's LDS mailbox, or (first wave of a member without a relay wave) through HBM
     const bool has_out = (uint64_t)(gw + 1) * 64u * CM < ncol;                // a wave on the right owns real columns (the host sized the pipeline for the longest sequence)
     const bool out_lds = wv + 1 < NW;
     const unsigned long long* mb_in_h = cl.mbox + (uint64_t)(cl.mem ? cl.mem - 1 : 0) * cl.stride;
     unsigned long long* mb_out_h = cl.mbox + (uint64_t)cl.mem * cl.stride;
-    const unsigned long long* mb_in_l = wm_box + (size_t)(wv ? wv - 1 : 0) * WAVE_MBOX;
+    const unsigned long long* mb_in_l = wm_box + (size_t)(wv ? wv - 1 : relay_mode ? RELAY_BOX : 0) * WAVE_MBOX;
     unsigned long long* mb_out_l = wm_box + (size_t)wv * WAVE_MBOX;
-    uint32_t* cons_in = wm_cons + (wv ? wv - 1 : 0);                          // what this wave has taken from the boundary on its left
+    uint32_t* cons_in = wm_cons + (wv ? wv - 1 : relay_mode ? RELAY_BOX : 0);   // what this wave has taken from the boundary on its left
     const uint32_t* cons_out = wm_cons + wv;                                  // what the wave on the right has taken from this wave's mailbox
     if (has_in && in_lds && lane == 0) st_wg(cons_in, cl.tag0);               // everything of earlier DPs counts as taken (a wave may have sat out a short sequence)
     const uint32_t* farslot = reinterpret_cast<const uint32_t*>(g.pred);      // per rank: row of H that holds the far-read row (consensus scratch, free during the DP)
