@@ -6,15 +6,18 @@
 // the published rvaser/spoa 1.1.3 algorithm as restated in oracle/oracle.cpp (same recurrences, same
 // tie-breaking, same graph update and topological order), so results are bit-identical to the oracle.
 //
-// Mapping (details in DESIGN.md "K6 in detail"): one workgroup per edge, or 2-8 cooperating workgroups ("members", one CU each) for
-// gaps above 2047 columns; sequences of an edge are aligned one after the other, edges run concurrently.
+// Mapping (details in DESIGN.md "K6 in detail"): one workgroup per edge, or 2-16 cooperating workgroups ("members", one CU each) for
+// gaps above 2047 columns - for the few costliest edges of a small call WIDE members: 1024 lanes of which the first 256 run the DP, all of
+// them the graph phases, one spare wave relays the carries arriving through HBM; sequences of an edge are aligned one after the other,
+// edges run concurrently (persistent workgroups pulling edges off a counter when a launch class has more edges than workspace slots).
 //   * sequence k is decoded from the 2-bit packed read arena into a byte row
 //   * DP (dp_rows): rows = graph nodes in topological order, columns = sequence positions, CM contiguous columns per lane kept in
 //     registers. Cells are keys (64 x score + 6 tie-break bits), so one max() per decision reproduces the reference's tie rules and the
 //     low bits are the traceback's direction byte. Horizontal recurrence = lane-serial pass + one DPP prefix-max scan (+ wave totals
 //     through LDS and one LDS-only barrier per row; + one tagged mailbox word per row between members). Rows needed later as
 //     non-adjacent predecessors live in an LDS ring, the overflow in HBM.
-//   * traceback: the first wavefront walks 32x16 tiles of direction bytes with v_readlane
+//   * traceback: the first wavefront walks 32x16 tiles of direction nibbles with v_readlane; a second wavefront, where the workgroup has
+//     one, touches the lines the walk reaches next (cache warm-up only)
 //   * graph update (spoa add_alignment), order update and the rank-ordered CSR rebuild run on all lanes (prefix sums for the ids the
 //     serial walk would hand out); the reference's DFS topological sort runs only for end-node ties that a column cannot decide and
 //     for heaviest bundles that do not end in a unique sink (one wavefront in lock step, on ranks).
