@@ -11,7 +11,8 @@ computed" (on every rank, when there are several). Inputs are uploaded to HBM be
 N=1 workload: BASELINE.json configs[2], the largest single-GPU configuration — S. cerevisiae-size 12 Mb genome,
 Nanopore-like 25x long reads + PAF against short-read contigs, synthetic (tools/hxsim, seed 0x4841534c + 2;
 there is no network for real reads). configs[1] (E. coli-size 4.6 Mb, PacBio-like 25x) is measured too and
-reported under "configs1" (`--workload ecoli` makes it the main line instead).
+reported under "configs1" (`--workload ecoli` makes it the main line instead); configs[3]'s 140 Mb data set is run on
+the one GPU as well and reported under "configs3" (the many-edge regime: throughput, not one edge's chain).
 N>1: reads sharded by id range, ONE all-gather of edge records (RCCL), edges sharded by estimated DP cost for
 coordinates + consensus, one all-gather of the results; the ranks agree on success before every collective.
 N = 4 runs BASELINE.json configs[3] as it is named (140 Mb PacBio-like, read-sharded over 4 GPUs); N = 2, 8 scale the
@@ -159,6 +160,7 @@ def main():
     ap.add_argument("--poa-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs1", action="store_true", help="skip the extra E. coli-size (configs[1]) measurement")
+    ap.add_argument("--no-configs3", action="store_true", help="skip the extra D. melanogaster-size (configs[3], 140 Mb on this one GPU: the many-edge regime) measurement")
     args = ap.parse_args()
 
     import torch
@@ -337,7 +339,7 @@ def main():
         line = {
             "metric": "long-read bases/sec through backbone+consensus; GFA match + FASTA %identity",
             "value": value, "unit": "long-read bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "fixed-size (configs[3] as named)" if as_named else "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{wl['name']}: {glen} bp genome, {wl['model']}-like 25x long reads + PAF vs short-read contigs "
                                    f"(BASELINE.json configs[{wl['config']}]{(', read-sharded over %d GPUs as BASELINE names it' % world) if as_named else (' x%d, read-sharded' % world if world > 1 else '')})",
@@ -380,6 +382,53 @@ def main():
                 last = None
             except Exception as e:  # noqa: BLE001
                 line["configs1"] = {"error": str(e)}
+        if not args.no_configs3 and world == 1 and args.workload != "fly" and not args.genome_len:
+            # BASELINE.json configs[3]'s data set (140 Mb, PacBio-like 25x) on this ONE GPU: the many-edge regime (13 000 edges, every CU busy) - the regime the
+            # CHM1 target lives in, where the step is throughput and not one edge's serial chain. ~60 s to simulate, ~3 s to parse, 3 passes.
+            try:
+                if last is not None:
+                    last.close(); last = None
+                try:
+                    ds.close()
+                except Exception:  # noqa: BLE001
+                    pass
+                w3 = WORKLOADS["fly"]
+                t0 = time.perf_counter()
+                pre3 = make_dataset(w3, w3["genome"], "gpu")
+                t_sim = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                ds3 = host.Dataset(pre3 + ".contigs.fa", pre3 + ".reads.fa", pre3 + ".paf")
+                t_parse3 = time.perf_counter() - t0
+                ctx.upload(ds3)
+                dt3, run3 = measure(ctx, ds3, ds3.params(), ctx.backend(), 2, 1, 1, 0, sync, None, 0)
+                tm3 = ctx.timing()
+                st3 = run3.cns_stats()
+                p3 = tm3["poa"]["ms"] / max(1, tm3["poa"]["launches"])
+                cns3 = run3.cns_out()
+                h3 = hashlib.sha256()
+                for c in cns3:
+                    h3.update(c if isinstance(c, bytes) else str(c).encode()); h3.update(b"\n")
+                ph3 = ctx.poa_phase_cycles()
+                sq3 = {}
+                for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")), reverse=True):
+                    try:
+                        t = json.load(open(cand))
+                        if t.get("bench_workload") == "fly":
+                            q = t["counters_summed_over_k_poa_dispatches"]
+                            sq3 = {"valu_lane_ops_per_cell": q["SQ_INSTS_VALU"] * 64 / st3["dp_cells"], "sq_counters_source": os.path.relpath(cand, ROOT),
+                                   "valu_issue_util": q["SQ_INSTS_VALU"] * 2 / (256 * 4 * SHADER_CLOCK_HZ * q.get("profiled_kernel_ms", p3) / 1e3)}
+                            break
+                    except Exception:  # noqa: BLE001
+                        pass
+                line["configs3"] = {"workload": f"{w3['name']}: {w3['genome']} bp genome, pacbio-like 25x (BASELINE.json configs[3]'s data set, here on ONE GPU)",
+                                    "value": ds3.total_read_bases * 2 / dt3, "ms_per_step": dt3 / 2 * 1e3, "steps": 2, "warmup": 1, "edges": run3.n_edges,
+                                    "kernel_ms_per_launch": p3, "gcups": st3["dp_cells"] / (p3 / 1e3) / 1e9, "dp_cells_per_launch": st3["dp_cells"],
+                                    "long_read_bases": ds3.total_read_bases, "poa_workspace_bytes": ctx.poa_workspace_bytes(), "consensus_sha256": h3.hexdigest(),
+                                    "critical_path_ms": sum(ph3["slowest_edge"].values()) / SHADER_CLOCK_HZ * 1e3, "stage_ms": {k: v * 1e3 for k, v in run3.timings().items()},
+                                    "simulate_s": t_sim, "parse_s": t_parse3, **sq3}
+                run3.close(); ds3.close()
+            except Exception as e:  # noqa: BLE001
+                line["configs3"] = {"error": str(e)}
         print(json.dumps(line), flush=True)
     if last is not None:
         last.close()

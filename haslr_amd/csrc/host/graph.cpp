@@ -178,7 +178,7 @@ namespace {
 // node visited without need takes the reference's own early exit: the edits, their order and the logs are the serial algorithm's, whatever
 // the thread count. (The small-bubble test - "has a triangle" - can only turn false by removals, so its set needs no additions.)
 // ---------------------------------------------------------------------------------------------------------------------------
-unsigned clean_threads(uint32_t n_nodes) {
+unsigned clean_threads_(uint32_t n_nodes) {
     if (const char* e = getenv("HASLR_CLEAN_THREADS")) return (unsigned)std::max(1, atoi(e));
     if (n_nodes < 200000) return 1;                   // (below that the scan is microseconds: threads would cost more than they save)
     return std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
@@ -188,7 +188,7 @@ template <class Pred>
 std::vector<uint64_t> candidate_bits(const Graph& g, Pred pred) {
     const uint32_t n = g.n_nodes, words = (n + 63) / 64;
     std::vector<uint64_t> bits(words + 1, 0);
-    const unsigned T = clean_threads(n);
+    const unsigned T = clean_threads_(n);
     auto work = [&](uint32_t w0, uint32_t w1) {
         for (uint32_t w = w0; w < w1; w++) {
             uint64_t b = 0;
@@ -247,6 +247,7 @@ void remove_path(Graph& g, const std::vector<PathElem>& p) {
 }
 
 }  // namespace
+unsigned clean_threads(uint32_t n_nodes) { return clean_threads_(n_nodes); }
 
 int clean_tips(Graph& g, int max_depth, const std::string& logpath) {
     FILE* fp = open_or_null(logpath, max_depth == 1 ? "w" : "a");

@@ -119,6 +119,7 @@ void graph_write_gfa(const Graph& g, const Dataset& d, const std::string& path);
 std::vector<std::pair<uint32_t, uint32_t>> graph_arc_list(const Graph& g);
 void graph_write_gfa_arcs(const std::vector<std::pair<uint32_t, uint32_t>>& arcs, const Dataset& d, const std::string& path);
 void graph_report_branching(const Graph& g, const std::string& path);
+unsigned clean_threads(uint32_t n_nodes);   // host threads the candidate scans of the cleaning passes use (HASLR_CLEAN_THREADS; 1 below 200 000 nodes)
 int clean_tips(Graph& g, int max_depth, const std::string& logpath);
 int clean_simple_bubbles(Graph& g, int max_depth, const std::string& logpath);
 int clean_super_bubbles(Graph& g, const std::string& logpath);

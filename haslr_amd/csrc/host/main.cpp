@@ -66,6 +66,14 @@ static void help(const hx_params& p) {
     fprintf(stderr, "    -h                Prints this help message (also --help)\n\n");
 }
 
+// tools that write their data from atexit handlers / static destructors (rocprofv3, roctracer, gcov, sanitizers) need the ordinary exit
+static bool tooling_attached() {
+    for (const char* v : {"HASLR_FULL_TEARDOWN", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB", "ROCTRACER_DOMAIN", "GCOV_PREFIX", "ASAN_OPTIONS", "LSAN_OPTIONS", "TSAN_OPTIONS", "UBSAN_OPTIONS"})
+        if (getenv(v)) return true;
+    if (const char* pre = getenv("LD_PRELOAD")) if (strstr(pre, "rocprof") || strstr(pre, "roctracer") || strstr(pre, "asan")) return true;
+    return false;
+}
+
 int main(int argc, char* argv[]) {
     hx_params prm{500, 0.85, 55, 0.15, 3, 0.0};
     std::string contig_path, long_path, mapping_path, out_dir;
@@ -124,7 +132,9 @@ int main(int argc, char* argv[]) {
     hx_ctx* ctx = nullptr;
     hx_group* group = nullptr;
     if (grouped) {
-        if (hx_group_create(gpus, nullptr, &group) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
+        std::vector<int> devs((size_t)gpus);
+        for (int r = 0; r < gpus; r++) devs[(size_t)r] = device + r;   // --device with --gpus N: the ranks run on devices device .. device + N - 1
+        if (hx_group_create(gpus, device ? devs.data() : nullptr, &group) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
         fprintf(stderr, "[NOTE] %d GPU ranks in this process, edge-record exchange over %s\n\n", gpus, hx_group_transport(group));
         ctx = hx_group_ctx(group, 0);
         if (poa_block) for (int r = 0; r < gpus; r++) hx_set_poa_block(hx_group_ctx(group, r), poa_block);
@@ -174,11 +184,16 @@ int main(int argc, char* argv[]) {
         static const char* notes[5] = {"[NOTE] fixing overlapping alignments and building compact long reads...", "[NOTE] building and cleaning the backbone graph...",
                                        "[NOTE] calculating long read coordinates between anchors...", "[NOTE] calling consensus sequence between anchors...",
                                        "[NOTE] generating the assembly from the cleaned backbone graph..."};
-        struct Cb { decltype(elapsed)* el; hx_group* g; } cb{&elapsed, group};
+        struct Cb { decltype(elapsed)* el; hx_group* g; std::vector<hxh_run*>* runs; bool from_paf; } cb{&elapsed, group, &runs, !used_li};
         auto on_stage = [](int s, int begin, void* u) {
             Cb* c = (Cb*)u;
             if (begin) fprintf(stderr, "%s\n", notes[s]);
             else {
+                if (s == 0 && c->from_paf) {   // (the count the reference prints at load time, main.cpp:70,103: the ranks' filtered sets together)
+                    unsigned long n = 0;
+                    for (hxh_run* r : *c->runs) n += (unsigned long)hxh_run_chain_out(r)->n_aln;
+                    fprintf(stderr, "       loaded %lu alignments\n", n);
+                }
                 if (s == 1) { uint64_t by = 0; double ms = 0; hx_group_exchange_stats(c->g, &by, &ms); fprintf(stderr, "       exchanged %lu bytes of edge records in %.2f ms (%s)\n", (unsigned long)by, ms, hx_group_transport(c->g)); }
                 (*c->el)();
             }
@@ -189,7 +204,7 @@ int main(int argc, char* argv[]) {
         fprintf(stderr, "[NOTE] cleaning up the memory!\n");
         fprintf(stderr, "[NOTE] elapsed time %.2lf CPU seconds (%.2lf real seconds)\n\n*** BYE ***\n\n", cpu_time() - c0, real_time() - r0);
         fflush(nullptr);
-        if (getenv("HASLR_FULL_TEARDOWN")) { for (hxh_run* r : runs) hxh_run_free(r); hxh_dataset_free(ds); hx_group_destroy(group); return EXIT_SUCCESS; }
+        if (tooling_attached()) { for (hxh_run* r : runs) hxh_run_free(r); hxh_dataset_free(ds); hx_group_destroy(group); return EXIT_SUCCESS; }   // (profilers, sanitizers, leak checks: the ordinary exit)
         _exit(EXIT_SUCCESS);
     }
     if (hx_upload(ctx, &vc, &vr, &vh, rho) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
@@ -216,7 +231,12 @@ int main(int argc, char* argv[]) {
     };
     for (auto& st : stages) {
         fprintf(stderr, "%s\n", st.note);
-        if (st.fn(run) != 0) { fprintf(stderr, "[ERROR] %s\n", hxh_last_error()); finish_index(); return EXIT_FAILURE; }
+        if (st.fn(run) != 0) {
+            fprintf(stderr, "[ERROR] %s\n", hxh_last_error());
+            finish_index();
+            hxh_run_free(run);   // joins the GFA writer threads: nothing streams into backbone.0x.gfa while the static destructors run
+            return EXIT_FAILURE;
+        }
         if (st.fn == hxh_run_chain && !used_li) fprintf(stderr, "       loaded %lu alignments\n", (unsigned long)hxh_run_chain_out(run)->n_aln);   // (the count the reference prints at load time)
         if (st.fn == hxh_run_chain && !used_li) {
             const std::string path = out_dir + "/index.longread";
@@ -230,12 +250,7 @@ int main(int argc, char* argv[]) {
     }
     if (!finish_index()) return EXIT_FAILURE;
     fprintf(stderr, "[NOTE] cleaning up the memory!\n");
-    // tools that write their data from atexit handlers / static destructors (rocprofv3, roctracer, gcov, sanitizers) need the ordinary exit
-    bool tooling = false;
-    for (const char* v : {"HASLR_FULL_TEARDOWN", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB", "ROCTRACER_DOMAIN", "GCOV_PREFIX", "ASAN_OPTIONS", "LSAN_OPTIONS", "TSAN_OPTIONS", "UBSAN_OPTIONS"})
-        if (getenv(v)) tooling = true;
-    if (const char* pre = getenv("LD_PRELOAD")) if (strstr(pre, "rocprof") || strstr(pre, "roctracer") || strstr(pre, "asan")) tooling = true;
-    if (!tooling) {   // everything is written and closed: the release of up to ~250 GB of device memory and of the host arrays is left
+    if (!tooling_attached()) {   // everything is written and closed: the release of up to ~250 GB of device memory and of the host arrays is left
                                             // to the end of the process (1.5-2 s of a 10 s run at 140 Mb); HASLR_FULL_TEARDOWN=1 frees object by object (leak checks)
         fprintf(stderr, "[NOTE] elapsed time %.2lf CPU seconds (%.2lf real seconds)\n\n*** BYE ***\n\n", cpu_time() - c0, real_time() - r0);
         fflush(nullptr);

@@ -161,6 +161,7 @@ static int run_graph(Run& r) {
     Graph& g = r.g;
     graph_build(g, (uint32_t)d.contig_len.size(), r.edges);
     lap("build");
+    if (dbg) fprintf(stderr, "[hxh] graph stage: cleaning passes on %u threads (%u nodes)\n", clean_threads(g.n_nodes), g.n_nodes);
     graph_write_stats(g, d, r.path("backbone.01.init.stat"));
     gfa.start("backbone.01.init.gfa");
     lap("stat + gfa 01");

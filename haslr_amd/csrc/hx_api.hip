@@ -1095,17 +1095,29 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
     }
     if (getenv("HX_DEBUG") && ne) {
         const unsigned long long* q = &c->poa_phase[(size_t)c->dbg_slowest * 12];
-        if (getenv("HX_PROF3")) { for (int k = 6; k < 11; k++) fprintf(stderr, "[hx] prof3 bucket %d: rows %llu, cycles per row %.0f\n", k - 6, q[k] >> 40, (q[k] >> 40) ? (double)(q[k] & ((1ull << 40) - 1)) / (double)(q[k] >> 40) : 0.0); }
-        fprintf(stderr, "[hx] slowest edge %u: lmax=%u nseq=%u | DP rows %llu (multi-pred %llu, ring refs %llu, far refs %llu, kept %llu) over %llu sequences\n", c->dbg_slowest,
-                c->dbg_lmax[c->dbg_slowest], c->dbg_nseq[c->dbg_slowest], q[6], q[7], q[8], q[9], q[10], q[11] & 0xffffffffull);
+        if (getenv("HX_PROF3")) {   // (a build with -DHX_DP_PROF3: per member of the five longest edges, kilocycles inside the DP and of them waiting for carries)
+            std::vector<std::pair<unsigned long long, uint32_t>> tt;
+            for (size_t e = 0; e < ne; e++) { unsigned long long t = 0; for (int k = 0; k < 6; k++) t += c->poa_phase[e * 12 + k]; tt.push_back({t, (uint32_t)e}); }
+            std::sort(tt.rbegin(), tt.rend());
+            for (size_t k = 0; k < std::min<size_t>(5, tt.size()); k++) {
+                const unsigned long long* q2 = &c->poa_phase[(size_t)tt[k].second * 12];
+                fprintf(stderr, "[hx] prof3 edge %u lmax=%u nseq=%u dp %llu:", tt[k].second, c->dbg_lmax[tt[k].second], c->dbg_nseq[tt[k].second], q2[1]);
+                for (int m = 0; m < 6; m++) fprintf(stderr, " m%d dp %lluk wait %lluk", m, q2[6 + m] & 0xffffffffull, q2[6 + m] >> 32);
+                fprintf(stderr, "\n");
+            }
+            return (uint32_t)ne;
+        }
+        const unsigned long long M40 = (1ull << 40) - 1;
+        fprintf(stderr, "[hx] slowest edge %u: lmax=%u nseq=%u | DP rows %llu (multi-pred %llu, ring refs %llu, far refs %llu, kept %llu, more than 4 predecessors %llu, fifth-and-later entries %llu) over %llu sequences\n", c->dbg_slowest,
+                c->dbg_lmax[c->dbg_slowest], c->dbg_nseq[c->dbg_slowest], q[6], q[7], q[8] & M40, q[9] & M40, q[10], q[9] >> 40, q[8] >> 40, q[11] & 0xffffffffull);
         {   // the five longest edges (critical-path candidates)
             std::vector<std::pair<unsigned long long, uint32_t>> tt;
             for (size_t e = 0; e < ne; e++) { unsigned long long t = 0; for (int k = 0; k < 6; k++) t += c->poa_phase[e * 12 + k]; tt.push_back({t, (uint32_t)e}); }
             std::sort(tt.rbegin(), tt.rend());
             for (size_t k = 0; k < std::min<size_t>(5, tt.size()); k++) {
                 const unsigned long long* q2 = &c->poa_phase[(size_t)tt[k].second * 12];
-                fprintf(stderr, "[hx] top edge %u: lmax=%u nseq=%u cycles=%llu (dp %llu tb %llu graph %llu order %llu csr %llu) rows %llu\n", tt[k].second, c->dbg_lmax[tt[k].second], c->dbg_nseq[tt[k].second],
-                        tt[k].first, q2[1], q2[2], q2[3], q2[4], q2[5], q2[6]);
+                fprintf(stderr, "[hx] top edge %u: lmax=%u nseq=%u cycles=%llu (dp %llu tb %llu graph %llu order %llu csr %llu) rows %llu multi %llu ring %llu far %llu kept %llu wide %llu fifth+ %llu\n", tt[k].second, c->dbg_lmax[tt[k].second], c->dbg_nseq[tt[k].second],
+                        tt[k].first, q2[1], q2[2], q2[3], q2[4], q2[5], q2[6], q2[7], q2[8] & ((1ull << 40) - 1), q2[9] & ((1ull << 40) - 1), q2[10], q2[9] >> 40, q2[8] >> 40);
             }
         }
         {   // finished graphs against the workspace estimate: nodes per base of the longest sequence, as a + b x sequences
@@ -1123,7 +1135,7 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
         }
         {   // per launch class: how often a row is read back from the LDS ring / from HBM
             unsigned long long cr[12][4] = {};
-            for (size_t e = 0; e < ne; e++) { const int k = e < c->dbg_cls.size() ? c->dbg_cls[e] : 11; const unsigned long long* q3 = &c->poa_phase[e * 12]; cr[k][0] += q3[6]; cr[k][1] += q3[10]; cr[k][2] += q3[8]; cr[k][3] += q3[9]; }
+            for (size_t e = 0; e < ne; e++) { const int k = e < c->dbg_cls.size() ? c->dbg_cls[e] : 11; const unsigned long long* q3 = &c->poa_phase[e * 12]; cr[k][0] += q3[6]; cr[k][1] += q3[10]; cr[k][2] += q3[8] & ((1ull << 40) - 1); cr[k][3] += q3[9] & ((1ull << 40) - 1); }
             for (int k = 0; k < 12; k++) if (cr[k][0]) fprintf(stderr, "[hx] class %d (ring %u): DP rows %llu, kept %.1f %%, ring refs %.1f %%, far refs %.2f %%\n", k, k < 11 ? c->dbg_ring[k] : 0, cr[k][0], 100.0 * cr[k][1] / cr[k][0], 100.0 * cr[k][2] / cr[k][0], 100.0 * cr[k][3] / cr[k][0]);
             unsigned long long cy[12][4] = {};   // edges, all cycles, DP cycles, longest edge
             for (size_t e = 0; e < ne; e++) {
@@ -1134,7 +1146,7 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
             for (int k = 0; k < 12; k++) if (cy[k][0]) fprintf(stderr, "[hx] class %d: %llu workgroups, %.3e cycles in all (DP %.0f %%), longest %.3e, DP cycles per row %.0f\n", k, cy[k][0], (double)cy[k][1], 100.0 * cy[k][2] / cy[k][1], (double)cy[k][3], cr[k][0] ? (double)cy[k][2] / cr[k][0] : 0.0);
         }
         unsigned long long tot[6] = {0, 0, 0, 0, 0, 0};
-        for (size_t e = 0; e < ne; e++) for (int k = 0; k < 6; k++) tot[k] += k == 5 ? (c->poa_phase[e * 12 + 11] & 0xffffffffull) : c->poa_phase[e * 12 + 6 + k];
+        for (size_t e = 0; e < ne; e++) for (int k = 0; k < 6; k++) tot[k] += k == 5 ? (c->poa_phase[e * 12 + 11] & 0xffffffffull) : (k == 2 || k == 3 ? c->poa_phase[e * 12 + 6 + k] & ((1ull << 40) - 1) : c->poa_phase[e * 12 + 6 + k]);
         fprintf(stderr, "[hx] all edges: DP rows %llu (multi-pred %llu, ring refs %llu, far refs %llu, kept %llu) over %llu sequences\n", tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]);
     }
     return (uint32_t)ne;

@@ -618,6 +618,10 @@ template <int CM> __device__ __forceinline__ void store_nibbles(uint8_t* p, cons
     }
 }
 
+#ifdef HX_DP_PROF3   // development: per member of a shared edge, cycles inside the DP and cycles of them spent waiting for carries (phase slots 6 + member)
+#define HX_DP_PROF
+#define HX_DP_PROF2
+#endif
 #if defined(HX_DP_PROF) && !defined(HX_DP_PROF2)
 #define DP_T(k) do { if (tid == 0) { const long long _n = clock64(); prof[k] += (unsigned long long)(_n - tprev); tprev = _n; } } while (0)
 #else
@@ -804,6 +808,9 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             const uint32_t nb = min(CARRY_BATCH, ie - rb), i0 = ib + rb + 1;   // rows i0 .. i0 + nb - 1
             int cinV = NEGK;     // lane r: carry into this wave for row i0 + r
             if (has_in) {
+#ifdef HX_DP_PROF3
+                const long long tw0 = clock64();
+#endif
                 for (uint32_t spin = 0;; spin++) {
                     unsigned long long v = 0;
                     bool ok = true;
@@ -816,6 +823,9 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                     if (in_lds) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(8);
                 }
                 if (in_lds && lane == 0) st_wg(cons_in, cl.tag0 + i0 + nb - 1);   // the entries of these rows may be written again
+#ifdef HX_DP_PROF3
+                if (tid == 0) prof[0] += (unsigned long long)(clock64() - tw0);
+#endif
             }
             if (has_out && out_lds) {   // the rows of this batch overwrite the entries of the rows WAVE_MBOX earlier: the wave on the right must have taken those
                 const uint32_t need = i0 + nb - 1 > WAVE_MBOX ? cl.tag0 + i0 + nb - 1 - WAVE_MBOX : 0;
@@ -963,7 +973,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     __shared__ long long tc;
     if (threadIdx.x == 0) { for (int k = 0; k < 12; k++) ph[k] = 0; tc = clock64(); }
 #define PHASE(k) do { if (tid == 0) { long long _n = clock64(); ph[k] += (unsigned long long)(_n - tc); tc = _n; } } while (0)
-#ifdef HX_DP_PROF2
+#if defined(HX_DP_PROF2) && !defined(HX_DP_PROF3)
     __shared__ long long tc2;
 #define SUBT(k) do { if (tid == 0) { long long _n = clock64(); ph[k] += (unsigned long long)(_n - tc2); tc2 = _n; } } while (0)
 #define SUBT0() do { if (tid == 0) tc2 = clock64(); } while (0)
@@ -1051,11 +1061,11 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
         __syncthreads();
         if (in_lds) {
             uint32_t* ranks = reinterpret_cast<uint32_t*>(g.score);   // free between the CSR build and the graph update
-#ifdef HX_DP_PROF2
+#if defined(HX_DP_PROF2) && !defined(HX_DP_PROF3)
             long long tq0 = clock64();
 #endif
             if (tid < 64) toposort_rank(g, Vn, st_lds, t_stack, t_cache, t_tags, ranks);   // wave 0, 64 lanes in lock step
-#ifdef HX_DP_PROF2
+#if defined(HX_DP_PROF2) && !defined(HX_DP_PROF3)
             if (tid == 0) ph[11] += (unsigned long long)(clock64() - tq0);
 #endif
             __syncthreads();
@@ -1112,7 +1122,14 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
         if (mem == 0) SUBT(6);   // publish
         if (V > 0) {
             uint32_t ns = 0xffffffffu;
+#ifdef HX_DP_PROF3
+            const long long td0 = clock64();
+            if (tid == 0) ph[6] = 0;
+#endif
             HX_DP_DISPATCH(L, V, ns);
+#ifdef HX_DP_PROF3
+            if (tid == 0 && phase) atomicAdd(&phase[(uint64_t)eidx * 12 + 6 + min(mem, 5u)], ((ph[6] >> 10) << 32) | ((unsigned long long)(clock64() - td0) >> 10));
+#endif
             if (ns != 0xffffffffu) sNsink = ns;   // written by the lane that owns column L
             cl.tag0 += V;
         }
@@ -1584,10 +1601,10 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                     kex += kept;
                 }
                 __syncthreads();
-                uint32_t st_multi = 0, st_ring = 0, st_far = 0;
+                uint32_t st_multi = 0, st_ring = 0, st_far = 0, st_wide = 0, st_fifth = 0;
                 for (uint32_t r = r0; r < r1; r++) {
                     const uint32_t po = g.row_pred_off[r], np = g.row_meta[r] >> META_NP;
-                    st_multi += np >= 2;
+                    st_multi += np >= 2; st_wide += np > 4; st_fifth += np > 4 ? np - 4 : 0;
                     for (uint32_t q = 0; q < np; q++) {
                         const uint32_t pr = g.pred_rank[po + q];
                         uint32_t loc;
@@ -1624,8 +1641,8 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
 #ifndef HX_DP_PROF
                 if (phase) {   // statistics of the rows the next DP will run over
                     if (st_multi) atomicAdd(&ph[7], (unsigned long long)st_multi);
-                    if (st_ring) atomicAdd(&ph[8], (unsigned long long)st_ring);
-                    if (st_far) atomicAdd(&ph[9], (unsigned long long)st_far);
+                    if (st_ring | st_fifth) atomicAdd(&ph[8], (unsigned long long)st_ring | ((unsigned long long)st_fifth << 40));   // (high bits: fifth-and-later predecessor entries, fetched inside the row)
+                    if (st_far | st_wide) atomicAdd(&ph[9], (unsigned long long)st_far | ((unsigned long long)st_wide << 40));      // (high bits: rows with more than 4 predecessors)
                     if (tid == 0) { atomicAdd(&ph[6], (unsigned long long)V2); atomicAdd(&ph[10], (unsigned long long)ktot); atomicAdd(&ph[11], 1ull); }
                 }
 #endif
@@ -1681,7 +1698,11 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
 #endif
         }
         PHASE(3);
+#ifdef HX_DP_PROF3
+        if (phase) for (int k = 0; k < 6; k++) phase[(uint64_t)eidx * 12 + k] = ph[k];
+#else
         if (phase) for (int k = 0; k < 12; k++) phase[(uint64_t)eidx * 12 + k] = ph[k];
+#endif
     }
 }
 

@@ -159,7 +159,7 @@ def gather_results(run, device, group=None):
 
 def sharded_stages(run, device, group=None):
     """chain -> graph (the record all-gather happens inside, behind its own agreement) -> coords -> consensus -> gathered results, with the ranks
-    agreeing on success after the stages that are followed by a collective. Returns the bytes of results gathered."""
+    agreeing on success after every stage (no rank is left waiting in a later collective). Returns the bytes of results gathered."""
     def stage(fn, name):
         err = None
         try:
@@ -171,7 +171,9 @@ def sharded_stages(run, device, group=None):
         except RuntimeError as a:
             raise (err or a)
     stage(run.chain, "chain stage")
-    run.graph()                                   # (fails on every rank together: agreement inside the backend's edge_support)
+    # the record all-gather inside fails on every rank together (agreement in the backend's edge_support); what follows it on a rank - the
+    # import, the graph build, rank 0's GFA / stat / log files - can still fail alone, so the stage as a whole is agreed on as well
+    stage(run.graph, "graph stage")
     stage(lambda: (run.coords(), run.consensus()), "coordinate / consensus stage")
     return gather_results(run, device, group)
 

@@ -95,7 +95,9 @@ int hx_edge_records_import(hx_ctx*, const void* src_device, uint64_t n_records, 
  *                          edge-support records, all-gathers the packed records (ONE ncclAllGather, padded to the largest shard; counts are
  *                          exchanged through the process's memory), imports the concatenation (rank order = read order), sorts and segments:
  *                          `out` like hx_edge_support, identical on every rank (bbg_build_graph's multiset, Backbone_graph.cpp:148-171).
- *                          The ranks agree on failure before the collective: if one fails, all return an error, none hangs.
+ *                          The ranks agree on failure before the collective: if one fails there (emission, export, buffers), all return an error, none
+ *                          hangs. A failure INSIDE the collective (ncclAllGather returning an error on one rank, a device fault on its stream) is not
+ *                          covered: the other ranks are then waiting on the collective's stream and RCCL's own abort / watchdog ends them.
  *   hx_group_backend_fill  the rank's hx_backend table: its own chain / coordinate / consensus operators, hx_edge_merge as edge_support
  *   hx_group_exchange_stats  bytes of records exchanged by the last hx_edge_merge and its wall time in ms */
 typedef struct hx_group hx_group;

@@ -22,20 +22,26 @@
 // in the order it was computed. spoa 1.1.3 exits on invalid input; this header throws std::runtime_error with the
 // library's message instead (there is no CPU fallback: without a HIP device every consensus fails loudly).
 //
-// Threads: the reference calls from gopt.num_threads pthreads, each with its own engine and graph. All of them share
-// one device context here (created on first use, device HASLR_DEVICE or 0), guarded by a mutex: correct, but one edge
-// at a time keeps a 256-CU GPU mostly idle. spoa::hx::consensus_batch() below is the entry to use from new code: all
-// edges in one call (that is what haslr_amd's own pipeline does through hx_poa_batch).
+// Threads: the reference calls from gopt.num_threads pthreads, each with its own engine and graph (asm_cal_cns_seq_MT, Assemble.cpp:562-605).
+// All of them share one device context here (created on first use, device HASLR_DEVICE or 0), and their generate_consensus() calls are
+// FLAT-COMBINED: a caller queues its sequence set; the first one in becomes the submitter, waits HASLR_SPOA_BATCH_US microseconds (default
+// 200) or until HASLR_SPOA_BATCH sets (default 256) are queued, and sends everything queued through ONE hx_poa_sequences call; callers that
+// arrive while a call is on the device form the next batch. With -t 64 the reference's own thread fan-out therefore puts ~64 edges into
+// every launch instead of one. spoa::hx::consensus_batch() below is the entry to use from new code: all edges in one call (that is what
+// haslr_amd's own pipeline does through hx_poa_batch). spoa::hx::stats() tells how many device calls served how many sets.
 //
 // This is product code. It is never used to build oracle/_ref (a reference build must not be made with stand-in
 // headers): tests/test_spoa_header.py compiles a small caller written against the five symbols, nothing else.
 #ifndef HASLR_SPOA_HX_HPP
 #define HASLR_SPOA_HX_HPP
+#include <chrono>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
+#include <algorithm>
 #include <string>
 #include <utility>
 #include <vector>
@@ -51,9 +57,16 @@ namespace hx {
 
 struct Device {
     hx_ctx* ctx = nullptr;
-    std::mutex mu;
+    std::mutex mu;                    // guards ctx and every call into it
+    // flat combining of concurrent generate_consensus() calls
+    struct Request { const std::vector<std::string>* seqs; std::int8_t m, n, g; std::string result, error; bool done; };
+    std::mutex qmu;
+    std::condition_variable qcv;
+    std::vector<Request*> queue;
+    bool submitting = false;          // a submitter is collecting or has a batch on the device
+    std::uint64_t calls = 0, sets = 0;
     // (no destructor: this object is destroyed during static destruction, possibly after the HIP runtime has torn itself down -
-    //  the context and its device memory are left to the end of the process)
+    //  the context and its device memory are left to the end of the process; spoa::hx::shutdown() releases them explicitly)
 };
 inline Device& device() {
     static Device d;
@@ -61,18 +74,32 @@ inline Device& device() {
 }
 inline hx_ctx* context_locked(Device& d) {   // call with d.mu held
     if (!d.ctx) {
+        // before HIP initialises: the POA launch classes overlap on separate hardware queues (include/haslr_hip.h; an application's own setting wins)
+        setenv("GPU_MAX_HW_QUEUES", "8", 0);
         const char* dev = std::getenv("HASLR_DEVICE");
         if (hx_ctx_create(dev ? std::atoi(dev) : 0, nullptr, &d.ctx) != 0) throw std::runtime_error(std::string("spoa_hx: ") + hx_last_error());
     }
     return d.ctx;
 }
+// releases the shared device context (optional: call it when no Graph is in use any more, before main returns)
+inline void shutdown() {
+    Device& d = device();
+    std::lock_guard<std::mutex> lock(d.mu);
+    if (d.ctx) { hx_ctx_destroy(d.ctx); d.ctx = nullptr; }
+}
+struct Stats { std::uint64_t device_calls, sets; };
+inline Stats stats() {
+    Device& d = device();
+    std::lock_guard<std::mutex> lock(d.qmu);
+    return Stats{d.calls, d.sets};
+}
 
 // consensus of every set of sequences (set = the sub-sequences of one edge in alignment order) in ONE device call
-inline std::vector<std::string> consensus_batch(const std::vector<std::vector<std::string>>& sets, std::int8_t m = 5, std::int8_t n = -4, std::int8_t g = -8) {
+inline std::vector<std::string> consensus_batch(const std::vector<const std::vector<std::string>*>& sets, std::int8_t m = 5, std::int8_t n = -4, std::int8_t g = -8) {
     std::vector<std::uint64_t> set_off{0}, seq_off{0};
     std::string bases;
-    for (const auto& st : sets) {
-        for (const auto& s : st) { bases += s; seq_off.push_back(bases.size()); }
+    for (const auto* st : sets) {
+        for (const auto& s : *st) { bases += s; seq_off.push_back(bases.size()); }
         set_off.push_back(seq_off.size() - 1);
     }
     const hx_poa_params pp{m, n, g};
@@ -86,6 +113,57 @@ inline std::vector<std::string> consensus_batch(const std::vector<std::vector<st
     for (std::size_t i = 0; i < sets.size(); i++) res[i].assign(out.cns + out.cns_off[i], out.cns + out.cns_off[i + 1]);
     hx_free_cns(ctx, &out);
     return res;
+}
+inline std::vector<std::string> consensus_batch(const std::vector<std::vector<std::string>>& sets, std::int8_t m = 5, std::int8_t n = -4, std::int8_t g = -8) {
+    std::vector<const std::vector<std::string>*> p;
+    for (const auto& st : sets) p.push_back(&st);
+    return consensus_batch(p, m, n, g);
+}
+
+// one set on behalf of one caller thread, combined with whatever other threads have queued (see "Threads" above)
+inline std::string consensus_combined(const std::vector<std::string>& seqs, std::int8_t m, std::int8_t n, std::int8_t g) {
+    Device& d = device();
+    static const long window_us = std::getenv("HASLR_SPOA_BATCH_US") ? std::atol(std::getenv("HASLR_SPOA_BATCH_US")) : 200;
+    static const std::size_t batch_max = std::getenv("HASLR_SPOA_BATCH") ? (std::size_t)std::max(1L, std::atol(std::getenv("HASLR_SPOA_BATCH"))) : 256;
+    Device::Request me{&seqs, m, n, g, std::string(), std::string(), false};
+    std::unique_lock<std::mutex> lk(d.qmu);
+    d.queue.push_back(&me);
+    d.qcv.notify_all();                                        // (a submitter that is collecting counts the queue)
+    while (!me.done) {
+        if (d.submitting) { d.qcv.wait(lk); continue; }         // somebody else submits: my request rides along, or waits for the next batch
+        d.submitting = true;                                    // I submit: collect for the window, then take everything queued
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us);
+        while (d.queue.size() < batch_max && d.qcv.wait_until(lk, until) != std::cv_status::timeout) { }
+        std::vector<Device::Request*> batch;
+        batch.swap(d.queue);
+        if (batch.size() > batch_max) { d.queue.assign(batch.begin() + (std::ptrdiff_t)batch_max, batch.end()); batch.resize(batch_max); }
+        lk.unlock();
+        // one device call per score triple in the batch (the reference uses one triple)
+        std::vector<char> served(batch.size(), 0);
+        std::uint64_t calls = 0;
+        for (std::size_t i = 0; i < batch.size(); i++) {
+            if (served[i]) continue;
+            std::vector<std::size_t> idx;
+            std::vector<const std::vector<std::string>*> sets;
+            for (std::size_t j = i; j < batch.size(); j++)
+                if (!served[j] && batch[j]->m == batch[i]->m && batch[j]->n == batch[i]->n && batch[j]->g == batch[i]->g) { idx.push_back(j); sets.push_back(batch[j]->seqs); served[j] = 1; }
+            try {
+                std::vector<std::string> res = consensus_batch(sets, batch[i]->m, batch[i]->n, batch[i]->g);
+                for (std::size_t q = 0; q < idx.size(); q++) batch[idx[q]]->result.swap(res[q]);
+            } catch (const std::exception& e) {
+                for (std::size_t q : idx) batch[q]->error = e.what();
+            }
+            calls++;
+        }
+        lk.lock();
+        for (Device::Request* r : batch) r->done = true;
+        d.calls += calls; d.sets += batch.size();
+        d.submitting = false;
+        d.qcv.notify_all();
+    }
+    lk.unlock();
+    if (!me.error.empty()) throw std::runtime_error(me.error);
+    return me.result;
 }
 
 }  // namespace hx
@@ -103,7 +181,7 @@ public:
     // spoa::Graph::generate_consensus()
     std::string generate_consensus() {
         if (sequences_.empty()) return std::string();
-        return hx::consensus_batch({sequences_}, m_, n_, g_)[0];
+        return hx::consensus_combined(sequences_, m_, n_, g_);
     }
 
 private:

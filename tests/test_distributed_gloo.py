@@ -11,6 +11,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -236,7 +237,8 @@ table = T.Backend()
 C.memmove(C.byref(table), C.byref(ob.table), C.sizeof(T.Backend))
 proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(T.CoordsOut))
 cb = proto(lambda *_: -1)
-if rank == 1:
+fail_at = sys.argv[3]
+if rank == 1 and fail_at == "coords":
     table.edge_coords = C.cast(cb, C.c_void_p).value      # this rank's coordinate operator fails
 
 
@@ -245,6 +247,8 @@ class Rec:                                              # the oracle's edge_supp
     def emit(self): return 0
     def export(self, n): return torch.zeros(1, dtype=torch.uint8)
     def import_(self, merged, total, out):
+        if rank == 1 and fail_at == "graph":             # AFTER the record all-gather (the import, the graph build, rank 0's files): this rank alone fails
+            return -1
         proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(T.Params), C.POINTER(T.EdgesOut))
         return proto(ob.table.edge_support)(ob.table.ctx, C.byref(prm), out)
 
@@ -262,15 +266,16 @@ os._exit(code)
 '''
 
 
-def test_failure_on_one_rank_stops_every_rank(sim, built, tmp_path):
-    """a rank whose coordinate stage fails: the ranks agree before the results all-gather, so every rank raises within seconds instead of
-    waiting in the collective for the gloo / RCCL watchdog"""
+@pytest.mark.parametrize("fail_at,port", [("coords", "29527"), ("graph", "29529")])
+def test_failure_on_one_rank_stops_every_rank(sim, built, tmp_path, fail_at, port):
+    """a rank whose coordinate stage - or whose graph stage, after the record all-gather - fails: the ranks agree after every stage, so every
+    rank raises within seconds instead of waiting in the next collective for the gloo / RCCL watchdog"""
     pre = sim("--genome-len", "120000", "--seed", "77", "--variant-per-mb", "30", "--cov", "12")
     w = tmp_path / "worker_fail.py"
     w.write_text(FAIL_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
-                        "--master-port", "29527", str(w), ROOT, pre], env=env, capture_output=True, text=True, timeout=300)
+                        "--master-port", port, str(w), ROOT, pre, fail_at], env=env, capture_output=True, text=True, timeout=300)
     out = r.stdout + r.stderr
     assert r.returncode != 0
     for k in range(3):

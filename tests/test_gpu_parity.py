@@ -110,6 +110,36 @@ def test_golden_fixtures_through_hip(case, sim, ctx, tmp_path):
     assert util.edge_supp_text(run.edges_out(sides=False)) == gzip.open(os.path.join(exp, "edge_supp.01.txt.gz"), "rt").read()
 
 
+def test_cli_with_threaded_cleaning_equals_the_reference_fixture(sim, built, tmp_path):
+    """SURVEY 8f #3 under the driver's eyes: the haslr_assemble binary on the fixture where all four cleaning passes fire (tips, simple / super / small
+    bubbles), with the host-parallel formulation of the passes forced on (HASLR_CLEAN_THREADS=16; by default it starts at 200 000 nodes), against
+    the GFA / stat / log files the COMPILED REFERENCE wrote for these inputs"""
+    cd = os.path.join(GOLD, "nanopore_rich_300k_s5")
+    man = json.load(open(os.path.join(cd, "manifest.json")))
+    pre = sim(*man["hxsim_args"])
+    for k, h in man["inputs"].items():
+        if util.sha256_file(pre + k) != h:
+            pytest.skip("generator bytes differ from fixture")
+    exe = os.path.join(ROOT, "haslr_amd", "bin", "haslr_assemble")
+    out = tmp_path / "cli16"
+    r = subprocess.run([exe, "-t", "16", "-c", pre + ".contigs.fa", "-l", pre + ".reads.fa", "-m", pre + ".paf", "-d", str(out)],
+                       capture_output=True, text=True, env=dict(os.environ, HASLR_CLEAN_THREADS="16", HASLR_GRAPH_DEBUG="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "cleaning passes on 16 threads" in r.stderr, r.stderr[-2000:]
+    exp = os.path.join(cd, "expected")
+    checked = 0
+    for f in sorted(os.listdir(exp)):
+        if f.endswith(".skel"):
+            assert util.sha256_file(os.path.join(out, f[:-5])) == man["outputs"][f[:-5]], f
+            checked += 1
+        elif not f.endswith(".gz") and f != "uniq_freq.txt":
+            assert open(os.path.join(out, f)).read() == open(os.path.join(exp, f)).read(), f
+            checked += 1
+    assert checked >= 18
+    for log, what in (("backbone.03.tip.log", 1), ("backbone.04.simplebubble.log", 1), ("backbone.05.superbubble.log", 1), ("backbone.06.smallbubble.log", 1)):
+        assert os.path.getsize(os.path.join(out, log)) > 0, log   # every pass did something on this graph
+
+
 def test_against_compiled_reference_front_half(sim, ctx, ref_front, tmp_path):
     pre = sim("--genome-len", "110000", "--seed", "31", "--variant-per-mb", "40", "--cov", "14")
     rd = tmp_path / "ref"

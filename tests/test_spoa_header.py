@@ -15,7 +15,7 @@ def caller(built, tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("spoa") / "spoa_caller")
     lib = os.path.join(ROOT, "haslr_amd", "lib")
     subprocess.check_call(["g++", "-O2", "-std=c++11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "spoa_caller.cpp"), "-o", exe,
-                           "-L", lib, "-lhaslr_hip", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"])
+                           "-L", lib, "-lhaslr_hip", "-pthread", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
 
@@ -49,3 +49,20 @@ def test_caller_returns_the_oracle_consensus(caller, mode):
     assert r.returncode == 0, r.stderr
     want = [orclib.poa_consensus([q for q in st if q != "-"]) for st in ss]
     assert r.stdout.split("\n")[:-1] == want
+
+
+@pytest.mark.gpu
+def test_concurrent_callers_are_combined_into_few_device_calls(caller):
+    """the reference's own fan-out (asm_cal_cns_seq_MT: N pthreads, an engine + a graph each, Assemble.cpp:562-605) through the five symbols: 16 threads
+    over 128 edges return the oracle's consensus for every edge, and their generate_consensus() calls are flat-combined - at most 128 / 8 device calls"""
+    import orclib
+    rnd = random.Random(9)
+    ss = []
+    for k in range(128):
+        t = "".join(rnd.choice("ACGT") for _ in range(rnd.randrange(60, 700)))
+        ss.append(["".join(c for c in t if rnd.random() > 0.07) for _ in range(rnd.randrange(3, 9))])
+    r = subprocess.run([caller, "--threads", "16"], input=text(ss), capture_output=True, text=True, env=dict(os.environ, HASLR_SPOA_BATCH_US="3000"))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split("\n")[:-1] == [orclib.poa_consensus(st) for st in ss]
+    calls = int(r.stderr.split("device_calls=")[1].split()[0])
+    assert int(r.stderr.split("sets=")[1].split()[0]) == 128 and calls <= 16, r.stderr

@@ -4,6 +4,8 @@ import os, sys, time
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 sys.path.insert(0, ROOT)
 from haslr_amd import hip, host
+if os.environ.get('HASLR_DEV_LIBDIR'):   # (development: another build of libhaslr_hip.so)
+    hip._LIBDIR = os.environ['HASLR_DEV_LIBDIR']
 pre, world = sys.argv[1], int(sys.argv[2])
 ranks = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else list(range(world))
 ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf", threads=min(32, os.cpu_count() or 1))
