@@ -641,15 +641,19 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     // dependent instructions - so the ring is cut to HX_POA_RING_KB per wave and several workgroups share a CU.
     const bool many_edges = todo.size() > kManyEdges;
     const uint64_t ring_kb_wave = getenv("HX_POA_RING_KB") ? (uint64_t)std::max(1, atoi(getenv("HX_POA_RING_KB"))) : many_edges ? 11 : 0;   // 0 = no cut
-    auto ring_rows_of = [ring_kb_wave](uint32_t nt, uint32_t cm, uint64_t& row_bytes) -> uint32_t {   // kept rows the LDS ring holds; row_bytes returns the ring's LDS bytes
-        row_bytes = (uint64_t)cm * (nt / 64) * 65 * 4;   // planes of 65 words per wave
+    // Packed 16-bit rows (kernels/poa.hip dp_rows16; HX_POA_PK16=0 switches them off): every direction-byte launch with 4 or 8 columns per lane, when the scores fit
+    const bool pk_on = !(getenv("HX_POA_PK16") && atoi(getenv("HX_POA_PK16")) == 0);
+    auto pk_of = [&](uint32_t cm, bool dir) -> bool { return pk_on && dir && cm <= 8 && hxk::poa_pk16_ok(pp->match, pp->mismatch, pp->gap, (int)cm); };
+    auto ring_rows_of = [ring_kb_wave](uint32_t nt, uint32_t cm, bool pk, uint64_t& row_bytes) -> uint32_t {   // kept rows the LDS ring holds; row_bytes returns the LDS bytes of the ring (+ the score registers of packed rows)
+        row_bytes = (uint64_t)(pk ? cm / 2 : cm) * (nt / 64) * 65 * 4;   // planes of 65 words per wave
+        const uint64_t tbl = pk ? (uint64_t)(nt / 64) * 512 * cm : 0;   // packed rows: 4 letters x 64 lanes x cm / 2 registers per wave
         uint64_t lds_budget = nt >= 1024 ? 128 * 1024 : nt == 64 ? 32 * 1024 : 64 * 1024 * (nt / 128 > 2 ? 2 : 1);
-        if (ring_kb_wave) lds_budget = std::min<uint64_t>(lds_budget, std::max<uint64_t>(ring_kb_wave * 1024 * (nt / 64), 2 * row_bytes));
-        if (2 * row_bytes > lds_budget) lds_budget = kPoaLdsMax;   // wide rows: whatever the CU has
-        const uint64_t rows_fit = std::min<uint64_t>(lds_budget, kPoaLdsMax) / row_bytes;
+        if (ring_kb_wave) lds_budget = std::min<uint64_t>(lds_budget, std::max<uint64_t>(ring_kb_wave * 1024 * (nt / 64), 2 * row_bytes + tbl));
+        if (2 * row_bytes + tbl > lds_budget) lds_budget = kPoaLdsMax;   // wide rows: whatever the CU has
+        const uint64_t rows_fit = (std::min<uint64_t>(lds_budget, kPoaLdsMax) - std::min<uint64_t>(tbl, kPoaLdsMax)) / row_bytes;
         uint32_t R = rows_fit >= 8 ? 8 : rows_fit >= 4 ? 4 : rows_fit >= 2 ? 2 : 0;   // kept rows: a power of two (slot = kept-row counter & (R-1)); 0 = every kept row goes through HBM
         if (getenv("HX_POA_RING_ZERO")) R = 0;                          // (testing: the ring-less mode that otherwise only gaps above 16 383 columns in ONE workgroup reach)
-        row_bytes *= std::max<uint32_t>(R, 1);                          // -> LDS bytes of the ring (at least one row's worth: the kernel's other phases use the space too)
+        row_bytes = row_bytes * std::max<uint32_t>(R, 1) + tbl;         // -> LDS bytes (at least one row's worth: the kernel's other phases use the space too)
         return R;
     };
     auto cm_round = [](uint32_t ncol, uint32_t lanes) -> uint32_t { uint32_t cm = (ncol + lanes - 1) / lanes, r = 4; while (r < cm) r <<= 1; return r; };
@@ -710,7 +714,8 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             hxk::PoaEdge& E = P.edges[e];
             const uint32_t ncol = E.lmax + 1, nt = E.members > 1 ? cl_lanes : (uint32_t)kClassNT[class_of(e)];
             uint64_t rb;
-            const uint32_t Rp = ring_rows_of(nt, cm_round(ncol, E.members > 1 ? E.members * cl_lanes : nt), rb);
+            const uint32_t cmq = cm_round(ncol, E.members > 1 ? E.members * cl_lanes : nt);
+            const uint32_t Rp = ring_rows_of(nt, cmq, pk_of(cmq, !full_h[e]), rb);
             // measured on PacBio-like data, rows read back from HBM per DP row: 0.15-0.4 % with 8 ring rows, 3-5 % with 4, 16-25 % on average
             // with 2 (single edges: up to every kept row, ~60 % of the rows). Graphs fill ~70 % of the node estimate these are fractions of.
             uint32_t est = far_rows >= 0 ? (uint32_t)far_rows : Rp >= 8 ? E.vcap / 32 + 256 : Rp >= 4 ? E.vcap / 8 + 256 : Rp >= 2 ? E.vcap / 2 + 256 : E.vcap + 1;
@@ -746,7 +751,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
         auto need_bytes = [](const Need& n) -> uint64_t { return n.nn * 90 + n.ec * 28 + n.hc * 4 + n.dc + n.wc + n.lm + n.st * 4 + n.al * 8; };
         // launch classes: (shared?, lanes per workgroup, columns per lane, traceback flavour) - one kernel instance each, so that every
         // launch runs with the registers ITS row loop needs (kernels/poa.hip)
-        struct Cls { bool shared; uint32_t nt, cm; bool dir; uint32_t dpl = 0 /* lanes in the DP when the workgroups are wider (wide cluster members), else 0 */; std::vector<uint32_t> edges; size_t blocks = 0, order_at = 0, slot_at = 0, n_slots = 0; Need need{}; bool persistent = false; };
+        struct Cls { bool shared; uint32_t nt, cm; bool dir; uint32_t dpl = 0 /* lanes in the DP when the workgroups are wider (wide cluster members), else 0 */; std::vector<uint32_t> edges; size_t blocks = 0, order_at = 0, slot_at = 0, n_slots = 0; Need need{}; bool persistent = false; bool pk = false /* packed 16-bit rows */; };
         auto build_classes = [&](const std::vector<uint32_t>& batch, std::vector<Cls>& classes) -> int {
             classes.clear();
             auto cls_of = [&](bool shared, uint32_t nt, uint32_t cm, bool dir, uint32_t dpl = 0) -> Cls& {
@@ -787,6 +792,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             });
             for (Cls& q : classes) {
                 q.need = Need{};
+                q.pk = pk_of(q.cm, q.dir);
                 for (uint32_t e : q.edges) need_max(q.need, need_of(e));
             }
             return 0;
@@ -948,7 +954,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                 // LDS of the launch: the ring its row width allows, a power of two of kept rows
                 uint64_t ring_need = 0;
                 const uint32_t dp_nt = q.dpl ? q.dpl : q.nt;   // lanes in the DP
-                const uint32_t R = ring_rows_of(dp_nt, q.cm, ring_need);
+                const uint32_t R = ring_rows_of(dp_nt, q.cm, q.pk, ring_need);
                 // few edges: ask for enough LDS per workgroup that the dispatcher cannot stack them on a handful of CUs while others idle
                 // (a lone wave runs at twice the speed of two waves sharing a SIMD); many edges: request only what the ring needs
                 uint64_t lds_bytes = ring_need;
@@ -966,7 +972,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                 HIPCHK(hipStreamWaitEvent(c->poa_streams[sk], c->poa_ev[8], 0));
                 hxk::poa_run(d_edges.p, d_order.p + q.order_at, q.persistent ? (uint32_t)q.edges.size() : (uint32_t)q.blocks, c->poa_slots.p + (q.persistent ? q.slot_at : 0), q.persistent ? c->poa_counters.p + ci : nullptr,
                              (uint32_t)q.blocks, d_seqs.p, in.d_packed, in.d_roff, in.d_rlen, pools, pp->match, pp->mismatch,
-                             pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)q.nt, (int)q.cm, poll_limit, (uint32_t)lds_bytes, q.dir, max_indeg, q.dpl, c->poa_streams[sk]);
+                             pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)q.nt, (int)q.cm, poll_limit, (uint32_t)lds_bytes, q.dir, max_indeg, q.dpl, q.pk, c->poa_streams[sk]);
                 HIPCHK(hipEventRecord(c->poa_ev[sk], c->poa_streams[sk]));
                 HIPCHK(hipStreamWaitEvent(s, c->poa_ev[sk], 0));
                 if (q.dpl) {
@@ -984,7 +990,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             if (getenv("HX_DEBUG")) {
                 HIPCHK(hipStreamSynchronize(s));
                 fprintf(stderr, "[hx] POA batch: %zu edges, %.2f GB workspace, workgroups", batch.size(), bytes / 1e9);
-                for (const Cls& q : classes) fprintf(stderr, " %s%s%s%ux%u:%zu(%zu edges, largest %.1f MB)", q.shared ? "shared/" : "", q.persistent ? "persistent/" : "", q.dir ? "" : "matrix/", q.nt, q.cm, q.blocks, q.edges.size(), need_bytes(q.need) / 1e6);
+                for (const Cls& q : classes) fprintf(stderr, " %s%s%s%s%ux%u:%zu(%zu edges, largest %.1f MB)", q.shared ? "shared/" : "", q.persistent ? "persistent/" : "", q.dir ? "" : "matrix/", q.pk ? "pk16/" : "", q.nt, q.cm, q.blocks, q.edges.size(), need_bytes(q.need) / 1e6);
                 fprintf(stderr, ", %.1f ms since the call began\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count());
             }
             std::vector<uint32_t> h_len(ne), h_status(ne);
@@ -1095,6 +1101,17 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
     }
     if (getenv("HX_DEBUG") && ne) {
         const unsigned long long* q = &c->poa_phase[(size_t)c->dbg_slowest * 12];
+        if (getenv("HX_PROF2")) {   // (a build with -DHX_DP_PROF -DHX_DP_PROF2: where member 0's DP phase goes, for the five longest edges)
+            std::vector<std::pair<unsigned long long, uint32_t>> tt;
+            for (size_t e = 0; e < ne; e++) { unsigned long long t = 0; for (int k = 0; k < 6; k++) t += c->poa_phase[e * 12 + k]; tt.push_back({t, (uint32_t)e}); }
+            std::sort(tt.rbegin(), tt.rend());
+            for (size_t k = 0; k < std::min<size_t>(5, tt.size()); k++) {
+                const unsigned long long* q2 = &c->poa_phase[(size_t)tt[k].second * 12];
+                fprintf(stderr, "[hx] prof2 edge %u lmax=%u nseq=%u dp phase %llu: publish %llu own columns %llu wait members %llu end node %llu (ties sorted %llu, toposort %llu)\n", tt[k].second, c->dbg_lmax[tt[k].second],
+                        c->dbg_nseq[tt[k].second], q2[1], q2[6], q2[7], q2[8], q2[9], q2[10], q2[11]);
+            }
+            return (uint32_t)ne;
+        }
         if (getenv("HX_PROF3")) {   // (a build with -DHX_DP_PROF3: per member of the five longest edges, kilocycles inside the DP and of them waiting for carries)
             std::vector<std::pair<unsigned long long, uint32_t>> tt;
             for (size_t e = 0; e < ne; e++) { unsigned long long t = 0; for (int k = 0; k < 6; k++) t += c->poa_phase[e * 12 + k]; tt.push_back({t, (uint32_t)e}); }

@@ -136,7 +136,15 @@ struct PoaPools {
 // kernel instance (largest workgroup it is compiled for) that serves workgroups of `block_threads` lanes, and the columns per lane it can be had with
 inline int poa_kernel_lanes(int block_threads) { return block_threads <= 64 ? 64 : block_threads <= 256 ? 256 : block_threads <= 512 ? 512 : 1024; }
 inline int poa_kernel_max_cm(int block_threads) { return block_threads <= 256 ? 32 : block_threads <= 512 ? 16 : 32; }
-inline bool poa_persistent_ok(bool use_dir) { return use_dir; }   // launches that can run persistent (the score-matrix flavour is rare: one workgroup per edge)
+inline bool poa_persistent_ok(bool use_dir) { return use_dir; }
+// Packed 16-bit rows (kernels/poa.hip, dp_rows16): a key is 512 + 4 Xr + type with 0 <= Xr <= (match - 2 gap) x the columns of one wave, and a candidate
+// carries up to 4 (match - 2 gap) + 3 more before its frame shift is taken off: all of it must stay below 2^16. True for the reference's 5 / -4 / -8 with 4 or 8
+// columns per lane (43 610 at 8); other scores fall back to the int32 rows.
+inline bool poa_pk16_ok(int match, int mismatch, int gap, int cm) {
+    if (!(cm == 4 || cm == 8) || gap >= 0 || match <= 0 || mismatch > match) return false;
+    const long long span = 4ll * (match - 2ll * gap);
+    return 512 + span * 64 * cm + 3 + span + 3 <= 65535 && -4ll * gap <= 4096;
+}   // launches that can run persistent (the score-matrix flavour is rare: one workgroup per edge)
 // One launch of a class. counter == nullptr: one workgroup per entry of `order` (edge | member << 24; shared edges, each in its own slot
 // PoaEdge::slot); else PERSISTENT: n_blocks workgroups, workgroup b owns slots[b] and pulls the n_items edges of `order` through *counter.
 void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_items, const PoaSlot* slots, uint32_t* counter, uint32_t n_blocks, const PoaSeq* seqs, const uint8_t* packed,
@@ -145,7 +153,8 @@ void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_items, cons
              unsigned long long* cells, unsigned long long* phase_cycles /* 12 per edge or null */, int block_threads /* multiple of 64, <= 1024 */,
              int cm /* columns per lane of the launch: 4, 8, 16 or 32; every edge's longest sequence fits members x block_threads x cm columns */,
              uint32_t poll_limit /* polls before a wave gives up waiting for another (-> HXE_POA_STALLED) */, uint32_t ring_bytes /* dynamic LDS */,
-             bool use_dir /* direction-byte traceback (in-degrees <= max_indeg <= 16, else the edge comes back with HXE_POA_NODIR) */, uint32_t max_indeg, uint32_t dp_lanes /* 0: every lane of the workgroup; else the lanes that take part in the DP (a wide cluster member) */, hipStream_t s);
+             bool use_dir /* direction-byte traceback (in-degrees <= max_indeg <= 16, else the edge comes back with HXE_POA_NODIR) */, uint32_t max_indeg, uint32_t dp_lanes /* 0: every lane of the workgroup; else the lanes that take part in the DP (a wide cluster member) */,
+             bool pk16 /* packed 16-bit rows (use_dir, cm 4 or 8, poa_pk16_ok): ring_bytes then holds the ring of packed rows AND 1 KB x cm / 2 per DP wave of score registers */, hipStream_t s);
 
 }  // namespace hxk
 #endif

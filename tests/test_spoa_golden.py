@@ -3,6 +3,8 @@
 some; from then on the oracle (CPU) and the HIP kernel (through the C-ABI entry spoa_hx.hpp calls) are pinned to the
 real library without any code change. Reference call sites: Assemble.cpp:499,500,539,540,554."""
 import glob
+import gzip
+import hashlib
 import json
 import os
 
@@ -58,3 +60,52 @@ def test_hip_against_spoa_vectors(built):
                 assert have == want, name
     finally:
         ctx.close()
+
+
+# ---- the committed INPUT sets (tests/golden/spoa/inputs): ready for a maintainer's make_spoa_vectors call; until then they pin the oracle and
+# the kernel to the digests recorded when the sets were made
+def load_inputs(name):
+    cases = []
+    for para in gzip.open(os.path.join(GOLD, "inputs", name), "rt").read().split("\n\n"):
+        ls = [x for x in para.split("\n") if x]
+        if ls:
+            assert ls[0][0] == ">"
+            cases.append((ls[0][1:], [s for s in ls[1:] if s != "-"]))
+    return cases
+
+
+INPUTS = json.load(open(os.path.join(GOLD, "inputs", "manifest.json")))
+
+
+@pytest.mark.parametrize("name", sorted(INPUTS))
+def test_committed_inputs_oracle_digest(name):
+    cases = load_inputs(name)
+    assert len(cases) == INPUTS[name]["cases"]
+    if name != "pacbio25.sequences.txt.gz":
+        cases = cases[:12]                                   # (CPU suite: the whole first set, a slice of the others; the gpu test takes all)
+        h = None
+    else:
+        h = hashlib.sha256()
+    for nm, seqs in cases:
+        c = orclib.poa_consensus(seqs)
+        assert set(c) <= set("ACGT") and (len(c) > 0) == (len(seqs) > 0)
+        if h is not None:
+            h.update((nm + "\t" + c + "\n").encode())
+    if h is not None:
+        assert h.hexdigest() == INPUTS[name]["oracle_consensus_sha256"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(INPUTS))
+def test_committed_inputs_through_hip(name, built):
+    from haslr_amd import hip
+    cases = load_inputs(name)
+    ctx = hip.HipContext(0)
+    try:
+        got = ctx.poa_sequences([s for _, s in cases], 5, -4, -8)
+    finally:
+        ctx.close()
+    h = hashlib.sha256()
+    for (nm, _), c in zip(cases, got):
+        h.update((nm + "\t" + c + "\n").encode())
+    assert h.hexdigest() == INPUTS[name]["oracle_consensus_sha256"]

@@ -15,7 +15,7 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = hip.HipContext(0)
 os.makedirs('/tmp/fz', exist_ok=True)
 bad = 0
-KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS', 'HX_POA_BATCHES', 'HX_POA_NODE_EST_PCT', 'HX_POA_RING_KB', 'HX_POA_COLS', 'HX_POA_CLUSTER_TOPK', 'HX_POA_SLOTS', 'HX_POA_WORKSPACE_GB', 'HX_POA_FORCE_CM', 'HX_POA_RING_ZERO', 'HX_POA_WIDE_MEMBERS')
+KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS', 'HX_POA_BATCHES', 'HX_POA_NODE_EST_PCT', 'HX_POA_RING_KB', 'HX_POA_COLS', 'HX_POA_CLUSTER_TOPK', 'HX_POA_SLOTS', 'HX_POA_WORKSPACE_GB', 'HX_POA_FORCE_CM', 'HX_POA_RING_ZERO', 'HX_POA_WIDE_MEMBERS', 'HX_POA_PK16')
 for it in range(n):
     big = os.environ.get('FUZZ_BIG') is not None   # long gaps at real sizes: the default launch shapes (512-lane cluster members) get real work
     glen = rng.choice([400000, 700000, 1000000]) if big else rng.choice([40000, 60000, 90000, 150000, 250000])
@@ -56,6 +56,8 @@ for it in range(n):
         env['HX_POA_RING_ZERO'] = '1'                               # no LDS ring: every kept row is read back from HBM
     if rng.random() < 0.5:
         env['HX_POA_WIDE_MEMBERS'] = str(rng.choice([0, 1, 100]))   # shared edges with 1024-lane members (default: the 4 costliest below 3 000 edges per call)
+    if rng.random() < 0.2:
+        env['HX_POA_PK16'] = '0'                                    # the int32 rows instead of the packed 16-bit ones (round 4)
     if rng.random() < 0.25:
         env['HX_POA_NODE_EST_PCT'] = str(rng.choice([2, 10, 30, 60]))
     os.environ.update(env)
