@@ -641,8 +641,10 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     // dependent instructions - so the ring is cut to HX_POA_RING_KB per wave and several workgroups share a CU.
     const bool many_edges = todo.size() > kManyEdges;
     const uint64_t ring_kb_wave = getenv("HX_POA_RING_KB") ? (uint64_t)std::max(1, atoi(getenv("HX_POA_RING_KB"))) : many_edges ? 11 : 0;   // 0 = no cut
-    // Packed 16-bit rows (kernels/poa.hip dp_rows16; HX_POA_PK16=0 switches them off): every direction-byte launch with 4 or 8 columns per lane, when the scores fit
-    const bool pk_on = !(getenv("HX_POA_PK16") && atoi(getenv("HX_POA_PK16")) == 0);
+    // Packed 16-bit rows (kernels/poa.hip dp_rows16): every direction-byte launch with 4 or 8 columns per lane, when the scores fit. OPT-IN (HX_POA_PK16=1):
+    // bit-exact like the int32 rows, but measured slower in both regimes on gfx950 (12 Mb step 252 against 238 ms, 140 Mb consensus 2.22 against 2.10 s in the
+    // same calls) - v_pk_* are 4-cycle instructions like v_max_i32, the row's fixed part grows by a table read and a scalar frame chain
+    const bool pk_on = getenv("HX_POA_PK16") && atoi(getenv("HX_POA_PK16")) != 0;
     auto pk_of = [&](uint32_t cm, bool dir) -> bool { return pk_on && dir && cm <= 8 && hxk::poa_pk16_ok(pp->match, pp->mismatch, pp->gap, (int)cm); };
     auto ring_rows_of = [ring_kb_wave](uint32_t nt, uint32_t cm, bool pk, uint64_t& row_bytes) -> uint32_t {   // kept rows the LDS ring holds; row_bytes returns the LDS bytes of the ring (+ the score registers of packed rows)
         row_bytes = (uint64_t)(pk ? cm / 2 : cm) * (nt / 64) * 65 * 4;   // planes of 65 words per wave

@@ -1058,7 +1058,8 @@ __device__ __forceinline__ void dp_rows16(const G& g, uint32_t* __restrict__ Hp,
     const bool live = j0 <= L;
     const bool owns_last = live && L < j0 + CM;
     const uint32_t klast = owns_last ? L - j0 : 0;
-    const uint32_t hleft = W + gw;                   // far rows end with one word per wave: B of the row in that wave
+    const uint32_t hleft = (W >> 1) + gw;            // a far row: packed keys in the first W / 2 words (live chunks end below W, a multiple of the chunk), then one word per wave: 4 B of the row in that wave
+                                                     // (NOT at W + gw like dp_rows: a one-wave edge has no extra words behind W, and unlike there the word is written by every wave)
     const int g4 = 4 * gap;
     const int Bq0 = g4 * ((int)c0 - 1);              // 4 B of the virtual row 0 in this wave
     const uint32_t OFF2 = pk_dup(PK_OFF);
@@ -1358,7 +1359,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     const PoaEdge ED = edges[eidx];
     const uint32_t tid = threadIdx.x, NT = blockDim.x;
     const uint32_t DL = dp_lanes ? dp_lanes : NT;   // lanes in the DP: the whole workgroup, or the first waves of a "wide" cluster member (one wave per SIMD in the DP, sixteen in the graph phases)
-    extern __shared__ __attribute__((aligned(16))) int32_t ring[];
+    extern __shared__ int32_t ring[];   // (no alignment attribute: the packed rows' table reads are split by the compiler; with aligned(16) the int32 row loop of this build came out 10 % slower - same instructions, another layout)
     G g;
     {
         const uint64_t no = SL.node_off, eo = SL.edge_off;

@@ -388,7 +388,10 @@ def test_in_degree_retry_with_score_matrix(sim, ctx):
                                             ("-1", {"HX_POA_NODE_EST_PCT": "3"}), ("1", {"HX_POA_NODE_EST_PCT": "20", "HX_POA_BATCHES": "2"}),
                                             # persistent workgroups (what thousands of edges get): 1-3 workspace slots per launch class, every workgroup works through many edges
                                             ("-1", {"HX_POA_SLOTS": "1"}), ("1", {"HX_POA_SLOTS": "2"}), ("0", {"HX_POA_SLOTS": "3", "HX_POA_NODE_EST_PCT": "20"}),
-                                            ("-1", {"HX_POA_SLOTS": "2", "HX_POA_CLUSTER_MIN": "100000", "HX_POA_COLS": "8"})])
+                                            ("-1", {"HX_POA_SLOTS": "2", "HX_POA_CLUSTER_MIN": "100000", "HX_POA_COLS": "8"}),
+                                            # the packed 16-bit row body (opt-in): plain, far rows forced, shared edges, persistent workgroups with 8 columns per lane
+                                            ("-1", {"HX_POA_PK16": "1"}), ("1", {"HX_POA_PK16": "1"}), ("0", {"HX_POA_PK16": "1", "HX_POA_CLUSTER_MIN": "300", "HX_POA_MEMBER_LANES": "128", "HX_POA_CLUSTER_MAX": "3"}),
+                                            ("2", {"HX_POA_PK16": "1", "HX_POA_SLOTS": "2", "HX_POA_CLUSTER_MIN": "100000", "HX_POA_COLS": "8"})])
 def test_far_row_estimate_overflow_is_retried(sim, ctx, far_rows, shape):
     """with direction bytes H keeps only the rows that a successor reads after they left the LDS ring, in as many rows as the host
     estimated; an edge that needs more comes back and is redone with room for every row. Forced here by an estimate of 0..2 rows

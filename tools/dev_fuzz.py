@@ -56,8 +56,8 @@ for it in range(n):
         env['HX_POA_RING_ZERO'] = '1'                               # no LDS ring: every kept row is read back from HBM
     if rng.random() < 0.5:
         env['HX_POA_WIDE_MEMBERS'] = str(rng.choice([0, 1, 100]))   # shared edges with 1024-lane members (default: the 4 costliest below 3 000 edges per call)
-    if rng.random() < 0.2:
-        env['HX_POA_PK16'] = '0'                                    # the int32 rows instead of the packed 16-bit ones (round 4)
+    if rng.random() < 0.35:
+        env['HX_POA_PK16'] = '1'                                    # the packed 16-bit rows (round 4; opt-in) instead of the int32 ones
     if rng.random() < 0.25:
         env['HX_POA_NODE_EST_PCT'] = str(rng.choice([2, 10, 30, 60]))
     os.environ.update(env)

@@ -12,6 +12,8 @@ for step in "$@"; do
     shard4p3) pre=$(fly); HASLR_DEV_LIBDIR=$GRAFT_REPO_ROOT/haslr_amd/lib_prof3 HX_PROF3=1 HX_DEBUG=1 python tools/dev_shard_time.py $pre 4 0 2>&1 | grep "^rank\|prof3" | cut -c1-400 | tee $O/shard4p3.txt ;;
     shard4p2) pre=$(fly); HASLR_DEV_LIBDIR=$GRAFT_REPO_ROOT/haslr_amd/lib_prof2 HX_PROF2=1 HX_DEBUG=1 python tools/dev_shard_time.py $pre 4 0 2>&1 | grep "^rank\|prof2" | cut -c1-400 | tee $O/shard4p2.txt ;;
     quick) timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_poa_known_answers.py tests/test_spoa_header.py -m gpu -x -q -k "not full_size and not configs and not 65535" 2>&1 | tail -15 | tee $O/quick.txt ;;
+    quickv) timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_poa_known_answers.py tests/test_spoa_header.py -m gpu -q -k "not full_size and not configs and not 65535" 2>&1 | grep -v "^       removed" | cut -c1-600 | tail -150 | tee $O/quickv.txt ;;
+    quick0) HX_POA_PK16=0 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_poa_known_answers.py tests/test_spoa_header.py -m gpu -q -k "not full_size and not configs and not 65535" 2>&1 | grep -v "^       removed" | cut -c1-600 | tail -60 | tee $O/quick0.txt ;;
     fuzz) timeout 1500 python tools/dev_fuzz.py ${FUZZ_N:-40} ${FUZZ_SEED:-4001} > $O/fuzz.txt 2>&1; tail -n 1 $O/fuzz.txt; grep -c " OK " $O/fuzz.txt; grep -v " OK " $O/fuzz.txt | head -20 ;;
     fuzzbig) FUZZ_BIG=1 timeout 1500 python tools/dev_fuzz.py ${FUZZ_NB:-12} ${FUZZ_SEEDB:-4002} > $O/fuzzbig.txt 2>&1; tail -n 1 $O/fuzzbig.txt; grep -c " OK " $O/fuzzbig.txt; grep -v " OK " $O/fuzzbig.txt | head -20 ;;
     benchq) timeout 900 python bench.py --no-cpu-baseline --no-configs3 > $O/benchq.json 2> $O/benchq.err; python -c "
