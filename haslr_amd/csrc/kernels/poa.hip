@@ -1561,73 +1561,78 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                 (void)first;
                 sNcand = ncand; sBestI = ncand ? (int)sink_row[0] : -1; sBestKey = 0xffffffffu;
                 lds_u[8] = 0; lds_u[9] = 0; lds_u[10] = 0;   // (traceback helper: nowhere yet, not done)
-                // Ties, the usual case: all candidates sit in ONE column (aligned group) whose members are all sinks, e.g. the letters seen
-                // at the end of the gap. Such a column is entered by the reference's DFS only through its oldest member (roots are taken in
-                // node-id order, a sink is nobody's predecessor), which emits itself and then its aligned list; every later member was
-                // appended to that list when it was created, so the column appears in node-id order: the smallest id wins, no sort needed.
-                if (ncand > 1 && ncand <= 4) {
-                    const uint32_t n0 = g.rank2node[sink_row[0] - 1], na0 = g.n_aligned[n0];
-                    uint32_t grp[4] = {n0, NONE, NONE, NONE};
-                    bool ok = g.out_head[n0] == NONE;
-                    for (uint32_t q = 0; q < na0; q++) { grp[1 + q] = g.aligned[3 * n0 + q]; ok = ok && g.out_head[grp[1 + q]] == NONE; }
-                    uint32_t best_n = NONE; int best_row = -1;
-                    for (uint32_t c = 0; c < ncand && ok; c++) {
-                        const uint32_t n = g.rank2node[sink_row[c] - 1];
-                        ok = n == grp[0] || n == grp[1] || n == grp[2] || n == grp[3];
-                        if (n < best_n) { best_n = n; best_row = (int)sink_row[c]; }
+                // Ties (a quarter of all alignments have one): the winner is the candidate the REFERENCE's topological order lists first. That order is a DFS
+                // over in-edges and aligned nodes with the roots taken in node-id order (toposort above) - the whole graph, serial, 1 500 cycles per node
+                // when it has to run (36 M cycles per tie on a 20 000-node graph: 22 ties were HALF the chain of the longest edge of a 3 316-edge call).
+                // It need not run: let U be the candidates' columns (aligned groups) and everything downstream of them, closed under out-edges and
+                // aligned mates. No node outside U has a node of U among its ancestors, so neither a root outside U nor the predecessors a node of U
+                // has outside U ever visit a node of U: the order in which the DFS visits, finishes and emits the nodes of U is that of the same DFS run
+                // on U alone (roots = U in id order, predecessors outside U taken as finished). Candidates are sinks at the end of the graph: U is the
+                // few letters seen at the end of the gap (at most 8 nodes in 99.7 %, never above 32 on the three committed SPOA input sets: 1 267 ties,
+                // every one decided like the full sort - the oracle's ORC_POA_TIES statistic runs the same simulation on the CPU).
+                // One lane; ids, marks and the stack sit in the LDS the ring has left. More than 32 nodes / 8 candidates: the full sort below.
+                if (ncand > 1 && ncand <= 8 && lds_bytes >= 640u) {
+                    constexpr uint32_t UCAP = 32, SCAP = 256;
+                    uint32_t* U = reinterpret_cast<uint32_t*>(ring);
+                    uint8_t* mk = reinterpret_cast<uint8_t*>(U + UCAP);
+                    uint8_t* ck = mk + UCAP;
+                    uint8_t* stk = ck + UCAP;
+                    uint32_t nu = 0, cn[8];
+                    bool ok = true;
+                    auto find = [&](uint32_t x) -> uint32_t { for (uint32_t q = 0; q < nu; q++) if (U[q] == x) return q; return NONE; };
+                    auto addcol = [&](uint32_t x) {   // a column enters U whole (its members list each other: one member in U <=> all of them)
+                        if (find(x) != NONE) return;
+                        const uint32_t na = g.n_aligned[x];
+                        if (nu + 1 + na > UCAP) { ok = false; return; }
+                        U[nu++] = x;
+                        for (uint32_t k = 0; k < na; k++) U[nu++] = g.aligned[3 * x + k];
+                    };
+                    for (uint32_t c = 0; c < ncand; c++) { cn[c] = g.rank2node[sink_row[c] - 1]; if (ok) addcol(cn[c]); }
+                    for (uint32_t q = 0; q < nu && ok; q++)
+                        for (uint32_t e = g.out_head[U[q]]; e != NONE && ok; e = g.e_next_out[e]) addcol(g.e_to[e]);
+                    if (ok) {
+                        for (uint32_t q = 1; q < nu; q++) {   // roots are taken in id order
+                            const uint32_t x = U[q]; uint32_t r = q;
+                            while (r > 0 && U[r - 1] > x) { U[r] = U[r - 1]; r--; }
+                            U[r] = x;
+                        }
+                        for (uint32_t q = 0; q < nu; q++) { mk[q] = 0; ck[q] = 1; }
+                        auto cand_of = [&](uint32_t x) -> uint32_t { for (uint32_t c = 0; c < ncand; c++) if (cn[c] == x) return c; return NONE; };
+                        uint32_t win = NONE;
+                        for (uint32_t root = 0; root < nu && win == NONE && ok; root++) {
+                            if (mk[root]) continue;
+                            uint32_t sp = 0;
+                            stk[sp++] = (uint8_t)root;
+                            while (sp && win == NONE && ok) {
+                                const uint32_t q = stk[sp - 1], n = U[q];
+                                bool valid = true;
+                                if (mk[q] != 2) {
+                                    for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) {
+                                        const uint32_t f = find(g.e_from[e]);
+                                        if (f != NONE && mk[f] != 2) { if (sp < SCAP) stk[sp++] = (uint8_t)f; else ok = false; valid = false; }
+                                    }
+                                    const uint32_t na = g.n_aligned[n];
+                                    if (ck[q])
+                                        for (uint32_t k = 0; k < na; k++) {
+                                            const uint32_t a = find(g.aligned[3 * n + k]);
+                                            if (mk[a] != 2) { if (sp < SCAP) stk[sp++] = (uint8_t)a; else ok = false; ck[a] = 0; valid = false; }
+                                        }
+                                    if (valid) {
+                                        mk[q] = 2;
+                                        if (ck[q]) {   // emitted: the node, then its aligned list in list order
+                                            win = cand_of(n);
+                                            for (uint32_t k = 0; k < na && win == NONE; k++) win = cand_of(g.aligned[3 * n + k]);
+                                        }
+                                    } else mk[q] = 1;
+                                }
+                                if (valid) sp--;
+                            }
+                        }
+                        if (ok && win != NONE) { sBestI = (int)sink_row[win]; sNcand = 1; }
                     }
-                    if (ok) { sBestI = best_row; sNcand = 1; }
                 }
             }
             __syncthreads();
-            if (sNcand > 1 && sNcand <= 4 && sOk == 1) {
-                // Ties across columns, round 4. The reference's order is SOME topological order of the graph with every aligned group ("column") contiguous -
-                // like the order the DP maintains. If the column of the candidate with the smallest maintained rank is an ANCESTOR of every other
-                // candidate's column (a path in the graph with columns contracted), it precedes them in every such order, the reference's included: no
-                // sort needed. Ties are between sinks near the end of the graph, a few columns apart, so a backward sweep over the ranks between the
-                // two columns decides (one lane; marks in the LDS the ring has left). Only incomparable columns go on to the reference's sort below - which
-                // costs 20-35 M cycles on a 20 000-node graph and was 45 % of the longest chain of a 3 316-edge call (22 ties on one edge).
-                if (tid == 0) {
-                    auto col_ext = [&](uint32_t r, uint32_t& lo, uint32_t& hi) {
-                        lo = hi = r;
-                        const uint32_t al = g.row_al[r];
-                        for (uint32_t k = 0; k < 3; k++) { const uint32_t d = (al >> (3 * k)) & 7u; if (d) { const uint32_t rr = r + d - 4u; lo = min(lo, rr); hi = max(hi, rr); } }
-                    };
-                    const uint32_t nc = sNcand;
-                    uint32_t cr[4], ia = 0;
-                    for (uint32_t q = 0; q < nc; q++) { cr[q] = sink_row[q] - 1; if (cr[q] < cr[ia]) ia = q; }
-                    uint32_t alo, ahi;
-                    col_ext(cr[ia], alo, ahi);
-                    uint8_t* mk = reinterpret_cast<uint8_t*>(ring);
-                    const uint32_t cap = min(lds_bytes, 8192u) & ~3u;
-                    bool ok = true;
-                    for (uint32_t q = 0; q < nc && ok; q++) {
-                        if (q == ia) continue;
-                        uint32_t clo, chi;
-                        col_ext(cr[q], clo, chi);
-                        if (clo <= ahi || chi - alo + 1 > cap) { ok = false; break; }   // the same column (its list order decides), or too far apart for the sweep
-                        const uint32_t span = chi - alo + 1;
-                        for (uint32_t x = 0; x < (span + 3) / 4; x++) reinterpret_cast<uint32_t*>(mk)[x] = 0u;
-                        for (uint32_t r = clo; r <= chi; r++) mk[r - alo] = 1;
-                        bool reached = false;
-                        for (uint32_t r = chi; r > ahi && !reached; r--) {       // predecessors have smaller ranks: one descending sweep
-                            if (!mk[r - alo]) continue;
-                            const uint32_t np = g.row_meta[r] >> META_NP, off = g.row_pred_off[r];
-                            for (uint32_t k = 0; k < np; k++) {
-                                const uint32_t pr = g.pred_rank[off + k] & 0x0fffffffu;
-                                if (pr < alo) continue;
-                                if (pr <= ahi) { reached = true; break; }
-                                uint32_t plo, phi;
-                                col_ext(pr, plo, phi);
-                                for (uint32_t x = plo; x <= phi; x++) mk[x - alo] = 1;   // (the whole column: a path may enter it through one member and leave through another)
-                            }
-                        }
-                        ok = reached;
-                    }
-                    if (ok) { sBestI = (int)sink_row[ia]; sNcand = 1; }
-                }
-                __syncthreads();
-            }
             if (sNcand > 1 && sOk == 1) {
                 if (tid == 0) ph[10] += 1;
                 exact_order(V, tmp_u32);

@@ -15,6 +15,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <map>
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -737,6 +738,56 @@ struct PoaAligner {
                 K.horiz(row, g, W);
             }
             if (G.outs[n].empty() && max_score < row[W - 1]) { max_score = row[W - 1]; max_i = (int64_t)i; }   // first max in rank order
+        }
+        if (getenv("ORC_POA_TIES")) {   // development statistics: how end-node ties look (what the kernel's tie shortcuts have to decide without the DFS order)
+            std::vector<size_t> cand;
+            for (size_t r = 1; r <= V; r++) if (G.outs[G.rank2node[r - 1]].empty() && H[r * W + W - 1] == max_score) cand.push_back(r);
+            if (cand.size() > 1) {
+                auto same_col = [&](uint32_t a, uint32_t b) { if (a == b) return true; for (uint32_t x : G.aligned[a]) if (x == b) return true; return false; };
+                const uint32_t n0 = G.rank2node[cand[0] - 1];
+                bool onecol = true, allsink = G.outs[n0].empty();
+                for (size_t c : cand) onecol = onecol && same_col(n0, G.rank2node[c - 1]);
+                for (uint32_t a : G.aligned[n0]) allsink = allsink && G.outs[a].empty();
+                uint32_t minid = 0xffffffffu; for (size_t c : cand) minid = std::min(minid, G.rank2node[c - 1]);
+                // the column's first emitted member (the one the DFS reached with check = 1) is the first of the column in rank order
+                size_t r0 = cand[0]; while (r0 > 1 && same_col(n0, G.rank2node[r0 - 2])) r0--;
+                const uint32_t lead = G.rank2node[r0 - 1];
+                uint32_t colmin = lead; for (uint32_t a : G.aligned[lead]) colmin = std::min(colmin, a);
+                // the local simulation the kernel uses (poa.hip, "local order"): U = the candidates' columns and everything downstream of them (closed under
+                // out-edges and aligned mates); the reference's DFS restricted to U, roots in id order, predecessors outside U taken as finished
+                {
+                    std::vector<uint32_t> U;
+                    auto inU = [&](uint32_t x) { return std::find(U.begin(), U.end(), x) != U.end(); };
+                    auto addcol = [&](uint32_t x) { if (inU(x)) return; U.push_back(x); for (uint32_t a : G.aligned[x]) if (!inU(a)) U.push_back(a); };
+                    for (size_t c : cand) addcol(G.rank2node[c - 1]);
+                    for (size_t q = 0; q < U.size() && U.size() <= 4096; q++) for (uint32_t e : G.outs[U[q]]) addcol(G.edges[e].to);
+                    std::sort(U.begin(), U.end());
+                    std::map<uint32_t, int> mk, ck;
+                    for (uint32_t u : U) { mk[u] = 0; ck[u] = 1; }
+                    std::vector<uint32_t> st; int64_t win = -1;
+                    auto is_cand = [&](uint32_t x) { for (size_t c : cand) if (G.rank2node[c - 1] == x) return true; return false; };
+                    for (uint32_t r : U) {
+                        if (win >= 0) break;
+                        if (mk[r]) continue;
+                        st.push_back(r);
+                        while (!st.empty() && win < 0) {
+                            uint32_t n = st.back(); bool valid = true;
+                            if (mk[n] != 2) {
+                                for (uint32_t e : G.in[n]) { uint32_t f = G.edges[e].from; if (mk.count(f) && mk[f] != 2) { st.push_back(f); valid = false; } }
+                                if (ck[n]) for (uint32_t a : G.aligned[n]) if (mk[a] != 2) { st.push_back(a); ck[a] = 0; valid = false; }
+                                if (valid) {
+                                    mk[n] = 2;
+                                    if (ck[n]) { if (is_cand(n)) win = n; else for (uint32_t a : G.aligned[n]) if (is_cand(a)) { win = a; break; } }
+                                } else mk[n] = 1;
+                            }
+                            if (valid) st.pop_back();
+                        }
+                    }
+                    fprintf(stderr, "POALOCAL U=%zu ok=%d\n", U.size(), (int)(win == (int64_t)G.rank2node[cand[0] - 1]));
+                }
+                fprintf(stderr, "POATIE V=%zu ncand=%zu onecol=%d allsink=%d span=%zu winner_is_min_id=%d colsize=%zu lead_is_col_min_id=%d lead_is_sink=%d winner_is_lead=%d\n", V, cand.size(), (int)onecol, (int)allsink,
+                        cand.back() - cand[0], (int)(G.rank2node[cand[0] - 1] == minid), G.aligned[n0].size() + 1, (int)(lead == colmin), (int)G.outs[lead].empty(), (int)(lead == n0));
+            }
         }
         // traceback: diagonal (in-edge order), then vertical (in-edge order), then horizontal
         size_t i = (size_t)max_i, j = W - 1;
