@@ -753,7 +753,22 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
         auto need_bytes = [](const Need& n) -> uint64_t { return n.nn * 90 + n.ec * 28 + n.hc * 4 + n.dc + n.wc + n.lm + n.st * 4 + n.al * 8; };
         // launch classes: (shared?, lanes per workgroup, columns per lane, traceback flavour) - one kernel instance each, so that every
         // launch runs with the registers ITS row loop needs (kernels/poa.hip)
-        struct Cls { bool shared; uint32_t nt, cm; bool dir; uint32_t dpl = 0 /* lanes in the DP when the workgroups are wider (wide cluster members), else 0 */; std::vector<uint32_t> edges; size_t blocks = 0, order_at = 0, slot_at = 0, n_slots = 0; Need need{}; bool persistent = false; bool pk = false /* packed 16-bit rows */; };
+        struct Cls { bool shared; uint32_t nt, cm; bool dir; uint32_t dpl = 0 /* lanes in the DP when the workgroups are wider (wide cluster members), else 0 */; std::vector<uint32_t> edges; size_t blocks = 0, order_at = 0, slot_at = 0, n_slots = 0; Need need{}; bool persistent = false; bool pk = false /* packed 16-bit rows */;
+                     double share = 0 /* of the batch's wave-slot time: DP rows x lanes reserved */; };
+        // Thousands of edges: every launch class is persistent and would, on its own, ask for the whole chip (4096 waves) - six classes oversubscribe it six
+        // times and the dispatcher deals the wave slots out as it pleases. A 1024-lane workgroup (16 waves: an EMPTY CU) can only be placed where nothing
+        // else sits, so the 1024-lane class ran on the CUs it had grabbed in the first microseconds until everything else had finished: measured at 140 Mb
+        // (profiles/r04_v1_fly_*), the classes ended at 920 / 1 130 / 1 440 / 1 730 / 1 900 ms - a tail of 0.8 s with the chip emptier and emptier.
+        // Balanced launch (HX_POA_BALANCE=0 switches it off): the classes of 512- and 1024-lane workgroups get workgroups for THEIR SHARE of the call's
+        // wave-slot time (rows x lanes reserved: a workgroup holds its lanes whether or not a gap uses them all) x HX_POA_BALANCE_PCT / 100, and a head start
+        // (HX_POA_WIDE_DELAY_US) so that they are resident before the small workgroups fragment the CUs; the small classes keep asking for the whole
+        // chip and fill what is left - and what a large class that ends early leaves. Order: the 1024-lane class, then the shared edges (their waves are the
+        // OLDEST on their SIMDs and win the issue arbitration: launched behind the 512-lane class as well, their chain - the longest of the call - took
+        // 3.6 times as long), then the rest by size. (Measured on the way: 91 workgroups of 1024 lanes launched BEHIND the shared edges end at 2 230 ms,
+        // 87 launched first at 1 540 ms - residency is the whole point.)
+        const bool balanced = many_edges && !(getenv("HX_POA_BALANCE") && atoi(getenv("HX_POA_BALANCE")) == 0);
+        const double balance_f = (getenv("HX_POA_BALANCE_PCT") ? std::max(10, atoi(getenv("HX_POA_BALANCE_PCT"))) : 125) / 100.0;
+        const uint32_t balance_nt = getenv("HX_POA_BALANCE_LANES") ? (uint32_t)atoi(getenv("HX_POA_BALANCE_LANES")) : 512;   // classes of at least this many lanes per workgroup get a share
         auto build_classes = [&](const std::vector<uint32_t>& batch, std::vector<Cls>& classes) -> int {
             classes.clear();
             auto cls_of = [&](bool shared, uint32_t nt, uint32_t cm, bool dir, uint32_t dpl = 0) -> Cls& {
@@ -786,17 +801,26 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                 cls_of(false, nt, cmq, !full_h[e]).edges.push_back(e);
             }
             // order of the launches: shared edges first (they set the duration), then by lanes; score-matrix launches after their direction-byte twins
-            std::stable_sort(classes.begin(), classes.end(), [](const Cls& a, const Cls& b) {
+            std::stable_sort(classes.begin(), classes.end(), [balanced](const Cls& a, const Cls& b) {
                 if (a.dir != b.dir) return a.dir;
+                // (balanced launch: the 1024-lane workgroups - a whole CU each - go out before anything else sits anywhere; they share no SIMD with
+                // the shared edges' members, which stay the oldest waves wherever they land)
+                if (balanced && (a.nt >= 1024 && !a.shared) != (b.nt >= 1024 && !b.shared)) return a.nt >= 1024 && !a.shared;
                 if (a.shared != b.shared) return a.shared;
                 if (a.nt != b.nt) return a.nt > b.nt;
                 return a.cm > b.cm;
             });
+            double total_cost = 0;
             for (Cls& q : classes) {
                 q.need = Need{};
                 q.pk = pk_of(q.cm, q.dir);
-                for (uint32_t e : q.edges) need_max(q.need, need_of(e));
+                for (uint32_t e : q.edges) {
+                    need_max(q.need, need_of(e));
+                    q.share += (double)P.edges[e].vcap * std::max<uint32_t>(1, P.nseq[e]) * (q.shared ? (double)P.edges[e].members * cl_lanes : (double)q.nt);   // DP rows x lanes reserved
+                }
+                total_cost += q.share;
             }
+            for (Cls& q : classes) q.share = total_cost > 0 ? q.share / total_cost : 0;
             return 0;
         };
         // Slots of a persistent class: as many workgroups as the chip holds of that size at 16 waves per CU (all classes share the CUs, but when the
@@ -807,6 +831,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
         auto slots_wanted = [&](const Cls& q, uint32_t shrink) -> size_t {
             if (q.shared) return q.edges.size();
             size_t cap = std::max<size_t>(1, ((size_t)4096 / (q.nt / 64)) * slot_scale / 100 * shrink / 1000);   // (`shrink`: per mille of the full count)
+            if (balanced && q.dir && q.nt >= balance_nt) cap = std::max<size_t>(1, std::min<size_t>(cap, (size_t)((double)cap * q.share * balance_f + 0.999)));   // the class's share of the chip
             if (slot_abs) cap = slot_abs;                                        // (testing: HX_POA_SLOTS workgroups per class, many edges each)
             return std::min(q.edges.size(), cap);
         };
@@ -945,7 +970,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                                 B.mark.p, B.check.p, B.stack.p, B.score.p, B.pred.p, B.row_code.p, B.row_sink.p, B.row_pred_off.p, B.pred_rank.p, B.row_meta.p, B.row_pred0.p, B.row_pred1.p, B.nrec.p,
                                 B.e_from.p, B.e_to.p, B.e_next_in.p, B.e_next_out.p, B.e_w.p, B.aln_node.p, B.aln_pos.p, B.H.p, B.dir.p, B.dirw.p, B.wslot.p, B.seq.p,
                                 B.mbox.p, B.csync.p, B.sinkbuf.p, B.row_al.p, B.pred_w.p};
-            const size_t n_streams = getenv("HX_POA_STREAMS") ? (size_t)std::min(8, std::max(1, atoi(getenv("HX_POA_STREAMS")))) : 6;
+            const size_t n_streams = getenv("HX_POA_STREAMS") ? (size_t)std::min(8, std::max(1, atoi(getenv("HX_POA_STREAMS")))) : 8;   // (8: a stream per launch class of a 140 Mb call - with 6, the two one-wave classes waited 130 / 300 ms behind the shared edges)
             size_t wg_total = 0;
             for (const Cls& q : classes) wg_total += q.blocks;
             c->tick();
@@ -977,7 +1002,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
                              pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)q.nt, (int)q.cm, poll_limit, (uint32_t)lds_bytes, q.dir, max_indeg, q.dpl, q.pk, c->poa_streams[sk]);
                 HIPCHK(hipEventRecord(c->poa_ev[sk], c->poa_streams[sk]));
                 HIPCHK(hipStreamWaitEvent(s, c->poa_ev[sk], 0));
-                if (q.dpl) {
+                if (q.dpl || (balanced && q.nt >= balance_nt && q.nt >= 512 && q.persistent)) {
                     // a 1024-lane workgroup needs an EMPTY CU: give the dispatcher a head start before the other launches fill the chip with small
                     // workgroups (once they have, a CU only empties when its longest resident workgroup ends)
                     static const int wide_us = getenv("HX_POA_WIDE_DELAY_US") ? atoi(getenv("HX_POA_WIDE_DELAY_US")) : 60;

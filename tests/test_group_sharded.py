@@ -83,8 +83,8 @@ def test_error_on_one_rank_ends_all_ranks(sim, tmp_path):
         ob.close()
 
 
-def _cli(args, env=None):
-    return subprocess.run([BIN] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, **(env or {})), timeout=600)
+def _cli(args, env=None, timeout=600):
+    return subprocess.run([BIN] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, **(env or {})), timeout=timeout)
 
 
 @pytest.mark.gpu
@@ -108,6 +108,32 @@ def test_binary_with_two_ranks_on_one_gpu_and_one_rank_over_rccl(sim, built, tmp
     # more ranks than devices over RCCL is refused, loudly
     bad = _cli(base + ["-d", str(tmp_path / "bad"), "--gpus", "64"], {"HASLR_GROUP_TRANSPORT": "rccl"})
     assert bad.returncode != 0 and "[ERROR]" in bad.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(bool(os.environ.get("HASLR_SKIP_HUGE")), reason="HASLR_SKIP_HUGE is set (developer runs)")
+def test_binary_with_eight_ranks_on_the_140mb_data_set(sim, built, tmp_path):
+    """configs[4]'s world size through the product binary: haslr_assemble --gpus 8 on the 140 Mb PacBio-like data set (BASELINE configs[3]'s), all eight
+    ranks on the one device of the box and the record exchange staged through host memory (what one GPU per lease allows) - every rank uploads
+    the whole input, chains its eighth of the reads, merges 1/8 of the records, aligns its LPT share of ~13 000 edges inside an eighth of the workspace -
+    and every output file equals the --gpus 1 run's."""
+    args = ("--genome-len", "140000000", "--seed", hex(0x4841534C + 3), "--model", "pacbio", "--cov", "25", "--variant-per-mb", "1.5")
+    pre = sim(*args)
+    try:
+        base = ["-t", "16", "-c", pre + ".contigs.fa", "-l", pre + ".reads.fa", "-m", pre + ".paf"]
+        one = _cli(base + ["-d", str(tmp_path / "one")])
+        assert one.returncode == 0, one.stderr[-2000:]
+        eight = _cli(base + ["-d", str(tmp_path / "eight"), "--gpus", "8"], {"HASLR_GROUP_TRANSPORT": "host", "HX_POA_WORKSPACE_GB": "24"}, timeout=1500)
+        assert eight.returncode == 0, eight.stderr[-2000:]
+        assert "8 GPU ranks in this process" in eight.stderr
+        assert util.compare_dirs(str(tmp_path / "one"), str(tmp_path / "eight")) == []
+        assert os.path.getsize(tmp_path / "one" / "asm.final.fa") > 100e6
+    finally:
+        for suffix in (".contigs.fa", ".reads.fa", ".paf", ".genome.fa", ".truth.tsv"):
+            try:
+                os.remove(pre + suffix)
+            except OSError:
+                pass
 
 
 @pytest.mark.gpu
