@@ -791,6 +791,8 @@ struct PoaAligner {
         }
         // traceback: diagonal (in-edge order), then vertical (in-edge order), then horizontal
         size_t i = (size_t)max_i, j = W - 1;
+        const bool tbstat = getenv("ORC_POA_TB") != nullptr;   // development statistics: how the traceback's steps look (runs a wave could take at once)
+        uint64_t tb_steps = 0, tb_diag = 0, tb_diag0 = 0, tb_diag0_lag1 = 0, tb_diag0_lag2 = 0, tb_runs1 = 0, tb_runs12 = 0; bool in1 = false, in12 = false;
         while (!(i == 0 && j == 0)) {
             int32_t hij = H[i * W + j];
             bool found = false;
@@ -814,8 +816,22 @@ struct PoaAligner {
             }
             if (!found) { pi_ = i; pj_ = j - 1; found = true; }   // horizontal: the only remaining source of H[i][j]
             aln.emplace_back(i == pi_ ? -1 : (int32_t)G.rank2node[i - 1], j == pj_ ? -1 : (int32_t)(j - 1));
+            if (tbstat) {
+                tb_steps++;
+                const bool diag = pi_ != i && pj_ != j;
+                bool d0 = false;
+                if (diag && i != 0) { uint32_t n = G.rank2node[i - 1]; size_t first = G.in[n].empty() ? 0 : node2rank[G.edges[G.in[n][0]].from] + 1; d0 = first == pi_; }
+                tb_diag += diag; tb_diag0 += d0;
+                const bool l1 = d0 && pi_ + 1 == i, l12 = d0 && (pi_ + 1 == i || pi_ + 2 == i);
+                tb_diag0_lag1 += l1; tb_diag0_lag2 += d0 && pi_ + 2 == i;
+                if (l1 && !in1) tb_runs1++;
+                if (l12 && !in12) tb_runs12++;
+                in1 = l1; in12 = l12;
+            }
             i = pi_; j = pj_;
         }
+        if (tbstat) fprintf(stderr, "POATB steps=%lu diag=%lu diag_slot0=%lu slot0_lag1=%lu slot0_lag2=%lu runs_lag1=%lu runs_lag12=%lu\n", (unsigned long)tb_steps, (unsigned long)tb_diag, (unsigned long)tb_diag0,
+                            (unsigned long)tb_diag0_lag1, (unsigned long)tb_diag0_lag2, (unsigned long)tb_runs1, (unsigned long)tb_runs12);
         std::reverse(aln.begin(), aln.end());
         return aln;
     }
