@@ -1128,6 +1128,18 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
     }
     if (getenv("HX_DEBUG") && ne) {
         const unsigned long long* q = &c->poa_phase[(size_t)c->dbg_slowest * 12];
+        if (getenv("HX_PROF1")) {   // (a build with -DHX_DP_PROF: where the rows of the first wave of every workgroup spend their cycles, per launch class)
+            static const char* seg[6] = {"decode", "predecessors + cells + chain", "wave scan", "carry", "carry applied + ring", "stores"};
+            unsigned long long cs[12][7] = {};
+            for (size_t e = 0; e < ne; e++) { const int k = e < c->dbg_cls.size() ? c->dbg_cls[e] : 11; for (int j = 0; j < 6; j++) cs[k][j] += c->poa_phase[e * 12 + 6 + j]; cs[k][6] += c->poa_phase[e * 12 + 1]; }
+            for (int k = 0; k < 12; k++) {
+                unsigned long long t = 0; for (int j = 0; j < 6; j++) t += cs[k][j];
+                if (!t) continue;
+                fprintf(stderr, "[hx] prof1 class %d: row segments of wave 0, %.3g cycles (DP phase %.3g):", k, (double)t, (double)cs[k][6]);
+                for (int j = 0; j < 6; j++) fprintf(stderr, " %s %.1f %%%s", seg[j], 100.0 * (double)cs[k][j] / (double)t, j < 5 ? "," : "\n");
+            }
+            return (uint32_t)ne;
+        }
         if (getenv("HX_PROF2")) {   // (a build with -DHX_DP_PROF -DHX_DP_PROF2: where member 0's DP phase goes, for the five longest edges)
             std::vector<std::pair<unsigned long long, uint32_t>> tt;
             for (size_t e = 0; e < ne; e++) { unsigned long long t = 0; for (int k = 0; k < 6; k++) t += c->poa_phase[e * 12 + k]; tt.push_back({t, (uint32_t)e}); }
