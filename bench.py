@@ -225,7 +225,7 @@ def main():
         table = backend.table
 
         def gather(run):
-            gathered[0] = hd.sharded_stages(run, comm_device)
+            gathered[0] = hd.sharded_stages(run, comm_device, backend=backend)
     else:
         table, gather = ctx.backend(), None
 

@@ -772,8 +772,8 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             left = S[(CM - 1) * PW];
         } else if (loc == 14u) {                 // a source node starts from the virtual row 0
 #pragma unroll
-            for (int k = 0; k < CM; k++) hp[k] = jg0 + k * g64;
-            left = gt > 0 ? jg0 - g64 : NEGK;
+            for (int k = 0; k < CM; k++) hp[k] = 0;   // (row 0 is the gap ramp itself)
+            left = gt > 0 ? 0 : NEGK;
         } else if (live
                    ) {                       // kept row that fell out of the ring: HBM
             // with direction bytes only the rows a far successor reads are in HBM, in the slots the CSR build gave them
@@ -783,8 +783,8 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             left = lane > 0 ? Gp[-1] : has_in ? Gp[(int64_t)hleft - (int64_t)j0] : NEGK;   // (lane 0: the wave's own copy - the column belongs to a wave that may be far ahead)
             if (!DIR) {                          // the score matrix holds plain scores
 #pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] <<= 6;
-                if (gt > 0) left <<= 6;
+                for (int k = 0; k < CM; k++) hp[k] = (hp[k] << 6) - (jg0 + k * g64);
+                if (gt > 0) left = (left << 6) - (jg0 - g64);
             }
             // the loaded values are consumed HERE: otherwise the wait for them is placed where the three sources of a predecessor row
             // join - on the path of every row - and waits for the previous rows' direction stores as well (vmcnt counts them)
@@ -851,7 +851,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 // traceback nibble as they are; a "wide" row (rare) uses type * 16 + 15 - slot and stores a byte per cell in a side pool.
                 const bool wide = !DIR || (meta & 32u);
                 const int kd = wide ? KD : 15, kv = wide ? KV : 11, kh = wide ? KH : 4;
-                const int md = m64 + kd, gv = g64 + kv, gh = g64 + kh;
+                const int md = m64 - g64 + kd, gv = g64 + kv;   // (a diagonal move leaves the ramp of column j - 1 for that of column j)
                 auto score_of = [&](int k) -> int {   // 64 x substitution score of column k + the diagonal move code
                     int neg;   // -1 on a mismatch, 0 on a match
                     if constexpr (CM <= 16) neg = __builtin_amdgcn_sbfe((int)mis, 2 * k, 1);
@@ -885,10 +885,10 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 }
                 // chunk-local horizontal recurrence (type 1 loses every tie)
 #pragma unroll
-                for (int k = 1; k < CM; k++) m[k] = max(m[k], (m[k - 1] & ~63) + gh);
+                for (int k = 1; k < CM; k++) m[k] = max(m[k], (m[k - 1] & ~63) | kh);
                 DP_T(1);   // predecessor rows + cells + horizontal chain
                 // prefix maximum over the lanes to the left of (chunk end score - its column * gap)
-                const int inc = wave_incl_max((m[CM - 1] & ~63) - (jg0 + (CM - 1) * g64));
+                const int inc = wave_incl_max(m[CM - 1] & ~63);
                 int ex = wave_shift_up1(inc, NEGK);
                 DP_T(2);   // wave scan
                 const int cin = __builtin_amdgcn_readlane(cinV, rj);   // NEGK without a wave on the left
@@ -899,13 +899,14 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 }
                 ex = max(ex, cin);
                 DP_T(3);   // carry in / out
-                const int base = ex + jg0;            // 64 x (score reaching column j0 through a horizontal move from the left neighbour)
+                const int base = ex;                  // the finished key left of this chunk = what a horizontal move brings to every column of it
+                const int bh = base | kh;
 #pragma unroll
-                for (int k = 0; k < CM; k++) m[k] = max(m[k], base + k * g64 + kh);
+                for (int k = 0; k < CM; k++) m[k] = max(m[k], bh);
                 int t[CM];
 #pragma unroll
                 for (int k = 0; k < CM; k++) t[k] = m[k] & ~63;
-                const int left_now = base - g64;      // 64 x H[i][j0-1]: the exclusive prefix already is the finished value left of this chunk
+                const int left_now = base;            // key of column j0 - 1: the exclusive prefix already is the finished value left of this chunk
                 const uint32_t slot = (meta >> META_SLOT) & 15u;   // (the CSR build counted the kept rows)
                 if (slot != 15u) {   // a kept row goes to its ring slot
                     int32_t* S = ring_me + slot * ring_w;
@@ -927,9 +928,9 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                     } else {
                         int pl[CM];
 #pragma unroll
-                        for (int k = 0; k < CM; k++) pl[k] = t[k] >> 6;
+                        for (int k = 0; k < CM; k++) pl[k] = (t[k] + jg0 + k * g64) >> 6;
                         store_chunk_i32<CM>(hrow + j0, pl);
-                        if (lane == 0 && has_in) hrow[hleft] = left_now >> 6;   // the wave's own copy of the column on its left
+                        if (lane == 0 && has_in) hrow[hleft] = (left_now + jg0 - g64) >> 6;   // the wave's own copy of the column on its left
                     }
                 }
                 DP_T(5);   // stores
@@ -950,7 +951,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                         int v = NEGK;
 #pragma unroll
                         for (int k = 0; k < CM; k++) if ((uint32_t)k == klast) v = t[k];
-                        if (nsink < sink_cap) { sink_row[nsink] = i; sink_score[nsink] = v >> 6; }
+                        if (nsink < sink_cap) { sink_row[nsink] = i; sink_score[nsink] = (v >> 6) + (int)L * gap; }
                         nsink++;
                     }
                 }

@@ -12,6 +12,11 @@ The path shards twice with ONE exchange of inputs in between:
            can then stitch the assembly (asm_get_assembly needs all of them, Assemble.cpp:1045-1077)
 Raw inputs (CIGAR ops, packed reads) are replicated on every GPU, so records only carry indices.
 
+Collectives of one pass (round 4: four, two of them on the data path - what the in-binary group of `haslr_assemble --gpus N` does with one
+count exchange through the process's memory and one ncclAllGather each way): before each of the two all-gathers ONE small all-gather carries
+every rank's byte count AND its verdict on everything it did since the previous exchange (`exchange_counts`), so a rank that failed takes every
+rank out together and nobody is left waiting in a collective - without separate agreement rounds.
+
 `ShardedBackend` is the compute-backend table of a rank; `run_sharded` drives one whole pass. Both take the
 record source as an object with emit() / export(buffer) / import_(buffer, n, out), so that the CPU tests can
 drive exactly this code over gloo with the test oracle in place of the HIP context.
@@ -39,27 +44,48 @@ def shard_bounds(read_hit_off, n_reads, world):
     return bounds
 
 
-def allgather_records(local: torch.Tensor, n_local: int, rec_bytes: int, group=None):
-    """All-gather of variable-length packed record buffers (uint8 tensors of n_local*rec_bytes bytes).
-    Returns (merged tensor in rank order, total record count). One data collective (+ a count exchange):
-    every rank contributes its buffer padded to the largest, the padding is cut out afterwards."""
+def exchange_counts(values, ok, device, group=None, what="stage"):
+    """ONE small all-gather: every rank's verdict (`ok`) on what it did since the last exchange, and its counts for the data collective that
+    follows. Every rank leaves with all ranks' counts - or, when any rank arrived with a failure, with the same RuntimeError (a rank that
+    failed never leaves the others waiting in the next collective). One host synchronisation."""
+    world = dist.get_world_size(group)
+    mine = torch.tensor([0 if ok else 1] + [int(v) for v in values], dtype=torch.int64, device=device)
+    out = torch.empty(world * mine.numel(), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    rows = out.cpu().view(world, -1).tolist()
+    bad = [r for r, row in enumerate(rows) if row[0]]
+    if bad:
+        raise RuntimeError(f"{what} failed on rank{'s' if len(bad) > 1 else ''} {', '.join(map(str, bad))} ({'another rank' if ok else 'this rank among them'}): all ranks stop")
+    return [row[1:] for row in rows]
+
+
+def allgather_padded(local: torch.Tensor, counts_bytes, group=None):
+    """All-gather of byte buffers whose lengths every rank already knows (`counts_bytes`, from exchange_counts): every rank contributes its
+    buffer padded to the largest, the padding is cut out afterwards (the gather buffer is the result when there is none). ONE collective."""
     world = dist.get_world_size(group)
     dev = local.device
-    mine = torch.tensor([n_local], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, mine, group=group)
-    counts_h = [int(c.item()) for c in counts]
-    cap = max(max(counts_h), 1) * rec_bytes
-    padded = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    padded[: n_local * rec_bytes] = local[: n_local * rec_bytes]
+    n_local = counts_bytes[dist.get_rank(group)]
+    cap = max(max(counts_bytes), 1)
+    if local.numel() == cap:
+        padded = local
+    else:
+        padded = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        padded[:n_local] = local[:n_local]
     gathered = torch.empty(world * cap, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(gathered, padded, group=group)
-    if sum(counts_h) == 0:
-        return torch.zeros(0, dtype=torch.uint8, device=dev), 0
-    if all(c == counts_h[0] for c in counts_h):
-        return gathered, int(sum(counts_h))                       # no padding anywhere: the gather buffer is the result
-    merged = torch.cat([gathered[r * cap: r * cap + c * rec_bytes] for r, c in enumerate(counts_h)])
-    return merged.contiguous(), int(sum(counts_h))
+    if sum(counts_bytes) == 0:
+        return torch.zeros(0, dtype=torch.uint8, device=dev)
+    if all(c == cap for c in counts_bytes):
+        return gathered
+    return torch.cat([gathered[r * cap: r * cap + c] for r, c in enumerate(counts_bytes)]).contiguous()
+
+
+def allgather_records(local: torch.Tensor, n_local: int, rec_bytes: int, group=None):
+    """All-gather of variable-length packed record buffers (uint8 tensors of n_local*rec_bytes bytes).
+    Returns (merged tensor in rank order, total record count): the count exchange, then one data collective."""
+    counts = [c[0] for c in exchange_counts([n_local], True, local.device, group, "record exchange")]
+    merged = allgather_padded(local, [c * rec_bytes for c in counts], group)
+    return merged, int(sum(counts))
 
 
 def allgather_bytes(blob: bytes, device, group=None) -> bytes:
@@ -67,15 +93,6 @@ def allgather_bytes(blob: bytes, device, group=None) -> bytes:
     local = torch.frombuffer(bytearray(blob) if blob else bytearray(1), dtype=torch.uint8).to(device)
     merged, total = allgather_records(local, len(blob), 1, group)
     return merged.cpu().numpy().tobytes()[:total]
-
-
-def agree(ok: bool, device, group=None, what="stage"):
-    """Every rank arrives with its own verdict, every rank leaves with the worst one: a rank that failed never leaves the others waiting in
-    the next collective (one 1-element all-reduce). Raises on every rank when any rank failed."""
-    t = torch.tensor([0 if ok else 1], dtype=torch.int32, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-    if int(t.item()):
-        raise RuntimeError(f"{what} failed on {'this rank' if not ok else 'another rank'} (all ranks stop)")
 
 
 class HipRecords:
@@ -118,64 +135,105 @@ class ShardedBackend:
         self.exchange_bytes = 0
         self.exchange_ms = 0.0
         self.error = None
+        self.pending_error = None
+        self.stopped = None      # the RuntimeError of a count round that stopped all ranks
 
     def _edge_support(self, _ctx, _prm, out):
         try:
-            n, local = 0, None
-            try:
-                n = self.records.emit()
-                local = self.records.export(n)
-            except Exception as e:  # noqa: BLE001
-                self.error = e
-            agree(local is not None, getattr(self.records, "comm_device", torch.device("cpu")), self.group, "edge-record emission")   # before the all-gather: all or nobody
+            n, local, err = 0, None, self.pending_error
+            if err is None:
+                try:
+                    n = self.records.emit()
+                    local = self.records.export(n)
+                except Exception as e:  # noqa: BLE001
+                    err = self.error = e
+            dev = getattr(self.records, "comm_device", torch.device("cpu"))
             t0 = time.perf_counter()
-            merged, total = allgather_records(local, n, self.records.rec_bytes, self.group)
+            # the counts and the verdicts on chain + emission travel together: all ranks go into the all-gather, or none
+            try:
+                counts = [c[0] for c in exchange_counts([n], err is None, dev, self.group, "chain stage / edge-record emission")]
+            except RuntimeError as stop:
+                self.stopped = stop
+                raise
+            merged = allgather_padded(local, [c * self.records.rec_bytes for c in counts], self.group)
+            total = int(sum(counts))
             if merged.is_cuda:
                 torch.cuda.synchronize()
             self.exchange_ms = (time.perf_counter() - t0) * 1e3       # counts exchange + the padded all-gather of the records (+ the cut of the padding)
             self.exchange_bytes = total * self.records.rec_bytes
             return self.records.import_(merged, total, out)
         except Exception as e:  # noqa: BLE001 - must not propagate through the C callback
-            self.error = e
+            self.error = self.error or e
             print(f"[ERROR] sharded edge_support: {e}", flush=True)
             return -1
 
-
-def gather_results(run, device, group=None):
-    """All ranks exchange the coordinates / supports / consensus of their share of the edges; afterwards every
-    rank's run holds all of them and can stitch. Returns the number of bytes gathered."""
-    blob, err = None, None
-    try:
-        blob = run.results_export()
-    except Exception as e:  # noqa: BLE001
-        err = e
-    agree(blob is not None, device, group, f"results export ({err})" if err else "results export")
-    merged = allgather_bytes(blob, device, group)
-    run.results_import(merged)
-    if run.results_missing:
-        raise RuntimeError(f"{run.results_missing} edges are without results after the gather")
-    return len(merged)
-
-
-def sharded_stages(run, device, group=None):
-    """chain -> graph (the record all-gather happens inside, behind its own agreement) -> coords -> consensus -> gathered results, with the ranks
-    agreeing on success after every stage (no rank is left waiting in a later collective). Returns the bytes of results gathered."""
-    def stage(fn, name):
-        err = None
+    def fail_exchange(self, err):
+        """A rank whose chain stage failed still takes part in the record exchange's count round - with its verdict - so that every rank stops there."""
+        self.pending_error = err
         try:
-            fn()
+            self._edge_support(None, None, None)
+        finally:
+            self.pending_error = None
+
+
+def gather_results(run, device, group=None, err=None, text=None):
+    """All ranks exchange the coordinates / supports / consensus of their share of the edges (and, `text` given, their part of
+    compact_uniq.txt in the same buffer); afterwards every rank's run holds all of them and can stitch. `err`: what went wrong on this rank
+    since the record exchange (it then arrives with that verdict and every rank raises). Returns (bytes of results gathered, merged text)."""
+    blob = None
+    if err is None:
+        try:
+            blob = run.results_export()
         except Exception as e:  # noqa: BLE001
             err = e
+    tbytes = text if (text is not None and err is None) else b""
+    try:
+        counts = exchange_counts([len(blob or b""), len(tbytes)], err is None, device, group, "graph / coordinate / consensus stage")
+    except RuntimeError as a:
+        raise (err or a)
+    mine = (blob or b"") + tbytes
+    local = torch.frombuffer(bytearray(mine) if mine else bytearray(1), dtype=torch.uint8).to(device)
+    merged = allgather_padded(local, [c[0] + c[1] for c in counts], group).cpu().numpy().tobytes()
+    res, txt, o = [], [], 0
+    for nres, ntxt in counts:
+        res.append(merged[o: o + nres]); txt.append(merged[o + nres: o + nres + ntxt]); o += nres + ntxt
+    res = b"".join(res)
+    run.results_import(res)
+    if run.results_missing:
+        raise RuntimeError(f"{run.results_missing} edges are without results after the gather")
+    return len(res), b"".join(txt)
+
+
+def sharded_stages(run, device, group=None, backend=None, with_text=False):
+    """chain -> graph (the record exchange happens inside) -> coords -> consensus -> gathered results: two exchanges, each a count round that
+    also carries the ranks' verdicts on everything since the previous one, and one all-gather. Returns the bytes of results gathered
+    (with_text: and the merged compact_uniq text)."""
+    err = None
+    try:
+        run.chain()
+    except Exception as e:  # noqa: BLE001
+        err = e
+    if err is not None:
+        if backend is not None:
+            backend.fail_exchange(err)        # this rank's verdict reaches the count round of the record exchange: every rank stops there
+        raise err
+    if err is None:
+        # the record exchange inside fails on every rank together; what follows it on a rank - the import, the graph build, rank 0's GFA / stat /
+        # log files - can still fail alone: that verdict travels with the count round of the results exchange
         try:
-            agree(err is None, device, group, name)
-        except RuntimeError as a:
-            raise (err or a)
-    stage(run.chain, "chain stage")
-    # the record all-gather inside fails on every rank together (agreement in the backend's edge_support); what follows it on a rank - the
-    # import, the graph build, rank 0's GFA / stat / log files - can still fail alone, so the stage as a whole is agreed on as well
-    stage(run.graph, "graph stage")
-    stage(lambda: (run.coords(), run.consensus()), "coordinate / consensus stage")
-    return gather_results(run, device, group)
+            run.graph()
+        except Exception as e:  # noqa: BLE001
+            if backend is not None and backend.stopped is not None:
+                raise (backend.error if backend.error is not None and backend.error is not backend.stopped else backend.stopped)   # every rank is raising here
+            err = e
+    if err is None:
+        try:
+            run.coords()
+            run.consensus()
+        except Exception as e:  # noqa: BLE001
+            err = e
+    n, text = gather_results(run, device, group, err, run.compact_text() if (with_text and err is None) else (b"" if with_text else None))
+    return (n, text) if with_text else n
 
 
 def run_sharded(ds, params, backend: ShardedBackend, lr_begin, rank, world, device, group=None, out_dir=None, assemble=True):
@@ -185,12 +243,10 @@ def run_sharded(ds, params, backend: ShardedBackend, lr_begin, rank, world, devi
     run = host.Run(ds, params, backend.table, out_dir)
     run.set_edge_shard(rank, world)
     run.set_read_shard(lr_begin)
-    sharded_stages(run, device, group)
-    if out_dir is not None or world > 1:
-        text = allgather_bytes(run.compact_text(), device, group)   # compact_uniq.txt lists every read: rank order = read order
-        if out_dir is not None:
-            with open(f"{out_dir}/compact_uniq.txt", "wb") as f:
-                f.write(text)
+    _, text = sharded_stages(run, device, group, backend, with_text=True)   # compact_uniq.txt lists every read: rank order = read order
+    if out_dir is not None:
+        with open(f"{out_dir}/compact_uniq.txt", "wb") as f:
+            f.write(text)
     if assemble:
         run.assemble()
     return run

@@ -789,6 +789,38 @@ struct PoaAligner {
                         cand.back() - cand[0], (int)(G.rank2node[cand[0] - 1] == minid), G.aligned[n0].size() + 1, (int)(lead == colmin), (int)G.outs[lead].empty(), (int)(lead == n0));
             }
         }
+        if (getenv("ORC_POA_PRUNE")) {   // development statistics: which cells an exact score-bound pruning would have to compute. A cell is LIVE when
+            // U = H[i][j] + match * (columns to go) reaches a threshold T <= the final score (no path through a dead cell reaches T: U never
+            // grows along a path); a (row, block of BW columns) must be computed when one of its inputs is live: the predecessor rows' cells of
+            // the block and of the column on its left, the row's own block on the left (the carry).
+            static std::atomic<uint64_t> tot{0}, liveT[2] = {{0}, {0}}, blk[2][3] = {{{0}, {0}, {0}}, {{0}, {0}, {0}}};
+            static struct Pr { ~Pr() { fprintf(stderr, "POAPRUNE cells %.4g | T=opt: live %.3f, blocks of 64/256/512 columns %.3f %.3f %.3f | T=0.9 opt: live %.3f, blocks %.3f %.3f %.3f\n", (double)tot.load(),
+                (double)liveT[0] / tot, (double)blk[0][0] / tot, (double)blk[0][1] / tot, (double)blk[0][2] / tot, (double)liveT[1] / tot, (double)blk[1][0] / tot, (double)blk[1][1] / tot, (double)blk[1][2] / tot); } } printer;
+            tot += (uint64_t)V * W;
+            const int BWs[3] = {64, 256, 512};
+            for (int ti = 0; ti < 2; ti++) {
+                const int64_t T = ti == 0 ? max_score : (max_score > 0 ? (int64_t)(0.9 * max_score) : (int64_t)(1.1 * max_score));
+                uint64_t lv = 0;
+                for (int bi = 0; bi < 3; bi++) {
+                    const size_t BW = BWs[bi], NB = (W + BW - 1) / BW;
+                    std::vector<uint8_t> lb((V + 1) * NB, 0);   // block (row, w) holds a live cell
+                    for (size_t r = 0; r <= V; r++) for (size_t jj = 0; jj < W; jj++)
+                        if ((int64_t)H[r * W + jj] + (int64_t)m * (int64_t)(W - 1 - jj) >= T) { lb[r * NB + jj / BW] = 1; if (bi == 0) lv++; }
+                    uint64_t need = 0;
+                    for (size_t r = 1; r <= V; r++) {
+                        const uint32_t n = G.rank2node[r - 1];
+                        for (size_t w = 0; w < NB; w++) {
+                            bool in = w > 0 && lb[r * NB + w - 1];
+                            auto pred = [&](size_t p) { in = in || lb[p * NB + w] || (w > 0 && lb[p * NB + w - 1]); };
+                            if (G.in[n].empty()) pred(0); else for (uint32_t e : G.in[n]) pred(node2rank[G.edges[e].from] + 1);
+                            if (in || lb[r * NB + w]) need += std::min(BW, W - w * BW);
+                        }
+                    }
+                    blk[ti][bi] += need;
+                }
+                liveT[ti] += lv;
+            }
+        }
         // traceback: diagonal (in-edge order), then vertical (in-edge order), then horizontal
         size_t i = (size_t)max_i, j = W - 1;
         const bool tbstat = getenv("ORC_POA_TB") != nullptr;   // development statistics: how the traceback's steps look (runs a wave could take at once)

@@ -240,6 +240,8 @@ cb = proto(lambda *_: -1)
 fail_at = sys.argv[3]
 if rank == 1 and fail_at == "coords":
     table.edge_coords = C.cast(cb, C.c_void_p).value      # this rank's coordinate operator fails
+if rank == 1 and fail_at == "chain":
+    table.chain_reads = C.cast(cb, C.c_void_p).value      # this rank's chain operator fails: its verdict travels with the count round of the record exchange
 
 
 class Rec:                                              # the oracle's edge_support already returns the merged multiset: nothing to exchange
@@ -266,10 +268,11 @@ os._exit(code)
 '''
 
 
-@pytest.mark.parametrize("fail_at,port", [("coords", "29527"), ("graph", "29529")])
+@pytest.mark.parametrize("fail_at,port", [("coords", "29527"), ("graph", "29529"), ("chain", "29531")])
 def test_failure_on_one_rank_stops_every_rank(sim, built, tmp_path, fail_at, port):
-    """a rank whose coordinate stage - or whose graph stage, after the record all-gather - fails: the ranks agree after every stage, so every
-    rank raises within seconds instead of waiting in the next collective for the gloo / RCCL watchdog"""
+    """a rank whose chain stage, whose coordinate stage - or whose graph stage, after the record all-gather - fails: the count round ahead of
+    each of the two all-gathers carries every rank's verdict on what it did since the previous one, so every rank raises within seconds
+    instead of waiting in the next collective for the gloo / RCCL watchdog"""
     pre = sim("--genome-len", "120000", "--seed", "77", "--variant-per-mb", "30", "--cov", "12")
     w = tmp_path / "worker_fail.py"
     w.write_text(FAIL_WORKER)
