@@ -523,7 +523,9 @@ template <int CM> __device__ __forceinline__ void store_chunk_u8(uint8_t* p, con
 // Columns beyond L are computed like real ones and never read by a real column, so the loop has no column predicates.
 // ---------------------------------------------------------------------------------------------------
 constexpr int32_t NEGK = -(1 << 30);   // "minus infinity" key
-constexpr int KD = 63, KV = 47, KH = 16;   // low 6 bits of a key = move type * 16 + 15 - predecessor slot: diagonal 3, vertical 2, horizontal 1
+constexpr int KD = 63, KV = 47;           // low 6 bits of a key of a wide row = move type * 16 + 15 - predecessor slot: diagonal 3, vertical 2
+constexpr int KHC = 4;                    // ... and the horizontal move's code in EVERY row format (4-bit rows: type 1 * 4 + 3 - 3; wide rows: below every other code, the
+                                          // traceback takes type 0 and 1 alike): a finished key (score x 64 + KHC) is the horizontal candidate of the next column as it is
 
 constexpr uint32_t CARRY_BATCH = 32;       // rows whose carries a wave takes at a time (= how far it runs behind its left neighbour)
 constexpr uint32_t WAVE_MBOX = 64;         // entries of the LDS mailbox between two waves of a workgroup (a power of two >= 2 * CARRY_BATCH)
@@ -772,8 +774,8 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             left = S[(CM - 1) * PW];
         } else if (loc == 14u) {                 // a source node starts from the virtual row 0
 #pragma unroll
-            for (int k = 0; k < CM; k++) hp[k] = 0;   // (row 0 is the gap ramp itself)
-            left = gt > 0 ? 0 : NEGK;
+            for (int k = 0; k < CM; k++) hp[k] = KHC;   // (row 0 is the gap ramp itself)
+            left = gt > 0 ? KHC : NEGK;
         } else if (live
                    ) {                       // kept row that fell out of the ring: HBM
             // with direction bytes only the rows a far successor reads are in HBM, in the slots the CSR build gave them
@@ -783,8 +785,8 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             left = lane > 0 ? Gp[-1] : has_in ? Gp[(int64_t)hleft - (int64_t)j0] : NEGK;   // (lane 0: the wave's own copy - the column belongs to a wave that may be far ahead)
             if (!DIR) {                          // the score matrix holds plain scores
 #pragma unroll
-                for (int k = 0; k < CM; k++) hp[k] = (hp[k] << 6) - (jg0 + k * g64);
-                if (gt > 0) left = (left << 6) - (jg0 - g64);
+                for (int k = 0; k < CM; k++) hp[k] = (hp[k] << 6) - (jg0 + k * g64) + KHC;
+                if (gt > 0) left = (left << 6) - (jg0 - g64) + KHC;
             }
             // the loaded values are consumed HERE: otherwise the wait for them is placed where the three sources of a predecessor row
             // join - on the path of every row - and waits for the previous rows' direction stores as well (vmcnt counts them)
@@ -850,8 +852,8 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 // format is the row's own). A row with at most 4 predecessors uses 4 bits - type * 4 + 3 - predecessor slot - which are its
                 // traceback nibble as they are; a "wide" row (rare) uses type * 16 + 15 - slot and stores a byte per cell in a side pool.
                 const bool wide = !DIR || (meta & 32u);
-                const int kd = wide ? KD : 15, kv = wide ? KV : 11, kh = wide ? KH : 4;
-                const int md = m64 - g64 + kd, gv = g64 + kv;   // (a diagonal move leaves the ramp of column j - 1 for that of column j)
+                const int kd = wide ? KD : 15, kv = wide ? KV : 11;
+                const int md = m64 - g64 + kd - KHC, gv = g64 + kv - KHC;   // (a diagonal move leaves the ramp of column j - 1 for that of column j; a finished key carries KHC)
                 auto score_of = [&](int k) -> int {   // 64 x substitution score of column k + the diagonal move code
                     int neg;   // -1 on a mismatch, 0 on a match
                     if constexpr (CM <= 16) neg = __builtin_amdgcn_sbfe((int)mis, 2 * k, 1);
@@ -883,12 +885,14 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                         for (int k = 0; k < CM; k++) m[k] = max(m[k], max((k == 0 ? left : hp[k - 1]) + score_of(k) - ps, hp[k] + (gv - ps)));
                     }
                 }
-                // chunk-local horizontal recurrence (type 1 loses every tie)
+                // what this chunk hands to the right whatever comes in from the left: its largest key (the horizontal move of de-ramped keys is a
+                // plain prefix maximum, so the chunk's own recurrence can wait for the carry and run ONCE, after the scan)
+                int lm = m[0];
 #pragma unroll
-                for (int k = 1; k < CM; k++) m[k] = max(m[k], (m[k - 1] & ~63) | kh);
-                DP_T(1);   // predecessor rows + cells + horizontal chain
-                // prefix maximum over the lanes to the left of (chunk end score - its column * gap)
-                const int inc = wave_incl_max(m[CM - 1] & ~63);
+                for (int k = 1; k < CM; k++) lm = max(lm, m[k]);
+                DP_T(1);   // predecessor rows + cells
+                // prefix maximum over the lanes to the left
+                const int inc = wave_incl_max((lm & ~63) | KHC);
                 int ex = wave_shift_up1(inc, NEGK);
                 DP_T(2);   // wave scan
                 const int cin = __builtin_amdgcn_readlane(cinV, rj);   // NEGK without a wave on the left
@@ -899,14 +903,14 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 }
                 ex = max(ex, cin);
                 DP_T(3);   // carry in / out
-                const int base = ex;                  // the finished key left of this chunk = what a horizontal move brings to every column of it
-                const int bh = base | kh;
-#pragma unroll
-                for (int k = 0; k < CM; k++) m[k] = max(m[k], bh);
+                // the horizontal recurrence from the finished key left of this chunk (the exclusive prefix; it carries the horizontal code, which
+                // loses every tie) through the chunk: each finished key t[k] is both the next column's horizontal candidate and the row as a predecessor
+                m[0] = max(m[0], ex);
                 int t[CM];
+                t[0] = (m[0] & ~63) | KHC;
 #pragma unroll
-                for (int k = 0; k < CM; k++) t[k] = m[k] & ~63;
-                const int left_now = base;            // key of column j0 - 1: the exclusive prefix already is the finished value left of this chunk
+                for (int k = 1; k < CM; k++) { m[k] = max(m[k], t[k - 1]); t[k] = (m[k] & ~63) | KHC; }
+                const int left_now = ex;              // key of column j0 - 1
                 const uint32_t slot = (meta >> META_SLOT) & 15u;   // (the CSR build counted the kept rows)
                 if (slot != 15u) {   // a kept row goes to its ring slot
                     int32_t* S = ring_me + slot * ring_w;
