@@ -513,6 +513,12 @@ template <int CM> __device__ __forceinline__ void store_chunk_u8(uint8_t* p, con
 // wins. Scores stay below 2^24 in magnitude (8*(V+L) with V+L < 2^21, checked by the host), so keys fit 32 bits. The 6 bits of the
 // winning move ARE the direction byte written to HBM for the traceback (in-degrees above 16 send the edge back to the host, which
 // retries it with the score-matrix traceback).
+// Round 4: the score in a key is DE-RAMPED, X[i][j] = H[i][j] - gap * j. A horizontal move then keeps the key's score, so the row's
+// horizontal recurrence is a plain prefix maximum: the scan input is the chunk's largest key, nothing is subtracted before the scan or
+// added after it, and the chunk's own recurrence runs once, after the carry is known - each finished key (score x 64 + KHC, the one
+// horizontal code of every row format) is the next column's horizontal candidate and the row as later rows read it, in one register.
+// A diagonal move adds (substitution score - gap), a vertical one gap; only the sink scores and the score-matrix flavour's HBM rows
+// (plain scores for its traceback) put the ramp back.
 //
 // Rows that a later row needs as a NON-adjacent predecessor are flagged by the CSR build ("kept") and copied to an LDS
 // ring in the order they are produced (per wave: CM planes of 65 words, column t*CM+k at word 65*CM*w + 65*k + 1 + t, conflict-free; word 0
@@ -690,6 +696,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     const bool in_lds = wv > 0 || relay_mode;                                 // ... through the workgroup's LDS mailbox, or (first wave of a member without a relay wave) through HBM
     const bool has_out = (uint64_t)(gw + 1) * 64u * CM < ncol;                // a wave on the right owns real columns (the host sized the pipeline for the longest sequence)
     const bool out_lds = wv + 1 < NW;
+    const bool out_l = has_out && out_lds, out_h = has_out && !out_lds;   // (two plain tests per row instead of a nest)
     const unsigned long long* mb_in_h = cl.mbox + (uint64_t)(cl.mem ? cl.mem - 1 : 0) * cl.stride;
     unsigned long long* mb_out_h = cl.mbox + (uint64_t)cl.mem * cl.stride;
     const unsigned long long* mb_in_l = wm_box + (size_t)(wv ? wv - 1 : relay_mode ? RELAY_BOX : 0) * WAVE_MBOX;
@@ -708,10 +715,11 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     using mask_t = typename std::conditional<(CM <= 16), uint32_t, unsigned long long>::type;
     static_assert(CM <= 32, "at most 32 columns per lane");
     mask_t bases = 0, nobase = 0;
+    uint32_t onehot = 0;   // up to 8 columns per lane: bit 4 k + letter of the base under column k - a row's match bits are ONE shift by its letter (no base: no bit)
 #pragma unroll
     for (int k = 0; k < CM; k++) {
         const uint32_t j = j0 + k;
-        if (j >= 1 && j < ncol) bases |= (mask_t)seq[j - 1] << (2 * k); else nobase |= (mask_t)1 << (2 * k);
+        if (j >= 1 && j < ncol) { bases |= (mask_t)seq[j - 1] << (2 * k); if constexpr (CM <= 8) onehot |= 1u << (4 * k + seq[j - 1]); } else nobase |= (mask_t)1 << (2 * k);
     }
     const int mm64 = mismatch * 64, g64 = gap * 64, m64 = match * 64;
     const int jg0 = (int)j0 * g64;
@@ -807,7 +815,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
         fetch_more(ib + 64, mN, oN, aN, bN, cN, dN, fN);
         const uint32_t ie = min(64u, V - ib);
         for (uint32_t rb = 0; rb < ie; rb += CARRY_BATCH) {
-            const uint32_t nb = min(CARRY_BATCH, ie - rb), i0 = ib + rb + 1;   // rows i0 .. i0 + nb - 1
+            const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(CARRY_BATCH, ie - rb)), i0 = ib + rb + 1;   // rows i0 .. i0 + nb - 1
             int cinV = NEGK;     // lane r: carry into this wave for row i0 + r
             if (has_in) {
 #ifdef HX_DP_PROF3
@@ -843,8 +851,10 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 const uint32_t meta = __builtin_amdgcn_readlane(mC, ri), p0 = __builtin_amdgcn_readlane(aC, ri);
                 const uint32_t npred = meta >> META_NP;
                 // mismatch bits of this row: bit 2k set <=> the base under column k differs from the row's letter
-                mask_t mis;
-                {
+                mask_t mis = 0;
+                uint32_t hit = 0;     // (CM <= 8) bit 4 k set <=> the base under column k is the row's letter
+                if constexpr (CM <= 8) hit = onehot >> (meta & 3u);
+                else {
                     const mask_t x = bases ^ ((mask_t)(meta & 3u) * (mask_t)0x5555555555555555ull);
                     mis = x | (x >> 1) | nobase;
                 }
@@ -855,6 +865,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 const int kd = wide ? KD : 15, kv = wide ? KV : 11;
                 const int md = m64 - g64 + kd - KHC, gv = g64 + kv - KHC;   // (a diagonal move leaves the ramp of column j - 1 for that of column j; a finished key carries KHC)
                 auto score_of = [&](int k) -> int {   // 64 x substitution score of column k + the diagonal move code
+                    if constexpr (CM <= 8) return md + (mm64 - m64) + ((m64 - mm64) & __builtin_amdgcn_sbfe((int)hit, (4 * k) & 31, 1));   // (-1 on a match)
                     int neg;   // -1 on a mismatch, 0 on a match
                     if constexpr (CM <= 16) neg = __builtin_amdgcn_sbfe((int)mis, 2 * k, 1);
                     else neg = 2 * k < 32 ? __builtin_amdgcn_sbfe((int)(uint32_t)mis, (2 * k) & 31, 1) : __builtin_amdgcn_sbfe((int)(uint32_t)(mis >> 32), (2 * k) & 31, 1);
@@ -896,11 +907,9 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 int ex = wave_shift_up1(inc, NEGK);
                 DP_T(2);   // wave scan
                 const int cin = __builtin_amdgcn_readlane(cinV, rj);   // NEGK without a wave on the left
-                if (has_out) {   // the carry of this row for the wave on the right: the prefix maximum through this wave's last column (lane 63 holds it)
-                    const unsigned long long e = (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, inc) << 32);
-                    if (out_lds) { if (lane == 63) st_wg64(mb_out_l + (i & (WAVE_MBOX - 1)), e); }
-                    else if (lane == 63) st_dev64(mb_out_h + i, e);
-                }
+                // the carry of this row for the wave on the right: the prefix maximum through this wave's last column (lane 63 holds it)
+                if (out_l) { if (lane == 63) st_wg64(mb_out_l + (i & (WAVE_MBOX - 1)), (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, inc) << 32)); }
+                if (out_h) { if (lane == 63) st_dev64(mb_out_h + i, (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, inc) << 32)); }
                 ex = max(ex, cin);
                 DP_T(3);   // carry in / out
                 // the horizontal recurrence from the finished key left of this chunk (the exclusive prefix; it carries the horizontal code, which
