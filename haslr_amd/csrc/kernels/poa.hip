@@ -626,6 +626,23 @@ template <int CM> __device__ __forceinline__ void store_nibbles(uint8_t* p, cons
     }
 }
 
+// the same nibbles through a raw buffer resource (base = the row, range = its bytes): offsets beyond the range are not written
+template <int CM> __device__ __forceinline__ void store_nibbles_buf(__amdgpu_buffer_rsrc_t r, const uint32_t off, const uint32_t (&v)[CM]) {
+    static_assert(CM >= 4 && CM % 4 == 0, "4, 8, 16 or 32 columns per lane");
+    uint32_t b[CM / 2];
+#pragma unroll
+    for (int q = 0; q < CM / 2; q++) b[q] = (v[2 * q] & 15u) | (v[2 * q + 1] << 4);
+    if constexpr (CM == 4) __builtin_amdgcn_raw_buffer_store_b16((short)__builtin_amdgcn_perm(b[1], b[0], 0x0c0c0400u), r, (int)off, 0, 0);
+    else {
+        uint32_t w[CM / 8];
+#pragma unroll
+        for (int q = 0; q < CM / 8; q++) w[q] = pack_b0(b[4 * q], b[4 * q + 1], b[4 * q + 2], b[4 * q + 3]);
+        if constexpr (CM == 8) __builtin_amdgcn_raw_buffer_store_b32(w[0], r, (int)off, 0, 0);
+        else if constexpr (CM == 16) { typedef uint32_t u32x2 __attribute__((ext_vector_type(2))); __builtin_amdgcn_raw_buffer_store_b64((u32x2){w[0], w[1]}, r, (int)off, 0, 0); }
+        else { typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[0], w[1], w[2], w[3]}, r, (int)off, 0, 0); }
+    }
+}
+
 #ifdef HX_DP_PROF3   // development: per member of a shared edge, cycles inside the DP and cycles of them spent waiting for carries (phase slots 6 + member)
 #define HX_DP_PROF
 #define HX_DP_PROF2
@@ -696,7 +713,9 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     const bool in_lds = wv > 0 || relay_mode;                                 // ... through the workgroup's LDS mailbox, or (first wave of a member without a relay wave) through HBM
     const bool has_out = (uint64_t)(gw + 1) * 64u * CM < ncol;                // a wave on the right owns real columns (the host sized the pipeline for the longest sequence)
     const bool out_lds = wv + 1 < NW;
-    const bool out_l = has_out && out_lds, out_h = has_out && !out_lds;   // (two plain tests per row instead of a nest)
+    // (wave-uniform tests of the row loop as 32-bit scalars: a test of a lane-mask boolean is `s_andn2 vcc` + a vcc branch, ~32 cycles for a lone
+    // wave against ~15 for `s_cmp` + an scc branch: tools/dev_lonebench.hip)
+    const uint32_t out_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(has_out && out_lds)), out_h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(has_out && !out_lds));
     const unsigned long long* mb_in_h = cl.mbox + (uint64_t)(cl.mem ? cl.mem - 1 : 0) * cl.stride;
     unsigned long long* mb_out_h = cl.mbox + (uint64_t)cl.mem * cl.stride;
     const unsigned long long* mb_in_l = wm_box + (size_t)(wv ? wv - 1 : relay_mode ? RELAY_BOX : 0) * WAVE_MBOX;
@@ -846,9 +865,12 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                     __builtin_amdgcn_s_sleep(2);
                 }
             }
+            // (a row's record words are read out of their lane during the row BEFORE: a scalar instruction that consumes a readlane's result at once
+            // waits ~14 cycles for it)
+            uint32_t meta_nx = __builtin_amdgcn_readlane(mC, rb), p0_nx = __builtin_amdgcn_readlane(aC, rb);
             for (uint32_t rj = 0; rj < nb; rj++) {
                 const uint32_t ri = rb + rj, i = ib + ri + 1;
-                const uint32_t meta = __builtin_amdgcn_readlane(mC, ri), p0 = __builtin_amdgcn_readlane(aC, ri);
+                const uint32_t meta = meta_nx, p0 = p0_nx;
                 const uint32_t npred = meta >> META_NP;
                 // mismatch bits of this row: bit 2k set <=> the base under column k differs from the row's letter
                 mask_t mis = 0;
@@ -907,9 +929,10 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 int ex = wave_shift_up1(inc, NEGK);
                 DP_T(2);   // wave scan
                 const int cin = __builtin_amdgcn_readlane(cinV, rj);   // NEGK without a wave on the left
+                meta_nx = __builtin_amdgcn_readlane(mC, (ri + 1) & 63u); p0_nx = __builtin_amdgcn_readlane(aC, (ri + 1) & 63u);   // (the next row's record; beyond the batch: unused)
                 // the carry of this row for the wave on the right: the prefix maximum through this wave's last column (lane 63 holds it)
-                if (out_l) { if (lane == 63) st_wg64(mb_out_l + (i & (WAVE_MBOX - 1)), (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, inc) << 32)); }
-                if (out_h) { if (lane == 63) st_dev64(mb_out_h + i, (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, inc) << 32)); }
+                if (out_l != 0u) { if (lane == 63) st_wg64(mb_out_l + (i & (WAVE_MBOX - 1)), (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, inc) << 32)); }
+                if (out_h != 0u) { if (lane == 63) st_dev64(mb_out_h + i, (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, inc) << 32)); }
                 ex = max(ex, cin);
                 DP_T(3);   // carry in / out
                 // the horizontal recurrence from the finished key left of this chunk (the exclusive prefix; it carries the horizontal code, which
@@ -931,14 +954,16 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 for (int k = 0; k < CM; k++) tp[k] = t[k];
                 lnp = left_now;
                 DP_T(4);   // carry applied, ring copy
-                if (__builtin_expect(live, 1)) {
-                    if (DIR) {
-                        uint32_t dc[CM];
+                if (DIR) {
+                    // the move code of every cell: type * 4 + 3 - predecessor slot. The row is stored through a buffer resource of ITS bytes: chunks
+                    // beyond the row (the padding lanes of the last wave) fail the range check and are dropped - no exec mask, no branch
+                    uint32_t dc[CM];
 #pragma unroll
-                        for (int k = 0; k < CM; k++) dc[k] = (uint32_t)m[k];
-                        store_nibbles<CM>(drow + (j0 >> 1), dc);      // the move code of every cell: type * 4 + 3 - predecessor slot
-                        if (__builtin_expect((meta & 32u) != 0, 0)) store_dirs<CM>(Dwide + (uint64_t)wideslot[i - 1] * W + j0, dc, 0x3f3f3f3fu);   // wide row: type * 16 + 15 - slot
-                    } else {
+                    for (int k = 0; k < CM; k++) dc[k] = (uint32_t)m[k];
+                    store_nibbles_buf<CM>(__builtin_amdgcn_make_buffer_rsrc(drow, 0, (int)(W >> 1), 0x00020000), j0 >> 1, dc);
+                }
+                if (!DIR && __builtin_expect(live, 1)) {
+                    {
                         int pl[CM];
 #pragma unroll
                         for (int k = 0; k < CM; k++) pl[k] = (t[k] + jg0 + k * g64) >> 6;
@@ -947,7 +972,13 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                     }
                 }
                 DP_T(5);   // stores
-                if (__builtin_expect((meta & (8u | 4u)) != 0, 0)) {
+                if (__builtin_expect((meta & (32u | 8u | 4u)) != 0, 0)) {   // ONE test for everything rare: wide row, far reader, sink
+                    if (DIR && (meta & 32u) && live) {   // wide row: type * 16 + 15 - slot, a byte per cell
+                        uint32_t dc[CM];
+#pragma unroll
+                        for (int k = 0; k < CM; k++) dc[k] = (uint32_t)m[k];
+                        store_dirs<CM>(Dwide + (uint64_t)wideslot[i - 1] * W + j0, dc, 0x3f3f3f3fu);
+                    }
                     if (meta & 8u) {   // a far successor reads this row back from HBM (keys; with the score matrix it is there already)
                         // (the slot is read out of its lane HERE, where every lane is active: inside the divergent block below a register
                         // that was spilled is reloaded for the active lanes only, and lane ri need not be one of them)

@@ -1,0 +1,62 @@
+// dev_lonebench.hip — what one wavefront alone on its SIMD pays per instruction KIND (the regime of the POA row loop of a chain-bound call):
+// straight-line bodies of 64 "slots" built with .rept, looped 2000 times, timed with s_memtime. Development tool (round 4).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#define ITER 2000
+// every body: 16 x { 4 x v_add (independent registers) + EXTRA }
+#define BODY(EXTRA) asm volatile(".rept 16\n\tv_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %4\n\t" EXTRA "\n\t.endr" \
+    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0) : "scc", "vcc", "s40", "s41", "s42", "s43", "memory")
+__global__ void k(long long* out, int* sink, int mode) {
+    __shared__ unsigned long long lds[256];
+    const int tid = threadIdx.x;
+    int a0 = tid + sink[0], a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b0 = 3 + sink[1];
+    lds[tid & 255] = tid;
+    __syncthreads();
+    const uint32_t la = (uint32_t)(uintptr_t)(&lds[tid & 63]);
+    asm volatile("s_cmp_eq_u32 0, 1" ::: "scc");   // scc = 0
+    long long t0 = clock64();
+    for (int i = 0; i < ITER; i++) {
+        switch (mode) {
+        case 0: BODY(""); break;                                                     // 64 VALU
+        case 1: BODY("s_add_u32 s40, s40, 1"); break;                                 // + 16 SALU
+        case 2: BODY("s_cmp_eq_u32 0, 1\n\ts_cbranch_scc1 1f\n\t1:"); break;               // + 16 x (s_cmp + branch NOT taken)
+        case 3: BODY("s_cmp_eq_u32 0, 0\n\ts_cbranch_scc1 1f\n\ts_nop 0\n\t1:"); break;    // + 16 x (s_cmp + branch TAKEN over one s_nop)
+        case 4: BODY("s_and_saveexec_b64 s[40:41], vcc\n\ts_or_b64 exec, exec, s[40:41]"); break;   // + 16 x exec save / restore (vcc: whatever)
+        case 5: BODY("s_waitcnt lgkmcnt(0)"); break;                                  // + 16 x waitcnt with nothing outstanding
+        case 6: BODY("s_nop 1"); break;
+        case 7: BODY("v_readlane_b32 s40, %0, 5\n\ts_lshr_b32 s41, s40, 3"); break;   // + 16 x (readlane -> dependent SALU)
+        case 8: BODY("v_mov_b32_dpp %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf"); break;
+        case 9: BODY("v_cmp_eq_u32 vcc, 0, %0\n\ts_cbranch_vccz 1f\n\t1:"); break;         // + 16 x (v_cmp + vcc branch, mostly taken: vcc = 0 ... either way)
+        case 10: asm volatile(".rept 16\n\tv_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %4\n\tds_write_b64 %5, %[d]\n\t.endr"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(la), [d] "v"((unsigned long long)a0) : "memory"); break;   // + 16 x ds_write_b64 (no wait)
+        case 11: BODY("v_max_i32_dpp %1, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf"); break;
+        case 12: BODY("v_add3_u32 %1, %0, %4, %1"); break;                            // + 16 x VOP3 (8-byte encoding)
+        case 13: BODY("s_andn2_b64 vcc, exec, s[42:43]\n\ts_cbranch_vccnz 1f\n\t1:"); break;   // + 16 x (s_andn2 -> vcc branch): the compiler's flag test
+        case 14: BODY("s_cmp_eq_u32 0, 0\n\ts_cbranch_scc1 1f\n\t.rept 64\n\ts_nop 0\n\t.endr\n\t1:"); break;   // TAKEN over 64 instructions (256 bytes: new fetch lines)
+        case 15: BODY("v_readlane_b32 s40, %0, 5"); break;                            // + 16 x readlane alone
+        }
+    }
+    long long t1 = clock64();
+    if (tid == 0) out[mode] = t1 - t0;
+    sink[tid + 8] = a0 + a1 + a2 + a3;
+}
+int main() {
+    long long* out; int* sink;
+    hipMalloc(&out, 64 * 8); hipMalloc(&sink, 1 << 20); hipMemset(sink, 0, 1 << 20);
+    const char* names[] = {"64 v_add", "+16 s_add", "+16 (s_cmp, branch not taken)", "+16 (s_cmp, branch taken, s_nop)", "+16 (saveexec, s_or exec)", "+16 s_waitcnt lgkmcnt(0)", "+16 s_nop 1",
+                           "+16 (readlane, dependent s_lshr)", "+16 v_mov_dpp wave_shr:1", "+16 (v_cmp, vcc branch)", "+16 ds_write_b64", "+16 v_max_dpp row_shr:1", "+16 v_add3 (8-byte)",
+                           "+16 (s_andn2 vcc, vccnz branch)", "+16 (s_cmp, branch taken over 256 B)", "+16 readlane"};
+    for (int rep = 0; rep < 2; rep++) {
+        long long base = 0;
+        for (int m = 0; m < 16; m++) {
+            k<<<1, 64>>>(out, sink, m); hipDeviceSynchronize();
+            long long h; hipMemcpy(&h, out + m, 8, hipMemcpyDeviceToHost);
+            const double per = (double)h / ITER;
+            if (m == 0) base = h;
+            printf("  %-40s %8.1f cycles per body, extra per item %6.1f\n", names[m], per, (double)(h - base) / ITER / 16);
+        }
+        printf("\n");
+    }
+    return 0;
+}
