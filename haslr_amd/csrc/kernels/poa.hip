@@ -742,6 +742,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     }
     const int mm64 = mismatch * 64, g64 = gap * 64, m64 = match * 64;
     const int jg0 = (int)j0 * g64;
+    const int mdN = m64 - g64 + 15 - KHC, mdW = m64 - g64 + KD - KHC, gvN = g64 + 11 - KHC, gvW = g64 + KV - KHC;   // diagonal (match) / vertical constants of 4-bit and wide rows
     // The previous row is still in the registers of the lanes that own its columns (tp, lnp): a successor that follows it immediately
     // reads it there - no LDS round trip on the most common dependency. Every row a NON-adjacent successor reads ("kept") lives in the LDS
     // ring, R slots in the order they are produced; rows nobody else reads are not written at all. A predecessor reference is a code from
@@ -803,27 +804,29 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
 #pragma unroll
             for (int k = 0; k < CM; k++) hp[k] = KHC;   // (row 0 is the gap ramp itself)
             left = gt > 0 ? KHC : NEGK;
-        } else if (live
-                   ) {                       // kept row that fell out of the ring: HBM
+        } else {                                 // kept row that fell out of the ring: HBM
+            // (no divergent branch in here: with one, the compiler structurises the whole dispatch and every row pays a flag test. Padding lanes
+            // - columns beyond the sequence, last wave only - read the row's first chunk instead: their keys reach no real column)
             // with direction bytes only the rows a far successor reads are in HBM, in the slots the CSR build gave them
             const uint32_t hr = DIR ? (slot_known ? ent & 0x0fffffffu : farslot[ent & 0x0fffffffu]) : (ent & 0x0fffffffu) + 1;
-            const int32_t* Gp = H + (uint64_t)hr * WH + j0;
+            const int32_t* Grow = H + (uint64_t)hr * WH;
+            const uint32_t jl = live ? j0 : 0u;
+            const int32_t* Gp = Grow + jl;
             load_chunk_i32<CM>(Gp, hp);
-            left = lane > 0 ? Gp[-1] : has_in ? Gp[(int64_t)hleft - (int64_t)j0] : NEGK;   // (lane 0: the wave's own copy - the column belongs to a wave that may be far ahead)
+            // the key left of the chunk: the neighbour's last column - lane 0: the wave's own copy (the column belongs to a wave that may be far ahead)
+            const int32_t* lp = (lane > 0 && live) ? Gp - 1 : has_in ? Grow + hleft : Grow;
+            left = *lp;
             if (!DIR) {                          // the score matrix holds plain scores
 #pragma unroll
                 for (int k = 0; k < CM; k++) hp[k] = (hp[k] << 6) - (jg0 + k * g64) + KHC;
-                if (gt > 0) left = (left << 6) - (jg0 - g64) + KHC;
+                left = (left << 6) - (jg0 - g64) + KHC;
             }
+            left = gt > 0 ? left : NEGK;
             // the loaded values are consumed HERE: otherwise the wait for them is placed where the three sources of a predecessor row
             // join - on the path of every row - and waits for the previous rows' direction stores as well (vmcnt counts them)
 #pragma unroll
             for (int k = 0; k < CM; k++) asm volatile("" : "+v"(hp[k]));
             asm volatile("" : "+v"(left));
-        } else {
-#pragma unroll
-            for (int k = 0; k < CM; k++) hp[k] = NEGK;
-            left = NEGK;
         }
     };
     for (uint32_t ib = 0; ib < V; ib += 64) {
@@ -884,10 +887,11 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 // format is the row's own). A row with at most 4 predecessors uses 4 bits - type * 4 + 3 - predecessor slot - which are its
                 // traceback nibble as they are; a "wide" row (rare) uses type * 16 + 15 - slot and stores a byte per cell in a side pool.
                 const bool wide = !DIR || (meta & 32u);
-                const int kd = wide ? KD : 15, kv = wide ? KV : 11;
-                const int md = m64 - g64 + kd - KHC, gv = g64 + kv - KHC;   // (a diagonal move leaves the ramp of column j - 1 for that of column j; a finished key carries KHC)
+                // (a diagonal move leaves the ramp of column j - 1 for that of column j; a finished key carries KHC; both formats' constants wait in
+                // scalar registers: one bit test and three selects per row)
+                const int md = wide ? mdW : mdN, gv = wide ? gvW : gvN, mmd = wide ? mdW + (mm64 - m64) : mdN + (mm64 - m64);
                 auto score_of = [&](int k) -> int {   // 64 x substitution score of column k + the diagonal move code
-                    if constexpr (CM <= 8) return md + (mm64 - m64) + ((m64 - mm64) & __builtin_amdgcn_sbfe((int)hit, (4 * k) & 31, 1));   // (-1 on a match)
+                    if constexpr (CM <= 8) return mmd + ((m64 - mm64) & __builtin_amdgcn_sbfe((int)hit, (4 * k) & 31, 1));   // (-1 on a match)
                     int neg;   // -1 on a mismatch, 0 on a match
                     if constexpr (CM <= 16) neg = __builtin_amdgcn_sbfe((int)mis, 2 * k, 1);
                     else neg = 2 * k < 32 ? __builtin_amdgcn_sbfe((int)(uint32_t)mis, (2 * k) & 31, 1) : __builtin_amdgcn_sbfe((int)(uint32_t)(mis >> 32), (2 * k) & 31, 1);
@@ -1736,22 +1740,27 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                         }
                         const uint32_t ilo = ti > 31u ? ti - 31u : 1u;                 // the walk goes on while i >= ilo (rows of the tile, never row 0) ...
                         const int32_t jb0 = 2 * bs;                                  // ... and j >= first column of the tile
+                        // (bit dr: the tile's row dr has more than 4 predecessors - a scalar bit test per step instead of a readlane of the row's record)
+                        const uint32_t wmask = (uint32_t)__ballot(ln < 32 && (mt & 32u) != 0);
                         for (;;) {
                             const uint32_t dr = ti - i, jb = (uint32_t)((int32_t)j - jb0);   // row and column inside the tile (0..31, 0..15)
                             const uint32_t wsel = (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)(dr * 2 + (jb >> 3)));
                             const uint32_t n4 = (wsel >> (4 * (jb & 7u))) & 15u;
-                            const uint32_t rmeta = (uint32_t)__builtin_amdgcn_readlane((int)mt, (int)dr);
                             // move code: type (3 diagonal / 2 vertical / 1 horizontal) * 4 + 3 - predecessor slot; a row with more than 4 predecessors
                             // keeps type * 16 + 15 - slot in the wide-row pool
                             // (a move into the third or a later predecessor - codes 8, 9, 12, 13 of a 4-bit row - has to fetch that predecessor's rank)
-                            uint32_t type = n4 >> 2, slot = 3u - (n4 & 3u), later = (0x3300u >> n4) & 1u;
-                            if (__builtin_expect((rmeta & 32u) != 0, 0)) {
-                                const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)Dw[(uint64_t)__builtin_amdgcn_readlane((int)qw, (int)dr) * W + j]);
-                                type = d >> 4; slot = 15u - (d & 15u); later = slot >= 2 && type > 1u;
-                            }
+                            uint32_t type = n4 >> 2, slot = 3u - (n4 & 3u);
                             uint32_t pv = slot == 0 ? (uint32_t)__builtin_amdgcn_readlane((int)pv0, (int)dr) : (uint32_t)__builtin_amdgcn_readlane((int)pv1, (int)dr);
-                            if (__builtin_expect(later != 0, 0))
-                                pv = ((uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[(uint32_t)__builtin_amdgcn_readlane((int)qo, (int)dr) + slot]) & 0x0fffffffu) + 1;
+                            if (__builtin_expect((((0x3300u >> n4) | (wmask >> dr)) & 1u) != 0, 0)) {   // ONE test for the rare moves: a wide row, a third or later predecessor
+                                uint32_t later = (0x3300u >> n4) & 1u;
+                                if ((wmask >> dr) & 1u) {
+                                    const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)Dw[(uint64_t)__builtin_amdgcn_readlane((int)qw, (int)dr) * W + j]);
+                                    type = d >> 4; slot = 15u - (d & 15u); later = slot >= 2 && type > 1u;
+                                    pv = slot == 0 ? (uint32_t)__builtin_amdgcn_readlane((int)pv0, (int)dr) : (uint32_t)__builtin_amdgcn_readlane((int)pv1, (int)dr);
+                                }
+                                if (later != 0)
+                                    pv = ((uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[(uint32_t)__builtin_amdgcn_readlane((int)qo, (int)dr) + slot]) & 0x0fffffffu) + 1;
+                            }
                             {
                                 const int el = (int)(na & 63u);
                                 // (M0 is saved and restored around the two v_writelane: the compiler reserves it - an earlier version that listed it as a

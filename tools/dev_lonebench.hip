@@ -6,7 +6,7 @@
 #define ITER 2000
 // every body: 16 x { 4 x v_add (independent registers) + EXTRA }
 #define BODY(EXTRA) asm volatile(".rept 16\n\tv_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %4\n\t" EXTRA "\n\t.endr" \
-    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0) : "scc", "vcc", "s40", "s41", "s42", "s43", "memory")
+    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0) : "scc", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "memory")
 __global__ void k(long long* out, int* sink, int mode) {
     __shared__ unsigned long long lds[256];
     const int tid = threadIdx.x;
@@ -14,7 +14,7 @@ __global__ void k(long long* out, int* sink, int mode) {
     lds[tid & 255] = tid;
     __syncthreads();
     const uint32_t la = (uint32_t)(uintptr_t)(&lds[tid & 63]);
-    asm volatile("s_cmp_eq_u32 0, 1" ::: "scc");   // scc = 0
+    asm volatile("s_cmp_eq_u32 0, 1\n\ts_mov_b32 s44, 0\n\ts_mov_b32 s45, 0\n\ts_mov_b32 s46, 0\n\ts_mov_b32 s47, 0x00020000\n\ts_mov_b32 s42, 3\n\ts_mov_b32 s43, 7" ::: "scc", "s42", "s43", "s44", "s45", "s46", "s47");   // scc = 0; a null buffer resource
     long long t0 = clock64();
     for (int i = 0; i < ITER; i++) {
         switch (mode) {
@@ -35,6 +35,12 @@ __global__ void k(long long* out, int* sink, int mode) {
         case 13: BODY("s_andn2_b64 vcc, exec, s[42:43]\n\ts_cbranch_vccnz 1f\n\t1:"); break;   // + 16 x (s_andn2 -> vcc branch): the compiler's flag test
         case 14: BODY("s_cmp_eq_u32 0, 0\n\ts_cbranch_scc1 1f\n\t.rept 64\n\ts_nop 0\n\t.endr\n\t1:"); break;   // TAKEN over 64 instructions (256 bytes: new fetch lines)
         case 15: BODY("v_readlane_b32 s40, %0, 5"); break;                            // + 16 x readlane alone
+        case 16: BODY("s_and_saveexec_b64 s[40:41], exec\n\ts_cbranch_execz 1f\n\t1:\n\ts_or_b64 exec, exec, s[40:41]"); break;   // + 16 x (saveexec, execz branch not taken, restore)
+        case 17: BODY("v_readlane_b32 s40, %0, 5\n\tv_add_u32 %1, s40, %1"); break;     // + 16 x (readlane -> dependent VALU)
+        case 18: BODY("s_bitcmp1_b32 s42, 5\n\ts_cselect_b32 s40, 63, 15\n\ts_cselect_b32 s41, 47, 11"); break;   // + 16 x 3 SALU
+        case 19: BODY("s_mov_b32 m0, s42\n\ts_nop 0\n\tv_writelane_b32 %1, s43, m0"); break;   // + 16 x (m0, writelane)
+        case 20: BODY("buffer_store_short %0, %4, s[44:47], 0 offen"); break;          // + 16 x buffer store whose offsets fail the range check (num_records 0)
+        case 21: BODY("s_cmp_eq_u32 0, 1\n\ts_cbranch_scc1 1f\n\t1:\n\ts_cmp_eq_u32 0, 1\n\ts_cbranch_scc1 2f\n\t2:"); break;   // + 16 x two not-taken scc branches back to back
         }
     }
     long long t1 = clock64();
@@ -46,10 +52,11 @@ int main() {
     hipMalloc(&out, 64 * 8); hipMalloc(&sink, 1 << 20); hipMemset(sink, 0, 1 << 20);
     const char* names[] = {"64 v_add", "+16 s_add", "+16 (s_cmp, branch not taken)", "+16 (s_cmp, branch taken, s_nop)", "+16 (saveexec, s_or exec)", "+16 s_waitcnt lgkmcnt(0)", "+16 s_nop 1",
                            "+16 (readlane, dependent s_lshr)", "+16 v_mov_dpp wave_shr:1", "+16 (v_cmp, vcc branch)", "+16 ds_write_b64", "+16 v_max_dpp row_shr:1", "+16 v_add3 (8-byte)",
-                           "+16 (s_andn2 vcc, vccnz branch)", "+16 (s_cmp, branch taken over 256 B)", "+16 readlane"};
+                           "+16 (s_andn2 vcc, vccnz branch)", "+16 (s_cmp, branch taken over 256 B)", "+16 readlane",
+                           "+16 (saveexec, execz branch, s_or)", "+16 (readlane, dependent v_add)", "+16 (s_bitcmp, 2 s_cselect)", "+16 (s_mov m0, s_nop, v_writelane)", "+16 buffer_store (out of range)", "+16 x 2 branches not taken"};
     for (int rep = 0; rep < 2; rep++) {
         long long base = 0;
-        for (int m = 0; m < 16; m++) {
+        for (int m = 0; m < 22; m++) {
             k<<<1, 64>>>(out, sink, m); hipDeviceSynchronize();
             long long h; hipMemcpy(&h, out + m, 8, hipMemcpyDeviceToHost);
             const double per = (double)h / ITER;
