@@ -533,7 +533,8 @@ constexpr int KD = 63, KV = 47;           // low 6 bits of a key of a wide row =
 constexpr int KHC = 4;                    // ... and the horizontal move's code in EVERY row format (4-bit rows: type 1 * 4 + 3 - 3; wide rows: below every other code, the
                                           // traceback takes type 0 and 1 alike): a finished key (score x 64 + KHC) is the horizontal candidate of the next column as it is
 
-constexpr uint32_t CARRY_BATCH = 32;       // rows whose carries a wave takes at a time (= how far it runs behind its left neighbour)
+constexpr uint32_t CARRY_BATCH = 32;       // rows whose carries a wave takes at a time at most
+constexpr uint32_t CARRY_MIN = 4;          // ... and at least (int32 rows; = how far a wave that keeps up runs behind its left neighbour)
 constexpr uint32_t WAVE_MBOX = 64;         // entries of the LDS mailbox between two waves of a workgroup (a power of two >= 2 * CARRY_BATCH)
 constexpr uint32_t MAX_WAVES = 16;         // waves per workgroup at most
 constexpr uint32_t WG_POLL_LIMIT = 1u << 24;   // polls of a wave for another wave of its own workgroup (resident by construction) before it flags an internal error
@@ -683,13 +684,17 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             bool dead = false;
             for (uint32_t ib = 0; ib < V; ib += 64) {
                 const uint32_t ie = min(64u, V - ib);
-                for (uint32_t rb = 0; rb < ie; rb += CARRY_BATCH) {
-                    const uint32_t nb = min(CARRY_BATCH, ie - rb), i0 = ib + rb + 1;
+                uint32_t nb = 0;
+                for (uint32_t rb = 0; rb < ie; rb += nb) {
+                    const uint32_t want = min(CARRY_BATCH, ie - rb), i0 = ib + rb + 1;   // (as many rows as have arrived, at least CARRY_MIN: like the DP waves)
+                    nb = want;
                     unsigned long long v = (unsigned long long)(cl.tag0 + i0 + lane);   // (a relay that gave up still hands out tagged entries: the edge is flagged and redone)
                     for (uint32_t spin = 0; !dead; spin++) {
                         bool ok = true;
-                        if (lane < nb) { v = ld_dev64(src + i0 + lane); ok = (uint32_t)v == cl.tag0 + i0 + lane; }
-                        if (__ballot(ok) == ~0ull) break;
+                        if (lane < want) { v = ld_dev64(src + i0 + lane); ok = (uint32_t)v == cl.tag0 + i0 + lane; }
+                        const unsigned long long okm = __ballot(ok);
+                        const uint32_t run = okm == ~0ull ? want : (uint32_t)__builtin_ctzll(~okm);
+                        if (run >= min(want, CARRY_MIN)) { nb = run; break; }
                         if (spin > cl.poll_limit) { if (lane == 0) st_dev(cl.err, 1u); dead = true; v = (unsigned long long)(cl.tag0 + i0 + lane); break; }
                         __builtin_amdgcn_s_sleep(8);
                     }
@@ -836,8 +841,12 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
         fetch(ib + 128, mF, aF, bF, oF);
         fetch_more(ib + 64, mN, oN, aN, bN, cN, dN, fN);
         const uint32_t ie = min(64u, V - ib);
-        for (uint32_t rb = 0; rb < ie; rb += CARRY_BATCH) {
-            const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(CARRY_BATCH, ie - rb)), i0 = ib + rb + 1;   // rows i0 .. i0 + nb - 1
+        uint32_t nb = 0;
+        for (uint32_t rb = 0; rb < ie; rb += nb) {
+            // rows i0 .. i0 + nb - 1: up to CARRY_BATCH rows of the record batch - as many as have their carries in the mailbox, at least CARRY_MIN (a
+            // wave follows its left neighbour at that distance when it keeps up, and the mailbox's 64 entries still absorb a neighbour's hiccup)
+            const uint32_t want = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(CARRY_BATCH, ie - rb)), i0 = ib + rb + 1;
+            nb = want;
             int cinV = NEGK;     // lane r: carry into this wave for row i0 + r
             if (has_in) {
 #ifdef HX_DP_PROF3
@@ -846,11 +855,13 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 for (uint32_t spin = 0;; spin++) {
                     unsigned long long v = 0;
                     bool ok = true;
-                    if (lane < nb) {
+                    if (lane < want) {
                         v = in_lds ? ld_wg64(mb_in_l + ((i0 + lane) & (WAVE_MBOX - 1))) : ld_dev64(mb_in_h + i0 + lane);
                         ok = (uint32_t)v == cl.tag0 + i0 + lane;
                     }
-                    if (__ballot(ok) == ~0ull) { cinV = (int)(uint32_t)(v >> 32); break; }
+                    const unsigned long long okm = __ballot(ok);
+                    const uint32_t run = okm == ~0ull ? want : (uint32_t)__builtin_ctzll(~okm);   // leading rows whose carries have arrived
+                    if (run >= min(want, CARRY_MIN)) { nb = run; cinV = (int)(uint32_t)(v >> 32); break; }
                     if (spin > (in_lds ? WG_POLL_LIMIT : cl.poll_limit)) { if (lane == 0) st_dev(cl.err, in_lds ? 2u : 1u); break; }
                     if (in_lds) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(8);
                 }
