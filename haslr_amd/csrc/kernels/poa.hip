@@ -588,6 +588,44 @@ __device__ __forceinline__ int wave_incl_max(int v) {
         : "=&v"(x) : "v"(v));
     return x;
 }
+// The same scan with the wait states a DPP read needs (two after a VALU write of its source) spent on scalar work of the row instead of s_nop - a lone
+// wave pays ~8 cycles per `s_nop 1` (tools/dev_lonebench.hip). Scalar outputs: the LDS address of mailbox entry i and its tag, the row's ring slot (4 bits of
+// its record) and the slot's byte offset, the record's rare-case bits; the nibble row pointer (dlo, dhi) moves on by dstep.
+__device__ __forceinline__ int wave_incl_max_fill(int v, uint32_t i, uint32_t tag0, uint32_t mb_lds, uint32_t meta, uint32_t ring_w4, uint32_t dstep,
+                                                  uint32_t& mb_addr, uint32_t& mb_tag, uint32_t& slot, uint32_t& rare, uint32_t& roff, uint32_t& dlo, uint32_t& dhi) {
+    int x;
+    // (every scalar operand through readfirstlane: a no-op for a value that already sits in a scalar register, and the only way to tell the compiler so)
+    i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i); tag0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tag0); mb_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb_lds);
+    meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta); ring_w4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ring_w4); dstep = (uint32_t)__builtin_amdgcn_readfirstlane((int)dstep);
+    dlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)dlo); dhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)dhi);
+    asm volatile(
+        "v_mov_b32 %[x], %[v]\n\t"
+        "s_and_b32 %[a], %[i], 63\n\t"
+        "s_lshl_b32 %[a], %[a], 3\n\t"
+        "v_max_i32_dpp %[x], %[v], %[v] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %[x], %[v], %[x] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %[x], %[v], %[x] row_shr:3 row_mask:0xf bank_mask:0xf\n\t"
+        "s_add_i32 %[a], %[a], %[mb]\n\t"
+        "s_add_i32 %[t], %[i], %[tag0]\n\t"
+        "v_max_i32_dpp %[x], %[x], %[x] row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+        "s_bfe_u32 %[slot], %[meta], 0x40008\n\t"
+        "s_and_b32 %[rare], %[meta], 44\n\t"
+        "v_max_i32_dpp %[x], %[x], %[x] row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_mul_i32 %[roff], %[slot], %[rw]\n\t"
+        "s_add_u32 %[dlo], %[dlo], %[dstep]\n\t"
+        "v_max_i32_dpp %[x], %[x], %[x] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_addc_u32 %[dhi], %[dhi], 0\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %[x], %[x], %[x] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : [x] "=&v"(x), [a] "=&s"(mb_addr), [t] "=&s"(mb_tag), [slot] "=&s"(slot), [rare] "=&s"(rare), [roff] "=&s"(roff), [dlo] "+s"(dlo), [dhi] "+s"(dhi)
+        : [v] "v"(v), [i] "s"(i), [tag0] "s"(tag0), [mb] "s"(mb_lds), [meta] "s"(meta), [rw] "s"(ring_w4), [dstep] "s"(dstep) : "scc");
+    // (... and back: the compiler takes what an asm statement writes for divergent - a v_cmp for every test of it, a waterfall loop around the buffer store)
+    mb_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb_addr); mb_tag = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb_tag); slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+    rare = (uint32_t)__builtin_amdgcn_readfirstlane((int)rare); roff = (uint32_t)__builtin_amdgcn_readfirstlane((int)roff);
+    dlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)dlo); dhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)dhi);
+    return x;
+}
 // byte 0 of four registers -> one dword
 __device__ __forceinline__ uint32_t pack_b0(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     const uint32_t ab = __builtin_amdgcn_perm(b, a, 0x0c0c0400u), cd = __builtin_amdgcn_perm(d, c, 0x0c0c0400u);
@@ -789,7 +827,9 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     fetch(64, mF, aF, bF, oF);
     fetch_more(0, mN, oN, aN, bN, cN, dN, fN);
     int32_t* hrow = H;
-    uint8_t* drow = D;
+    uint32_t dlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)D), dhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)D >> 32));   // the row of direction nibbles (a scalar pointer in two halves: wave_incl_max_fill moves it)
+    const uint32_t mb_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)mb_out_l);   // LDS byte address of this wave's mailbox towards the right
+    const uint32_t ring_w4 = ring_w * 4u, tag0_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)cl.tag0), dstep_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(DIR ? W >> 1 : 0u));
     // predecessor row `ent` (slot << 28 | rank): its columns under this lane and the value left of them
     int tp[CM], lnp = NEGK;                  // the previous row's finished keys under this lane, and the key left of the wave's first column (lane 0's is used)
 #pragma unroll
@@ -909,7 +949,6 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                     return md + ((mm64 - m64) & neg);
                 };
                 hrow += WH;
-                if (DIR) drow += W >> 1;
                 DP_T(0);   // row decode
                 int m[CM];
                 {   // the first predecessor (or row 0): diagonal and vertical move
@@ -939,15 +978,17 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
 #pragma unroll
                 for (int k = 1; k < CM; k++) lm = max(lm, m[k]);
                 DP_T(1);   // predecessor rows + cells
-                // prefix maximum over the lanes to the left
-                const int inc = wave_incl_max((lm & ~63) | KHC);
+                // prefix maximum over the lanes to the left; the wait states of its DPP steps do the row's scalar chores (mailbox entry address and tag,
+                // ring slot and its offset, the test word of the rare cases, the step of the nibble row pointer)
+                uint32_t mb_addr, mb_tag, slot, rare, roff;
+                const int inc = wave_incl_max_fill((lm & ~63) | KHC, (uint32_t)__builtin_amdgcn_readfirstlane((int)i), tag0_s, mb_lds, meta, ring_w4, dstep_s, mb_addr, mb_tag, slot, rare, roff, dlo, dhi);
                 int ex = wave_shift_up1(inc, NEGK);
                 DP_T(2);   // wave scan
                 const int cin = __builtin_amdgcn_readlane(cinV, rj);   // NEGK without a wave on the left
                 meta_nx = __builtin_amdgcn_readlane(mC, (ri + 1) & 63u); p0_nx = __builtin_amdgcn_readlane(aC, (ri + 1) & 63u);   // (the next row's record; beyond the batch: unused)
                 // the carry of this row for the wave on the right: the prefix maximum through this wave's last column (lane 63 holds it)
-                if (out_l != 0u) { if (lane == 63) st_wg64(mb_out_l + (i & (WAVE_MBOX - 1)), (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, inc) << 32)); }
-                if (out_h != 0u) { if (lane == 63) st_dev64(mb_out_h + i, (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)max(cin, inc) << 32)); }
+                if (out_l != 0u) { if (lane == 63) *(volatile __attribute__((address_space(3))) unsigned long long*)(uintptr_t)mb_addr = (unsigned long long)mb_tag | ((unsigned long long)(uint32_t)max(cin, inc) << 32); }
+                if (out_h != 0u) { if (lane == 63) st_dev64(mb_out_h + i, (unsigned long long)mb_tag | ((unsigned long long)(uint32_t)max(cin, inc) << 32)); }
                 ex = max(ex, cin);
                 DP_T(3);   // carry in / out
                 // the horizontal recurrence from the finished key left of this chunk (the exclusive prefix; it carries the horizontal code, which
@@ -958,9 +999,8 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
 #pragma unroll
                 for (int k = 1; k < CM; k++) { m[k] = max(m[k], t[k - 1]); t[k] = (m[k] & ~63) | KHC; }
                 const int left_now = ex;              // key of column j0 - 1
-                const uint32_t slot = (meta >> META_SLOT) & 15u;   // (the CSR build counted the kept rows)
-                if (slot != 15u) {   // a kept row goes to its ring slot
-                    int32_t* S = ring_me + slot * ring_w;
+                if (slot != 15u) {   // a kept row goes to its ring slot (the CSR build counted the kept rows)
+                    int32_t* S = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ring_me) + roff);
 #pragma unroll
                     for (int k = 0; k < CM; k++) S[k * PW + 1] = t[k];
                     if (lane == 0) S[(CM - 1) * PW] = left_now;   // (first wave of the edge: "minus infinity")
@@ -975,7 +1015,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                     uint32_t dc[CM];
 #pragma unroll
                     for (int k = 0; k < CM; k++) dc[k] = (uint32_t)m[k];
-                    store_nibbles_buf<CM>(__builtin_amdgcn_make_buffer_rsrc(drow, 0, (int)(W >> 1), 0x00020000), j0 >> 1, dc);
+                    store_nibbles_buf<CM>(__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t*>(((uintptr_t)dhi << 32) | dlo), 0, (int)(W >> 1), 0x00020000), j0 >> 1, dc);
                 }
                 if (!DIR && __builtin_expect(live, 1)) {
                     {
@@ -987,7 +1027,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                     }
                 }
                 DP_T(5);   // stores
-                if (__builtin_expect((meta & (32u | 8u | 4u)) != 0, 0)) {   // ONE test for everything rare: wide row, far reader, sink
+                if (__builtin_expect(rare != 0u, 0)) {   // ONE test for everything rare: wide row, far reader, sink (meta & 44)
                     if (DIR && (meta & 32u) && live) {   // wide row: type * 16 + 15 - slot, a byte per cell
                         uint32_t dc[CM];
 #pragma unroll
