@@ -957,19 +957,34 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
 #pragma unroll
                     for (int k = 0; k < CM; k++) m[k] = max((k == 0 ? left : hp[k - 1]) + score_of(k), hp[k] + gv);
                 }
-                if (__builtin_expect(npred > 1, 0)) {
+                if (npred > 1) {   // (two rows in five at 25-45x)
                     // the maximum over the predecessors: the low bits carry the move type and 15 - p, so ONE running maximum does it all
-                    // (a diagonal beats a vertical move of the same score, the first predecessor in in-edge order beats the later ones)
-                    const uint32_t po = __builtin_amdgcn_readlane(oC, ri);
-                    for (uint32_t p = 1; p < npred; p++) {
-                        // the first four predecessors come with the row records (registers): only a fifth and later ones are fetched here
-                        const uint32_t ent = p == 1 ? __builtin_amdgcn_readlane(bC, ri) : p == 2 ? __builtin_amdgcn_readlane(cC, ri) : p == 3 ? __builtin_amdgcn_readlane(dC, ri)
-                                                    : (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[po + p]);
-                        const int ps = DIR ? (int)p : 0;        // direction bytes exist only while in-degrees stay <= 16 (the CSR build checks)
+                    // (a diagonal beats a vertical move of the same score, the first predecessor in in-edge order beats the later ones).
+                    // The second, third and fourth predecessor are spelled out - their entries come with the row records, one readlane each, and most of
+                    // them live in the LDS ring, which is read here without the general dispatch; a loop that picks the entry by its index and then
+                    // dispatches compiles into a dozen flag tests per predecessor (~300 cycles for a lone wave).
+                    auto more = [&](const uint32_t ent, const int ps, const bool slot_known) {
                         int hp[CM], left;
-                        pred_row(ent, hp, left, p == 1);
+                        const uint32_t loc = ent >> 28;
+                        if (__builtin_expect(loc - 1u < 12u, 1)) {
+                            const int32_t* S = ring_me + (size_t)(loc - 1) * ring_w;
+#pragma unroll
+                            for (int k = 0; k < CM; k++) hp[k] = S[k * PW + 1];
+                            left = S[(CM - 1) * PW];
+                        } else pred_row(ent, hp, left, slot_known);
 #pragma unroll
                         for (int k = 0; k < CM; k++) m[k] = max(m[k], max((k == 0 ? left : hp[k - 1]) + score_of(k) - ps, hp[k] + (gv - ps)));
+                    };
+                    more(__builtin_amdgcn_readlane(bC, ri), DIR ? 1 : 0, true);
+                    if (npred > 2) {
+                        more(__builtin_amdgcn_readlane(cC, ri), DIR ? 2 : 0, false);
+                        if (npred > 3) {
+                            more(__builtin_amdgcn_readlane(dC, ri), DIR ? 3 : 0, false);
+                            if (__builtin_expect(npred > 4, 0)) {   // a fifth and later ones are fetched here (direction bytes exist only while in-degrees stay <= 16: the CSR build checks)
+                                const uint32_t po = __builtin_amdgcn_readlane(oC, ri);
+                                for (uint32_t p = 4; p < npred; p++) more((uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[po + p]), DIR ? (int)p : 0, false);
+                            }
+                        }
                     }
                 }
                 // what this chunk hands to the right whatever comes in from the left: its largest key (the horizontal move of de-ramped keys is a
