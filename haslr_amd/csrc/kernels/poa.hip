@@ -966,14 +966,22 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                     auto more = [&](const uint32_t ent, const int ps, const bool slot_known) {
                         int hp[CM], left;
                         const uint32_t loc = ent >> 28;
-                        if (__builtin_expect(loc - 1u < 12u, 1)) {
-                            const int32_t* S = ring_me + (size_t)(loc - 1) * ring_w;
+                        const bool inring = loc - 1u < 12u;
+                        // the ring row is requested FIRST, whatever the entry is (another kind asks for slot 0 and is overwritten below): one not-taken
+                        // test on the usual path instead of an if / else whose join the compiler guards with a flag test
+                        const int32_t* S = ring_me + (size_t)(inring ? loc - 1u : 0u) * ring_w;
 #pragma unroll
-                            for (int k = 0; k < CM; k++) hp[k] = S[k * PW + 1];
-                            left = S[(CM - 1) * PW];
-                        } else pred_row(ent, hp, left, slot_known);
+                        for (int k = 0; k < CM; k++) hp[k] = S[k * PW + 1];
+                        left = S[(CM - 1) * PW];
+                        if (__builtin_expect(!inring, 0)) pred_row(ent, hp, left, slot_known);
+                        // (diagonal: ONE three-operand add per cell - predecessor key + the cell's substitution term + the slot's code offset)
+                        const int mps = -ps, gvp = gv - ps;
 #pragma unroll
-                        for (int k = 0; k < CM; k++) m[k] = max(m[k], max((k == 0 ? left : hp[k - 1]) + score_of(k) - ps, hp[k] + (gv - ps)));
+                        for (int k = 0; k < CM; k++) {
+                            int dg;
+                            asm("v_add3_u32 %0, %1, %2, %3" : "=v"(dg) : "v"(k == 0 ? left : hp[k - 1]), "v"(score_of(k)), "s"(mps));
+                            m[k] = max(m[k], max(dg, hp[k] + gvp));
+                        }
                     };
                     more(__builtin_amdgcn_readlane(bC, ri), DIR ? 1 : 0, true);
                     if (npred > 2) {
