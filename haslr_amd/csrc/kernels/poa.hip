@@ -1824,7 +1824,9 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                             // keeps type * 16 + 15 - slot in the wide-row pool
                             // (a move into the third or a later predecessor - codes 8, 9, 12, 13 of a 4-bit row - has to fetch that predecessor's rank)
                             uint32_t type = n4 >> 2, slot = 3u - (n4 & 3u);
-                            uint32_t pv = slot == 0 ? (uint32_t)__builtin_amdgcn_readlane((int)pv0, (int)dr) : (uint32_t)__builtin_amdgcn_readlane((int)pv1, (int)dr);
+                            // (both candidates read, the choice made by arithmetic: the compiler turns the obvious select into two branches and a flag test)
+                            const uint32_t pva = (uint32_t)__builtin_amdgcn_readlane((int)pv0, (int)dr), pvb = (uint32_t)__builtin_amdgcn_readlane((int)pv1, (int)dr);
+                            uint32_t pv = pvb ^ ((pva ^ pvb) & (0u - (uint32_t)(slot == 0)));
                             if (__builtin_expect((((0x3300u >> n4) | (wmask >> dr)) & 1u) != 0, 0)) {   // ONE test for the rare moves: a wide row, a third or later predecessor
                                 uint32_t later = (0x3300u >> n4) & 1u;
                                 if ((wmask >> dr) & 1u) {
