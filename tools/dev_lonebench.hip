@@ -10,7 +10,7 @@
 __global__ void k(long long* out, int* sink, int mode) {
     __shared__ unsigned long long lds[256];
     const int tid = threadIdx.x;
-    int a0 = tid + sink[0], a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b0 = 3 + sink[1];
+    int a0 = tid + sink[0], a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7, b0 = 3 + sink[1];
     lds[tid & 255] = tid;
     __syncthreads();
     const uint32_t la = (uint32_t)(uintptr_t)(&lds[tid & 63]);
@@ -40,12 +40,18 @@ __global__ void k(long long* out, int* sink, int mode) {
         case 18: BODY("s_bitcmp1_b32 s42, 5\n\ts_cselect_b32 s40, 63, 15\n\ts_cselect_b32 s41, 47, 11"); break;   // + 16 x 3 SALU
         case 19: BODY("s_mov_b32 m0, s42\n\ts_nop 0\n\tv_writelane_b32 %1, s43, m0"); break;   // + 16 x (m0, writelane)
         case 20: BODY("buffer_store_short %0, %4, s[44:47], 0 offen"); break;          // + 16 x buffer store whose offsets fail the range check (num_records 0)
+        case 22: asm volatile(".rept 8\n\tv_add_u32 %0, %0, %8\n\tv_add_u32 %1, %1, %8\n\tv_add_u32 %2, %2, %8\n\tv_add_u32 %3, %3, %8\n\tv_add_u32 %4, %4, %8\n\tv_add_u32 %5, %5, %8\n\tv_add_u32 %6, %6, %8\n\tv_add_u32 %7, %7, %8\n\t.endr"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0)); break;   // 64 v_add, eight independent chains
+        case 23: asm volatile(".rept 64\n\tv_add_u32 %0, %0, %1\n\t.endr" : "+v"(a0) : "v"(b0)); break;                     // 64 v_add, ONE dependent chain
+        case 24: asm volatile("s_mov_b32 s40, 16\n\t1:\n\tv_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %4\n\ts_sub_u32 s40, s40, 1\n\ts_cmp_lg_u32 s40, 0\n\ts_cbranch_scc1 1b"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0) : "scc", "s40"); break;                           // the same 64 v_add as a loop of 4 (16 taken branches)
+        case 25: asm volatile(".rept 32\n\tv_add_u32 %0, %0, %4\n\tv_max_i32 %1, %1, %0\n\t.endr" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0)); break;   // 64 VALU: pairs, the second depends on the first
         case 21: BODY("s_cmp_eq_u32 0, 1\n\ts_cbranch_scc1 1f\n\t1:\n\ts_cmp_eq_u32 0, 1\n\ts_cbranch_scc1 2f\n\t2:"); break;   // + 16 x two not-taken scc branches back to back
         }
     }
     long long t1 = clock64();
     if (tid == 0) out[mode] = t1 - t0;
-    sink[tid + 8] = a0 + a1 + a2 + a3;
+    sink[tid + 8] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 int main() {
     long long* out; int* sink;
@@ -53,10 +59,11 @@ int main() {
     const char* names[] = {"64 v_add", "+16 s_add", "+16 (s_cmp, branch not taken)", "+16 (s_cmp, branch taken, s_nop)", "+16 (saveexec, s_or exec)", "+16 s_waitcnt lgkmcnt(0)", "+16 s_nop 1",
                            "+16 (readlane, dependent s_lshr)", "+16 v_mov_dpp wave_shr:1", "+16 (v_cmp, vcc branch)", "+16 ds_write_b64", "+16 v_max_dpp row_shr:1", "+16 v_add3 (8-byte)",
                            "+16 (s_andn2 vcc, vccnz branch)", "+16 (s_cmp, branch taken over 256 B)", "+16 readlane",
-                           "+16 (saveexec, execz branch, s_or)", "+16 (readlane, dependent v_add)", "+16 (s_bitcmp, 2 s_cselect)", "+16 (s_mov m0, s_nop, v_writelane)", "+16 buffer_store (out of range)", "+16 x 2 branches not taken"};
+                           "+16 (saveexec, execz branch, s_or)", "+16 (readlane, dependent v_add)", "+16 (s_bitcmp, 2 s_cselect)", "+16 (s_mov m0, s_nop, v_writelane)", "+16 buffer_store (out of range)", "+16 x 2 branches not taken",
+                           "64 v_add, 8 independent chains", "64 v_add, one dependent chain", "64 v_add as a loop of 4 x 16", "32 x (v_add, dependent v_max)"};
     for (int rep = 0; rep < 2; rep++) {
         long long base = 0;
-        for (int m = 0; m < 22; m++) {
+        for (int m = 0; m < 26; m++) {
             k<<<1, 64>>>(out, sink, m); hipDeviceSynchronize();
             long long h; hipMemcpy(&h, out + m, 8, hipMemcpyDeviceToHost);
             const double per = (double)h / ITER;
