@@ -12,10 +12,12 @@
 // edges run concurrently (persistent workgroups pulling edges off a counter when a launch class has more edges than workspace slots).
 //   * sequence k is decoded from the 2-bit packed read arena into a byte row
 //   * DP (dp_rows): rows = graph nodes in topological order, columns = sequence positions, CM contiguous columns per lane kept in
-//     registers. Cells are keys (64 x score + 6 tie-break bits), so one max() per decision reproduces the reference's tie rules and the
-//     low bits are the traceback's direction byte. Horizontal recurrence = lane-serial pass + one DPP prefix-max scan (+ wave totals
-//     through LDS and one LDS-only barrier per row; + one tagged mailbox word per row between members). Rows needed later as
-//     non-adjacent predecessors live in an LDS ring, the overflow in HBM.
+//     registers. Cells are keys (64 x DE-RAMPED score, H - gap x column, + 6 tie-break bits), so one max() per decision reproduces the
+//     reference's tie rules and the low bits are the traceback's direction nibble. Horizontal recurrence = a plain prefix maximum: one DPP
+//     scan of the chunks' largest keys, then one lane-serial pass from the finished key on the left; the waves of an edge form a pipeline
+//     (tagged mailboxes in LDS between waves, one tagged word per row in HBM between members, no barrier inside the DP). Rows needed
+//     later as non-adjacent predecessors live in an LDS ring, the overflow in HBM. The row loop is written against what ONE wave alone on
+//     its SIMD pays per instruction kind (tools/dev_lonebench.hip): scalar flags, one test for the rare cases, buffer-resource stores.
 //   * traceback: the first wavefront walks 32x16 tiles of direction nibbles with v_readlane; a second wavefront, where the workgroup has
 //     one, touches the lines the walk reaches next (cache warm-up only)
 //   * graph update (spoa add_alignment), order update and the rank-ordered CSR rebuild run on all lanes (prefix sums for the ids the
