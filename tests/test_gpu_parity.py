@@ -62,6 +62,19 @@ def test_every_stage_bit_exact(args, sim, ctx, tmp_path):
     assert os.path.getsize(tmp_path / "g" / "asm.final.fa") > 0
 
 
+@pytest.mark.parametrize("lds_supp", ["0", "3"])
+def test_coords_through_the_global_scratch(lds_supp, sim, ctx, tmp_path, monkeypatch):
+    """K5 keeps the sorted lists and event records of an edge in LDS up to 384 supports; HX_COORDS_LDS_SUPP sends every edge (0) or every edge with
+    more than three supports through the global scratch path that only an edge with hundreds of supports would take - same coordinates either way
+    (hairpins included: their output slices are doubled)"""
+    monkeypatch.setenv("HX_COORDS_LDS_SUPP", lds_supp)
+    pre = sim("--genome-len", "150000", "--seed", "22", "--variant-per-mb", "20", "--hairpin-frac", "0.05")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    ro, rg, ob = both(ds, ctx, None, None)
+    assert_same_arrays(ro.coords_out(), rg.coords_out(), "coords")
+    assert ro.cns_out() == rg.cns_out()
+
+
 @pytest.mark.parametrize("block", [64, 128, 512, 1024])
 def test_poa_block_sizes_agree(block, sim, ctx, tmp_path):
     pre = sim("--genome-len", "100000", "--seed", "25", "--variant-per-mb", "20")
