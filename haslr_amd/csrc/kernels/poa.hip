@@ -1473,6 +1473,14 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     __shared__ long long tc;
     if (threadIdx.x == 0) { for (int k = 0; k < 12; k++) ph[k] = 0; tc = clock64(); }
 #define PHASE(k) do { if (tid == 0) { long long _n = clock64(); ph[k] += (unsigned long long)(_n - tc); tc = _n; } } while (0)
+#ifdef HX_GU_PROF   // development: where the graph update (slots 6-10) and the CSR rebuild (slot 11: its first half) spend their cycles - printed by HX_PROF2 (its labels are the DP's)
+#define GU_T0() do { __syncthreads(); if (tid == 0) tg = clock64(); } while (0)
+#define GU_T(k) do { __syncthreads(); if (tid == 0) { long long _n = clock64(); ph[k] += (unsigned long long)(_n - tg); tg = _n; } } while (0)
+    long long tg = 0;
+#else
+#define GU_T0() do { } while (0)
+#define GU_T(k) do { } while (0)
+#endif
 #if defined(HX_DP_PROF2) && !defined(HX_DP_PROF3)
     __shared__ long long tc2;
 #define SUBT(k) do { if (tid == 0) { long long _n = clock64(); ph[k] += (unsigned long long)(_n - tc2); tc2 = _n; } } while (0)
@@ -1971,6 +1979,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
             const bool room = E0 + L + 1 <= g.ecap && L <= g.vcap;   // edges: worst case (every base a new edge); per-base scratch lives in node pools; nodes are counted exactly below
             if (!room) { if (tid == 0) sOk = 0; }
             else {
+                GU_T0();
                 if (tid == 0) sNcand = 0;
                 for (uint32_t p = tid; p < L; p += NT) anode[p] = -2;
                 __syncthreads();
@@ -1978,6 +1987,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                 for (uint32_t k = tid; k < na; k += NT) { const int32_t pos = g.aln_pos[k]; if (pos != -1) { anode[pos] = g.aln_node[k]; nv++; } }
                 if (nv) atomicAdd(&sNcand, nv);
                 __syncthreads();
+                GU_T(6);   // alignment scattered to the bases
                 const bool chain = na == 0;                 // empty graph: the sequence becomes a chain
                 const bool par = chain || sNcand == L;      // always true for a global alignment
                 if (!par) {                                 // (kept for safety: the serial walk handles any alignment shape)
@@ -1997,6 +2007,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                         path[p] = tgt; colref[p] = an >= 0 ? (uint32_t)an : NONE;
                         cnt += tgt == NONE;
                     }
+                    GU_T(7);   // target node of every base (reuse / column member / new)
                     uint32_t newV;
                     uint32_t nid = V0 + block_excl_scan_add(cnt, lds_u, &newV);
                     if (V0 + newV > g.vcap) { if (tid == 0) sOk = 0; }   // the graph outgrows its workspace (same verdict on every lane): the host retries with more
@@ -2014,6 +2025,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                         path[p] = nn;
                     }
                     __syncthreads();
+                    GU_T(8);   // node ids (scan) + new nodes and their columns
                     cnt = 0;
                     for (uint32_t p = max(a0, 1u); p < a1; p++) {
                         const uint32_t f = path[p - 1], t = path[p];
@@ -2023,6 +2035,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                         eref[p] = hit;
                         cnt += hit == NONE;
                     }
+                    GU_T(9);   // existing edge of every step (out-list search)
                     uint32_t newE;
                     uint32_t eid = E0 + block_excl_scan_add(cnt, lds_u, &newE);
                     for (uint32_t p = max(a0, 1u); p < a1; p++) {
@@ -2036,6 +2049,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                         else { g.e_next_in[g.in_tail[t]] = e; if (r[1] == NONE) r[1] = f; else r[3] |= 0x80000000u; }
                         g.in_tail[t] = e;
                     }
+                    GU_T(10);  // edge ids (scan) + new edges appended
                     if (tid == 0) { sV = V0 + newV; sE = E0 + newE; }
                     }
                 }
@@ -2201,7 +2215,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                     for (uint32_t r = r0; r < r1; r++) if (g.row_meta[r] & 32u) g.wslot[r] = wex++;
                     if (tid == 0 && wtot > ED.wrows && sOk == 1) sOk = 7;   // more of them than the estimate: the host retries with more
                 }
-#ifndef HX_DP_PROF
+#if !defined(HX_DP_PROF) && !defined(HX_GU_PROF)
                 if (phase) {   // statistics of the rows the next DP will run over
                     if (st_multi) atomicAdd(&ph[7], (unsigned long long)st_multi);
                     if (st_ring | st_fifth) atomicAdd(&ph[8], (unsigned long long)st_ring | ((unsigned long long)st_fifth << 40));   // (high bits: fifth-and-later predecessor entries, fetched inside the row)
@@ -2256,7 +2270,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
         else if (sOk == 8) { status[eidx] = HXE_POA_STALLED; cns_len[eidx] = 0; }
         else {
             status[eidx] = 0; cns_len[eidx] = !sV ? 0 : sCtl; atomicAdd(cells, sCells);
-#ifndef HX_DP_PROF
+#if !defined(HX_DP_PROF) && !defined(HX_GU_PROF)
             if (phase) atomicAdd(&ph[11], (unsigned long long)sV << 32);   // statistics: nodes of the finished graph (high word)
 #endif
         }
