@@ -339,7 +339,7 @@ def main():
         line = {
             "metric": "long-read bases/sec through backbone+consensus; GFA match + FASTA %identity",
             "value": value, "unit": "long-read bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "fixed-size (configs[3] as named)" if as_named else "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "single GPU" if world == 1 else "fixed-size (configs[3] as named)" if as_named else "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{wl['name']}: {glen} bp genome, {wl['model']}-like 25x long reads + PAF vs short-read contigs "
                                    f"(BASELINE.json configs[{wl['config']}]{(', read-sharded over %d GPUs as BASELINE names it' % world) if as_named else (' x%d, read-sharded' % world if world > 1 else '')})",
@@ -349,11 +349,11 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_poa (launch group: one kernel per lane-count class, concurrent)", "kernel_ms_per_launch": poa_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "gcups": gcups, "dp_cells_per_launch": cells, "poa_workspace_bytes": ctx.poa_workspace_bytes(), "valu_bound_gcups": valu_bound, "frac_of_valu_bound": gcups / valu_bound,
                          "valu_peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "valu_ops_per_cell_model": VALU_OPS_PER_CELL_MODEL, **sq_fig,
-                         "critical_path_ms": critical_ms, "critical_path_share_of_launch": critical_ms / poa_ms if poa_ms > 0 else None,
+                         "critical_path_ms": critical_ms, "critical_path_share_of_launch": critical_ms / poa_ms if poa_ms > 0 else None, "pruning": ctx.poa_prune_stats(),
                          "note": "POA is an O(L^2) integer DP over O(L) bytes: HBM fraction is low by construction (SURVEY.md 8d); GCUPS against the VALU issue bound "
                                  "(256 CU x 4 SIMD-32 x 2.4 GHz lane-ops/s / 10 lane-ops per cell) is the figure of merit; valu_lane_ops_per_cell / valu_issue_util / wait_share are "
                                  "what the SQ counters of the committed profile say the kernel really issues; critical_path_ms = the slowest edge's serial chain (its lane-0 cycle counters / 2.4 GHz)"},
-            "stage_ms": stage_ms, "kernel_ms": kernel_ms, "poa_phase_cycles": phase, "assembly": assembly, "gfa": gfa_gpu,
+            "stage_ms": stage_ms, "kernel_ms": kernel_ms, "poa_phase_cycles": {"edges": phase["edges"], "slowest_edge": phase["slowest_edge"]}, "assembly": assembly, "gfa": gfa_gpu,
             # outside the timed region (the metric starts with parsed, resident inputs): text ingest and the PCIe upload
             "ingest": {"seconds": t_parse, "input_mb": in_bytes / 1e6, "mb_per_s": in_bytes / 1e6 / t_parse, "threads": os.environ.get("HASLR_IO_THREADS", "auto (<= 16)"), "upload_seconds": t_upload},
         }
@@ -378,6 +378,7 @@ def main():
                 line["configs1"] = {"workload": f"{w1['name']}: {w1['genome']} bp genome, pacbio-like 25x (BASELINE.json configs[1])", "value": ds1.total_read_bases * 3 / dt1,
                                     "ms_per_step": dt1 / 3 * 1e3, "steps": 3, "warmup": 1, "edges": run1.n_edges, "kernel_ms_per_launch": p1, "gcups": c1 / (p1 / 1e3) / 1e9,
                                     "long_read_bases": ds1.total_read_bases}
+                line["config"]["configs1_ms_per_step"] = line["configs1"]["ms_per_step"]   # (inside `config`: the driver's record keeps that object)
                 run1.close(); ds1.close()
                 last = None
             except Exception as e:  # noqa: BLE001
@@ -425,7 +426,14 @@ def main():
                                     "kernel_ms_per_launch": p3, "gcups": st3["dp_cells"] / (p3 / 1e3) / 1e9, "dp_cells_per_launch": st3["dp_cells"],
                                     "long_read_bases": ds3.total_read_bases, "poa_workspace_bytes": ctx.poa_workspace_bytes(), "consensus_sha256": h3.hexdigest(),
                                     "critical_path_ms": sum(ph3["slowest_edge"].values()) / SHADER_CLOCK_HZ * 1e3, "stage_ms": {k: v * 1e3 for k, v in run3.timings().items()},
-                                    "simulate_s": t_sim, "parse_s": t_parse3, **sq3}
+                                    "simulate_s": t_sim, "parse_s": t_parse3, "pruning": ctx.poa_prune_stats(), **sq3}
+                # the many-edge figures inside `config` and `roofline`, the objects the driver's record keeps (BENCH_rNN.json.parsed)
+                line["config"].update({"configs3_ms_per_step": line["configs3"]["ms_per_step"], "configs3_gcups": line["configs3"]["gcups"], "configs3_edges": run3.n_edges,
+                                       "configs3_value": line["configs3"]["value"], "configs3_consensus_sha256": h3.hexdigest()})
+                pr3 = line["configs3"]["pruning"]
+                line["roofline"].update({"configs3_kernel_ms_per_launch": p3, "configs3_gcups": line["configs3"]["gcups"], "configs3_frac_of_valu_bound": line["configs3"]["gcups"] / valu_bound,
+                                         "configs3_wave_rows_skipped": (pr3["wave_rows_skipped"] / pr3["wave_rows"]) if pr3["wave_rows"] else None,
+                                         "configs3_valu_lane_ops_per_cell": sq3.get("valu_lane_ops_per_cell")})
                 run3.close(); ds3.close()
             except Exception as e:  # noqa: BLE001
                 line["configs3"] = {"error": str(e)}

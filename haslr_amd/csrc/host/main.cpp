@@ -74,6 +74,8 @@ static bool tooling_attached() {
     return false;
 }
 
+extern char** environ;
+
 int main(int argc, char* argv[]) {
     hx_params prm{500, 0.85, 55, 0.15, 3, 0.0};
     std::string contig_path, long_path, mapping_path, out_dir;
@@ -134,13 +136,28 @@ int main(int argc, char* argv[]) {
     if (grouped) {
         std::vector<int> devs((size_t)gpus);
         for (int r = 0; r < gpus; r++) devs[(size_t)r] = device + r;   // --device with --gpus N: the ranks run on devices device .. device + N - 1
-        if (hx_group_create(gpus, device ? devs.data() : nullptr, &group) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
+        if (hx_group_create(gpus, device ? devs.data() : nullptr, getenv("HASLR_GROUP_TRANSPORT"), &group) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
+        if (const char* ts = getenv("HASLR_GROUP_TIMEOUT_S")) hx_group_set_timeout(group, atof(ts));
         fprintf(stderr, "[NOTE] %d GPU ranks in this process, edge-record exchange over %s\n\n", gpus, hx_group_transport(group));
         ctx = hx_group_ctx(group, 0);
         if (poa_block) for (int r = 0; r < gpus; r++) hx_set_poa_block(hx_group_ctx(group, r), poa_block);
     } else {
         if (hx_ctx_create(device, nullptr, &ctx) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
         if (poa_block) hx_set_poa_block(ctx, poa_block);
+    }
+    // The library reads no environment: this APPLICATION hands the HX_* variables that name library options (hx_option_names) to its contexts, once
+    {
+        const std::string names = std::string(",") + hx_option_names() + ",prof1,prof2,prof3,";
+        for (char** ev = environ; ev && *ev; ev++) {
+            if (strncmp(*ev, "HX_", 3) != 0) continue;
+            const char* eq = strchr(*ev, '=');
+            if (!eq) continue;
+            std::string key((const char*)*ev + 3, eq);
+            for (char& ch : key) ch = (char)tolower((unsigned char)ch);
+            if (names.find("," + key + ",") == std::string::npos) { fprintf(stderr, "[WARNING] %.*s is not an option of this build (ignored)\n", (int)(eq - *ev), *ev); continue; }
+            for (int r = 0; r < (grouped ? gpus : 1); r++)
+                if (hx_set_option(grouped ? hx_group_ctx(group, r) : ctx, key.c_str(), eq + 1) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
+        }
     }
 
     fprintf(stderr, "[NOTE] loading contig sequences, long read sequences and alignments...\n");

@@ -108,6 +108,40 @@ struct PoaPoolBufs {
 };
 }  // namespace
 
+// ---- tuning and test switches of a context. They used to be HX_* environment variables read inside the library on every call; now they are
+// state of the context, set through hx_set_option (include/haslr_hip.h) - by the applications (the CLI and haslr_amd/hip.py copy the HX_*
+// variables of their environment in, once, when they create a context) and by the tests. Defaults in the table below; -1 = automatic.
+namespace {
+struct HxOptions {
+    int debug = 0;                 // progress and statistics of every consensus call on stderr
+    int prof = 0;                  // 1 / 2 / 3: how hx_poa_phase_cycles reads the phase words of a build with -DHX_DP_PROF / PROF2 / PROF3 (development)
+    double poa_workspace_gb = 0;   // cap of the POA workspace in GB (0: 90 % of the memory that was free at the context's first consensus call)
+    int poa_poll_limit = 1 << 24;  // polls before a wave gives up waiting for another member (testing: forces the unshared retry)
+    int poa_max_indeg = 16;        // in-degree the direction bytes hold (testing: forces the score-matrix retry earlier)
+    int poa_member_lanes = 256, poa_cluster_min = 2048, poa_cluster_max = -1, poa_cluster_topk = -1, poa_wide_members = -1, poa_cluster_cols = 4;
+    int poa_node_est_pct = 100, poa_far_rows = -1;
+    int poa_wave_max = 512, poa_cols = -1, poa_ring_kb = -1, poa_ring_zero = 0;
+    int poa_balance = 1, poa_balance_pct = 125, poa_balance_lanes = 512;
+    int poa_slots_pct = 100, poa_slots = 0, poa_batches = 0, poa_force_cm = 0, poa_no_xcd_map = 0, poa_streams = 8, poa_wide_delay_us = 60;
+    int poa_prune = -1;            // exact score-bound pruning of the DP: -1 automatic (calls of thousands of edges), 0 never, else the threshold's percentage of the previous alignment's score per base
+    int poa_prune_lanes = 128;     // ... in launches of workgroups of at least this many lanes (a one-wave workgroup has no block to skip)
+    int coords_lds_supp = -1;      // supports per edge the coordinate kernel sorts in LDS (testing: 0 sends every edge through the global scratch)
+};
+struct OptDesc { const char* name; int HxOptions::*ip; double HxOptions::*dp; };
+const OptDesc kOptions[] = {
+    {"debug", &HxOptions::debug, nullptr}, {"prof", &HxOptions::prof, nullptr}, {"poa_workspace_gb", nullptr, &HxOptions::poa_workspace_gb},
+    {"poa_poll_limit", &HxOptions::poa_poll_limit, nullptr}, {"poa_max_indeg", &HxOptions::poa_max_indeg, nullptr}, {"poa_member_lanes", &HxOptions::poa_member_lanes, nullptr},
+    {"poa_cluster_min", &HxOptions::poa_cluster_min, nullptr}, {"poa_cluster_max", &HxOptions::poa_cluster_max, nullptr}, {"poa_cluster_topk", &HxOptions::poa_cluster_topk, nullptr},
+    {"poa_wide_members", &HxOptions::poa_wide_members, nullptr}, {"poa_cluster_cols", &HxOptions::poa_cluster_cols, nullptr}, {"poa_node_est_pct", &HxOptions::poa_node_est_pct, nullptr},
+    {"poa_far_rows", &HxOptions::poa_far_rows, nullptr}, {"poa_wave_max", &HxOptions::poa_wave_max, nullptr}, {"poa_cols", &HxOptions::poa_cols, nullptr},
+    {"poa_ring_kb", &HxOptions::poa_ring_kb, nullptr}, {"poa_ring_zero", &HxOptions::poa_ring_zero, nullptr}, {"poa_balance", &HxOptions::poa_balance, nullptr},
+    {"poa_balance_pct", &HxOptions::poa_balance_pct, nullptr}, {"poa_balance_lanes", &HxOptions::poa_balance_lanes, nullptr}, {"poa_slots_pct", &HxOptions::poa_slots_pct, nullptr},
+    {"poa_slots", &HxOptions::poa_slots, nullptr}, {"poa_batches", &HxOptions::poa_batches, nullptr}, {"poa_force_cm", &HxOptions::poa_force_cm, nullptr},
+    {"poa_no_xcd_map", &HxOptions::poa_no_xcd_map, nullptr}, {"poa_streams", &HxOptions::poa_streams, nullptr}, {"poa_wide_delay_us", &HxOptions::poa_wide_delay_us, nullptr},
+    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
+};
+}  // namespace
+
 struct hx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -172,6 +206,8 @@ struct hx_ctx {
     DV<uint32_t> poa_order, poa_len, poa_status, poa_counters;
     DV<hxk::PoaSlot> poa_slots;
     uint64_t poa_workspace_bytes = 0;   // largest POA workspace (pools) a call of this context has used
+    uint64_t poa_last_workspace_bytes = 0, poa_free_at_first_call = 0;   // ... the last call's; free device memory when the budget was taken
+    HxOptions opt;
     DV<char> poa_cns;
     DV<unsigned long long> poa_phase_d, poa_cells_d;
     std::vector<unsigned long long> poa_phase;   // per edge x 6, cycles of the last hx_poa_batch
@@ -265,6 +301,38 @@ extern "C" int hx_upload(hx_ctx* c, const hx_contigs* ctg, const hx_reads* rd, c
 }
 
 extern "C" void hx_set_prefiltered(hx_ctx* c, int on) { c->prefiltered = on != 0; }
+
+// option names: lower case, as in kOptions; the old environment variable spellings (HX_POA_SLOTS, HX_DEBUG ...) are accepted too
+static std::string opt_key(const char* name) {
+    std::string k(name ? name : "");
+    for (char& ch : k) ch = (char)tolower((unsigned char)ch);
+    if (k.rfind("hx_", 0) == 0) k = k.substr(3);
+    if (k == "prof1" || k == "prof2" || k == "prof3") return k;
+    return k;
+}
+extern "C" int hx_set_option(hx_ctx* c, const char* name, const char* value) {
+    const std::string k = opt_key(name);
+    const HxOptions dflt;
+    const bool reset = !value || !*value;
+    if (k == "prof1" || k == "prof2" || k == "prof3") { c->opt.prof = reset ? 0 : k[4] - '0'; return 0; }   // (HX_PROF1 / 2 / 3 of the development builds)
+    for (const OptDesc& d : kOptions)
+        if (k == d.name) {
+            char* end = nullptr;
+            if (d.ip) { const long v = reset ? dflt.*(d.ip) : strtol(value, &end, 10); if (!reset && (end == value || *end)) return fail(std::string("hx_set_option: ") + d.name + " takes an integer, not '" + value + "'"); c->opt.*(d.ip) = (int)v; }
+            else { const double v = reset ? dflt.*(d.dp) : strtod(value, &end); if (!reset && (end == value || *end)) return fail(std::string("hx_set_option: ") + d.name + " takes a number, not '" + value + "'"); c->opt.*(d.dp) = v; }
+            return 0;
+        }
+    return fail("hx_set_option: unknown option '" + std::string(name ? name : "") + "' (hx_option_names lists them)");
+}
+extern "C" const char* hx_option_names(void) {
+    static const std::string names = [] { std::string n; for (const OptDesc& d : kOptions) { if (!n.empty()) n += ","; n += d.name; } return n; }();
+    return names.c_str();
+}
+extern "C" int hx_get_option(const hx_ctx* c, const char* name, double* value) {
+    const std::string k = opt_key(name);
+    for (const OptDesc& d : kOptions) if (k == d.name) { *value = d.ip ? (double)(c->opt.*(d.ip)) : c->opt.*(d.dp); return 0; }
+    return fail("hx_get_option: unknown option '" + std::string(name ? name : "") + "'");
+}
 
 extern "C" int hx_set_read_shard(hx_ctx* c, uint32_t b, uint32_t e) {
     if (b > e || e > c->n_reads) return fail("hx_set_read_shard: bad range");
@@ -486,7 +554,7 @@ extern "C" int hx_edge_coords(hx_ctx* c, uint32_t n_sel, const uint32_t* sel, hx
     hxk::CoordsScratch sc{b1.p, e1.p, b2.p, e2.p, cur.p, nullptr, nullptr, best_list.p};
     c->tick();
     hxk::edge_coords(c->rec.view(), c->edge_key.p, c->edge_off.p, c->cg_ops.p, c->clen.p, c->rlen.p, n_sel, d_sel.p, d_cap.p, sc,
-                     c->k_head_end.p, c->k_tail_beg.p, d_nsupp.p, t_lr.p, t_sp.p, t_ep.p, s);
+                     c->k_head_end.p, c->k_tail_beg.p, d_nsupp.p, t_lr.p, t_sp.p, t_ep.p, c->opt.coords_lds_supp, s);
     hxk::exclusive_scan_u32(d_nsupp.p, d_out_off.p, n_sel, s, c->ws);
     if (ws_ok(c, "hx_edge_coords")) return -1;
     uint64_t tot = 0;
@@ -532,101 +600,127 @@ struct PoaInput {
     const uint64_t* d_roff;
     const uint32_t* d_rlen;
 };
-}  // namespace
 
-static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp, hx_cns_out* out) {
-    const auto dbg_t0 = std::chrono::steady_clock::now();
-    memset(out, 0, sizeof(*out));
-    HIPCHK(hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    const uint32_t ne = in.n_edge;
-    // ---- plan: the sub-sequence rule of Assemble.cpp:530-537 (u32 wrap + substr clamp; empty ones skipped)
+struct Need { uint64_t nn = 0, ec = 0, hc = 0, dc = 0, wc = 0, lm = 0, st = 0, al = 0; };
+inline void need_max(Need& a, const Need& b) {
+    a.nn = std::max(a.nn, b.nn); a.ec = std::max(a.ec, b.ec); a.hc = std::max(a.hc, b.hc); a.dc = std::max(a.dc, b.dc); a.wc = std::max(a.wc, b.wc);
+    a.lm = std::max(a.lm, b.lm); a.st = std::max(a.st, b.st); a.al = std::max(a.al, b.al);
+}
+inline uint64_t need_bytes(const Need& n) { return n.nn * 90 + n.ec * 28 + n.hc * 4 + n.dc + n.wc + n.lm + n.st * 4 + n.al * 8; }
+
+// launch classes: (shared?, lanes per workgroup, columns per lane, traceback flavour) - one kernel instance each, so that every
+// launch runs with the registers ITS row loop needs (kernels/poa.hip)
+struct Cls {
+    bool shared; uint32_t nt, cm; bool dir;
+    uint32_t dpl = 0;   // lanes in the DP when the workgroups are wider (wide cluster members), else 0
+    std::vector<uint32_t> edges;
+    size_t blocks = 0, order_at = 0, slot_at = 0, n_slots = 0;
+    Need need{};
+    bool persistent = false;
+    double share = 0;   // of the batch's wave-slot time: DP rows x lanes reserved
+};
+
+constexpr int NCLS = 11;
+constexpr uint64_t kPoaLdsMax = 140 * 1024;   // dynamic LDS of a POA workgroup at most (160 KB per CU less the 1024-lane kernel's static 16.5 KB: sink lists, wave mailboxes)
+const int kClassNT[NCLS] = {0, 1024, 512, 256, 128, 64, 1024, 512, 256, 128, 64};
+constexpr size_t kManyEdges = 3000;
+
+// One consensus call: the PLAN (sub-sequences, per-edge capacities, launch classes, workspace slots and batches against the memory budget), the
+// LAUNCH of a batch, and the COLLECTION of its results with the verdict on every edge (done / again with more room / again another way).
+struct PoaCall {
+    hx_ctx* c;
+    const PoaInput& in;
+    const hx_poa_params* pp;
+    const HxOptions& o;
+    const uint32_t ne;
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     PoaPlan P;
-    P.edges.resize(ne); P.sumL.assign(ne, 0); P.nseq.assign(ne, 0);
-    uint64_t seq_bases = 0, n_aligned = 0;
-    for (uint32_t e = 0; e < ne; e++) {
-        hxk::PoaEdge& E = P.edges[e];
-        memset(&E, 0, sizeof(E));
-        E.seq_begin = (uint32_t)P.seqs.size();
-        for (uint64_t k = in.supp_off[e]; k < in.supp_off[e + 1]; k++) {
-            uint32_t rid = in.supp_lr[k] & 0x7fffffffu, strand = in.supp_lr[k] >> 31;
-            uint32_t rl = in.h_rlen[rid], sp = in.spos[k], ep = in.epos[k];
-            if (sp > rl) return fail("hx_poa_batch: consensus support starts beyond its read (the reference would throw std::out_of_range, Assemble.cpp:530)");
-            uint32_t want = ep - sp + 1, n = std::min(want, rl - sp);
-            if (n == 0) continue;
-            P.seqs.push_back({rid, strand, sp, n});
-            P.sumL[e] += n; P.nseq[e]++; E.lmax = std::max(E.lmax, n);
-            seq_bases += n; n_aligned++;
+    uint64_t seq_bases = 0, n_aligned = 0, budget = 0;
+    std::vector<std::string> cns;
+    std::vector<uint8_t> grow;         // times an edge's graph outgrew its workspace: the node estimate doubles each time
+    std::vector<uint8_t> force_nodir;  // edges whose in-degrees outgrew the direction bytes
+    std::vector<uint8_t> full_h;       // edges that run with the score-matrix traceback
+    std::vector<uint8_t> wide_grow;    // times an edge had more rows with over 4 predecessors than its wide-row pool: the estimate quadruples each time
+    std::vector<uint8_t> no_share;     // edges whose members did not get through together: one workgroup from now on
+    std::vector<uint8_t> many_sinks;   // edges with more sink rows than the smaller kernels keep in LDS: one 1024-lane workgroup
+    std::vector<uint8_t> far_full;     // times an edge's far rows outgrew the estimate: four times the room each time
+    std::vector<uint32_t> mlanes;      // shared edges: lanes per member (the option's, or 1024 where the gap needs them to fit at all)
+    // knobs of this round (the option, or what the number of edges in the call asks for)
+    bool many_edges = false, balanced = false;
+    uint32_t cl_lanes = 256, cl_min = 2048, cl_max = 16, cl_pref = 16, cl_topk = 192, wide_k = 0, cl_cols = 4, cols_per_lane = 4, wave_max = 512, prune_pct = 0;
+    uint64_t ring_kb_wave = 0;
+    double balance_f = 1.25;
+    uint32_t balance_nt = 512;
+
+    PoaCall(hx_ctx* c_, const PoaInput& in_, const hx_poa_params* pp_) : c(c_), in(in_), pp(pp_), o(c_->opt), ne(in_.n_edge) {}
+    double ms_since_start() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+
+    // ---- plan, part 1: the sub-sequence rule of Assemble.cpp:530-537 (u32 wrap + substr clamp; empty ones skipped)
+    int plan_input(std::vector<uint32_t>& todo) {
+        P.edges.resize(ne); P.sumL.assign(ne, 0); P.nseq.assign(ne, 0);
+        for (uint32_t e = 0; e < ne; e++) {
+            hxk::PoaEdge& E = P.edges[e];
+            memset(&E, 0, sizeof(E));
+            E.seq_begin = (uint32_t)P.seqs.size();
+            for (uint64_t k = in.supp_off[e]; k < in.supp_off[e + 1]; k++) {
+                uint32_t rid = in.supp_lr[k] & 0x7fffffffu, strand = in.supp_lr[k] >> 31;
+                uint32_t rl = in.h_rlen[rid], sp = in.spos[k], ep = in.epos[k];
+                if (sp > rl) return fail("hx_poa_batch: consensus support starts beyond its read (the reference would throw std::out_of_range, Assemble.cpp:530)");
+                uint32_t want = ep - sp + 1, n = std::min(want, rl - sp);
+                if (n == 0) continue;
+                P.seqs.push_back({rid, strand, sp, n});
+                P.sumL[e] += n; P.nseq[e]++; E.lmax = std::max(E.lmax, n);
+                seq_bases += n; n_aligned++;
+            }
+            E.seq_end = (uint32_t)P.seqs.size();
         }
-        E.seq_end = (uint32_t)P.seqs.size();
+        for (uint32_t e = 0; e < ne; e++) if (P.nseq[e]) todo.push_back(e);
+        cns.assign(ne, std::string());
+        grow.assign(ne, 0); force_nodir.assign(ne, 0); full_h.assign(ne, 0); wide_grow.assign(ne, 0); no_share.assign(ne, 0); many_sinks.assign(ne, 0); far_full.assign(ne, 0);
+        mlanes.assign(ne, 0);
+        return 0;
     }
-    std::vector<uint32_t> todo;
-    if (getenv("HX_DEBUG")) fprintf(stderr, "[hx] POA call: %u edges prepared in %.1f ms\n", (unsigned)ne, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count());
-    for (uint32_t e = 0; e < ne; e++) if (P.nseq[e]) todo.push_back(e);
-    c->dbg_cls.assign(ne, 11); for (int k = 0; k < 11; k++) c->dbg_ring[k] = 0;
-    c->dbg_nseq = P.nseq; c->dbg_lmax.resize(ne); for (uint32_t e = 0; e < ne; e++) c->dbg_lmax[e] = P.edges[e].lmax;
-    std::vector<uint32_t> cns_len(ne, 0);
-    std::vector<std::string> cns(ne);
-    DV<hxk::PoaSeq>& d_seqs = c->poa_seqs;
-    HIPCHK(d_seqs.reserve(P.seqs.size()));
-    if (!P.seqs.empty()) HIPCHK(hipMemcpyAsync(d_seqs.p, P.seqs.data(), P.seqs.size() * sizeof(hxk::PoaSeq), hipMemcpyHostToDevice, s));
-    DV<unsigned long long>& d_cells = c->poa_cells_d;
-    HIPCHK(d_cells.reserve(1));
-    HIPCHK(hipMemsetAsync(d_cells.p, 0, 8, s));
-    if (!c->poa_budget) {   // measured once: later calls would count the context's own (persistent) workspace as used
-        size_t free_b = 0, total_b = 0;
-        HIPCHK(hipMemGetInfo(&free_b, &total_b));
-        c->poa_budget = (uint64_t)(free_b * 0.9);
+
+    // ---- plan, part 2: the knobs of a round. Sharing an edge buys latency for that edge and costs throughput. Hundreds of edges (the longest is the
+    // step): up to 16 members, the 192 costliest shared. Thousands (every CU busy anyway): 8 members (more only where a gap needs them to fit at
+    // all), the 32 costliest - measured on 13 262 edges: 2.10 s with 16 x 192, 1.98 s with 8 x 32, 2.29 s without sharing (the largest edges then
+    // run on after everything else has finished). (The two launch shapes cross between 2 200 and 3 300 edges: 292 against 313 ms at 2 214 edges,
+    // 390-400 against 374 ms at 3 294.)
+    int knobs(size_t n_todo) {
+        const bool many_in = ne > kManyEdges;
+        many_edges = n_todo > kManyEdges;
+        cl_lanes = (uint32_t)o.poa_member_lanes; cl_min = (uint32_t)o.poa_cluster_min;
+        cl_max = o.poa_cluster_max >= 0 ? (uint32_t)o.poa_cluster_max : 16;           // members per edge at most
+        cl_pref = o.poa_cluster_max >= 0 ? cl_max : many_in ? 8 : 16;                 // ... unless the gap needs more to fit at all
+        cl_topk = o.poa_cluster_topk >= 0 ? (uint32_t)o.poa_cluster_topk : many_in ? 32 : 192;   // shared edges per call at most (the costliest)
+        wide_k = o.poa_wide_members >= 0 ? (uint32_t)o.poa_wide_members : 0;         // shared edges per call (the costliest) whose members are 1024-lane workgroups (default: size_edges)
+        cl_cols = (uint32_t)o.poa_cluster_cols;                                       // columns per lane a member aims at
+        wave_max = (uint32_t)o.poa_wave_max;                                          // columns handled by ONE wavefront per edge
+        // columns per lane of the multi-wave classes: 4 while edges are few (more lanes = a shorter row for the edges that set the step time),
+        // 8 when thousands of edges keep every CU busy anyway (a row then costs fewer instructions in total: the per-row overhead is per wave).
+        cols_per_lane = o.poa_cols > 0 ? (uint32_t)o.poa_cols : many_edges ? 8 : 4;
+        // LDS of the kept-row ring. Few edges (their longest sets the duration): as many kept rows as fit, so that hardly any row is read back
+        // from HBM. Thousands of edges (every CU busy): what counts is waves per SIMD - each wave spends most of its time waiting for its own
+        // dependent instructions - so the ring is cut to `poa_ring_kb` per wave and several workgroups share a CU.
+        ring_kb_wave = o.poa_ring_kb > 0 ? (uint64_t)o.poa_ring_kb : many_edges ? 11 : 0;   // 0 = no cut
+        // Balanced launch for calls of thousands of edges: see build_classes / slots_wanted
+        balanced = many_edges && o.poa_balance != 0;
+        balance_f = std::max(10, o.poa_balance_pct) / 100.0;
+        balance_nt = (uint32_t)o.poa_balance_lanes;                                   // classes of at least this many lanes per workgroup get a share
+        // Exact score-bound pruning (kernels/poa.hip PRUNE) skips the (row, wave) blocks that cannot reach the alignment's score: work saved in the
+        // multi-wave launches of a call whose CUs are all busy; a chain-bound call (hundreds of edges, the longest one is the step) gains nothing
+        // from it - a row stays a row - so there the full-matrix instances run. poa_prune: -1 automatic, 0 never, else the percentage.
+        prune_pct = o.poa_prune < 0 ? (many_edges ? 95u : 0u) : (uint32_t)o.poa_prune;
+        if (cl_lanes != 64 && cl_lanes != 128 && cl_lanes != 256 && cl_lanes != 512 && cl_lanes != 1024) return fail("option poa_member_lanes must be 64, 128, 256, 512 or 1024");
+        return 0;
     }
-    // HX_POA_WORKSPACE_GB: cap of the POA workspace (default: 90 % of what was free when the context first ran a consensus). The workgroups in
-    // flight per launch class are scaled down until the slots fit. Measured at 140 Mb (13 230 edges): 257 GB 2.0-2.1 s, 138 GB 2.10-2.13 s (and
-    // the first call, which allocates the pools, 4.1 instead of 5-7.6 s), 39 GB 4.6 s, 22 GB 8.5 s; a 400 Mb genome (37 608 edges): 148 GB 6.7 s.
-    const uint64_t budget = getenv("HX_POA_WORKSPACE_GB") ? (uint64_t)(atof(getenv("HX_POA_WORKSPACE_GB")) * 1e9) : c->poa_budget;
-    PoaPoolBufs& B = c->poa_pools;
-    DV<hxk::PoaEdge>& d_edges = c->poa_edges;
-    DV<uint32_t>&d_order = c->poa_order, &d_len = c->poa_len, &d_status = c->poa_status;
-    DV<char>& d_cns = c->poa_cns;
-    DV<unsigned long long>& d_phase = c->poa_phase_d;
-    HIPCHK(d_phase.reserve((size_t)ne * 12));
-    HIPCHK(hipMemsetAsync(d_phase.p, 0, std::max<size_t>(1, (size_t)ne * 12) * 8, s));
-    std::vector<uint8_t> grow(ne, 0);          // times an edge's graph outgrew its workspace: the node estimate doubles each time
-    std::vector<uint8_t> force_nodir(ne, 0);   // edges whose in-degrees outgrew the direction bytes
-    std::vector<uint8_t> full_h(ne, 0);        // edges that run with the score-matrix traceback
-    std::vector<uint8_t> wide_grow(ne, 0);     // times an edge had more rows with over 4 predecessors than its wide-row pool: the estimate quadruples each time
-    std::vector<uint8_t> no_share(ne, 0);      // edges whose members did not get through together: one workgroup from now on
-    std::vector<uint8_t> many_sinks(ne, 0);    // edges with more sink rows than the smaller kernels keep in LDS: one 1024-lane workgroup
-    const uint32_t poll_limit = getenv("HX_POA_POLL_LIMIT") ? (uint32_t)atol(getenv("HX_POA_POLL_LIMIT")) : 1u << 24;   // (testing: forces the unshared retry)
-    const uint32_t max_indeg = (getenv("HX_POA_MAX_INDEG") ? std::min<uint32_t>(16, (uint32_t)atoi(getenv("HX_POA_MAX_INDEG"))) : 16);   // (testing: forces the score-matrix retry earlier)
-    const uint32_t cl_lanes = getenv("HX_POA_MEMBER_LANES") ? (uint32_t)atoi(getenv("HX_POA_MEMBER_LANES")) : 256;   // lanes per cluster member
-    const uint32_t cl_min = getenv("HX_POA_CLUSTER_MIN") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MIN")) : 2048;       // columns above which an edge is shared
-    // Sharing an edge buys latency for that edge and costs throughput. Hundreds of edges (the longest is the step): up to 16 members, the
-    // 192 costliest shared. Thousands (every CU busy anyway): 8 members (more only where a gap needs them to fit), the 32 costliest - measured on 13 262 edges: 2.10 s with 16 x 192,
-    // 1.98 s with 8 x 32, 2.29 s without sharing (the largest edges then run on after everything else has finished).
-    // (the two launch shapes cross between 2 200 and 3 300 edges: 292 against 313 ms at 2 214 edges, 390-400 against 374 ms at 3 294)
-    constexpr size_t kManyEdges = 3000;
-    const bool many_edges_in = ne > kManyEdges;
-    const uint32_t cl_max = getenv("HX_POA_CLUSTER_MAX") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_MAX")) : 16;                              // members per edge at most
-    const uint32_t cl_pref = getenv("HX_POA_CLUSTER_MAX") ? cl_max : many_edges_in ? 8 : 16;                                                  // ... unless the gap needs more to fit at all
-    const uint32_t cl_topk = getenv("HX_POA_CLUSTER_TOPK") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_TOPK")) : many_edges_in ? 32 : 192;    // shared edges per call at most (the costliest)
-    uint32_t wide_k = getenv("HX_POA_WIDE_MEMBERS") ? (uint32_t)atoi(getenv("HX_POA_WIDE_MEMBERS")) : 0;   // shared edges per call (the costliest) whose members are 1024-lane workgroups (default: below)
-    const uint32_t cl_cols = getenv("HX_POA_CLUSTER_COLS") ? (uint32_t)atoi(getenv("HX_POA_CLUSTER_COLS")) : 4;            // columns per lane a member aims at
-    const uint64_t est_pct = getenv("HX_POA_NODE_EST_PCT") ? (uint64_t)std::max(1L, atol(getenv("HX_POA_NODE_EST_PCT"))) : 100;   // (testing: scales the node estimate)
-    const long far_rows = getenv("HX_POA_FAR_ROWS") ? atol(getenv("HX_POA_FAR_ROWS")) : -1;   // (testing: rows of H per edge on the first attempt)
-    if (cl_lanes != 64 && cl_lanes != 128 && cl_lanes != 256 && cl_lanes != 512 && cl_lanes != 1024) return fail("HX_POA_MEMBER_LANES must be 64, 128, 256, 512 or 1024");
+
     // lanes per edge. Gaps up to 2047 bases: ONE wavefront per edge (row in registers, no barriers, many edges per CU).
     // Longer gaps: a multi-wave workgroup with ~8 columns per lane (256..1024 lanes). One launch per class, classes run concurrently.
     // Class 0 = edges shared by several workgroups (cluster members of cl_lanes lanes); classes 1..5 = one workgroup per edge.
     // Classes 6..10 = classes 1..5 for the edges that need the score-matrix traceback (rare: an in-degree
     // the direction bytes cannot hold, or the test switch), launched after their direction-byte twins on the same streams.
-    constexpr int NCLS = 11;
-    static constexpr uint64_t kPoaLdsMax = 140 * 1024;   // dynamic LDS of a POA workgroup at most (160 KB per CU less the 1024-lane kernel's static 16.5 KB: sink lists, wave mailboxes)
-    static const int kClassNT[NCLS] = {0, 1024, 512, 256, 128, 64, 1024, 512, 256, 128, 64};
-    const uint32_t wave_max = getenv("HX_POA_WAVE_MAX") ? (uint32_t)atoi(getenv("HX_POA_WAVE_MAX")) : 512;   // columns handled by ONE wavefront per edge
-    // columns per lane of the multi-wave classes: 4 while edges are few (more lanes = a shorter row for the edges that set the step time),
-    // 16 when thousands of edges keep every CU busy anyway (a row then costs fewer instructions in total: the per-row overhead is per wave).
-    // Measured: 1 846 edges 463 ms with 4 vs 482 ms with 16; 5 570 edges 1 166 vs 1 151 ms; 13 262 edges 4.17 vs 3.97 s.
-    const uint32_t cols_per_lane = getenv("HX_POA_COLS") ? (uint32_t)atoi(getenv("HX_POA_COLS")) : todo.size() > kManyEdges ? 8 : 4;
-    auto class_of = [&](uint32_t e) -> int {   // launch class of an edge that is not shared (members == 1), direction-byte flavour
+    int class_of(uint32_t e) const {   // launch class of an edge that is not shared (members == 1), direction-byte flavour
         static const uint32_t kMaxCm[6] = {0, 8, 16, 32, 32, 32};   // columns per lane each kernel variant keeps in registers
         const uint32_t ncol = P.edges[e].lmax + 1;
         int k = 5;
@@ -635,35 +729,28 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
         else if (ncol > wave_max) { k = 4; while (k > 1 && (uint64_t)kClassNT[k] * cols_per_lane < ncol) k--; }
         while (k > 1 && (uint64_t)kClassNT[k] * kMaxCm[k] < ncol) k--;
         return k;
-    };
-    // LDS of the kept-row ring. Few edges (their longest sets the duration): as many kept rows as fit, so that hardly any row is read back
-    // from HBM. Thousands of edges (every CU busy): what counts is waves per SIMD - each wave spends most of its time waiting for its own
-    // dependent instructions - so the ring is cut to HX_POA_RING_KB per wave and several workgroups share a CU.
-    const bool many_edges = todo.size() > kManyEdges;
-    const uint64_t ring_kb_wave = getenv("HX_POA_RING_KB") ? (uint64_t)std::max(1, atoi(getenv("HX_POA_RING_KB"))) : many_edges ? 11 : 0;   // 0 = no cut
-    // Packed 16-bit rows (kernels/poa.hip dp_rows16): every direction-byte launch with 4 or 8 columns per lane, when the scores fit. OPT-IN (HX_POA_PK16=1):
-    // bit-exact like the int32 rows, but measured slower in both regimes on gfx950 (12 Mb step 252 against 238 ms, 140 Mb consensus 2.22 against 2.10 s in the
-    // same calls) - v_pk_* are 4-cycle instructions like v_max_i32, the row's fixed part grows by a table read and a scalar frame chain
-    const bool pk_on = getenv("HX_POA_PK16") && atoi(getenv("HX_POA_PK16")) != 0;
-    auto pk_of = [&](uint32_t cm, bool dir) -> bool { return pk_on && dir && cm <= 8 && hxk::poa_pk16_ok(pp->match, pp->mismatch, pp->gap, (int)cm); };
-    auto ring_rows_of = [ring_kb_wave](uint32_t nt, uint32_t cm, bool pk, uint64_t& row_bytes) -> uint32_t {   // kept rows the LDS ring holds; row_bytes returns the LDS bytes of the ring (+ the score registers of packed rows)
-        row_bytes = (uint64_t)(pk ? cm / 2 : cm) * (nt / 64) * 65 * 4;   // planes of 65 words per wave
-        const uint64_t tbl = pk ? (uint64_t)(nt / 64) * 512 * cm : 0;   // packed rows: 4 letters x 64 lanes x cm / 2 registers per wave
+    }
+    uint32_t lanes_of(uint32_t e) const { return P.edges[e].members > 1 ? mlanes[e] : (uint32_t)kClassNT[class_of(e)]; }   // lanes of the edge's workgroup(s)
+    static uint32_t cm_round(uint32_t ncol, uint32_t lanes) { uint32_t cm = (ncol + lanes - 1) / lanes, r = 4; while (r < cm) r <<= 1; return r; }
+    // kept rows the LDS ring holds; row_bytes returns the LDS bytes of the ring
+    uint32_t ring_rows_of(uint32_t nt, uint32_t cm, uint64_t& row_bytes) const {
+        row_bytes = (uint64_t)cm * (nt / 64) * 65 * 4;   // planes of 65 words per wave
         uint64_t lds_budget = nt >= 1024 ? 128 * 1024 : nt == 64 ? 32 * 1024 : 64 * 1024 * (nt / 128 > 2 ? 2 : 1);
-        if (ring_kb_wave) lds_budget = std::min<uint64_t>(lds_budget, std::max<uint64_t>(ring_kb_wave * 1024 * (nt / 64), 2 * row_bytes + tbl));
-        if (2 * row_bytes + tbl > lds_budget) lds_budget = kPoaLdsMax;   // wide rows: whatever the CU has
-        const uint64_t rows_fit = (std::min<uint64_t>(lds_budget, kPoaLdsMax) - std::min<uint64_t>(tbl, kPoaLdsMax)) / row_bytes;
+        if (ring_kb_wave) lds_budget = std::min<uint64_t>(lds_budget, std::max<uint64_t>(ring_kb_wave * 1024 * (nt / 64), 2 * row_bytes));
+        if (2 * row_bytes > lds_budget) lds_budget = kPoaLdsMax;   // wide rows: whatever the CU has
+        const uint64_t rows_fit = std::min<uint64_t>(lds_budget, kPoaLdsMax) / row_bytes;
         uint32_t R = rows_fit >= 8 ? 8 : rows_fit >= 4 ? 4 : rows_fit >= 2 ? 2 : 0;   // kept rows: a power of two (slot = kept-row counter & (R-1)); 0 = every kept row goes through HBM
-        if (getenv("HX_POA_RING_ZERO")) R = 0;                          // (testing: the ring-less mode that otherwise only gaps above 16 383 columns in ONE workgroup reach)
-        row_bytes = row_bytes * std::max<uint32_t>(R, 1) + tbl;         // -> LDS bytes (at least one row's worth: the kernel's other phases use the space too)
+        if (o.poa_ring_zero) R = 0;                                    // (testing: the ring-less mode that otherwise only gaps above 16 383 columns in ONE workgroup reach)
+        row_bytes = row_bytes * std::max<uint32_t>(R, 1);              // -> LDS bytes (at least one row's worth: the kernel's other phases use the space too)
         return R;
-    };
-    auto cm_round = [](uint32_t ncol, uint32_t lanes) -> uint32_t { uint32_t cm = (ncol + lanes - 1) / lanes, r = 4; while (r < cm) r <<= 1; return r; };
-    std::vector<uint8_t> far_full(ne, 0);      // times an edge's far rows outgrew the estimate: four times the room each time
+    }
     // DP work of an edge ~ sum over its sequences of (nodes so far) x (length): with nodes growing linearly that is about half of
-    // (final nodes) x (longest sequence) x (sequences). vcap < 2^21, lmax < 2^16, nseq < 2^24: no overflow
-    auto edge_cost = [&](uint32_t e) -> uint64_t { return (uint64_t)P.edges[e].vcap * P.edges[e].lmax * std::max<uint32_t>(1, P.nseq[e]); };
-    while (!todo.empty()) {
+    // (final nodes) x (longest sequence) x (sequences). vcap < 2^21, lmax < 2^20, nseq < 2^24: no overflow
+    uint64_t edge_cost(uint32_t e) const { return (uint64_t)P.edges[e].vcap * P.edges[e].lmax * std::max<uint32_t>(1, P.nseq[e]); }
+
+    // ---- plan, part 3: per-edge capacities, members, far / wide row estimates; orders `todo` costliest first
+    int size_edges(std::vector<uint32_t>& todo) {
+        const uint64_t est_pct = (uint64_t)std::max(1, o.poa_node_est_pct);   // (testing: scales the node estimate)
         // ---- workspace sizes. Nodes of the finished graph: measured (nodes - L) / (L x sequences) on 13 %-error PacBio-like and 12 %-error
         // Nanopore-like reads is 0.05-0.06 (median), 0.07-0.08 (99th percentile, small edges). The estimate allows 0.09 plus a fifth of L
         // (a tighter one - 0.07 plus a twelfth - sent 7 of 13 230 edges of the 140 Mb data into a second attempt, which cost more than the memory was worth)
@@ -679,13 +766,25 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             // rows of H. The score-matrix traceback keeps every row; with direction bytes only rows that a successor reads after they left
             // the LDS ring go to HBM (about 1 row in 1000 on PacBio-like data): a sixteenth of the rows is the estimate, all of them the retry
             full_h[e] = c->poa_no_dir || force_nodir[e];   // (any number of sequences: the kernel reports an in-degree the direction bytes cannot hold, see max_indeg)
-
-            // long gaps: the DP columns of the edge are shared by several workgroups (one CU each), ~8 columns per lane
-            E.members = 1;
+            // long gaps: the DP columns of the edge are shared by several workgroups (one CU each). Members of cl_lanes lanes x up to 32 columns per
+            // lane x up to cl_max members hold 131 071 columns by default; a longer gap sub-sequence (the u32 wrap of Assemble.cpp:530 makes "the whole
+            // tail of a read" a real case) gets 1024-lane members, 16 of which hold 524 287 columns.
+            E.members = 1; mlanes[e] = cl_lanes;
             const uint32_t ncol = E.lmax + 1;
-            if (!c->poa_block && !c->poa_no_dir && !force_nodir[e] && !many_sinks[e] && !no_share[e] && ncol > cl_min) E.members = (uint32_t)std::min<uint64_t>(cl_max, std::max<uint64_t>(std::min<uint64_t>(cl_pref, (ncol + (uint64_t)cl_lanes * cl_cols - 1) / ((uint64_t)cl_lanes * cl_cols)),
-                                                                                                                                                                                       (ncol + (uint64_t)cl_lanes * 32 - 1) / ((uint64_t)cl_lanes * 32)));
-            if (E.members < 2 || ((uint64_t)ncol + (uint64_t)E.members * cl_lanes - 1) / ((uint64_t)E.members * cl_lanes) > 32) E.members = 1;   // (members too small for this gap: one workgroup)
+            if (ncol >= (1u << 20)) return fail("hx_poa_batch: a gap sub-sequence of " + std::to_string(ncol - 1) + " bases is longer than the POA kernel's score keys hold (1 048 574)");
+            const bool may_share = !c->poa_block && !c->poa_no_dir && !force_nodir[e] && !many_sinks[e] && !no_share[e];
+            if (may_share && ncol > cl_min) {
+                auto members_for = [&](uint32_t lanes) -> uint64_t {
+                    return std::min<uint64_t>(cl_max, std::max<uint64_t>(std::min<uint64_t>(cl_pref, (ncol + (uint64_t)lanes * cl_cols - 1) / ((uint64_t)lanes * cl_cols)), (ncol + (uint64_t)lanes * 32 - 1) / ((uint64_t)lanes * 32)));
+                };
+                uint64_t mb = members_for(cl_lanes);
+                if (((uint64_t)ncol + mb * cl_lanes - 1) / (mb * cl_lanes) > 32 && cl_lanes < 1024) { mlanes[e] = 1024; mb = members_for(1024); }   // (the gap does not fit the configured members)
+                E.members = (uint32_t)mb;
+            }
+            if (E.members < 2 || ((uint64_t)ncol + (uint64_t)E.members * mlanes[e] - 1) / ((uint64_t)E.members * mlanes[e]) > 32) E.members = 1;   // (members too small for this gap: one workgroup)
+            if (E.members == 1 && ncol > 1024u * (uint32_t)hxk::poa_kernel_max_cm(1024))
+                return fail("hx_poa_batch: a gap sub-sequence of " + std::to_string(ncol - 1) + " bases needs the shared (cluster) mode - direction-byte traceback, automatic block size - with " +
+                            std::to_string((ncol + 1024 * 32 - 1) / (1024 * 32)) + " members of 1024 lanes (option poa_cluster_max: " + std::to_string(cl_max) + ")");
         }
         // Sharing an edge among several CUs buys latency for the edge and costs throughput (the other members idle while member 0 walks
         // back and updates the graph). It pays while large edges are few; with many of them only the costliest keep their members.
@@ -693,10 +792,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             std::vector<uint32_t> sh;
             for (uint32_t e : todo) if (P.edges[e].members > 1) sh.push_back(e);
             if (sh.size() > cl_topk) {
-                std::sort(sh.begin(), sh.end(), [&](uint32_t a, uint32_t b) {
-                    const uint64_t ca = edge_cost(a), cb = edge_cost(b);
-                    return ca != cb ? ca > cb : a < b;
-                });
+                std::sort(sh.begin(), sh.end(), [&](uint32_t a, uint32_t b) { const uint64_t ca = edge_cost(a), cb = edge_cost(b); return ca != cb ? ca > cb : a < b; });
                 for (size_t q = cl_topk; q < sh.size(); q++) if (P.edges[sh[q]].lmax + 1 <= 8192) P.edges[sh[q]].members = 1;   // (longer gaps than a 1024-lane workgroup holds with its ring stay shared)
             }
         }
@@ -705,22 +801,22 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
         // / throughput. Measured (Nanopore-like 25x): 4.6 Mb / 12 Mb genomes (423 / 1 079 edges) 0.190 -> 0.177 s and 0.248 -> 0.230 s with them, but 20 Mb
         // (1 864 edges, a chain 1.75 x longer) 0.426 -> 0.454 s and 30 Mb (2 737 edges) 0.327 -> 0.351 s: from ~1 500 edges on the chip is busy whatever the
         // longest chain does, so the edge count decides and the chain / work ratio only keeps calls without a dominant edge out.
-        if (!getenv("HX_POA_WIDE_MEMBERS")) {
+        if (o.poa_wide_members < 0) {
             uint64_t top_rows = 0, sum_cost = 0;
             for (uint32_t e : todo) { top_rows = std::max<uint64_t>(top_rows, (uint64_t)P.edges[e].vcap * std::max<uint32_t>(1, P.nseq[e])); sum_cost += edge_cost(e); }
             wide_k = ne <= 1500 && (double)top_rows * 5e5 > (double)sum_cost ? 4 : 0;
-            if (getenv("HX_DEBUG")) fprintf(stderr, "[hx] wide members: longest chain %.3g node-sequences, all edges %.3g cost units -> %u\n", (double)top_rows, (double)sum_cost, wide_k);
+            if (o.debug) fprintf(stderr, "[hx] wide members: longest chain %.3g node-sequences, all edges %.3g cost units -> %u\n", (double)top_rows, (double)sum_cost, wide_k);
         }
         // rows of H (see full_h above): how many rows leave the LDS ring before their last reader depends on how many the ring holds
         for (uint32_t e : todo) {
             hxk::PoaEdge& E = P.edges[e];
-            const uint32_t ncol = E.lmax + 1, nt = E.members > 1 ? cl_lanes : (uint32_t)kClassNT[class_of(e)];
+            const uint32_t ncol = E.lmax + 1, nt = lanes_of(e);
             uint64_t rb;
-            const uint32_t cmq = cm_round(ncol, E.members > 1 ? E.members * cl_lanes : nt);
-            const uint32_t Rp = ring_rows_of(nt, cmq, pk_of(cmq, !full_h[e]), rb);
+            const uint32_t cmq = cm_round(ncol, E.members > 1 ? E.members * nt : nt);
+            const uint32_t Rp = ring_rows_of(nt, cmq, rb);
             // measured on PacBio-like data, rows read back from HBM per DP row: 0.15-0.4 % with 8 ring rows, 3-5 % with 4, 16-25 % on average
             // with 2 (single edges: up to every kept row, ~60 % of the rows). Graphs fill ~70 % of the node estimate these are fractions of.
-            uint32_t est = far_rows >= 0 ? (uint32_t)far_rows : Rp >= 8 ? E.vcap / 32 + 256 : Rp >= 4 ? E.vcap / 8 + 256 : Rp >= 2 ? E.vcap / 2 + 256 : E.vcap + 1;
+            uint32_t est = o.poa_far_rows >= 0 ? (uint32_t)o.poa_far_rows : Rp >= 8 ? E.vcap / 32 + 256 : Rp >= 4 ? E.vcap / 8 + 256 : Rp >= 2 ? E.vcap / 2 + 256 : E.vcap + 1;
             E.hrows = full_h[e] || far_full[e] >= 3 ? E.vcap + 1 : (uint32_t)std::min<uint64_t>((uint64_t)E.vcap + 1, far_full[e] ? (uint64_t)std::max<uint32_t>(est, 256) << (2 * far_full[e]) : est);   // (a fourth attempt gets a row per node)
             // rows with more than 4 predecessors (a move byte per cell instead of a nibble): 1-2 % of the rows the DPs of 25- to 45-fold edges run
             // over, up to ~10 % of a finished deep graph; a 16th of the node estimate (graphs fill about a third of it) is the room, four times
@@ -728,339 +824,388 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
             E.wrows = wide_grow[e] >= 3 ? E.vcap + 1 : (uint32_t)std::min<uint64_t>((uint64_t)E.vcap + 1, ((uint64_t)E.vcap / 16 + 64) << (2 * wide_grow[e]));
         }
         // largest first (block scheduling is in grid order): cost ~ rows x columns x sequences
-        std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) {
-            const uint64_t ca = edge_cost(a), cb = edge_cost(b);
-            return ca != cb ? ca > cb : a < b;
+        std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) { const uint64_t ca = edge_cost(a), cb = edge_cost(b); return ca != cb ? ca > cb : a < b; });
+        return 0;
+    }
+
+    // ---- workspace. An edge that is shared by several workgroups owns a workspace slot for the call; every other launch class is PERSISTENT:
+    // a number of slots, each sized for the class's largest edge, each owned by one workgroup that pulls edges (costliest first) from the class's
+    // list (kernels/poa.hip). The workspace of a call is slots x largest edge, not the sum over its edges: 140 Mb on one GPU took 241 GB per
+    // edge, a 400 Mb genome three batches. When even that does not fit the budget the slot counts are halved (fewer workgroups in flight); when a
+    // class's slots alone do not fit, the edges are dealt to several batches in cost order as before.
+    Need need_of(uint32_t e) const {
+        const hxk::PoaEdge& E = P.edges[e];
+        const uint64_t rw = ((uint64_t)E.lmax + 1 + 31) & ~31ull;                 // rows padded to 32 columns (the widest lane chunk)
+        const uint64_t waves = (uint64_t)E.members * (lanes_of(e) / 64);
+        const uint64_t rwh = rw + (waves > 1 ? (waves + 3) & ~3ull : 0);       // rows of H end with one word per wave of the edge's pipeline
+        Need n;
+        n.nn = (uint64_t)E.vcap + 1; n.ec = E.ecap; n.dc = full_h[e] ? 0 : n.nn * (rw / 2); n.hc = (uint64_t)E.hrows * rwh; n.wc = full_h[e] ? 0 : (uint64_t)E.wrows * rw;
+        n.lm = E.lmax; n.st = 4 * n.nn + E.ecap; n.al = n.nn + E.lmax + 2;
+        return n;
+    }
+    // Thousands of edges: every launch class is persistent and would, on its own, ask for the whole chip (4096 waves) - six classes oversubscribe it six
+    // times and the dispatcher deals the wave slots out as it pleases. A 1024-lane workgroup (16 waves: an EMPTY CU) can only be placed where nothing
+    // else sits, so the 1024-lane class ran on the CUs it had grabbed in the first microseconds until everything else had finished: measured at 140 Mb
+    // (profiles/r04_v1_fly_*), the classes ended at 920 / 1 130 / 1 440 / 1 730 / 1 900 ms - a tail of 0.8 s with the chip emptier and emptier.
+    // Balanced launch (option poa_balance=0 switches it off): the classes of 512- and 1024-lane workgroups get workgroups for THEIR SHARE of the call's
+    // wave-slot time (rows x lanes reserved: a workgroup holds its lanes whether or not a gap uses them all) x poa_balance_pct / 100, and a head start
+    // (poa_wide_delay_us) so that they are resident before the small workgroups fragment the CUs; the small classes keep asking for the whole
+    // chip and fill what is left - and what a large class that ends early leaves. Order: the 1024-lane class, then the shared edges (their waves are the
+    // OLDEST on their SIMDs and win the issue arbitration: launched behind the 512-lane class as well, their chain - the longest of the call - took
+    // 3.6 times as long), then the rest by size. (Measured on the way: 91 workgroups of 1024 lanes launched BEHIND the shared edges end at 2 230 ms,
+    // 87 launched first at 1 540 ms - residency is the whole point.)
+    int build_classes(const std::vector<uint32_t>& batch, std::vector<Cls>& classes) const {
+        classes.clear();
+        auto cls_of = [&](bool shared, uint32_t nt, uint32_t cm, bool dir, uint32_t dpl = 0) -> Cls& {
+            for (Cls& q : classes) if (q.shared == shared && q.nt == nt && q.cm == cm && q.dir == dir && q.dpl == dpl) return q;
+            classes.push_back(Cls{shared, nt, cm, dir, dpl, {}});
+            return classes.back();
+        };
+        uint32_t n_wide = 0;
+        for (uint32_t e : batch) {
+            const uint32_t ncol = P.edges[e].lmax + 1;
+            if (P.edges[e].members > 1) {
+                const uint32_t ml = mlanes[e];
+                const uint32_t cmr = cm_round(ncol, P.edges[e].members * ml);
+                if (cmr > (uint32_t)hxk::poa_kernel_max_cm((int)ml)) return fail("hx_poa_batch: gap too long for the configured cluster size (raise option poa_cluster_max)");
+                // the costliest shared edges run with WIDE members: workgroups of 1024 lanes of which the first cl_lanes take part in the DP (one
+                // wave per SIMD, as before) and all sixteen waves in the graph phases of member 0 (graph update, CSR build, orders: latency-bound
+                // loops over the nodes that want lanes). Such a workgroup has a CU to itself, so only a few edges get them.
+                if (n_wide < wide_k && ml < 1024 && cmr <= 8) { n_wide++; cls_of(true, 1024, cmr, true, ml).edges.push_back(e); continue; }
+                cls_of(true, ml, cmr, true).edges.push_back(e);   // batch is cost-sorted, so every class list is too
+                continue;
+            }
+            const uint32_t nt = (uint32_t)kClassNT[class_of(e)];
+            uint32_t cmq = cm_round(ncol, nt);
+            if (o.poa_force_cm > 0) cmq = std::max<uint32_t>(cmq, std::min<uint32_t>((uint32_t)o.poa_force_cm, (uint32_t)hxk::poa_kernel_max_cm((int)nt)));   // (testing: a wider kernel instance than the gap needs)
+            cls_of(false, nt, cmq, !full_h[e]).edges.push_back(e);
+        }
+        // order of the launches: shared edges first (they set the duration), then by lanes; score-matrix launches after their direction-byte twins
+        const bool bal = balanced;
+        std::stable_sort(classes.begin(), classes.end(), [bal](const Cls& a, const Cls& b) {
+            if (a.dir != b.dir) return a.dir;
+            // (balanced launch: the 1024-lane workgroups - a whole CU each - go out before anything else sits anywhere; they share no SIMD with
+            // the shared edges' members, which stay the oldest waves wherever they land)
+            if (bal && (a.nt >= 1024 && !a.shared) != (b.nt >= 1024 && !b.shared)) return a.nt >= 1024 && !a.shared;
+            if (a.shared != b.shared) return a.shared;
+            if (a.nt != b.nt) return a.nt > b.nt;
+            return a.cm > b.cm;
         });
-        // ---- workspace. An edge that is shared by several workgroups owns a workspace slot for the call; every other launch class is PERSISTENT:
-        // a number of slots, each sized for the class's largest edge, each owned by one workgroup that pulls edges (costliest first) from the class's
-        // list (kernels/poa.hip). The workspace of a call is slots x largest edge, not the sum over its edges: 140 Mb on one GPU took 241 GB per
-        // edge, a 400 Mb genome three batches. When even that does not fit the budget the slot counts are halved (fewer workgroups in flight); when a
-        // class's slots alone do not fit, the edges are dealt to several batches in cost order as before.
-        struct Need { uint64_t nn, ec, hc, dc, wc, lm, st, al; };
-        auto need_of = [&](uint32_t e) -> Need {
-            const hxk::PoaEdge& E = P.edges[e];
-            const uint64_t rw = ((uint64_t)E.lmax + 1 + 31) & ~31ull;                 // rows padded to 32 columns (the widest lane chunk)
-            const uint64_t waves = (uint64_t)E.members * ((E.members > 1 ? cl_lanes : (uint32_t)kClassNT[class_of(e)]) / 64);
-            const uint64_t rwh = rw + (waves > 1 ? (waves + 3) & ~3ull : 0);       // rows of H end with one word per wave of the edge's pipeline
-            Need n;
-            n.nn = (uint64_t)E.vcap + 1; n.ec = E.ecap; n.dc = full_h[e] ? 0 : n.nn * (rw / 2); n.hc = (uint64_t)E.hrows * rwh; n.wc = full_h[e] ? 0 : (uint64_t)E.wrows * rw;
-            n.lm = E.lmax; n.st = 4 * n.nn + E.ecap; n.al = n.nn + E.lmax + 2;
-            return n;
-        };
-        auto need_max = [](Need& a, const Need& b) { a.nn = std::max(a.nn, b.nn); a.ec = std::max(a.ec, b.ec); a.hc = std::max(a.hc, b.hc); a.dc = std::max(a.dc, b.dc); a.wc = std::max(a.wc, b.wc);
-                                                       a.lm = std::max(a.lm, b.lm); a.st = std::max(a.st, b.st); a.al = std::max(a.al, b.al); };
-        auto need_bytes = [](const Need& n) -> uint64_t { return n.nn * 90 + n.ec * 28 + n.hc * 4 + n.dc + n.wc + n.lm + n.st * 4 + n.al * 8; };
-        // launch classes: (shared?, lanes per workgroup, columns per lane, traceback flavour) - one kernel instance each, so that every
-        // launch runs with the registers ITS row loop needs (kernels/poa.hip)
-        struct Cls { bool shared; uint32_t nt, cm; bool dir; uint32_t dpl = 0 /* lanes in the DP when the workgroups are wider (wide cluster members), else 0 */; std::vector<uint32_t> edges; size_t blocks = 0, order_at = 0, slot_at = 0, n_slots = 0; Need need{}; bool persistent = false; bool pk = false /* packed 16-bit rows */;
-                     double share = 0 /* of the batch's wave-slot time: DP rows x lanes reserved */; };
-        // Thousands of edges: every launch class is persistent and would, on its own, ask for the whole chip (4096 waves) - six classes oversubscribe it six
-        // times and the dispatcher deals the wave slots out as it pleases. A 1024-lane workgroup (16 waves: an EMPTY CU) can only be placed where nothing
-        // else sits, so the 1024-lane class ran on the CUs it had grabbed in the first microseconds until everything else had finished: measured at 140 Mb
-        // (profiles/r04_v1_fly_*), the classes ended at 920 / 1 130 / 1 440 / 1 730 / 1 900 ms - a tail of 0.8 s with the chip emptier and emptier.
-        // Balanced launch (HX_POA_BALANCE=0 switches it off): the classes of 512- and 1024-lane workgroups get workgroups for THEIR SHARE of the call's
-        // wave-slot time (rows x lanes reserved: a workgroup holds its lanes whether or not a gap uses them all) x HX_POA_BALANCE_PCT / 100, and a head start
-        // (HX_POA_WIDE_DELAY_US) so that they are resident before the small workgroups fragment the CUs; the small classes keep asking for the whole
-        // chip and fill what is left - and what a large class that ends early leaves. Order: the 1024-lane class, then the shared edges (their waves are the
-        // OLDEST on their SIMDs and win the issue arbitration: launched behind the 512-lane class as well, their chain - the longest of the call - took
-        // 3.6 times as long), then the rest by size. (Measured on the way: 91 workgroups of 1024 lanes launched BEHIND the shared edges end at 2 230 ms,
-        // 87 launched first at 1 540 ms - residency is the whole point.)
-        const bool balanced = many_edges && !(getenv("HX_POA_BALANCE") && atoi(getenv("HX_POA_BALANCE")) == 0);
-        const double balance_f = (getenv("HX_POA_BALANCE_PCT") ? std::max(10, atoi(getenv("HX_POA_BALANCE_PCT"))) : 125) / 100.0;
-        const uint32_t balance_nt = getenv("HX_POA_BALANCE_LANES") ? (uint32_t)atoi(getenv("HX_POA_BALANCE_LANES")) : 512;   // classes of at least this many lanes per workgroup get a share
-        auto build_classes = [&](const std::vector<uint32_t>& batch, std::vector<Cls>& classes) -> int {
-            classes.clear();
-            auto cls_of = [&](bool shared, uint32_t nt, uint32_t cm, bool dir, uint32_t dpl = 0) -> Cls& {
-                for (Cls& q : classes) if (q.shared == shared && q.nt == nt && q.cm == cm && q.dir == dir && q.dpl == dpl) return q;
-                classes.push_back(Cls{shared, nt, cm, dir, dpl, {}});
-                return classes.back();
-            };
-            uint32_t n_wide = 0;
-            for (uint32_t e : batch) {
-                const uint32_t ncol = P.edges[e].lmax + 1;
-                // widest row: the shared mode (members x lanes x columns per lane), or one 1024-lane workgroup when the members were made small
-                const uint64_t col_cap = std::max<uint64_t>((uint64_t)cl_max * cl_lanes * hxk::poa_kernel_max_cm((int)cl_lanes), 1024ull * hxk::poa_kernel_max_cm(1024));
-                if (ncol > col_cap || ncol >= (1u << 20))
-                    return fail("hx_poa_batch: a gap sub-sequence of " + std::to_string(ncol - 1) + " bases is longer than the POA kernel holds (" +
-                                std::to_string(col_cap - 1) + " with HX_POA_CLUSTER_MAX x HX_POA_MEMBER_LANES x 32 columns per lane)");
-                if (P.edges[e].members > 1) {
-                    const uint32_t cmr = cm_round(ncol, P.edges[e].members * cl_lanes);
-                    if (cmr > (uint32_t)hxk::poa_kernel_max_cm((int)cl_lanes)) return fail("hx_poa_batch: gap too long for the configured cluster size (raise HX_POA_CLUSTER_MAX)");
-                    // the costliest shared edges run with WIDE members: workgroups of 1024 lanes of which the first cl_lanes take part in the DP (one
-                    // wave per SIMD, as before) and all sixteen waves in the graph phases of member 0 (graph update, CSR build, orders: latency-bound
-                    // loops over the nodes that want lanes). Such a workgroup has a CU to itself, so only a few edges get them.
-                    if (n_wide < wide_k && cl_lanes < 1024 && cmr <= 8) { n_wide++; cls_of(true, 1024, cmr, true, cl_lanes).edges.push_back(e); continue; }
-                    cls_of(true, cl_lanes, cmr, true).edges.push_back(e);   // batch is cost-sorted, so every class list is too
-                    continue;
-                }
-                if (ncol > 32768) return fail("hx_poa_batch: a gap longer than 32767 bases needs the shared (cluster) mode: direction-byte traceback, automatic block size");
-                const uint32_t nt = (uint32_t)kClassNT[class_of(e)];
-                uint32_t cmq = cm_round(ncol, nt);
-                if (const char* fc = getenv("HX_POA_FORCE_CM")) cmq = std::max<uint32_t>(cmq, std::min<uint32_t>((uint32_t)atoi(fc), (uint32_t)hxk::poa_kernel_max_cm((int)nt)));   // (testing: a wider kernel instance than the gap needs)
-                cls_of(false, nt, cmq, !full_h[e]).edges.push_back(e);
+        double total_cost = 0;
+        for (Cls& q : classes) {
+            q.need = Need{};
+            for (uint32_t e : q.edges) {
+                need_max(q.need, need_of(e));
+                q.share += (double)P.edges[e].vcap * std::max<uint32_t>(1, P.nseq[e]) * (q.shared ? (double)P.edges[e].members * mlanes[e] : (double)q.nt);   // DP rows x lanes reserved
             }
-            // order of the launches: shared edges first (they set the duration), then by lanes; score-matrix launches after their direction-byte twins
-            std::stable_sort(classes.begin(), classes.end(), [balanced](const Cls& a, const Cls& b) {
-                if (a.dir != b.dir) return a.dir;
-                // (balanced launch: the 1024-lane workgroups - a whole CU each - go out before anything else sits anywhere; they share no SIMD with
-                // the shared edges' members, which stay the oldest waves wherever they land)
-                if (balanced && (a.nt >= 1024 && !a.shared) != (b.nt >= 1024 && !b.shared)) return a.nt >= 1024 && !a.shared;
-                if (a.shared != b.shared) return a.shared;
-                if (a.nt != b.nt) return a.nt > b.nt;
-                return a.cm > b.cm;
-            });
-            double total_cost = 0;
-            for (Cls& q : classes) {
-                q.need = Need{};
-                q.pk = pk_of(q.cm, q.dir);
-                for (uint32_t e : q.edges) {
-                    need_max(q.need, need_of(e));
-                    q.share += (double)P.edges[e].vcap * std::max<uint32_t>(1, P.nseq[e]) * (q.shared ? (double)P.edges[e].members * cl_lanes : (double)q.nt);   // DP rows x lanes reserved
-                }
-                total_cost += q.share;
-            }
-            for (Cls& q : classes) q.share = total_cost > 0 ? q.share / total_cost : 0;
-            return 0;
-        };
-        // Slots of a persistent class: as many workgroups as the chip holds of that size at 16 waves per CU (all classes share the CUs, but when the
-        // others have finished, what is left of this one still finds the whole chip: measured at 140 Mb, 1.95 s against 2.12 s with slots in
-        // proportion to the classes' shares), at most one per edge. `shrink` scales the number down (memory budget).
-        const uint32_t slot_scale = getenv("HX_POA_SLOTS_PCT") ? (uint32_t)std::max(1, atoi(getenv("HX_POA_SLOTS_PCT"))) : 100;   // (testing: fewer slots = more edges per workgroup)
-        const size_t slot_abs = getenv("HX_POA_SLOTS") ? (size_t)std::max(1, atoi(getenv("HX_POA_SLOTS"))) : 0;
-        auto slots_wanted = [&](const Cls& q, uint32_t shrink) -> size_t {
-            if (q.shared) return q.edges.size();
-            size_t cap = std::max<size_t>(1, ((size_t)4096 / (q.nt / 64)) * slot_scale / 100 * shrink / 1000);   // (`shrink`: per mille of the full count)
-            if (balanced && q.dir && q.nt >= balance_nt) cap = std::max<size_t>(1, std::min<size_t>(cap, (size_t)((double)cap * q.share * balance_f + 0.999)));   // the class's share of the chip
-            if (slot_abs) cap = slot_abs;                                        // (testing: HX_POA_SLOTS workgroups per class, many edges each)
-            return std::min(q.edges.size(), cap);
-        };
-        // A class runs persistent when it has more edges than slots: its list stays in DP-cost order (costliest first, taken by whoever is free) and
-        // every slot is sized for the class's largest edge. (Tried: the slots' first edges = the edges with the largest workspace need, slot b sized
-        // for its own first edge and the largest of the rest - 148 GB instead of 257 GB at 140 Mb, but 2.32-2.42 s against 2.03-2.09 s in the same
-        // call: need and cost do not agree well enough - a gap aligned by 60 reads costs 20 times one aligned by 3 at the same need - and the
-        // costliest edges then start late. Memory is saved by halving the slot counts instead: HX_POA_WORKSPACE_GB.)
-        auto arrange = [&](Cls& q, uint32_t shrink) {
-            q.n_slots = slots_wanted(q, shrink);
+            total_cost += q.share;
+        }
+        for (Cls& q : classes) q.share = total_cost > 0 ? q.share / total_cost : 0;
+        return 0;
+    }
+    // Slots of a persistent class: as many workgroups as the chip holds of that size at 16 waves per CU (all classes share the CUs, but when the
+    // others have finished, what is left of this one still finds the whole chip: measured at 140 Mb, 1.95 s against 2.12 s with slots in
+    // proportion to the classes' shares), at most one per edge. `shrink` scales the number down (memory budget).
+    size_t slots_wanted(const Cls& q, uint32_t shrink, size_t cu_reserved) const {
+        if (q.shared) return q.edges.size();
+        size_t cap = std::max<size_t>(1, ((size_t)4096 / (q.nt / 64)) * (size_t)std::max(1, o.poa_slots_pct) / 100 * shrink / 1000);   // (`shrink`: per mille of the full count)
+        if (balanced && q.dir && q.nt >= balance_nt) {
+            cap = std::max<size_t>(1, std::min<size_t>(cap, (size_t)((double)cap * q.share * balance_f + 0.999)));   // the class's share of the chip
+            // the members of shared edges must be resident TOGETHER (a member that waits for a CU stalls its edge: HXE_POA_STALLED and an unshared
+            // redo): a wide class that holds most of the call's cost would otherwise take every CU before they are placed
+            if (cu_reserved && q.nt >= 1024) cap = std::max<size_t>(1, std::min<size_t>(cap, 256 > cu_reserved ? 256 - cu_reserved : 1));
+            cap = std::max<size_t>(cap, std::min<size_t>(4, q.edges.size()));   // (a floor: the share is a crude model and must not starve a class down to one workgroup)
+        }
+        if (o.poa_slots > 0) cap = (size_t)o.poa_slots;                        // (testing: workgroups per class, many edges each)
+        return std::min(q.edges.size(), cap);
+    }
+    // A class runs persistent when it has more edges than slots: its list stays in DP-cost order (costliest first, taken by whoever is free) and
+    // every slot is sized for the class's largest edge. (Tried: the slots' first edges = the edges with the largest workspace need, slot b sized
+    // for its own first edge and the largest of the rest - 148 GB instead of 257 GB at 140 Mb, but 2.32-2.42 s against 2.03-2.09 s in the same
+    // call: need and cost do not agree well enough - a gap aligned by 60 reads costs 20 times one aligned by 3 at the same need - and the
+    // costliest edges then start late. Memory is saved by halving the slot counts instead: option poa_workspace_gb.)
+    void arrange(std::vector<Cls>& classes, uint32_t shrink) const {
+        size_t cu_reserved = 0;   // CUs the shared edges' member workgroups need (a 256-lane member: a quarter of a CU's wave slots, a wide one: a CU)
+        for (const Cls& q : classes) if (q.shared) for (uint32_t e : q.edges) cu_reserved += ((size_t)P.edges[e].members * q.nt + 1023) / 1024;
+        cu_reserved = std::min<size_t>(cu_reserved, 192);
+        for (Cls& q : classes) {
+            q.n_slots = slots_wanted(q, shrink, cu_reserved);
             q.persistent = !q.shared && q.n_slots < q.edges.size() && hxk::poa_persistent_ok(q.dir);
             if (!q.persistent) q.n_slots = q.edges.size();
-        };
-        auto slot_needs = [&](const Cls& q) -> std::vector<Need> {   // per slot: the edge's own need, or (persistent) the largest of the class
-            std::vector<Need> v(q.n_slots);
-            for (size_t b = 0; b < q.n_slots; b++) v[b] = q.persistent ? q.need : need_of(q.edges[b]);
-            return v;
-        };
-        auto total_bytes = [&](std::vector<Cls>& classes, uint32_t shrink) -> uint64_t {
-            uint64_t t = 0;
-            for (Cls& q : classes) {
-                arrange(q, shrink);
-                for (const Need& n : slot_needs(q)) t += need_bytes(n);
-                for (uint32_t e : q.edges) t += P.edges[e].vcap + (q.shared ? (uint64_t)P.edges[e].members * ((uint64_t)P.edges[e].vcap + 1) * 8 : 0);   // consensus output, cluster mailboxes
-            }
-            return t;
-        };
-        std::vector<std::vector<uint32_t>> batches(1, todo);
-        std::vector<uint32_t> batch_shrink(1, 1000);
-        {
-            const size_t forced = getenv("HX_POA_BATCHES") ? (size_t)atol(getenv("HX_POA_BATCHES")) : 0;   // (testing)
-            for (size_t nb = std::max<size_t>(1, forced);; nb++) {
-                nb = std::min(nb, std::max<size_t>(1, todo.size()));
-                batches.assign(nb, {}); batch_shrink.assign(nb, 1000);
-                for (size_t i = 0; i < todo.size(); i++) batches[i % nb].push_back(todo[i]);   // dealt in cost order: every batch has its share of the large edges
-                bool fits = true;
-                for (size_t bi = 0; bi < nb && fits; bi++) {
-                    std::vector<Cls> cl;
-                    if (build_classes(batches[bi], cl)) return -1;
-                    uint32_t sh = 1000;   // per mille of the full slot counts: the largest that fits (down to 1 %: below that, more batches)
-                    if (total_bytes(cl, sh) > budget) {
-                        uint32_t lo = 10, hi = 1000;
-                        while (hi - lo > 10) { const uint32_t mid = (lo + hi) / 2; if (total_bytes(cl, mid) <= budget) lo = mid; else hi = mid; }
-                        sh = lo;
-                    }
-                    batch_shrink[bi] = sh;
-                    fits = total_bytes(cl, sh) <= budget;
+        }
+    }
+    Need slot_need(const Cls& q, size_t b) const { return q.persistent ? q.need : need_of(q.edges[b]); }   // per slot: the edge's own need, or (persistent) the largest of the class
+    uint64_t total_bytes(std::vector<Cls>& classes, uint32_t shrink) const {
+        uint64_t t = 0;
+        arrange(classes, shrink);
+        for (Cls& q : classes) {
+            for (size_t b = 0; b < q.n_slots; b++) t += need_bytes(slot_need(q, b));
+            for (uint32_t e : q.edges) t += P.edges[e].vcap + (q.shared ? (uint64_t)P.edges[e].members * ((uint64_t)P.edges[e].vcap + 1) * 8 : 0);   // consensus output, cluster mailboxes
+        }
+        return t;
+    }
+    // ---- plan, part 4: batches and slot counts against the budget
+    int plan_batches(const std::vector<uint32_t>& todo, std::vector<std::vector<uint32_t>>& batches, std::vector<uint32_t>& batch_shrink) {
+        const size_t forced = o.poa_batches > 0 ? (size_t)o.poa_batches : 0;   // (testing)
+        for (size_t nb = std::max<size_t>(1, forced);; nb++) {
+            nb = std::min(nb, std::max<size_t>(1, todo.size()));
+            batches.assign(nb, {}); batch_shrink.assign(nb, 1000);
+            for (size_t i = 0; i < todo.size(); i++) batches[i % nb].push_back(todo[i]);   // dealt in cost order: every batch has its share of the large edges
+            bool fits = true;
+            for (size_t bi = 0; bi < nb && fits; bi++) {
+                std::vector<Cls> cl;
+                if (build_classes(batches[bi], cl)) return -1;
+                uint32_t sh = 1000;   // per mille of the full slot counts: the largest that fits (down to 1 %: below that, more batches)
+                if (total_bytes(cl, sh) > budget) {
+                    uint32_t lo = 10, hi = 1000;
+                    while (hi - lo > 10) { const uint32_t mid = (lo + hi) / 2; if (total_bytes(cl, mid) <= budget) lo = mid; else hi = mid; }
+                    sh = lo;
                 }
-                if (fits) break;
-                if (nb >= todo.size()) return fail("hx_poa_batch: a single edge needs more POA workspace than the device has free");
+                batch_shrink[bi] = sh;
+                fits = total_bytes(cl, sh) <= budget;
+            }
+            if (fits) break;
+            if (nb >= todo.size()) return fail("hx_poa_batch: a single edge needs more POA workspace than the device has free");
+        }
+        return 0;
+    }
+
+    // ---- launch of one batch; what the collection needs afterwards
+    struct Launched { std::vector<uint32_t> edges; uint64_t cns_bytes = 0, bytes = 0; std::vector<Cls> classes; };
+    int launch_batch(const std::vector<uint32_t>& batch, uint32_t shrink, Launched& lb) {
+        hipStream_t s = c->stream;
+        PoaPoolBufs& B = c->poa_pools;
+        lb.edges = batch;
+        std::vector<Cls>& classes = lb.classes;
+        if (build_classes(batch, classes)) return -1;
+        // ---- slots and their offsets into the pools
+        std::vector<hxk::PoaSlot> h_slots;
+        uint64_t no = 0, eo = 0, ho = 0, dro = 0, wo = 0, so = 0, co = 0, sto = 0, ao = 0, clo = 0;
+        auto add_slot = [&](const Need& n) {
+            h_slots.push_back(hxk::PoaSlot{no, eo, ho, dro, wo, so, sto, ao});
+            no += n.nn; eo += n.ec; ho += n.hc; dro += n.dc; wo += n.wc; so += n.lm; sto += n.st; ao += n.al;
+        };
+        arrange(classes, shrink);
+        for (Cls& q : classes) {
+            q.slot_at = h_slots.size();
+            for (size_t k = 0; k < q.n_slots; k++) {
+                if (!q.persistent) P.edges[q.edges[k]].slot = (uint32_t)h_slots.size();   // one workgroup (or cluster) per edge: the edge's own slot
+                add_slot(slot_need(q, k));
+            }
+            for (uint32_t e : q.edges) {
+                P.edges[e].cns_off = co; co += P.edges[e].vcap;
+                if (q.shared) { P.edges[e].cl_off = clo; clo += (uint64_t)P.edges[e].members * ((uint64_t)P.edges[e].vcap + 1); }
             }
         }
+        lb.cns_bytes = co;
+        const uint64_t bytes = no * 90 + eo * 28 + ho * 4 + dro + wo + so + sto * 4 + ao * 8 + clo * 8 + co;
+        lb.bytes = bytes;
+        // Pools grow and never shrink, each to the largest batch it has seen: after batches of different shapes (direction bytes for one,
+        // the whole score matrix for a retry) the capacities together can exceed the device although this batch alone fits the budget.
+        // Then everything is released and reserved again at this batch's sizes.
+        auto reserve_pools = [&]() -> hipError_t {
+            hipError_t e;
+#define HX_RSV(buf, n) do { if ((e = (buf).reserve(n)) != hipSuccess) return e; } while (0)
+            HX_RSV(B.H, std::max<uint64_t>(1, ho)); HX_RSV(B.dir, std::max<uint64_t>(1, dro)); HX_RSV(B.dirw, std::max<uint64_t>(1, wo)); HX_RSV(B.wslot, no);
+            HX_RSV(B.code, no); HX_RSV(B.n_aligned, no); HX_RSV(B.mark, no); HX_RSV(B.check, no); HX_RSV(B.row_code, no); HX_RSV(B.row_sink, no); HX_RSV(B.row_al, no);
+            HX_RSV(B.aligned, 3 * no); HX_RSV(B.in_head, no); HX_RSV(B.in_tail, no); HX_RSV(B.out_head, no); HX_RSV(B.out_tail, no); HX_RSV(B.rank2node, no);
+            HX_RSV(B.node2rank, no); HX_RSV(B.row_pred_off, no); HX_RSV(B.score, no); HX_RSV(B.pred, no); HX_RSV(B.pred_rank, eo); HX_RSV(B.pred_w, eo); HX_RSV(B.e_from, eo);
+            HX_RSV(B.e_to, eo); HX_RSV(B.e_next_in, eo); HX_RSV(B.e_next_out, eo); HX_RSV(B.e_w, eo); HX_RSV(B.stack, sto); HX_RSV(B.aln_node, ao); HX_RSV(B.aln_pos, ao);
+            HX_RSV(B.row_meta, no); HX_RSV(B.row_pred0, no); HX_RSV(B.row_pred1, no); HX_RSV(B.nrec, no); HX_RSV(B.seq, so); HX_RSV(c->poa_cns, co);
+            HX_RSV(B.mbox, std::max<uint64_t>(1, clo));
+            HX_RSV(B.csync, (size_t)ne * 8); HX_RSV(B.sinkbuf, (size_t)ne * (1 + 2 * 1024));
+#undef HX_RSV
+            return hipSuccess;
+        };
+        if (reserve_pools() != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(hipStreamSynchronize(s));
+            B.release_all(); c->poa_cns.release();
+            HIPCHK(reserve_pools());
+        }
+        c->poa_workspace_bytes = std::max<uint64_t>(c->poa_workspace_bytes, bytes);
+        c->poa_last_workspace_bytes = std::max<uint64_t>(c->poa_last_workspace_bytes, bytes);
+        HIPCHK(hipMemsetAsync(B.csync.p, 0, (size_t)ne * 8 * 4, s));
+        if (clo) HIPCHK(hipMemsetAsync(B.mbox.p, 0, clo * 8, s));   // tag 0 = nothing published
+        HIPCHK(c->poa_edges.reserve(ne)); HIPCHK(c->poa_len.reserve(ne)); HIPCHK(c->poa_status.reserve(ne));
+        std::vector<uint32_t> order_all;   // shared launches: one entry per workgroup (edge | member << 24); persistent launches: the class's edges, costliest first
+        for (Cls& q : classes) {
+            q.order_at = order_all.size();
+            if (q.shared && !o.poa_no_xcd_map) {
+                // Workgroups are handed to the 8 XCDs round-robin by index: put the members of one edge 8 indices apart so that they share an
+                // XCD (one L2 for the carries, the handshakes and the direction bytes member 0 walks back over). Holes are no-op workgroups.
+                for (size_t g0 = 0; g0 < q.edges.size(); g0 += 8) {
+                    const size_t g1 = std::min(q.edges.size(), g0 + 8);
+                    uint32_t gmax = 0;
+                    for (size_t j = g0; j < g1; j++) gmax = std::max(gmax, P.edges[q.edges[j]].members);
+                    for (uint32_t m = 0; m < gmax; m++)
+                        for (size_t j = g0; j < g0 + 8; j++)
+                            order_all.push_back(j < g1 && m < P.edges[q.edges[j]].members ? (q.edges[j] | (m << 24)) : 0x00ffffffu);
+                }
+            } else if (q.shared)
+                for (uint32_t e : q.edges) for (uint32_t m = 0; m < P.edges[e].members; m++) order_all.push_back(e | (m << 24));
+            else
+                for (uint32_t e : q.edges) order_all.push_back(e);
+            q.blocks = q.shared ? order_all.size() - q.order_at : q.n_slots;   // (not shared: one workgroup per slot - per edge unless persistent)
+        }
+        if (ne >= (1u << 24)) return fail("hx_poa_batch: more than 2^24 edges in one call");
+        HIPCHK(hipMemcpyAsync(c->poa_edges.p, P.edges.data(), (size_t)ne * sizeof(hxk::PoaEdge), hipMemcpyHostToDevice, s));
+        HIPCHK(c->poa_order.reserve(order_all.size()));
+        HIPCHK(hipMemcpyAsync(c->poa_order.p, order_all.data(), order_all.size() * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c->poa_slots.reserve(h_slots.size()));
+        HIPCHK(hipMemcpyAsync(c->poa_slots.p, h_slots.data(), h_slots.size() * sizeof(hxk::PoaSlot), hipMemcpyHostToDevice, s));
+        HIPCHK(c->poa_counters.reserve(classes.size()));
+        HIPCHK(hipMemsetAsync(c->poa_counters.p, 0, classes.size() * 4, s));
+        hxk::PoaPools pools{B.code.p, B.n_aligned.p, B.aligned.p, B.in_head.p, B.in_tail.p, B.out_head.p, B.out_tail.p, B.rank2node.p, B.node2rank.p,
+                            B.mark.p, B.check.p, B.stack.p, B.score.p, B.pred.p, B.row_code.p, B.row_sink.p, B.row_pred_off.p, B.pred_rank.p, B.row_meta.p, B.row_pred0.p, B.row_pred1.p, B.nrec.p,
+                            B.e_from.p, B.e_to.p, B.e_next_in.p, B.e_next_out.p, B.e_w.p, B.aln_node.p, B.aln_pos.p, B.H.p, B.dir.p, B.dirw.p, B.wslot.p, B.seq.p,
+                            B.mbox.p, B.csync.p, B.sinkbuf.p, B.row_al.p, B.pred_w.p};
+        const size_t n_streams = (size_t)std::min(8, std::max(1, o.poa_streams));   // (8: a stream per launch class of a 140 Mb call - with 6, the two one-wave classes waited 130 / 300 ms behind the shared edges)
+        size_t wg_total = 0;
+        for (const Cls& q : classes) wg_total += q.blocks;
+        c->tick();
+        HIPCHK(hipEventRecord(c->poa_ev[8], s));
+        size_t ci = 0;
+        for (const Cls& q : classes) {
+            const int sk = (int)(ci % n_streams);   // stream / event of the launch (launches that share a stream run one after the other)
+            // LDS of the launch: the ring its row width allows, a power of two of kept rows
+            uint64_t ring_need = 0;
+            const uint32_t dp_nt = q.dpl ? q.dpl : q.nt;   // lanes in the DP
+            const uint32_t R = ring_rows_of(dp_nt, q.cm, ring_need);
+            // few edges: ask for enough LDS per workgroup that the dispatcher cannot stack them on a handful of CUs while others idle
+            // (a lone wave runs at twice the speed of two waves sharing a SIMD); many edges: request only what the ring needs
+            uint64_t lds_bytes = ring_need;
+            {
+                const uint64_t per_cu = (wg_total + 255) / 256;
+                if (per_cu < 8) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(kPoaLdsMax, (158 * 1024) / per_cu - 18 * 1024));
+                // hundreds of edges: the longest ones set the duration, and their waves run faster with two neighbours on a SIMD than with
+                // three - 10 KB of LDS per wave keeps a CU at 12 waves (thousands of edges: 16, the ring alone is 8.3 KB per wave)
+                if (!many_edges) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(kPoaLdsMax, 10 * 1024 * (uint64_t)(dp_nt / 64)));
+                if (o.poa_ring_zero) lds_bytes = ring_need;   // (one row's worth: the kernel then finds room for no kept row either)
+            }
+            const int dcls = q.shared ? 0 : q.nt >= 1024 ? 1 : q.nt >= 512 ? 2 : q.nt >= 256 ? 3 : q.nt >= 128 ? 4 : 5;
+            for (uint32_t e : q.edges) c->dbg_cls[e] = (uint8_t)(dcls + (q.dir ? 0 : 5));
+            c->dbg_ring[dcls + (q.dir ? 0 : 5)] = R;
+            HIPCHK(hipStreamWaitEvent(c->poa_streams[sk], c->poa_ev[8], 0));
+            hxk::PoaLaunch L{};
+            L.edges = c->poa_edges.p; L.order = c->poa_order.p + q.order_at; L.n_items = q.persistent ? (uint32_t)q.edges.size() : (uint32_t)q.blocks;
+            L.slots = c->poa_slots.p + (q.persistent ? q.slot_at : 0); L.counter = q.persistent ? c->poa_counters.p + ci : nullptr; L.n_blocks = (uint32_t)q.blocks;
+            L.seqs = c->poa_seqs.p; L.packed = in.d_packed; L.read_off = in.d_roff; L.read_len = in.d_rlen; L.pools = pools;
+            L.match = pp->match; L.mismatch = pp->mismatch; L.gap = pp->gap; L.cns = c->poa_cns.p; L.cns_len = c->poa_len.p; L.status = c->poa_status.p;
+            L.cells = c->poa_cells_d.p; L.phase = c->poa_phase_d.p; L.block_threads = (int)q.nt; L.cm = (int)q.cm; L.poll_limit = (uint32_t)o.poa_poll_limit; L.ring_bytes = (uint32_t)lds_bytes;
+            L.use_dir = q.dir; L.max_indeg = (uint32_t)std::min(16, std::max(1, o.poa_max_indeg)); L.dp_lanes = q.dpl;
+            L.prune_pct = !q.shared && hxk::poa_prune_ok(q.dir, (int)q.cm) && q.nt >= (uint32_t)o.poa_prune_lanes ? prune_pct : 0u;   // (a one-wave workgroup has nothing to skip: its rows are whole rows)
+            hxk::poa_run(L, c->poa_streams[sk]);
+            HIPCHK(hipEventRecord(c->poa_ev[sk], c->poa_streams[sk]));
+            HIPCHK(hipStreamWaitEvent(s, c->poa_ev[sk], 0));
+            if (q.dpl || (balanced && q.nt >= balance_nt && q.nt >= 512 && q.persistent)) {
+                // a 1024-lane workgroup needs an EMPTY CU: give the dispatcher a head start before the other launches fill the chip with small
+                // workgroups (once they have, a CU only empties when its longest resident workgroup ends)
+                HIPCHK(hipEventSynchronize(c->poa_ev[8]));   // (what precedes the launches on `s` is done: the wide launch is starting)
+                const auto tw = std::chrono::steady_clock::now();
+                while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw).count() < o.poa_wide_delay_us) { }
+            }
+            ci++;
+        }
+        c->tock(3);
+        HIPCHK(hipGetLastError());
+        if (o.debug) {
+            HIPCHK(hipStreamSynchronize(s));
+            fprintf(stderr, "[hx] POA batch: %zu edges, %.2f GB workspace, workgroups", batch.size(), bytes / 1e9);
+            for (const Cls& q : classes) fprintf(stderr, " %s%s%s%s%ux%u:%zu(%zu edges, largest %.1f MB)", q.shared ? "shared/" : "", q.persistent ? "persistent/" : "", q.dir ? "" : "matrix/",
+                                                 !q.shared && hxk::poa_prune_ok(q.dir, (int)q.cm) && q.nt >= (uint32_t)o.poa_prune_lanes && prune_pct ? "pruned/" : "", q.nt, q.cm, q.blocks, q.edges.size(), need_bytes(q.need) / 1e6);
+            fprintf(stderr, ", %.1f ms since the call began\n", ms_since_start());
+        }
+        return 0;
+    }
+
+    // ---- collection: consensus strings of the edges that are done; the others go to `retry` (worst-case workspace next) / `retry_same` (another way)
+    int collect_batch(const Launched& lb, std::vector<uint32_t>& retry, std::vector<uint32_t>& retry_same) {
+        std::vector<uint32_t> h_len(ne), h_status(ne);
+        HIPCHK(hipMemcpy(h_len.data(), c->poa_len.p, (size_t)ne * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(h_status.data(), c->poa_status.p, (size_t)ne * 4, hipMemcpyDeviceToHost));
+        std::vector<char> h_cns(lb.cns_bytes);
+        if (lb.cns_bytes) HIPCHK(hipMemcpy(h_cns.data(), c->poa_cns.p, lb.cns_bytes, hipMemcpyDeviceToHost));
+        if (o.debug) {
+            size_t n_far = 0, n_nodir = 0, n_over = 0, n_wide = 0, n_sinks = 0, n_stall = 0;
+            for (uint32_t e : lb.edges) { n_far += !!(h_status[e] & HXE_POA_FARROWS); n_nodir += !!(h_status[e] & HXE_POA_NODIR); n_over += !!(h_status[e] & HXE_POA_OVERFLOW); n_wide += !!(h_status[e] & HXE_POA_WIDEROWS); n_sinks += !!(h_status[e] & HXE_POA_SINKS); n_stall += !!(h_status[e] & HXE_POA_STALLED); }
+            if (n_far + n_nodir + n_over + n_wide + n_sinks + n_stall) fprintf(stderr, "[hx] POA batch: to be redone: %zu (rows read back from HBM outgrew H), %zu (in-degree above the direction bytes' limit), %zu (graph outgrew its workspace), %zu (rows with more than 4 predecessors outgrew the wide-row pool), %zu (more sink rows than the launch keeps), %zu (members of a shared edge not resident together%s: unshared next)\n",
+                                                                       n_far, n_nodir, n_over, n_wide, n_sinks, n_stall, balanced ? ", in a balanced launch" : "");
+        }
+        for (uint32_t e : lb.edges) {
+            if (h_status[e] & HXE_POA_FARROWS) { if (P.edges[e].hrows >= P.edges[e].vcap + 1) return fail("hx_poa_batch: internal error (far-row retry)"); far_full[e]++; retry_same.push_back(e); continue; }
+            if (h_status[e] & HXE_POA_STALLED) {
+                if (P.edges[e].members < 2) return fail("hx_poa_batch: internal error (a wave of an unshared edge gave up waiting)");
+                no_share[e] = 1; retry_same.push_back(e); continue;
+            }
+            if (h_status[e] & HXE_POA_WIDEROWS) { if (P.edges[e].wrows >= P.edges[e].vcap + 1) return fail("hx_poa_batch: internal error (wide-row retry)"); wide_grow[e]++; retry_same.push_back(e); continue; }
+            if (h_status[e] & HXE_POA_SINKS) { if (many_sinks[e]) return fail("hx_poa_batch: internal error (sink-list retry)"); many_sinks[e] = 1; retry_same.push_back(e); continue; }
+            if (h_status[e] & HXE_POA_NODIR) { if (force_nodir[e]) return fail("hx_poa_batch: internal error (direction-byte retry)"); force_nodir[e] = 1; retry_same.push_back(e); continue; }
+            if (h_status[e] & ~(uint32_t)HXE_POA_OVERFLOW) return fail("hx_poa_batch: internal error (kernel variant / column count mismatch)");
+            if (h_status[e] & HXE_POA_OVERFLOW) {
+                if (P.edges[e].vcap >= P.sumL[e]) return fail("hx_poa_batch: POA workspace overflow at worst-case size (internal error)");
+                grow[e]++;
+                retry.push_back(e);
+            } else cns[e].assign(h_cns.data() + P.edges[e].cns_off, h_len[e]);
+        }
+        return 0;
+    }
+};
+}  // namespace
+
+static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp, hx_cns_out* out) {
+    memset(out, 0, sizeof(*out));
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    PoaCall K(c, in, pp);
+    const uint32_t ne = K.ne;
+    std::vector<uint32_t> todo;
+    if (K.plan_input(todo)) return -1;
+    if (c->opt.debug) fprintf(stderr, "[hx] POA call: %u edges prepared in %.1f ms\n", (unsigned)ne, K.ms_since_start());
+    c->dbg_cls.assign(ne, 11); for (int k = 0; k < 11; k++) c->dbg_ring[k] = 0;
+    c->dbg_nseq = K.P.nseq; c->dbg_lmax.resize(ne); for (uint32_t e = 0; e < ne; e++) c->dbg_lmax[e] = K.P.edges[e].lmax;
+    HIPCHK(c->poa_seqs.reserve(K.P.seqs.size()));
+    if (!K.P.seqs.empty()) HIPCHK(hipMemcpyAsync(c->poa_seqs.p, K.P.seqs.data(), K.P.seqs.size() * sizeof(hxk::PoaSeq), hipMemcpyHostToDevice, s));
+    HIPCHK(c->poa_cells_d.reserve(1));
+    HIPCHK(hipMemsetAsync(c->poa_cells_d.p, 0, 8, s));
+    if (!c->poa_budget) {   // measured once: later calls would count the context's own (persistent) workspace as used
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        c->poa_budget = (uint64_t)(free_b * 0.9);
+        c->poa_free_at_first_call = free_b;
+    }
+    // option poa_workspace_gb: cap of the POA workspace (default: 90 % of what was free when the context first ran a consensus). The workgroups in
+    // flight per launch class are scaled down until the slots fit. Measured at 140 Mb (13 230 edges): 257 GB 2.0-2.1 s, 138 GB 2.10-2.13 s (and
+    // the first call, which allocates the pools, 4.1 instead of 5-7.6 s), 39 GB 4.6 s, 22 GB 8.5 s; a 400 Mb genome (37 608 edges): 148 GB 6.7 s.
+    K.budget = c->opt.poa_workspace_gb > 0 ? (uint64_t)(c->opt.poa_workspace_gb * 1e9) : c->poa_budget;
+    c->poa_last_workspace_bytes = 0;
+    HIPCHK(c->poa_phase_d.reserve((size_t)ne * hxk::POA_PHASE_WORDS));
+    HIPCHK(hipMemsetAsync(c->poa_phase_d.p, 0, std::max<size_t>(1, (size_t)ne * hxk::POA_PHASE_WORDS) * 8, s));
+    while (!todo.empty()) {
+        if (K.knobs(todo.size()) || K.size_edges(todo)) return -1;
+        std::vector<std::vector<uint32_t>> batches;
+        std::vector<uint32_t> batch_shrink;
+        if (K.plan_batches(todo, batches, batch_shrink)) return -1;
         std::vector<uint32_t> retry, retry_same;   // retry with the worst-case workspace / with the score-matrix traceback
         for (size_t bi = 0; bi < batches.size(); bi++) {
-            const std::vector<uint32_t>& batch = batches[bi];
-            if (batch.empty()) continue;
-            std::vector<Cls> classes;
-            if (build_classes(batch, classes)) return -1;
-            // ---- slots and their offsets into the pools
-            std::vector<hxk::PoaSlot> h_slots;
-            uint64_t no = 0, eo = 0, ho = 0, dro = 0, wo = 0, so = 0, co = 0, sto = 0, ao = 0, clo = 0;
-            auto add_slot = [&](const Need& n) {
-                h_slots.push_back(hxk::PoaSlot{no, eo, ho, dro, wo, so, sto, ao});
-                no += n.nn; eo += n.ec; ho += n.hc; dro += n.dc; wo += n.wc; so += n.lm; sto += n.st; ao += n.al;
-            };
-            for (Cls& q : classes) {
-                arrange(q, batch_shrink[bi]);
-                q.slot_at = h_slots.size();
-                const std::vector<Need> sn = slot_needs(q);
-                for (size_t k = 0; k < q.n_slots; k++) {
-                    if (!q.persistent) P.edges[q.edges[k]].slot = (uint32_t)h_slots.size();   // one workgroup (or cluster) per edge: the edge's own slot
-                    add_slot(sn[k]);
-                }
-                for (uint32_t e : q.edges) {
-                    P.edges[e].cns_off = co; co += P.edges[e].vcap;
-                    if (q.shared) { P.edges[e].cl_off = clo; clo += (uint64_t)P.edges[e].members * ((uint64_t)P.edges[e].vcap + 1); }
-                }
-            }
-            const uint64_t bytes = no * 90 + eo * 28 + ho * 4 + dro + wo + so + sto * 4 + ao * 8 + clo * 8 + co;
-            // Pools grow and never shrink, each to the largest batch it has seen: after batches of different shapes (direction bytes for one,
-            // the whole score matrix for a retry) the capacities together can exceed the device although this batch alone fits the budget.
-            // Then everything is released and reserved again at this batch's sizes.
-            auto reserve_pools = [&]() -> hipError_t {
-                hipError_t e;
-#define HX_RSV(buf, n) do { if ((e = (buf).reserve(n)) != hipSuccess) return e; } while (0)
-                HX_RSV(B.H, std::max<uint64_t>(1, ho)); HX_RSV(B.dir, std::max<uint64_t>(1, dro)); HX_RSV(B.dirw, std::max<uint64_t>(1, wo)); HX_RSV(B.wslot, no);
-                HX_RSV(B.code, no); HX_RSV(B.n_aligned, no); HX_RSV(B.mark, no); HX_RSV(B.check, no); HX_RSV(B.row_code, no); HX_RSV(B.row_sink, no); HX_RSV(B.row_al, no);
-                HX_RSV(B.aligned, 3 * no); HX_RSV(B.in_head, no); HX_RSV(B.in_tail, no); HX_RSV(B.out_head, no); HX_RSV(B.out_tail, no); HX_RSV(B.rank2node, no);
-                HX_RSV(B.node2rank, no); HX_RSV(B.row_pred_off, no); HX_RSV(B.score, no); HX_RSV(B.pred, no); HX_RSV(B.pred_rank, eo); HX_RSV(B.pred_w, eo); HX_RSV(B.e_from, eo);
-                HX_RSV(B.e_to, eo); HX_RSV(B.e_next_in, eo); HX_RSV(B.e_next_out, eo); HX_RSV(B.e_w, eo); HX_RSV(B.stack, sto); HX_RSV(B.aln_node, ao); HX_RSV(B.aln_pos, ao);
-                HX_RSV(B.row_meta, no); HX_RSV(B.row_pred0, no); HX_RSV(B.row_pred1, no); HX_RSV(B.nrec, no); HX_RSV(B.seq, so); HX_RSV(d_cns, co);
-                HX_RSV(B.mbox, std::max<uint64_t>(1, clo));
-                HX_RSV(B.csync, (size_t)ne * 8); HX_RSV(B.sinkbuf, (size_t)ne * (1 + 2 * 1024));
-#undef HX_RSV
-                return hipSuccess;
-            };
-            if (reserve_pools() != hipSuccess) {
-                (void)hipGetLastError();
-                HIPCHK(hipStreamSynchronize(s));
-                B.release_all(); d_cns.release();
-                HIPCHK(reserve_pools());
-            }
-            c->poa_workspace_bytes = std::max<uint64_t>(c->poa_workspace_bytes, bytes);
-            HIPCHK(hipMemsetAsync(B.csync.p, 0, (size_t)ne * 8 * 4, s));
-            if (clo) HIPCHK(hipMemsetAsync(B.mbox.p, 0, clo * 8, s));   // tag 0 = nothing published
-            HIPCHK(d_edges.reserve(ne)); HIPCHK(d_len.reserve(ne)); HIPCHK(d_status.reserve(ne));
-            std::vector<uint32_t> order_all;   // shared launches: one entry per workgroup (edge | member << 24); persistent launches: the class's edges, costliest first
-            for (Cls& q : classes) {
-                q.order_at = order_all.size();
-                if (q.shared && !getenv("HX_POA_NO_XCD_MAP")) {
-                    // Workgroups are handed to the 8 XCDs round-robin by index: put the members of one edge 8 indices apart so that they share an
-                    // XCD (one L2 for the carries, the handshakes and the direction bytes member 0 walks back over). Holes are no-op workgroups.
-                    for (size_t g0 = 0; g0 < q.edges.size(); g0 += 8) {
-                        const size_t g1 = std::min(q.edges.size(), g0 + 8);
-                        uint32_t gmax = 0;
-                        for (size_t j = g0; j < g1; j++) gmax = std::max(gmax, P.edges[q.edges[j]].members);
-                        for (uint32_t m = 0; m < gmax; m++)
-                            for (size_t j = g0; j < g0 + 8; j++)
-                                order_all.push_back(j < g1 && m < P.edges[q.edges[j]].members ? (q.edges[j] | (m << 24)) : 0x00ffffffu);
-                    }
-                } else if (q.shared)
-                    for (uint32_t e : q.edges) for (uint32_t m = 0; m < P.edges[e].members; m++) order_all.push_back(e | (m << 24));
-                else
-                    for (uint32_t e : q.edges) order_all.push_back(e);
-                q.blocks = q.shared ? order_all.size() - q.order_at : q.n_slots;   // (not shared: one workgroup per slot - per edge unless persistent)
-            }
-            if (ne >= (1u << 24)) return fail("hx_poa_batch: more than 2^24 edges in one call");
-            HIPCHK(hipMemcpyAsync(d_edges.p, P.edges.data(), (size_t)ne * sizeof(hxk::PoaEdge), hipMemcpyHostToDevice, s));
-            HIPCHK(d_order.reserve(order_all.size()));
-            HIPCHK(hipMemcpyAsync(d_order.p, order_all.data(), order_all.size() * 4, hipMemcpyHostToDevice, s));
-            HIPCHK(c->poa_slots.reserve(h_slots.size()));
-            HIPCHK(hipMemcpyAsync(c->poa_slots.p, h_slots.data(), h_slots.size() * sizeof(hxk::PoaSlot), hipMemcpyHostToDevice, s));
-            HIPCHK(c->poa_counters.reserve(classes.size()));
-            HIPCHK(hipMemsetAsync(c->poa_counters.p, 0, classes.size() * 4, s));
-            hxk::PoaPools pools{B.code.p, B.n_aligned.p, B.aligned.p, B.in_head.p, B.in_tail.p, B.out_head.p, B.out_tail.p, B.rank2node.p, B.node2rank.p,
-                                B.mark.p, B.check.p, B.stack.p, B.score.p, B.pred.p, B.row_code.p, B.row_sink.p, B.row_pred_off.p, B.pred_rank.p, B.row_meta.p, B.row_pred0.p, B.row_pred1.p, B.nrec.p,
-                                B.e_from.p, B.e_to.p, B.e_next_in.p, B.e_next_out.p, B.e_w.p, B.aln_node.p, B.aln_pos.p, B.H.p, B.dir.p, B.dirw.p, B.wslot.p, B.seq.p,
-                                B.mbox.p, B.csync.p, B.sinkbuf.p, B.row_al.p, B.pred_w.p};
-            const size_t n_streams = getenv("HX_POA_STREAMS") ? (size_t)std::min(8, std::max(1, atoi(getenv("HX_POA_STREAMS")))) : 8;   // (8: a stream per launch class of a 140 Mb call - with 6, the two one-wave classes waited 130 / 300 ms behind the shared edges)
-            size_t wg_total = 0;
-            for (const Cls& q : classes) wg_total += q.blocks;
-            c->tick();
-            HIPCHK(hipEventRecord(c->poa_ev[8], s));
-            size_t ci = 0;
-            for (const Cls& q : classes) {
-                const int sk = (int)(ci % n_streams);   // stream / event of the launch (launches that share a stream run one after the other)
-                // LDS of the launch: the ring its row width allows, a power of two of kept rows
-                uint64_t ring_need = 0;
-                const uint32_t dp_nt = q.dpl ? q.dpl : q.nt;   // lanes in the DP
-                const uint32_t R = ring_rows_of(dp_nt, q.cm, q.pk, ring_need);
-                // few edges: ask for enough LDS per workgroup that the dispatcher cannot stack them on a handful of CUs while others idle
-                // (a lone wave runs at twice the speed of two waves sharing a SIMD); many edges: request only what the ring needs
-                uint64_t lds_bytes = ring_need;
-                {
-                    const uint64_t per_cu = (wg_total + 255) / 256;
-                    if (per_cu < 8) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(kPoaLdsMax, (158 * 1024) / per_cu - 18 * 1024));
-                    // hundreds of edges: the longest ones set the duration, and their waves run faster with two neighbours on a SIMD than with
-                    // three - 10 KB of LDS per wave keeps a CU at 12 waves (thousands of edges: 16, the ring alone is 8.3 KB per wave)
-                    if (!many_edges) lds_bytes = std::max<uint64_t>(lds_bytes, std::min<uint64_t>(kPoaLdsMax, 10 * 1024 * (uint64_t)(dp_nt / 64)));
-                    if (getenv("HX_POA_RING_ZERO")) lds_bytes = ring_need;   // (one row's worth: the kernel then finds room for no kept row either)
-                }
-                const int dcls = q.shared ? 0 : q.nt >= 1024 ? 1 : q.nt >= 512 ? 2 : q.nt >= 256 ? 3 : q.nt >= 128 ? 4 : 5;
-                for (uint32_t e : q.edges) c->dbg_cls[e] = (uint8_t)(dcls + (q.dir ? 0 : 5));
-                c->dbg_ring[dcls + (q.dir ? 0 : 5)] = R;
-                HIPCHK(hipStreamWaitEvent(c->poa_streams[sk], c->poa_ev[8], 0));
-                hxk::poa_run(d_edges.p, d_order.p + q.order_at, q.persistent ? (uint32_t)q.edges.size() : (uint32_t)q.blocks, c->poa_slots.p + (q.persistent ? q.slot_at : 0), q.persistent ? c->poa_counters.p + ci : nullptr,
-                             (uint32_t)q.blocks, d_seqs.p, in.d_packed, in.d_roff, in.d_rlen, pools, pp->match, pp->mismatch,
-                             pp->gap, d_cns.p, d_len.p, d_status.p, d_cells.p, d_phase.p, (int)q.nt, (int)q.cm, poll_limit, (uint32_t)lds_bytes, q.dir, max_indeg, q.dpl, q.pk, c->poa_streams[sk]);
-                HIPCHK(hipEventRecord(c->poa_ev[sk], c->poa_streams[sk]));
-                HIPCHK(hipStreamWaitEvent(s, c->poa_ev[sk], 0));
-                if (q.dpl || (balanced && q.nt >= balance_nt && q.nt >= 512 && q.persistent)) {
-                    // a 1024-lane workgroup needs an EMPTY CU: give the dispatcher a head start before the other launches fill the chip with small
-                    // workgroups (once they have, a CU only empties when its longest resident workgroup ends)
-                    static const int wide_us = getenv("HX_POA_WIDE_DELAY_US") ? atoi(getenv("HX_POA_WIDE_DELAY_US")) : 60;
-                    HIPCHK(hipEventSynchronize(c->poa_ev[8]));   // (what precedes the launches on `s` is done: the wide launch is starting)
-                    const auto t0 = std::chrono::steady_clock::now();
-                    while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < wide_us) { }
-                }
-                ci++;
-            }
-            c->tock(3);
-            HIPCHK(hipGetLastError());
-            if (getenv("HX_DEBUG")) {
-                HIPCHK(hipStreamSynchronize(s));
-                fprintf(stderr, "[hx] POA batch: %zu edges, %.2f GB workspace, workgroups", batch.size(), bytes / 1e9);
-                for (const Cls& q : classes) fprintf(stderr, " %s%s%s%s%ux%u:%zu(%zu edges, largest %.1f MB)", q.shared ? "shared/" : "", q.persistent ? "persistent/" : "", q.dir ? "" : "matrix/", q.pk ? "pk16/" : "", q.nt, q.cm, q.blocks, q.edges.size(), need_bytes(q.need) / 1e6);
-                fprintf(stderr, ", %.1f ms since the call began\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count());
-            }
-            std::vector<uint32_t> h_len(ne), h_status(ne);
-            HIPCHK(hipMemcpy(h_len.data(), d_len.p, (size_t)ne * 4, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(h_status.data(), d_status.p, (size_t)ne * 4, hipMemcpyDeviceToHost));
-            std::vector<char> h_cns(co);
-            if (co) HIPCHK(hipMemcpy(h_cns.data(), d_cns.p, co, hipMemcpyDeviceToHost));
-            if (getenv("HX_DEBUG")) {
-                size_t n_far = 0, n_nodir = 0, n_over = 0, n_wide = 0, n_sinks = 0;
-                for (uint32_t e : batch) { n_far += !!(h_status[e] & HXE_POA_FARROWS); n_nodir += !!(h_status[e] & HXE_POA_NODIR); n_over += !!(h_status[e] & HXE_POA_OVERFLOW); n_wide += !!(h_status[e] & HXE_POA_WIDEROWS); n_sinks += !!(h_status[e] & HXE_POA_SINKS); }
-                if (n_far + n_nodir + n_over + n_wide + n_sinks) fprintf(stderr, "[hx] POA batch: to be redone: %zu (rows read back from HBM outgrew H), %zu (in-degree above the direction bytes' limit), %zu (graph outgrew its workspace), %zu (rows with more than 4 predecessors outgrew the wide-row pool), %zu (more sink rows than the launch keeps)\n", n_far, n_nodir, n_over, n_wide, n_sinks);
-            }
-            for (uint32_t e : batch) {
-                if (h_status[e] & HXE_POA_FARROWS) { if (P.edges[e].hrows >= P.edges[e].vcap + 1) return fail("hx_poa_batch: internal error (far-row retry)"); far_full[e]++; retry_same.push_back(e); continue; }
-                if (h_status[e] & HXE_POA_STALLED) {
-                    if (P.edges[e].members < 2) return fail("hx_poa_batch: internal error (a wave of an unshared edge gave up waiting)");
-                    no_share[e] = 1; retry_same.push_back(e); continue;
-                }
-                if (h_status[e] & HXE_POA_WIDEROWS) { if (P.edges[e].wrows >= P.edges[e].vcap + 1) return fail("hx_poa_batch: internal error (wide-row retry)"); wide_grow[e]++; retry_same.push_back(e); continue; }
-                if (h_status[e] & HXE_POA_SINKS) { if (many_sinks[e]) return fail("hx_poa_batch: internal error (sink-list retry)"); many_sinks[e] = 1; retry_same.push_back(e); continue; }
-                if (h_status[e] & HXE_POA_NODIR) { if (force_nodir[e]) return fail("hx_poa_batch: internal error (direction-byte retry)"); force_nodir[e] = 1; retry_same.push_back(e); continue; }
-                if (h_status[e] & ~(uint32_t)HXE_POA_OVERFLOW) return fail("hx_poa_batch: internal error (kernel variant / column count mismatch)");
-                if (h_status[e] & HXE_POA_OVERFLOW) {
-                    if (P.edges[e].vcap >= P.sumL[e]) return fail("hx_poa_batch: POA workspace overflow at worst-case size (internal error)");
-                    grow[e]++;
-                    retry.push_back(e);
-                } else cns[e].assign(h_cns.data() + P.edges[e].cns_off, h_len[e]);
-            }
+            if (batches[bi].empty()) continue;
+            PoaCall::Launched lb;
+            if (K.launch_batch(batches[bi], batch_shrink[bi], lb) || K.collect_batch(lb, retry, retry_same)) return -1;
         }
         todo.swap(retry);
         todo.insert(todo.end(), retry_same.begin(), retry_same.end());
     }
     unsigned long long cells = 0;
-    HIPCHK(hipMemcpy(&cells, d_cells.p, 8, hipMemcpyDeviceToHost));
-    c->poa_phase.assign((size_t)ne * 12, 0);
-    if (ne) HIPCHK(hipMemcpy(c->poa_phase.data(), d_phase.p, (size_t)ne * 12 * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&cells, c->poa_cells_d.p, 8, hipMemcpyDeviceToHost));
+    c->poa_phase.assign((size_t)ne * hxk::POA_PHASE_WORDS, 0);
+    if (ne) HIPCHK(hipMemcpy(c->poa_phase.data(), c->poa_phase_d.p, (size_t)ne * hxk::POA_PHASE_WORDS * 8, hipMemcpyDeviceToHost));
     std::vector<uint64_t> off((size_t)ne + 1, 0);
-    for (uint32_t e = 0; e < ne; e++) off[e + 1] = off[e] + cns[e].size();
+    for (uint32_t e = 0; e < ne; e++) off[e + 1] = off[e] + K.cns[e].size();
     out->n_edge = ne;
     out->cns_off = (uint64_t*)malloc(((size_t)ne + 1) * 8); memcpy(out->cns_off, off.data(), ((size_t)ne + 1) * 8);
     out->cns = (char*)malloc(std::max<uint64_t>(1, off[ne]));
-    for (uint32_t e = 0; e < ne; e++) memcpy(out->cns + off[e], cns[e].data(), cns[e].size());
-    out->dp_cells = cells; out->seq_bases = seq_bases; out->n_aligned = n_aligned;
+    for (uint32_t e = 0; e < ne; e++) memcpy(out->cns + off[e], K.cns[e].data(), K.cns[e].size());
+    out->dp_cells = cells; out->seq_bases = K.seq_bases; out->n_aligned = K.n_aligned;
     return 0;
 }
 
@@ -1117,21 +1262,22 @@ extern "C" void hx_timing_get(hx_ctx* c, double* ms, uint64_t* launches) { for (
 extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max6) {
     // lane-0 cycle counters of the last hx_poa_batch: [decode, dp, traceback, graph update+consensus, toposort, csr];
     // sum over edges and the breakdown of the edge with the largest total (the critical path)
+    constexpr size_t PW_ = hxk::POA_PHASE_WORDS;
     for (int k = 0; k < 6; k++) { sum6[k] = 0; max6[k] = 0; }
     unsigned long long best = 0;
-    size_t ne = c->poa_phase.size() / 12;
-    for (size_t e = 0; e < ne; e++) for (int k = 0; k < 6; k++) if ((long long)c->poa_phase[e * 12 + k] < 0) c->poa_phase[e * 12 + k] = 0;   // (a phase that began and ended on different waves' clocks)
+    size_t ne = c->poa_phase.size() / PW_;
+    for (size_t e = 0; e < ne; e++) for (int k = 0; k < 6; k++) if ((long long)c->poa_phase[e * PW_ + k] < 0) c->poa_phase[e * PW_ + k] = 0;   // (a phase that began and ended on different waves' clocks)
     for (size_t e = 0; e < ne; e++) {
         unsigned long long t = 0;
-        for (int k = 0; k < 6; k++) { sum6[k] += c->poa_phase[e * 12 + k]; t += c->poa_phase[e * 12 + k]; }
-        if (t > best) { best = t; for (int k = 0; k < 6; k++) max6[k] = c->poa_phase[e * 12 + k]; c->dbg_slowest = (uint32_t)e; }
+        for (int k = 0; k < 6; k++) { sum6[k] += c->poa_phase[e * PW_ + k]; t += c->poa_phase[e * PW_ + k]; }
+        if (t > best) { best = t; for (int k = 0; k < 6; k++) max6[k] = c->poa_phase[e * PW_ + k]; c->dbg_slowest = (uint32_t)e; }
     }
-    if (getenv("HX_DEBUG") && ne) {
-        const unsigned long long* q = &c->poa_phase[(size_t)c->dbg_slowest * 12];
-        if (getenv("HX_PROF1")) {   // (a build with -DHX_DP_PROF: where the rows of the first wave of every workgroup spend their cycles, per launch class)
+    if (c->opt.debug && ne) {
+        const unsigned long long* q = &c->poa_phase[(size_t)c->dbg_slowest * PW_];
+        if (c->opt.prof == 1) {   // (a build with -DHX_DP_PROF: where the rows of the first wave of every workgroup spend their cycles, per launch class)
             static const char* seg[6] = {"decode", "predecessors + cells + chain", "wave scan", "carry", "carry applied + ring", "stores"};
             unsigned long long cs[12][7] = {};
-            for (size_t e = 0; e < ne; e++) { const int k = e < c->dbg_cls.size() ? c->dbg_cls[e] : 11; for (int j = 0; j < 6; j++) cs[k][j] += c->poa_phase[e * 12 + 6 + j]; cs[k][6] += c->poa_phase[e * 12 + 1]; }
+            for (size_t e = 0; e < ne; e++) { const int k = e < c->dbg_cls.size() ? c->dbg_cls[e] : 11; for (int j = 0; j < 6; j++) cs[k][j] += c->poa_phase[e * PW_ + 6 + j]; cs[k][6] += c->poa_phase[e * PW_ + 1]; }
             for (int k = 0; k < 12; k++) {
                 unsigned long long t = 0; for (int j = 0; j < 6; j++) t += cs[k][j];
                 if (!t) continue;
@@ -1140,23 +1286,23 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
             }
             return (uint32_t)ne;
         }
-        if (getenv("HX_PROF2")) {   // (a build with -DHX_DP_PROF -DHX_DP_PROF2: where member 0's DP phase goes, for the five longest edges)
+        if (c->opt.prof == 2) {   // (a build with -DHX_DP_PROF -DHX_DP_PROF2: where member 0's DP phase goes, for the five longest edges)
             std::vector<std::pair<unsigned long long, uint32_t>> tt;
-            for (size_t e = 0; e < ne; e++) { unsigned long long t = 0; for (int k = 0; k < 6; k++) t += c->poa_phase[e * 12 + k]; tt.push_back({t, (uint32_t)e}); }
+            for (size_t e = 0; e < ne; e++) { unsigned long long t = 0; for (int k = 0; k < 6; k++) t += c->poa_phase[e * PW_ + k]; tt.push_back({t, (uint32_t)e}); }
             std::sort(tt.rbegin(), tt.rend());
             for (size_t k = 0; k < std::min<size_t>(5, tt.size()); k++) {
-                const unsigned long long* q2 = &c->poa_phase[(size_t)tt[k].second * 12];
+                const unsigned long long* q2 = &c->poa_phase[(size_t)tt[k].second * PW_];
                 fprintf(stderr, "[hx] prof2 edge %u lmax=%u nseq=%u dp phase %llu: publish %llu own columns %llu wait members %llu end node %llu (ties sorted %llu, toposort %llu)\n", tt[k].second, c->dbg_lmax[tt[k].second],
                         c->dbg_nseq[tt[k].second], q2[1], q2[6], q2[7], q2[8], q2[9], q2[10], q2[11]);
             }
             return (uint32_t)ne;
         }
-        if (getenv("HX_PROF3")) {   // (a build with -DHX_DP_PROF3: per member of the five longest edges, kilocycles inside the DP and of them waiting for carries)
+        if (c->opt.prof == 3) {   // (a build with -DHX_DP_PROF3: per member of the five longest edges, kilocycles inside the DP and of them waiting for carries)
             std::vector<std::pair<unsigned long long, uint32_t>> tt;
-            for (size_t e = 0; e < ne; e++) { unsigned long long t = 0; for (int k = 0; k < 6; k++) t += c->poa_phase[e * 12 + k]; tt.push_back({t, (uint32_t)e}); }
+            for (size_t e = 0; e < ne; e++) { unsigned long long t = 0; for (int k = 0; k < 6; k++) t += c->poa_phase[e * PW_ + k]; tt.push_back({t, (uint32_t)e}); }
             std::sort(tt.rbegin(), tt.rend());
             for (size_t k = 0; k < std::min<size_t>(5, tt.size()); k++) {
-                const unsigned long long* q2 = &c->poa_phase[(size_t)tt[k].second * 12];
+                const unsigned long long* q2 = &c->poa_phase[(size_t)tt[k].second * PW_];
                 fprintf(stderr, "[hx] prof3 edge %u lmax=%u nseq=%u dp %llu:", tt[k].second, c->dbg_lmax[tt[k].second], c->dbg_nseq[tt[k].second], q2[1]);
                 for (int m = 0; m < 6; m++) fprintf(stderr, " m%d dp %lluk wait %lluk", m, q2[6 + m] & 0xffffffffull, q2[6 + m] >> 32);
                 fprintf(stderr, "\n");
@@ -1168,10 +1314,10 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
                 c->dbg_lmax[c->dbg_slowest], c->dbg_nseq[c->dbg_slowest], q[6], q[7], q[8] & M40, q[9] & M40, q[10], q[9] >> 40, q[8] >> 40, q[11] & 0xffffffffull);
         {   // the five longest edges (critical-path candidates)
             std::vector<std::pair<unsigned long long, uint32_t>> tt;
-            for (size_t e = 0; e < ne; e++) { unsigned long long t = 0; for (int k = 0; k < 6; k++) t += c->poa_phase[e * 12 + k]; tt.push_back({t, (uint32_t)e}); }
+            for (size_t e = 0; e < ne; e++) { unsigned long long t = 0; for (int k = 0; k < 6; k++) t += c->poa_phase[e * PW_ + k]; tt.push_back({t, (uint32_t)e}); }
             std::sort(tt.rbegin(), tt.rend());
             for (size_t k = 0; k < std::min<size_t>(5, tt.size()); k++) {
-                const unsigned long long* q2 = &c->poa_phase[(size_t)tt[k].second * 12];
+                const unsigned long long* q2 = &c->poa_phase[(size_t)tt[k].second * PW_];
                 fprintf(stderr, "[hx] top edge %u: lmax=%u nseq=%u cycles=%llu (dp %llu tb %llu graph %llu order %llu csr %llu) rows %llu multi %llu ring %llu far %llu kept %llu wide %llu fifth+ %llu\n", tt[k].second, c->dbg_lmax[tt[k].second], c->dbg_nseq[tt[k].second],
                         tt[k].first, q2[1], q2[2], q2[3], q2[4], q2[5], q2[6], q2[7], q2[8] & ((1ull << 40) - 1), q2[9] & ((1ull << 40) - 1), q2[10], q2[9] >> 40, q2[8] >> 40);
             }
@@ -1179,7 +1325,7 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
         {   // finished graphs against the workspace estimate: nodes per base of the longest sequence, as a + b x sequences
             std::vector<double> grow, fill;
             for (size_t e = 0; e < ne; e++) {
-                const double V = (double)(c->poa_phase[e * 12 + 11] >> 32), L = c->dbg_lmax[e], S = c->dbg_nseq[e];
+                const double V = (double)(c->poa_phase[e * PW_ + 11] >> 32), L = c->dbg_lmax[e], S = c->dbg_nseq[e];
                 if (V <= 0 || L <= 0 || S <= 0) continue;
                 grow.push_back((V - L) / (L * S));
                 fill.push_back(V / (L * (3 + S / 10) + 1024));
@@ -1191,23 +1337,43 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
         }
         {   // per launch class: how often a row is read back from the LDS ring / from HBM
             unsigned long long cr[12][4] = {};
-            for (size_t e = 0; e < ne; e++) { const int k = e < c->dbg_cls.size() ? c->dbg_cls[e] : 11; const unsigned long long* q3 = &c->poa_phase[e * 12]; cr[k][0] += q3[6]; cr[k][1] += q3[10]; cr[k][2] += q3[8] & ((1ull << 40) - 1); cr[k][3] += q3[9] & ((1ull << 40) - 1); }
+            for (size_t e = 0; e < ne; e++) { const int k = e < c->dbg_cls.size() ? c->dbg_cls[e] : 11; const unsigned long long* q3 = &c->poa_phase[e * PW_]; cr[k][0] += q3[6]; cr[k][1] += q3[10]; cr[k][2] += q3[8] & ((1ull << 40) - 1); cr[k][3] += q3[9] & ((1ull << 40) - 1); }
             for (int k = 0; k < 12; k++) if (cr[k][0]) fprintf(stderr, "[hx] class %d (ring %u): DP rows %llu, kept %.1f %%, ring refs %.1f %%, far refs %.2f %%\n", k, k < 11 ? c->dbg_ring[k] : 0, cr[k][0], 100.0 * cr[k][1] / cr[k][0], 100.0 * cr[k][2] / cr[k][0], 100.0 * cr[k][3] / cr[k][0]);
             unsigned long long cy[12][4] = {};   // edges, all cycles, DP cycles, longest edge
             for (size_t e = 0; e < ne; e++) {
-                const int k = e < c->dbg_cls.size() ? c->dbg_cls[e] : 11; const unsigned long long* q3 = &c->poa_phase[e * 12];
+                const int k = e < c->dbg_cls.size() ? c->dbg_cls[e] : 11; const unsigned long long* q3 = &c->poa_phase[e * PW_];
                 unsigned long long t = 0; for (int j = 0; j < 6; j++) t += q3[j];
                 cy[k][0]++; cy[k][1] += t; cy[k][2] += q3[1]; cy[k][3] = std::max(cy[k][3], t);
             }
             for (int k = 0; k < 12; k++) if (cy[k][0]) fprintf(stderr, "[hx] class %d: %llu workgroups, %.3e cycles in all (DP %.0f %%), longest %.3e, DP cycles per row %.0f\n", k, cy[k][0], (double)cy[k][1], 100.0 * cy[k][2] / cy[k][1], (double)cy[k][3], cr[k][0] ? (double)cy[k][2] / cr[k][0] : 0.0);
         }
+        {   // the pruning (kernels/poa.hip PRUNE): wave-rows of the pruned launches, those skipped, attempts repeated, per launch class
+            unsigned long long pr[12][4] = {};
+            for (size_t e = 0; e < ne; e++) { const int k = e < c->dbg_cls.size() ? c->dbg_cls[e] : 11; for (int j = 0; j < 4; j++) pr[k][j] += c->poa_phase[e * PW_ + 12 + j]; }
+            for (int k = 0; k < 12; k++) if (pr[k][0]) fprintf(stderr, "[hx] class %d pruning: %.4g wave-rows, %.1f %% skipped, %llu alignments with a threshold, %llu repeated\n", k, (double)pr[k][0], 100.0 * pr[k][1] / pr[k][0], pr[k][3], pr[k][2]);
+        }
         unsigned long long tot[6] = {0, 0, 0, 0, 0, 0};
-        for (size_t e = 0; e < ne; e++) for (int k = 0; k < 6; k++) tot[k] += k == 5 ? (c->poa_phase[e * 12 + 11] & 0xffffffffull) : (k == 2 || k == 3 ? c->poa_phase[e * 12 + 6 + k] & ((1ull << 40) - 1) : c->poa_phase[e * 12 + 6 + k]);
+        for (size_t e = 0; e < ne; e++) for (int k = 0; k < 6; k++) tot[k] += k == 5 ? (c->poa_phase[e * PW_ + 11] & 0xffffffffull) : (k == 2 || k == 3 ? c->poa_phase[e * PW_ + 6 + k] & ((1ull << 40) - 1) : c->poa_phase[e * PW_ + 6 + k]);
         fprintf(stderr, "[hx] all edges: DP rows %llu (multi-pred %llu, ring refs %llu, far refs %llu, kept %llu) over %llu sequences\n", tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]);
     }
     return (uint32_t)ne;
 }
 extern "C" uint64_t hx_poa_workspace_bytes(const hx_ctx* c) { return c->poa_workspace_bytes; }
+extern "C" int hx_poa_release_workspace(hx_ctx* c) {
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->poa_pools.release_all(); c->poa_cns.release();
+    c->poa_budget = 0;   // taken again, from what is free then, by the next consensus call
+    return 0;
+}
+extern "C" void hx_poa_memory_stats(const hx_ctx* c, uint64_t* free_at_first_call, uint64_t* budget, uint64_t* last_call_workspace) {
+    *free_at_first_call = c->poa_free_at_first_call; *budget = c->poa_budget; *last_call_workspace = c->poa_last_workspace_bytes;
+}
+extern "C" void hx_poa_prune_stats(const hx_ctx* c, uint64_t* out4) {
+    for (int j = 0; j < 4; j++) out4[j] = 0;
+    const size_t PW_ = hxk::POA_PHASE_WORDS, ne = c->poa_phase.size() / PW_;
+    for (size_t e = 0; e < ne; e++) for (int j = 0; j < 4; j++) out4[j] += c->poa_phase[e * PW_ + 12 + j];
+}
 extern "C" void hx_set_poa_traceback(hx_ctx* c, int use_direction_bytes) { c->poa_no_dir = !use_direction_bytes; }
 extern "C" void hx_set_poa_block(hx_ctx* c, int t) { c->poa_block = t <= 0 ? 0 : t >= 1024 ? 1024 : t >= 512 ? 512 : t >= 256 ? 256 : t >= 128 ? 128 : 64; }
 
@@ -1236,7 +1402,9 @@ extern "C" void hx_backend_fill(hx_ctx* c, void* table) {
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <condition_variable>
+#include <thread>
 #include <memory>
 #include <mutex>
 
@@ -1254,7 +1422,12 @@ struct hx_group {
     ncclResult_t (*p_init_all)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*p_all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*p_destroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*p_abort)(ncclComm_t) = nullptr;
     const char* (*p_errstr)(ncclResult_t) = nullptr;
+    std::atomic<int> abort_flag{0};               // a rank failed inside the collective: the ranks still waiting on their streams abort their communicators
+    bool broken = false;                          // ... after which the group refuses further exchanges
+    double timeout_s = 300;                       // bound of the wait for the collective (hx_group_set_timeout)
+    int fault_rank = -1;                          // (testing, hx_group_inject_fault: this rank's all-gather "returns an error")
     // rendezvous of the rank threads: everybody arrives with a status, everybody leaves with the worst one (so that no rank enters a
     // collective the others will never join)
     std::mutex mu;
@@ -1277,23 +1450,23 @@ struct hx_group {
     }
 };
 
-extern "C" int hx_group_create(int n, const int* devices, hx_group** out) {
+extern "C" int hx_group_create(int n, const int* devices, const char* transport, hx_group** out) {
     *out = nullptr;
     int ndev = 0;
     if (n < 1) return fail("hx_group_create: at least one rank");
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail("hx_group_create: no HIP device available (no CPU fallback)");
     std::unique_ptr<hx_group> g(new hx_group);
     g->n = n;
-    const char* tr = getenv("HASLR_GROUP_TRANSPORT");
+    const char* tr = transport && *transport ? transport : nullptr;   // (the applications pass what their HASLR_GROUP_TRANSPORT says: the library reads no environment)
     bool distinct = true;
     for (int r = 0; r < n; r++) {
         const int d = devices ? devices[r] : (tr && !strcmp(tr, "host") ? r % ndev : r);
         if (d < 0 || d >= ndev) return fail("hx_group_create: rank " + std::to_string(r) + " asks for device " + std::to_string(d) + " of " + std::to_string(ndev) +
-                                            " (one device per rank over RCCL; HASLR_GROUP_TRANSPORT=host lets ranks share devices)");
+                                            " (one device per rank over RCCL; transport \"host\" lets ranks share devices)");
         for (int q : g->dev) distinct = distinct && q != d;
         g->dev.push_back(d);
     }
-    if (tr && strcmp(tr, "host") && strcmp(tr, "rccl")) return fail("HASLR_GROUP_TRANSPORT must be rccl or host");
+    if (tr && strcmp(tr, "host") && strcmp(tr, "rccl")) return fail("hx_group_create: transport must be \"rccl\" or \"host\" (or NULL: automatic)");
     g->rccl = tr ? !strcmp(tr, "rccl") : distinct;
     if (g->rccl && !distinct) return fail("hx_group_create: RCCL needs one device per rank");
     g->ctx.assign(n, nullptr);
@@ -1312,6 +1485,7 @@ extern "C" int hx_group_create(int n, const int* devices, hx_group** out) {
         g->p_all_gather = (decltype(g->p_all_gather))dlsym(g->lib, "ncclAllGather");
         g->p_destroy = (decltype(g->p_destroy))dlsym(g->lib, "ncclCommDestroy");
         g->p_errstr = (decltype(g->p_errstr))dlsym(g->lib, "ncclGetErrorString");
+        g->p_abort = (decltype(g->p_abort))dlsym(g->lib, "ncclCommAbort");
         if (!g->p_init_all || !g->p_all_gather || !g->p_destroy || !g->p_errstr) { for (hx_ctx* c : g->ctx) hx_ctx_destroy(c); return fail("hx_group_create: librccl lacks ncclCommInitAll / ncclAllGather"); }
         g->comm.assign(n, nullptr);
         const ncclResult_t rc = g->p_init_all(g->comm.data(), n, g->dev.data());
@@ -1330,6 +1504,8 @@ extern "C" void hx_group_destroy(hx_group* g) {
     delete g;
 }
 extern "C" int hx_group_size(const hx_group* g) { return g->n; }
+extern "C" void hx_group_inject_fault(hx_group* g, int rank) { g->fault_rank = rank; }
+extern "C" void hx_group_set_timeout(hx_group* g, double seconds) { g->timeout_s = seconds > 0 ? seconds : 300; }
 extern "C" hx_ctx* hx_group_ctx(hx_group* g, int rank) { return rank >= 0 && rank < g->n ? g->ctx[rank] : nullptr; }
 extern "C" const char* hx_group_transport(const hx_group* g) { return g->rccl ? "rccl" : "host"; }
 extern "C" void hx_group_exchange_stats(const hx_group* g, uint64_t* bytes, double* ms) { *bytes = g->last_bytes; *ms = g->last_ms; }
@@ -1337,6 +1513,7 @@ extern "C" void hx_group_exchange_stats(const hx_group* g, uint64_t* bytes, doub
 extern "C" int hx_edge_merge(hx_group* g, int rank, const hx_params* prm, hx_edges_out* out) {
     memset(out, 0, sizeof(*out));
     if (rank < 0 || rank >= g->n) return fail("hx_edge_merge: rank out of range");
+    if (g->broken) return fail("hx_edge_merge: the group's collective failed earlier (communicators aborted): create a new group");
     hx_ctx* c = g->ctx[rank];
     const uint32_t rb = hx_edge_records_bytes();
     uint64_t n = 0;
@@ -1357,17 +1534,37 @@ extern "C" int hx_edge_merge(hx_group* g, int rank, const hx_params* prm, hx_edg
     if (g->rccl) {
         // THE collective of the path: every rank contributes its packed records padded to the largest shard (counts travelled through the
         // process's memory above: the ranks are threads of one process)
-        const ncclResult_t nr = g->p_all_gather(sb.p, rv.p, cap, ncclUint8, g->comm[rank], c->stream);
-        if (nr != ncclSuccess) { rc = -1; own_err = std::string("ncclAllGather: ") + g->p_errstr(nr); }
-        else if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = -1; own_err = "hx_edge_merge: all-gather failed on the stream"; }
-    } else {
+        // A failure INSIDE the collective must not leave the other ranks parked on their streams: the wait is a bounded poll of the stream; a rank
+        // whose ncclAllGather returns an error (or whose stream faults, or whose wait runs out) raises the group's abort flag, every rank that sees it
+        // aborts its communicator (ncclCommAbort ends the kernels of the collective on its device) and all of them meet at the rendezvous below with
+        // the failure. The group is unusable afterwards (hx_edge_merge refuses).
+        const ncclResult_t nr = g->fault_rank == rank ? ncclInternalError : g->p_all_gather(sb.p, rv.p, cap, ncclUint8, g->comm[rank], c->stream);
+        if (nr != ncclSuccess) { rc = -1; own_err = std::string("ncclAllGather: ") + g->p_errstr(nr); g->abort_flag.store(1); }
+        else {
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(g->timeout_s);
+            for (;;) {
+                const hipError_t q = hipStreamQuery(c->stream);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) { rc = -1; own_err = std::string("hx_edge_merge: all-gather failed on the stream: ") + hipGetErrorString(q); g->abort_flag.store(1); break; }
+                const bool late = std::chrono::steady_clock::now() > deadline;
+                if (g->abort_flag.load() || late) {
+                    rc = -1; own_err = late ? "hx_edge_merge: the all-gather did not finish within " + std::to_string((int)g->timeout_s) + " s (hx_group_set_timeout)" : "hx_edge_merge: another rank failed inside the all-gather";
+                    g->abort_flag.store(1);
+                    if (g->p_abort && g->comm[rank]) { (void)g->p_abort(g->comm[rank]); g->comm[rank] = nullptr; }
+                    (void)hipStreamSynchronize(c->stream);
+                    break;
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+        }
+        } else {
         g->stage[rank].resize(cap);
         if (hipMemcpy(g->stage[rank].data(), sb.p, cap, hipMemcpyDeviceToHost) != hipSuccess) { rc = -1; own_err = "hx_edge_merge: copy to the host staging buffer failed"; }
         if (g->rendezvous(rc != 0)) return fail(rc ? own_err : "hx_edge_merge: another rank failed in the exchange");
         for (int r = 0; r < g->n && !rc; r++)
             if (hipMemcpy(rv.p + (uint64_t)r * cap, g->stage[r].data(), cap, hipMemcpyHostToDevice) != hipSuccess) { rc = -1; own_err = "hx_edge_merge: copy from the host staging buffer failed"; }
     }
-    if (g->rendezvous(rc != 0)) return fail(rc ? own_err : "hx_edge_merge: another rank failed in the exchange");
+    if (g->rendezvous(rc != 0)) { if (g->rccl) g->broken = true; return fail(rc ? own_err : "hx_edge_merge: another rank failed in the exchange"); }
     if (rank == 0) { g->last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); g->last_bytes = total * rb; }
     const uint8_t* src = rv.p;
     if (!equal) {   // cut the padding out: rank order = ascending read ids, which the stable key sort relies on

@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(K5_NT) k_edge_coords(EdgeRecs R, const uint64_
     __shared__ uint32_t sh[8];
     __shared__ uint64_t l_sorted[4 * LDS_SUPP];
     __shared__ uint32_t l_step[4 * LDS_SUPP];
-    const bool in_lds = n <= lds_supp;   // (LDS_SUPP; HX_COORDS_LDS_SUPP=0 sends every edge through the global scratch: testing)
+    const bool in_lds = n <= lds_supp;   // (LDS_SUPP; option coords_lds_supp=0 sends every edge through the global scratch: testing)
     // (generic pointers: the sweep's dependent loads are LDS round trips for nearly every edge, HBM ones only for an edge with hundreds of supports)
     uint64_t* beg1 = in_lds ? l_sorted : sc.beg1 + so;
     uint64_t* end1 = in_lds ? l_sorted + LDS_SUPP : sc.end1 + so;
@@ -258,8 +258,8 @@ __global__ void k_coords_compact(const uint64_t* __restrict__ cap_off, const uin
 
 void edge_coords(const EdgeRecs& recs, const uint64_t* edge_key, const uint64_t* edge_off, const uint32_t* cg_ops, const uint32_t* contig_len,
                  const uint32_t* read_len, uint32_t n_sel, const uint32_t* sel_edge, const uint64_t* sel_rec_off, const CoordsScratch& sc,
-                 uint32_t* head_end, uint32_t* tail_beg, uint32_t* n_supp, uint32_t* supp_lr, uint32_t* spos, uint32_t* epos, hipStream_t s) {
-    const uint32_t lds_supp = getenv("HX_COORDS_LDS_SUPP") ? std::min<uint32_t>(LDS_SUPP, (uint32_t)atoi(getenv("HX_COORDS_LDS_SUPP"))) : LDS_SUPP;
+                 uint32_t* head_end, uint32_t* tail_beg, uint32_t* n_supp, uint32_t* supp_lr, uint32_t* spos, uint32_t* epos, int lds_supp_opt, hipStream_t s) {
+    const uint32_t lds_supp = lds_supp_opt >= 0 ? std::min<uint32_t>(LDS_SUPP, (uint32_t)lds_supp_opt) : LDS_SUPP;   // (option coords_lds_supp; 0 sends every edge through the global scratch: testing)
     if (n_sel) k_edge_coords<<<n_sel, K5_NT, 0, s>>>(recs, edge_key, edge_off, cg_ops, contig_len, read_len, n_sel, sel_edge, sel_rec_off, sc,
                                                  head_end, tail_beg, n_supp, supp_lr, spos, epos, lds_supp);
 }

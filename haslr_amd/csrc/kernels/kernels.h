@@ -78,7 +78,7 @@ void edge_coords(const EdgeRecs& recs, const uint64_t* edge_key, const uint64_t*
                  const uint32_t* contig_len, const uint32_t* read_len, uint32_t n_sel, const uint32_t* sel_edge,
                  const uint64_t* sel_rec_off,   // n_sel+1: scratch / output capacity offsets (records, doubled for hairpins)
                  const CoordsScratch& sc, uint32_t* head_end, uint32_t* tail_beg, uint32_t* n_supp,
-                 uint32_t* supp_lr, uint32_t* spos, uint32_t* epos, hipStream_t s);
+                 uint32_t* supp_lr, uint32_t* spos, uint32_t* epos, int lds_supp /* supports per edge sorted in LDS: -1 = the kernel's capacity */, hipStream_t s);
 void coords_compact(const uint64_t* cap_off, const uint64_t* out_off, uint32_t n_sel, const uint32_t* lr_in, const uint32_t* sp_in,
                     const uint32_t* ep_in, uint32_t* lr_out, uint32_t* sp_out, uint32_t* ep_out, hipStream_t s);
 
@@ -136,25 +136,27 @@ struct PoaPools {
 // kernel instance (largest workgroup it is compiled for) that serves workgroups of `block_threads` lanes, and the columns per lane it can be had with
 inline int poa_kernel_lanes(int block_threads) { return block_threads <= 64 ? 64 : block_threads <= 256 ? 256 : block_threads <= 512 ? 512 : 1024; }
 inline int poa_kernel_max_cm(int block_threads) { return block_threads <= 256 ? 32 : block_threads <= 512 ? 16 : 32; }
-inline bool poa_persistent_ok(bool use_dir) { return use_dir; }
-// Packed 16-bit rows (kernels/poa.hip, dp_rows16): a key is 512 + 4 Xr + type with 0 <= Xr <= (match - 2 gap) x the columns of one wave, and a candidate
-// carries up to 4 (match - 2 gap) + 3 more before its frame shift is taken off: all of it must stay below 2^16. True for the reference's 5 / -4 / -8 with 4 or 8
-// columns per lane (43 610 at 8); other scores fall back to the int32 rows.
-inline bool poa_pk16_ok(int match, int mismatch, int gap, int cm) {
-    if (!(cm == 4 || cm == 8) || gap >= 0 || match <= 0 || mismatch > match) return false;
-    const long long span = 4ll * (match - 2ll * gap);
-    return 512 + span * 64 * cm + 3 + span + 3 <= 65535 && -4ll * gap <= 4096;
-}   // launches that can run persistent (the score-matrix flavour is rare: one workgroup per edge)
+inline bool poa_persistent_ok(bool use_dir) { return use_dir; }   // launches that can run persistent (the score-matrix flavour is rare: one workgroup per edge)
+// Exact score-bound pruning of the DP (kernels/poa.hip "PRUNE"): instances exist for the direction-byte flavour with 4 or 8 columns per lane, for
+// launches of one workgroup per edge (a shared edge's members would have to repeat an attempt together)
+inline bool poa_prune_ok(bool use_dir, int cm) { return use_dir && cm <= 8; }
+constexpr int32_t PRUNE_OFF = -(1 << 24);   // a threshold no real cell is below (|scores| < 2^24: the host checks 8 (nodes + columns))
+constexpr int POA_PHASE_WORDS = 16;         // per edge: 6 phase cycle counters, 6 row statistics, 4 of the pruning (wave-rows, wave-rows skipped, attempts repeated, alignments with a threshold)
 // One launch of a class. counter == nullptr: one workgroup per entry of `order` (edge | member << 24; shared edges, each in its own slot
 // PoaEdge::slot); else PERSISTENT: n_blocks workgroups, workgroup b owns slots[b] and pulls the n_items edges of `order` through *counter.
-void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_items, const PoaSlot* slots, uint32_t* counter, uint32_t n_blocks, const PoaSeq* seqs, const uint8_t* packed,
-             const uint64_t* read_off, const uint32_t* read_len, PoaPools pools,
-             int32_t match, int32_t mismatch, int32_t gap, char* cns, uint32_t* cns_len, uint32_t* status,
-             unsigned long long* cells, unsigned long long* phase_cycles /* 12 per edge or null */, int block_threads /* multiple of 64, <= 1024 */,
-             int cm /* columns per lane of the launch: 4, 8, 16 or 32; every edge's longest sequence fits members x block_threads x cm columns */,
-             uint32_t poll_limit /* polls before a wave gives up waiting for another (-> HXE_POA_STALLED) */, uint32_t ring_bytes /* dynamic LDS */,
-             bool use_dir /* direction-byte traceback (in-degrees <= max_indeg <= 16, else the edge comes back with HXE_POA_NODIR) */, uint32_t max_indeg, uint32_t dp_lanes /* 0: every lane of the workgroup; else the lanes that take part in the DP (a wide cluster member) */,
-             bool pk16 /* packed 16-bit rows (use_dir, cm 4 or 8, poa_pk16_ok): ring_bytes then holds the ring of packed rows AND 1 KB x cm / 2 per DP wave of score registers */, hipStream_t s);
+struct PoaLaunch {
+    const PoaEdge* edges; const uint32_t* order; uint32_t n_items; const PoaSlot* slots; uint32_t* counter; uint32_t n_blocks;
+    const PoaSeq* seqs; const uint8_t* packed; const uint64_t* read_off; const uint32_t* read_len; PoaPools pools;
+    int32_t match, mismatch, gap; char* cns; uint32_t *cns_len, *status;
+    unsigned long long *cells, *phase /* POA_PHASE_WORDS per edge or null */;
+    int block_threads /* multiple of 64, <= 1024 */;
+    int cm /* columns per lane of the launch: 4, 8, 16 or 32; every edge's longest sequence fits members x block_threads x cm columns */;
+    uint32_t poll_limit /* polls before a wave gives up waiting for another (-> HXE_POA_STALLED) */, ring_bytes /* dynamic LDS */;
+    bool use_dir /* direction-byte traceback (in-degrees <= max_indeg <= 16, else the edge comes back with HXE_POA_NODIR) */;
+    uint32_t max_indeg, dp_lanes /* 0: every lane of the workgroup; else the lanes that take part in the DP (a wide cluster member) */;
+    uint32_t prune_pct /* 0: full matrix; else the pruned instance (poa_prune_ok, unshared edges) with thresholds at this percentage of the previous alignment's score per base */;
+};
+void poa_run(const PoaLaunch& q, hipStream_t s);
 
 }  // namespace hxk
 #endif

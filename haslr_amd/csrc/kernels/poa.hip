@@ -698,10 +698,12 @@ template <int CM> __device__ __forceinline__ void store_nibbles_buf(__amdgpu_buf
 // predecessor lives (registers / LDS ring / anything else), then straight-line code: rare events (row spilled to HBM, sink row) share
 // one not-taken branch, only rows with a non-adjacent reader are copied to the LDS ring (slot from the row's record), selects are
 // arithmetic.
-template <int CM, bool DIR>
+template <int CM, bool DIR, bool PRUNE>
 __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, uint8_t* __restrict__ Dwide, const uint32_t W, const uint32_t WH, const uint8_t* __restrict__ seq,
                         const uint32_t L_, const uint32_t V_, int32_t* ring, const uint32_t R_, const uint32_t ring_w_, const int match, const int mismatch, const int gap,
-                        unsigned long long* wm_box, uint32_t* wm_cons, uint32_t* sink_row, int* sink_score, const uint32_t sink_cap, uint32_t& nSinkOut, const DpCl& cl, unsigned long long* prof) {
+                        unsigned long long* wm_box, uint32_t* wm_cons, uint32_t* sink_row, int* sink_score, const uint32_t sink_cap, uint32_t& nSinkOut, const DpCl& cl, unsigned long long* prof,
+                        const int thrT /* PRUNE: score threshold T of this alignment (PRUNE_OFF: nothing real is below it) */, unsigned long long* pstat /* PRUNE: wave-rows, wave-rows skipped */) {
+    static_assert(!PRUNE || DIR, "pruned rows: direction-byte flavour only");
 #if defined(HX_DP_PROF) && !defined(HX_DP_PROF2)
     long long tprev = clock64();
 #endif
@@ -836,6 +838,27 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     int tp[CM], lnp = NEGK;                  // the previous row's finished keys under this lane, and the key left of the wave's first column (lane 0's is used)
 #pragma unroll
     for (int k = 0; k < CM; k++) tp[k] = NEGK;
+    // ---- PRUNE: exact score-bound pruning at the granularity this pipeline works at, (row, wave). U(i, j) = H[i][j] + match x (L - j) bounds the
+    // final score of every path through cell (i, j) and never grows along a path, so with a threshold T <= the final score S no cell with U < T
+    // lies on an optimal path, every cell of an optimal path keeps its exact value whatever stands in the dead cells (anything <= their true
+    // value), and the traceback - which compares the candidates of optimal cells only - is unchanged. In de-ramped keys (X = H - gap j, never
+    // decreasing along a row) U = X + match L - (match - gap) j: a lane's columns are all dead when the key of its LAST column, taken at its
+    // FIRST, is below T (`thr_lane`), the carry entering the wave is dead below `thr_cin`. A wave SKIPS a row (no predecessor reads, no cells, no
+    // scan, no ring copy, no nibbles: it forwards the incoming carry under the row's tag) when the carry is dead and none of its predecessor
+    // rows was FLAGGED by this wave; a computed row is flagged when one of its lanes or its carry-in is live. The flags of the rows a successor
+    // can name live in one scalar word FM, bit = the location code of a predecessor entry: 1 + ring slot, 13 the previous row, 14 the virtual
+    // row 0, 15 a row read back from HBM (always set: a skipped row with a far reader stores "nothing" there, so it may be read). Predecessors
+    // whose flag is clear are not read at all (their registers / ring slot hold an older row). T is the caller's: poa_edge checks S >= T
+    // afterwards and repeats the alignment otherwise. (kernels.h: PRUNE_OFF; oracle.cpp prune_sim = this rule on the CPU, a statistic.)
+    int thr_lane = 0; uint32_t FM = 0xffffu, n_dead = 0; int thr_cin = 0;
+    if constexpr (PRUNE) {
+        const int mg = match - gap, thr_base = thrT - match * (int)L;
+        const int c0 = (int)(gw * 64u * CM);
+        thr_lane = (thr_base + mg * (int)j0) * 64;
+        thr_cin = __builtin_amdgcn_readfirstlane((thr_base + mg * (c0 - 1)) * 64);
+        const uint32_t f0 = (uint32_t)(match * (int)L - mg * max(c0 - 1, 0) >= thrT);
+        FM = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0x8000u | (f0 << 14)));   // nothing in the ring, no previous row yet
+    }
     auto pred_row = [&](const uint32_t ent, int (&hp)[CM], int& left, const bool slot_known) {
         const uint32_t loc = ent >> 28;
         if (__builtin_expect(loc == 13u, 1)) {   // the previous row: registers (the likely case falls through: a taken scalar branch costs a lone wave ~35 cycles)
@@ -928,6 +951,49 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 const uint32_t ri = rb + rj, i = ib + ri + 1;
                 const uint32_t meta = meta_nx, p0 = p0_nx;
                 const uint32_t npred = meta >> META_NP;
+                uint32_t cin_live = 0, fl0 = 1, flB = 1, flC = 1, flD = 1;
+                if constexpr (PRUNE) {
+                    // does anything this wave can read for the row still reach T? (all scalar: flags of the predecessor entries, the carry's test)
+                    const int cin_e = __builtin_amdgcn_readlane(cinV, rj);
+                    cin_live = (uint32_t)(cin_e >= thr_cin);
+                    fl0 = (FM >> (p0 >> 28)) & 1u;
+                    uint32_t act = cin_live | fl0;
+                    if (npred > 1) {
+                        flB = (FM >> ((uint32_t)__builtin_amdgcn_readlane(bC, ri) >> 28)) & 1u; act |= flB;
+                        if (npred > 2) {
+                            flC = (FM >> ((uint32_t)__builtin_amdgcn_readlane(cC, ri) >> 28)) & 1u; act |= flC;
+                            if (npred > 3) { flD = (FM >> ((uint32_t)__builtin_amdgcn_readlane(dC, ri) >> 28)) & 1u; act |= flD | (uint32_t)(npred > 4); }
+                        }
+                    }
+                    if (act == 0u) {
+                        // ---- a skipped row: the carry passes through, the row's flags are cleared, a far reader finds "nothing"
+                        n_dead++;
+                        const uint32_t slot_d = (meta >> META_SLOT) & 15u;
+                        FM &= ~(0x2000u | (2u << slot_d));   // (slot 15 = not kept: bit 16, which nobody reads)
+                        meta_nx = __builtin_amdgcn_readlane(mC, (ri + 1) & 63u); p0_nx = __builtin_amdgcn_readlane(aC, (ri + 1) & 63u);
+                        {
+                            const unsigned long long ent = (unsigned long long)(tag0_s + i) | ((unsigned long long)(uint32_t)cin_e << 32);
+                            if (out_l != 0u) { if (lane == 63) *(volatile __attribute__((address_space(3))) unsigned long long*)(uintptr_t)(mb_lds + ((i & (WAVE_MBOX - 1)) << 3)) = ent; }
+                            if (out_h != 0u) { if (lane == 63) st_dev64(mb_out_h + i, ent); }
+                        }
+                        {   // the nibble row pointer moves on (live rows: inside the scan)
+                            const unsigned long long dp_ = (((unsigned long long)dhi << 32) | dlo) + dstep_s;
+                            dlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dp_); dhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dp_ >> 32));
+                        }
+                        if (__builtin_expect((meta & 8u) != 0u, 0)) {   // a far successor will read this row from HBM: keys of "nothing" (its flag is always taken for set)
+                            const uint32_t fslot = __builtin_amdgcn_readlane(fC, ri);
+                            if (live) {
+                                int32_t* F = H + (uint64_t)fslot * WH;
+                                int ng[CM];
+#pragma unroll
+                                for (int k = 0; k < CM; k++) ng[k] = NEGK;
+                                store_chunk_i32<CM>(F + j0, ng);
+                                if (lane == 0 && has_in) F[hleft] = NEGK;
+                            }
+                        }
+                        continue;
+                    }
+                }
                 // mismatch bits of this row: bit 2k set <=> the base under column k differs from the row's letter
                 mask_t mis = 0;
                 uint32_t hit = 0;     // (CM <= 8) bit 4 k set <=> the base under column k is the row's letter
@@ -953,11 +1019,14 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 hrow += WH;
                 DP_T(0);   // row decode
                 int m[CM];
-                {   // the first predecessor (or row 0): diagonal and vertical move
+                if (!PRUNE || __builtin_expect(fl0 != 0u, 1)) {   // the first predecessor (or row 0): diagonal and vertical move
                     int hp[CM], left;
                     pred_row(p0, hp, left, true);
 #pragma unroll
                     for (int k = 0; k < CM; k++) m[k] = max((k == 0 ? left : hp[k - 1]) + score_of(k), hp[k] + gv);
+                } else {                                          // (PRUNE: a skipped row is not read)
+#pragma unroll
+                    for (int k = 0; k < CM; k++) m[k] = NEGK;
                 }
                 if (npred > 1) {   // (two rows in five at 25-45x)
                     // the maximum over the predecessors: the low bits carry the move type and 15 - p, so ONE running maximum does it all
@@ -985,14 +1054,17 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                             m[k] = max(m[k], max(dg, hp[k] + gvp));
                         }
                     };
-                    more(__builtin_amdgcn_readlane(bC, ri), DIR ? 1 : 0, true);
+                    if (!PRUNE || flB != 0u) more(__builtin_amdgcn_readlane(bC, ri), DIR ? 1 : 0, true);
                     if (npred > 2) {
-                        more(__builtin_amdgcn_readlane(cC, ri), DIR ? 2 : 0, false);
+                        if (!PRUNE || flC != 0u) more(__builtin_amdgcn_readlane(cC, ri), DIR ? 2 : 0, false);
                         if (npred > 3) {
-                            more(__builtin_amdgcn_readlane(dC, ri), DIR ? 3 : 0, false);
+                            if (!PRUNE || flD != 0u) more(__builtin_amdgcn_readlane(dC, ri), DIR ? 3 : 0, false);
                             if (__builtin_expect(npred > 4, 0)) {   // a fifth and later ones are fetched here (direction bytes exist only while in-degrees stay <= 16: the CSR build checks)
                                 const uint32_t po = __builtin_amdgcn_readlane(oC, ri);
-                                for (uint32_t p = 4; p < npred; p++) more((uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[po + p]), DIR ? (int)p : 0, false);
+                                for (uint32_t p = 4; p < npred; p++) {
+                                    const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[po + p]);
+                                    if (!PRUNE || ((FM >> (ent >> 28)) & 1u) != 0u) more(ent, DIR ? (int)p : 0, false);
+                                }
                             }
                         }
                     }
@@ -1033,6 +1105,10 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
 #pragma unroll
                 for (int k = 0; k < CM; k++) tp[k] = t[k];
                 lnp = left_now;
+                if constexpr (PRUNE) {   // the row's flag for its successors: a lane whose last key, taken at its first column, reaches T - or a live carry-in (the column left of the wave)
+                    const uint32_t fl = (uint32_t)(__builtin_amdgcn_ballot_w64(t[CM - 1] >= thr_lane) != 0ull) | cin_live;
+                    FM = (FM & ~(0x2000u | (2u << slot))) | (fl << 13) | ((fl << 1) << slot);
+                }
                 DP_T(4);   // carry applied, ring copy
                 if (DIR) {
                     // the move code of every cell: type * 4 + 3 - predecessor slot. The row is stored through a buffer resource of ITS bytes: chunks
@@ -1083,395 +1159,21 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
         }
     }
     if (owns_last) nSinkOut = nsink;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// The packed 16-bit row body (round 4): two columns per register, half the instructions per cell of the int32 keys above. Same pipeline of
-// waves, same mailboxes, same ring / far-row / wide-row bookkeeping, same move codes for the traceback - another number format for the cells.
-//
-// Register q (0 <= q < h = CM / 2) of a lane holds column j0 + q in its low half and column j0 + q + h in its high half ("split" layout: the
-// left neighbours of a register's two columns are the previous register - no per-register alignment instruction). A cell is the 16-bit key
-//       K = 4 * Xr + type + OFF (unsigned),      Xr = H[i][j] - B[i] - gap * (j - c0 + 1)
-// c0 = the wave's first column, B[i] = H[i][c0 - 1] = the finished score just LEFT of the wave in row i, which is what the wave on the left
-// hands over (the first wave of an edge uses B[i] = H[i][0] - gap, a virtual column -1, and computes it from its predecessors' B). Xr is the
-// score relative to the wave's own left edge with the gap ramp taken out: a horizontal step changes H by at least gap and at most
-// match - gap, so 0 <= Xr <= (match - 2 gap) * 64 CM whatever the gap length - 4 Xr + 3 < 2^16 for 512 columns per wave with the reference's
-// scores (poa_pk16_ok). No gap-length limit, no int32 fallback for long gaps. Recurrences in this frame, dq = 4 (B[p] - B[i]) <= -4 gap for every
-// predecessor p: the constants carry + (-4 gap), and (-4 gap) - dq >= 0 is SUBTRACTED with unsigned saturation - exact wherever the result can
-// matter, "nothing" (below every finished key) for a predecessor far below this row, whatever the distance; nothing else can leave the range:
-//       diagonal    K = Kp[j-1] + 4 (s - gap) + 3 + dq            (stored rows are masked: low bits 0)
-//       vertical    K = Kp[j]   + 4 gap + 2 + dq
-//       horizontal  K = (K[j-1] & ~3)                              (type 0; Xr does not change along a horizontal move: a prefix maximum)
-// One max() per decision keeps the reference's tie order diagonal > vertical > horizontal; among predecessors the first in in-edge order
-// wins (a strict packed comparison moves the slot - only rows with several predecessors pay for slots). The per-letter score registers of a
-// lane come from a small LDS table written once per sequence (one ds_read per row). Checked cell by cell against the plain recurrence on
-// POA-shaped DAGs by tools/dev_pk16_model.cpp (the same arithmetic, instruction by instruction, on the CPU).
-// ---------------------------------------------------------------------------------------------------
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b))); }
-__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }   // v_pk_sub_u16 clamp
-__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
-__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
-__device__ __forceinline__ uint32_t pk_mul(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b))); }
-// (the same instruction behind an asm: min(a -sat b, 1) is otherwise rewritten into two 16-bit compares, two selects and a permute)
-__device__ __forceinline__ uint32_t pk_subs_opaque(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ uint32_t pk_dup(int v) { return ((uint32_t)v & 0xffffu) * 0x00010001u; }
-
-constexpr int PK_OFF = 512;                         // key of Xr = 0, type 0 (keys are UNSIGNED 16-bit numbers): everything a row keeps is >= this, 0 = "nothing"
-constexpr uint32_t PK_MASK = 0xfffcfffcu;           // the score part of both halves
-
-template <int CM>
-__device__ __forceinline__ void dp_rows16(const G& g, uint32_t* __restrict__ Hp, uint8_t* __restrict__ D, uint8_t* __restrict__ Dwide, const uint32_t W, const uint32_t WH, const uint8_t* __restrict__ seq,
-                        const uint32_t L_, const uint32_t V_, int32_t* ring, const uint32_t R_, const uint32_t ring_w_, uint32_t* tbl, const int match, const int mismatch, const int gap,
-                        unsigned long long* wm_box, uint32_t* wm_cons, uint32_t* sink_row, int* sink_score, const uint32_t sink_cap, uint32_t& nSinkOut, const DpCl& cl, unsigned long long* prof) {
-    static_assert(CM == 4 || CM == 8, "packed rows: 4 or 8 columns per lane");
-    constexpr int h = CM / 2;
-    const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)L_), V = (uint32_t)__builtin_amdgcn_readfirstlane((int)V_);
-    const uint32_t R = (uint32_t)__builtin_amdgcn_readfirstlane((int)R_), ring_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)ring_w_);
-    const uint32_t tid = threadIdx.x, NT = blockDim.x, lane = tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), NW = cl.lanes >> 6;
-    const uint32_t ncol = L + 1;
-    constexpr uint32_t RELAY_BOX = MAX_WAVES - 2;
-    const bool relay_mode = NT == 1024u && NW + 2u <= 16u && cl.mem > 0;
-    if (wv >= NW) {                                                           // (a wave of a wide member that sits the DP out; wave NW + 1 relays the carries: see dp_rows)
-        if (relay_mode && wv == NW + 1u && (uint64_t)(cl.mem * NW) * 64u * CM < ncol) {
-            const unsigned long long* src = cl.mbox + (uint64_t)(cl.mem - 1) * cl.stride;
-            unsigned long long* dst = wm_box + (size_t)RELAY_BOX * WAVE_MBOX;
-            const uint32_t* cons = wm_cons + RELAY_BOX;
-            bool dead = false;
-            for (uint32_t ib = 0; ib < V; ib += 64) {
-                const uint32_t ie = min(64u, V - ib);
-                for (uint32_t rb = 0; rb < ie; rb += CARRY_BATCH) {
-                    const uint32_t nb = min(CARRY_BATCH, ie - rb), i0 = ib + rb + 1;
-                    unsigned long long v = (unsigned long long)(cl.tag0 + i0 + lane);
-                    for (uint32_t spin = 0; !dead; spin++) {
-                        bool ok = true;
-                        if (lane < nb) { v = ld_dev64(src + i0 + lane); ok = (uint32_t)v == cl.tag0 + i0 + lane; }
-                        if (__ballot(ok) == ~0ull) break;
-                        if (spin > cl.poll_limit) { if (lane == 0) st_dev(cl.err, 1u); dead = true; v = (unsigned long long)(cl.tag0 + i0 + lane); break; }
-                        __builtin_amdgcn_s_sleep(8);
-                    }
-                    const uint32_t need = i0 + nb - 1 > WAVE_MBOX ? cl.tag0 + i0 + nb - 1 - WAVE_MBOX : 0;
-                    for (uint32_t spin = 0; need; spin++) {
-                        const uint32_t got = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_wg(cons));
-                        if ((int32_t)(got - need) >= 0) break;
-                        if (spin > WG_POLL_LIMIT) { if (lane == 0) st_dev(cl.err, 2u); break; }
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                    if (lane < nb) st_wg64(dst + ((i0 + lane) & (WAVE_MBOX - 1)), v);
-                }
-            }
-        }
-        return;
-    }
-    const uint32_t gw = cl.mem * NW + wv;                                     // this wave's place in the edge's pipeline
-    if ((uint64_t)gw * 64u * CM >= ncol) return;                              // the wave owns no real column of this sequence
-    const uint32_t gt = gw * 64u + lane;
-    const bool has_in = gw > 0;
-    const bool in_lds = wv > 0 || relay_mode;
-    const bool has_out = (uint64_t)(gw + 1) * 64u * CM < ncol;
-    const bool out_lds = wv + 1 < NW;
-    const unsigned long long* mb_in_h = cl.mbox + (uint64_t)(cl.mem ? cl.mem - 1 : 0) * cl.stride;
-    unsigned long long* mb_out_h = cl.mbox + (uint64_t)cl.mem * cl.stride;
-    const unsigned long long* mb_in_l = wm_box + (size_t)(wv ? wv - 1 : relay_mode ? RELAY_BOX : 0) * WAVE_MBOX;
-    unsigned long long* mb_out_l = wm_box + (size_t)wv * WAVE_MBOX;
-    uint32_t* cons_in = wm_cons + (wv ? wv - 1 : relay_mode ? RELAY_BOX : 0);
-    const uint32_t* cons_out = wm_cons + wv;
-    if (has_in && in_lds && lane == 0) st_wg(cons_in, cl.tag0);
-    const uint32_t* farslot = reinterpret_cast<const uint32_t*>(g.pred);
-    const uint32_t* wideslot = g.wslot;
-    const uint32_t j0 = gt * CM, c0 = gw * 64u * CM;
-    const bool live = j0 <= L;
-    const bool owns_last = live && L < j0 + CM;
-    const uint32_t klast = owns_last ? L - j0 : 0;
-    const uint32_t hleft = (W >> 1) + gw;            // a far row: packed keys in the first W / 2 words (live chunks end below W, a multiple of the chunk), then one word per wave: 4 B of the row in that wave
-                                                     // (NOT at W + gw like dp_rows: a one-wave edge has no extra words behind W, and unlike there the word is written by every wave)
-    const int g4 = 4 * gap;
-    const int Bq0 = g4 * ((int)c0 - 1);              // 4 B of the virtual row 0 in this wave
-    const uint32_t OFF2 = pk_dup(PK_OFF);
-    // "the column left of lane 0": the wave's left edge (Xr = 0) - or, in the first wave of the edge, nothing at all. In the HIGH half (v_alignbit takes it from there).
-    const uint32_t fillw = gw == 0 ? 0u : OFF2 & 0xffff0000u;
-    const uint32_t cV = pk_dup(2);                  // vertical move: 4 gap + 2, plus the -4 gap every candidate carries until the frame shift is taken off
-    // ---- per-letter score registers of this lane, in LDS: entry of letter a at tbl_me + a * 64 * h (h dwords, one ds_read per row)
-    uint32_t* tbl_me = tbl + wv * (256u * h) + lane * h;
-    {
-        const int cm_ = 4 * (match - 2 * gap) + 3, cx_ = 4 * (mismatch - 2 * gap) + 3;   // diagonal move: 4 (s - gap) + 3, plus the -4 gap (see cV)
-        uint32_t b[CM];
-#pragma unroll
-        for (int k = 0; k < CM; k++) { const uint32_t j = j0 + k; b[k] = (j >= 1 && j < ncol) ? (uint32_t)seq[j - 1] : 4u; }   // (columns without a base never match)
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int q = 0; q < h; q++)
-                tbl_me[a * 64 * h + q] = ((uint32_t)(b[q] == (uint32_t)a ? cm_ : cx_) & 0xffffu) | ((uint32_t)(b[q + h] == (uint32_t)a ? cm_ : cx_) << 16);
-    }
-    constexpr uint32_t PW = 65u;
-    int32_t* const ring_me = ring + wv * (65u * h) + lane;       // per wave: h planes of 65 words, register q of lane t at word 65 q + 1 + t; word 0 of the LAST plane = the fill
-    if (lane == 0) for (uint32_t sl_ = 0; sl_ < R; sl_++) ring_me[sl_ * ring_w + (h - 1) * PW] = (int32_t)fillw;
-    uint32_t nsink = 0;
-    uint32_t mC = 0, aC = 0, bC = 0, oC = 0, cC = 0, dC = 0, fC = 0, mN = 0, aN = 0, bN = 0, oN = 0, cN = 0, dN = 0, fN = 0, mF = 0, aF = 0, bF = 0, oF = 0;
-    auto fetch = [&](uint32_t base, uint32_t& m, uint32_t& a, uint32_t& b, uint32_t& o) {
-        const uint32_t r = base + lane;
-        if (r < V) { m = g.row_meta[r]; a = g.row_pred0[r]; b = g.row_pred1[r]; o = g.row_pred_off[r]; }
-    };
-    auto fetch_more = [&](uint32_t base, uint32_t m, uint32_t o, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d, uint32_t& f) {
-        if (base + lane < V) {
-            if ((m >> META_NP) > 2u) c = g.pred_rank[o + 2];
-            if ((m >> META_NP) > 3u) d = g.pred_rank[o + 3];
-            if ((a >> 28) == 15u) a = 0xf0000000u | farslot[a & 0x0fffffffu];
-            if ((b >> 28) == 15u && (m >> META_NP) > 1u) b = 0xf0000000u | farslot[b & 0x0fffffffu];
-            if (m & 8u) f = farslot[base + lane];
-        }
-    };
-    fetch(0, mN, aN, bN, oN);
-    fetch(64, mF, aF, bF, oF);
-    fetch_more(0, mN, oN, aN, bN, cN, dN, fN);
-    uint8_t* drow = D;
-    uint32_t tp[h];                          // the previous row's finished keys (masked) under this lane
-#pragma unroll
-    for (int q = 0; q < h; q++) tp[q] = OFF2;
-    int Bprev = Bq0;                         // 4 B of the previous row
-    uint32_t Bslots = 0;                     // lane s: 4 B of the row in ring slot s
-    // 4 B of predecessor `ent` (wave-uniform)
-    auto pred_B = [&](const uint32_t ent, const bool slot_known) -> int {
-        const uint32_t loc = ent >> 28;
-        if (loc == 13u) return Bprev;
-        if (loc < 13u) return __builtin_amdgcn_readlane((int)Bslots, (int)(loc - 1));
-        if (loc == 14u) return Bq0;
-        const uint32_t hr = slot_known ? ent & 0x0fffffffu : farslot[ent & 0x0fffffffu];
-        return __builtin_amdgcn_readfirstlane((int)Hp[(uint64_t)hr * WH + hleft]);
-    };
-    // predecessor row `ent`: its registers under this lane, the register of the lane on the left that holds the column left of this lane's first (high half), its 4 B
-    auto pred_row = [&](const uint32_t ent, uint32_t (&hp)[h], uint32_t& nbw, int& Bp, const bool slot_known) {
-        const uint32_t loc = ent >> 28;
-        if (__builtin_expect(loc == 13u, 1)) {
-#pragma unroll
-            for (int q = 0; q < h; q++) hp[q] = tp[q];
-            nbw = (uint32_t)wave_shift_up1((int)tp[h - 1], (int)fillw);
-            Bp = Bprev;
-        } else if (__builtin_expect(loc < 13u, 1)) {
-            const int32_t* S = ring_me + (size_t)(loc - 1) * ring_w;
-#pragma unroll
-            for (int q = 0; q < h; q++) hp[q] = (uint32_t)S[q * PW + 1];
-            nbw = (uint32_t)S[(h - 1) * PW];
-            Bp = __builtin_amdgcn_readlane((int)Bslots, (int)(loc - 1));
-        } else if (loc == 14u) {
-#pragma unroll
-            for (int q = 0; q < h; q++) hp[q] = OFF2;
-            nbw = lane ? OFF2 : fillw;
-            Bp = Bq0;
-        } else {
-            const uint32_t hr = slot_known ? ent & 0x0fffffffu : farslot[ent & 0x0fffffffu];
-            const uint32_t* Gp = Hp + (uint64_t)hr * WH;
-            Bp = __builtin_amdgcn_readfirstlane((int)Gp[hleft]);
-            if (live) {
-#pragma unroll
-                for (int q = 0; q < h; q++) hp[q] = Gp[gt * h + q];
-                nbw = lane ? Gp[gt * h - 1] : fillw;
-            } else {
-#pragma unroll
-                for (int q = 0; q < h; q++) hp[q] = OFF2;
-                nbw = OFF2;
-            }
-#pragma unroll
-            for (int q = 0; q < h; q++) asm volatile("" : "+v"(hp[q]));   // consumed here: see dp_rows
-            asm volatile("" : "+v"(nbw));
-        }
-    };
-    auto pack_dq = [&](int dq) -> uint32_t {   // dq = 4 (B[p] - B[i]) <= -4 gap: what is taken off a candidate that carries -4 gap, both halves
-        return pk_dup(min(-g4 - dq, 65535));
-    };
-    for (uint32_t ib = 0; ib < V; ib += 64) {
-        mC = mN; aC = aN; bC = bN; oC = oN; cC = cN; dC = dN; fC = fN;
-        mN = mF; aN = aF; bN = bF; oN = oF;
-        fetch(ib + 128, mF, aF, bF, oF);
-        fetch_more(ib + 64, mN, oN, aN, bN, cN, dN, fN);
-        const uint32_t ie = min(64u, V - ib);
-        for (uint32_t rb = 0; rb < ie; rb += CARRY_BATCH) {
-            const uint32_t nb = min(CARRY_BATCH, ie - rb), i0 = ib + rb + 1;
-            int cinV = 0;        // lane r: 4 B of row i0 + r in this wave = 4 x the finished score of the last column of the wave on the left
-            if (has_in) {
-#ifdef HX_DP_PROF3
-                const long long tw0 = clock64();
-#endif
-                for (uint32_t spin = 0;; spin++) {
-                    unsigned long long v = 0;
-                    bool ok = true;
-                    if (lane < nb) {
-                        v = in_lds ? ld_wg64(mb_in_l + ((i0 + lane) & (WAVE_MBOX - 1))) : ld_dev64(mb_in_h + i0 + lane);
-                        ok = (uint32_t)v == cl.tag0 + i0 + lane;
-                    }
-                    if (__ballot(ok) == ~0ull) { cinV = (int)(uint32_t)(v >> 32); break; }
-                    if (spin > (in_lds ? WG_POLL_LIMIT : cl.poll_limit)) { if (lane == 0) st_dev(cl.err, in_lds ? 2u : 1u); break; }
-                    if (in_lds) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(8);
-                }
-                if (in_lds && lane == 0) st_wg(cons_in, cl.tag0 + i0 + nb - 1);
-#ifdef HX_DP_PROF3
-                if (tid == 0) prof[0] += (unsigned long long)(clock64() - tw0);
-#endif
-            }
-            if (has_out && out_lds) {
-                const uint32_t need = i0 + nb - 1 > WAVE_MBOX ? cl.tag0 + i0 + nb - 1 - WAVE_MBOX : 0;
-                for (uint32_t spin = 0; need; spin++) {
-                    const uint32_t got = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_wg(cons_out));
-                    if ((int32_t)(got - need) >= 0) break;
-                    if (spin > WG_POLL_LIMIT) { if (lane == 0) st_dev(cl.err, 2u); break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            }
-            for (uint32_t rj = 0; rj < nb; rj++) {
-                const uint32_t ri = rb + rj, i = ib + ri + 1;
-                const uint32_t meta = __builtin_amdgcn_readlane(mC, ri), p0 = __builtin_amdgcn_readlane(aC, ri);
-                const uint32_t npred = meta >> META_NP;
-                // the lane's score registers for this row's letter
-                uint32_t sc[h];
-                {
-                    const uint32_t* T = tbl_me + (meta & 3u) * (64u * h);
-                    if constexpr (h == 4) { const uint4 x = *reinterpret_cast<const uint4*>(T); sc[0] = x.x; sc[1] = x.y; sc[2] = x.z; sc[3] = x.w; }
-                    else { const uint2 x = *reinterpret_cast<const uint2*>(T); sc[0] = x.x; sc[1] = x.y; }
-                }
-                drow += W >> 1;
-                const uint32_t po = __builtin_amdgcn_readlane(oC, ri);
-                // 4 B of this row: handed over by the wave on the left - or (first wave) the best predecessor's + gap
-                int Bi;
-                if (has_in) Bi = __builtin_amdgcn_readlane(cinV, rj);
-                else {
-                    Bi = pred_B(p0, true);
-                    if (__builtin_expect(npred > 1, 0))
-                        for (uint32_t p = 1; p < npred; p++) {
-                            const uint32_t ent = p == 1 ? __builtin_amdgcn_readlane(bC, ri) : p == 2 ? __builtin_amdgcn_readlane(cC, ri) : p == 3 ? __builtin_amdgcn_readlane(dC, ri)
-                                                        : (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[po + p]);
-                            Bi = max(Bi, pred_B(ent, p == 1));
-                        }
-                    Bi += g4;
-                }
-                uint32_t m[h], sl[h];
-                {   // the first predecessor (or row 0)
-                    uint32_t hp[h], nbw; int Bp;
-                    pred_row(p0, hp, nbw, Bp, true);
-                    const uint32_t dpk = pack_dq(Bp - Bi);
-                    const uint32_t d0 = __builtin_amdgcn_alignbit(hp[h - 1], nbw, 16);   // low: the column left of this lane's first, high: the column left of register 0's high column
-#pragma unroll
-                    for (int q = 0; q < h; q++) m[q] = pk_subs(pk_max(pk_add(q ? hp[q - 1] : d0, sc[q]), pk_add(hp[q], cV)), dpk);
-                }
-                if (__builtin_expect(npred > 1, 0)) {
-#pragma unroll
-                    for (int q = 0; q < h; q++) sl[q] = 0;
-                    for (uint32_t p = 1; p < npred; p++) {
-                        const uint32_t ent = p == 1 ? __builtin_amdgcn_readlane(bC, ri) : p == 2 ? __builtin_amdgcn_readlane(cC, ri) : p == 3 ? __builtin_amdgcn_readlane(dC, ri)
-                                                    : (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[po + p]);
-                        uint32_t hp[h], nbw; int Bp;
-                        pred_row(ent, hp, nbw, Bp, p == 1);
-                        const uint32_t dpk = pack_dq(Bp - Bi), ppk = p * 0x00010001u;
-                        const uint32_t d0 = __builtin_amdgcn_alignbit(hp[h - 1], nbw, 16);
-#pragma unroll
-                        for (int q = 0; q < h; q++) {
-                            const uint32_t cand = pk_subs(pk_max(pk_add(q ? hp[q - 1] : d0, sc[q]), pk_add(hp[q], cV)), dpk);
-                            const uint32_t gt_ = pk_min(pk_subs_opaque(cand, m[q]), 0x00010001u);   // 1 where this predecessor is strictly better (higher score, or the same score by a diagonal against a vertical move)
-                            sl[q] = pk_max(sl[q], pk_mul(gt_, ppk));
-                            m[q] = pk_max(m[q], cand);
-                        }
-                    }
-                }
-                // prefix maximum over the lane's columns (both halves at once, then the low chain's total into the high halves)
-                uint32_t r[h];
-                r[0] = m[0];
-#pragma unroll
-                for (int q = 1; q < h; q++) r[q] = pk_max(m[q], r[q - 1]);
-                const uint32_t clo = r[h - 1] << 16;
-#pragma unroll
-                for (int q = 0; q < h; q++) r[q] = pk_max(r[q], clo);
-                // prefix maximum over the lanes to the left (score parts of the chunk ends), starting from the wave's left edge (Xr = 0)
-                const int inc = wave_incl_max((int)(r[h - 1] >> 16) & ~3);
-                const int E = max(wave_shift_up1(inc, PK_OFF), PK_OFF);
-                if (has_out) {   // 4 x the finished score of this wave's last column = 4 B of the row in the wave on the right (lane 63 holds it)
-                    const int Bnext = Bi + (max(inc, PK_OFF) - PK_OFF) + g4 * (64 * CM);
-                    const unsigned long long e = (unsigned long long)(cl.tag0 + i) | ((unsigned long long)(uint32_t)Bnext << 32);
-                    if (out_lds) { if (lane == 63) st_wg64(mb_out_l + (i & (WAVE_MBOX - 1)), e); }
-                    else if (lane == 63) st_dev64(mb_out_h + i, e);
-                }
-                const uint32_t Epk = pk_dup(E);
-                uint32_t K[h];
-#pragma unroll
-                for (int q = 0; q < h; q++) {
-                    const uint32_t sh = q ? r[q - 1] : (clo | (uint32_t)E);   // the finished prefix left of the register's two columns inside the lane
-                    K[q] = pk_max(m[q], pk_max(sh, Epk) & PK_MASK);   // the horizontal move: type 0 here (the lowest key of its score; the traceback takes 0 and 1 for horizontal)
-                }
-#pragma unroll
-                for (int q = 0; q < h; q++) tp[q] = K[q] & PK_MASK;
-                Bprev = Bi;
-                const uint32_t slot = (meta >> META_SLOT) & 15u;
-                if (slot != 15u) {   // a kept row goes to its ring slot
-                    int32_t* S = ring_me + slot * ring_w;
-#pragma unroll
-                    for (int q = 0; q < h; q++) S[q * PW + 1] = (int32_t)tp[q];
-                    Bslots = lane == slot ? (uint32_t)Bi : Bslots;
-                }
-                if (__builtin_expect(live, 1)) {
-                    // move nibbles: type * 4 + 3 - predecessor slot, column k of the lane in nibble k of its CM / 2 bytes
-                    uint32_t ty, sq = 0;
-                    if constexpr (h == 4) {
-                        const uint32_t a = (K[0] & 0x00030003u) | ((K[1] << 4) & ~0x00030003u), b = (K[2] & 0x00030003u) | ((K[3] << 4) & ~0x00030003u);
-                        ty = __builtin_amdgcn_perm(b, a, 0x06020400u);        // bytes: columns (0,1) (2,3) (4,5) (6,7); what is not a type bit is overwritten below
-                    } else {
-                        const uint32_t a = (K[0] & 0x00030003u) | ((K[1] << 4) & ~0x00030003u);
-                        ty = __builtin_amdgcn_perm(a, a, 0x0c0c0200u);
-                    }
-                    uint32_t nib = (ty << 2) | 0x33333333u;
-                    if (__builtin_expect(npred > 1, 0)) {
-                        if constexpr (h == 4) sq = __builtin_amdgcn_perm(sl[2] | (sl[3] << 4), sl[0] | (sl[1] << 4), 0x06020400u);
-                        else { const uint32_t a = sl[0] | (sl[1] << 4); sq = __builtin_amdgcn_perm(a, a, 0x0c0c0200u); }
-                        nib -= sq & 0x33333333u;   // (slots above 3 belong to a wide row, whose nibbles nobody reads)
-                    }
-                    if constexpr (h == 4) *reinterpret_cast<uint32_t*>(drow + (j0 >> 1)) = nib;
-                    else *reinterpret_cast<uint16_t*>(drow + (j0 >> 1)) = (uint16_t)nib;
-                    if (__builtin_expect((meta & 32u) != 0, 0)) {   // wide row: a byte per cell, type * 16 + 15 - slot
-                        uint8_t* wp = Dwide + (uint64_t)wideslot[i - 1] * W + j0;
-                        uint32_t wb[h];
-#pragma unroll
-                        for (int q = 0; q < h; q++) wb[q] = ((K[q] & 0x00030003u) << 4) + 0x000f000fu - sl[q];   // byte 0: column q, byte 2: column q + h
-                        if constexpr (h == 4) {
-                            const uint32_t x01 = __builtin_amdgcn_perm(wb[1], wb[0], 0x06020400u), x23 = __builtin_amdgcn_perm(wb[3], wb[2], 0x06020400u);   // bytes: q0.lo q1.lo q0.hi q1.hi
-                            *reinterpret_cast<uint2*>(wp) = make_uint2(__builtin_amdgcn_perm(x23, x01, 0x05040100u), __builtin_amdgcn_perm(x23, x01, 0x07060302u));
-                        } else *reinterpret_cast<uint32_t*>(wp) = __builtin_amdgcn_perm(wb[1], wb[0], 0x06020400u);
-                    }
-                }
-                if (__builtin_expect((meta & (8u | 4u)) != 0, 0)) {
-                    if (meta & 8u) {   // a far successor reads this row back from HBM
-                        const uint32_t fslot = __builtin_amdgcn_readlane(fC, ri);   // (read where every lane is active: see dp_rows)
-                        uint32_t* F = Hp + (uint64_t)fslot * WH;
-                        if (live) {
-#pragma unroll
-                            for (int q = 0; q < h; q++) F[gt * h + q] = tp[q];
-                        }
-                        if (lane == 0) F[hleft] = (uint32_t)Bi;
-                    }
-                    if (owns_last && (meta & 4u)) {   // sink node: candidate end of the global alignment
-                        uint32_t kk = 0;
-#pragma unroll
-                        for (int q = 0; q < h; q++) { if ((uint32_t)q == klast) kk = K[q] & 0xffffu; if ((uint32_t)(q + h) == klast) kk = K[q] >> 16; }
-                        const int key = (int)kk;
-                        if (nsink < sink_cap) { sink_row[nsink] = i; sink_score[nsink] = ((key - PK_OFF) >> 2) + (Bi >> 2) + gap * (int)(L - c0 + 1); }
-                        nsink++;
-                    }
-                }
-            }
-        }
-    }
-    if (owns_last) nSinkOut = nsink;
+    if constexpr (PRUNE) { if (lane == 0 && pstat) { atomicAdd(&pstat[0], (unsigned long long)V); atomicAdd(&pstat[1], (unsigned long long)n_dead); } }
 }
 
 // One kernel per (largest workgroup, columns per lane, traceback flavour): the register budget of a launch is that of ITS row loop, so the
 // many short gaps (one wavefront, 4-8 columns per lane) run with a fraction of the registers - and several times the waves per SIMD - of
 // the few long ones; sequences shorter than the edge's longest leave the upper lanes / waves of the pipeline idle.
-template <int MAXNT, int CM, bool DIR, bool PK>
+template <int MAXNT, int CM, bool DIR, bool PRUNE>
 __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem, const PoaSlot SL, const PoaEdge* __restrict__ edges,
                                          const PoaSeq* __restrict__ seqs, const uint8_t* __restrict__ packed, const uint64_t* __restrict__ read_off,
                                          const uint32_t* __restrict__ read_len, const PoaPools& P, int32_t match, int32_t mismatch, int32_t gap,
                                          char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells, unsigned long long* phase,
-                                         uint32_t poll_limit, uint32_t lds_bytes, uint32_t max_indeg, uint32_t dp_lanes) {
-    __shared__ unsigned long long ph[12];            // lane-0 cycle counts: decode, dp, traceback, graph update, toposort, csr; then row statistics
+                                         uint32_t poll_limit, uint32_t lds_bytes, uint32_t max_indeg, uint32_t dp_lanes, uint32_t prune_pct) {
+    __shared__ unsigned long long ph[POA_PHASE_WORDS];   // lane-0 cycle counts: decode, dp, traceback, graph update, toposort, csr; then row statistics (6-11) and the pruning's (12-15)
     __shared__ long long tc;
-    if (threadIdx.x == 0) { for (int k = 0; k < 12; k++) ph[k] = 0; tc = clock64(); }
+    if (threadIdx.x == 0) { for (int k = 0; k < POA_PHASE_WORDS; k++) ph[k] = 0; tc = clock64(); }
 #define PHASE(k) do { if (tid == 0) { long long _n = clock64(); ph[k] += (unsigned long long)(_n - tc); tc = _n; } } while (0)
 #ifdef HX_GU_PROF   // development: where the graph update (slots 6-10) and the CSR rebuild (slot 11: its first half) spend their cycles - printed by HX_PROF2 (its labels are the DP's)
 #define GU_T0() do { __syncthreads(); if (tid == 0) tg = clock64(); } while (0)
@@ -1511,15 +1213,13 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     uint8_t* Dw = DIR ? P.dirw + SL.w_off : nullptr;  // direction bytes of the rows with more than 4 predecessors: ED.wrows rows of W
     // ring geometry is a property of the edge (its longest sequence) and of the launch
     const uint32_t GM = ED.members;                  // workgroups sharing this edge's DP columns
-    static_assert(!PK || (DIR && (CM == 4 || CM == 8)), "packed 16-bit rows: direction-byte traceback, 4 or 8 columns per lane");
-    const uint32_t ring_w = (PK ? CM / 2 : CM) * (DL >> 6) * 65u;    // planes of 65 words per wave: one per column (dp_rows) or per packed pair of columns (dp_rows16)
-    const uint32_t tbl_bytes = PK ? (DL >> 6) * 256u * (CM / 2) * 4u : 0u;   // packed rows: the per-letter score registers of every lane (dp_rows16), behind the ring
+    const uint32_t ring_w = CM * (DL >> 6) * 65u;    // planes of 65 words per wave: one per column (dp_rows)
     // kept rows the LDS ring holds for THIS edge: what fits the launch's LDS at the edge's own row width (a launch serves edges of several
     // widths; the host sizes the LDS for the widest), a power of two (slot = kept-row counter & (R - 1)). Only rows with a non-adjacent
     // reader go there (the previous row is read from registers), so every slot holds a kept row.
     uint32_t R = 0;
     {
-        const uint32_t fit = lds_bytes > tbl_bytes ? (lds_bytes - tbl_bytes) / (ring_w * 4u) : 0u;
+        const uint32_t fit = lds_bytes / (ring_w * 4u);
         R = fit >= 8 ? 8 : fit >= 4 ? 4 : fit >= 2 ? 2 : 0;   // (0: rows too wide for two of them - every kept row is read back from HBM)
         if (fit < 1) R = 0xffffffffu;
     }
@@ -1538,7 +1238,8 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     __shared__ int sink_score[SINK_LDS];
     __shared__ uint32_t sCtl;
     __shared__ unsigned long long sCells;   // DP cells of this edge (reported only when the edge completes: retried edges count once)
-    if (tid == 0) { sV = 0; sE = 0; sOk = R != 0xffffffffu ? 1 : 2; sCells = 0; }   // (the host gives every launch LDS for at least the latest row)
+    __shared__ int sPrevScore, sNewT; __shared__ uint32_t sPrevLen, sRetry;   // PRUNE: score and length of the edge's previous alignment (the source of the threshold), the verdict on an attempt
+    if (tid == 0) { sV = 0; sE = 0; sOk = R != 0xffffffffu ? 1 : 2; sCells = 0; sPrevScore = 0; sPrevLen = 0; sRetry = 0; sNewT = PRUNE_OFF; }   // (the host gives every launch LDS for at least the latest row)
     if constexpr (MAXNT > 64) {
         for (uint32_t q = tid; q < (MAXNT / 64 - 1) * WAVE_MBOX; q += NT) wmail.box[q] = 0ull;   // tag 0 = nothing published
         if (tid < MAXNT / 64) wmail.consumed[tid] = 0u;
@@ -1550,10 +1251,9 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     cl.mem = mem; cl.members = GM; cl.stride = ED.vcap + 1; cl.tag0 = 0;
     cl.mbox = P.mbox + ED.cl_off; cl.err = csy + 4; cl.poll_limit = poll_limit; cl.lanes = DL;
     constexpr uint32_t CL_ABORT = 0xffffffffu;
-#define HX_DP_DISPATCH(Lq, Vq, nsq) do { \
+#define HX_DP_DISPATCH(Lq, Vq, nsq, Tq) do { \
         if (((Lq) + 1 + GM * DL - 1) / (GM * DL) <= (uint32_t)CM) {    /* the host puts an edge into a launch whose columns per lane hold its longest sequence */ \
-            if constexpr (PK) dp_rows16<CM>(g, reinterpret_cast<uint32_t*>(H), Dm, Dw, W, WH, seq, Lq, Vq, ring, R, ring_w, reinterpret_cast<uint32_t*>(ring) + (size_t)R * ring_w, match, mismatch, gap, wmail.box, wmail.consumed, sink_row, sink_score, SINK_LDS, nsq, cl, ph + 6); \
-            else dp_rows<CM, DIR>(g, H, Dm, Dw, W, WH, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, wmail.box, wmail.consumed, sink_row, sink_score, SINK_LDS, nsq, cl, ph + 6); \
+            dp_rows<CM, DIR, PRUNE>(g, H, Dm, Dw, W, WH, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, wmail.box, wmail.consumed, sink_row, sink_score, SINK_LDS, nsq, cl, ph + 6, Tq, ph + 12); \
         } else sOk = 2; } while (0)
     // The reference's topological order (spoa's DFS, inherently serial) is needed in two places only: to break ties between equally scored
     // end nodes of an alignment, and for the heaviest-bundle traversal of the finished graph. The DP itself runs on a cheaper order that
@@ -1631,15 +1331,28 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
         }
         // =================================================== DP over (rank, column): every member, its own columns
         if (mem == 0) SUBT(6);   // publish
+        // PRUNE: the threshold of this alignment = what the previous one of the edge scored per base, on this length, x prune_pct / 100 (scores per
+        // base rise as the graph turns into a consensus, so this errs low). Too high an estimate costs a second attempt, never a wrong result: the
+        // best sink of a pruned matrix is a real path's score, and an attempt that stays below its threshold is repeated with exactly that score.
+        int thrT = PRUNE_OFF;
+        if constexpr (PRUNE) {
+            if (GM == 1 && prune_pct != 0u && sPrevLen != 0u && V < (1u << 20)) {   // (2^20 rows: "nothing" keys lose at most a vertical move per row and must not wrap)
+                const float f = (float)prune_pct * 0.01f;
+                float e = (float)sPrevScore * (float)L / (float)sPrevLen;
+                e = e >= 0.f ? e * f : e * (2.f - f);
+                thrT = (int)fmaxf((float)PRUNE_OFF, floorf(e));
+            }
+        }
+    redo_dp:
         if (V > 0) {
             uint32_t ns = 0xffffffffu;
 #ifdef HX_DP_PROF3
             const long long td0 = clock64();
             if (tid == 0) ph[6] = 0;
 #endif
-            HX_DP_DISPATCH(L, V, ns);
+            HX_DP_DISPATCH(L, V, ns, thrT);
 #ifdef HX_DP_PROF3
-            if (tid == 0 && phase) atomicAdd(&phase[(uint64_t)eidx * 12 + 6 + min(mem, 5u)], ((ph[6] >> 10) << 32) | ((unsigned long long)(clock64() - td0) >> 10));
+            if (tid == 0 && phase) atomicAdd(&phase[(uint64_t)eidx * POA_PHASE_WORDS + 6 + min(mem, 5u)], ((ph[6] >> 10) << 32) | ((unsigned long long)(clock64() - td0) >> 10));
 #endif
             if (ns != 0xffffffffu) sNsink = ns;   // written by the lane that owns column L
             cl.tag0 += V;
@@ -1692,6 +1405,11 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                 for (uint32_t q = 0; q < nsk; q++) if (sink_score[q] > best) best = sink_score[q];
                 for (uint32_t q = 0; q < nsk; q++) if (sink_score[q] == best) { if (!ncand) first = q; sink_row[ncand++] = sink_row[q]; }   // compact candidates to the front
                 (void)first;
+                if constexpr (PRUNE) {   // did the alignment reach its threshold? (else: again, with the score it did reach - a real path's - or, no sink computed at all, unpruned)
+                    sRetry = thrT > PRUNE_OFF && sOk == 1 && best < thrT;
+                    if (sRetry) { sNewT = nsk ? max(best, PRUNE_OFF) : PRUNE_OFF; ph[14]++; }
+                    else { sPrevScore = best; sPrevLen = L; ph[15] += thrT > PRUNE_OFF; }
+                }
                 sNcand = ncand; sBestI = ncand ? (int)sink_row[0] : -1; sBestKey = 0xffffffffu;
                 lds_u[8] = 0; lds_u[9] = 0; lds_u[10] = 0;   // (traceback helper: nowhere yet, not done)
                 // Ties (a quarter of all alignments have one): the winner is the candidate the REFERENCE's topological order lists first. That order is a DFS
@@ -1704,7 +1422,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                 // few letters seen at the end of the gap (at most 8 nodes in 99.7 %, never above 32 on the three committed SPOA input sets: 1 267 ties,
                 // every one decided like the full sort - the oracle's ORC_POA_TIES statistic runs the same simulation on the CPU).
                 // One lane; ids, marks and the stack sit in the LDS the ring has left. More than 32 nodes / 8 candidates: the full sort below.
-                if (ncand > 1 && ncand <= 8 && lds_bytes >= 640u) {
+                if (ncand > 1 && ncand <= 8 && lds_bytes >= 640u && !(PRUNE && sRetry)) {
                     constexpr uint32_t UCAP = 32, SCAP = 256;
                     uint32_t* U = reinterpret_cast<uint32_t*>(ring);
                     uint8_t* mk = reinterpret_cast<uint8_t*>(U + UCAP);
@@ -1766,6 +1484,14 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                 }
             }
             __syncthreads();
+            if constexpr (PRUNE) {
+                if (sRetry) {   // (uniform: every thread reads the same word after the barrier)
+                    thrT = sNewT;
+                    __syncthreads();
+                    if (tid == 0) sRetry = 0;
+                    goto redo_dp;
+                }
+            }
             if (sNcand > 1 && sOk == 1) {
                 if (tid == 0) ph[10] += 1;
                 exact_order(V, tmp_u32);
@@ -2276,9 +2002,9 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
         }
         PHASE(3);
 #ifdef HX_DP_PROF3
-        if (phase) for (int k = 0; k < 6; k++) phase[(uint64_t)eidx * 12 + k] = ph[k];
+        if (phase) for (int k = 0; k < 6; k++) phase[(uint64_t)eidx * POA_PHASE_WORDS + k] = ph[k];
 #else
-        if (phase) for (int k = 0; k < 12; k++) phase[(uint64_t)eidx * 12 + k] = ph[k];
+        if (phase) for (int k = 0; k < POA_PHASE_WORDS; k++) phase[(uint64_t)eidx * POA_PHASE_WORDS + k] = ph[k];
 #endif
     }
 }
@@ -2290,13 +2016,13 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
 // the class), not the sum over all its edges.
 // (two instances per shape: the plain one keeps the register allocation of a kernel that runs one edge - the loop of the persistent one costs
 // 8-12 VGPRs, which takes the 4-column kernels from 4 to 3 waves per SIMD - and is what the few-edge regime launches)
-template <int MAXNT, int CM, bool DIR, bool PERSIST, bool PK>
+template <int MAXNT, int CM, bool DIR, bool PERSIST, bool PRUNE>
 __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const PoaEdge* __restrict__ edges, const uint32_t* __restrict__ order, uint32_t n_items,
                                             const PoaSlot* __restrict__ slots, uint32_t* __restrict__ counter /* null: one workgroup per entry of `order` */,
                                             const PoaSeq* __restrict__ seqs, const uint8_t* __restrict__ packed, const uint64_t* __restrict__ read_off,
                                             const uint32_t* __restrict__ read_len, PoaPools P, int32_t match, int32_t mismatch, int32_t gap,
                                             char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells, unsigned long long* phase,
-                                            uint32_t poll_limit, uint32_t lds_bytes, uint32_t max_indeg, uint32_t dp_lanes) {
+                                            uint32_t poll_limit, uint32_t lds_bytes, uint32_t max_indeg, uint32_t dp_lanes, uint32_t prune_pct) {
     __shared__ uint32_t sNext;
     for (uint32_t round = 0;; round++) {   // (one call site of the edge body for both kinds of launch)
         uint32_t eidx, mem = 0;
@@ -2319,34 +2045,31 @@ __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const P
             eidx = order[idx] & 0x00ffffffu;
             SL = slots[blockIdx.x];
         }
-        poa_edge<MAXNT, CM, DIR, PK>(eidx, mem, SL, edges, seqs, packed, read_off, read_len, P, match, mismatch, gap, cns, cns_len, status, cells, phase, poll_limit, lds_bytes, max_indeg, dp_lanes);
+        poa_edge<MAXNT, CM, DIR, PRUNE>(eidx, mem, SL, edges, seqs, packed, read_off, read_len, P, match, mismatch, gap, cns, cns_len, status, cells, phase, poll_limit, lds_bytes, max_indeg, dp_lanes, prune_pct);
         if (!PERSIST) return;
     }
 }
 
 }  // namespace
 
-void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_items, const PoaSlot* slots, uint32_t* counter, uint32_t n_blocks, const PoaSeq* seqs, const uint8_t* packed,
-             const uint64_t* read_off, const uint32_t* read_len, PoaPools pools, int32_t match, int32_t mismatch, int32_t gap, char* cns, uint32_t* cns_len,
-             uint32_t* status, unsigned long long* cells, unsigned long long* phase, int block_threads, int cm, uint32_t poll_limit, uint32_t ring_bytes,
-             bool use_dir, uint32_t max_indeg, uint32_t dp_lanes, bool pk16, hipStream_t s) {
-    if (!n_blocks || !n_items) return;
-    if (counter && !use_dir) return;   // (the host never asks for it: poa_persistent_ok)
-#define HX_LAUNCH(MNT, CMV, DIRV, PERS, PKV) do { \
-        (void)hipFuncSetAttribute((const void*)k_poa<MNT, CMV, DIRV, PERS, PKV>, hipFuncAttributeMaxDynamicSharedMemorySize, 142 * 1024); \
-        k_poa<MNT, CMV, DIRV, PERS, PKV><<<n_blocks, block_threads, ring_bytes, s>>>(edges, order, n_items, slots, counter, seqs, packed, read_off, read_len, pools, match, mismatch, gap, \
-                                                                       cns, cns_len, status, cells, phase, poll_limit, ring_bytes, max_indeg, dp_lanes); } while (0)
-    // (persistent instances exist for the direction-byte flavour only: poa_persistent_ok)
-#define HX_LAUNCH_CM(MNT, CMV) do { if (use_dir && counter) HX_LAUNCH(MNT, CMV, true, true, false); else if (use_dir) HX_LAUNCH(MNT, CMV, true, false, false); else HX_LAUNCH(MNT, CMV, false, false, false); } while (0)
-    // packed 16-bit rows (dp_rows16): direction-byte flavour, 4 or 8 columns per lane
-#define HX_LAUNCH_PK(MNT, CMV) do { if (counter) HX_LAUNCH(MNT, CMV, true, true, true); else HX_LAUNCH(MNT, CMV, true, false, true); } while (0)
+void poa_run(const PoaLaunch& q, hipStream_t s) {
+    if (!q.n_blocks || !q.n_items) return;
+    if (q.counter && !q.use_dir) return;   // (the host never asks for it: poa_persistent_ok)
+    const bool prune = poa_prune_ok(q.use_dir, q.cm) && q.prune_pct != 0u;
+#define HX_LAUNCH(MNT, CMV, DIRV, PERS, PRN) do { \
+        (void)hipFuncSetAttribute((const void*)k_poa<MNT, CMV, DIRV, PERS, PRN>, hipFuncAttributeMaxDynamicSharedMemorySize, 142 * 1024); \
+        k_poa<MNT, CMV, DIRV, PERS, PRN><<<q.n_blocks, q.block_threads, q.ring_bytes, s>>>(q.edges, q.order, q.n_items, q.slots, q.counter, q.seqs, q.packed, q.read_off, q.read_len, q.pools, q.match, q.mismatch, q.gap, \
+                                                                       q.cns, q.cns_len, q.status, q.cells, q.phase, q.poll_limit, q.ring_bytes, q.max_indeg, q.dp_lanes, q.prune_pct); } while (0)
+    // (persistent instances exist for the direction-byte flavour only: poa_persistent_ok; pruned ones for it with 4 or 8 columns per lane: poa_prune_ok)
+#define HX_LAUNCH_CM(MNT, CMV) do { if (q.use_dir && q.counter) HX_LAUNCH(MNT, CMV, true, true, false); else if (q.use_dir) HX_LAUNCH(MNT, CMV, true, false, false); else HX_LAUNCH(MNT, CMV, false, false, false); } while (0)
+#define HX_LAUNCH_PR(MNT, CMV) do { if (q.counter) HX_LAUNCH(MNT, CMV, true, true, true); else HX_LAUNCH(MNT, CMV, true, false, true); } while (0)
     // the instances the host's launch classes use (poa_kernel_lanes): workgroups up to 64 / 256 / 512 / 1024 lanes x 4, 8, 16 or 32 columns per lane
-    const int mnt = poa_kernel_lanes(block_threads);
-    if (pk16 && use_dir && cm <= 8) {
-        if (mnt == 64) { if (cm <= 4) HX_LAUNCH_PK(64, 4); else HX_LAUNCH_PK(64, 8); }
-        else if (mnt == 256) { if (cm <= 4) HX_LAUNCH_PK(256, 4); else HX_LAUNCH_PK(256, 8); }
-        else if (mnt == 512) { if (cm <= 4) HX_LAUNCH_PK(512, 4); else HX_LAUNCH_PK(512, 8); }
-        else { if (cm <= 4) HX_LAUNCH_PK(1024, 4); else HX_LAUNCH_PK(1024, 8); }
+    const int mnt = poa_kernel_lanes(q.block_threads), cm = q.cm;
+    if (prune) {
+        if (mnt == 64) { if (cm <= 4) HX_LAUNCH_PR(64, 4); else HX_LAUNCH_PR(64, 8); }
+        else if (mnt == 256) { if (cm <= 4) HX_LAUNCH_PR(256, 4); else HX_LAUNCH_PR(256, 8); }
+        else if (mnt == 512) { if (cm <= 4) HX_LAUNCH_PR(512, 4); else HX_LAUNCH_PR(512, 8); }
+        else { if (cm <= 4) HX_LAUNCH_PR(1024, 4); else HX_LAUNCH_PR(1024, 8); }
         return;
     }
     if (mnt == 64) { if (cm <= 4) HX_LAUNCH_CM(64, 4); else if (cm <= 8) HX_LAUNCH_CM(64, 8); else if (cm <= 16) HX_LAUNCH_CM(64, 16); else HX_LAUNCH_CM(64, 32); }
@@ -2354,7 +2077,7 @@ void poa_run(const PoaEdge* edges, const uint32_t* order, uint32_t n_items, cons
     else if (mnt == 512) { if (cm <= 4) HX_LAUNCH_CM(512, 4); else if (cm <= 8) HX_LAUNCH_CM(512, 8); else HX_LAUNCH_CM(512, 16); }
     else { if (cm <= 4) HX_LAUNCH_CM(1024, 4); else if (cm <= 8) HX_LAUNCH_CM(1024, 8); else if (cm <= 16) HX_LAUNCH_CM(1024, 16); else HX_LAUNCH_CM(1024, 32); }   // (1024 x 32: one workgroup for a gap of 8192..32767 bases: register spills, rare)
 #undef HX_LAUNCH_CM
-#undef HX_LAUNCH_PK
+#undef HX_LAUNCH_PR
 #undef HX_LAUNCH
 }
 

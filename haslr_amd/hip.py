@@ -16,6 +16,7 @@ SYMBOLS = ["hx_last_error", "hx_device_count", "hx_ctx_create", "hx_ctx_destroy"
            "hx_chain_reads", "hx_edge_support", "hx_edge_coords", "hx_poa_batch", "hx_free_chain", "hx_free_edges",
            "hx_free_coords", "hx_free_cns", "hx_edge_emit", "hx_edge_records_bytes", "hx_edge_records_export",
            "hx_edge_records_import", "hx_poa_supports", "hx_poa_sequences", "hx_timing_reset", "hx_timing_get", "hx_set_poa_block", "hx_backend_fill", "hx_poa_phase_cycles", "hx_set_poa_traceback", "hx_poa_workspace_bytes",
+           "hx_set_option", "hx_get_option", "hx_option_names", "hx_poa_memory_stats", "hx_poa_release_workspace", "hx_poa_prune_stats", "hx_group_set_timeout", "hx_group_inject_fault",
            "hx_group_create", "hx_group_destroy", "hx_group_size", "hx_group_ctx", "hx_group_transport", "hx_edge_merge", "hx_group_backend_fill", "hx_group_exchange_stats"]
 
 
@@ -60,7 +61,15 @@ def lib():
         L.hx_poa_workspace_bytes.argtypes = [C.c_void_p]
         L.hx_poa_workspace_bytes.restype = C.c_uint64
         # multi-GPU inside one process (one thread per rank): hx_group_*
-        L.hx_group_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+        L.hx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.hx_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
+        L.hx_option_names.restype = C.c_char_p
+        L.hx_poa_memory_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.hx_poa_release_workspace.argtypes = [C.c_void_p]
+        L.hx_poa_prune_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 4)]
+        L.hx_group_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_char_p, C.POINTER(C.c_void_p)]
+        L.hx_group_set_timeout.argtypes = [C.c_void_p, C.c_double]
+        L.hx_group_inject_fault.argtypes = [C.c_void_p, C.c_int]
         L.hx_group_destroy.argtypes = [C.c_void_p]
         L.hx_group_size.argtypes = [C.c_void_p]
         L.hx_group_ctx.argtypes = [C.c_void_p, C.c_int]
@@ -74,10 +83,22 @@ def lib():
     return _lib
 
 
+def option_names():
+    return lib().hx_option_names().decode().split(",")
+
+
+def env_options(environ=None):
+    """the HX_* variables of the environment that name library options ({option: text}): what an APPLICATION hands to hx_set_option when it
+    creates a context - the library itself reads no environment (include/haslr_hip.h)"""
+    environ = os.environ if environ is None else environ
+    names = set(option_names()) | {"prof1", "prof2", "prof3"}
+    return {k[3:].lower(): v for k, v in environ.items() if k.startswith("HX_") and k[3:].lower() in names}
+
+
 class HipContext:
     """One GPU: resident inputs + the four hot-path operators."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, options=None, use_env=True):
         L = lib()
         h = C.c_void_p()
         if L.hx_ctx_create(device, stream, C.byref(h)) != 0:
@@ -86,6 +107,52 @@ class HipContext:
         self._ds = None
         self.table = T.Backend()
         L.hx_backend_fill(self._h, C.byref(self.table))
+        if use_env:
+            self.set_options(**env_options())   # (this Python process is the application: its HX_* variables are the context's options, copied ONCE)
+        if options:
+            self.set_options(**options)
+
+    def set_option(self, name, value):
+        """tuning / test switch of this context (include/haslr_hip.h: hx_set_option); value None = back to the default"""
+        self._chk(lib().hx_set_option(self._h, str(name).encode(), None if value is None else str(value).encode()))
+
+    def set_options(self, **kv):
+        for k, v in kv.items():
+            self.set_option(k, v)
+
+    def get_option(self, name):
+        v = C.c_double()
+        self._chk(lib().hx_get_option(self._h, str(name).encode(), C.byref(v)))
+        return v.value
+
+    def options(self, **kv):
+        """context manager: the options hold inside the block and return to what they were afterwards"""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self_):
+                self_.old = {k: ctx.get_option(k) for k in kv}
+                ctx.set_options(**kv)
+                return ctx
+
+            def __exit__(self_, *exc):
+                for k, v in self_.old.items():
+                    ctx.set_option(k, int(v) if float(v).is_integer() else v)
+                return False
+        return _Scope()
+
+    def poa_memory_stats(self):
+        a, b, w = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        lib().hx_poa_memory_stats(self._h, C.byref(a), C.byref(b), C.byref(w))
+        return {"free_at_first_call": a.value, "budget": b.value, "last_call_workspace": w.value}
+
+    def poa_release_workspace(self):
+        self._chk(lib().hx_poa_release_workspace(self._h))
+
+    def poa_prune_stats(self):
+        o = (C.c_uint64 * 4)()
+        lib().hx_poa_prune_stats(self._h, C.byref(o))
+        return {"wave_rows": o[0], "wave_rows_skipped": o[1], "attempts_repeated": o[2], "alignments_with_threshold": o[3]}
 
     def _chk(self, rc):
         if rc != 0:

@@ -43,6 +43,24 @@ int hx_device_count(void); /* number of HIP devices, <0 on error */
 int hx_ctx_create(int device, void* stream, hx_ctx** out);
 void hx_ctx_destroy(hx_ctx*);
 
+/* Tuning and test switches of a context: what used to be HX_* environment variables read inside the library (31 of them, on every call) is
+ * state of the context. The library reads NO environment variable; applications that want the old behaviour copy the HX_* variables of their
+ * environment in when they create a context (haslr_assemble and haslr_amd/hip.py do, bench.py through hip.py). The reference keeps its knobs in
+ * one options struct filled by its command line (Common.hpp:44-65, Commandline.cpp:46-66); these are the knobs it does not have.
+ *   hx_set_option    name = an entry of hx_option_names() (the old spelling works too: "HX_POA_SLOTS" = "poa_slots"), value = a number as text;
+ *                    NULL or "" = back to the default. Unknown name or malformed value: error. Takes effect with the next operator call.
+ *   hx_get_option    current value as a double
+ *   hx_option_names  comma-separated list: debug, prof, poa_workspace_gb (cap of the consensus workspace, GB; 0 = 90 % of the free memory),
+ *                    poa_prune (exact score-bound pruning of the DP: -1 automatic = calls of thousands of edges, 0 never, else the threshold as a
+ *                    percentage of the previous alignment's score per base), launch-shape knobs (poa_cols, poa_member_lanes, poa_cluster_min /
+ *                    _max / _topk / _cols, poa_wide_members, poa_wave_max, poa_ring_kb, poa_balance, poa_balance_pct, poa_balance_lanes, poa_streams,
+ *                    poa_wide_delay_us, poa_prune_lanes) and test switches that force rare paths (poa_poll_limit, poa_max_indeg, poa_node_est_pct,
+ *                    poa_far_rows, poa_ring_zero, poa_slots, poa_slots_pct, poa_batches, poa_force_cm, poa_no_xcd_map, coords_lds_supp).
+ *                    Results never depend on any of them. */
+int hx_set_option(hx_ctx*, const char* name, const char* value);
+int hx_get_option(const hx_ctx*, const char* name, double* value);
+const char* hx_option_names(void);
+
 /* copy inputs to HBM; they stay resident for the life of the context (replicated on every GPU in a
  * multi-GPU run). Read shard defaults to all reads. */
 int hx_upload(hx_ctx*, const hx_contigs*, const hx_reads*, const hx_hits*, const uint64_t* read_hit_off);
@@ -87,21 +105,25 @@ int hx_edge_records_import(hx_ctx*, const void* src_device, uint64_t n_records, 
 /* Multi-GPU inside ONE process: the GPUs of a node behind the same binary, like the reference's worker threads behind asm_calc_edge_coordinates_MT
  * / asm_cal_cns_seq_MT (Assemble.cpp:453-477, :580-605, called from main.cpp:203-208). A group holds one context per rank (one host thread
  * each) and one RCCL communicator per rank (ncclCommInitAll; librccl is loaded at run time, only by this call).
- *   hx_group_create        n ranks on `devices` (NULL: ranks 0..n-1 on devices 0..n-1). Transport: RCCL over xGMI when every rank has its own
- *                          device; HASLR_GROUP_TRANSPORT=host stages the exchange through host memory and lets ranks share devices (a rehearsal
- *                          of the multi-GPU logic on a box with fewer GPUs than ranks).
+ *   hx_group_create        n ranks on `devices` (NULL: ranks 0..n-1 on devices 0..n-1). `transport`: NULL = RCCL over xGMI when every rank has its
+ *                          own device; "rccl" insists on it; "host" stages the exchange through host memory and lets ranks share devices (a
+ *                          rehearsal of the multi-GPU logic on a box with fewer GPUs than ranks; haslr_assemble passes its HASLR_GROUP_TRANSPORT).
  *   hx_group_ctx           the rank's context: hx_upload (inputs are replicated), hx_set_read_shard, hx_set_prefiltered per rank as usual
  *   hx_edge_merge          COLLECTIVE - every rank's thread calls it once per pass, after hx_chain_reads on its read shard: emits the shard's
  *                          edge-support records, all-gathers the packed records (ONE ncclAllGather, padded to the largest shard; counts are
  *                          exchanged through the process's memory), imports the concatenation (rank order = read order), sorts and segments:
  *                          `out` like hx_edge_support, identical on every rank (bbg_build_graph's multiset, Backbone_graph.cpp:148-171).
  *                          The ranks agree on failure before the collective: if one fails there (emission, export, buffers), all return an error, none
- *                          hangs. A failure INSIDE the collective (ncclAllGather returning an error on one rank, a device fault on its stream) is not
- *                          covered: the other ranks are then waiting on the collective's stream and RCCL's own abort / watchdog ends them.
+ *                          hangs. A failure INSIDE the collective (ncclAllGather returning an error on one rank, a fault on its stream, or no
+ *                          completion within hx_group_set_timeout - 300 s by default) raises the group's abort flag: every rank polls its stream
+ *                          instead of blocking on it, aborts its communicator (ncclCommAbort) when it sees the flag, and all ranks return the
+ *                          error; the group refuses further exchanges.
  *   hx_group_backend_fill  the rank's hx_backend table: its own chain / coordinate / consensus operators, hx_edge_merge as edge_support
  *   hx_group_exchange_stats  bytes of records exchanged by the last hx_edge_merge and its wall time in ms */
 typedef struct hx_group hx_group;
-int hx_group_create(int n_ranks, const int* devices, hx_group** out);
+int hx_group_create(int n_ranks, const int* devices, const char* transport, hx_group** out);
+void hx_group_set_timeout(hx_group*, double seconds);
+void hx_group_inject_fault(hx_group*, int rank); /* testing: this rank's next all-gather "returns an error" (-1: none) */
 void hx_group_destroy(hx_group*);
 int hx_group_size(const hx_group*);
 hx_ctx* hx_group_ctx(hx_group*, int rank);
@@ -115,11 +137,20 @@ void hx_group_exchange_stats(const hx_group*, uint64_t* bytes, double* ms);
 void hx_timing_reset(hx_ctx*);
 void hx_timing_get(hx_ctx*, double* ms, uint64_t* launches);
 /* diagnostics of the last hx_poa_batch: shader-clock cycles spent by lane 0 per phase [decode, dp, traceback,
- * graph update + consensus, toposort, csr], summed over edges (sum6) and for the slowest edge (max6); returns #edges */
+ * graph update + consensus, toposort, csr], summed over edges (sum6) and for the slowest edge (max6); returns #edges.
+ * With option debug set it also prints the per-class row statistics of the call to stderr. */
 uint32_t hx_poa_phase_cycles(hx_ctx*, uint64_t* sum6, uint64_t* max6);
 /* bytes of POA workspace (all pools) the largest hx_poa_batch of this context has needed: (resident work-groups) x (largest edge of a launch
  * class) + the shared edges' own slots - not the sum over the edges of the call */
 uint64_t hx_poa_workspace_bytes(const hx_ctx*);
+/* memory of the consensus stage: device memory free when the context first ran a consensus (the budget is 90 % of it unless option
+ * poa_workspace_gb says otherwise), the budget, and the workspace the LAST call settled on (slot counts are scaled down until it fits) */
+/* frees the consensus workspace (the pools grow to the largest call and otherwise live as long as the context) and forgets the memory budget: the next
+ * consensus call takes it again from what is free then, and allocates anew */
+int hx_poa_release_workspace(hx_ctx*);
+void hx_poa_memory_stats(const hx_ctx*, uint64_t* free_at_first_call, uint64_t* budget, uint64_t* last_call_workspace);
+/* pruning statistics of the last hx_poa_batch, summed over the pruned launches: [wave-rows, wave-rows skipped, attempts repeated, alignments with a threshold] */
+void hx_poa_prune_stats(const hx_ctx*, uint64_t* out4);
 /* POA work-group size: 0 = automatic (64..256 lanes per edge, ~8 DP columns per lane; gaps > 2047 columns are shared by several
  * work-groups), or force one work-group of 64/128/256/512/1024 lanes per edge (gaps up to 32767 bases) */
 void hx_set_poa_block(hx_ctx*, int threads);

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -700,6 +701,7 @@ struct PoaAligner {
     int32_t m, x, g;
     std::vector<int32_t> H, prof;
     std::vector<uint32_t> node2rank;
+    int64_t prev_score = 0; uint32_t prev_len = 0;   // (ORC_POA_PRUNE_SIM only: the previous alignment of this edge, the source of the pruning threshold)
     // spoa SisdAlignmentEngine::align (kNW, linear gap). Returns (node|-1, seq pos|-1) pairs.
     std::vector<std::pair<int32_t, int32_t>> align(const PoaGraph& G, const uint8_t* seq, uint32_t len, uint64_t* cells) {
         std::vector<std::pair<int32_t, int32_t>> aln;
@@ -865,7 +867,118 @@ struct PoaAligner {
         if (tbstat) fprintf(stderr, "POATB steps=%lu diag=%lu diag_slot0=%lu slot0_lag1=%lu slot0_lag2=%lu runs_lag1=%lu runs_lag12=%lu\n", (unsigned long)tb_steps, (unsigned long)tb_diag, (unsigned long)tb_diag0,
                             (unsigned long)tb_diag0_lag1, (unsigned long)tb_diag0_lag2, (unsigned long)tb_runs1, (unsigned long)tb_runs12);
         std::reverse(aln.begin(), aln.end());
+        if (const char* ps = getenv("ORC_POA_PRUNE_SIM")) prune_sim(G, seq, len, atoi(ps) > 0 ? atoi(ps) : 8, max_score, aln);
+        prev_score = max_score; prev_len = len;
         return aln;
+    }
+
+    // ---- ORC_POA_PRUNE_SIM=<columns per lane>: development model of K6's exact score-bound pruning (kernels/poa.hip, "Pruning"), a STATISTIC - the
+    // alignment returned above is the unpruned one, always. The model runs the kernel's rule on the CPU: the DP columns of a row are dealt to
+    // wavefronts of 64 lanes x CM columns; with U(i, j) = H[i][j] + match x (L - j) an upper bound of any path through the cell (it never grows
+    // along a path) and a threshold T, the block (row i, wave w) is COMPUTED only when one of its inputs can still reach T - a predecessor row's
+    // block of the same wave that was flagged, or the carry entering from the wave on the left; everything else counts as minus infinity. A
+    // computed block is FLAGGED for its successors when one of its lanes passes the per-lane test (the finished key of the lane's last column
+    // with the bias of its first), or its carry-in is live. T comes from the previous alignment of the edge (score per base x this length x
+    // ORC_POA_PRUNE_F); an attempt whose best sink stays below T is repeated with T = that score (a real path's, so the repeat cannot fail).
+    // Checked here: the pruned matrix gives the same end node and the same traceback as the full one, every time.
+    void prune_sim(const PoaGraph& G, const uint8_t* seq, uint32_t len, int CM, int32_t full_score, const std::vector<std::pair<int32_t, int32_t>>& full_aln) {
+        static std::atomic<uint64_t> n_aln{0}, n_retry{0}, n_unpruned{0}, n_bad{0}, rows_all{0}, rows_done{0}, rows_retry{0}, mw_all{0}, mw_done{0}, mw_retry{0}, lane_live{0}, lane_all{0};
+        static struct Pr { ~Pr() {
+            fprintf(stderr, "POAPRUNESIM alignments %lu (first of an edge / no estimate: %lu unpruned), retries %lu, WRONG %lu | wave-rows %.4g computed %.3f (+ retries %.3f) | multi-wave alignments only: wave-rows %.4g computed %.3f (+ retries %.3f)\n",
+                    (unsigned long)n_aln.load(), (unsigned long)n_unpruned.load(), (unsigned long)n_retry.load(), (unsigned long)n_bad.load(), (double)rows_all.load(), (double)rows_done.load() / std::max<double>(1, (double)rows_all.load()),
+                    (double)rows_retry.load() / std::max<double>(1, (double)rows_all.load()), (double)mw_all.load(), (double)mw_done.load() / std::max<double>(1, (double)mw_all.load()), (double)mw_retry.load() / std::max<double>(1, (double)mw_all.load())); } } printer;
+        const size_t V = G.code.size(), W = (size_t)len + 1, BW = 64 * (size_t)CM, NB = (W + BW - 1) / BW;
+        const int64_t NEGV = -(1ll << 40), L = len;
+        const double f = getenv("ORC_POA_PRUNE_F") ? atof(getenv("ORC_POA_PRUNE_F")) : 0.9;
+        n_aln++;
+        rows_all += (uint64_t)V * NB; if (NB > 1) mw_all += (uint64_t)V * NB;
+        std::vector<int64_t> Hp((V + 1) * W), CI((V + 1) * (NB + 1));
+        std::vector<uint8_t> F((V + 1) * NB);
+        auto attempt = [&](int64_t T, uint64_t& blocks, int64_t& S, int64_t& Si) {
+            std::fill(Hp.begin(), Hp.end(), NEGV); std::fill(F.begin(), F.end(), 0); std::fill(CI.begin(), CI.end(), NEGV);
+            blocks = 0;
+            for (size_t j = 0; j < W; j++) Hp[j] = (int64_t)j * g;
+            for (size_t w = 0; w < NB; w++) {
+                const int64_t c0 = (int64_t)(w * BW), cl = std::max<int64_t>(c0 - 1, 0);
+                F[w] = (int64_t)m * L - (int64_t)(m - g) * cl >= T;
+                CI[w] = w ? (c0 - 1) * g : NEGV;
+            }
+            S = NEGV; Si = -1;
+            for (size_t i = 1; i <= V; i++) {
+                const uint32_t n = G.rank2node[i - 1];
+                const int32_t* pr = &prof[(size_t)G.code[n] * W];
+                const size_t np = G.in[n].size();
+                for (size_t w = 0; w < NB; w++) {
+                    const int64_t c0 = (int64_t)(w * BW), c1 = std::min<int64_t>((int64_t)W, c0 + (int64_t)BW);
+                    const int64_t cin = w ? CI[i * (NB + 1) + w] : NEGV;   // H of column c0 - 1 in this row, as the wave on the left handed it over
+                    const bool cin_live = w && cin > NEGV / 2 && (cin - (c0 - 1) * g) + (int64_t)m * L - (int64_t)(m - g) * (c0 - 1) >= T;
+                    bool act = cin_live || np > 4;
+                    auto rank_of = [&](size_t p) -> size_t { return np == 0 ? 0 : node2rank[G.edges[G.in[n][p]].from] + 1; };
+                    for (size_t p = 0; p < std::max<size_t>(1, np) && !act; p++) act = F[rank_of(p) * NB + w];
+                    if (!act) { CI[i * (NB + 1) + w + 1] = cin > NEGV / 2 ? cin + g * (c1 - c0) : NEGV; continue; }
+                    blocks++;
+                    for (int64_t j = c0; j < c1; j++) {
+                        int64_t v = NEGV;
+                        for (size_t p = 0; p < std::max<size_t>(1, np); p++) {
+                            const size_t pi = rank_of(p);
+                            if (!F[pi * NB + w]) continue;   // an unflagged predecessor block is not read (it may never have been written)
+                            const int64_t left = j == 0 ? NEGV : j == c0 ? CI[pi * (NB + 1) + w] : Hp[pi * W + j - 1];
+                            if (j > 0 && left > NEGV / 2) v = std::max(v, left + pr[j]);
+                            if (Hp[pi * W + j] > NEGV / 2) v = std::max(v, Hp[pi * W + j] + g);
+                        }
+                        const int64_t hl = j == c0 ? cin : Hp[i * W + j - 1];
+                        if (hl > NEGV / 2) v = std::max(v, hl + g);
+                        Hp[i * W + j] = v;
+                    }
+                    CI[i * (NB + 1) + w + 1] = Hp[i * W + c1 - 1];
+                    bool fl = cin_live;
+                    for (int64_t j0 = c0; j0 < c1 && !fl; j0 += CM) {
+                        const int64_t jl = std::min<int64_t>(j0 + CM - 1, (int64_t)W - 1), h = Hp[i * W + jl];
+                        fl = h > NEGV / 2 && (h - jl * g) + (int64_t)m * L - (int64_t)(m - g) * j0 >= T;
+                    }
+                    F[i * NB + w] = fl;
+                }
+                if (G.outs[n].empty() && Hp[i * W + W - 1] > S) { S = Hp[i * W + W - 1]; Si = (int64_t)i; }
+            }
+        };
+        uint64_t blocks = 0; int64_t S = 0, Si = -1;
+        int64_t T = NEGV;
+        const bool est = prev_len > 0;
+        if (est) { const double e = (double)prev_score * (double)len / (double)prev_len; T = (int64_t)std::floor(e >= 0 ? e * f : e * (2 - f)); } else n_unpruned++;
+        attempt(T, blocks, S, Si);
+        rows_done += blocks; if (NB > 1) mw_done += blocks;
+        if (S < T) {
+            n_retry++;
+            attempt(Si >= 0 ? S : NEGV, blocks, S, Si);
+            rows_retry += blocks; if (NB > 1) mw_retry += blocks;
+        }
+        // the pruned matrix must give the reference's alignment: same end node, same walk
+        bool ok = S == full_score;
+        std::vector<std::pair<int32_t, int32_t>> a2;
+        if (ok) {
+            size_t i = (size_t)Si, j = W - 1;
+            while (!(i == 0 && j == 0)) {
+                const int64_t hij = Hp[i * W + j];
+                bool found = false; size_t pi_ = 0, pj_ = 0;
+                const size_t wj = j / BW;
+                auto val = [&](size_t r, size_t c, size_t wave_of_reader) -> int64_t {   // what the walk reads: a block that was never computed holds nothing
+                    (void)wave_of_reader; return Hp[r * W + c]; };
+                if (i != 0 && j != 0) {
+                    const uint32_t n = G.rank2node[i - 1]; const int32_t mc = prof[(size_t)G.code[n] * W + j]; const size_t np = G.in[n].size();
+                    for (size_t p = 0; p < std::max<size_t>(1, np) && !found; p++) { const size_t pi = np == 0 ? 0 : node2rank[G.edges[G.in[n][p]].from] + 1; if (hij == val(pi, j - 1, wj) + mc) { pi_ = pi; pj_ = j - 1; found = true; } }
+                }
+                if (!found && i != 0) {
+                    const uint32_t n = G.rank2node[i - 1]; const size_t np = G.in[n].size();
+                    for (size_t p = 0; p < std::max<size_t>(1, np) && !found; p++) { const size_t pi = np == 0 ? 0 : node2rank[G.edges[G.in[n][p]].from] + 1; if (hij == val(pi, j, wj) + g) { pi_ = pi; pj_ = j; found = true; } }
+                }
+                if (!found) { pi_ = i; pj_ = j - 1; }
+                a2.emplace_back(i == pi_ ? -1 : (int32_t)G.rank2node[i - 1], j == pj_ ? -1 : (int32_t)(j - 1));
+                i = pi_; j = pj_;
+            }
+            std::reverse(a2.begin(), a2.end());
+            ok = a2 == full_aln;
+        }
+        if (!ok) { n_bad++; fprintf(stderr, "POAPRUNESIM MISMATCH V=%zu L=%u T=%lld S=%lld full=%d\n", V, len, (long long)T, (long long)S, full_score); }
     }
 };
 

@@ -63,14 +63,14 @@ def test_every_stage_bit_exact(args, sim, ctx, tmp_path):
 
 
 @pytest.mark.parametrize("lds_supp", ["0", "3"])
-def test_coords_through_the_global_scratch(lds_supp, sim, ctx, tmp_path, monkeypatch):
-    """K5 keeps the sorted lists and event records of an edge in LDS up to 384 supports; HX_COORDS_LDS_SUPP sends every edge (0) or every edge with
+def test_coords_through_the_global_scratch(lds_supp, sim, ctx, tmp_path):
+    """K5 keeps the sorted lists and event records of an edge in LDS up to 384 supports; option coords_lds_supp sends every edge (0) or every edge with
     more than three supports through the global scratch path that only an edge with hundreds of supports would take - same coordinates either way
     (hairpins included: their output slices are doubled)"""
-    monkeypatch.setenv("HX_COORDS_LDS_SUPP", lds_supp)
     pre = sim("--genome-len", "150000", "--seed", "22", "--variant-per-mb", "20", "--hairpin-frac", "0.05")
     ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
-    ro, rg, ob = both(ds, ctx, None, None)
+    with ctx.options(coords_lds_supp=lds_supp):
+        ro, rg, ob = both(ds, ctx, None, None)
     assert_same_arrays(ro.coords_out(), rg.coords_out(), "coords")
     assert ro.cns_out() == rg.cns_out()
 
@@ -349,19 +349,10 @@ def test_shared_edges_cluster_mode(sim, ctx, cfg):
     ro = host.Run(ds, prm, be.table, None)
     ro.all()
     ctx.upload(ds)
-    keys = ("HX_POA_CLUSTER_MIN", "HX_POA_MEMBER_LANES", "HX_POA_CLUSTER_COLS", "HX_POA_CLUSTER_MAX", "HX_POA_WIDE_MEMBERS")
-    old = {k: os.environ.get(k) for k in keys}
-    try:
-        for k, v in zip(keys, cfg):
-            os.environ[k] = v
+    keys = ("poa_cluster_min", "poa_member_lanes", "poa_cluster_cols", "poa_cluster_max", "poa_wide_members")
+    with ctx.options(**dict(zip(keys, cfg))):
         rg = host.Run(ds, prm, ctx.backend(), None)
         rg.all()
-    finally:
-        for k in keys:
-            if old[k] is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = old[k]
     assert ro.cns_out() == rg.cns_out()
     assert ro.assembly_fasta() == rg.assembly_fasta()
     assert ro.cns_stats()["dp_cells"] == rg.cns_stats()["dp_cells"]
@@ -380,16 +371,9 @@ def test_in_degree_retry_with_score_matrix(sim, ctx):
     ro = host.Run(ds, prm, be.table, None)
     ro.all()
     ctx.upload(ds)
-    old = os.environ.get("HX_POA_MAX_INDEG")
-    try:
-        os.environ["HX_POA_MAX_INDEG"] = "2"
+    with ctx.options(poa_max_indeg=2):
         rg = host.Run(ds, prm, ctx.backend(), None)
         rg.all()
-    finally:
-        if old is None:
-            os.environ.pop("HX_POA_MAX_INDEG", None)
-        else:
-            os.environ["HX_POA_MAX_INDEG"] = old
     assert ro.cns_out() == rg.cns_out()
     assert ro.cns_stats()["dp_cells"] == rg.cns_stats()["dp_cells"]
     rg.close(); ro.close(); be.close(); ds.close()
@@ -402,9 +386,13 @@ def test_in_degree_retry_with_score_matrix(sim, ctx):
                                             # persistent workgroups (what thousands of edges get): 1-3 workspace slots per launch class, every workgroup works through many edges
                                             ("-1", {"HX_POA_SLOTS": "1"}), ("1", {"HX_POA_SLOTS": "2"}), ("0", {"HX_POA_SLOTS": "3", "HX_POA_NODE_EST_PCT": "20"}),
                                             ("-1", {"HX_POA_SLOTS": "2", "HX_POA_CLUSTER_MIN": "100000", "HX_POA_COLS": "8"}),
-                                            # the packed 16-bit row body (opt-in): plain, far rows forced, shared edges, persistent workgroups with 8 columns per lane
-                                            ("-1", {"HX_POA_PK16": "1"}), ("1", {"HX_POA_PK16": "1"}), ("0", {"HX_POA_PK16": "1", "HX_POA_CLUSTER_MIN": "300", "HX_POA_MEMBER_LANES": "128", "HX_POA_CLUSTER_MAX": "3"}),
-                                            ("2", {"HX_POA_PK16": "1", "HX_POA_SLOTS": "2", "HX_POA_CLUSTER_MIN": "100000", "HX_POA_COLS": "8"})])
+                                            # the pruned row loop (what calls of thousands of edges get; forced here): plain, far rows forced, persistent workgroups with 8 / 4 columns per
+                                            # lane, two-wave workgroups, an optimistic threshold (every other alignment is repeated), no ring (every kept row through HBM)
+                                            ("-1", {"HX_POA_PRUNE": "95", "HX_POA_WAVE_MAX": "128"}), ("1", {"HX_POA_PRUNE": "95", "HX_POA_WAVE_MAX": "64", "HX_POA_COLS": "8"}),
+                                            ("0", {"HX_POA_PRUNE": "90", "HX_POA_WAVE_MAX": "128", "HX_POA_SLOTS": "2", "HX_POA_CLUSTER_MIN": "100000", "HX_POA_COLS": "8"}),
+                                            ("2", {"HX_POA_PRUNE": "104", "HX_POA_WAVE_MAX": "128", "HX_POA_SLOTS": "3", "HX_POA_CLUSTER_MIN": "100000"}),
+                                            ("-1", {"HX_POA_PRUNE": "110", "HX_POA_WAVE_MAX": "64", "HX_POA_CLUSTER_MIN": "100000", "HX_POA_RING_KB": "1"}),
+                                            ("-1", {"HX_POA_PRUNE": "95", "HX_POA_WAVE_MAX": "128", "HX_POA_CLUSTER_MIN": "100000", "HX_POA_RING_ZERO": "1"})])
 def test_far_row_estimate_overflow_is_retried(sim, ctx, far_rows, shape):
     """with direction bytes H keeps only the rows that a successor reads after they left the LDS ring, in as many rows as the host
     estimated; an edge that needs more comes back and is redone with room for every row. Forced here by an estimate of 0..2 rows
@@ -417,18 +405,9 @@ def test_far_row_estimate_overflow_is_retried(sim, ctx, far_rows, shape):
     ro = host.Run(ds, prm, be.table, None)
     ro.all()
     ctx.upload(ds)
-    env = dict(shape, HX_POA_FAR_ROWS=far_rows)
-    old = {k: os.environ.get(k) for k in env}
-    try:
-        os.environ.update(env)
+    with ctx.options(**dict(shape, HX_POA_FAR_ROWS=far_rows)):   # (the old environment spellings name the same options: hx_set_option)
         rg = host.Run(ds, prm, ctx.backend(), None)
         rg.all()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
     assert ro.cns_out() == rg.cns_out()
     assert ro.cns_stats()["dp_cells"] == rg.cns_stats()["dp_cells"]
     assert rg.n_edges > 0
@@ -446,17 +425,10 @@ def test_persistent_workgroups_on_many_edges(sim, ctx):
     ro = host.Run(ds, prm, be.table, None)
     ro.all()
     ctx.upload(ds)
-    old = os.environ.get("HX_POA_SLOTS")
-    try:
-        os.environ["HX_POA_SLOTS"] = "4"
+    with ctx.options(poa_slots=4):
         rg = host.Run(ds, prm, ctx.backend(), None)
         rg.all()
         ws_few = ctx.poa_workspace_bytes()
-    finally:
-        if old is None:
-            os.environ.pop("HX_POA_SLOTS", None)
-        else:
-            os.environ["HX_POA_SLOTS"] = old
     assert rg.n_edges > 60
     assert ro.cns_out() == rg.cns_out() and ro.assembly_fasta() == rg.assembly_fasta()
     assert ro.cns_stats()["dp_cells"] == rg.cns_stats()["dp_cells"]
@@ -510,19 +482,13 @@ def test_random_data_sets_and_launch_shapes(sim, ctx, case):
     ro = host.Run(ds, ds.params(**pk), be.table, None)
     ro.all()
     ctx.upload(ds)
-    old = {k: os.environ.get(k) for k in knobs}
     try:
-        os.environ.update(env)
         ctx.set_poa_block(block)
-        rg = host.Run(ds, ds.params(**pk), ctx.backend(), None)
-        rg.all()
+        with ctx.options(**env):
+            rg = host.Run(ds, ds.params(**pk), ctx.backend(), None)
+            rg.all()
     finally:
         ctx.set_poa_block(0)
-        for k in knobs:
-            if old[k] is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = old[k]
     assert ro.cns_out() == rg.cns_out(), (shape, env, block, pk)
     assert ro.assembly_fasta() == rg.assembly_fasta()
     rg.close(); ro.close(); be.close(); ds.close()
@@ -639,26 +605,44 @@ def test_configs4_share_full_size_properties(sim, ctx, tmp_path):
         inner[starts[starts < a.size].astype(np.int64)] = False                                # first element of every compact read
         assert np.all(c["q_end"][a[:-1]][inner[1:]] <= c["q_start"][a[1:]][inner[1:]])        # chained hits never overlap on the read
         fasta1, cns1 = run.assembly_fasta(), run.cns_out()
-        ws_free = ctx.poa_workspace_bytes()
+        ws_free = ctx.poa_memory_stats()["last_call_workspace"]   # what this call took with the device (nearly) to itself
         run.close()
-        # A rank of configs[4] holds the WHOLE replicated input beside its POA workspace: at CHM1 scale ~36 GB of packed reads + CIGAR words
-        # (printed below, extrapolated from this data set) leave ~250 GB, and the workspace of this share took 260 GB when it had the device to itself. The
-        # second pass runs under HALF of that (HX_POA_WORKSPACE_GB=130: fewer workgroups in flight per launch class, hx_api.hip slots_wanted / total_bytes)
-        # and must give the same consensus and assembly - the budget logic under pressure, and idempotence at this size.
-        old_ws = os.environ.get("HX_POA_WORKSPACE_GB")
-        os.environ["HX_POA_WORKSPACE_GB"] = "130"
-        try:
-            run2 = host.Run(ds, prm, ctx.backend(), None)
-            run2.all()
-        finally:
-            if old_ws is None:
-                os.environ.pop("HX_POA_WORKSPACE_GB", None)
-            else:
-                os.environ["HX_POA_WORKSPACE_GB"] = old_ws
-        assert run2.cns_out() == cns1 and run2.assembly_fasta() == fasta1
-        run2.close()
+        # A rank of configs[4] holds the WHOLE replicated input beside its POA workspace: at CHM1 scale 82 GB of packed reads + CIGAR words (DESIGN.md 3,
+        # 7.75 x this data set). Second pass at that shape for real: the workspace is released, a device BALLAST brings what is resident beside it to
+        # 82 GB, the budget is taken again from what hipMemGetInfo reports free (no option caps it) - same consensus, same assembly. Third pass under
+        # real shortage: more ballast until less is free than the workspace wanted, so the slot counts of the launch classes are scaled down until the
+        # pools fit (hx_api.hip plan_batches / slots_wanted): the path a rank of a 288 GB device takes when its input share grows.
         resident = {"packed_read_bytes": int(ds.reads.off[ds.reads.n]), "cigar_word_bytes": 4 * int(ds.hits.cg_off[ds.hits.n]), "paf_records": int(ds.hits.n),
                     "read_bases": int(ds.total_read_bases), "poa_workspace_bytes_unconstrained": int(ws_free)}
+        ballast = util.DeviceBallast(0)
+        try:
+            ctx.poa_release_workspace()
+            free0 = ballast.free_bytes()
+            ballast.hold(max(0, int(82e9) - resident["packed_read_bytes"] - resident["cigar_word_bytes"]))
+            run2 = host.Run(ds, prm, ctx.backend(), None)
+            run2.all()
+            m2 = ctx.poa_memory_stats()
+            print("configs4 share beside 82 GB of resident input: free before the ballast %.1f GB, ballast %.1f GB, free at the consensus call %.1f GB, budget %.1f GB, workspace settled on %.1f GB" %
+                  (free0 / 1e9, ballast.bytes / 1e9, m2["free_at_first_call"] / 1e9, m2["budget"] / 1e9, m2["last_call_workspace"] / 1e9))
+            assert run2.cns_out() == cns1 and run2.assembly_fasta() == fasta1
+            assert m2["last_call_workspace"] <= m2["budget"] <= 0.9 * m2["free_at_first_call"] + 1
+            run2.close()
+            ctx.poa_release_workspace()
+            want_free = int(0.55 * ws_free)                       # what the third pass finds free: about half of what the workspace took when it had the device
+            extra = ballast.free_bytes() - want_free
+            assert extra > 0, "the device has less free memory than the shortage this test wants to create"
+            ballast.hold(extra)
+            run3 = host.Run(ds, prm, ctx.backend(), None)
+            run3.all()
+            m3 = ctx.poa_memory_stats()
+            print("configs4 share under real shortage: ballast %.1f GB, free at the consensus call %.1f GB, budget %.1f GB, workspace settled on %.1f GB (unconstrained: %.1f GB)" %
+                  (ballast.bytes / 1e9, m3["free_at_first_call"] / 1e9, m3["budget"] / 1e9, m3["last_call_workspace"] / 1e9, ws_free / 1e9))
+            assert run3.cns_out() == cns1 and run3.assembly_fasta() == fasta1
+            assert m3["last_call_workspace"] <= m3["budget"] < ws_free          # the budget path ran short, for real, and held
+            run3.close()
+        finally:
+            ballast.release()
+            ctx.poa_release_workspace()
         print("configs4 share, resident inputs per GPU:", resident)
         assert resident["packed_read_bytes"] + resident["cigar_word_bytes"] < 40e9          # (400 Mb: ~2.6 + ~2.2 GB; x 7.75 for CHM1 = the replication cost per rank)
         o = subprocess.check_output([os.path.join(ROOT, "tools", "hxident"), pre + ".genome.fa", os.path.join(out, "asm.final.fa")], text=True)
@@ -753,16 +737,8 @@ def test_shared_edge_that_stalls_is_redone_unshared(sim, ctx):
     pre = sim("--genome-len", "150000", "--seed", "31", "--variant-per-mb", "15")
     ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
     knobs = {"HX_POA_CLUSTER_MIN": "300", "HX_POA_MEMBER_LANES": "64", "HX_POA_CLUSTER_COLS": "4", "HX_POA_CLUSTER_MAX": "8", "HX_POA_POLL_LIMIT": "0"}
-    old = {k: os.environ.get(k) for k in knobs}
-    try:
-        os.environ.update(knobs)
+    with ctx.options(**knobs):
         ro, rg, ob = both(ds, ctx, None, None)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
     assert ro.cns_out() == rg.cns_out() and ro.assembly_fasta() == rg.assembly_fasta()
 
 
@@ -808,18 +784,63 @@ def test_one_workgroup_with_32_columns_per_lane(ctx, length, force_cm):
     tmpl = "".join(rnd.choice("ACGT") for _ in range(length))
     groups = [[noisy(tmpl) for _ in range(n)] for n in (3, 5)]
     want = [orclib.poa_consensus(g) for g in groups]
-    old = os.environ.get("HX_POA_FORCE_CM")
     try:
-        if force_cm:
-            os.environ["HX_POA_FORCE_CM"] = force_cm
-        for dirb in (1, 0):
-            ctx.set_poa_block(1024)
-            hip.lib().hx_set_poa_traceback(ctx._h, dirb)
-            assert ctx.poa_sequences(groups) == want, "traceback flavour %d" % dirb
+        with ctx.options(poa_force_cm=force_cm or 0):
+            for dirb in (1, 0):
+                ctx.set_poa_block(1024)
+                hip.lib().hx_set_poa_traceback(ctx._h, dirb)
+                assert ctx.poa_sequences(groups) == want, "traceback flavour %d" % dirb
     finally:
         ctx.set_poa_block(0)
         hip.lib().hx_set_poa_traceback(ctx._h, 1)
-        if old is None:
-            os.environ.pop("HX_POA_FORCE_CM", None)
-        else:
-            os.environ["HX_POA_FORCE_CM"] = old
+
+
+def test_gap_longer_than_the_default_members_hold(ctx):
+    """a 150 000-base sub-sequence (what the u32 wrap of Assemble.cpp:530-532 makes of `epos + 1 < spos` on an ultra-long read: the whole tail) does
+    not fail the call any more: above 131 071 columns the edge gets 1024-lane members (16 x 1024 lanes x 32 columns = 524 287). Too long for the
+    oracle's full int32 matrix inside a test (90 GB), so known answers: three copies of one random sequence, two of them with sparse private
+    substitutions, give the sequence back; the same shape at 3 000 bases with forced 1024-lane members is compared with the oracle bit for bit."""
+    import random
+    rnd = random.Random(1505)
+    for length, knobs in ((3000, {"poa_member_lanes": 1024, "poa_cluster_min": 1000, "poa_cluster_max": 2, "poa_cluster_cols": 4}), (150000, {})):
+        s = "".join(rnd.choice("ACGT") for _ in range(length))
+
+        def mutated(step, off):
+            t = list(s)
+            for i in range(off, length, step):
+                t[i] = "ACGT"[("ACGT".index(t[i]) + 1) % 4]
+            return "".join(t)
+        sets = [[s, mutated(997, 11), mutated(1009, 500)], [s[:length // 2], s[:length // 2]]]
+        with ctx.options(**knobs):
+            got = ctx.poa_sequences(sets)
+        assert got[0] == s and got[1] == s[:length // 2], length
+        if length <= 5000:
+            assert got == [orclib.poa_consensus(st) for st in sets]
+    # beyond what the score keys hold (2^20 columns) the call fails loudly, naming the limit
+    with pytest.raises(hip.HipError, match="longer than the POA kernel"):
+        ctx.poa_sequences([["A" * (1 << 20), "A" * 10]])
+
+
+@huge
+def test_read_arena_above_4_gib(sim, ctx, tmp_path):
+    """five unreferenced filler reads of 3.6 Gbases ahead of the real ones: the packed 2-bit arena is 4.5 GB, EVERY read a hit or a consensus support names
+    sits at a byte offset above 2^32 (the shape of a CHM1 rank: 20 GB of packed reads). Every stage array, every consensus and the
+    assembly equal the oracle's on the same data set - K1's hit gathers, K5, K6's decode and the packed edge records with 64-bit offsets for real."""
+    args = ("--genome-len", "2000000", "--seed", "4242", "--cov", "20", "--variant-per-mb", "10", "--filler-reads", "5", "--filler-len", "3600000000")
+    pre = sim(*args)
+    try:
+        ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf", threads=min(16, os.cpu_count() or 1))
+        off = np.ctypeslib.as_array(ds.reads.off, shape=(int(ds.reads.n) + 1,))
+        assert int(off[5]) > (1 << 32) and int(off[-1]) > (1 << 32), "the filler reads must push every real read beyond 4 GiB"
+        ro, rg, ob = both(ds, ctx, str(tmp_path / "o"), str(tmp_path / "g"), threads=min(64, os.cpu_count() or 8))
+        assert_same_arrays(ro.chain_out(), rg.chain_out(), "chain")
+        assert_same_arrays(ro.edges_out(), rg.edges_out(), "edges")
+        assert_same_arrays(ro.coords_out(), rg.coords_out(), "coords")
+        sup = rg.coords_out()["supp_lr"]
+        assert sup.size > 1000 and int((sup & 0x7fffffff).min()) >= 5          # supports name real reads only - all of them beyond the fillers
+        assert ro.cns_out() == rg.cns_out() and rg.n_edges > 100
+        assert util.compare_dirs(str(tmp_path / "o"), str(tmp_path / "g")) == []
+        print("read arena: %.2f GB packed, first real read at byte %d, %d edges" % (int(off[-1]) / 1e9, int(off[5]), rg.n_edges))
+        rg.close(); ro.close(); ob.close(); ds.close()
+    finally:
+        _drop_sim_files(pre)

@@ -171,12 +171,8 @@ def test_edge_merge_through_the_c_abi_equals_edge_support(sim, built):
     whole = ctx.edge_support(prm)
     ctx.close()
     L = hip.lib()
-    os.environ["HASLR_GROUP_TRANSPORT"] = "host"
-    try:
-        g = C.c_void_p()
-        assert L.hx_group_create(3, None, C.byref(g)) == 0, L.hx_last_error()
-    finally:
-        del os.environ["HASLR_GROUP_TRANSPORT"]
+    g = C.c_void_p()
+    assert L.hx_group_create(3, None, b"host", C.byref(g)) == 0, L.hx_last_error()
     assert L.hx_group_size(g) == 3 and L.hx_group_transport(g) == b"host"
     b = host.shard_bounds(ds, 3)
     got, errs = [None] * 3, []
@@ -204,3 +200,36 @@ def test_edge_merge_through_the_c_abi_equals_edge_support(sim, built):
         for k in whole:
             assert np.array_equal(whole[k], got[r][k]), (r, k)
     L.hx_group_destroy(g)
+
+
+@pytest.mark.gpu
+def test_a_failure_inside_the_collective_ends_the_exchange_with_an_error(sim, built):
+    """a rank whose all-gather fails (injected: hx_group_inject_fault) raises the group's abort flag instead of leaving anybody parked on a stream: the
+    call returns the error, and the group refuses further exchanges. One rank over real RCCL (the only world size a one-GPU box can run it at); the
+    ranks that would be WAITING in a larger group take the same bounded-poll path (hx_api.hip hx_edge_merge)."""
+    from haslr_amd import hip
+    pre = sim("--genome-len", "150000", "--seed", "21", "--variant-per-mb", "30")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    prm = ds.params()
+    L = hip.lib()
+    g = C.c_void_p()
+    assert L.hx_group_create(1, None, b"rccl", C.byref(g)) == 0, L.hx_last_error()
+    assert L.hx_group_transport(g) == b"rccl"
+    L.hx_group_set_timeout(g, 20.0)
+    c = L.hx_group_ctx(g, 0)
+    assert L.hx_upload(c, C.byref(ds.contigs), C.byref(ds.reads), C.byref(ds.hits), ds.read_hit_off) == 0
+    ch = T.ChainOut()
+    assert L.hx_chain_reads(c, C.byref(prm), C.byref(ch)) == 0
+    L.hx_free_chain(c, C.byref(ch))
+    e = T.EdgesOut()
+    assert L.hx_edge_merge(g, 0, C.byref(prm), C.byref(e)) == 0, L.hx_last_error()      # the exchange works ...
+    n_ok = e.n_rec
+    L.hx_free_edges(c, C.byref(e))
+    assert n_ok > 0
+    L.hx_group_inject_fault(g, 0)
+    assert L.hx_edge_merge(g, 0, C.byref(prm), C.byref(e)) != 0                           # ... an injected failure comes back as an error, at once
+    assert b"ncclAllGather" in L.hx_last_error()
+    L.hx_group_inject_fault(g, -1)
+    assert L.hx_edge_merge(g, 0, C.byref(prm), C.byref(e)) != 0 and b"failed earlier" in L.hx_last_error()   # the group is broken for good
+    L.hx_group_destroy(g)
+    ds.close()

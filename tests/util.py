@@ -114,3 +114,40 @@ def compare_dirs(a, b, names=None):
         if os.path.exists(pb) and open(pa, "rb").read() != open(pb, "rb").read():
             bad.append(f)
     return bad
+
+
+class DeviceBallast:
+    """device memory held for the duration of a test (hipMalloc through libamdhip64): what ELSE is resident on a GPU beside the thing under test"""
+
+    def __init__(self, device=0):
+        import ctypes as C
+        self._C = C
+        self._hip = C.CDLL("libamdhip64.so")
+        self._hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self._hip.hipFree.argtypes = [C.c_void_p]
+        self._hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        assert self._hip.hipSetDevice(device) == 0
+        self._blocks = []
+        self.bytes = 0
+
+    def free_bytes(self):
+        f, t = self._C.c_size_t(), self._C.c_size_t()
+        assert self._hip.hipMemGetInfo(self._C.byref(f), self._C.byref(t)) == 0
+        return int(f.value)
+
+    def hold(self, n_bytes):
+        """n_bytes more, in blocks of at most 8 GB"""
+        left = int(n_bytes)
+        while left > 0:
+            n = min(left, 8 << 30)
+            p = self._C.c_void_p()
+            rc = self._hip.hipMalloc(self._C.byref(p), n)
+            assert rc == 0, f"hipMalloc of {n} ballast bytes failed ({rc}); {self.free_bytes()} free"
+            self._blocks.append(p)
+            self.bytes += n
+            left -= n
+
+    def release(self):
+        for p in self._blocks:
+            self._hip.hipFree(p)
+        self._blocks, self.bytes = [], 0

@@ -15,7 +15,7 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = hip.HipContext(0)
 os.makedirs('/tmp/fz', exist_ok=True)
 bad = 0
-KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS', 'HX_POA_BATCHES', 'HX_POA_NODE_EST_PCT', 'HX_POA_RING_KB', 'HX_POA_COLS', 'HX_POA_CLUSTER_TOPK', 'HX_POA_SLOTS', 'HX_POA_WORKSPACE_GB', 'HX_POA_FORCE_CM', 'HX_POA_RING_ZERO', 'HX_POA_WIDE_MEMBERS', 'HX_POA_PK16')
+KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS', 'HX_POA_BATCHES', 'HX_POA_NODE_EST_PCT', 'HX_POA_RING_KB', 'HX_POA_COLS', 'HX_POA_CLUSTER_TOPK', 'HX_POA_SLOTS', 'HX_POA_WORKSPACE_GB', 'HX_POA_FORCE_CM', 'HX_POA_RING_ZERO', 'HX_POA_WIDE_MEMBERS', 'HX_POA_PRUNE', 'HX_POA_PRUNE_LANES')
 for it in range(n):
     big = os.environ.get('FUZZ_BIG') is not None   # long gaps at real sizes: the default launch shapes (512-lane cluster members) get real work
     glen = rng.choice([400000, 700000, 1000000]) if big else rng.choice([40000, 60000, 90000, 150000, 250000])
@@ -27,7 +27,7 @@ for it in range(n):
     env = {}
     shape = rng.choice(['default', 'default', 'small-members', 'block']) if big else rng.choice(['default', 'small-members', 'one-wave', 'block'])
     for k in KNOBS:
-        os.environ.pop(k, None)
+        ctx.set_option(k, None)          # back to the default (the knobs are options of the context: hx_set_option)
     ctx.set_poa_block(0)
     if shape == 'small-members':
         env = {'HX_POA_CLUSTER_MIN': str(rng.choice([200, 400, 800])), 'HX_POA_MEMBER_LANES': str(rng.choice([64, 128, 256])),
@@ -56,11 +56,14 @@ for it in range(n):
         env['HX_POA_RING_ZERO'] = '1'                               # no LDS ring: every kept row is read back from HBM
     if rng.random() < 0.5:
         env['HX_POA_WIDE_MEMBERS'] = str(rng.choice([0, 1, 100]))   # shared edges with 1024-lane members (default: the 4 costliest below 3 000 edges per call)
-    if rng.random() < 0.35:
-        env['HX_POA_PK16'] = '1'                                    # the packed 16-bit rows (round 4; opt-in) instead of the int32 ones
+    if rng.random() < 0.6:
+        env['HX_POA_PRUNE'] = str(rng.choice([80, 95, 95, 100, 104, 115]))   # exact score-bound pruning (round 5): thresholds below / at / above the previous alignment's score per base (above: repeats)
+        env['HX_POA_PRUNE_LANES'] = str(rng.choice([64, 128, 128, 256]))
+        if 'HX_POA_WAVE_MAX' not in env and rng.random() < 0.7:
+            env['HX_POA_WAVE_MAX'] = str(rng.choice([64, 128, 256]))          # several waves per workgroup on the short gaps of a small data set
     if rng.random() < 0.25:
         env['HX_POA_NODE_EST_PCT'] = str(rng.choice([2, 10, 30, 60]))
-    os.environ.update(env)
+    ctx.set_options(**env)
     ds = host.Dataset('/tmp/fz/s.contigs.fa', '/tmp/fz/s.reads.fa', '/tmp/fz/s.paf')
     pk = dict(min_aln_block=rng.choice([250, 500, 500, 1000]), min_aln_sim=rng.choice([0.8, 0.85, 0.85, 0.9]), min_edge_sup=rng.choice([2, 3, 3, 5]), max_uniq_dev=rng.choice([0.15, 0.15, 0.3]))
     env = dict(env, **{k: str(v) for k, v in pk.items()})   # (printed with the knobs)
@@ -72,10 +75,10 @@ for it in range(n):
     try:
         rg.all()
     except host.HostError as e:
-        if 'HX_POA_WORKSPACE_GB' in os.environ and 'more POA workspace' in str(e):
+        if 'HX_POA_WORKSPACE_GB' in env and 'more POA workspace' in str(e):
             print(it, 'workspace cap too small for the largest edge (loud error, as it should be): again without the cap', flush=True)
-            os.environ.pop('HX_POA_WORKSPACE_GB')
-        elif shape == 'block' and 'longer than 32767 bases needs the shared' in str(e):
+            ctx.set_option('HX_POA_WORKSPACE_GB', None)
+        elif shape == 'block' and 'needs the shared (cluster) mode' in str(e):
             print(it, 'a forced block size cannot hold a gap above 32 767 bases (loud error, as it should be): again with the automatic shape', flush=True)
             ctx.set_poa_block(0)
         else:

@@ -10,6 +10,11 @@
 // The generator is build-owned test/bench infrastructure. It is deterministic for
 // a given (seed, options): its own xoshiro256** PRNG, no std:: distributions.
 //
+// --chromosomes K (round 5): the genome is K independent chromosomes of genome-len / K bases, simulated by --threads T threads (chromosome k
+// with seed + 7919 k), written in chromosome order with contig and read ids running on - 140 Mb took 42 s on one thread. K = 1 (the default)
+// writes exactly what the single-threaded generator always wrote. --filler-reads N --filler-len L: N unreferenced reads of L bases ('A') ahead of
+// the real ones (test: a packed read arena above 4 GiB, every supporting read at a byte offset above 2^32).
+//
 // Planted features (each exercises a reference code path, cited in DESIGN.md):
 //   * repeat families collapsed into one contig with km ~ 30*copies
 //   * contigs < 250 bp (never mapped) and 250..500 bp (fail --aln-block)
@@ -24,7 +29,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -102,10 +109,59 @@ struct Opts {
 
 struct ErrModel { double ins, del, sub; };
 
+struct Hit { uint32_t qs, qe, tid, tlen, ts, te, nm, nb; bool rev; uint8_t mapq; std::string cg; };
+
+// where a simulation's products go: straight to the files (one chromosome), or into memory with local ids (one of several chromosomes)
+struct Sink {
+    virtual ~Sink() {}
+    virtual void contigs(const std::vector<Contig>& contigs, const std::vector<uint32_t>& order) = 0;   // order[id] = index of the contig with that id
+    virtual void genome(const std::string& g) = 0;
+    virtual void read(const std::string& seq, uint32_t rlen, const std::vector<Hit>& hits) = 0;
+};
+struct FileSink : Sink {
+    std::string prefix; FILE *fr = nullptr, *fp = nullptr; uint64_t read_id = 0;
+    bool open_reads() { fr = fopen((prefix + ".reads.fa").c_str(), "w"); fp = fopen((prefix + ".paf").c_str(), "w"); return fr && fp; }
+    void contigs(const std::vector<Contig>& cs, const std::vector<uint32_t>& order) override {
+        FILE* fc = fopen((prefix + ".contigs.fa").c_str(), "w");
+        if (!fc) { perror("hxsim: contigs"); exit(1); }
+        for (size_t id = 0; id < order.size(); id++) {
+            const Contig& c = cs[order[id]];
+            fprintf(fc, ">%zu LN:i:%zu KC:i:%u km:f:%.3f\n%s\n", id, c.seq.size(), c.kc, c.km, c.seq.c_str());
+        }
+        fclose(fc);
+    }
+    void genome(const std::string& g) override {
+        FILE* fg = fopen((prefix + ".genome.fa").c_str(), "w");
+        if (!fg) { perror("hxsim: genome"); exit(1); }
+        fprintf(fg, ">genome\n%s\n", g.c_str());
+        fclose(fg);
+    }
+    void read(const std::string& seq, uint32_t rlen, const std::vector<Hit>& hits) override {
+        fprintf(fr, ">%" PRIu64 "\n%s\n", read_id, seq.c_str());
+        for (const Hit& h : hits)
+            fprintf(fp, "%" PRIu64 "\t%u\t%u\t%u\t%c\t%u\t%u\t%u\t%u\t%u\t%u\t%u\ttp:A:P\tcm:i:%u\ts1:i:%u\tcg:Z:%s\n",
+                    read_id, rlen, h.qs, h.qe, h.rev ? '-' : '+', h.tid, h.tlen, h.ts, h.te, h.nm, h.nb,
+                    (unsigned)h.mapq, h.nm / 10, h.nm, h.cg.c_str());
+        read_id++;
+    }
+};
+struct MemSink : Sink {
+    struct Rd { std::string seq; uint32_t rlen; std::vector<Hit> hits; };
+    std::vector<Contig> cs; std::string g; std::vector<Rd> reads;   // contigs in id order (local ids)
+    void contigs(const std::vector<Contig>& c, const std::vector<uint32_t>& order) override { cs.reserve(order.size()); for (uint32_t i : order) cs.push_back(c[i]); }
+    void genome(const std::string& gg) override { g = gg; }
+    void read(const std::string& seq, uint32_t rlen, const std::vector<Hit>& hits) override { reads.push_back({seq, rlen, hits}); }
+};
+
+struct SimStats { size_t contigs = 0, families = 0, molecules = 0; uint64_t reads = 0, bases = 0, hits = 0; };
+int simulate(Opts o, Sink& sink, SimStats& st);
+
 }  // namespace
 
 int main(int argc, char** argv) {
     Opts o;
+    int chromosomes = 1, threads = 0;
+    uint64_t filler_reads = 0, filler_len = 0;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&](const char* name) -> const char* {
@@ -123,12 +179,78 @@ int main(int argc, char** argv) {
         else if (a == "--variant-per-mb") o.variant_per_mb = atof(val("--variant-per-mb"));
         else if (a == "--no-variants") o.variants = false;
         else if (a == "--hairpin-frac") o.hairpin_frac = atof(val("--hairpin-frac"));
+        else if (a == "--chromosomes") chromosomes = std::max(1, atoi(val("--chromosomes")));
+        else if (a == "--threads") threads = atoi(val("--threads"));
+        else if (a == "--filler-reads") filler_reads = strtoull(val("--filler-reads"), nullptr, 0);
+        else if (a == "--filler-len") filler_len = strtoull(val("--filler-len"), nullptr, 0);
         else { fprintf(stderr, "hxsim: unknown option %s\n", a.c_str()); return 2; }
     }
+    if (o.model != "nanopore" && o.model != "perfect" && o.model != "pacbio") { fprintf(stderr, "hxsim: unknown model %s\n", o.model.c_str()); return 2; }
+    if (filler_reads && (filler_len < 1 || filler_len > 0xfffffff0ull)) { fprintf(stderr, "hxsim: --filler-len must be 1 .. 2^32 - 16\n"); return 2; }
+    SimStats tot;
+    FileSink out;
+    out.prefix = o.prefix;
+    if (!out.open_reads()) { perror("hxsim: reads/paf"); return 1; }
+    if (filler_reads) {   // unreferenced reads ahead of the real ones: no PAF record names them
+        std::string blk((size_t)std::min<uint64_t>(filler_len, 1u << 24), 'A');
+        for (uint64_t f = 0; f < filler_reads; f++) {
+            fprintf(out.fr, ">%" PRIu64 "\n", out.read_id++);
+            for (uint64_t w = 0; w < filler_len; w += blk.size()) fwrite(blk.data(), 1, (size_t)std::min<uint64_t>(blk.size(), filler_len - w), out.fr);
+            fputc('\n', out.fr);
+        }
+    }
+    if (chromosomes == 1) {
+        if (int rc = simulate(o, out, tot)) return rc;
+    } else {
+        // K chromosomes on T threads into memory (local ids), then written in chromosome order with the ids running on
+        if (threads <= 0) threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), (unsigned)chromosomes);
+        std::vector<MemSink> ms((size_t)chromosomes);
+        std::vector<SimStats> sts((size_t)chromosomes);
+        std::vector<int> rcs((size_t)chromosomes, 0);
+        std::atomic<int> next{0};
+        auto work = [&]() {
+            for (;;) {
+                const int k = next.fetch_add(1);
+                if (k >= chromosomes) break;
+                Opts ok = o;
+                ok.glen = o.glen / chromosomes; ok.seed = o.seed + 7919ull * (uint64_t)k;
+                rcs[(size_t)k] = simulate(ok, ms[(size_t)k], sts[(size_t)k]);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; t++) th.emplace_back(work);
+        for (auto& t : th) t.join();
+        for (int rc : rcs) if (rc) return rc;
+        FILE* fc = fopen((o.prefix + ".contigs.fa").c_str(), "w");
+        FILE* fg = fopen((o.prefix + ".genome.fa").c_str(), "w");
+        if (!fc || !fg) { perror("hxsim: contigs/genome"); return 1; }
+        size_t cbase = 0;
+        for (int k = 0; k < chromosomes; k++) {
+            MemSink& m = ms[(size_t)k];
+            for (size_t id = 0; id < m.cs.size(); id++) fprintf(fc, ">%zu LN:i:%zu KC:i:%u km:f:%.3f\n%s\n", cbase + id, m.cs[id].seq.size(), m.cs[id].kc, m.cs[id].km, m.cs[id].seq.c_str());
+            fprintf(fg, ">chr%d\n%s\n", k, m.g.c_str());
+            for (MemSink::Rd& r : m.reads) {
+                for (Hit& h : r.hits) h.tid += (uint32_t)cbase;
+                out.read(r.seq, r.rlen, r.hits);
+            }
+            cbase += m.cs.size();
+            tot.contigs += sts[(size_t)k].contigs; tot.families += sts[(size_t)k].families; tot.molecules += sts[(size_t)k].molecules;
+            tot.reads += sts[(size_t)k].reads; tot.bases += sts[(size_t)k].bases; tot.hits += sts[(size_t)k].hits;
+            m = MemSink();
+        }
+        fclose(fc); fclose(fg);
+    }
+    fclose(out.fr); fclose(out.fp);
+    fprintf(stderr, "hxsim: genome=%" PRId64 " contigs=%zu (repeat families=%zu) molecules=%zu reads=%" PRIu64 " bases=%" PRIu64 " hits=%" PRIu64 "\n",
+            o.glen, tot.contigs, tot.families, tot.molecules, tot.reads, tot.bases, tot.hits);
+    return 0;
+}
+
+namespace {
+int simulate(Opts o, Sink& sink, SimStats& st) {
     ErrModel em{0.08, 0.03, 0.02};
     if (o.model == "nanopore") { em = {0.03, 0.05, 0.04}; o.read_median = 7000; o.read_sigma = 0.8; }
     else if (o.model == "perfect") em = {0, 0, 0};
-    else if (o.model != "pacbio") { fprintf(stderr, "hxsim: unknown model %s\n", o.model.c_str()); return 2; }
 
     Rng rng(o.seed);
     // ---------------------------------------------------------------- genome + repeats
@@ -292,17 +414,8 @@ int main(int argc, char** argv) {
     {
         std::vector<uint32_t> order(contigs.size());
         for (size_t i = 0; i < contigs.size(); i++) order[new_id[i]] = i;
-        FILE* fc = fopen((o.prefix + ".contigs.fa").c_str(), "w");
-        if (!fc) { perror("hxsim: contigs"); return 1; }
-        for (size_t id = 0; id < order.size(); id++) {
-            const Contig& c = contigs[order[id]];
-            fprintf(fc, ">%zu LN:i:%zu KC:i:%u km:f:%.3f\n%s\n", id, c.seq.size(), c.kc, c.km, c.seq.c_str());
-        }
-        fclose(fc);
-        FILE* fg = fopen((o.prefix + ".genome.fa").c_str(), "w");
-        if (!fg) { perror("hxsim: genome"); return 1; }
-        fprintf(fg, ">genome\n%s\n", axes[0].c_str());
-        fclose(fg);
+        sink.contigs(contigs, order);
+        sink.genome(axes[0]);
     }
     // placements per axis sorted by start
     std::vector<std::vector<Placement>> axis_places(axes.size());
@@ -310,12 +423,7 @@ int main(int argc, char** argv) {
     for (auto& v : axis_places) std::sort(v.begin(), v.end(), [](const Placement& a, const Placement& b) { return a.s < b.s; });
 
     // ---------------------------------------------------------------- reads + PAF
-    FILE* fr = fopen((o.prefix + ".reads.fa").c_str(), "w");
-    FILE* fp = fopen((o.prefix + ".paf").c_str(), "w");
-    if (!fr || !fp) { perror("hxsim: reads/paf"); return 1; }
     uint64_t read_id = 0, total_bases = 0, total_hits = 0;
-
-    struct Hit { uint32_t qs, qe, tid, tlen, ts, te, nm, nb; bool rev; uint8_t mapq; std::string cg; };
     std::string tmpl, rseq;
     std::vector<uint32_t> t_axis_piece;       // piece index of each template base
     std::vector<char> col_op;                 // per column: 'M' match, 'X' mismatch, 'I', 'D'
@@ -432,19 +540,13 @@ int main(int argc, char** argv) {
             if (read_rev) for (Hit& h : hits) { const uint32_t qs = h.qs; h.qs = rlen - h.qe; h.qe = rlen - qs; h.rev = !h.rev; }
             std::sort(hits.begin(), hits.end(), [](const Hit& x, const Hit& y) { return x.qs != y.qs ? x.qs < y.qs : x.qe < y.qe; });
             std::string out = read_rev ? revcomp(rseq) : rseq;
-            fprintf(fr, ">%" PRIu64 "\n%s\n", read_id, out.c_str());
-            for (const Hit& h : hits) {
-                fprintf(fp, "%" PRIu64 "\t%u\t%u\t%u\t%c\t%u\t%u\t%u\t%u\t%u\t%u\t%u\ttp:A:P\tcm:i:%u\ts1:i:%u\tcg:Z:%s\n",
-                        read_id, rlen, h.qs, h.qe, h.rev ? '-' : '+', h.tid, h.tlen, h.ts, h.te, h.nm, h.nb,
-                        (unsigned)h.mapq, h.nm / 10, h.nm, h.cg.c_str());
-                total_hits++;
-            }
+            sink.read(out, rlen, hits);
+            total_hits += hits.size();
             total_bases += rlen;
             read_id++;
         }
     }
-    fclose(fr); fclose(fp);
-    fprintf(stderr, "hxsim: genome=%" PRId64 " contigs=%zu (repeat families=%zu) molecules=%zu reads=%" PRIu64 " bases=%" PRIu64 " hits=%" PRIu64 "\n",
-            o.glen, contigs.size(), fam_unit.size(), mols.size(), read_id, total_bases, total_hits);
+    st.contigs = contigs.size(); st.families = fam_unit.size(); st.molecules = mols.size(); st.reads = read_id; st.bases = total_bases; st.hits = total_hits;
     return 0;
 }
+}  // namespace
