@@ -15,8 +15,10 @@ reported under "configs1" (`--workload ecoli` makes it the main line instead); c
 the one GPU as well and reported under "configs3" (the many-edge regime: throughput, not one edge's chain).
 N>1: reads sharded by id range, ONE all-gather of edge records (RCCL), edges sharded by estimated DP cost for
 coordinates + consensus, one all-gather of the results; the ranks agree on success before every collective.
-N = 4 runs BASELINE.json configs[3] as it is named (140 Mb PacBio-like, read-sharded over 4 GPUs); N = 2, 8 scale the
-12 Mb genome x N (weak scaling; `config.workload` says which). After the timed steps every rank stitches the
+N = 4 runs BASELINE.json configs[3] as it is named (140 Mb PacBio-like, read-sharded over 4 GPUs); N = 2 and N = 8 give every GPU a 140 Mb
+chromosome's worth (280 Mb; 1.12 Gb = the shape of configs[4] at 0.36 x its size): the many-edge regime the north star's target lives in
+(`config.workload` says which). Launched WITHOUT torch.distributed.run, `--gpus N` runs the product binary's own multi-GPU path instead: N ranks
+inside this process (hx_group_create, one RCCL all-gather in hx_edge_merge, hxh_runs_all_sharded - what `haslr_assemble --gpus N` runs). After the timed steps every rank stitches the
 assembly, the ranks' assemblies must be identical, and rank 0 repeats the pass on its GPU alone and requires the
 same assembly (`assembly.matches_single_gpu`).
 
@@ -56,20 +58,38 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def make_dataset(wl, genome_len, tag):
+def make_dataset(wl, genome_len, tag, chromosomes=1):
+    """chromosomes > 1: the genome as that many independent chromosomes, simulated in parallel (tools/hxsim --chromosomes: chromosome k with seed + 7919 k)"""
     d = os.environ.get("HASLR_BENCH_DIR", "/tmp/haslr_bench")
     os.makedirs(d, exist_ok=True)
     seed = SEED0 + wl["config"]
-    pre = os.path.join(d, f"{tag}_{wl['model']}_g{genome_len}_s{seed:x}")
+    pre = os.path.join(d, f"{tag}_{wl['model']}_g{genome_len}_s{seed:x}" + (f"_c{chromosomes}" if chromosomes > 1 else ""))
     if not all(os.path.exists(pre + s) for s in (".contigs.fa", ".reads.fa", ".paf", ".done")):
         sim = os.path.join(ROOT, "tools", "hxsim")
         if not os.path.exists(sim):
             import __graft_entry__
             __graft_entry__.build()
+        extra = ["--chromosomes", str(chromosomes)] if chromosomes > 1 else []
         subprocess.check_call([sim, "--genome-len", str(genome_len), "--seed", hex(seed), "--model", wl["model"], "--cov", "25",
-                               "--variant-per-mb", wl["variants"], "--out-prefix", pre], stderr=subprocess.DEVNULL)
+                               "--variant-per-mb", wl["variants"], "--out-prefix", pre] + extra, stderr=subprocess.DEVNULL)
         open(pre + ".done", "w").close()
     return pre
+
+
+def multi_gpu_workload(world, workload=None, genome_len=0):
+    """What N > 1 GPUs run by default - the MANY-EDGE regime the north star's target lives in (thousands of edges per GPU: throughput, not one edge's
+    chain): N = 4 is BASELINE configs[3] as named (140 Mb read-sharded over 4 GPUs, fixed size); N = 2 and N = 8 give every GPU a 140 Mb chromosome's
+    worth (280 Mb / 1.12 Gb: weak scaling; N = 8 = the shape of configs[4] - CHM1, 3.1 Gb on 8 GPUs - at 0.36 x its size, which is what fits the
+    driver's run time: ~1 min to simulate in parallel, ~70 GB of text). Returns (workload key, genome length, chromosomes, as_named)."""
+    if workload is None:
+        workload = "fly" if world > 1 else "yeast"
+    wl = WORKLOADS[workload]
+    as_named = workload == "fly" and world == 4
+    if genome_len:
+        return workload, genome_len, max(1, world if genome_len >= 2 * 17_000_000 else 1), False
+    if world == 1 or as_named:
+        return workload, wl["genome"], 1, as_named
+    return workload, wl["genome"] * world, world if workload == "fly" else 1, False
 
 
 def gfa_digest(out_dir):
@@ -111,8 +131,8 @@ def cpu_baseline(ds, gpu_cns, gpu_gfa=None, work_dir=None):
                       f"(chain -> graph -> coordinates -> consensus); oracle/liboracle.so, POA row kernels {orclib.lib().orc_poa_kernel_name().decode()}, "
                       f"{main['threads']} threads over edges (costliest first) in {main['seconds']:.2f} s",
             "gcups": main["gcups"], "consensus_equals_gpu": all(r["consensus_equals_gpu"] for r in runs), "gfa_equals_gpu": gfa_equal, "host_cores": ncpu, "runs": runs,
-            "note": "stand-in for '64-thread CPU haslr_assemble' (the reference cannot be built here: spoa 1.1.3 is not vendored); int32 AVX2 lanes, "
-                    "spoa's engine would use int16 lanes where scores fit"}
+            "note": "stand-in for '64-thread CPU haslr_assemble' (the reference cannot be built here: spoa 1.1.3 is not vendored); AVX2 rows, 16 x int16 where "
+                    "8 x (nodes + columns) fits 16 bits (the dispatch of spoa's SIMD engine), 8 x int32 elsewhere"}
 
 
 def measure(ctx, ds, prm, table, steps, warmup, world, rank, sync, gather, lr_begin, sharded=None):
@@ -149,6 +169,101 @@ def measure(ctx, ds, prm, table, steps, warmup, world, rank, sync, gather, lr_be
     return time.perf_counter() - t0, last
 
 
+def run_group(args):
+    """`--gpus N` without a launcher: the product binary's multi-GPU path driven from here - N ranks INSIDE this process (hx_group_create: one context +
+    one RCCL communicator per rank; HASLR_GROUP_TRANSPORT=host stages the exchange through host memory and lets the ranks share a device: the
+    rehearsal on a one-GPU box), hxh_runs_all_sharded = one host thread per rank: chain (own reads) -> hx_edge_merge (ONE ncclAllGather of the packed
+    records) -> cleaning (redundant) -> coordinates + consensus (own share of the queue, LPT) -> results through the process's memory -> rank 0
+    assembles. A step is timed from its start to the end of the consensus stage (the assembly that the call also makes is outside the metric)."""
+    import ctypes as C
+
+    from haslr_amd import ctypes_defs as T
+    from haslr_amd import hip, host
+    n = args.gpus
+    workload, glen, chroms, as_named = multi_gpu_workload(n, args.workload, args.genome_len)
+    wl = WORKLOADS[workload]
+    pre = make_dataset(wl, glen, "gpu", chroms)
+    t0 = time.perf_counter()
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    t_parse = time.perf_counter() - t0
+    prm = ds.params()
+    L, H = hip.lib(), host.lib()
+    g = C.c_void_p()
+    tr = os.environ.get("HASLR_GROUP_TRANSPORT")
+    if L.hx_group_create(n, None, tr.encode() if tr else None, C.byref(g)) != 0:
+        raise SystemExit("bench.py --gpus %d (in-process group): %s" % (n, L.hx_last_error().decode()))
+    transport = L.hx_group_transport(g).decode()
+    bounds = host.shard_bounds(ds, n)
+    tables = [T.Backend() for _ in range(n)]
+    t1 = time.perf_counter()
+    for r in range(n):
+        c = L.hx_group_ctx(g, r)
+        for k, v in hip.env_options().items():
+            if L.hx_set_option(c, k.encode(), str(v).encode()) != 0:
+                raise SystemExit(L.hx_last_error().decode())
+        if L.hx_upload(c, C.byref(ds.contigs), C.byref(ds.reads), C.byref(ds.hits), ds.read_hit_off) != 0 or L.hx_set_read_shard(c, bounds[r], bounds[r + 1]) != 0:
+            raise SystemExit(L.hx_last_error().decode())
+        L.hx_group_backend_fill(g, r, C.byref(tables[r]))
+    t_upload = time.perf_counter() - t1
+    marks = {}
+    cb_t = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_void_p)
+    cb = cb_t(lambda stage, begin, _u: marks.__setitem__((stage, begin), time.perf_counter()))
+    rb = (C.c_uint32 * n)(*bounds[:n])
+
+    def step():
+        runs = [host.Run(ds, prm, tables[r], None) for r in range(n)]
+        hs = (C.c_void_p * n)(*[r._h for r in runs])
+        ts = time.perf_counter()
+        if H.hxh_runs_all_sharded(hs, n, rb, cb, None) != 0:
+            raise SystemExit("hxh_runs_all_sharded: " + H.hxh_last_error().decode())
+        return runs, marks[(3, 0)] - ts, {k: marks[(k, 0)] - marks[(k, 1)] for k in range(5)}
+
+    for _ in range(args.warmup):
+        for r in step()[0]:
+            r.close()
+    total, last, stages = 0.0, None, None
+    for _ in range(args.steps):
+        if last:
+            for r in last:
+                r.close()
+        last, dt, stages = step()
+        total += dt
+        log(f"[group of {n}] step {dt:.3f} s  stages {stages}")
+    by, ms = C.c_uint64(), C.c_double()
+    L.hx_group_exchange_stats(g, C.byref(by), C.byref(ms))
+    fasta = last[0].assembly_fasta()
+    sha = hashlib.sha256(fasta.encode()).hexdigest()
+    cells = sum(r.cns_stats()["dp_cells"] for r in last)
+    n_edges = last[0].n_edges_total
+    # the same data through ONE rank (device 0, plain context): the sharded assembly must equal it
+    for r in last:
+        r.close()
+    L.hx_group_destroy(g)
+    ctx = hip.HipContext(0)
+    ctx.upload(ds)
+    solo = host.Run(ds, prm, ctx.backend(), None)
+    t0 = time.perf_counter()
+    solo.all()
+    t_solo = time.perf_counter() - t0
+    same = hashlib.sha256(solo.assembly_fasta().encode()).hexdigest() == sha
+    solo.close(); ctx.close()
+    line = {"metric": "long-read bases/sec through backbone+consensus; GFA match + FASTA %identity", "value": ds.total_read_bases * args.steps / total, "unit": "long-read bases/s",
+            "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": total / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "fixed-size (configs[3] as named)" if as_named else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"{wl['name']}: {glen} bp genome in {chroms} chromosome(s), {wl['model']}-like 25x long reads + PAF vs short-read contigs (BASELINE.json configs[{wl['config']}]"
+                                   + (", read-sharded over %d GPUs as BASELINE names it)" % n if as_named else " x%d, read-sharded)" % n),
+                       "launch": f"in-process group: {n} ranks as threads of this process (hx_group_create / hx_edge_merge / hxh_runs_all_sharded = haslr_assemble --gpus {n}), transport {transport}",
+                       "reads": ds.reads.n, "long_read_bases": ds.total_read_bases, "paf_records": ds.hits.n, "edges": int(n_edges),
+                       "parallelism": f"reads+edges sharded x{n}, 1 all-gather of edge records ({transport}), results through process memory",
+                       "edge_record_exchange_bytes": by.value, "edge_record_exchange_ms": ms.value},
+            "stage_s": stages, "dp_cells_per_step": cells,
+            "assembly": {"sha256": sha, "contigs": fasta.count(">"), "matches_single_gpu": same, "single_gpu_pass_s": t_solo},
+            "ingest": {"seconds": t_parse, "upload_seconds_all_ranks": t_upload}}
+    print(json.dumps(line), flush=True)
+    if not same:
+        raise SystemExit("in-process group: the sharded assembly differs from the single-GPU pass")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,7 +289,7 @@ def main():
     # gave, also 1: a one-GPU box then executes the RCCL collectives of the multi-GPU path for real
     dist_on = world > 1 or os.environ.get("HASLR_BENCH_FORCE_DIST") == "1"
     if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        return run_group(args)                     # no launcher: the ranks live inside this process, like haslr_assemble --gpus N
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     # HASLR_DIST_BACKEND=gloo (testing): the N>1 path on a box with fewer GPUs than ranks - ranks share devices, collectives go through host memory
@@ -192,16 +307,13 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
-    if args.workload is None:
-        args.workload = "fly" if world == 4 else "yeast"   # BASELINE.json configs[3] is quoted on 4 GPUs; N = 2, 8: the yeast-size genome x N (weak scaling)
+    args.workload, glen, chroms, as_named = multi_gpu_workload(world, args.workload, args.genome_len)
     wl = WORKLOADS[args.workload]
-    as_named = args.workload == "fly" and world == 4       # the configuration exactly as BASELINE names it: no x N
-    glen = args.genome_len or (wl["genome"] if as_named else wl["genome"] * world)
     if rank == 0:
-        make_dataset(wl, glen, "gpu")
+        make_dataset(wl, glen, "gpu", chroms)
     if dist_on:
         dist.barrier()
-    pre = make_dataset(wl, glen, "gpu")
+    pre = make_dataset(wl, glen, "gpu", chroms)
     t0 = time.perf_counter()
     ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")   # multi-threaded ingest, automatic thread count
     t_parse = time.perf_counter() - t0
@@ -342,7 +454,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "single GPU" if world == 1 else "fixed-size (configs[3] as named)" if as_named else "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{wl['name']}: {glen} bp genome, {wl['model']}-like 25x long reads + PAF vs short-read contigs "
-                                   f"(BASELINE.json configs[{wl['config']}]{(', read-sharded over %d GPUs as BASELINE names it' % world) if as_named else (' x%d, read-sharded' % world if world > 1 else '')})",
+                                   f"(BASELINE.json configs[{wl['config']}]{(', read-sharded over %d GPUs as BASELINE names it' % world) if as_named else ((' x%d = %d chromosomes, read-sharded' % (world, chroms)) + ('; the shape of configs[4] at %.2f x its size' % (glen / 3.1e9) if world == 8 else '') if world > 1 else '')})",
                        "reads": ds.reads.n, "long_read_bases": ds.total_read_bases, "paf_records": ds.hits.n, "edges": int(n_edges),
                        "poa_block_threads": args.poa_block or "auto", "parallelism": f"reads+edges sharded x{world}, 1 all-gather of edge records + 1 of results" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -124,6 +124,8 @@ struct HxOptions {
     int poa_balance = 1, poa_balance_pct = 125, poa_balance_lanes = 512;
     int poa_slots_pct = 100, poa_slots = 0, poa_batches = 0, poa_force_cm = 0, poa_no_xcd_map = 0, poa_streams = 8, poa_wide_delay_us = 60;
     int poa_prune = -1;            // exact score-bound pruning of the DP: -1 automatic (calls of thousands of edges), 0 never, else the threshold's percentage of the previous alignment's score per base
+    int poa_pass_lanes = -1;       // column passes: unshared multi-wave edges run in workgroups of this many lanes, their DP columns in windows taken one after the other (-1 automatic: 256 where the rows are pruned; 0 never)
+    int poa_prune_lazy = 1;        // ... a wave that skipped a whole batch of rows polls for the next one rarely (0: like any wave)
     int poa_prune_lanes = 128;     // ... in launches of workgroups of at least this many lanes (a one-wave workgroup has no block to skip)
     int coords_lds_supp = -1;      // supports per edge the coordinate kernel sorts in LDS (testing: 0 sends every edge through the global scratch)
 };
@@ -138,7 +140,7 @@ const OptDesc kOptions[] = {
     {"poa_balance_pct", &HxOptions::poa_balance_pct, nullptr}, {"poa_balance_lanes", &HxOptions::poa_balance_lanes, nullptr}, {"poa_slots_pct", &HxOptions::poa_slots_pct, nullptr},
     {"poa_slots", &HxOptions::poa_slots, nullptr}, {"poa_batches", &HxOptions::poa_batches, nullptr}, {"poa_force_cm", &HxOptions::poa_force_cm, nullptr},
     {"poa_no_xcd_map", &HxOptions::poa_no_xcd_map, nullptr}, {"poa_streams", &HxOptions::poa_streams, nullptr}, {"poa_wide_delay_us", &HxOptions::poa_wide_delay_us, nullptr},
-    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
+    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
 };
 }  // namespace
 
@@ -601,12 +603,12 @@ struct PoaInput {
     const uint32_t* d_rlen;
 };
 
-struct Need { uint64_t nn = 0, ec = 0, hc = 0, dc = 0, wc = 0, lm = 0, st = 0, al = 0; };
+struct Need { uint64_t nn = 0, ec = 0, hc = 0, dc = 0, wc = 0, lm = 0, st = 0, al = 0, mb = 0; };
 inline void need_max(Need& a, const Need& b) {
     a.nn = std::max(a.nn, b.nn); a.ec = std::max(a.ec, b.ec); a.hc = std::max(a.hc, b.hc); a.dc = std::max(a.dc, b.dc); a.wc = std::max(a.wc, b.wc);
-    a.lm = std::max(a.lm, b.lm); a.st = std::max(a.st, b.st); a.al = std::max(a.al, b.al);
+    a.lm = std::max(a.lm, b.lm); a.st = std::max(a.st, b.st); a.al = std::max(a.al, b.al); a.mb = std::max(a.mb, b.mb);
 }
-inline uint64_t need_bytes(const Need& n) { return n.nn * 90 + n.ec * 28 + n.hc * 4 + n.dc + n.wc + n.lm + n.st * 4 + n.al * 8; }
+inline uint64_t need_bytes(const Need& n) { return n.nn * 90 + n.ec * 28 + n.hc * 4 + n.dc + n.wc + n.lm + n.st * 4 + n.al * 8 + n.mb * 8; }
 
 // launch classes: (shared?, lanes per workgroup, columns per lane, traceback flavour) - one kernel instance each, so that every
 // launch runs with the registers ITS row loop needs (kernels/poa.hip)
@@ -647,7 +649,7 @@ struct PoaCall {
     std::vector<uint32_t> mlanes;      // shared edges: lanes per member (the option's, or 1024 where the gap needs them to fit at all)
     // knobs of this round (the option, or what the number of edges in the call asks for)
     bool many_edges = false, balanced = false;
-    uint32_t cl_lanes = 256, cl_min = 2048, cl_max = 16, cl_pref = 16, cl_topk = 192, wide_k = 0, cl_cols = 4, cols_per_lane = 4, wave_max = 512, prune_pct = 0;
+    uint32_t cl_lanes = 256, cl_min = 2048, cl_max = 16, cl_pref = 16, cl_topk = 192, wide_k = 0, cl_cols = 4, cols_per_lane = 4, wave_max = 512, prune_pct = 0, pass_lanes = 0;
     uint64_t ring_kb_wave = 0;
     double balance_f = 1.25;
     uint32_t balance_nt = 512;
@@ -711,6 +713,11 @@ struct PoaCall {
         // multi-wave launches of a call whose CUs are all busy; a chain-bound call (hundreds of edges, the longest one is the step) gains nothing
         // from it - a row stays a row - so there the full-matrix instances run. poa_prune: -1 automatic, 0 never, else the percentage.
         prune_pct = o.poa_prune < 0 ? (many_edges ? 95u : 0u) : (uint32_t)o.poa_prune;
+        // Column passes (kernels/poa.hip): with the rows pruned, an edge's wave slots are mostly held by waves that skip - so the unshared multi-wave edges run
+        // in workgroups of `pass_lanes` lanes and take their columns window by window. The call is bound by wave-slot time (thousands of edges, every slot
+        // taken): an edge of 8 000 columns holds 4 waves instead of 16 for little more than the same time.
+        pass_lanes = prune_pct == 0 || cols_per_lane > 8 ? 0u : o.poa_pass_lanes < 0 ? 256u : (uint32_t)o.poa_pass_lanes;
+        if (pass_lanes != 0 && pass_lanes != 64 && pass_lanes != 128 && pass_lanes != 256 && pass_lanes != 512 && pass_lanes != 1024) return fail("option poa_pass_lanes must be 0, 64, 128, 256, 512 or 1024");
         if (cl_lanes != 64 && cl_lanes != 128 && cl_lanes != 256 && cl_lanes != 512 && cl_lanes != 1024) return fail("option poa_member_lanes must be 64, 128, 256, 512 or 1024");
         return 0;
     }
@@ -727,6 +734,7 @@ struct PoaCall {
         if (many_sinks[e]) return 1;   // (the 1024-lane kernel keeps the full sink list)
         if (c->poa_block) { for (k = 1; k < 5 && kClassNT[k] > c->poa_block; k++) {} }
         else if (ncol > wave_max) { k = 4; while (k > 1 && (uint64_t)kClassNT[k] * cols_per_lane < ncol) k--; }
+        if (P.edges[e].passes > 1) { for (int q = 1; q <= 5; q++) if ((uint32_t)kClassNT[q] == pass_lanes) return q; }   // (column passes: workgroups of pass_lanes lanes, whatever the gap length)
         while (k > 1 && (uint64_t)kClassNT[k] * kMaxCm[k] < ncol) k--;
         return k;
     }
@@ -757,6 +765,7 @@ struct PoaCall {
         // and doubles when a graph outgrows it, up to the proven bound (every base a node of its own).
         for (uint32_t e : todo) {
             hxk::PoaEdge& E = P.edges[e];
+            if (E.lmax + 1 >= (1u << 20)) return fail("hx_poa_batch: a gap sub-sequence of " + std::to_string(E.lmax) + " bases is longer than the POA kernel's score keys hold (1 048 574)");
             const uint64_t est = std::max<uint64_t>(1, (((uint64_t)E.lmax * (120 + 9 * (uint64_t)P.nseq[e])) / 100 + 1024) * est_pct / 100) << std::min<uint32_t>(grow[e], 20);
             const uint64_t vc = std::max<uint64_t>(std::min<uint64_t>(P.sumL[e], est), E.lmax);   // (never below one sequence: per-base scratch shares the node pools)
             if (vc >= 0x7fffffffULL) return fail("hx_poa_batch: POA graph too large");
@@ -771,7 +780,6 @@ struct PoaCall {
             // tail of a read" a real case) gets 1024-lane members, 16 of which hold 524 287 columns.
             E.members = 1; mlanes[e] = cl_lanes;
             const uint32_t ncol = E.lmax + 1;
-            if (ncol >= (1u << 20)) return fail("hx_poa_batch: a gap sub-sequence of " + std::to_string(ncol - 1) + " bases is longer than the POA kernel's score keys hold (1 048 574)");
             const bool may_share = !c->poa_block && !c->poa_no_dir && !force_nodir[e] && !many_sinks[e] && !no_share[e];
             if (may_share && ncol > cl_min) {
                 auto members_for = [&](uint32_t lanes) -> uint64_t {
@@ -782,7 +790,10 @@ struct PoaCall {
                 E.members = (uint32_t)mb;
             }
             if (E.members < 2 || ((uint64_t)ncol + (uint64_t)E.members * mlanes[e] - 1) / ((uint64_t)E.members * mlanes[e]) > 32) E.members = 1;   // (members too small for this gap: one workgroup)
-            if (E.members == 1 && ncol > 1024u * (uint32_t)hxk::poa_kernel_max_cm(1024))
+            E.passes = 1;
+            if (E.members == 1 && pass_lanes && !c->poa_block && !full_h[e] && !many_sinks[e] && ncol > wave_max && ncol > pass_lanes * cols_per_lane)
+                E.passes = (uint32_t)(((uint64_t)ncol + (uint64_t)pass_lanes * cols_per_lane - 1) / ((uint64_t)pass_lanes * cols_per_lane));
+            if (E.members == 1 && E.passes == 1 && ncol > 1024u * (uint32_t)hxk::poa_kernel_max_cm(1024))
                 return fail("hx_poa_batch: a gap sub-sequence of " + std::to_string(ncol - 1) + " bases needs the shared (cluster) mode - direction-byte traceback, automatic block size - with " +
                             std::to_string((ncol + 1024 * 32 - 1) / (1024 * 32)) + " members of 1024 lanes (option poa_cluster_max: " + std::to_string(cl_max) + ")");
         }
@@ -812,7 +823,7 @@ struct PoaCall {
             hxk::PoaEdge& E = P.edges[e];
             const uint32_t ncol = E.lmax + 1, nt = lanes_of(e);
             uint64_t rb;
-            const uint32_t cmq = cm_round(ncol, E.members > 1 ? E.members * nt : nt);
+            const uint32_t cmq = cm_round(ncol, E.members > 1 ? E.members * nt : nt * std::max<uint32_t>(1, E.passes));
             const uint32_t Rp = ring_rows_of(nt, cmq, rb);
             // measured on PacBio-like data, rows read back from HBM per DP row: 0.15-0.4 % with 8 ring rows, 3-5 % with 4, 16-25 % on average
             // with 2 (single edges: up to every kept row, ~60 % of the rows). Graphs fill ~70 % of the node estimate these are fractions of.
@@ -836,11 +847,12 @@ struct PoaCall {
     Need need_of(uint32_t e) const {
         const hxk::PoaEdge& E = P.edges[e];
         const uint64_t rw = ((uint64_t)E.lmax + 1 + 31) & ~31ull;                 // rows padded to 32 columns (the widest lane chunk)
-        const uint64_t waves = (uint64_t)E.members * (lanes_of(e) / 64);
+        const uint64_t waves = (uint64_t)E.members * std::max<uint32_t>(1, E.passes) * (lanes_of(e) / 64);
         const uint64_t rwh = rw + (waves > 1 ? (waves + 3) & ~3ull : 0);       // rows of H end with one word per wave of the edge's pipeline
         Need n;
         n.nn = (uint64_t)E.vcap + 1; n.ec = E.ecap; n.dc = full_h[e] ? 0 : n.nn * (rw / 2); n.hc = (uint64_t)E.hrows * rwh; n.wc = full_h[e] ? 0 : (uint64_t)E.wrows * rw;
         n.lm = E.lmax; n.st = 4 * n.nn + E.ecap; n.al = n.nn + E.lmax + 2;
+        n.mb = E.passes > 1 ? (uint64_t)E.passes * n.nn : 0;   // the carries handed from one column pass to the next
         return n;
     }
     // Thousands of edges: every launch class is persistent and would, on its own, ask for the whole chip (4096 waves) - six classes oversubscribe it six
@@ -876,7 +888,7 @@ struct PoaCall {
                 continue;
             }
             const uint32_t nt = (uint32_t)kClassNT[class_of(e)];
-            uint32_t cmq = cm_round(ncol, nt);
+            uint32_t cmq = cm_round(ncol, nt * std::max<uint32_t>(1, P.edges[e].passes));
             if (o.poa_force_cm > 0) cmq = std::max<uint32_t>(cmq, std::min<uint32_t>((uint32_t)o.poa_force_cm, (uint32_t)hxk::poa_kernel_max_cm((int)nt)));   // (testing: a wider kernel instance than the gap needs)
             cls_of(false, nt, cmq, !full_h[e]).edges.push_back(e);
         }
@@ -982,8 +994,8 @@ struct PoaCall {
         std::vector<hxk::PoaSlot> h_slots;
         uint64_t no = 0, eo = 0, ho = 0, dro = 0, wo = 0, so = 0, co = 0, sto = 0, ao = 0, clo = 0;
         auto add_slot = [&](const Need& n) {
-            h_slots.push_back(hxk::PoaSlot{no, eo, ho, dro, wo, so, sto, ao});
-            no += n.nn; eo += n.ec; ho += n.hc; dro += n.dc; wo += n.wc; so += n.lm; sto += n.st; ao += n.al;
+            h_slots.push_back(hxk::PoaSlot{no, eo, ho, dro, wo, so, sto, ao, clo});
+            no += n.nn; eo += n.ec; ho += n.hc; dro += n.dc; wo += n.wc; so += n.lm; sto += n.st; ao += n.al; clo += n.mb;
         };
         arrange(classes, shrink);
         for (Cls& q : classes) {
@@ -1094,7 +1106,7 @@ struct PoaCall {
             L.match = pp->match; L.mismatch = pp->mismatch; L.gap = pp->gap; L.cns = c->poa_cns.p; L.cns_len = c->poa_len.p; L.status = c->poa_status.p;
             L.cells = c->poa_cells_d.p; L.phase = c->poa_phase_d.p; L.block_threads = (int)q.nt; L.cm = (int)q.cm; L.poll_limit = (uint32_t)o.poa_poll_limit; L.ring_bytes = (uint32_t)lds_bytes;
             L.use_dir = q.dir; L.max_indeg = (uint32_t)std::min(16, std::max(1, o.poa_max_indeg)); L.dp_lanes = q.dpl;
-            L.prune_pct = !q.shared && hxk::poa_prune_ok(q.dir, (int)q.cm) && q.nt >= (uint32_t)o.poa_prune_lanes ? prune_pct : 0u;   // (a one-wave workgroup has nothing to skip: its rows are whole rows)
+            L.prune_pct = !q.shared && hxk::poa_prune_ok(q.dir, (int)q.cm) && q.nt >= (uint32_t)o.poa_prune_lanes && prune_pct ? (std::min<uint32_t>(prune_pct, 1000u) | (o.poa_prune_lazy ? 1u << 16 : 0u)) : 0u;   // (a one-wave workgroup has nothing to skip: its rows are whole rows)
             hxk::poa_run(L, c->poa_streams[sk]);
             HIPCHK(hipEventRecord(c->poa_ev[sk], c->poa_streams[sk]));
             HIPCHK(hipStreamWaitEvent(s, c->poa_ev[sk], 0));

@@ -92,7 +92,7 @@ struct PoaEdge {
     uint32_t members;              // workgroups ("members", one CU each) that share this edge's DP columns; 1 = the usual single workgroup
     uint32_t wrows;                // rows of the wide-row pool (an estimate, overflow -> retry)
     uint32_t slot;                 // workspace slot of a shared edge (members > 1); other edges run in the slot of the workgroup that pulls them
-    uint32_t pad_;
+    uint32_t passes;               // column passes (members == 1): the workgroup's waves take the DP columns of a sequence in this many windows, one after the other (1: all at once)
 };
 // A workspace slot: offsets into the pools. A persistent workgroup owns one for its lifetime (sized for the largest edge of its launch), a shared
 // edge owns one for the call.
@@ -105,6 +105,7 @@ struct PoaSlot {
     uint64_t seq_off;              // into the decoded-sequence pool (bytes, lmax per edge)
     uint64_t stack_off;            // into the toposort stack pool (4*(vcap+1) + ecap entries per edge)
     uint64_t aln_off;              // into the alignment pools (vcap + lmax + 2 entries per edge)
+    uint64_t mbox_off;             // into the mailbox pool: passes x (vcap + 1) words for the carries handed from one column pass to the next (edges with passes > 1)
 };
 struct PoaPools {
     // per node (pool length = sum (vcap+1))

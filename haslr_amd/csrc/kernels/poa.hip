@@ -667,7 +667,13 @@ template <int CM> __device__ __forceinline__ void store_nibbles(uint8_t* p, cons
     }
 }
 
-// the same nibbles through a raw buffer resource (base = the row, range = its bytes): offsets beyond the range are not written
+// the same nibbles through a raw buffer resource (base = the row, range = its bytes): offsets beyond the range are not written.
+// Word 3 of the resource (0x00020000: raw, dword data format) and the rule the row loop relies on - "an access whose offset lies beyond num_records
+// is dropped" - are the gfx9 family's; gfx10+ / gfx12 encode the word differently and check ranges per format. This file is written for gfx950 only:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "kernels/poa.hip stores its nibble rows through a gfx9 raw buffer resource (written for gfx950): another target needs the predicated store_nibbles()"
+#endif
+// (the row's resource covers W / 2 bytes = exactly the pitch of the nibble matrix: dp_rows steps its row pointer by the same W >> 1)
 template <int CM> __device__ __forceinline__ void store_nibbles_buf(__amdgpu_buffer_rsrc_t r, const uint32_t off, const uint32_t (&v)[CM]) {
     static_assert(CM >= 4 && CM % 4 == 0, "4, 8, 16 or 32 columns per lane");
     uint32_t b[CM / 2];
@@ -702,7 +708,7 @@ template <int CM, bool DIR, bool PRUNE>
 __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, uint8_t* __restrict__ Dwide, const uint32_t W, const uint32_t WH, const uint8_t* __restrict__ seq,
                         const uint32_t L_, const uint32_t V_, int32_t* ring, const uint32_t R_, const uint32_t ring_w_, const int match, const int mismatch, const int gap,
                         unsigned long long* wm_box, uint32_t* wm_cons, uint32_t* sink_row, int* sink_score, const uint32_t sink_cap, uint32_t& nSinkOut, const DpCl& cl, unsigned long long* prof,
-                        const int thrT /* PRUNE: score threshold T of this alignment (PRUNE_OFF: nothing real is below it) */, unsigned long long* pstat /* PRUNE: wave-rows, wave-rows skipped */) {
+                        const int thrT /* PRUNE: score threshold T of this alignment (PRUNE_OFF: nothing real is below it) */, const uint32_t lazy_on /* PRUNE: skipped waves poll rarely */, unsigned long long* pstat /* PRUNE: wave-rows, wave-rows skipped */) {
     static_assert(!PRUNE || DIR, "pruned rows: direction-byte flavour only");
 #if defined(HX_DP_PROF) && !defined(HX_DP_PROF2)
     long long tprev = clock64();
@@ -850,7 +856,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     // row 0, 15 a row read back from HBM (always set: a skipped row with a far reader stores "nothing" there, so it may be read). Predecessors
     // whose flag is clear are not read at all (their registers / ring slot hold an older row). T is the caller's: poa_edge checks S >= T
     // afterwards and repeats the alignment otherwise. (kernels.h: PRUNE_OFF; oracle.cpp prune_sim = this rule on the CPU, a statistic.)
-    int thr_lane = 0; uint32_t FM = 0xffffu, n_dead = 0; int thr_cin = 0;
+    int thr_lane = 0; uint32_t FM = 0xffffu, n_dead = 0, lazy = 0; int thr_cin = 0;
     if constexpr (PRUNE) {
         const int mg = match - gap, thr_base = thrT - match * (int)L;
         const int c0 = (int)(gw * 64u * CM);
@@ -926,9 +932,12 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                     }
                     const unsigned long long okm = __ballot(ok);
                     const uint32_t run = okm == ~0ull ? want : (uint32_t)__builtin_ctzll(~okm);   // leading rows whose carries have arrived
-                    if (run >= min(want, CARRY_MIN)) { nb = run; cinV = (int)(uint32_t)(v >> 32); break; }
+                    // (PRUNE: a wave whose last batch was skipped whole is AHEAD of the band - it is not what its edge waits for, but a poll every ~130 cycles
+                    // takes issue slots from the waves that are: it waits for whole batches and sleeps 16 times as long between polls)
+                    if (run >= min(want, PRUNE && lazy ? want : CARRY_MIN)) { nb = run; cinV = (int)(uint32_t)(v >> 32); break; }
                     if (spin > (in_lds ? WG_POLL_LIMIT : cl.poll_limit)) { if (lane == 0) st_dev(cl.err, in_lds ? 2u : 1u); break; }
-                    if (in_lds) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(8);
+                    if (PRUNE && lazy) __builtin_amdgcn_s_sleep(32);
+                    else if (in_lds) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(8);
                 }
                 if (in_lds && lane == 0) st_wg(cons_in, cl.tag0 + i0 + nb - 1);   // the entries of these rows may be written again
 #ifdef HX_DP_PROF3
@@ -946,7 +955,31 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             }
             // (a row's record words are read out of their lane during the row BEFORE: a scalar instruction that consumes a readlane's result at once
             // waits ~14 cycles for it)
+            if constexpr (PRUNE) {
+                // A whole batch skipped at once: nothing in the ring or the previous row is flagged (FM), no carry of the batch is live, and no row of it
+                // names a predecessor outside those (the virtual row 0, a row in HBM, a fifth predecessor) or is itself read back from HBM (it would have
+                // to store "nothing" there) - all of it read off the 64 row records in their lanes. The batch's carries go out as one vector store.
+                if ((FM & 0x3ffeu) == 0u) {
+                    const bool in_b = lane >= rb && lane < rb + nb;                                   // this lane's record belongs to the batch
+                    const uint32_t np_l = mC >> META_NP;
+                    const bool risky = in_b && ((aC >> 28) >= 14u || (np_l > 1u && (bC >> 28) >= 14u) || (np_l > 2u && (cC >> 28) >= 14u) || (np_l > 3u && (dC >> 28) >= 14u) || np_l > 4u || (mC & 8u) != 0u);
+                    const bool clive = lane < nb && cinV >= thr_cin;
+                    if (__builtin_amdgcn_ballot_w64(risky || clive) == 0ull) {
+                        if (lane < nb) {
+                            const unsigned long long ent = (unsigned long long)(tag0_s + i0 + lane) | ((unsigned long long)(uint32_t)cinV << 32);
+                            if (out_l != 0u) st_wg64(mb_out_l + ((i0 + lane) & (WAVE_MBOX - 1)), ent);
+                            if (out_h != 0u) st_dev64(mb_out_h + i0 + lane, ent);
+                        }
+                        n_dead += nb;
+                        const unsigned long long dp_ = (((unsigned long long)dhi << 32) | dlo) + (unsigned long long)dstep_s * nb;
+                        dlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dp_); dhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dp_ >> 32));
+                        lazy = lazy_on;
+                        continue;
+                    }
+                }
+            }
             uint32_t meta_nx = __builtin_amdgcn_readlane(mC, rb), p0_nx = __builtin_amdgcn_readlane(aC, rb);
+            const uint32_t dead_before = n_dead;
             for (uint32_t rj = 0; rj < nb; rj++) {
                 const uint32_t ri = rb + rj, i = ib + ri + 1;
                 const uint32_t meta = meta_nx, p0 = p0_nx;
@@ -1156,6 +1189,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                     }
                 }
             }
+            if constexpr (PRUNE) lazy = (uint32_t)(n_dead - dead_before == nb) & lazy_on;
         }
     }
     if (owns_last) nSinkOut = nsink;
@@ -1225,7 +1259,13 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     }
     uint8_t* seq = P.seq + SL.seq_off;
     const uint32_t W = (ED.lmax + 1 + 31) & ~31u;   // row stride: a multiple of the widest lane chunk (32 columns), so chunks are vector-aligned and stay inside their row
-    const uint32_t WH = W + (GM * (DL >> 6) > 1 ? (GM * (DL >> 6) + 3u) & ~3u : 0u);   // rows of H end with one word per wave of the edge's pipeline (dp_rows)
+    // Column passes (round 5): an unshared edge whose sequences are wider than its workgroup takes the DP columns in NP windows of DL lanes x CM columns, one
+    // after the other - the same pipeline as NP cluster members (member p = window p: the carries of a window's last column travel through the HBM
+    // mailbox, complete before the next window starts), run by ONE workgroup. With the pruned rows most of a window's rows are skipped in bulk, so a
+    // pass costs little more than the rows its window shares with the live band, and the edge holds NP times fewer wave slots while it runs.
+    const uint32_t NP = GM == 1 && ED.passes > 1 ? ED.passes : 1u;
+    const uint32_t WT = GM * NP * (DL >> 6);             // waves of the edge's whole pipeline
+    const uint32_t WH = W + (WT > 1 ? (WT + 3u) & ~3u : 0u);   // rows of H end with one word per wave of the edge's pipeline (dp_rows)
 
     // static LDS is kept small for the launches that can share a CU: sink rows kept in LDS (an alignment ends in at most one sink per sequence
     // aligned so far; an edge with more than 256 is redone by the 1024-lane kernel), wave mailboxes for the waves the launch can have
@@ -1249,11 +1289,11 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     int32_t* sinkbuf = P.sinkbuf + (uint64_t)eidx * (1 + 2 * SINK_CAP);
     DpCl cl;
     cl.mem = mem; cl.members = GM; cl.stride = ED.vcap + 1; cl.tag0 = 0;
-    cl.mbox = P.mbox + ED.cl_off; cl.err = csy + 4; cl.poll_limit = poll_limit; cl.lanes = DL;
+    cl.mbox = P.mbox + (NP > 1 ? SL.mbox_off : ED.cl_off); cl.err = csy + 4; cl.poll_limit = poll_limit; cl.lanes = DL;
     constexpr uint32_t CL_ABORT = 0xffffffffu;
 #define HX_DP_DISPATCH(Lq, Vq, nsq, Tq) do { \
-        if (((Lq) + 1 + GM * DL - 1) / (GM * DL) <= (uint32_t)CM) {    /* the host puts an edge into a launch whose columns per lane hold its longest sequence */ \
-            dp_rows<CM, DIR, PRUNE>(g, H, Dm, Dw, W, WH, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, wmail.box, wmail.consumed, sink_row, sink_score, SINK_LDS, nsq, cl, ph + 6, Tq, ph + 12); \
+        if (((Lq) + 1 + GM * NP * DL - 1) / (GM * NP * DL) <= (uint32_t)CM) {    /* the host puts an edge into a launch whose columns per lane hold its longest sequence */ \
+            dp_rows<CM, DIR, PRUNE>(g, H, Dm, Dw, W, WH, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, wmail.box, wmail.consumed, sink_row, sink_score, SINK_LDS, nsq, cl, ph + 6, Tq, (prune_pct >> 16) & 1u, ph + 12); \
         } else sOk = 2; } while (0)
     // The reference's topological order (spoa's DFS, inherently serial) is needed in two places only: to break ties between equally scored
     // end nodes of an alignment, and for the heaviest-bundle traversal of the finished graph. The DP itself runs on a cheaper order that
@@ -1337,7 +1377,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
         int thrT = PRUNE_OFF;
         if constexpr (PRUNE) {
             if (GM == 1 && prune_pct != 0u && sPrevLen != 0u && V < (1u << 20)) {   // (2^20 rows: "nothing" keys lose at most a vertical move per row and must not wrap)
-                const float f = (float)prune_pct * 0.01f;
+                const float f = (float)(prune_pct & 0xffffu) * 0.01f;
                 float e = (float)sPrevScore * (float)L / (float)sPrevLen;
                 e = e >= 0.f ? e * f : e * (2.f - f);
                 thrT = (int)fmaxf((float)PRUNE_OFF, floorf(e));
@@ -1350,6 +1390,15 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
             const long long td0 = clock64();
             if (tid == 0) ph[6] = 0;
 #endif
+            if (NP > 1) {
+                for (uint32_t pass = 0; pass < NP && (uint64_t)pass * DL * CM <= L; pass++) {   // (a window beyond the sequence has nothing to do)
+                    cl.mem = pass; cl.members = NP;
+                    HX_DP_DISPATCH(L, V, ns, thrT);
+                    __threadfence();          // the carries of this window's last column, its far rows: visible to the next window's waves
+                    __syncthreads();
+                }
+                cl.mem = 0; cl.members = 1;
+            } else
             HX_DP_DISPATCH(L, V, ns, thrT);
 #ifdef HX_DP_PROF3
             if (tid == 0 && phase) atomicAdd(&phase[(uint64_t)eidx * POA_PHASE_WORDS + 6 + min(mem, 5u)], ((ph[6] >> 10) << 32) | ((unsigned long long)(clock64() - td0) >> 10));

@@ -137,9 +137,11 @@ class ShardedBackend:
         self.error = None
         self.pending_error = None
         self.stopped = None      # the RuntimeError of a count round that stopped all ranks
+        self.exchanged = False   # this pass's record exchange (its count round) has been entered: sharded_stages resets it per pass
 
     def _edge_support(self, _ctx, _prm, out):
         try:
+            self.exchanged = True
             n, local, err = 0, None, self.pending_error
             if err is None:
                 try:
@@ -207,32 +209,43 @@ def gather_results(run, device, group=None, err=None, text=None):
 def sharded_stages(run, device, group=None, backend=None, with_text=False):
     """chain -> graph (the record exchange happens inside) -> coords -> consensus -> gathered results: two exchanges, each a count round that
     also carries the ranks' verdicts on everything since the previous one, and one all-gather. Returns the bytes of results gathered
-    (with_text: and the merged compact_uniq text)."""
+    (with_text: and the merged compact_uniq text). `backend` (the rank's ShardedBackend) is required: a rank that fails before the record
+    exchange must still enter its count round - with its verdict - or the other ranks wait in the collective."""
+    if backend is None:
+        raise TypeError("sharded_stages needs the rank's ShardedBackend (failure agreement of the record exchange goes through it)")
+    backend.exchanged = False
+    backend.stopped = None
     err = None
     try:
         run.chain()
     except Exception as e:  # noqa: BLE001
         err = e
     if err is not None:
-        if backend is not None:
-            backend.fail_exchange(err)        # this rank's verdict reaches the count round of the record exchange: every rank stops there
+        backend.fail_exchange(err)        # this rank's verdict reaches the count round of the record exchange: every rank stops there
         raise err
-    if err is None:
-        # the record exchange inside fails on every rank together; what follows it on a rank - the import, the graph build, rank 0's GFA / stat /
-        # log files - can still fail alone: that verdict travels with the count round of the results exchange
-        try:
-            run.graph()
-        except Exception as e:  # noqa: BLE001
-            if backend is not None and backend.stopped is not None:
-                raise (backend.error if backend.error is not None and backend.error is not backend.stopped else backend.stopped)   # every rank is raising here
-            err = e
+    # the record exchange inside fails on every rank together; what follows it on a rank - the import, the graph build, rank 0's GFA / stat /
+    # log files - can still fail alone: that verdict travels with the count round of the results exchange
+    try:
+        run.graph()
+    except Exception as e:  # noqa: BLE001
+        if backend.stopped is not None:
+            raise (backend.error if backend.error is not None and backend.error is not backend.stopped else backend.stopped)   # every rank is raising here
+        if not backend.exchanged:
+            # the graph stage failed BEFORE it reached the record exchange: the other ranks are in (or on their way to) that count round, not the
+            # results one - this rank joins it with its verdict, and every rank stops there
+            backend.fail_exchange(e)
+            raise
+        err = e
+    text = None
     if err is None:
         try:
             run.coords()
             run.consensus()
+            if with_text:
+                text = run.compact_text()      # (inside the try: a failure here travels as this rank's verdict like any other)
         except Exception as e:  # noqa: BLE001
             err = e
-    n, text = gather_results(run, device, group, err, run.compact_text() if (with_text and err is None) else (b"" if with_text else None))
+    n, text = gather_results(run, device, group, err, text if (with_text and err is None) else (b"" if with_text else None))
     return (n, text) if with_text else n
 
 

@@ -25,8 +25,9 @@
 // Threads: the reference calls from gopt.num_threads pthreads, each with its own engine and graph (asm_cal_cns_seq_MT, Assemble.cpp:562-605).
 // All of them share one device context here (created on first use, device HASLR_DEVICE or 0), and their generate_consensus() calls are
 // FLAT-COMBINED: a caller queues its sequence set; the first one in becomes the submitter, waits HASLR_SPOA_BATCH_US microseconds (default
-// 200) or until HASLR_SPOA_BATCH sets (default 256) are queued, and sends everything queued through ONE hx_poa_sequences call; callers that
-// arrive while a call is on the device form the next batch. With -t 64 the reference's own thread fan-out therefore puts ~64 edges into
+// 200) or until HASLR_SPOA_BATCH sets (default 256) are queued - only while it has company: a lone caller (-t 1) submits at once - and sends
+// everything queued through ONE hx_poa_sequences call; callers that arrive while a call is on the device form the next batch. A set that makes the
+// shared call fail is isolated (every set of that call again, on its own): only its caller gets the exception. With -t 64 the reference's own thread fan-out therefore puts ~64 edges into
 // every launch instead of one. spoa::hx::consensus_batch() below is the entry to use from new code: all edges in one call (that is what
 // haslr_amd's own pipeline does through hx_poa_batch). spoa::hx::stats() tells how many device calls served how many sets.
 //
@@ -64,6 +65,8 @@ struct Device {
     std::condition_variable qcv;
     std::vector<Request*> queue;
     bool submitting = false;          // a submitter is collecting or has a batch on the device
+    bool company = false;             // the previous batch had, or its device call saw, more than one caller: the next submitter waits its window out
+    std::size_t arrivals = 0;         // requests queued since the current batch was taken
     std::uint64_t calls = 0, sets = 0;
     // (no destructor: this object is destroyed during static destruction, possibly after the HIP runtime has torn itself down -
     //  the context and its device memory are left to the end of the process; spoa::hx::shutdown() releases them explicitly)
@@ -128,36 +131,62 @@ inline std::string consensus_combined(const std::vector<std::string>& seqs, std:
     Device::Request me{&seqs, m, n, g, std::string(), std::string(), false};
     std::unique_lock<std::mutex> lk(d.qmu);
     d.queue.push_back(&me);
+    d.arrivals++;
     d.qcv.notify_all();                                        // (a submitter that is collecting counts the queue)
     while (!me.done) {
         if (d.submitting) { d.qcv.wait(lk); continue; }         // somebody else submits: my request rides along, or waits for the next batch
         d.submitting = true;                                    // I submit: collect for the window, then take everything queued
-        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us);
-        while (d.queue.size() < batch_max && d.qcv.wait_until(lk, until) != std::cv_status::timeout) { }
         std::vector<Device::Request*> batch;
-        batch.swap(d.queue);
-        if (batch.size() > batch_max) { d.queue.assign(batch.begin() + (std::ptrdiff_t)batch_max, batch.end()); batch.resize(batch_max); }
-        lk.unlock();
-        // one device call per score triple in the batch (the reference uses one triple)
-        std::vector<char> served(batch.size(), 0);
-        std::uint64_t calls = 0;
-        for (std::size_t i = 0; i < batch.size(); i++) {
-            if (served[i]) continue;
-            std::vector<std::size_t> idx;
-            std::vector<const std::vector<std::string>*> sets;
-            for (std::size_t j = i; j < batch.size(); j++)
-                if (!served[j] && batch[j]->m == batch[i]->m && batch[j]->n == batch[i]->n && batch[j]->g == batch[i]->g) { idx.push_back(j); sets.push_back(batch[j]->seqs); served[j] = 1; }
-            try {
-                std::vector<std::string> res = consensus_batch(sets, batch[i]->m, batch[i]->n, batch[i]->g);
-                for (std::size_t q = 0; q < idx.size(); q++) batch[idx[q]]->result.swap(res[q]);
-            } catch (const std::exception& e) {
-                for (std::size_t q : idx) batch[q]->error = e.what();
+        // Whatever goes wrong from here on (an allocation that throws as well), `submitting` is reset, the requests taken so far are answered (with
+        // the error) and the waiters are woken: no thread may be left waiting on a submitter that is gone.
+        try {
+            // The window is for company: a lone caller (the reference with -t 1, or the only thread that still has edges) would sit through it on
+            // every call for nothing. It is waited out only when somebody else has been seen since the previous batch closed (d.company), or is
+            // queued right now.
+            if (d.company || d.queue.size() > 1) {
+                const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us);
+                while (d.queue.size() < batch_max && d.qcv.wait_until(lk, until) != std::cv_status::timeout) { }
             }
-            calls++;
+            batch.swap(d.queue);
+            if (batch.size() > batch_max) { d.queue.assign(batch.begin() + (std::ptrdiff_t)batch_max, batch.end()); batch.resize(batch_max); }
+            d.arrivals = d.queue.size();                           // arrivals from here on = company for the next submitter
+            lk.unlock();
+            // one device call per score triple in the batch (the reference uses one triple)
+            std::vector<char> served(batch.size(), 0);
+            std::uint64_t calls = 0;
+            for (std::size_t i = 0; i < batch.size(); i++) {
+                if (served[i]) continue;
+                std::vector<std::size_t> idx;
+                std::vector<const std::vector<std::string>*> sets;
+                for (std::size_t j = i; j < batch.size(); j++)
+                    if (!served[j] && batch[j]->m == batch[i]->m && batch[j]->n == batch[i]->n && batch[j]->g == batch[i]->g) { idx.push_back(j); sets.push_back(batch[j]->seqs); served[j] = 1; }
+                try {
+                    std::vector<std::string> res = consensus_batch(sets, batch[i]->m, batch[i]->n, batch[i]->g);
+                    for (std::size_t q = 0; q < idx.size(); q++) batch[idx[q]]->result.swap(res[q]);
+                    calls++;
+                } catch (const std::exception& e) {
+                    // one bad set must not fail the callers that happened to share its launch: every set of the group again, on its own
+                    if (idx.size() == 1) batch[idx[0]]->error = e.what();
+                    else
+                        for (std::size_t q = 0; q < idx.size(); q++) {
+                            try { batch[idx[q]]->result = consensus_batch(std::vector<const std::vector<std::string>*>{sets[q]}, batch[i]->m, batch[i]->n, batch[i]->g)[0]; }
+                            catch (const std::exception& e1) { batch[idx[q]]->error = e1.what(); }
+                            calls++;
+                        }
+                    calls++;
+                }
+            }
+            lk.lock();
+            d.calls += calls; d.sets += batch.size();
+        } catch (...) {
+            if (!lk.owns_lock()) lk.lock();
+            for (Device::Request* r : batch) if (r->result.empty() && r->error.empty()) r->error = "spoa_hx: the submitting thread failed before the device call (out of memory?)";
+            if (batch.empty()) me.error = "spoa_hx: the submitting thread failed while collecting a batch (out of memory?)";
+            for (std::size_t q = 0; q < d.queue.size(); q++) if (d.queue[q] == &me) { d.queue.erase(d.queue.begin() + (std::ptrdiff_t)q); break; }
+            me.done = true;
         }
-        lk.lock();
         for (Device::Request* r : batch) r->done = true;
-        d.calls += calls; d.sets += batch.size();
+        d.company = batch.size() > 1 || d.arrivals > 0;         // did this batch have, or did its device call see, anybody else?
         d.submitting = false;
         d.qcv.notify_all();
     }

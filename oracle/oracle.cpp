@@ -685,6 +685,98 @@ __attribute__((target("avx2"))) void row_first_horiz_avx2(int32_t* row, const in
 }
 #endif
 
+// ---- the same four kernels on int16 cells, 16 per AVX2 vector: what spoa's SIMD engine runs when the scores fit 16 bits (its dispatch:
+// max penalty x (nodes + columns) below the int16 range; here 8 (V + L) + 256 < 32767, so that no real value ever saturates and the integers
+// are those of the int32 forms). Half the memory traffic per cell, twice the cells per instruction: bench.py's cpu_baseline is then the engine
+// width the reference would run at on short gaps, not the slower one. Saturating adds keep the "minus infinity" filler (-32768) from wrapping.
+struct RowKernels16 {
+    void (*first)(int16_t* row, const int16_t* pw, const int16_t* pr, int16_t g, size_t W);
+    void (*more)(int16_t* row, const int16_t* pw, const int16_t* pr, int16_t g, size_t W);
+    void (*horiz)(int16_t* row, int16_t g, size_t W);
+    void (*first_horiz)(int16_t* row, const int16_t* pw, const int16_t* pr, int16_t g, size_t W);
+    const char* name;
+};
+void row16_first_scalar(int16_t* row, const int16_t* pw, const int16_t* pr, int16_t g, size_t W) { for (size_t j = 1; j < W; j++) row[j] = (int16_t)std::max(pw[j - 1] + pr[j], pw[j] + g); }
+void row16_more_scalar(int16_t* row, const int16_t* pw, const int16_t* pr, int16_t g, size_t W) { for (size_t j = 1; j < W; j++) row[j] = (int16_t)std::max(pw[j - 1] + pr[j], std::max<int>(row[j], pw[j] + g)); }
+void row16_horiz_scalar(int16_t* row, int16_t g, size_t W) { for (size_t j = 1; j < W; j++) row[j] = (int16_t)std::max<int>(row[j - 1] + g, row[j]); }
+void row16_first_horiz_scalar(int16_t* row, const int16_t* pw, const int16_t* pr, int16_t g, size_t W) { for (size_t j = 1; j < W; j++) row[j] = (int16_t)std::max(row[j - 1] + g, std::max(pw[j - 1] + pr[j], pw[j] + g)); }
+#if defined(__x86_64__)
+// x shifted up by K 16-bit lanes (K = 1, 2, 4, 8) with "minus infinity" in the K lanes that open, plus K gaps: the step of the in-vector prefix scan
+template <int K> __attribute__((target("avx2"))) inline __m256i scan16_step(__m256i x, __m256i negk, __m256i gk) {
+    const __m256i t = _mm256_permute2x128_si256(x, x, 0x08);                       // [0, x.low]
+    const __m256i sh = K == 8 ? t : _mm256_alignr_epi8(x, t, (16 - 2 * K) & 15);   // lanes move up by K words across the 128-bit halves
+    return _mm256_max_epi16(x, _mm256_adds_epi16(_mm256_or_si256(sh, negk), gk));
+}
+struct Scan16 {
+    __m256i n1, n2, n4, n8, g1, g2, g4, g8, ramp;
+    __attribute__((target("avx2"))) explicit Scan16(int16_t g) {
+        alignas(32) int16_t a[16];
+        __m256i* const out[4] = {&n1, &n2, &n4, &n8};
+        for (int q = 0; q < 4; q++) { for (int i = 0; i < 16; i++) a[i] = i < (1 << q) ? (int16_t)0x8000 : (int16_t)0; *out[q] = _mm256_load_si256((const __m256i*)a); }
+        g1 = _mm256_set1_epi16(g); g2 = _mm256_set1_epi16((int16_t)(2 * g)); g4 = _mm256_set1_epi16((int16_t)(4 * g)); g8 = _mm256_set1_epi16((int16_t)(8 * g));
+        for (int i = 0; i < 16; i++) a[i] = (int16_t)((i + 1) * g);
+        ramp = _mm256_load_si256((const __m256i*)a);
+    }
+    __attribute__((target("avx2"))) inline __m256i run(__m256i x, int16_t& carry) const {
+        x = scan16_step<1>(x, n1, g1); x = scan16_step<2>(x, n2, g2); x = scan16_step<4>(x, n4, g4); x = scan16_step<8>(x, n8, g8);
+        x = _mm256_max_epi16(x, _mm256_adds_epi16(_mm256_set1_epi16(carry), ramp));
+        carry = (int16_t)_mm256_extract_epi16(x, 15);
+        return x;
+    }
+};
+__attribute__((target("avx2"))) void row16_first_avx2(int16_t* row, const int16_t* pw, const int16_t* pr, int16_t g, size_t W) {
+    const __m256i vg = _mm256_set1_epi16(g);
+    size_t j = 1;
+    for (; j + 16 <= W; j += 16) {
+        const __m256i d = _mm256_adds_epi16(_mm256_loadu_si256((const __m256i*)(pw + j - 1)), _mm256_loadu_si256((const __m256i*)(pr + j)));
+        const __m256i v = _mm256_adds_epi16(_mm256_loadu_si256((const __m256i*)(pw + j)), vg);
+        _mm256_storeu_si256((__m256i*)(row + j), _mm256_max_epi16(d, v));
+    }
+    for (; j < W; j++) row[j] = (int16_t)std::max(pw[j - 1] + pr[j], pw[j] + g);
+}
+__attribute__((target("avx2"))) void row16_more_avx2(int16_t* row, const int16_t* pw, const int16_t* pr, int16_t g, size_t W) {
+    const __m256i vg = _mm256_set1_epi16(g);
+    size_t j = 1;
+    for (; j + 16 <= W; j += 16) {
+        const __m256i d = _mm256_adds_epi16(_mm256_loadu_si256((const __m256i*)(pw + j - 1)), _mm256_loadu_si256((const __m256i*)(pr + j)));
+        const __m256i v = _mm256_adds_epi16(_mm256_loadu_si256((const __m256i*)(pw + j)), vg);
+        _mm256_storeu_si256((__m256i*)(row + j), _mm256_max_epi16(_mm256_loadu_si256((const __m256i*)(row + j)), _mm256_max_epi16(d, v)));
+    }
+    for (; j < W; j++) row[j] = (int16_t)std::max(pw[j - 1] + pr[j], std::max<int>(row[j], pw[j] + g));
+}
+__attribute__((target("avx2"))) void row16_horiz_avx2(int16_t* row, int16_t g, size_t W) {
+    const Scan16 S(g);
+    int16_t carry = row[0];
+    size_t j = 1;
+    for (; j + 16 <= W; j += 16) _mm256_storeu_si256((__m256i*)(row + j), S.run(_mm256_loadu_si256((const __m256i*)(row + j)), carry));
+    for (; j < W; j++) row[j] = (int16_t)std::max<int>(row[j - 1] + g, row[j]);
+}
+__attribute__((target("avx2"))) void row16_first_horiz_avx2(int16_t* row, const int16_t* pw, const int16_t* pr, int16_t g, size_t W) {
+    const Scan16 S(g);
+    const __m256i vg = _mm256_set1_epi16(g);
+    int16_t carry = row[0];
+    size_t j = 1;
+    for (; j + 16 <= W; j += 16) {
+        const __m256i d = _mm256_adds_epi16(_mm256_loadu_si256((const __m256i*)(pw + j - 1)), _mm256_loadu_si256((const __m256i*)(pr + j)));
+        const __m256i v = _mm256_adds_epi16(_mm256_loadu_si256((const __m256i*)(pw + j)), vg);
+        _mm256_storeu_si256((__m256i*)(row + j), S.run(_mm256_max_epi16(d, v), carry));
+    }
+    for (; j < W; j++) row[j] = (int16_t)std::max(row[j - 1] + g, std::max(pw[j - 1] + pr[j], pw[j] + g));
+}
+#endif
+const RowKernels16* row_kernels16() {   // nullptr: the int16 path is off (ORC_POA_INT16=0)
+    static const RowKernels16 k = []() {
+        RowKernels16 r{row16_first_scalar, row16_more_scalar, row16_horiz_scalar, row16_first_horiz_scalar, "scalar int16"};
+#if defined(__x86_64__)
+        const char* force = getenv("ORC_POA_SCALAR");
+        if (!(force && force[0] == '1') && __builtin_cpu_supports("avx2")) r = RowKernels16{row16_first_avx2, row16_more_avx2, row16_horiz_avx2, row16_first_horiz_avx2, "avx2 (16 x int16)"};
+#endif
+        return r;
+    }();
+    static const bool on = !(getenv("ORC_POA_INT16") && getenv("ORC_POA_INT16")[0] == '0');
+    return on ? &k : nullptr;
+}
+
 const RowKernels& row_kernels() {
     static const RowKernels k = []() {
         RowKernels r{row_first_scalar, row_more_scalar, row_horiz_scalar, row_first_horiz_scalar, "scalar"};
@@ -700,6 +792,7 @@ const RowKernels& row_kernels() {
 struct PoaAligner {
     int32_t m, x, g;
     std::vector<int32_t> H, prof;
+    std::vector<int16_t> H16, prof16;
     std::vector<uint32_t> node2rank;
     int64_t prev_score = 0; uint32_t prev_len = 0;   // (ORC_POA_PRUNE_SIM only: the previous alignment of this edge, the source of the pruning threshold)
     // spoa SisdAlignmentEngine::align (kNW, linear gap). Returns (node|-1, seq pos|-1) pairs.
@@ -709,6 +802,12 @@ struct PoaAligner {
         if (V == 0 || len == 0) return aln;
         const size_t W = (size_t)len + 1;
         *cells += (uint64_t)V * len;
+        {   // int16 cells where the scores fit (what spoa's SIMD engine does): same integers, see RowKernels16. The development statistics read the int32 matrix.
+            static const bool stats = getenv("ORC_POA_TIES") || getenv("ORC_POA_PRUNE") || getenv("ORC_POA_TB") || getenv("ORC_POA_PRUNE_SIM");
+            const int64_t pen = std::max<int64_t>(std::max<int64_t>(std::llabs(m), std::llabs(x)), std::llabs(g));
+            const RowKernels16* K16 = stats ? nullptr : row_kernels16();
+            if (K16 && pen * (int64_t)(V + len) + 32 * pen < 32767) return align16(G, seq, len, *K16);
+        }
         H.resize((V + 1) * W);
         prof.resize(4 * W);
         for (int c = 0; c < 4; c++) { prof[c * W] = 0; for (uint32_t j = 0; j < len; j++) prof[c * W + j + 1] = seq[j] == c ? m : x; }
@@ -868,6 +967,74 @@ struct PoaAligner {
                             (unsigned long)tb_diag0_lag1, (unsigned long)tb_diag0_lag2, (unsigned long)tb_runs1, (unsigned long)tb_runs12);
         std::reverse(aln.begin(), aln.end());
         if (const char* ps = getenv("ORC_POA_PRUNE_SIM")) prune_sim(G, seq, len, atoi(ps) > 0 ? atoi(ps) : 8, max_score, aln);
+        prev_score = max_score; prev_len = len;
+        return aln;
+    }
+
+    // the same alignment on int16 cells (every real value fits: the caller checked); fill and traceback follow align() statement by statement
+    std::vector<std::pair<int32_t, int32_t>> align16(const PoaGraph& G, const uint8_t* seq, uint32_t len, const RowKernels16& K) {
+        std::vector<std::pair<int32_t, int32_t>> aln;
+        const size_t V = G.code.size(), W = (size_t)len + 1;
+        std::vector<int16_t>& Hm = H16;
+        Hm.resize((V + 1) * W);
+        prof16.resize(4 * W);
+        const int16_t g16 = (int16_t)g;
+        for (int c = 0; c < 4; c++) { prof16[c * W] = 0; for (uint32_t j = 0; j < len; j++) prof16[c * W + j + 1] = (int16_t)(seq[j] == c ? m : x); }
+        node2rank.resize(V);
+        for (uint32_t i = 0; i < V; i++) node2rank[G.rank2node[i]] = i;
+        Hm[0] = 0;
+        for (size_t j = 1; j < W; j++) Hm[j] = (int16_t)((int32_t)j * g);
+        for (size_t i = 1; i <= V; i++) {   // first column
+            const uint32_t n = G.rank2node[i - 1];
+            if (G.in[n].empty()) Hm[i * W] = g16;
+            else {
+                int32_t pen = INT32_MIN + 1024;
+                for (uint32_t e : G.in[n]) pen = std::max<int32_t>(pen, Hm[(size_t)(node2rank[G.edges[e].from] + 1) * W]);
+                Hm[i * W] = (int16_t)(pen + g);
+            }
+        }
+        int32_t max_score = INT32_MIN + 1024; int64_t max_i = -1;
+        for (size_t i = 1; i <= V; i++) {
+            const uint32_t n = G.rank2node[i - 1];
+            const int16_t* pr = &prof16[(size_t)G.code[n] * W];
+            int16_t* row = &Hm[i * W];
+            const size_t pi = G.in[n].empty() ? 0 : node2rank[G.edges[G.in[n][0]].from] + 1;
+            const int16_t* pw = &Hm[pi * W];
+            if (G.in[n].size() <= 1) K.first_horiz(row, pw, pr, g16, W);
+            else {
+                K.first(row, pw, pr, g16, W);
+                for (size_t p = 1; p < G.in[n].size(); p++) K.more(row, &Hm[(size_t)(node2rank[G.edges[G.in[n][p]].from] + 1) * W], pr, g16, W);
+                K.horiz(row, g16, W);
+            }
+            if (G.outs[n].empty() && max_score < row[W - 1]) { max_score = row[W - 1]; max_i = (int64_t)i; }   // first max in rank order
+        }
+        size_t i = (size_t)max_i, j = W - 1;
+        while (!(i == 0 && j == 0)) {   // traceback: diagonal (in-edge order), then vertical (in-edge order), then horizontal
+            const int32_t hij = Hm[i * W + j];
+            bool found = false;
+            size_t pi_ = 0, pj_ = 0;
+            if (i != 0 && j != 0) {
+                const uint32_t n = G.rank2node[i - 1];
+                const int32_t mc = prof16[(size_t)G.code[n] * W + j];
+                const size_t np = G.in[n].size();
+                for (size_t p = 0; p < std::max<size_t>(1, np) && !found; p++) {
+                    const size_t pi = np == 0 ? 0 : node2rank[G.edges[G.in[n][p]].from] + 1;
+                    if (hij == Hm[pi * W + j - 1] + mc) { pi_ = pi; pj_ = j - 1; found = true; }
+                }
+            }
+            if (!found && i != 0) {
+                const uint32_t n = G.rank2node[i - 1];
+                const size_t np = G.in[n].size();
+                for (size_t p = 0; p < std::max<size_t>(1, np) && !found; p++) {
+                    const size_t pi = np == 0 ? 0 : node2rank[G.edges[G.in[n][p]].from] + 1;
+                    if (hij == Hm[pi * W + j] + g) { pi_ = pi; pj_ = j; found = true; }
+                }
+            }
+            if (!found) { pi_ = i; pj_ = j - 1; }
+            aln.emplace_back(i == pi_ ? -1 : (int32_t)G.rank2node[i - 1], j == pj_ ? -1 : (int32_t)(j - 1));
+            i = pi_; j = pj_;
+        }
+        std::reverse(aln.begin(), aln.end());
         prev_score = max_score; prev_len = len;
         return aln;
     }
@@ -1084,7 +1251,10 @@ extern "C" int orc_poa_batch(const hx_reads* R, const hx_coords_out* C, const hx
     return 0;
 }
 
-extern "C" const char* orc_poa_kernel_name(void) { return row_kernels().name; }
+extern "C" const char* orc_poa_kernel_name(void) {
+    static const std::string n = std::string(row_kernels().name) + (row_kernels16() ? std::string(", ") + row_kernels16()->name + " where 8 (nodes + columns) fits 16 bits" : std::string());
+    return n.c_str();
+}
 
 extern "C" void orc_free_cns(hx_cns_out* o) { free(o->cns_off); free(o->cns); memset(o, 0, sizeof(*o)); }
 

@@ -3,6 +3,7 @@
 // one after the other, consensus at the end. Input: edges separated by blank lines, one sequence per line; output: one consensus per line.
 // With --batch the same sets go through spoa::hx::consensus_batch in one call. With --threads N the edges are dealt to N threads, each in the
 // reference's pattern with its own engine and graph (asm_cal_cns_seq_MT, Assemble.cpp:562-605); stderr then says how many device calls served them.
+// --tolerant (with --threads): an edge whose consensus throws prints "ERROR <message>" in its place and the others go on (who gets the exception of a bad set?).
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -29,6 +30,7 @@ int main(int argc, char** argv) {
             return 0;
         }
         const int nthreads = argc > 2 && !strcmp(argv[1], "--threads") ? std::max(1, atoi(argv[2])) : 1;
+        const bool tolerant = argc > 3 && !strcmp(argv[3], "--tolerant");
         std::vector<std::string> cns(edges.size()), errs((size_t)nthreads);
         auto work = [&](int t) {
             try {
@@ -41,7 +43,8 @@ int main(int argc, char** argv) {
                         auto alignment = alignment_engine->align_sequence_with_graph(s, graph);
                         graph->add_alignment(alignment, s);
                     }
-                    cns[e] = graph->generate_consensus();
+                    if (!tolerant) cns[e] = graph->generate_consensus();
+                    else { try { cns[e] = graph->generate_consensus(); } catch (const std::exception& ex) { cns[e] = std::string("ERROR ") + ex.what(); } }
                 }
             } catch (const std::exception& e) { errs[(size_t)t] = e.what(); }
         };

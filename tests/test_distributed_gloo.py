@@ -242,6 +242,10 @@ if rank == 1 and fail_at == "coords":
     table.edge_coords = C.cast(cb, C.c_void_p).value      # this rank's coordinate operator fails
 if rank == 1 and fail_at == "chain":
     table.chain_reads = C.cast(cb, C.c_void_p).value      # this rank's chain operator fails: its verdict travels with the count round of the record exchange
+if rank == 1 and fail_at == "graph-early":                # the graph stage fails BEFORE it reaches the record exchange (the others are in that count round, not the results one)
+    def early(self):
+        raise host.HostError("graph stage failed before the record exchange")
+    host.Run.graph = early
 
 
 class Rec:                                              # the oracle's edge_support already returns the merged multiset: nothing to exchange
@@ -268,7 +272,7 @@ os._exit(code)
 '''
 
 
-@pytest.mark.parametrize("fail_at,port", [("coords", "29527"), ("graph", "29529"), ("chain", "29531")])
+@pytest.mark.parametrize("fail_at,port", [("coords", "29527"), ("graph", "29529"), ("chain", "29531"), ("graph-early", "29533")])
 def test_failure_on_one_rank_stops_every_rank(sim, built, tmp_path, fail_at, port):
     """a rank whose chain stage, whose coordinate stage - or whose graph stage, after the record all-gather - fails: the count round ahead of
     each of the two all-gathers carries every rank's verdict on what it did since the previous one, so every rank raises within seconds

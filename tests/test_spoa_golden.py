@@ -62,8 +62,10 @@ def test_hip_against_spoa_vectors(built):
         ctx.close()
 
 
-# ---- the committed INPUT sets (tests/golden/spoa/inputs): ready for a maintainer's make_spoa_vectors call; until then they pin the oracle and
-# the kernel to the digests recorded when the sets were made
+# ---- the committed INPUT sets (tests/golden/spoa/inputs): ready for a maintainer's make_spoa_vectors call. Until then the two tests below are
+# SELF-CONSISTENCY pins, not parity with the reference library: the digests in manifest.json were produced by THIS repository's oracle when the
+# sets were made, so they hold the oracle and the kernel to "the oracle of that day" (a regression alarm) and say nothing about SPOA 1.1.3 - a
+# tie-order or traceback reading shared by the oracle and the kernel passes them unnoticed. Parity with SPOA stays unpinned.
 def load_inputs(name):
     cases = []
     for para in gzip.open(os.path.join(GOLD, "inputs", name), "rt").read().split("\n\n"):
@@ -78,7 +80,7 @@ INPUTS = json.load(open(os.path.join(GOLD, "inputs", "manifest.json")))
 
 
 @pytest.mark.parametrize("name", sorted(INPUTS))
-def test_committed_inputs_oracle_digest(name):
+def test_committed_inputs_self_consistency_of_the_oracle(name):
     cases = load_inputs(name)
     assert len(cases) == INPUTS[name]["cases"]
     if name != "pacbio25.sequences.txt.gz":
@@ -97,7 +99,7 @@ def test_committed_inputs_oracle_digest(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(INPUTS))
-def test_committed_inputs_through_hip(name, built):
+def test_committed_inputs_self_consistency_through_hip(name, built):
     from haslr_amd import hip
     cases = load_inputs(name)
     ctx = hip.HipContext(0)
@@ -109,3 +111,23 @@ def test_committed_inputs_through_hip(name, built):
     for (nm, _), c in zip(cases, got):
         h.update((nm + "\t" + c + "\n").encode())
     assert h.hexdigest() == INPUTS[name]["oracle_consensus_sha256"]
+
+
+def test_int16_rows_of_the_oracle_give_the_int32_integers():
+    """the oracle's AVX2 int16 row kernels (used where 8 x (nodes + columns) fits 16 bits: the width spoa's SIMD engine would run those alignments at,
+    so that bench.py's cpu_baseline is not the slower engine) return what the int32 forms return: same consensus for every case of a committed
+    input set, with the int16 path on (this process), off, and in its scalar form (subprocesses: the selection is made once per process)"""
+    import subprocess
+    import sys
+    name = "nanopore25.sequences.txt.gz"
+    code = ("import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r); import orclib, test_spoa_golden as t\n"
+            "h = hashlib.sha256()\n"
+            "[h.update((nm + '\\t' + orclib.poa_consensus(seqs) + '\\n').encode()) for nm, seqs in t.load_inputs(%r)[:30]]\n"
+            "print(orclib.lib().orc_poa_kernel_name().decode(), '|', h.hexdigest())\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), name)
+    outs = {}
+    for tag, env in (("int16", {}), ("int32", {"ORC_POA_INT16": "0"}), ("scalar", {"ORC_POA_SCALAR": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        outs[tag] = r.stdout.strip().split(" | ")
+    assert "int16" in outs["int16"][0] and "int16" not in outs["int32"][0] and "scalar int16" in outs["scalar"][0], outs
+    assert outs["int16"][1] == outs["int32"][1] == outs["scalar"][1], outs

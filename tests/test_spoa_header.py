@@ -66,3 +66,33 @@ def test_concurrent_callers_are_combined_into_few_device_calls(caller):
     assert r.stdout.split("\n")[:-1] == [orclib.poa_consensus(st) for st in ss]
     calls = int(r.stderr.split("device_calls=")[1].split()[0])
     assert int(r.stderr.split("sets=")[1].split()[0]) == 128 and calls <= 16, r.stderr
+
+
+@pytest.mark.gpu
+def test_a_bad_set_fails_its_own_caller_only_and_a_lone_caller_does_not_wait(caller):
+    """flat combining must not spread a failure: 8 threads over 33 edges, one of which holds a sequence no POA kernel instance takes (2^20 bases:
+    hx_poa_sequences fails the call it is in) - that edge's caller gets the exception, every other edge the oracle's consensus. And a lone caller
+    (--threads 1, the reference with -t 1) does not sit through the batching window: with a window of 0.3 s, 12 edges take far less than 12 windows."""
+    import time
+
+    import orclib
+    rnd = random.Random(10)
+    ss = []
+    for k in range(32):
+        t = "".join(rnd.choice("ACGT") for _ in range(rnd.randrange(60, 400)))
+        ss.append(["".join(c for c in t if rnd.random() > 0.07) for _ in range(rnd.randrange(3, 7))])
+    bad = 13
+    ss.insert(bad, ["A" * (1 << 20), "ACGT"])
+    r = subprocess.run([caller, "--threads", "8", "--tolerant"], input=text(ss), capture_output=True, text=True, env=dict(os.environ, HASLR_SPOA_BATCH_US="20000"))
+    assert r.returncode == 0, r.stderr
+    got = r.stdout.split("\n")[:-1]
+    assert len(got) == 33 and got[bad].startswith("ERROR") and "longer than" in got[bad], got[bad][:200]
+    for k in range(33):
+        if k != bad:
+            assert got[k] == orclib.poa_consensus(ss[k]), k
+    t0 = time.perf_counter()
+    r = subprocess.run([caller, "--threads", "1"], input=text(ss[:12]), capture_output=True, text=True, env=dict(os.environ, HASLR_SPOA_BATCH_US="300000"))
+    dt = time.perf_counter() - t0
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split("\n")[:-1] == [orclib.poa_consensus(st) for st in ss[:12]]
+    assert "device_calls=12 sets=12" in r.stderr and dt < 12 * 0.3, (dt, r.stderr)   # (process start + context creation included: still below 12 windows)
