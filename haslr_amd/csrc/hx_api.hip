@@ -11,6 +11,7 @@
 #include <numeric>
 #include <string>
 #include <vector>
+#include <array>
 
 #include "../../include/haslr_hip.h"
 #include "host/haslr_host.h"
@@ -118,13 +119,16 @@ struct HxOptions {
     double poa_workspace_gb = 0;   // cap of the POA workspace in GB (0: 90 % of the memory that was free at the context's first consensus call)
     int poa_poll_limit = 1 << 24;  // polls before a wave gives up waiting for another member (testing: forces the unshared retry)
     int poa_max_indeg = 16;        // in-degree the direction bytes hold (testing: forces the score-matrix retry earlier)
-    int poa_member_lanes = 256, poa_cluster_min = 2048, poa_cluster_max = -1, poa_cluster_topk = -1, poa_wide_members = -1, poa_cluster_cols = 4;
+    int poa_member_lanes = 256, poa_cluster_min = 2048, poa_cluster_max = -1, poa_cluster_topk = -1, poa_wide_members = -1, poa_cluster_cols = -1;
     int poa_node_est_pct = 100, poa_far_rows = -1;
     int poa_wave_max = 512, poa_cols = -1, poa_ring_kb = -1, poa_ring_zero = 0;
     int poa_balance = 1, poa_balance_pct = 125, poa_balance_lanes = 512;
     int poa_slots_pct = 100, poa_slots = 0, poa_batches = 0, poa_force_cm = 0, poa_no_xcd_map = 0, poa_streams = 8, poa_wide_delay_us = 60;
     int poa_prune = -1;            // exact score-bound pruning of the DP: -1 automatic (calls of thousands of edges), 0 never, else the threshold's percentage of the previous alignment's score per base
-    int poa_pass_lanes = -1;       // column passes: unshared multi-wave edges run in workgroups of this many lanes, their DP columns in windows taken one after the other (-1 automatic: 256 where the rows are pruned; 0 never)
+    int poa_pass_lanes = -1;       // column passes: unshared multi-wave edges run in workgroups of this many lanes, their DP columns in windows taken one after the other (-1 automatic: by
+                                   // estimated chain length, where the rows are pruned; 0 never)
+    int poa_chain_ms = -1;         // ... the automatic choice: the narrowest workgroup whose estimated chain (size_edges: DP rows x what a row costs at that width and number of
+                                   // windows) stays below this many milliseconds; -1: the cap that balances the longest chain against the call's wave-slot time
     int poa_prune_lazy = 1;        // ... a wave that skipped a whole batch of rows polls for the next one rarely (0: like any wave)
     int poa_prune_lanes = 128;     // ... in launches of workgroups of at least this many lanes (a one-wave workgroup has no block to skip)
     int coords_lds_supp = -1;      // supports per edge the coordinate kernel sorts in LDS (testing: 0 sends every edge through the global scratch)
@@ -140,7 +144,7 @@ const OptDesc kOptions[] = {
     {"poa_balance_pct", &HxOptions::poa_balance_pct, nullptr}, {"poa_balance_lanes", &HxOptions::poa_balance_lanes, nullptr}, {"poa_slots_pct", &HxOptions::poa_slots_pct, nullptr},
     {"poa_slots", &HxOptions::poa_slots, nullptr}, {"poa_batches", &HxOptions::poa_batches, nullptr}, {"poa_force_cm", &HxOptions::poa_force_cm, nullptr},
     {"poa_no_xcd_map", &HxOptions::poa_no_xcd_map, nullptr}, {"poa_streams", &HxOptions::poa_streams, nullptr}, {"poa_wide_delay_us", &HxOptions::poa_wide_delay_us, nullptr},
-    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
+    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"poa_chain_ms", &HxOptions::poa_chain_ms, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
 };
 }  // namespace
 
@@ -185,6 +189,7 @@ struct hx_ctx {
     uint32_t dbg_slowest = 0;
     std::vector<uint32_t> dbg_lmax, dbg_nseq;
     std::vector<uint8_t> dbg_cls; uint32_t dbg_ring[11] = {};
+    std::vector<uint32_t> dbg_shape;   // per edge: lanes of its workgroup | column passes << 16 | members << 24
     bool poa_no_dir = false;   // diagnostics: force the score-matrix traceback
     int poa_block = 0;   // 0 = automatic (lanes per edge chosen from the gap length)
     hipStream_t poa_streams[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -205,7 +210,7 @@ struct hx_ctx {
     uint64_t poa_budget = 0;
     DV<hxk::PoaEdge> poa_edges;
     DV<hxk::PoaSeq> poa_seqs;
-    DV<uint32_t> poa_order, poa_len, poa_status, poa_counters;
+    DV<uint32_t> poa_order, poa_len, poa_status, poa_counters, poa_btab;
     DV<hxk::PoaSlot> poa_slots;
     uint64_t poa_workspace_bytes = 0;   // largest POA workspace (pools) a call of this context has used
     uint64_t poa_last_workspace_bytes = 0, poa_free_at_first_call = 0;   // ... the last call's; free device memory when the budget was taken
@@ -615,6 +620,8 @@ inline uint64_t need_bytes(const Need& n) { return n.nn * 90 + n.ec * 28 + n.hc 
 struct Cls {
     bool shared; uint32_t nt, cm; bool dir;
     uint32_t dpl = 0;   // lanes in the DP when the workgroups are wider (wide cluster members), else 0
+    uint32_t pb = 0;    // unshared edges of a call with column passes: bucket of their workspace need (log2 of the megabytes) - one slot size per bucket, all buckets of a kernel instance in ONE launch
+    bool pk = false;    // ... the pruned instance whatever the lanes (edges that take their columns in several passes are among the class's)
     std::vector<uint32_t> edges;
     size_t blocks = 0, order_at = 0, slot_at = 0, n_slots = 0;
     Need need{};
@@ -650,6 +657,9 @@ struct PoaCall {
     // knobs of this round (the option, or what the number of edges in the call asks for)
     bool many_edges = false, balanced = false;
     uint32_t cl_lanes = 256, cl_min = 2048, cl_max = 16, cl_pref = 16, cl_topk = 192, wide_k = 0, cl_cols = 4, cols_per_lane = 4, wave_max = 512, prune_pct = 0, pass_lanes = 0;
+    bool pass_on = false;
+    std::vector<uint16_t> plane;       // unshared edges with column passes: lanes of their workgroup
+    std::vector<float> chain_ms;       // estimated duration of the edge's chain (size_edges): the order of the launch lists
     uint64_t ring_kb_wave = 0;
     double balance_f = 1.25;
     uint32_t balance_nt = 512;
@@ -679,7 +689,7 @@ struct PoaCall {
         for (uint32_t e = 0; e < ne; e++) if (P.nseq[e]) todo.push_back(e);
         cns.assign(ne, std::string());
         grow.assign(ne, 0); force_nodir.assign(ne, 0); full_h.assign(ne, 0); wide_grow.assign(ne, 0); no_share.assign(ne, 0); many_sinks.assign(ne, 0); far_full.assign(ne, 0);
-        mlanes.assign(ne, 0);
+        mlanes.assign(ne, 0); plane.assign(ne, 0); chain_ms.assign(ne, 0.f);
         return 0;
     }
 
@@ -696,7 +706,10 @@ struct PoaCall {
         cl_pref = o.poa_cluster_max >= 0 ? cl_max : many_in ? 8 : 16;                 // ... unless the gap needs more to fit at all
         cl_topk = o.poa_cluster_topk >= 0 ? (uint32_t)o.poa_cluster_topk : many_in ? 32 : 192;   // shared edges per call at most (the costliest)
         wide_k = o.poa_wide_members >= 0 ? (uint32_t)o.poa_wide_members : 0;         // shared edges per call (the costliest) whose members are 1024-lane workgroups (default: size_edges)
-        cl_cols = (uint32_t)o.poa_cluster_cols;                                       // columns per lane a member aims at
+        // columns per lane a member aims at: 4 while the longest edges set the duration; 8 in calls of thousands of edges - the 4-column instances take 145-158
+        // registers, and ONE such wave on a SIMD leaves room for two waves of the 128-register instances instead of three: the 32 shared edges' 896 waves
+        // held the whole chip at 3 200 resident waves of 4 096 while they ran (tools/dev_r05.sh edgedump: 3 870 with 8 columns, the call 705 -> 657 ms)
+        cl_cols = o.poa_cluster_cols > 0 ? (uint32_t)o.poa_cluster_cols : many_in ? 8u : 4u;
         wave_max = (uint32_t)o.poa_wave_max;                                          // columns handled by ONE wavefront per edge
         // columns per lane of the multi-wave classes: 4 while edges are few (more lanes = a shorter row for the edges that set the step time),
         // 8 when thousands of edges keep every CU busy anyway (a row then costs fewer instructions in total: the per-row overhead is per wave).
@@ -716,7 +729,8 @@ struct PoaCall {
         // Column passes (kernels/poa.hip): with the rows pruned, an edge's wave slots are mostly held by waves that skip - so the unshared multi-wave edges run
         // in workgroups of `pass_lanes` lanes and take their columns window by window. The call is bound by wave-slot time (thousands of edges, every slot
         // taken): an edge of 8 000 columns holds 4 waves instead of 16 for little more than the same time.
-        pass_lanes = prune_pct == 0 || cols_per_lane > 8 ? 0u : o.poa_pass_lanes < 0 ? 256u : (uint32_t)o.poa_pass_lanes;
+        pass_on = prune_pct != 0 && cols_per_lane <= 8 && o.poa_pass_lanes != 0;
+        pass_lanes = !pass_on || o.poa_pass_lanes < 0 ? 0u : (uint32_t)o.poa_pass_lanes;   // (0 with pass_on: by gap length, size_edges)
         if (pass_lanes != 0 && pass_lanes != 64 && pass_lanes != 128 && pass_lanes != 256 && pass_lanes != 512 && pass_lanes != 1024) return fail("option poa_pass_lanes must be 0, 64, 128, 256, 512 or 1024");
         if (cl_lanes != 64 && cl_lanes != 128 && cl_lanes != 256 && cl_lanes != 512 && cl_lanes != 1024) return fail("option poa_member_lanes must be 64, 128, 256, 512 or 1024");
         return 0;
@@ -734,7 +748,7 @@ struct PoaCall {
         if (many_sinks[e]) return 1;   // (the 1024-lane kernel keeps the full sink list)
         if (c->poa_block) { for (k = 1; k < 5 && kClassNT[k] > c->poa_block; k++) {} }
         else if (ncol > wave_max) { k = 4; while (k > 1 && (uint64_t)kClassNT[k] * cols_per_lane < ncol) k--; }
-        if (P.edges[e].passes > 1) { for (int q = 1; q <= 5; q++) if ((uint32_t)kClassNT[q] == pass_lanes) return q; }   // (column passes: workgroups of pass_lanes lanes, whatever the gap length)
+        if (P.edges[e].passes > 1) { for (int q = 1; q <= 5; q++) if ((uint32_t)kClassNT[q] == plane[e]) return q; }   // (column passes: a narrow workgroup, whatever the gap length)
         while (k > 1 && (uint64_t)kClassNT[k] * kMaxCm[k] < ncol) k--;
         return k;
     }
@@ -791,9 +805,7 @@ struct PoaCall {
             }
             if (E.members < 2 || ((uint64_t)ncol + (uint64_t)E.members * mlanes[e] - 1) / ((uint64_t)E.members * mlanes[e]) > 32) E.members = 1;   // (members too small for this gap: one workgroup)
             E.passes = 1;
-            if (E.members == 1 && pass_lanes && !c->poa_block && !full_h[e] && !many_sinks[e] && ncol > wave_max && ncol > pass_lanes * cols_per_lane)
-                E.passes = (uint32_t)(((uint64_t)ncol + (uint64_t)pass_lanes * cols_per_lane - 1) / ((uint64_t)pass_lanes * cols_per_lane));
-            if (E.members == 1 && E.passes == 1 && ncol > 1024u * (uint32_t)hxk::poa_kernel_max_cm(1024))
+            if (E.members == 1 && ncol > 1024u * (uint32_t)hxk::poa_kernel_max_cm(1024))
                 return fail("hx_poa_batch: a gap sub-sequence of " + std::to_string(ncol - 1) + " bases needs the shared (cluster) mode - direction-byte traceback, automatic block size - with " +
                             std::to_string((ncol + 1024 * 32 - 1) / (1024 * 32)) + " members of 1024 lanes (option poa_cluster_max: " + std::to_string(cl_max) + ")");
         }
@@ -806,6 +818,61 @@ struct PoaCall {
                 std::sort(sh.begin(), sh.end(), [&](uint32_t a, uint32_t b) { const uint64_t ca = edge_cost(a), cb = edge_cost(b); return ca != cb ? ca > cb : a < b; });
                 for (size_t q = cl_topk; q < sh.size(); q++) if (P.edges[sh[q]].lmax + 1 <= 8192) P.edges[sh[q]].members = 1;   // (longer gaps than a 1024-lane workgroup holds with its ring stay shared)
             }
+        }
+        // Column passes for the multi-wave edges that run unshared (decided here, after the costliest have kept their members). With the rows pruned a call of
+        // thousands of edges is bound by WAVE-SLOT TIME: a 256-lane workgroup holds four wave slots of which the live band of the matrix keeps one or two
+        // busy, and all four sit through the serial phases (traceback, graph update, CSR rebuild). Measured per DP row of an edge, under the load of such a
+        // call (tools/dev_r05.sh edgedump, profiles/r05_edge_model.txt): a workgroup of 64 / 128 / 256 lanes takes 1.5 / 1.4 / 1.1 us with one window, 2.6 /
+        // 1.9 / 1.4 us with two, 3.3 / 2.5 / 1.9 us with four - the narrowest workgroup is always the cheapest in wave-slot time (1.6 against 2.7 against 4.5
+        // slot-us per row) and always the longest chain. So every edge gets the NARROWEST workgroup whose estimated chain stays below a cap, and the cap
+        // is the one that balances the longest chain against the call's wave-slot time over the chip's slots (list scheduling: costliest first).
+        if (pass_on) {
+            // cycles per DP row at 2.4 GHz: the DP with 1 .. 4 windows (then per further window), everything else of the chain
+            static const uint32_t kLanes[5] = {64, 128, 256, 512, 1024};
+            static const double kDp[5][4] = {{1470, 2900, 3800, 4435}, {1862, 2685, 3273, 3797}, {1741, 2430, 2900, 3150}, {1900, 2000, 2300, 2600}, {1850, 2000, 2200, 2400}};
+            static const double kDpMore[5] = {500, 450, 250, 250, 200}, kRest[5] = {3300, 1900, 1000, 930, 900};
+            struct Opt { double ms[5]; uint32_t np[5]; int first, last; };
+            std::vector<uint32_t> ord;
+            std::vector<Opt> opts;
+            double fixed_slot_ms = 0;   // wave-slot time of the edges that have no choice (shared edges, one-wave gaps, score-matrix retries)
+            for (uint32_t e : todo) {
+                const hxk::PoaEdge& E = P.edges[e];
+                const uint32_t ncol = E.lmax + 1, S = std::max<uint32_t>(1, P.nseq[e]);
+                const double rows = 1.18 * (double)E.lmax * (double)(S - 1) * (1.0 + 0.0275 * S);   // nodes of the graph before each sequence, summed (measured / model: 1.10 .. 1.23)
+                if (E.members > 1) { chain_ms[e] = (float)(rows * (1000 + 1000) / 2.4e6); fixed_slot_ms += chain_ms[e] * E.members * (mlanes[e] / 64); continue; }
+                if (ncol <= wave_max || c->poa_block || full_h[e] || many_sinks[e]) { chain_ms[e] = (float)(rows * (1470 + 2200) / 2.4e6); fixed_slot_ms += chain_ms[e]; continue; }
+                Opt q{}; q.first = -1; q.last = -1;
+                for (int k = 0; k < 5; k++) {
+                    const uint64_t win = (uint64_t)kLanes[k] * cols_per_lane;
+                    const uint32_t np = (uint32_t)((ncol + win - 1) / win);
+                    if (np > 64 || (pass_lanes && kLanes[k] != pass_lanes && np > 1)) continue;        // (option poa_pass_lanes: that width or the one that holds the gap)
+                    q.np[k] = np; q.ms[k] = rows * ((np <= 4 ? kDp[k][np - 1] : kDp[k][3] + kDpMore[k] * (np - 4)) + kRest[k]) / 2.4e6;
+                    if (q.first < 0) q.first = k;
+                    q.last = k;
+                    if (np == 1) break;                                                                // (wider than the gap: 4 columns per lane - not this model's)
+                }
+                if (q.first < 0) { chain_ms[e] = (float)(rows * 3000 / 2.4e6); continue; }
+                ord.push_back(e); opts.push_back(q);
+            }
+            auto pick = [&](const Opt& q, double cap) { int k = q.first; while (k < q.last && (q.np[k] == 0 || q.ms[k] > cap)) k++; while (q.np[k] == 0) k--; return k; };
+            double cap = o.poa_chain_ms > 0 ? (double)o.poa_chain_ms : 0;
+            if (cap == 0) {
+                double best = 1e300;
+                for (double cq = 100; cq <= 3200; cq *= 1.1892) {   // (a quarter octave apart)
+                    double slot = fixed_slot_ms, longest = 0;
+                    for (const Opt& q : opts) { const int k = pick(q, cq); slot += q.ms[k] * (kLanes[k] / 64); longest = std::max(longest, q.ms[k]); }
+                    const double est = std::max(1.5 * std::max(longest, cq), slot / 3800.0);   // (3 800: the waves resident on average of the 4 096 a chip of 16-wave CUs holds; 1.5: the model's error on one chain, and a chain that starts late)
+                    if (est < best) { best = est; cap = cq; }
+                }
+            }
+            size_t hist[5] = {};
+            for (size_t i = 0; i < ord.size(); i++) {
+                const int k = pick(opts[i], cap);
+                hist[k]++;
+                chain_ms[ord[i]] = (float)opts[i].ms[k];
+                if (opts[i].np[k] > 1) { P.edges[ord[i]].passes = opts[i].np[k]; plane[ord[i]] = (uint16_t)kLanes[k]; }
+            }
+            if (o.debug) fprintf(stderr, "[hx] column passes: chain cap %.0f ms; %zu / %zu / %zu / %zu / %zu unshared multi-wave edges in workgroups of 64 / 128 / 256 / 512 / 1024 lanes\n", cap, hist[0], hist[1], hist[2], hist[3], hist[4]);
         }
         // Wide members (build_classes) pay when ONE edge's serial chain is what the call waits for, and cost when the chip is busy anyway (every wide
         // workgroup has a CU to itself): time of the longest chain ~ its DP rows (nodes x sequences) x ~1 750 cycles, time of everything ~ DP cells
@@ -834,8 +901,9 @@ struct PoaCall {
             // more after every overflow
             E.wrows = wide_grow[e] >= 3 ? E.vcap + 1 : (uint32_t)std::min<uint64_t>((uint64_t)E.vcap + 1, ((uint64_t)E.vcap / 16 + 64) << (2 * wide_grow[e]));
         }
-        // largest first (block scheduling is in grid order): cost ~ rows x columns x sequences
-        std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) { const uint64_t ca = edge_cost(a), cb = edge_cost(b); return ca != cb ? ca > cb : a < b; });
+        // largest first (block scheduling is in grid order): cost ~ rows x columns x sequences; with column passes: the longest estimated chain first
+        if (pass_on) std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) { return chain_ms[a] != chain_ms[b] ? chain_ms[a] > chain_ms[b] : a < b; });
+        else std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) { const uint64_t ca = edge_cost(a), cb = edge_cost(b); return ca != cb ? ca > cb : a < b; });
         return 0;
     }
 
@@ -868,9 +936,9 @@ struct PoaCall {
     // 87 launched first at 1 540 ms - residency is the whole point.)
     int build_classes(const std::vector<uint32_t>& batch, std::vector<Cls>& classes) const {
         classes.clear();
-        auto cls_of = [&](bool shared, uint32_t nt, uint32_t cm, bool dir, uint32_t dpl = 0) -> Cls& {
-            for (Cls& q : classes) if (q.shared == shared && q.nt == nt && q.cm == cm && q.dir == dir && q.dpl == dpl) return q;
-            classes.push_back(Cls{shared, nt, cm, dir, dpl, {}});
+        auto cls_of = [&](bool shared, uint32_t nt, uint32_t cm, bool dir, uint32_t dpl = 0, uint32_t pb = 0, bool pk = false) -> Cls& {
+            for (Cls& q : classes) if (q.shared == shared && q.nt == nt && q.cm == cm && q.dir == dir && q.dpl == dpl && q.pb == pb && q.pk == pk) return q;
+            classes.push_back(Cls{shared, nt, cm, dir, dpl, pb, pk, {}});
             return classes.back();
         };
         uint32_t n_wide = 0;
@@ -889,8 +957,15 @@ struct PoaCall {
             }
             const uint32_t nt = (uint32_t)kClassNT[class_of(e)];
             uint32_t cmq = cm_round(ncol, nt * std::max<uint32_t>(1, P.edges[e].passes));
+            // (calls with column passes: the gaps of up to 255 bases run in the 8-column instance too - the 4-column instances take 143-158 registers, three waves
+            // per SIMD, and one such wave on a SIMD leaves room for two of the 128-register ones instead of three: CUs sat at 12 waves of their 16)
+            if (pass_on && !full_h[e] && cmq < 8) cmq = 8;
             if (o.poa_force_cm > 0) cmq = std::max<uint32_t>(cmq, std::min<uint32_t>((uint32_t)o.poa_force_cm, (uint32_t)hxk::poa_kernel_max_cm((int)nt)));   // (testing: a wider kernel instance than the gap needs)
-            cls_of(false, nt, cmq, !full_h[e]).edges.push_back(e);
+            // (calls with column passes: a class per power of two of workspace need - a persistent workgroup's slot is sized for the largest edge of its
+            // class, and a narrow workgroup may now hold a gap of any length; the classes of one kernel instance leave in one launch: launch_batch)
+            uint32_t pb = 0;
+            if (pass_on && !full_h[e]) { const uint64_t mb = need_bytes(need_of(e)) >> 20; while ((1ull << pb) <= mb) pb++; }
+            cls_of(false, nt, cmq, !full_h[e], 0, pb, pass_on && !full_h[e] && cmq > 4).edges.push_back(e);   // (pk: with column passes every 8-column launch is the pruned instance - one launch per width)
         }
         // order of the launches: shared edges first (they set the duration), then by lanes; score-matrix launches after their direction-byte twins
         const bool bal = balanced;
@@ -901,7 +976,9 @@ struct PoaCall {
             if (bal && (a.nt >= 1024 && !a.shared) != (b.nt >= 1024 && !b.shared)) return a.nt >= 1024 && !a.shared;
             if (a.shared != b.shared) return a.shared;
             if (a.nt != b.nt) return a.nt > b.nt;
-            return a.cm > b.cm;
+            if (a.cm != b.cm) return a.cm > b.cm;
+            if (a.pk != b.pk) return a.pk;
+            return a.pb > b.pb;
         });
         double total_cost = 0;
         for (Cls& q : classes) {
@@ -942,10 +1019,27 @@ struct PoaCall {
         cu_reserved = std::min<size_t>(cu_reserved, 192);
         for (Cls& q : classes) {
             q.n_slots = slots_wanted(q, shrink, cu_reserved);
-            q.persistent = !q.shared && q.n_slots < q.edges.size() && hxk::poa_persistent_ok(q.dir);
+            q.persistent = !q.shared && (q.n_slots < q.edges.size() || pass_on) && hxk::poa_persistent_ok(q.dir);   // (pass_on: the need buckets of an instance share a launch)
             if (!q.persistent) q.n_slots = q.edges.size();
         }
+        // the need buckets of one kernel instance share a launch and the chip: workgroups for 5/4 of what the chip holds of that width in all, dealt from the
+        // largest need down (a workgroup serves its bucket and every smaller one, not the other way round); a bucket keeps a few workgroups of its own
+        if (pass_on)
+            for (size_t i = 0; i < classes.size();) {
+                size_t j = i + 1;
+                while (j < classes.size() && same_instance(classes[i], classes[j])) j++;
+                if (classes[i].persistent && j - i > 1 && !o.poa_slots) {
+                    size_t left = std::max<size_t>(1, ((size_t)4096 / (classes[i].nt / 64)) * 5 / 4 * shrink / 1000);
+                    for (size_t k = i; k < j; k++) {
+                        Cls& q = classes[k];
+                        q.n_slots = std::min(q.n_slots, std::max<size_t>(left, std::min<size_t>(q.edges.size(), 8)));
+                        left -= std::min(left, q.n_slots);
+                    }
+                }
+                i = j;
+            }
     }
+    static bool same_instance(const Cls& a, const Cls& b) { return a.persistent && b.persistent && a.nt == b.nt && a.cm == b.cm && a.dir == b.dir && a.dpl == b.dpl && a.pk == b.pk; }
     Need slot_need(const Cls& q, size_t b) const { return q.persistent ? q.need : need_of(q.edges[b]); }   // per slot: the edge's own need, or (persistent) the largest of the class
     uint64_t total_bytes(std::vector<Cls>& classes, uint32_t shrink) const {
         uint64_t t = 0;
@@ -982,6 +1076,9 @@ struct PoaCall {
         return 0;
     }
 
+    // the pruned instance: unshared edges, direction bytes, 4 or 8 columns per lane, a workgroup of several waves - or of any width when its edges take their
+    // columns in passes (a one-wave workgroup that holds its gap has nothing to skip: its rows are whole rows)
+    bool launch_pruned(const Cls& q) const { return !q.shared && hxk::poa_prune_ok(q.dir, (int)q.cm) && (q.nt >= (uint32_t)o.poa_prune_lanes || q.pk) && prune_pct != 0; }
     // ---- launch of one batch; what the collection needs afterwards
     struct Launched { std::vector<uint32_t> edges; uint64_t cns_bytes = 0, bytes = 0; std::vector<Cls> classes; };
     int launch_batch(const std::vector<uint32_t>& batch, uint32_t shrink, Launched& lb) {
@@ -1076,10 +1173,35 @@ struct PoaCall {
         size_t wg_total = 0;
         for (const Cls& q : classes) wg_total += q.blocks;
         c->tick();
+        // The launches. Persistent classes that differ only in their need bucket (build_classes) leave in ONE launch: their slots, lists and counters
+        // lie side by side in class order (largest need first), `btab` tells a workgroup which bucket its slot belongs to (kernels/poa.hip k_poa).
+        std::vector<uint32_t> h_btab;
+        std::vector<std::array<size_t, 3>> groups;   // first class, one past the last, offset of the group's table in h_btab
+        for (size_t i = 0; i < classes.size();) {
+            size_t j = i + 1;
+            const Cls& a = classes[i];
+            while (j < classes.size() && same_instance(a, classes[j])) j++;
+            groups.push_back({i, j, h_btab.size()});
+            if (a.persistent) {
+                h_btab.push_back((uint32_t)(j - i));
+                uint32_t se = 0, ib = 0;
+                for (size_t k = i; k < j; k++) { se += (uint32_t)classes[k].blocks; h_btab.push_back(se); }
+                for (size_t k = i; k < j; k++) { h_btab.push_back(ib); ib += (uint32_t)classes[k].edges.size(); }
+                h_btab.push_back(ib);
+                for (size_t k = i; k < j; k++) for (uint32_t e : classes[k].edges) h_btab.push_back((uint32_t)std::min(4.0e9, (double)chain_ms[e] * 1000.0));   // est[]: microseconds
+            }
+            i = j;
+        }
+        HIPCHK(c->poa_btab.reserve(std::max<size_t>(1, h_btab.size())));
+        if (!h_btab.empty()) HIPCHK(hipMemcpyAsync(c->poa_btab.p, h_btab.data(), h_btab.size() * 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipEventRecord(c->poa_ev[8], s));
-        size_t ci = 0;
-        for (const Cls& q : classes) {
-            const int sk = (int)(ci % n_streams);   // stream / event of the launch (launches that share a stream run one after the other)
+        size_t gi = 0;
+        for (const auto& grp : groups) {
+            const size_t ci = grp[0];
+            const Cls& q = classes[ci];
+            size_t g_blocks = 0, g_items = 0;
+            for (size_t k = grp[0]; k < grp[1]; k++) { g_blocks += classes[k].blocks; g_items += classes[k].edges.size(); }
+            const int sk = (int)(gi % n_streams);   // stream / event of the launch (launches that share a stream run one after the other)
             // LDS of the launch: the ring its row width allows, a power of two of kept rows
             uint64_t ring_need = 0;
             const uint32_t dp_nt = q.dpl ? q.dpl : q.nt;   // lanes in the DP
@@ -1096,17 +1218,20 @@ struct PoaCall {
                 if (o.poa_ring_zero) lds_bytes = ring_need;   // (one row's worth: the kernel then finds room for no kept row either)
             }
             const int dcls = q.shared ? 0 : q.nt >= 1024 ? 1 : q.nt >= 512 ? 2 : q.nt >= 256 ? 3 : q.nt >= 128 ? 4 : 5;
-            for (uint32_t e : q.edges) c->dbg_cls[e] = (uint8_t)(dcls + (q.dir ? 0 : 5));
+            for (size_t k = grp[0]; k < grp[1]; k++)
+                for (uint32_t e : classes[k].edges) { c->dbg_cls[e] = (uint8_t)(dcls + (q.dir ? 0 : 5)); c->dbg_shape[e] = q.nt | std::min<uint32_t>(255, P.edges[e].passes) << 16 | std::min<uint32_t>(255, P.edges[e].members) << 24; }
             c->dbg_ring[dcls + (q.dir ? 0 : 5)] = R;
             HIPCHK(hipStreamWaitEvent(c->poa_streams[sk], c->poa_ev[8], 0));
             hxk::PoaLaunch L{};
-            L.edges = c->poa_edges.p; L.order = c->poa_order.p + q.order_at; L.n_items = q.persistent ? (uint32_t)q.edges.size() : (uint32_t)q.blocks;
-            L.slots = c->poa_slots.p + (q.persistent ? q.slot_at : 0); L.counter = q.persistent ? c->poa_counters.p + ci : nullptr; L.n_blocks = (uint32_t)q.blocks;
+            L.edges = c->poa_edges.p; L.order = c->poa_order.p + q.order_at; L.n_items = q.persistent ? (uint32_t)g_items : (uint32_t)q.blocks;
+            L.slots = c->poa_slots.p + (q.persistent ? q.slot_at : 0); L.counter = q.persistent ? c->poa_counters.p + ci : nullptr; L.n_blocks = (uint32_t)g_blocks;
+            L.btab = q.persistent ? c->poa_btab.p + grp[2] : nullptr;
             L.seqs = c->poa_seqs.p; L.packed = in.d_packed; L.read_off = in.d_roff; L.read_len = in.d_rlen; L.pools = pools;
             L.match = pp->match; L.mismatch = pp->mismatch; L.gap = pp->gap; L.cns = c->poa_cns.p; L.cns_len = c->poa_len.p; L.status = c->poa_status.p;
             L.cells = c->poa_cells_d.p; L.phase = c->poa_phase_d.p; L.block_threads = (int)q.nt; L.cm = (int)q.cm; L.poll_limit = (uint32_t)o.poa_poll_limit; L.ring_bytes = (uint32_t)lds_bytes;
             L.use_dir = q.dir; L.max_indeg = (uint32_t)std::min(16, std::max(1, o.poa_max_indeg)); L.dp_lanes = q.dpl;
-            L.prune_pct = !q.shared && hxk::poa_prune_ok(q.dir, (int)q.cm) && q.nt >= (uint32_t)o.poa_prune_lanes && prune_pct ? (std::min<uint32_t>(prune_pct, 1000u) | (o.poa_prune_lazy ? 1u << 16 : 0u)) : 0u;   // (a one-wave workgroup has nothing to skip: its rows are whole rows)
+            L.prune_pct = launch_pruned(q) ? (std::min<uint32_t>(prune_pct, 1000u) | (o.poa_prune_lazy ? 1u << 16 : 0u)) : 0u;
+            if (o.debug) { int occ = 0; L.occupancy = &occ; hxk::poa_run(L, c->poa_streams[sk]); L.occupancy = nullptr; fprintf(stderr, "[hx] launch %zu: %zu workgroups of %u lanes, %.1f KB of ring: %d workgroups per CU\n", gi, g_blocks, q.nt, lds_bytes / 1024.0, occ); }
             hxk::poa_run(L, c->poa_streams[sk]);
             HIPCHK(hipEventRecord(c->poa_ev[sk], c->poa_streams[sk]));
             HIPCHK(hipStreamWaitEvent(s, c->poa_ev[sk], 0));
@@ -1117,7 +1242,7 @@ struct PoaCall {
                 const auto tw = std::chrono::steady_clock::now();
                 while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw).count() < o.poa_wide_delay_us) { }
             }
-            ci++;
+            gi++;
         }
         c->tock(3);
         HIPCHK(hipGetLastError());
@@ -1125,7 +1250,7 @@ struct PoaCall {
             HIPCHK(hipStreamSynchronize(s));
             fprintf(stderr, "[hx] POA batch: %zu edges, %.2f GB workspace, workgroups", batch.size(), bytes / 1e9);
             for (const Cls& q : classes) fprintf(stderr, " %s%s%s%s%ux%u:%zu(%zu edges, largest %.1f MB)", q.shared ? "shared/" : "", q.persistent ? "persistent/" : "", q.dir ? "" : "matrix/",
-                                                 !q.shared && hxk::poa_prune_ok(q.dir, (int)q.cm) && q.nt >= (uint32_t)o.poa_prune_lanes && prune_pct ? "pruned/" : "", q.nt, q.cm, q.blocks, q.edges.size(), need_bytes(q.need) / 1e6);
+                                                 launch_pruned(q) ? (q.pk ? "pruned/passes/" : "pruned/") : "", q.nt, q.cm, q.blocks, q.edges.size(), need_bytes(q.need) / 1e6);
             fprintf(stderr, ", %.1f ms since the call began\n", ms_since_start());
         }
         return 0;
@@ -1175,6 +1300,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     if (K.plan_input(todo)) return -1;
     if (c->opt.debug) fprintf(stderr, "[hx] POA call: %u edges prepared in %.1f ms\n", (unsigned)ne, K.ms_since_start());
     c->dbg_cls.assign(ne, 11); for (int k = 0; k < 11; k++) c->dbg_ring[k] = 0;
+    c->dbg_shape.assign(ne, 0);
     c->dbg_nseq = K.P.nseq; c->dbg_lmax.resize(ne); for (uint32_t e = 0; e < ne; e++) c->dbg_lmax[e] = K.P.edges[e].lmax;
     HIPCHK(c->poa_seqs.reserve(K.P.seqs.size()));
     if (!K.P.seqs.empty()) HIPCHK(hipMemcpyAsync(c->poa_seqs.p, K.P.seqs.data(), K.P.seqs.size() * sizeof(hxk::PoaSeq), hipMemcpyHostToDevice, s));
@@ -1322,6 +1448,18 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
             return (uint32_t)ne;
         }
         const unsigned long long M40 = (1ull << 40) - 1;
+        if (c->opt.debug >= 2) {   // every edge: shape of its launch, begin and end on the 100 MHz wall clock (relative to the call's first edge), phase cycles, DP rows
+            unsigned long long t0 = ~0ull;
+            const unsigned long long M44 = (1ull << 44) - 1;
+            for (size_t e = 0; e < ne; e++) if (c->poa_phase[e * PW_ + 16]) t0 = std::min(t0, c->poa_phase[e * PW_ + 16] & M44);
+            for (size_t e = 0; e < ne; e++) {
+                const unsigned long long* q2 = &c->poa_phase[e * PW_];
+                if (!q2[16]) continue;
+                const uint32_t sh = e < c->dbg_shape.size() ? c->dbg_shape[e] : 0;
+                fprintf(stderr, "[hx-edge] %zu lmax %u nseq %u cls %d lanes %u passes %u members %u hw %u begin_us %.1f end_us %.1f decode %llu dp %llu tb %llu graph %llu order %llu csr %llu rows %llu wrows %llu wskip %llu\n", e, c->dbg_lmax[e], c->dbg_nseq[e],
+                        e < c->dbg_cls.size() ? c->dbg_cls[e] : 11, sh & 0xffffu, (sh >> 16) & 255u, sh >> 24, (unsigned)(q2[16] >> 44), (double)((q2[16] & M44) - t0) * 0.01, (double)(q2[17] - t0) * 0.01, q2[0], q2[1], q2[2], q2[3], q2[4], q2[5], q2[6], q2[12], q2[13]);
+            }
+        }
         fprintf(stderr, "[hx] slowest edge %u: lmax=%u nseq=%u | DP rows %llu (multi-pred %llu, ring refs %llu, far refs %llu, kept %llu, more than 4 predecessors %llu, fifth-and-later entries %llu) over %llu sequences\n", c->dbg_slowest,
                 c->dbg_lmax[c->dbg_slowest], c->dbg_nseq[c->dbg_slowest], q[6], q[7], q[8] & M40, q[9] & M40, q[10], q[9] >> 40, q[8] >> 40, q[11] & 0xffffffffull);
         {   // the five longest edges (critical-path candidates)

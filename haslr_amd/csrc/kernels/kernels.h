@@ -142,11 +142,14 @@ inline bool poa_persistent_ok(bool use_dir) { return use_dir; }   // launches th
 // launches of one workgroup per edge (a shared edge's members would have to repeat an attempt together)
 inline bool poa_prune_ok(bool use_dir, int cm) { return use_dir && cm <= 8; }
 constexpr int32_t PRUNE_OFF = -(1 << 24);   // a threshold no real cell is below (|scores| < 2^24: the host checks 8 (nodes + columns))
-constexpr int POA_PHASE_WORDS = 16;         // per edge: 6 phase cycle counters, 6 row statistics, 4 of the pruning (wave-rows, wave-rows skipped, attempts repeated, alignments with a threshold)
+constexpr int POA_PHASE_WORDS = 18;         // per edge: 6 phase cycle counters, 6 row statistics, 4 of the pruning (wave-rows, wave-rows skipped, attempts repeated, alignments with a threshold), the edge's begin and end on the 100 MHz wall clock
 // One launch of a class. counter == nullptr: one workgroup per entry of `order` (edge | member << 24; shared edges, each in its own slot
-// PoaEdge::slot); else PERSISTENT: n_blocks workgroups, workgroup b owns slots[b] and pulls the n_items edges of `order` through *counter.
+// PoaEdge::slot); else PERSISTENT: n_blocks workgroups, workgroup b owns slots[b]; the n_items edges of `order` come in nb buckets of workspace need
+// (largest first), bucket k = order[item_begin[k] .. item_begin[k + 1]) behind counter[k], its workgroups = the slots [slot_end[k - 1], slot_end[k]);
+// btab (device) = {nb, slot_end[0 .. nb), item_begin[0 .. nb], est[0 .. n_items)}: est = the estimated chain time of every entry of `order` (any unit). A
+// workgroup takes, of the next edges of its bucket and of the later (smaller) ones, the one with the longest chain.
 struct PoaLaunch {
-    const PoaEdge* edges; const uint32_t* order; uint32_t n_items; const PoaSlot* slots; uint32_t* counter; uint32_t n_blocks;
+    const PoaEdge* edges; const uint32_t* order; uint32_t n_items; const PoaSlot* slots; uint32_t* counter; const uint32_t* btab; uint32_t n_blocks;
     const PoaSeq* seqs; const uint8_t* packed; const uint64_t* read_off; const uint32_t* read_len; PoaPools pools;
     int32_t match, mismatch, gap; char* cns; uint32_t *cns_len, *status;
     unsigned long long *cells, *phase /* POA_PHASE_WORDS per edge or null */;
@@ -155,6 +158,7 @@ struct PoaLaunch {
     uint32_t poll_limit /* polls before a wave gives up waiting for another (-> HXE_POA_STALLED) */, ring_bytes /* dynamic LDS */;
     bool use_dir /* direction-byte traceback (in-degrees <= max_indeg <= 16, else the edge comes back with HXE_POA_NODIR) */;
     uint32_t max_indeg, dp_lanes /* 0: every lane of the workgroup; else the lanes that take part in the DP (a wide cluster member) */;
+    int* occupancy /* not null: no launch - the workgroups of this launch's shape a CU holds (hipOccupancyMaxActiveBlocksPerMultiprocessor), for the debug output */;
     uint32_t prune_pct /* 0: full matrix; else the pruned instance (poa_prune_ok, unshared edges) with thresholds at this percentage of the previous alignment's score per base */;
 };
 void poa_run(const PoaLaunch& q, hipStream_t s);

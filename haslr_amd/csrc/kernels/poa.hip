@@ -1207,7 +1207,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                                          uint32_t poll_limit, uint32_t lds_bytes, uint32_t max_indeg, uint32_t dp_lanes, uint32_t prune_pct) {
     __shared__ unsigned long long ph[POA_PHASE_WORDS];   // lane-0 cycle counts: decode, dp, traceback, graph update, toposort, csr; then row statistics (6-11) and the pruning's (12-15)
     __shared__ long long tc;
-    if (threadIdx.x == 0) { for (int k = 0; k < POA_PHASE_WORDS; k++) ph[k] = 0; tc = clock64(); }
+    if (threadIdx.x == 0) { for (int k = 0; k < POA_PHASE_WORDS; k++) ph[k] = 0; tc = clock64(); ph[16] = (wall_clock64() & ((1ull << 44) - 1)) | ((unsigned long long)((__builtin_amdgcn_s_getreg(63492) & 0x7fffu) | ((__builtin_amdgcn_s_getreg(63508) & 15u) << 15)) << 44); }   // (begin; where: HW_ID bits 0-14 = wave, SIMD, pipe, CU, SH, SE and the XCC)
 #define PHASE(k) do { if (tid == 0) { long long _n = clock64(); ph[k] += (unsigned long long)(_n - tc); tc = _n; } } while (0)
 #ifdef HX_GU_PROF   // development: where the graph update (slots 6-10) and the CSR rebuild (slot 11: its first half) spend their cycles - printed by HX_PROF2 (its labels are the DP's)
 #define GU_T0() do { __syncthreads(); if (tid == 0) tg = clock64(); } while (0)
@@ -1268,8 +1268,10 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     const uint32_t WH = W + (WT > 1 ? (WT + 3u) & ~3u : 0u);   // rows of H end with one word per wave of the edge's pipeline (dp_rows)
 
     // static LDS is kept small for the launches that can share a CU: sink rows kept in LDS (an alignment ends in at most one sink per sequence
-    // aligned so far; an edge with more than 256 is redone by the 1024-lane kernel), wave mailboxes for the waves the launch can have
-    constexpr uint32_t SINK_LDS = MAXNT < 1024 ? 256 : SINK_CAP;
+    // aligned so far; an edge with more than the launch keeps is redone by the 1024-lane kernel), wave mailboxes for the waves the launch can have
+    // (128 entries up to 256 lanes: with the 8.3 KB ring of a many-edge call a one-wave workgroup then takes 10 128 bytes of LDS - sixteen of them on a CU, where
+    // 256 entries left room for fourteen; round 5)
+    constexpr uint32_t SINK_LDS = MAXNT <= 256 ? 128 : MAXNT < 1024 ? 256 : SINK_CAP;
     __shared__ WaveMailT<MAXNT / 64> wmail;
     __shared__ uint32_t lds_u[16];
     __shared__ uint32_t sV, sE, sNaln, sOk, sNsink, sNcand, sBestKey;
@@ -1768,62 +1770,71 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                 if (!par) {                                 // (kept for safety: the serial walk handles any alignment shape)
                     if (tid == 0) { uint32_t V2 = V0, E2 = E0; if (!add_alignment(g, V2, E2, na, seq, L, path, colref)) sOk = 0; else { sV = V2; sE = E2; } }
                 } else {
-                    const uint32_t CH = (L + NT - 1) / NT;
-                    const uint32_t a0 = min(tid * CH, L), a1 = min(a0 + CH, L);
-                    uint32_t cnt = 0;
-                    for (uint32_t p = a0; p < a1; p++) {
-                        const uint8_t c = seq[p];
-                        const int32_t an = chain ? -1 : anode[p];
+                    // (round 5: lane = base. Bases are taken NT at a time - coalesced accesses by position, one scan per block with a running base for the ids -
+                    // where round 1 dealt them out in contiguous chunks per thread: every load of a wave then touched 64 different cache lines)
+                    uint32_t nbase = 0;
+                    bool ovf = false;
+                    for (uint32_t base = 0; base < L; base += NT) {
+                        const uint32_t p = base + tid;
+                        const bool on = p < L;
                         uint32_t tgt = NONE;                // NONE = new node
-                        if (an >= 0) {
-                            if (g.code[an] == c) tgt = (uint32_t)an;
-                            else for (uint32_t q = 0, nq = g.n_aligned[an]; q < nq; q++) { const uint32_t a = g.aligned[3 * an + q]; if (g.code[a] == c) { tgt = a; break; } }
+                        int32_t an = -1;
+                        uint8_t c = 0;
+                        if (on) {
+                            c = seq[p];
+                            an = chain ? -1 : anode[p];
+                            if (an >= 0) {
+                                if (g.code[an] == c) tgt = (uint32_t)an;
+                                else for (uint32_t q = 0, nq = g.n_aligned[an]; q < nq; q++) { const uint32_t a = g.aligned[3 * an + q]; if (g.code[a] == c) { tgt = a; break; } }
+                            }
                         }
-                        path[p] = tgt; colref[p] = an >= 0 ? (uint32_t)an : NONE;
-                        cnt += tgt == NONE;
+                        const bool isnew = on && tgt == NONE;
+                        uint32_t tot;
+                        const uint32_t ex = block_excl_scan_add((uint32_t)isnew, lds_u, &tot);
+                        if (V0 + nbase + tot > g.vcap) { ovf = true; break; }   // the graph outgrows its workspace (same verdict on every lane): the host retries with more
+                        if (isnew) {
+                            uint32_t vv = V0 + nbase + ex;
+                            const uint32_t nn = add_node(g, vv, c);
+                            if (an >= 0) {                  // joins the column of the node it was aligned to
+                                for (uint32_t q = 0, nq = g.n_aligned[an]; q < nq; q++) { const uint32_t a = g.aligned[3 * an + q]; push_aligned(g, nn, a); push_aligned(g, a, nn); }
+                                push_aligned(g, nn, (uint32_t)an); push_aligned(g, (uint32_t)an, nn);
+                            }
+                            tgt = nn;
+                        }
+                        if (on) { path[p] = tgt; colref[p] = an >= 0 ? (uint32_t)an : NONE; }
+                        nbase += tot;
                     }
-                    GU_T(7);   // target node of every base (reuse / column member / new)
-                    uint32_t newV;
-                    uint32_t nid = V0 + block_excl_scan_add(cnt, lds_u, &newV);
-                    if (V0 + newV > g.vcap) { if (tid == 0) sOk = 0; }   // the graph outgrows its workspace (same verdict on every lane): the host retries with more
+                    const uint32_t newV = nbase;
+                    GU_T(8);   // target node of every base (reuse / column member / new), node ids (scan) + new nodes and their columns
+                    if (ovf) { if (tid == 0) sOk = 0; }
                     else {
-                    for (uint32_t p = a0; p < a1; p++) {
-                        if (path[p] != NONE) continue;
-                        uint32_t vv = nid;
-                        const uint32_t nn = add_node(g, vv, seq[p]);
-                        nid++;
-                        const uint32_t an = colref[p];
-                        if (an != NONE) {                   // joins the column of the node it was aligned to
-                            for (uint32_t q = 0, nq = g.n_aligned[an]; q < nq; q++) { const uint32_t a = g.aligned[3 * an + q]; push_aligned(g, nn, a); push_aligned(g, a, nn); }
-                            push_aligned(g, nn, an); push_aligned(g, an, nn);
-                        }
-                        path[p] = nn;
-                    }
                     __syncthreads();
-                    GU_T(8);   // node ids (scan) + new nodes and their columns
-                    cnt = 0;
-                    for (uint32_t p = max(a0, 1u); p < a1; p++) {
-                        const uint32_t f = path[p - 1], t = path[p];
-                        uint32_t hit = NONE;
-                        if (f < V0 && t < V0) for (uint32_t e = g.out_head[f]; e != NONE; e = g.e_next_out[e]) if (g.e_to[e] == t) { hit = e; break; }
-                        if (hit != NONE) g.e_w[hit] += 2;
-                        eref[p] = hit;
-                        cnt += hit == NONE;
+                    uint32_t ebase = 0;
+                    for (uint32_t base = 0; base < L; base += NT) {
+                        const uint32_t p = base + tid;
+                        const bool on = p >= 1 && p < L;
+                        uint32_t f = NONE, t = NONE, hit = NONE;
+                        if (on) {
+                            f = path[p - 1]; t = path[p];
+                            if (f < V0 && t < V0) for (uint32_t e = g.out_head[f]; e != NONE; e = g.e_next_out[e]) if (g.e_to[e] == t) { hit = e; break; }
+                            if (hit != NONE) g.e_w[hit] += 2;
+                        }
+                        const bool isnew = on && hit == NONE;
+                        uint32_t tot;
+                        const uint32_t ex = block_excl_scan_add((uint32_t)isnew, lds_u, &tot);
+                        if (isnew) {
+                            const uint32_t e = E0 + ebase + ex;
+                            g.e_from[e] = f; g.e_to[e] = t; g.e_w[e] = 2; g.e_next_in[e] = NONE; g.e_next_out[e] = NONE;
+                            if (g.out_tail[f] == NONE) g.out_head[f] = e; else g.e_next_out[g.out_tail[f]] = e;
+                            g.out_tail[f] = e;
+                            uint32_t* r = reinterpret_cast<uint32_t*>(&g.nrec[t]);
+                            if (g.in_tail[t] == NONE) { g.in_head[t] = e; r[0] = f; }
+                            else { g.e_next_in[g.in_tail[t]] = e; if (r[1] == NONE) r[1] = f; else r[3] |= 0x80000000u; }
+                            g.in_tail[t] = e;
+                        }
+                        ebase += tot;
                     }
-                    GU_T(9);   // existing edge of every step (out-list search)
-                    uint32_t newE;
-                    uint32_t eid = E0 + block_excl_scan_add(cnt, lds_u, &newE);
-                    for (uint32_t p = max(a0, 1u); p < a1; p++) {
-                        if (eref[p] != NONE) continue;
-                        const uint32_t f = path[p - 1], t = path[p], e = eid++;
-                        g.e_from[e] = f; g.e_to[e] = t; g.e_w[e] = 2; g.e_next_in[e] = NONE; g.e_next_out[e] = NONE;
-                        if (g.out_tail[f] == NONE) g.out_head[f] = e; else g.e_next_out[g.out_tail[f]] = e;
-                        g.out_tail[f] = e;
-                        uint32_t* r = reinterpret_cast<uint32_t*>(&g.nrec[t]);
-                        if (g.in_tail[t] == NONE) { g.in_head[t] = e; r[0] = f; }
-                        else { g.e_next_in[g.in_tail[t]] = e; if (r[1] == NONE) r[1] = f; else r[3] |= 0x80000000u; }
-                        g.in_tail[t] = e;
-                    }
+                    const uint32_t newE = ebase;
                     GU_T(10);  // edge ids (scan) + new edges appended
                     if (tid == 0) { sV = V0 + newV; sE = E0 + newE; }
                     }
@@ -1870,17 +1881,17 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                     }
                 }
                 __syncthreads();
-                const uint32_t CH = (V_old + 1 + NT - 1) / NT;
-                const uint32_t a0 = min(tid * CH, V_old + 1), a1 = min(a0 + CH, V_old + 1);
-                uint32_t sum = 0;
-                for (uint32_t r = a0; r < a1; r++) sum += ins[r];
-                uint32_t tot;
-                uint32_t ex = block_excl_scan_add(sum, lds_u, &tot);
-                for (uint32_t r = a0; r < a1; r++) {
-                    const uint32_t c = ins[r];
-                    ins[r] = ex;                                            // new nodes with X == r start at r + ex
-                    if (r < V_old) tmp_u32[r + ex + c] = g.rank2node[r];    // the old node itself moves behind them
-                    ex += c;
+                uint32_t ibase = 0;
+                for (uint32_t base = 0; base <= V_old; base += NT) {      // (lane = old rank, NT at a time: one scan per block with a running base)
+                    const uint32_t r = base + tid;
+                    const uint32_t c = r <= V_old ? ins[r] : 0u;
+                    uint32_t tot;
+                    const uint32_t ex = ibase + block_excl_scan_add(c, lds_u, &tot);
+                    if (r <= V_old) {
+                        ins[r] = ex;                                        // new nodes with X == r start at r + ex
+                        if (r < V_old) tmp_u32[r + ex + c] = g.rank2node[r];    // the old node itself moves behind them
+                    }
+                    ibase += tot;
                 }
                 __syncthreads();
                 for (uint32_t q = tid; q < L; q += NT) {   // nodes with the same insertion point keep path order
@@ -1896,109 +1907,113 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
         PHASE(4);
         __syncthreads();
         // =================================================== rank-order CSR for the next DP (all lanes)
+        // Round 5: lane = rank. The first version dealt the ranks out in contiguous chunks per thread (a thread's prefix sums were then its own running
+        // counts) and ran seven passes of dependent list walks over them: every load of a wave touched 64 different cache lines, and the rebuild took ~2 000
+        // cycles PER ROW of a one-wave workgroup under load - a fifth of all wave cycles of a 13 000-edge call (tools/dev_r05.sh edgedump). Now the ranks
+        // are taken NT at a time, lane t = rank base + t: the rank-indexed arrays are read and written coalesced, the node-indexed ones nearly so (node ids
+        // rise with the ranks), offsets and ring slots come from a scan per block of ranks with a running base, and what used to need a pass of its own is
+        // read where it already is: the first two in-edge sources and the aligned ids from the node's 16-byte record, "kept" (a successor that is not the
+        // next row) from the node's own out-list instead of atomics from its successors. Four passes, one dependent chain of 3-4 loads each.
         {
             const uint32_t V2 = sV;
             for (uint32_t r = tid; r < V2; r += NT) g.node2rank[g.rank2node[r]] = r;
             __syncthreads();
-            const uint32_t CH = (V2 + NT - 1) / NT;
-            const uint32_t r0 = min(tid * CH, V2), r1 = min(r0 + CH, V2);
-            uint32_t cnt = 0;
-            for (uint32_t r = r0; r < r1; r++) {
-                uint32_t n = g.rank2node[r];
-                for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) cnt++;
-            }
-            uint32_t tot;
-            uint32_t off = block_excl_scan_add(cnt, lds_u, &tot);
-            for (uint32_t r = r0; r < r1; r++) {
-                uint32_t n = g.rank2node[r];
-                g.row_pred_off[r] = off;
-                const uint32_t cd = g.code[n], sink = g.out_head[n] == NONE;
-                g.row_code[r] = (uint8_t)cd;
-                g.row_sink[r] = (uint8_t)sink;
-                {   // the column's other members in list order, as rank deltas (a column is contiguous in this order)
-                    uint32_t alp = 0;
-                    for (uint32_t q = 0, nq = g.n_aligned[n]; q < nq; q++) alp |= ((g.node2rank[g.aligned[3 * n + q]] - r + 4u) & 7u) << (3 * q);
-                    g.row_al[r] = (uint16_t)alp;
-                }
-                uint32_t np = 0, q0 = 0, q1 = 0;
-                for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) {
-                    const uint32_t pr = g.node2rank[g.e_from[e]];
-                    g.pred_w[off] = g.e_w[e];
-                    g.pred_rank[off++] = pr;
-                    if (np == 0) q0 = pr; else if (np == 1) q1 = pr;
-                    np++;
-                }
-                g.row_meta[r] = cd | (sink << 2) | (np > 4u ? 32u : 0u) | (np << META_NP);
-                if (DIR && np > max_indeg) sOk = 4;   // the direction bytes hold a 4-bit predecessor slot (max_indeg <= 16)
-                g.row_pred0[r] = q0; g.row_pred1[r] = q1;
-            }
-            if (tid == NT - 1) g.row_pred_off[V2] = tot;
-            __syncthreads();
-            {
-                // Wave kernel: a row lives in the owning lanes' registers for exactly one more row. Rows with a NON-adjacent successor
-                // are "kept": they get ring slots in the order they are produced (slot = #kept rows before it, mod R), and every
-                // predecessor reference is tagged with where the DP will find the row: 1..R ring slot + 1, 13 the previous row (registers), 14 the virtual row 0, 15 HBM.
-                for (uint32_t r = r0; r < r1; r++)
-                    for (uint32_t q = g.row_pred_off[r], qe = q + (g.row_meta[r] >> META_NP); q < qe; q++)
-                        if (r - g.pred_rank[q] >= 2) atomicOr(&g.row_meta[g.pred_rank[q]], 16u);
-                __syncthreads();
-                uint32_t kc = 0;
-                for (uint32_t r = r0; r < r1; r++) kc += (g.row_meta[r] >> 4) & 1u;
-                uint32_t ktot;
-                uint32_t kex = block_excl_scan_add(kc, lds_u, &ktot);
-                for (uint32_t r = r0; r < r1; r++) {   // kept rows before r; the row's own ring slot goes into its record (own rows only: nobody else writes these words in this phase)
-                    const uint32_t kept = (g.row_meta[r] >> 4) & 1u;
-                    g.score[r] = (int32_t)kex;
-                    g.row_meta[r] |= (kept && R ? (kex & (R - 1)) : 15u) << META_SLOT;   // 15: no non-adjacent reader (or no ring at all) - the row is not written to the ring
-                    kex += kept;
-                }
-                __syncthreads();
-                uint32_t st_multi = 0, st_ring = 0, st_far = 0, st_wide = 0, st_fifth = 0;
-                for (uint32_t r = r0; r < r1; r++) {
-                    const uint32_t po = g.row_pred_off[r], np = g.row_meta[r] >> META_NP;
-                    st_multi += np >= 2; st_wide += np > 4; st_fifth += np > 4 ? np - 4 : 0;
-                    for (uint32_t q = 0; q < np; q++) {
-                        const uint32_t pr = g.pred_rank[po + q];
-                        uint32_t loc;
-                        if (r - pr == 1) loc = 13;   // the previous row: still in the registers of the lanes that own its columns
-                        else {
-                            const uint32_t live = (uint32_t)g.score[r] - (uint32_t)g.score[pr];   // kept rows produced in [pr, r), pr included
-                            if (live <= R) loc = 1 + ((uint32_t)g.score[pr] & (R - 1));
-                            else { loc = 15; atomicOr(&g.row_meta[pr], 8u); }
-                        }
-                        const uint32_t ent = pr | (loc << 28);
-                        st_ring += r - pr >= 2 && loc != 15; st_far += loc == 15;
-                        g.pred_rank[po + q] = ent;
-                        if (q == 0) g.row_pred0[r] = ent; else if (q == 1) g.row_pred1[r] = ent;
+            uint32_t off_base = 0, kept_base = 0;
+            uint32_t st_multi = 0, st_ring = 0, st_far = 0, st_wide = 0, st_fifth = 0;
+            for (uint32_t base = 0; base < V2; base += NT) {           // ---- pass B: everything a row knows about itself
+                const uint32_t r = base + tid;
+                const bool on = r < V2;
+                uint32_t n = 0, np = 0, kept = 0, cd = 0, sink = 0, alp = 0, e0 = NONE, f0 = NONE, f1 = NONE;
+                if (on) {
+                    n = g.rank2node[r];
+                    const uint4 rec = g.nrec[n];                       // {1st in-edge source, 2nd, aligned ids + 1 (3 x 21 bits), bit 63: more in-edges}
+                    e0 = g.in_head[n];
+                    const uint32_t oh = g.out_head[n];
+                    cd = g.code[n];
+                    f0 = rec.x; f1 = rec.y;
+                    np = f0 == NONE ? 0u : f1 == NONE ? 1u : 2u;
+                    if (rec.w & 0x80000000u) { np = 0; for (uint32_t e = e0; e != NONE; e = g.e_next_in[e]) np++; }   // three or more: the list is walked (rare)
+                    sink = oh == NONE;
+                    for (uint32_t e = oh; e != NONE; e = g.e_next_out[e]) kept |= (uint32_t)(g.node2rank[g.e_to[e]] - r >= 2u);   // a successor that is not the next row reads this one from the ring / HBM
+                    const unsigned long long al = ((unsigned long long)rec.z | ((unsigned long long)rec.w << 32)) & 0x7fffffffffffffffULL;
+                    for (uint32_t q = 0; q < 3; q++) {                 // the column's other members in list order, as rank deltas (a column is contiguous in this order)
+                        const uint32_t a1 = (uint32_t)(al >> (21 * q)) & 0x1fffffu;
+                        if (!a1) break;
+                        alp |= ((g.node2rank[a1 - 1] - r + 4u) & 7u) << (3 * q);
                     }
-                    if (np == 0) g.row_pred0[r] = 14u << 28;   // a source node: the virtual row 0
                 }
-                if (DIR) {   // rows that a far successor reads back from HBM get consecutive rows of H (the score matrix is not kept with direction bytes)
-                    __syncthreads();
-                    uint32_t fc = 0;
-                    for (uint32_t r = r0; r < r1; r++) fc += (g.row_meta[r] >> 3) & 1u;
-                    uint32_t ftot;
-                    uint32_t fex = block_excl_scan_add(fc, lds_u, &ftot);
-                    uint32_t* farslot = reinterpret_cast<uint32_t*>(g.pred);
-                    for (uint32_t r = r0; r < r1; r++) if (g.row_meta[r] & 8u) farslot[r] = fex++;
-                    if (tid == 0 && ftot > ED.hrows && sOk == 1) sOk = 5;   // more far rows than the estimate: the host retries with a row per node
-                    // rows with more than 4 predecessors keep a direction byte per cell in the wide-row pool
-                    uint32_t wc = 0;
-                    for (uint32_t r = r0; r < r1; r++) wc += (g.row_meta[r] >> 5) & 1u;
-                    uint32_t wtot;
-                    uint32_t wex = block_excl_scan_add(wc, lds_u, &wtot);
-                    for (uint32_t r = r0; r < r1; r++) if (g.row_meta[r] & 32u) g.wslot[r] = wex++;
-                    if (tid == 0 && wtot > ED.wrows && sOk == 1) sOk = 7;   // more of them than the estimate: the host retries with more
+                uint32_t tot_np, tot_k;
+                const uint32_t ex_np = block_excl_scan_add(np, lds_u, &tot_np);
+                const uint32_t ex_k = block_excl_scan_add(kept, lds_u, &tot_k);
+                if (on) {
+                    const uint32_t off = off_base + ex_np, kx = kept_base + ex_k;
+                    g.row_pred_off[r] = off; g.row_code[r] = (uint8_t)cd; g.row_sink[r] = (uint8_t)sink; g.row_al[r] = (uint16_t)alp;
+                    g.score[r] = (int32_t)kx;                          // kept rows before r
+                    uint32_t q0 = 0, q1 = 0, e = e0;
+                    for (uint32_t k = 0; k < np; k++) {
+                        const uint32_t f = k == 0 ? f0 : k == 1 ? f1 : g.e_from[e];
+                        const uint32_t pr = g.node2rank[f];
+                        g.pred_w[off + k] = g.e_w[e];
+                        g.pred_rank[off + k] = pr;
+                        if (k == 0) q0 = pr; else if (k == 1) q1 = pr;
+                        e = g.e_next_in[e];
+                    }
+                    g.row_meta[r] = cd | (sink << 2) | (kept << 4) | (np > 4u ? 32u : 0u) | ((kept && R ? (kx & (R - 1)) : 15u) << META_SLOT) | (np << META_NP);   // slot 15: no non-adjacent reader (or no ring at all) - the row is not written to the ring
+                    if (DIR && np > max_indeg) sOk = 4;                // the direction bytes hold a 4-bit predecessor slot (max_indeg <= 16)
+                    g.row_pred0[r] = q0; g.row_pred1[r] = q1;
+                    st_multi += np >= 2; st_wide += np > 4; st_fifth += np > 4 ? np - 4 : 0;
                 }
-#if !defined(HX_DP_PROF) && !defined(HX_GU_PROF)
-                if (phase) {   // statistics of the rows the next DP will run over
-                    if (st_multi) atomicAdd(&ph[7], (unsigned long long)st_multi);
-                    if (st_ring | st_fifth) atomicAdd(&ph[8], (unsigned long long)st_ring | ((unsigned long long)st_fifth << 40));   // (high bits: fifth-and-later predecessor entries, fetched inside the row)
-                    if (st_far | st_wide) atomicAdd(&ph[9], (unsigned long long)st_far | ((unsigned long long)st_wide << 40));      // (high bits: rows with more than 4 predecessors)
-                    if (tid == 0) { atomicAdd(&ph[6], (unsigned long long)V2); atomicAdd(&ph[10], (unsigned long long)ktot); atomicAdd(&ph[11], 1ull); }
-                }
-#endif
+                off_base += tot_np; kept_base += tot_k;
             }
+            if (tid == 0) g.row_pred_off[V2] = off_base;
+            const uint32_t ktot = kept_base;
+            __syncthreads();
+            // ---- pass C: where the DP will find each predecessor row: 1..R ring slot + 1, 13 the previous row (registers), 14 the virtual row 0, 15 HBM
+            // (a kept row that has left the ring by then: it is marked as read back from HBM)
+            for (uint32_t r = tid; r < V2; r += NT) {
+                const uint32_t po = g.row_pred_off[r], np = g.row_meta[r] >> META_NP, kr = (uint32_t)g.score[r];
+                for (uint32_t q = 0; q < np; q++) {
+                    const uint32_t pr = g.pred_rank[po + q];
+                    uint32_t loc;
+                    if (r - pr == 1) loc = 13;
+                    else {
+                        const uint32_t kp = (uint32_t)g.score[pr], live = kr - kp;   // kept rows produced in [pr, r), pr included
+                        if (live <= R) loc = 1 + (kp & (R - 1));
+                        else { loc = 15; atomicOr(&g.row_meta[pr], 8u); }
+                    }
+                    const uint32_t ent = pr | (loc << 28);
+                    st_ring += r - pr >= 2 && loc != 15; st_far += loc == 15;
+                    g.pred_rank[po + q] = ent;
+                    if (q == 0) g.row_pred0[r] = ent; else if (q == 1) g.row_pred1[r] = ent;
+                }
+                if (np == 0) g.row_pred0[r] = 14u << 28;               // a source node: the virtual row 0
+            }
+            if (DIR) {   // ---- pass D: rows that a far successor reads back from HBM get consecutive rows of H (the score matrix is not kept with direction bytes);
+                         // rows with more than 4 predecessors a row of the wide-row pool (a direction byte per cell)
+                __syncthreads();
+                uint32_t* farslot = reinterpret_cast<uint32_t*>(g.pred);
+                uint32_t far_base = 0, wide_base = 0;
+                for (uint32_t base = 0; base < V2; base += NT) {
+                    const uint32_t r = base + tid;
+                    const uint32_t mt = r < V2 ? g.row_meta[r] : 0u;
+                    uint32_t tf, tw;
+                    const uint32_t exf = block_excl_scan_add((mt >> 3) & 1u, lds_u, &tf);
+                    const uint32_t exw = block_excl_scan_add((mt >> 5) & 1u, lds_u, &tw);
+                    if (mt & 8u) farslot[r] = far_base + exf;
+                    if (mt & 32u) g.wslot[r] = wide_base + exw;
+                    far_base += tf; wide_base += tw;
+                }
+                if (tid == 0 && far_base > ED.hrows && sOk == 1) sOk = 5;    // more far rows than the estimate: the host retries with a row per node
+                if (tid == 0 && wide_base > ED.wrows && sOk == 1) sOk = 7;   // more wide rows than the estimate: the host retries with more
+            }
+#if !defined(HX_DP_PROF) && !defined(HX_GU_PROF)
+            if (phase) {   // statistics of the rows the next DP will run over
+                if (st_multi) atomicAdd(&ph[7], (unsigned long long)st_multi);
+                if (st_ring | st_fifth) atomicAdd(&ph[8], (unsigned long long)st_ring | ((unsigned long long)st_fifth << 40));   // (high bits: fifth-and-later predecessor entries, fetched inside the row)
+                if (st_far | st_wide) atomicAdd(&ph[9], (unsigned long long)st_far | ((unsigned long long)st_wide << 40));      // (high bits: rows with more than 4 predecessors)
+                if (tid == 0) { atomicAdd(&ph[6], (unsigned long long)V2); atomicAdd(&ph[10], (unsigned long long)ktot); atomicAdd(&ph[11], 1ull); }
+            }
+#endif
         }
         __syncthreads();
         PHASE(5);
@@ -2050,6 +2065,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
 #endif
         }
         PHASE(3);
+        ph[17] = wall_clock64() & ((1ull << 44) - 1);
 #ifdef HX_DP_PROF3
         if (phase) for (int k = 0; k < 6; k++) phase[(uint64_t)eidx * POA_PHASE_WORDS + k] = ph[k];
 #else
@@ -2060,19 +2076,22 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
 
 // The launch. An edge that is shared by several workgroups gets one workgroup per member and a workspace slot of its own (`order` entry =
 // edge | member << 24, the slot is the edge's PoaEdge::slot). Everything else runs PERSISTENT: the grid is a number of workspace slots, each
-// workgroup owns slot blockIdx.x - sized for the largest edge of the launch - and works through the launch's list (costliest first): entry
-// blockIdx.x first, then whatever comes next off an atomic counter. The workspace of a call is (workgroups in flight) x (largest edge of
-// the class), not the sum over all its edges.
+// workgroup owns slot blockIdx.x - sized for the largest edge of its BUCKET of the launch (buckets of workspace need: round 5) - and works
+// through the bucket's list (costliest first) off an atomic counter, then through the smaller buckets'. The workspace of a call is
+// (workgroups in flight) x (largest edge of their bucket), not the sum over all its edges.
 // (two instances per shape: the plain one keeps the register allocation of a kernel that runs one edge - the loop of the persistent one costs
 // 8-12 VGPRs, which takes the 4-column kernels from 4 to 3 waves per SIMD - and is what the few-edge regime launches)
 template <int MAXNT, int CM, bool DIR, bool PERSIST, bool PRUNE>
 __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const PoaEdge* __restrict__ edges, const uint32_t* __restrict__ order, uint32_t n_items,
                                             const PoaSlot* __restrict__ slots, uint32_t* __restrict__ counter /* null: one workgroup per entry of `order` */,
-                                            const PoaSeq* __restrict__ seqs, const uint8_t* __restrict__ packed, const uint64_t* __restrict__ read_off,
+                                            const uint32_t* __restrict__ btab /* persistent: buckets, slot ends, item begins (PoaLaunch) */, const PoaSeq* __restrict__ seqs, const uint8_t* __restrict__ packed, const uint64_t* __restrict__ read_off,
                                             const uint32_t* __restrict__ read_len, PoaPools P, int32_t match, int32_t mismatch, int32_t gap,
                                             char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells, unsigned long long* phase,
                                             uint32_t poll_limit, uint32_t lds_bytes, uint32_t max_indeg, uint32_t dp_lanes, uint32_t prune_pct) {
     __shared__ uint32_t sNext;
+    // persistent launch: the bucket whose slot this workgroup owns (slots are laid out bucket by bucket, largest workspace need first)
+    uint32_t kb = 0, nbk = 0;
+    if (PERSIST) { nbk = btab[0]; while (kb + 1 < nbk && blockIdx.x >= btab[1 + kb]) kb++; }
     for (uint32_t round = 0;; round++) {   // (one call site of the edge body for both kinds of launch)
         uint32_t eidx, mem = 0;
         PoaSlot SL;
@@ -2081,16 +2100,33 @@ __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const P
             if (eidx == 0x00ffffffu) return;              // hole in the XCD-aligned cluster grid
             SL = slots[edges[eidx].slot];
         } else {
-            // the list is in DP-cost order, costliest first: the first edge of workgroup b is entry b, the others come through the counter - whoever
-            // is free takes the next one; every slot is sized for the largest edge of the list
-            uint32_t idx = blockIdx.x;
-            if (round) {
-                __syncthreads();                          // (the previous edge has left the LDS)
-                if (threadIdx.x == 0) sNext = gridDim.x + atomicAdd(counter, 1u);
-                __syncthreads();
-                idx = sNext;
+            // The launch's edges come in BUCKETS of workspace need (a power of two each), every bucket's list ordered by estimated chain time, longest
+            // first, behind a counter of its own. A workgroup's slot is sized for the largest edge of ITS bucket, so it can take the edges of that
+            // bucket and of every bucket of smaller need - whoever is free takes ...
+            if (round) __syncthreads();                   // (the previous edge has left the LDS)
+            if (threadIdx.x == 0) {
+                // ... of the buckets it can serve, the one whose next edge has the longest estimated chain (est[]: beside the lists): the call ends when its
+                // longest chains end, and a long chain of little need must not wait behind its bucket's thousands
+                const uint32_t* ib = btab + 1 + nbk;
+                const uint32_t* est = ib + nbk + 1;
+                uint32_t idx = 0xffffffffu;
+                for (uint32_t tries = 0; tries < 64 && idx == 0xffffffffu; tries++) {
+                    uint32_t best = 0xffffffffu, bv = 0;
+                    for (uint32_t k = kb; k < nbk; k++) {
+                        const uint32_t b0 = ib[k], b1 = ib[k + 1], cur = __hip_atomic_load(counter + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (cur >= b1 - b0) continue;
+                        const uint32_t v = est[b0 + cur];
+                        if (best == 0xffffffffu || v > bv) { best = k; bv = v; }
+                    }
+                    if (best == 0xffffffffu) break;       // every bucket this workgroup can serve is empty
+                    const uint32_t t = ib[best] + atomicAdd(counter + best, 1u);
+                    if (t < ib[best + 1]) idx = t;        // (else: others emptied the bucket meanwhile - look again)
+                }
+                sNext = idx;
             }
-            if (idx >= n_items) return;
+            __syncthreads();
+            const uint32_t idx = sNext;
+            if (idx == 0xffffffffu) return;
             eidx = order[idx] & 0x00ffffffu;
             SL = slots[blockIdx.x];
         }
@@ -2101,33 +2137,67 @@ __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const P
 
 }  // namespace
 
+// The instances are compiled in four translation units, one per largest workgroup (kernels/poa_part{64,256,512,1024}.hip: `#define HX_POA_PART n` and
+// this file) - a build of all 61 instances in one unit takes three and a half minutes, the four side by side one; a unit without HX_POA_PART holds them all.
+#if !defined(HX_POA_PART) || HX_POA_PART == 64
+#define HX_POA_HAS_64 1
+#endif
+#if !defined(HX_POA_PART) || HX_POA_PART == 256
+#define HX_POA_HAS_256 1
+#endif
+#if !defined(HX_POA_PART) || HX_POA_PART == 512
+#define HX_POA_HAS_512 1
+#endif
+#if !defined(HX_POA_PART) || HX_POA_PART == 1024
+#define HX_POA_HAS_1024 1
+#endif
+#define HX_LAUNCH(MNT, CMV, DIRV, PERS, PRN) do { \
+        (void)hipFuncSetAttribute((const void*)k_poa<MNT, CMV, DIRV, PERS, PRN>, hipFuncAttributeMaxDynamicSharedMemorySize, 142 * 1024); \
+        if (q.occupancy) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(q.occupancy, (const void*)k_poa<MNT, CMV, DIRV, PERS, PRN>, q.block_threads, q.ring_bytes); break; } \
+        k_poa<MNT, CMV, DIRV, PERS, PRN><<<q.n_blocks, q.block_threads, q.ring_bytes, s>>>(q.edges, q.order, q.n_items, q.slots, q.counter, q.btab, q.seqs, q.packed, q.read_off, q.read_len, q.pools, q.match, q.mismatch, q.gap, \
+                                                                       q.cns, q.cns_len, q.status, q.cells, q.phase, q.poll_limit, q.ring_bytes, q.max_indeg, q.dp_lanes, q.prune_pct); } while (0)
+// (persistent instances exist for the direction-byte flavour only: poa_persistent_ok; pruned ones for it with 4 or 8 columns per lane: poa_prune_ok)
+#define HX_LAUNCH_CM(MNT, CMV) do { if (q.use_dir && q.counter) HX_LAUNCH(MNT, CMV, true, true, false); else if (q.use_dir) HX_LAUNCH(MNT, CMV, true, false, false); else HX_LAUNCH(MNT, CMV, false, false, false); } while (0)
+#define HX_LAUNCH_PR(MNT, CMV) do { if (q.counter) HX_LAUNCH(MNT, CMV, true, true, true); else HX_LAUNCH(MNT, CMV, true, false, true); } while (0)
+// the instances the host's launch classes use (poa_kernel_lanes): workgroups up to 64 / 256 / 512 / 1024 lanes x 4, 8, 16 or 32 columns per lane
+#define HX_POA_RUN_PART(MNT, LAST_CM) \
+    void poa_run_##MNT(const PoaLaunch& q, hipStream_t s, bool prune) { \
+        const int cm = q.cm; \
+        if (prune) { if (cm <= 4) HX_LAUNCH_PR(MNT, 4); else HX_LAUNCH_PR(MNT, 8); return; } \
+        if (cm <= 4) HX_LAUNCH_CM(MNT, 4); else if (cm <= 8) HX_LAUNCH_CM(MNT, 8); else if (cm <= 16 || LAST_CM == 16) HX_LAUNCH_CM(MNT, 16); else HX_LAUNCH_CM(MNT, LAST_CM); \
+    }
+#ifdef HX_POA_HAS_64
+HX_POA_RUN_PART(64, 32)
+#endif
+#ifdef HX_POA_HAS_256
+HX_POA_RUN_PART(256, 32)
+#endif
+#ifdef HX_POA_HAS_512
+HX_POA_RUN_PART(512, 16)
+#endif
+#ifdef HX_POA_HAS_1024
+HX_POA_RUN_PART(1024, 32)   // (1024 x 32: one workgroup for a gap of 8192..32767 bases: register spills, rare)
+#endif
+#undef HX_POA_RUN_PART
+#undef HX_LAUNCH_CM
+#undef HX_LAUNCH_PR
+#undef HX_LAUNCH
+
+#if !defined(HX_POA_PART) || HX_POA_PART == 64   // the dispatcher lives with the first part
+void poa_run_64(const PoaLaunch&, hipStream_t, bool);
+void poa_run_256(const PoaLaunch&, hipStream_t, bool);
+void poa_run_512(const PoaLaunch&, hipStream_t, bool);
+void poa_run_1024(const PoaLaunch&, hipStream_t, bool);
 void poa_run(const PoaLaunch& q, hipStream_t s) {
     if (!q.n_blocks || !q.n_items) return;
     if (q.counter && !q.use_dir) return;   // (the host never asks for it: poa_persistent_ok)
     const bool prune = poa_prune_ok(q.use_dir, q.cm) && q.prune_pct != 0u;
-#define HX_LAUNCH(MNT, CMV, DIRV, PERS, PRN) do { \
-        (void)hipFuncSetAttribute((const void*)k_poa<MNT, CMV, DIRV, PERS, PRN>, hipFuncAttributeMaxDynamicSharedMemorySize, 142 * 1024); \
-        k_poa<MNT, CMV, DIRV, PERS, PRN><<<q.n_blocks, q.block_threads, q.ring_bytes, s>>>(q.edges, q.order, q.n_items, q.slots, q.counter, q.seqs, q.packed, q.read_off, q.read_len, q.pools, q.match, q.mismatch, q.gap, \
-                                                                       q.cns, q.cns_len, q.status, q.cells, q.phase, q.poll_limit, q.ring_bytes, q.max_indeg, q.dp_lanes, q.prune_pct); } while (0)
-    // (persistent instances exist for the direction-byte flavour only: poa_persistent_ok; pruned ones for it with 4 or 8 columns per lane: poa_prune_ok)
-#define HX_LAUNCH_CM(MNT, CMV) do { if (q.use_dir && q.counter) HX_LAUNCH(MNT, CMV, true, true, false); else if (q.use_dir) HX_LAUNCH(MNT, CMV, true, false, false); else HX_LAUNCH(MNT, CMV, false, false, false); } while (0)
-#define HX_LAUNCH_PR(MNT, CMV) do { if (q.counter) HX_LAUNCH(MNT, CMV, true, true, true); else HX_LAUNCH(MNT, CMV, true, false, true); } while (0)
-    // the instances the host's launch classes use (poa_kernel_lanes): workgroups up to 64 / 256 / 512 / 1024 lanes x 4, 8, 16 or 32 columns per lane
-    const int mnt = poa_kernel_lanes(q.block_threads), cm = q.cm;
-    if (prune) {
-        if (mnt == 64) { if (cm <= 4) HX_LAUNCH_PR(64, 4); else HX_LAUNCH_PR(64, 8); }
-        else if (mnt == 256) { if (cm <= 4) HX_LAUNCH_PR(256, 4); else HX_LAUNCH_PR(256, 8); }
-        else if (mnt == 512) { if (cm <= 4) HX_LAUNCH_PR(512, 4); else HX_LAUNCH_PR(512, 8); }
-        else { if (cm <= 4) HX_LAUNCH_PR(1024, 4); else HX_LAUNCH_PR(1024, 8); }
-        return;
-    }
-    if (mnt == 64) { if (cm <= 4) HX_LAUNCH_CM(64, 4); else if (cm <= 8) HX_LAUNCH_CM(64, 8); else if (cm <= 16) HX_LAUNCH_CM(64, 16); else HX_LAUNCH_CM(64, 32); }
-    else if (mnt == 256) { if (cm <= 4) HX_LAUNCH_CM(256, 4); else if (cm <= 8) HX_LAUNCH_CM(256, 8); else if (cm <= 16) HX_LAUNCH_CM(256, 16); else HX_LAUNCH_CM(256, 32); }
-    else if (mnt == 512) { if (cm <= 4) HX_LAUNCH_CM(512, 4); else if (cm <= 8) HX_LAUNCH_CM(512, 8); else HX_LAUNCH_CM(512, 16); }
-    else { if (cm <= 4) HX_LAUNCH_CM(1024, 4); else if (cm <= 8) HX_LAUNCH_CM(1024, 8); else if (cm <= 16) HX_LAUNCH_CM(1024, 16); else HX_LAUNCH_CM(1024, 32); }   // (1024 x 32: one workgroup for a gap of 8192..32767 bases: register spills, rare)
-#undef HX_LAUNCH_CM
-#undef HX_LAUNCH_PR
-#undef HX_LAUNCH
+    const int mnt = poa_kernel_lanes(q.block_threads);
+    if (mnt == 64) poa_run_64(q, s, prune);
+    else if (mnt == 256) poa_run_256(q, s, prune);
+    else if (mnt == 512) poa_run_512(q, s, prune);
+    else poa_run_1024(q, s, prune);
 }
+#endif
 
 }  // namespace hxk

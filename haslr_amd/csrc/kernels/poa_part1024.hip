@@ -1,0 +1,3 @@
+// K6 instances with workgroups of up to 1024 lanes (kernels/poa.hip is compiled in four parts: see poa_run there)
+#define HX_POA_PART 1024
+#include "poa.hip"

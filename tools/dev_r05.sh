@@ -11,6 +11,7 @@ for step in "$@"; do
     fuzzbig) FUZZ_BIG=1 timeout 1500 python tools/dev_fuzz.py ${FUZZ_NB:-12} ${FUZZ_SEEDB:-5002} > $O/fuzzbig.txt 2>&1; tail -n 1 $O/fuzzbig.txt; grep -c " OK " $O/fuzzbig.txt; grep -v " OK " $O/fuzzbig.txt | head -20 ;;
     ab140) timeout 1500 python tools/dev_r05_ab.py ${AB_SPECS:-"poa_prune=0" "-" "poa_prune=90" "poa_prune=100"} 2> $O/ab140.err | tee $O/ab140.txt; grep -c "removed" $O/ab140.err ;;
     ab140dbg) HX_DEBUG=1 AB_PASSES=2 timeout 1500 python tools/dev_r05_ab.py ${AB_SPECS:-"-"} 2>&1 | grep "RESULT\|pruning\|class .: .* workgroups\|POA batch:\|top edge" | cut -c1-420 | tee $O/ab140dbg.txt ;;
+    edgedump) HX_DEBUG=2 AB_PASSES=2 timeout 1500 python tools/dev_r05_ab.py ${AB_SPECS:-"-"} 2> $O/edgedump.err | tee $O/edgedump.txt; grep -c "hx-edge" $O/edgedump.err ;;
     ab12) AB_WORKLOAD=yeast timeout 900 python tools/dev_r05_ab.py ${AB12_SPECS:-"-" "poa_prune=95"} 2> $O/ab12.err | tee $O/ab12.txt ;;
     benchq) timeout 1500 python bench.py --no-cpu-baseline --steps ${BENCH_STEPS:-6} --warmup 2 > $O/benchq.json 2> $O/benchq.err; python -c "
 import json;d=json.load(open('$O/benchq.json'));print('ms/step',d['ms_per_step'],'gcups',d['roofline']['gcups'],'slowest',d['poa_phase_cycles']['slowest_edge'],'config',d['config'])" ;;
