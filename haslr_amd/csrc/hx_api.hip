@@ -96,7 +96,7 @@ struct PoaPoolBufs {
     DV<uint32_t> aligned, in_head, in_tail, out_head, out_tail, rank2node, node2rank, stack, row_pred_off, pred_rank, e_from, e_to, e_next_in, e_next_out;
     DV<int32_t> score, pred, e_w, aln_node, aln_pos, H, pred_w;
     DV<uint32_t> row_meta, row_pred0, row_pred1;
-    DV<uint4> nrec;
+    DV<uint4> nrec, nrec2;
     DV<uint8_t> dir, dirw; DV<uint32_t> wslot;
     DV<unsigned long long> mbox; DV<int32_t> sinkbuf; DV<uint32_t> csync; DV<uint16_t> row_al;   // cluster mode (edges shared by several workgroups)
     void release_all() {
@@ -104,7 +104,7 @@ struct PoaPoolBufs {
         aligned.release(); in_head.release(); in_tail.release(); out_head.release(); out_tail.release(); rank2node.release(); node2rank.release();
         stack.release(); row_pred_off.release(); pred_rank.release(); e_from.release(); e_to.release(); e_next_in.release(); e_next_out.release();
         score.release(); pred.release(); e_w.release(); aln_node.release(); aln_pos.release(); H.release(); row_meta.release(); row_pred0.release();
-        row_pred1.release(); nrec.release(); pred_w.release(); dir.release(); dirw.release(); wslot.release(); mbox.release(); sinkbuf.release(); csync.release(); row_al.release();
+        row_pred1.release(); nrec.release(); nrec2.release(); pred_w.release(); dir.release(); dirw.release(); wslot.release(); mbox.release(); sinkbuf.release(); csync.release(); row_al.release();
     }
 };
 }  // namespace
@@ -613,7 +613,7 @@ inline void need_max(Need& a, const Need& b) {
     a.nn = std::max(a.nn, b.nn); a.ec = std::max(a.ec, b.ec); a.hc = std::max(a.hc, b.hc); a.dc = std::max(a.dc, b.dc); a.wc = std::max(a.wc, b.wc);
     a.lm = std::max(a.lm, b.lm); a.st = std::max(a.st, b.st); a.al = std::max(a.al, b.al); a.mb = std::max(a.mb, b.mb);
 }
-inline uint64_t need_bytes(const Need& n) { return n.nn * 90 + n.ec * 28 + n.hc * 4 + n.dc + n.wc + n.lm + n.st * 4 + n.al * 8 + n.mb * 8; }
+inline uint64_t need_bytes(const Need& n) { return n.nn * 106 + n.ec * 28 + n.hc * 4 + n.dc + n.wc + n.lm + n.st * 4 + n.al * 8 + n.mb * 8; }
 
 // launch classes: (shared?, lanes per workgroup, columns per lane, traceback flavour) - one kernel instance each, so that every
 // launch runs with the registers ITS row loop needs (kernels/poa.hip)
@@ -1107,7 +1107,7 @@ struct PoaCall {
             }
         }
         lb.cns_bytes = co;
-        const uint64_t bytes = no * 90 + eo * 28 + ho * 4 + dro + wo + so + sto * 4 + ao * 8 + clo * 8 + co;
+        const uint64_t bytes = no * 106 + eo * 28 + ho * 4 + dro + wo + so + sto * 4 + ao * 8 + clo * 8 + co;
         lb.bytes = bytes;
         // Pools grow and never shrink, each to the largest batch it has seen: after batches of different shapes (direction bytes for one,
         // the whole score matrix for a retry) the capacities together can exceed the device although this batch alone fits the budget.
@@ -1120,7 +1120,7 @@ struct PoaCall {
             HX_RSV(B.aligned, 3 * no); HX_RSV(B.in_head, no); HX_RSV(B.in_tail, no); HX_RSV(B.out_head, no); HX_RSV(B.out_tail, no); HX_RSV(B.rank2node, no);
             HX_RSV(B.node2rank, no); HX_RSV(B.row_pred_off, no); HX_RSV(B.score, no); HX_RSV(B.pred, no); HX_RSV(B.pred_rank, eo); HX_RSV(B.pred_w, eo); HX_RSV(B.e_from, eo);
             HX_RSV(B.e_to, eo); HX_RSV(B.e_next_in, eo); HX_RSV(B.e_next_out, eo); HX_RSV(B.e_w, eo); HX_RSV(B.stack, sto); HX_RSV(B.aln_node, ao); HX_RSV(B.aln_pos, ao);
-            HX_RSV(B.row_meta, no); HX_RSV(B.row_pred0, no); HX_RSV(B.row_pred1, no); HX_RSV(B.nrec, no); HX_RSV(B.seq, so); HX_RSV(c->poa_cns, co);
+            HX_RSV(B.row_meta, no); HX_RSV(B.row_pred0, no); HX_RSV(B.row_pred1, no); HX_RSV(B.nrec, no); HX_RSV(B.nrec2, no); HX_RSV(B.seq, so); HX_RSV(c->poa_cns, co);
             HX_RSV(B.mbox, std::max<uint64_t>(1, clo));
             HX_RSV(B.csync, (size_t)ne * 8); HX_RSV(B.sinkbuf, (size_t)ne * (1 + 2 * 1024));
 #undef HX_RSV
@@ -1166,7 +1166,7 @@ struct PoaCall {
         HIPCHK(c->poa_counters.reserve(classes.size()));
         HIPCHK(hipMemsetAsync(c->poa_counters.p, 0, classes.size() * 4, s));
         hxk::PoaPools pools{B.code.p, B.n_aligned.p, B.aligned.p, B.in_head.p, B.in_tail.p, B.out_head.p, B.out_tail.p, B.rank2node.p, B.node2rank.p,
-                            B.mark.p, B.check.p, B.stack.p, B.score.p, B.pred.p, B.row_code.p, B.row_sink.p, B.row_pred_off.p, B.pred_rank.p, B.row_meta.p, B.row_pred0.p, B.row_pred1.p, B.nrec.p,
+                            B.mark.p, B.check.p, B.stack.p, B.score.p, B.pred.p, B.row_code.p, B.row_sink.p, B.row_pred_off.p, B.pred_rank.p, B.row_meta.p, B.row_pred0.p, B.row_pred1.p, B.nrec.p, B.nrec2.p,
                             B.e_from.p, B.e_to.p, B.e_next_in.p, B.e_next_out.p, B.e_w.p, B.aln_node.p, B.aln_pos.p, B.H.p, B.dir.p, B.dirw.p, B.wslot.p, B.seq.p,
                             B.mbox.p, B.csync.p, B.sinkbuf.p, B.row_al.p, B.pred_w.p};
         const size_t n_streams = (size_t)std::min(8, std::max(1, o.poa_streams));   // (8: a stream per launch class of a 140 Mb call - with 6, the two one-wave classes waited 130 / 300 ms behind the shared edges)

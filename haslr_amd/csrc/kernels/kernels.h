@@ -118,6 +118,7 @@ struct PoaPools {
     uint8_t* row_code; uint8_t* row_sink; uint32_t* row_pred_off; uint32_t* pred_rank;   // row_pred_off: vcap+1 per edge; pred_rank: ecap
     uint32_t *row_meta, *row_pred0, *row_pred1;   // code | sink<<2 | far<<3 | npred<<8 ; first two predecessor ranks
     uint4* nrec;   // per node 16-byte record for the serial graph walks (first in-edge source, counts, packed aligned ids)
+    uint4* nrec2;  // ... second record: first two in-edge ids, first two out-edge targets (kernels/poa.hip G)
     // per graph edge (pool length = sum ecap)
     uint32_t *e_from, *e_to, *e_next_in, *e_next_out; int32_t* e_w;
     // alignment output of the traceback (node|-1, pos|-1), own pool, PoaEdge::aln_off

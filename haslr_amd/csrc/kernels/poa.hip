@@ -46,6 +46,7 @@ struct G {   // per-edge views into the pools
     uint32_t* wslot;                              // per rank: row of the wide-row pool (rows with more than 4 predecessors: a direction byte per cell)
     int32_t* pred_w;                              // per entry of pred_rank: weight of that in-edge
     uint4* nrec;   // per node, one 16-byte record for the serial graph walks: {1st in-edge source, 2nd in-edge source, 3 aligned ids (+1) x 21 bit, bit 63: more in-edges}
+    uint4* nrec2;  // ... and a second one (round 5, the CSR rebuild): {2nd out-edge, 2nd in-edge (edge ids: where a walk of the third and later list entries starts), 1st out-edge target | bit 31: more than two out-edges, 2nd out-edge target}; NONE = no entry
     uint32_t *e_from, *e_to, *e_next_in, *e_next_out; int32_t* e_w;
     int32_t *aln_node, *aln_pos;
     uint32_t vcap, ecap;
@@ -56,7 +57,21 @@ __device__ __forceinline__ uint32_t add_node(G& g, uint32_t& V, uint8_t c) {
     g.code[n] = c; g.n_aligned[n] = 0;
     g.in_head[n] = g.in_tail[n] = g.out_head[n] = g.out_tail[n] = NONE;
     g.nrec[n] = make_uint4(NONE, NONE, 0u, 0u);
+    g.nrec2[n] = make_uint4(NONE, NONE, NONE, NONE);
     return n;
+}
+
+// a new edge e = (f -> t) joins f's out-list and t's in-list, and the two nodes' records (the lists' first two entries)
+__device__ __forceinline__ void link_edge(G& g, const uint32_t e, const uint32_t f, const uint32_t t) {
+    uint32_t* rf = reinterpret_cast<uint32_t*>(&g.nrec2[f]);
+    if (g.out_tail[f] == NONE) { g.out_head[f] = e; rf[2] = t; }
+    else { g.e_next_out[g.out_tail[f]] = e; if (rf[3] == NONE) { rf[3] = t; rf[0] = e; } else rf[2] |= 0x80000000u; }   // third and later out-edges: walk the list (from the second edge on)
+    g.out_tail[f] = e;
+    uint32_t* r = reinterpret_cast<uint32_t*>(&g.nrec[t]);
+    uint32_t* r2 = reinterpret_cast<uint32_t*>(&g.nrec2[t]);
+    if (g.in_tail[t] == NONE) { g.in_head[t] = e; r[0] = f; }
+    else { g.e_next_in[g.in_tail[t]] = e; if (r[1] == NONE) { r[1] = f; r2[1] = e; } else r[3] |= 0x80000000u; }   // third and later in-edges: walk the list
+    g.in_tail[t] = e;
 }
 
 // spoa Graph::add_edge: an existing (from,to) edge gains the weight, else a new edge is appended to both lists
@@ -65,12 +80,7 @@ __device__ void add_edge(G& g, uint32_t& E, uint32_t f, uint32_t t, int32_t w) {
         if (g.e_to[e] == t) { g.e_w[e] += w; return; }
     uint32_t e = E++;
     g.e_from[e] = f; g.e_to[e] = t; g.e_w[e] = w; g.e_next_in[e] = NONE; g.e_next_out[e] = NONE;
-    if (g.out_tail[f] == NONE) g.out_head[f] = e; else g.e_next_out[g.out_tail[f]] = e;
-    g.out_tail[f] = e;
-    uint32_t* r = reinterpret_cast<uint32_t*>(&g.nrec[t]);
-    if (g.in_tail[t] == NONE) { g.in_head[t] = e; r[0] = f; }
-    else { g.e_next_in[g.in_tail[t]] = e; if (r[1] == NONE) r[1] = f; else r[3] |= 0x80000000u; }   // third and later in-edges: walk the list
-    g.in_tail[t] = e;
+    link_edge(g, e, f, t);
 }
 
 // append node `a` to node n's aligned list (array form + the packed copy in the node record)
@@ -128,85 +138,12 @@ __device__ void toposort(G& g, uint32_t V, uint32_t* out) {
 }
 
 
-// Same traversal, executed by one whole wavefront in lock step (every lane computes the same scalars) so that the 63 lanes which
-// would idle beside lane 0 can fetch node records cooperatively: records are read through a direct-mapped LDS cache of 16-record
-// lines (one coalesced 256-byte load per miss; node ids are visited in nearly ascending runs, so most visits hit). The mark/check
-// bits of every node sit in one LDS byte (st[]), the top of the DFS stack in an LDS window that spills to the HBM stack.
-// Requires node ids < 2^21 - 1 (aligned ids are packed 3 x 21 bit).
 constexpr uint32_t SINK_CAP = 1024;      // sink rows whose end score is kept per alignment (more: error)
 constexpr uint32_t TOPO_LCAP = 1024;     // stack window entries
 constexpr uint32_t TOPO_LINES = 64;      // cache lines of 16 records (16 KiB)
-__device__ void toposort_coop(G& g, const uint32_t V, uint8_t* st, uint32_t* lstack, uint4* cache, uint32_t* tags, uint32_t* out) {
-    // One visit = three dependent LDS round trips instead of ten: (1) the stack top, (2) the node's state byte and its record (tag and
-    // record are read together), (3) the state bytes of ALL its candidates at once — lane 0/1 look at the two in-edge sources, lanes
-    // 2-4 at the aligned nodes — and a ballot tells which of them still have to be visited; those lanes push themselves.
-    const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t i = lane; i < TOPO_LINES; i += 64) tags[i] = NONE;
-    uint32_t sp = 0, nr = 0, base = 0;
-    auto push1 = [&](uint32_t v) {   // scalar push (all lanes agree on v)
-        if (sp - base == TOPO_LCAP) { if (lane == 0) g.stack[base] = lstack[base & (TOPO_LCAP - 1)]; base++; }
-        if (lane == 0) lstack[sp & (TOPO_LCAP - 1)] = v;
-        sp++;
-    };
-    for (uint32_t i = 0; i < V; i++) {
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)st[i]) & 3u) continue;
-        push1(i);
-        while (sp) {
-            if (sp == base) { base--; if (lane == 0) lstack[base & (TOPO_LCAP - 1)] = g.stack[base]; }
-            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)lstack[(sp - 1) & (TOPO_LCAP - 1)]);
-            const uint32_t line = n >> 4, slot = line & (TOPO_LINES - 1);
-            const uint32_t tg = (uint32_t)__builtin_amdgcn_readfirstlane((int)tags[slot]);
-            const uint32_t sn = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[n]);
-            if ((sn & 3u) == 2u) { sp--; continue; }     // pushed more than once, finished meanwhile
-            if (tg != line) {
-                if (lane < 16) { const uint32_t id = (line << 4) + lane; cache[slot * 16 + lane] = id < g.vcap ? g.nrec[id] : make_uint4(NONE, NONE, 0u, 0u); }
-                if (lane == 0) tags[slot] = line;
-            }
-            const uint4 rv = cache[slot * 16 + (n & 15u)];
-            const uint32_t rx = (uint32_t)__builtin_amdgcn_readfirstlane((int)rv.x), ry = (uint32_t)__builtin_amdgcn_readfirstlane((int)rv.y);
-            const uint32_t rz = (uint32_t)__builtin_amdgcn_readfirstlane((int)rv.z), rw = (uint32_t)__builtin_amdgcn_readfirstlane((int)rv.w);
-            const bool chk = sn & 4u;
-            const unsigned long long al = ((unsigned long long)rz | ((unsigned long long)rw << 32)) & 0x7fffffffffffffffULL;
-            const uint32_t spb = sp;
-            if (rw & 0x80000000u) {   // three or more in-edges: walk the list (rare)
-                for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) {
-                    const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.e_from[e]);
-                    if (((uint32_t)__builtin_amdgcn_readfirstlane((int)st[f]) & 3u) != 2u) push1(f);
-                }
-            }
-            // candidates of the lanes: 0/1 in-edge sources (unless the list was walked), 2..4 aligned nodes (only if the node still checks its column)
-            uint32_t cand = NONE;
-            if (lane == 0 && !(rw & 0x80000000u)) cand = rx;
-            else if (lane == 1 && !(rw & 0x80000000u)) cand = ry;
-            else if (lane >= 2 && lane < 5 && chk) { const uint32_t a1 = (uint32_t)(al >> (21 * (lane - 2))) & 0x1fffffu; cand = a1 ? a1 - 1 : NONE; }
-            const bool todo = cand != NONE && (st[cand] & 3u) != 2u;
-            const unsigned long long tm = __ballot(todo);
-            const uint32_t npush = (uint32_t)__popcll(tm);
-            if (npush) {
-                while (sp + npush - base > TOPO_LCAP) { if (lane == 0) g.stack[base] = lstack[base & (TOPO_LCAP - 1)]; base++; }   // make room in the LDS window
-                if (todo) {
-                    const uint32_t pos = sp + (uint32_t)__popcll(tm & ((1ull << lane) - 1));
-                    lstack[pos & (TOPO_LCAP - 1)] = cand;
-                    if (lane >= 2) st[cand] &= (uint8_t)~4u;   // an aligned node reached from its column does not check the column again
-                }
-                sp += npush;
-            }
-            if (sp == spb) {   // every predecessor and column member is final: so is this node
-                if (lane == 0) st[n] = (uint8_t)((sn & ~3u) | 2u);
-                if (chk) {
-                    uint32_t cnt = 1;
-                    if (lane == 0) out[nr] = n;
-                    if (lane >= 2 && lane < 5) { const uint32_t a1 = (uint32_t)(al >> (21 * (lane - 2))) & 0x1fffffu; if (a1) out[nr + lane - 1] = a1 - 1; }
-                    for (uint32_t k = 0; k < 3; k++) if ((uint32_t)(al >> (21 * k)) & 0x1fffffu) cnt++; else break;
-                    nr += cnt;
-                }
-                sp--;
-            } else if (lane == 0) st[n] = (uint8_t)((sn & ~3u) | 1u);
-        }
-    }
-}
-
-// The same traversal on RANKS of the order the DP maintains (any valid topological order with contiguous columns): predecessors have
+// spoa's traversal (toposort above) by one whole wavefront in lock step - every lane computes the same scalars, the idle ones fetch records cooperatively
+// through a direct-mapped LDS cache of 16-record lines; the mark / check bits of every node sit in one LDS byte, the top of the DFS stack in an LDS window
+// that spills to the HBM stack - on RANKS of the order the DP maintains (any valid topological order with contiguous columns): predecessors have
 // smaller, nearby ranks, so the 16-rank record lines (row_meta, first two predecessor ranks, aligned-rank deltas) hit the LDS cache
 // almost always — node ids are visited in a scattered order, ranks are not. Roots are still taken in node-id order (that is what
 // fixes the reference's result); out[] receives ranks, the caller maps them back to node ids.
@@ -445,14 +382,36 @@ __device__ __forceinline__ int block_excl_scan_max(int v, int* lds /* blockDim/6
     return max(base, wave_shift_up1(inc, NEG));
 }
 
+// a pointer every lane holds the same value of, as a scalar
+template <class T> __device__ __forceinline__ T* uptr(T* p) {
+    const unsigned long long v = (unsigned long long)(uintptr_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return reinterpret_cast<T*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+}
+// inclusive prefix sum over the 64 lanes of a wave: the DPP sequence of wave_scan_max with an addition (no LDS round trips)
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
+    uint32_t x = v;
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false);   // row_shr:3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xe, false);   // row_shr:4 bank_mask:0xe
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xc, false);   // row_shr:8 bank_mask:0xc
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 row_mask:0xa
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 row_mask:0xc
+    return x;
+}
+// Exclusive prefix sum over the workgroup. Its barriers wait for LDS only: the loops of the graph phases call it once per block of ranks / bases, between
+// their stores - with __syncthreads (which drains the wave's outstanding global stores first, ~2 us under load) the scans WERE those loops' time.
+// A one-wave workgroup meets no barrier at all. Nothing here orders global memory: callers that hand data to other lanes through it synchronise themselves.
 __device__ __forceinline__ uint32_t block_excl_scan_add(uint32_t v, uint32_t* lds /* blockDim/64 */, uint32_t* total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NT = blockDim.x;
-    uint32_t inc = wave_scan_add(v);
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint32_t inc = wave_incl_add(v);
+    if (nw == 1) { *total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63); return inc - v; }
     if (lane == 63) lds[w] = inc;
-    __syncthreads();
+    barrier_lds_only();
     uint32_t base = 0, tot = 0;
-    for (int i = 0; i < NT / 64; i++) { if (i < w) base += lds[i]; tot += lds[i]; }
-    __syncthreads();
+    for (uint32_t i = 0; i < nw; i++) { const uint32_t x = lds[i]; if (i < w) base += x; tot += x; }
+    barrier_lds_only();
     *total = tot;
     return base + inc - v;
 }
@@ -1196,6 +1155,245 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     if constexpr (PRUNE) { if (lane == 0 && pstat) { atomicAdd(&pstat[0], (unsigned long long)V); atomicAdd(&pstat[1], (unsigned long long)n_dead); } }
 }
 
+// =================================================== rank-order CSR for the next DP (all lanes)
+// Round 5: lane = rank. The first version dealt the ranks out in contiguous chunks per thread (a thread's prefix sums were then its own running
+// counts) and ran seven passes of dependent list walks over them: every load of a wave touched 64 different cache lines, and the rebuild took ~2 000
+// cycles PER ROW of a one-wave workgroup under load - a fifth of all wave cycles of a 13 000-edge call (tools/dev_r05.sh edgedump). Now the ranks
+// are taken NT at a time, lane t = rank base + t: the rank-indexed arrays are read and written coalesced, the node-indexed ones nearly so (node ids
+// rise with the ranks), offsets and ring slots come from a scan per block of ranks with a running base, and what used to need a pass of its own is
+// read where it already is: the first two in-edge sources and the aligned ids from the node's 16-byte record, "kept" (a successor that is not the
+// next row) from the node's own out-list instead of atomics from its successors. Four passes, one dependent chain of 3-4 loads each.
+// (A function of its own, not inlined: its U-fold register arrays would otherwise count against the allocation of the whole kernel - with them inlined the
+// 4-column instances went from 145 to 164 registers, the 8-column ones spilled 50-60 bytes more, and the DP rows and the traceback of the longest 12 Mb
+// edge got 5 % and 18 % slower without a changed line.)
+template <int MAXNT, bool DIR>
+__device__ __attribute__((noinline)) void csr_rebuild(const G& g_in, const uint32_t V2, const uint32_t R, const uint32_t max_indeg, const uint32_t hrows, const uint32_t wrows, uint32_t* lds_u,
+                                                      uint32_t* sOk, unsigned long long* ph, const bool stats, const uint32_t eidx, const bool first_seq, const bool last_seq) {
+    // (the views arrive through memory: as they are, every pointer would sit in two VECTOR registers - the compiler cannot know them uniform - and 21 of them
+    // are used here; read through readfirstlane they are scalars)
+    G g = g_in;
+    g.rank2node = uptr(g.rank2node); g.node2rank = uptr(g.node2rank); g.nrec = uptr(g.nrec); g.nrec2 = uptr(g.nrec2); g.in_head = uptr(g.in_head); g.code = uptr(g.code);
+    g.e_w = uptr(g.e_w); g.e_next_in = uptr(g.e_next_in); g.e_next_out = uptr(g.e_next_out); g.e_to = uptr(g.e_to); g.e_from = uptr(g.e_from); g.row_pred_off = uptr(g.row_pred_off);
+    g.row_al = uptr(g.row_al); g.score = uptr(g.score); g.pred_rank = uptr(g.pred_rank); g.pred_w = uptr(g.pred_w); g.row_meta = uptr(g.row_meta); g.row_pred0 = uptr(g.row_pred0);
+    g.row_pred1 = uptr(g.row_pred1); g.pred = uptr(g.pred); g.wslot = uptr(g.wslot);
+        // Every access below is a round trip to a memory that 3 800 other waves are using (~1 us under the load of such a call), and a pass is as long as its
+        // chain of DEPENDENT round trips times its iterations: so each lane takes U ranks per iteration (their loads are issued together), and a row's
+        // in-edges and out-edges are read off the node's two records (the first two of each: link_edge) instead of walked - the lists only for the rare
+        // node with more. Pass B: rank -> node -> records -> ranks of the neighbours / weights: three round trips for U x NT rows.
+        constexpr uint32_t U = 2;
+        const uint32_t tid = threadIdx.x, NT = blockDim.x;
+#ifdef HX_CSR_PROF   // development: cycles of the rebuild's stages on lane 0 (printed for every 500th edge at its end)
+        __shared__ unsigned long long cp[8];
+        if (tid == 0 && first_seq) for (int q = 0; q < 8; q++) cp[q] = 0;
+        long long ct = clock64();
+#define CSR_T(q, reg) do { asm volatile("" :: "v"(reg)); if (tid == 0) { const long long _n = clock64(); cp[q] += (unsigned long long)(_n - ct); ct = _n; } } while (0)
+#else
+#define CSR_T(q, reg) do { } while (0)
+#endif
+        for (uint32_t base = 0; base < V2; base += NT * U) {
+            uint32_t nn_[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) { const uint32_t r = base + u * NT + tid; nn_[u] = r < V2 ? g.rank2node[r] : NONE; }
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) { const uint32_t r = base + u * NT + tid; if (nn_[u] != NONE) g.node2rank[nn_[u]] = r; }
+        }
+        __syncthreads();
+        CSR_T(0, V2);
+        uint32_t off_base = 0, kept_base = 0;
+        uint32_t st_multi = 0, st_ring = 0, st_far = 0, st_wide = 0, st_fifth = 0;
+        for (uint32_t base = 0; base < V2; base += NT * U) {       // ---- pass B: everything a row knows about itself
+            uint32_t n[U], cd[U], np[U], kept[U], alp[U], pf0[U], pf1[U], e0[U], ei[U], eo[U]; int32_t w0[U], w1[U];
+            uint4 A[U], B[U];
+            bool on[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) { const uint32_t r = base + u * NT + tid; on[u] = r < V2; n[u] = g.rank2node[on[u] ? r : 0u]; }
+            CSR_T(1, n[U - 1]);
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) { A[u] = g.nrec[n[u]]; B[u] = g.nrec2[n[u]]; e0[u] = g.in_head[n[u]]; cd[u] = g.code[n[u]]; }
+            CSR_T(2, cd[U - 1]);   // {f0, f1, aligned ids + 1 (3 x 21 bits) | bit 63: more in-edges}, {2nd out-edge, 2nd in-edge, t0 | bit 31: more out-edges, t1}
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t r = base + u * NT + tid;
+                const uint32_t f0 = A[u].x, f1 = A[u].y;
+                np[u] = !on[u] || f0 == NONE ? 0u : f1 == NONE ? 1u : 2u;
+                pf0[u] = g.node2rank[np[u] >= 1 ? f0 : 0u]; pf1[u] = g.node2rank[np[u] >= 2 ? f1 : 0u];
+                w0[u] = g.e_w[np[u] >= 1 ? e0[u] : 0u]; w1[u] = g.e_w[np[u] >= 2 ? B[u].y : 0u];
+                const bool o0 = B[u].z != NONE, o1 = B[u].w != NONE;
+                const uint32_t rt0 = g.node2rank[o0 ? B[u].z & 0x7fffffffu : 0u], rt1 = g.node2rank[o1 ? B[u].w : 0u];
+                kept[u] = (uint32_t)(on[u] && ((o0 && rt0 - r >= 2u) || (o1 && rt1 - r >= 2u)));   // a successor that is not the next row reads this one from the ring / HBM
+                const unsigned long long al = ((unsigned long long)A[u].z | ((unsigned long long)A[u].w << 32)) & 0x7fffffffffffffffULL;
+                const uint32_t a0 = (uint32_t)al & 0x1fffffu, a1 = (uint32_t)(al >> 21) & 0x1fffffu, a2 = (uint32_t)(al >> 42) & 0x1fffffu;
+                const uint32_t ra0 = g.node2rank[a0 ? a0 - 1 : 0u], ra1 = g.node2rank[a1 ? a1 - 1 : 0u], ra2 = g.node2rank[a2 ? a2 - 1 : 0u];
+                // the column's other members in list order, as rank deltas (a column is contiguous in this order; the list has no holes)
+                alp[u] = (a0 ? ((ra0 - r + 4u) & 7u) : 0u) | (a1 ? ((ra1 - r + 4u) & 7u) << 3 : 0u) | (a2 ? ((ra2 - r + 4u) & 7u) << 6 : 0u);
+                // the few nodes with more than two in-edges / out-edges: their lists from the second entry on - the U chains of a lane, and the lanes of the
+                // wave, step TOGETHER below (every wave has such nodes among its 64 x U, and one chain after the other was most of this pass)
+                ei[u] = on[u] && (A[u].w & 0x80000000u) ? B[u].y : NONE;
+                eo[u] = on[u] && B[u].z != NONE && (B[u].z & 0x80000000u) ? B[u].x : NONE;
+            }
+            CSR_T(3, alp[U - 1]);
+            uint32_t e3[U];                                        // third in-edge of the nodes that have one
+            {
+                bool first = true, more = false;
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) { more |= ei[u] != NONE || eo[u] != NONE; e3[u] = NONE; }
+                while (more) {
+                    uint32_t ni[U], no_[U], to[U];
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) { ni[u] = g.e_next_in[ei[u] != NONE ? ei[u] : 0u]; no_[u] = g.e_next_out[eo[u] != NONE ? eo[u] : 0u]; }
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) to[u] = g.e_to[eo[u] != NONE && no_[u] != NONE ? no_[u] : 0u];
+                    more = false;
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) {
+                        const uint32_t r = base + u * NT + tid;
+                        if (ei[u] != NONE) { ei[u] = ni[u]; if (ni[u] != NONE) np[u]++; if (first) e3[u] = ni[u]; }
+                        if (eo[u] != NONE) { eo[u] = no_[u]; if (no_[u] != NONE) kept[u] |= (uint32_t)(g.node2rank[to[u]] - r >= 2u); }
+                        more |= ei[u] != NONE || eo[u] != NONE;
+                    }
+                    first = false;
+                }
+            }
+            uint32_t off_[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t r = base + u * NT + tid;
+                uint32_t tot_np, tot_k;
+                const uint32_t ex_np = block_excl_scan_add(np[u], lds_u, &tot_np);
+                const uint32_t ex_k = block_excl_scan_add(kept[u], lds_u, &tot_k);
+                off_[u] = off_base + ex_np;
+                if (on[u]) {
+                    const uint32_t off = off_[u], kx = kept_base + ex_k, sink = B[u].z == NONE;
+                    g.row_pred_off[r] = off; g.row_al[r] = (uint16_t)alp[u];   // (the row's letter and sink flag: bits 0-1 and 2 of its record)
+                    g.score[r] = (int32_t)kx;                      // kept rows before r
+                    if (np[u] >= 1) { g.pred_rank[off] = pf0[u]; g.pred_w[off] = w0[u]; }
+                    if (np[u] >= 2) { g.pred_rank[off + 1] = pf1[u]; g.pred_w[off + 1] = w1[u]; }
+                    g.row_meta[r] = cd[u] | (sink << 2) | (kept[u] << 4) | (np[u] > 4u ? 32u : 0u) | ((kept[u] && R ? (kx & (R - 1)) : 15u) << META_SLOT) | (np[u] << META_NP);   // slot 15: no non-adjacent reader (or no ring at all) - the row is not written to the ring
+                    if (DIR && np[u] > max_indeg) *sOk = 4;         // the direction bytes hold a 4-bit predecessor slot (max_indeg <= 16)
+                    g.row_pred0[r] = pf0[u]; g.row_pred1[r] = pf1[u];
+                    st_multi += np[u] >= 2; st_wide += np[u] > 4; st_fifth += np[u] > 4 ? np[u] - 4 : 0;
+                }
+                off_base += tot_np; kept_base += tot_k;
+            }
+            {   // the third and later in-edges (same stepping: entry k of every chain that has one)
+                uint32_t mx = 0;
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) mx = max(mx, np[u]);
+                for (uint32_t k = 2; k < mx; k++) {
+                    uint32_t f[U], nx[U]; int32_t w[U];
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) { const uint32_t e = k < np[u] ? e3[u] : 0u; f[u] = g.e_from[e]; w[u] = g.e_w[e]; nx[u] = g.e_next_in[e]; }
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) if (k < np[u]) { g.pred_rank[off_[u] + k] = g.node2rank[f[u]]; g.pred_w[off_[u] + k] = w[u]; e3[u] = nx[u]; }
+                }
+            }
+#ifdef HX_CSR_PROF
+            CSR_T(4, off_base);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            CSR_T(7, off_base);   // (the iteration's stores acknowledged)
+#endif
+        }
+        if (tid == 0) g.row_pred_off[V2] = off_base;
+        const uint32_t ktot = kept_base;
+        __syncthreads();
+        CSR_T(4, off_base);
+        // ---- pass C: where the DP will find each predecessor row: 1..R ring slot + 1, 13 the previous row (registers), 14 the virtual row 0, 15 HBM
+        // (a kept row that has left the ring by then: it is marked as read back from HBM). Two round trips: the row's entries, their rows' kept counts.
+        for (uint32_t base = 0; base < V2; base += NT * U) {
+            uint32_t po[U], np[U], kr[U], p0[U], p1[U], k0[U], k1[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t r = base + u * NT + tid, rc = r < V2 ? r : 0u;
+                po[u] = g.row_pred_off[rc]; np[u] = r < V2 ? g.row_meta[rc] >> META_NP : 0u; kr[u] = (uint32_t)g.score[rc];
+                p0[u] = g.row_pred0[rc]; p1[u] = g.row_pred1[rc];   // (pass B left the first two predecessor ranks here)
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) { k0[u] = (uint32_t)g.score[np[u] >= 1 ? p0[u] : 0u]; k1[u] = (uint32_t)g.score[np[u] >= 2 ? p1[u] : 0u]; }
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t r = base + u * NT + tid;
+                if (r >= V2) continue;
+                auto place = [&](const uint32_t pr, const uint32_t kp) -> uint32_t {
+                    uint32_t loc;
+                    if (r - pr == 1) loc = 13;
+                    else {
+                        const uint32_t live = kr[u] - kp;          // kept rows produced in [pr, r), pr included
+                        if (live <= R) loc = 1 + (kp & (R - 1));
+                        else { loc = 15; atomicOr(&g.row_meta[pr], 8u); }
+                    }
+                    st_ring += r - pr >= 2 && loc != 15; st_far += loc == 15;
+                    return pr | (loc << 28);
+                };
+                if (np[u] >= 1) { const uint32_t ent = place(p0[u], k0[u]); g.pred_rank[po[u]] = ent; g.row_pred0[r] = ent; }
+                else g.row_pred0[r] = 14u << 28;                   // a source node: the virtual row 0
+                if (np[u] >= 2) { const uint32_t ent = place(p1[u], k1[u]); g.pred_rank[po[u] + 1] = ent; g.row_pred1[r] = ent; }
+            }
+            {   // the third and later entries, entry q of every row that has one at a time
+                uint32_t mx = 0;
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) mx = max(mx, np[u]);
+                for (uint32_t q = 2; q < mx; q++) {
+                    uint32_t pr[U], kp[U];
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) pr[u] = g.pred_rank[q < np[u] ? po[u] + q : 0u];
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) kp[u] = (uint32_t)g.score[q < np[u] ? pr[u] & 0x0fffffffu : 0u];
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) {
+                        const uint32_t r = base + u * NT + tid;
+                        if (q >= np[u]) continue;
+                        uint32_t loc;
+                        if (r - pr[u] == 1) loc = 13;
+                        else {
+                            const uint32_t live = kr[u] - kp[u];
+                            if (live <= R) loc = 1 + (kp[u] & (R - 1));
+                            else { loc = 15; atomicOr(&g.row_meta[pr[u]], 8u); }
+                        }
+                        st_ring += r - pr[u] >= 2 && loc != 15; st_far += loc == 15;
+                        g.pred_rank[po[u] + q] = pr[u] | (loc << 28);
+                    }
+                }
+            }
+        }
+        if (DIR) {   // ---- pass D: rows that a far successor reads back from HBM get consecutive rows of H (the score matrix is not kept with direction bytes);
+                     // rows with more than 4 predecessors a row of the wide-row pool (a direction byte per cell)
+            __syncthreads();
+            CSR_T(5, st_far);
+            uint32_t* farslot = reinterpret_cast<uint32_t*>(g.pred);
+            uint32_t far_base = 0, wide_base = 0;
+            for (uint32_t base = 0; base < V2; base += NT * U) {
+                uint32_t mt[U];
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) { const uint32_t r = base + u * NT + tid; mt[u] = r < V2 ? g.row_meta[r] : 0u; }
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) {
+                    const uint32_t r = base + u * NT + tid;
+                    uint32_t tf, tw;
+                    const uint32_t exf = block_excl_scan_add((mt[u] >> 3) & 1u, lds_u, &tf);
+                    const uint32_t exw = block_excl_scan_add((mt[u] >> 5) & 1u, lds_u, &tw);
+                    if (mt[u] & 8u) farslot[r] = far_base + exf;
+                    if (mt[u] & 32u) g.wslot[r] = wide_base + exw;
+                    far_base += tf; wide_base += tw;
+                }
+            }
+            if (tid == 0 && far_base > hrows && *sOk == 1) *sOk = 5;    // more far rows than the estimate: the host retries with a row per node
+            if (tid == 0 && wide_base > wrows && *sOk == 1) *sOk = 7;   // more wide rows than the estimate: the host retries with more
+            CSR_T(6, wide_base);
+        }
+#ifdef HX_CSR_PROF
+        if (tid == 0 && last_seq && eidx % 500 == 0)
+            printf("[csrprof] edge %u lanes %u V %u seqs %u: scatter %llu | B: ranks %llu records %llu neighbours %llu scans+stores %llu store drain %llu | C %llu | D %llu\n", eidx, NT, V2, 0u, cp[0], cp[1], cp[2], cp[3], cp[4], cp[7], cp[5], cp[6]);
+#endif
+#if !defined(HX_DP_PROF) && !defined(HX_GU_PROF)
+        if (stats) {   // statistics of the rows the next DP will run over
+            if (st_multi) atomicAdd(&ph[7], (unsigned long long)st_multi);
+            if (st_ring | st_fifth) atomicAdd(&ph[8], (unsigned long long)st_ring | ((unsigned long long)st_fifth << 40));   // (high bits: fifth-and-later predecessor entries, fetched inside the row)
+            if (st_far | st_wide) atomicAdd(&ph[9], (unsigned long long)st_far | ((unsigned long long)st_wide << 40));      // (high bits: rows with more than 4 predecessors)
+            if (tid == 0) { atomicAdd(&ph[6], (unsigned long long)V2); atomicAdd(&ph[10], (unsigned long long)ktot); atomicAdd(&ph[11], 1ull); }
+        }
+#endif
+    }
+
 // One kernel per (largest workgroup, columns per lane, traceback flavour): the register budget of a launch is that of ITS row loop, so the
 // many short gaps (one wavefront, 4-8 columns per lane) run with a fraction of the registers - and several times the waves per SIMD - of
 // the few long ones; sequences shorter than the edge's longest leave the upper lanes / waves of the pipeline idle.
@@ -1237,7 +1435,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
         g.rank2node = P.rank2node + no; g.node2rank = P.node2rank + no; g.mark = P.mark + no; g.check = P.check + no;
         g.stack = P.stack + SL.stack_off; g.score = P.score + no; g.pred = P.pred + no;
         g.row_code = P.row_code + no; g.row_sink = P.row_sink + no; g.row_pred_off = P.row_pred_off + no; g.pred_rank = P.pred_rank + eo; g.pred_w = P.pred_w + eo;
-        g.row_meta = P.row_meta + no; g.row_pred0 = P.row_pred0 + no; g.row_pred1 = P.row_pred1 + no; g.nrec = P.nrec + no; g.row_al = P.row_al + no; g.wslot = P.wslot + no;
+        g.row_meta = P.row_meta + no; g.row_pred0 = P.row_pred0 + no; g.row_pred1 = P.row_pred1 + no; g.nrec = P.nrec + no; g.nrec2 = P.nrec2 + no; g.row_al = P.row_al + no; g.wslot = P.wslot + no;
         g.e_from = P.e_from + eo; g.e_to = P.e_to + eo; g.e_next_in = P.e_next_in + eo; g.e_next_out = P.e_next_out + eo; g.e_w = P.e_w + eo;
         g.aln_node = P.aln_node + SL.aln_off; g.aln_pos = P.aln_pos + SL.aln_off;
         g.vcap = ED.vcap; g.ecap = ED.ecap;
@@ -1701,7 +1899,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                     uint32_t po = 0, pe = 0;
                     if (i != 0) { po = g.row_pred_off[i - 1]; pe = g.row_pred_off[i]; }
                     if (i != 0 && j != 0) {
-                        const int mc = seq[j - 1] == g.row_code[i - 1] ? match : mismatch;
+                        const int mc = seq[j - 1] == (uint8_t)(g.row_meta[i - 1] & 3u) ? match : mismatch;
                         if (po == pe) { if (hij == H[j - 1] + mc) { pi_ = 0; pj_ = j - 1; found = true; } }
                         else for (uint32_t p = po; p < pe && !found; p++) {
                             uint32_t pr = (g.pred_rank[p] & 0x0fffffffu) + 1;
@@ -1825,12 +2023,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                         if (isnew) {
                             const uint32_t e = E0 + ebase + ex;
                             g.e_from[e] = f; g.e_to[e] = t; g.e_w[e] = 2; g.e_next_in[e] = NONE; g.e_next_out[e] = NONE;
-                            if (g.out_tail[f] == NONE) g.out_head[f] = e; else g.e_next_out[g.out_tail[f]] = e;
-                            g.out_tail[f] = e;
-                            uint32_t* r = reinterpret_cast<uint32_t*>(&g.nrec[t]);
-                            if (g.in_tail[t] == NONE) { g.in_head[t] = e; r[0] = f; }
-                            else { g.e_next_in[g.in_tail[t]] = e; if (r[1] == NONE) r[1] = f; else r[3] |= 0x80000000u; }
-                            g.in_tail[t] = e;
+                            link_edge(g, e, f, t);   // (a node gains at most one in-edge and one out-edge per sequence: different words of its records)
                         }
                         ebase += tot;
                     }
@@ -1906,115 +2099,8 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
         }
         PHASE(4);
         __syncthreads();
-        // =================================================== rank-order CSR for the next DP (all lanes)
-        // Round 5: lane = rank. The first version dealt the ranks out in contiguous chunks per thread (a thread's prefix sums were then its own running
-        // counts) and ran seven passes of dependent list walks over them: every load of a wave touched 64 different cache lines, and the rebuild took ~2 000
-        // cycles PER ROW of a one-wave workgroup under load - a fifth of all wave cycles of a 13 000-edge call (tools/dev_r05.sh edgedump). Now the ranks
-        // are taken NT at a time, lane t = rank base + t: the rank-indexed arrays are read and written coalesced, the node-indexed ones nearly so (node ids
-        // rise with the ranks), offsets and ring slots come from a scan per block of ranks with a running base, and what used to need a pass of its own is
-        // read where it already is: the first two in-edge sources and the aligned ids from the node's 16-byte record, "kept" (a successor that is not the
-        // next row) from the node's own out-list instead of atomics from its successors. Four passes, one dependent chain of 3-4 loads each.
-        {
-            const uint32_t V2 = sV;
-            for (uint32_t r = tid; r < V2; r += NT) g.node2rank[g.rank2node[r]] = r;
-            __syncthreads();
-            uint32_t off_base = 0, kept_base = 0;
-            uint32_t st_multi = 0, st_ring = 0, st_far = 0, st_wide = 0, st_fifth = 0;
-            for (uint32_t base = 0; base < V2; base += NT) {           // ---- pass B: everything a row knows about itself
-                const uint32_t r = base + tid;
-                const bool on = r < V2;
-                uint32_t n = 0, np = 0, kept = 0, cd = 0, sink = 0, alp = 0, e0 = NONE, f0 = NONE, f1 = NONE;
-                if (on) {
-                    n = g.rank2node[r];
-                    const uint4 rec = g.nrec[n];                       // {1st in-edge source, 2nd, aligned ids + 1 (3 x 21 bits), bit 63: more in-edges}
-                    e0 = g.in_head[n];
-                    const uint32_t oh = g.out_head[n];
-                    cd = g.code[n];
-                    f0 = rec.x; f1 = rec.y;
-                    np = f0 == NONE ? 0u : f1 == NONE ? 1u : 2u;
-                    if (rec.w & 0x80000000u) { np = 0; for (uint32_t e = e0; e != NONE; e = g.e_next_in[e]) np++; }   // three or more: the list is walked (rare)
-                    sink = oh == NONE;
-                    for (uint32_t e = oh; e != NONE; e = g.e_next_out[e]) kept |= (uint32_t)(g.node2rank[g.e_to[e]] - r >= 2u);   // a successor that is not the next row reads this one from the ring / HBM
-                    const unsigned long long al = ((unsigned long long)rec.z | ((unsigned long long)rec.w << 32)) & 0x7fffffffffffffffULL;
-                    for (uint32_t q = 0; q < 3; q++) {                 // the column's other members in list order, as rank deltas (a column is contiguous in this order)
-                        const uint32_t a1 = (uint32_t)(al >> (21 * q)) & 0x1fffffu;
-                        if (!a1) break;
-                        alp |= ((g.node2rank[a1 - 1] - r + 4u) & 7u) << (3 * q);
-                    }
-                }
-                uint32_t tot_np, tot_k;
-                const uint32_t ex_np = block_excl_scan_add(np, lds_u, &tot_np);
-                const uint32_t ex_k = block_excl_scan_add(kept, lds_u, &tot_k);
-                if (on) {
-                    const uint32_t off = off_base + ex_np, kx = kept_base + ex_k;
-                    g.row_pred_off[r] = off; g.row_code[r] = (uint8_t)cd; g.row_sink[r] = (uint8_t)sink; g.row_al[r] = (uint16_t)alp;
-                    g.score[r] = (int32_t)kx;                          // kept rows before r
-                    uint32_t q0 = 0, q1 = 0, e = e0;
-                    for (uint32_t k = 0; k < np; k++) {
-                        const uint32_t f = k == 0 ? f0 : k == 1 ? f1 : g.e_from[e];
-                        const uint32_t pr = g.node2rank[f];
-                        g.pred_w[off + k] = g.e_w[e];
-                        g.pred_rank[off + k] = pr;
-                        if (k == 0) q0 = pr; else if (k == 1) q1 = pr;
-                        e = g.e_next_in[e];
-                    }
-                    g.row_meta[r] = cd | (sink << 2) | (kept << 4) | (np > 4u ? 32u : 0u) | ((kept && R ? (kx & (R - 1)) : 15u) << META_SLOT) | (np << META_NP);   // slot 15: no non-adjacent reader (or no ring at all) - the row is not written to the ring
-                    if (DIR && np > max_indeg) sOk = 4;                // the direction bytes hold a 4-bit predecessor slot (max_indeg <= 16)
-                    g.row_pred0[r] = q0; g.row_pred1[r] = q1;
-                    st_multi += np >= 2; st_wide += np > 4; st_fifth += np > 4 ? np - 4 : 0;
-                }
-                off_base += tot_np; kept_base += tot_k;
-            }
-            if (tid == 0) g.row_pred_off[V2] = off_base;
-            const uint32_t ktot = kept_base;
-            __syncthreads();
-            // ---- pass C: where the DP will find each predecessor row: 1..R ring slot + 1, 13 the previous row (registers), 14 the virtual row 0, 15 HBM
-            // (a kept row that has left the ring by then: it is marked as read back from HBM)
-            for (uint32_t r = tid; r < V2; r += NT) {
-                const uint32_t po = g.row_pred_off[r], np = g.row_meta[r] >> META_NP, kr = (uint32_t)g.score[r];
-                for (uint32_t q = 0; q < np; q++) {
-                    const uint32_t pr = g.pred_rank[po + q];
-                    uint32_t loc;
-                    if (r - pr == 1) loc = 13;
-                    else {
-                        const uint32_t kp = (uint32_t)g.score[pr], live = kr - kp;   // kept rows produced in [pr, r), pr included
-                        if (live <= R) loc = 1 + (kp & (R - 1));
-                        else { loc = 15; atomicOr(&g.row_meta[pr], 8u); }
-                    }
-                    const uint32_t ent = pr | (loc << 28);
-                    st_ring += r - pr >= 2 && loc != 15; st_far += loc == 15;
-                    g.pred_rank[po + q] = ent;
-                    if (q == 0) g.row_pred0[r] = ent; else if (q == 1) g.row_pred1[r] = ent;
-                }
-                if (np == 0) g.row_pred0[r] = 14u << 28;               // a source node: the virtual row 0
-            }
-            if (DIR) {   // ---- pass D: rows that a far successor reads back from HBM get consecutive rows of H (the score matrix is not kept with direction bytes);
-                         // rows with more than 4 predecessors a row of the wide-row pool (a direction byte per cell)
-                __syncthreads();
-                uint32_t* farslot = reinterpret_cast<uint32_t*>(g.pred);
-                uint32_t far_base = 0, wide_base = 0;
-                for (uint32_t base = 0; base < V2; base += NT) {
-                    const uint32_t r = base + tid;
-                    const uint32_t mt = r < V2 ? g.row_meta[r] : 0u;
-                    uint32_t tf, tw;
-                    const uint32_t exf = block_excl_scan_add((mt >> 3) & 1u, lds_u, &tf);
-                    const uint32_t exw = block_excl_scan_add((mt >> 5) & 1u, lds_u, &tw);
-                    if (mt & 8u) farslot[r] = far_base + exf;
-                    if (mt & 32u) g.wslot[r] = wide_base + exw;
-                    far_base += tf; wide_base += tw;
-                }
-                if (tid == 0 && far_base > ED.hrows && sOk == 1) sOk = 5;    // more far rows than the estimate: the host retries with a row per node
-                if (tid == 0 && wide_base > ED.wrows && sOk == 1) sOk = 7;   // more wide rows than the estimate: the host retries with more
-            }
-#if !defined(HX_DP_PROF) && !defined(HX_GU_PROF)
-            if (phase) {   // statistics of the rows the next DP will run over
-                if (st_multi) atomicAdd(&ph[7], (unsigned long long)st_multi);
-                if (st_ring | st_fifth) atomicAdd(&ph[8], (unsigned long long)st_ring | ((unsigned long long)st_fifth << 40));   // (high bits: fifth-and-later predecessor entries, fetched inside the row)
-                if (st_far | st_wide) atomicAdd(&ph[9], (unsigned long long)st_far | ((unsigned long long)st_wide << 40));      // (high bits: rows with more than 4 predecessors)
-                if (tid == 0) { atomicAdd(&ph[6], (unsigned long long)V2); atomicAdd(&ph[10], (unsigned long long)ktot); atomicAdd(&ph[11], 1ull); }
-            }
-#endif
-        }
+        // =================================================== rank-order CSR for the next DP (all lanes): csr_rebuild above
+        csr_rebuild<MAXNT, DIR>(g, sV, R, max_indeg, ED.hrows, ED.wrows, lds_u, &sOk, ph, phase != nullptr, eidx, k == ED.seq_begin, k + 1 == ED.seq_end);
         __syncthreads();
         PHASE(5);
     }

@@ -11,6 +11,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import bench  # noqa: E402
 from haslr_amd import hip, host  # noqa: E402
 
+if os.environ.get("AB_LIBDIR"):   # a variant build of libhaslr_hip.so (tools/dev_variant.sh)
+    hip._LIBDIR = os.path.join(ROOT, os.environ["AB_LIBDIR"])
+
 wl_name = os.environ.get("AB_WORKLOAD", "fly")
 wl = bench.WORKLOADS[wl_name]
 glen = int(os.environ.get("AB_GENOME", wl["genome"]))
