@@ -1163,11 +1163,12 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
 // rise with the ranks), offsets and ring slots come from a scan per block of ranks with a running base, and what used to need a pass of its own is
 // read where it already is: the first two in-edge sources and the aligned ids from the node's 16-byte record, "kept" (a successor that is not the
 // next row) from the node's own out-list instead of atomics from its successors. Four passes, one dependent chain of 3-4 loads each.
-// (A function of its own, not inlined: its U-fold register arrays would otherwise count against the allocation of the whole kernel - with them inlined the
-// 4-column instances went from 145 to 164 registers, the 8-column ones spilled 50-60 bytes more, and the DP rows and the traceback of the longest 12 Mb
-// edge got 5 % and 18 % slower without a changed line.)
+// (What the registers of this code cost the rest of the kernel, measured on the way: with four ranks per lane and the views read through the reference - every
+// pointer in two VECTOR registers, 21 of them - the 8-column instances, capped at 128 registers, spilled 50-60 bytes more, and a 13 000-edge call took 0.617 s
+// instead of 0.557 s; as a real function call the kernel takes the callee's registers as its own (132 > 128: three waves per SIMD) and the row loop of the
+// 4-column instances got 6 % slower (970 -> 1 030 cycles per row at 12 Mb) with the call ABI's scalar registers. Inlined, with scalar pointers and U = 2: both fine.)
 template <int MAXNT, bool DIR>
-__device__ __attribute__((noinline)) void csr_rebuild(const G& g_in, const uint32_t V2, const uint32_t R, const uint32_t max_indeg, const uint32_t hrows, const uint32_t wrows, uint32_t* lds_u,
+__device__ __forceinline__ void csr_rebuild(const G& g_in, const uint32_t V2, const uint32_t R, const uint32_t max_indeg, const uint32_t hrows, const uint32_t wrows, uint32_t* lds_u,
                                                       uint32_t* sOk, unsigned long long* ph, const bool stats, const uint32_t eidx, const bool first_seq, const bool last_seq) {
     // (the views arrive through memory: as they are, every pointer would sit in two VECTOR registers - the compiler cannot know them uniform - and 21 of them
     // are used here; read through readfirstlane they are scalars)
@@ -1393,6 +1394,172 @@ __device__ __attribute__((noinline)) void csr_rebuild(const G& g_in, const uint3
         }
 #endif
     }
+
+// spoa Graph::add_alignment by all lanes (poa_edge: "graph update"); the views' pointers as scalars, like the CSR rebuild
+__device__ __forceinline__ void graph_update(const G& g_in, const uint8_t* seq_, const uint32_t L, const uint32_t na, uint32_t* lds_u, uint32_t* sV_, uint32_t* sE_, uint32_t* sNcand_, uint32_t* sOk_) {
+    G g = g_in;
+    g.stack = uptr(g.stack); g.aln_pos = uptr(g.aln_pos); g.aln_node = uptr(g.aln_node); g.code = uptr(g.code); g.n_aligned = uptr(g.n_aligned); g.aligned = uptr(g.aligned);
+    g.score = uptr(g.score); g.row_pred1 = uptr(g.row_pred1); g.nrec = uptr(g.nrec); g.nrec2 = uptr(g.nrec2); g.out_head = uptr(g.out_head); g.out_tail = uptr(g.out_tail);
+    g.in_head = uptr(g.in_head); g.in_tail = uptr(g.in_tail); g.e_next_out = uptr(g.e_next_out); g.e_next_in = uptr(g.e_next_in); g.e_to = uptr(g.e_to); g.e_from = uptr(g.e_from); g.e_w = uptr(g.e_w);
+    const uint8_t* seq = uptr(seq_);
+    const uint32_t tid = threadIdx.x, NT = blockDim.x;
+    uint32_t* path = reinterpret_cast<uint32_t*>(g.score);   // node of every base of this sequence (vcap+1 words, free until the CSR build)
+    uint32_t* colref = g.row_pred1;                          // column reference of every base (free until the CSR build)
+    // spoa Graph::add_alignment, all lanes. A global alignment consumes every base exactly once and visits every aligned group
+    // ("column") at most once, so bases are independent: base p looks at the node it was aligned to (reuse it, reuse a same-letter
+    // member of its column, or open a new node that joins the column), and the edge (node of base p-1 -> node of base p) either
+    // exists (weight += 2) or is appended. New node / edge ids are prefix sums in base order — the ids the serial walk hands out —
+    // and every node gains at most one in-edge and one out-edge per sequence, so list appends never collide.
+    const uint32_t V0 = *sV_, E0 = *sE_;
+    int32_t* anode = reinterpret_cast<int32_t*>(g.stack);   // node aligned to base p, -1 = none (horizontal move)
+    const bool room = E0 + L + 1 <= g.ecap && L <= g.vcap;   // edges: worst case (every base a new edge); per-base scratch lives in node pools; nodes are counted exactly below
+    if (!room) { if (tid == 0) (*sOk_) = 0; }
+    else {
+        if (tid == 0) (*sNcand_) = 0;
+        for (uint32_t p = tid; p < L; p += NT) anode[p] = -2;
+        __syncthreads();
+        uint32_t nv = 0;
+        for (uint32_t k = tid; k < na; k += NT) { const int32_t pos = g.aln_pos[k]; if (pos != -1) { anode[pos] = g.aln_node[k]; nv++; } }
+        if (nv) atomicAdd(&(*sNcand_), nv);
+        __syncthreads();
+        const bool chain = na == 0;                 // empty graph: the sequence becomes a chain
+        const bool par = chain || (*sNcand_) == L;      // always true for a global alignment
+        if (!par) {                                 // (kept for safety: the serial walk handles any alignment shape)
+            if (tid == 0) { uint32_t V2 = V0, E2 = E0; if (!add_alignment(g, V2, E2, na, seq, L, path, colref)) (*sOk_) = 0; else { (*sV_) = V2; (*sE_) = E2; } }
+        } else {
+            // (round 5: lane = base. Bases are taken NT at a time - coalesced accesses by position, one scan per block with a running base for the ids -
+            // where round 1 dealt them out in contiguous chunks per thread: every load of a wave then touched 64 different cache lines)
+            uint32_t nbase = 0;
+            bool ovf = false;
+            for (uint32_t base = 0; base < L; base += NT) {
+                const uint32_t p = base + tid;
+                const bool on = p < L;
+                uint32_t tgt = NONE;                // NONE = new node
+                int32_t an = -1;
+                uint8_t c = 0;
+                if (on) {
+                    c = seq[p];
+                    an = chain ? -1 : anode[p];
+                    if (an >= 0) {
+                        if (g.code[an] == c) tgt = (uint32_t)an;
+                        else for (uint32_t q = 0, nq = g.n_aligned[an]; q < nq; q++) { const uint32_t a = g.aligned[3 * an + q]; if (g.code[a] == c) { tgt = a; break; } }
+                    }
+                }
+                const bool isnew = on && tgt == NONE;
+                uint32_t tot;
+                const uint32_t ex = block_excl_scan_add((uint32_t)isnew, lds_u, &tot);
+                if (V0 + nbase + tot > g.vcap) { ovf = true; break; }   // the graph outgrows its workspace (same verdict on every lane): the host retries with more
+                if (isnew) {
+                    uint32_t vv = V0 + nbase + ex;
+                    const uint32_t nn = add_node(g, vv, c);
+                    if (an >= 0) {                  // joins the column of the node it was aligned to
+                        for (uint32_t q = 0, nq = g.n_aligned[an]; q < nq; q++) { const uint32_t a = g.aligned[3 * an + q]; push_aligned(g, nn, a); push_aligned(g, a, nn); }
+                        push_aligned(g, nn, (uint32_t)an); push_aligned(g, (uint32_t)an, nn);
+                    }
+                    tgt = nn;
+                }
+                if (on) { path[p] = tgt; colref[p] = an >= 0 ? (uint32_t)an : NONE; }
+                nbase += tot;
+            }
+            const uint32_t newV = nbase;
+            if (ovf) { if (tid == 0) (*sOk_) = 0; }
+            else {
+            __syncthreads();
+            uint32_t ebase = 0;
+            for (uint32_t base = 0; base < L; base += NT) {
+                const uint32_t p = base + tid;
+                const bool on = p >= 1 && p < L;
+                uint32_t f = NONE, t = NONE, hit = NONE;
+                if (on) {
+                    f = path[p - 1]; t = path[p];
+                    if (f < V0 && t < V0) for (uint32_t e = g.out_head[f]; e != NONE; e = g.e_next_out[e]) if (g.e_to[e] == t) { hit = e; break; }
+                    if (hit != NONE) g.e_w[hit] += 2;
+                }
+                const bool isnew = on && hit == NONE;
+                uint32_t tot;
+                const uint32_t ex = block_excl_scan_add((uint32_t)isnew, lds_u, &tot);
+                if (isnew) {
+                    const uint32_t e = E0 + ebase + ex;
+                    g.e_from[e] = f; g.e_to[e] = t; g.e_w[e] = 2; g.e_next_in[e] = NONE; g.e_next_out[e] = NONE;
+                    link_edge(g, e, f, t);   // (a node gains at most one in-edge and one out-edge per sequence: different words of its records)
+                }
+                ebase += tot;
+            }
+            const uint32_t newE = ebase;
+            if (tid == 0) { (*sV_) = V0 + newV; (*sE_) = E0 + newE; }
+            }
+        }
+    }
+}
+
+// The order update of poa_edge
+__device__ __forceinline__ void order_update(const G& g_in, const uint32_t V_old, const uint32_t V2, const uint32_t L, uint32_t* lds_u) {
+    G g = g_in;
+    g.stack = uptr(g.stack); g.row_pred0 = uptr(g.row_pred0); g.row_pred1 = uptr(g.row_pred1); g.node2rank = uptr(g.node2rank); g.n_aligned = uptr(g.n_aligned); g.aligned = uptr(g.aligned);
+    g.score = uptr(g.score); g.rank2node = uptr(g.rank2node); g.pred = uptr(g.pred);
+    const uint32_t tid = threadIdx.x, NT = blockDim.x;
+    uint32_t* path = reinterpret_cast<uint32_t*>(g.score);
+    uint32_t* colref = g.row_pred1;
+    uint32_t* tmp_u32 = reinterpret_cast<uint32_t*>(g.pred);
+    // Order update. Ranks keep every aligned group ("column") contiguous, like the reference's order does: a later sequence may
+    // enter a column through one member and continue from another, so edges must run from earlier columns to later ones.
+    // The new sequence's path visits existing columns in increasing rank. Each new node gets an insertion point X in the OLD order:
+    //   new mismatch node (joins the column of the old node it was aligned to)  -> X = last rank of that column + 1
+    //   new unaligned node (a new column)                                       -> X = first rank of the next existing column on the path (or the end)
+    // Nodes with the same X keep path order (X never decreases along the path). New rank of an old node = old rank + #new nodes
+    // with X <= old rank: one prefix sum over the old order instead of a serial DFS over the whole graph.
+    
+    uint32_t* ins = g.stack;          // V_old+1 counters, then their exclusive prefix
+    uint32_t* xq = g.row_pred0;       // insertion point of every new node, by sequence position (free until the CSR build)
+    if (V_old == 0) {
+        for (uint32_t r = tid; r < V2; r += NT) g.rank2node[r] = r;
+    } else {
+        uint32_t* firstidx = g.stack + (V_old + 1);   // per insertion point: the first new node (in path order) that goes there
+        for (uint32_t r = tid; r <= V_old; r += NT) { ins[r] = 0; firstidx[r] = NONE; }
+        __syncthreads();
+        {
+            // every base on its own: new node ids are consecutive in path order, so "position among the new nodes" = id - V_old
+            auto col_first = [&](uint32_t n) { uint32_t f = g.node2rank[n]; for (uint32_t k = 0, na = g.n_aligned[n]; k < na; k++) { const uint32_t a = g.aligned[3 * n + k]; if (a < V_old) f = min(f, g.node2rank[a]); } return f; };
+            auto col_last = [&](uint32_t n) { uint32_t f = g.node2rank[n]; for (uint32_t k = 0, na = g.n_aligned[n]; k < na; k++) { const uint32_t a = g.aligned[3 * n + k]; if (a < V_old) f = max(f, g.node2rank[a]); } return f; };
+            for (uint32_t q = tid; q < L; q += NT) {
+                const uint32_t n = path[q];
+                if (n < V_old) continue;
+                uint32_t X;
+                if (colref[q] != NONE) X = col_last(colref[q]) + 1;
+                else {                                                // unaligned new node: the next existing column on the path
+                    uint32_t q2 = q + 1;
+                    while (q2 < L && path[q2] >= V_old && colref[q2] == NONE) q2++;
+                    X = q2 < L ? col_first(path[q2] < V_old ? path[q2] : colref[q2]) : V_old;
+                }
+                xq[q] = X;
+                atomicAdd(&ins[X], 1u);
+                atomicMin(&firstidx[X], n - V_old);
+            }
+        }
+        __syncthreads();
+        uint32_t ibase = 0;
+        for (uint32_t base = 0; base <= V_old; base += NT) {      // (lane = old rank, NT at a time: one scan per block with a running base)
+            const uint32_t r = base + tid;
+            const uint32_t c = r <= V_old ? ins[r] : 0u;
+            uint32_t tot;
+            const uint32_t ex = ibase + block_excl_scan_add(c, lds_u, &tot);
+            if (r <= V_old) {
+                ins[r] = ex;                                        // new nodes with X == r start at r + ex
+                if (r < V_old) tmp_u32[r + ex + c] = g.rank2node[r];    // the old node itself moves behind them
+            }
+            ibase += tot;
+        }
+        __syncthreads();
+        for (uint32_t q = tid; q < L; q += NT) {   // nodes with the same insertion point keep path order
+            const uint32_t n = path[q];
+            if (n < V_old) continue;
+            const uint32_t X = xq[q];
+            tmp_u32[X + ins[X] + (n - V_old - firstidx[X])] = n;
+        }
+        __syncthreads();
+        for (uint32_t r = tid; r < V2; r += NT) g.rank2node[r] = tmp_u32[r];
+    }
+}
 
 // One kernel per (largest workgroup, columns per lane, traceback flavour): the register budget of a launch is that of ITS row loop, so the
 // many short gaps (one wavefront, 4-8 columns per lane) run with a fraction of the registers - and several times the waves per SIMD - of
@@ -1938,165 +2105,13 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
         }
         __syncthreads();
         PHASE(2);
-        // =================================================== graph update (lane 0) + order update (all lanes)
+        // =================================================== graph update + order update (all lanes): graph_update / order_update above
         const uint32_t V_old = sV;
-        uint32_t* path = reinterpret_cast<uint32_t*>(g.score);   // node of every base of this sequence (vcap+1 words, free until the CSR build)
-        uint32_t* colref = g.row_pred1;                          // column reference of every base (free until the CSR build)
-        {
-            // spoa Graph::add_alignment, all lanes. A global alignment consumes every base exactly once and visits every aligned group
-            // ("column") at most once, so bases are independent: base p looks at the node it was aligned to (reuse it, reuse a same-letter
-            // member of its column, or open a new node that joins the column), and the edge (node of base p-1 -> node of base p) either
-            // exists (weight += 2) or is appended. New node / edge ids are prefix sums in base order — the ids the serial walk hands out —
-            // and every node gains at most one in-edge and one out-edge per sequence, so list appends never collide.
-            const uint32_t V0 = sV, E0 = sE, na = sNaln;
-            int32_t* anode = reinterpret_cast<int32_t*>(g.stack);   // node aligned to base p, -1 = none (horizontal move)
-            uint32_t* eref = g.stack + L;                            // existing edge into base p's node, NONE = append one
-            const bool room = E0 + L + 1 <= g.ecap && L <= g.vcap;   // edges: worst case (every base a new edge); per-base scratch lives in node pools; nodes are counted exactly below
-            if (!room) { if (tid == 0) sOk = 0; }
-            else {
-                GU_T0();
-                if (tid == 0) sNcand = 0;
-                for (uint32_t p = tid; p < L; p += NT) anode[p] = -2;
-                __syncthreads();
-                uint32_t nv = 0;
-                for (uint32_t k = tid; k < na; k += NT) { const int32_t pos = g.aln_pos[k]; if (pos != -1) { anode[pos] = g.aln_node[k]; nv++; } }
-                if (nv) atomicAdd(&sNcand, nv);
-                __syncthreads();
-                GU_T(6);   // alignment scattered to the bases
-                const bool chain = na == 0;                 // empty graph: the sequence becomes a chain
-                const bool par = chain || sNcand == L;      // always true for a global alignment
-                if (!par) {                                 // (kept for safety: the serial walk handles any alignment shape)
-                    if (tid == 0) { uint32_t V2 = V0, E2 = E0; if (!add_alignment(g, V2, E2, na, seq, L, path, colref)) sOk = 0; else { sV = V2; sE = E2; } }
-                } else {
-                    // (round 5: lane = base. Bases are taken NT at a time - coalesced accesses by position, one scan per block with a running base for the ids -
-                    // where round 1 dealt them out in contiguous chunks per thread: every load of a wave then touched 64 different cache lines)
-                    uint32_t nbase = 0;
-                    bool ovf = false;
-                    for (uint32_t base = 0; base < L; base += NT) {
-                        const uint32_t p = base + tid;
-                        const bool on = p < L;
-                        uint32_t tgt = NONE;                // NONE = new node
-                        int32_t an = -1;
-                        uint8_t c = 0;
-                        if (on) {
-                            c = seq[p];
-                            an = chain ? -1 : anode[p];
-                            if (an >= 0) {
-                                if (g.code[an] == c) tgt = (uint32_t)an;
-                                else for (uint32_t q = 0, nq = g.n_aligned[an]; q < nq; q++) { const uint32_t a = g.aligned[3 * an + q]; if (g.code[a] == c) { tgt = a; break; } }
-                            }
-                        }
-                        const bool isnew = on && tgt == NONE;
-                        uint32_t tot;
-                        const uint32_t ex = block_excl_scan_add((uint32_t)isnew, lds_u, &tot);
-                        if (V0 + nbase + tot > g.vcap) { ovf = true; break; }   // the graph outgrows its workspace (same verdict on every lane): the host retries with more
-                        if (isnew) {
-                            uint32_t vv = V0 + nbase + ex;
-                            const uint32_t nn = add_node(g, vv, c);
-                            if (an >= 0) {                  // joins the column of the node it was aligned to
-                                for (uint32_t q = 0, nq = g.n_aligned[an]; q < nq; q++) { const uint32_t a = g.aligned[3 * an + q]; push_aligned(g, nn, a); push_aligned(g, a, nn); }
-                                push_aligned(g, nn, (uint32_t)an); push_aligned(g, (uint32_t)an, nn);
-                            }
-                            tgt = nn;
-                        }
-                        if (on) { path[p] = tgt; colref[p] = an >= 0 ? (uint32_t)an : NONE; }
-                        nbase += tot;
-                    }
-                    const uint32_t newV = nbase;
-                    GU_T(8);   // target node of every base (reuse / column member / new), node ids (scan) + new nodes and their columns
-                    if (ovf) { if (tid == 0) sOk = 0; }
-                    else {
-                    __syncthreads();
-                    uint32_t ebase = 0;
-                    for (uint32_t base = 0; base < L; base += NT) {
-                        const uint32_t p = base + tid;
-                        const bool on = p >= 1 && p < L;
-                        uint32_t f = NONE, t = NONE, hit = NONE;
-                        if (on) {
-                            f = path[p - 1]; t = path[p];
-                            if (f < V0 && t < V0) for (uint32_t e = g.out_head[f]; e != NONE; e = g.e_next_out[e]) if (g.e_to[e] == t) { hit = e; break; }
-                            if (hit != NONE) g.e_w[hit] += 2;
-                        }
-                        const bool isnew = on && hit == NONE;
-                        uint32_t tot;
-                        const uint32_t ex = block_excl_scan_add((uint32_t)isnew, lds_u, &tot);
-                        if (isnew) {
-                            const uint32_t e = E0 + ebase + ex;
-                            g.e_from[e] = f; g.e_to[e] = t; g.e_w[e] = 2; g.e_next_in[e] = NONE; g.e_next_out[e] = NONE;
-                            link_edge(g, e, f, t);   // (a node gains at most one in-edge and one out-edge per sequence: different words of its records)
-                        }
-                        ebase += tot;
-                    }
-                    const uint32_t newE = ebase;
-                    GU_T(10);  // edge ids (scan) + new edges appended
-                    if (tid == 0) { sV = V0 + newV; sE = E0 + newE; }
-                    }
-                }
-            }
-            PHASE(3);
-        }
+        graph_update(g, seq, L, sNaln, lds_u, &sV, &sE, &sNcand, &sOk);
+        PHASE(3);
         __syncthreads();
         if (sOk != 1) break;
-        {
-            // Order update. Ranks keep every aligned group ("column") contiguous, like the reference's order does: a later sequence may
-            // enter a column through one member and continue from another, so edges must run from earlier columns to later ones.
-            // The new sequence's path visits existing columns in increasing rank. Each new node gets an insertion point X in the OLD order:
-            //   new mismatch node (joins the column of the old node it was aligned to)  -> X = last rank of that column + 1
-            //   new unaligned node (a new column)                                       -> X = first rank of the next existing column on the path (or the end)
-            // Nodes with the same X keep path order (X never decreases along the path). New rank of an old node = old rank + #new nodes
-            // with X <= old rank: one prefix sum over the old order instead of a serial DFS over the whole graph.
-            const uint32_t V2 = sV;
-            uint32_t* ins = g.stack;          // V_old+1 counters, then their exclusive prefix
-            uint32_t* xq = g.row_pred0;       // insertion point of every new node, by sequence position (free until the CSR build)
-            if (V_old == 0) {
-                for (uint32_t r = tid; r < V2; r += NT) g.rank2node[r] = r;
-            } else {
-                uint32_t* firstidx = g.stack + (V_old + 1);   // per insertion point: the first new node (in path order) that goes there
-                for (uint32_t r = tid; r <= V_old; r += NT) { ins[r] = 0; firstidx[r] = NONE; }
-                __syncthreads();
-                {
-                    // every base on its own: new node ids are consecutive in path order, so "position among the new nodes" = id - V_old
-                    auto col_first = [&](uint32_t n) { uint32_t f = g.node2rank[n]; for (uint32_t k = 0, na = g.n_aligned[n]; k < na; k++) { const uint32_t a = g.aligned[3 * n + k]; if (a < V_old) f = min(f, g.node2rank[a]); } return f; };
-                    auto col_last = [&](uint32_t n) { uint32_t f = g.node2rank[n]; for (uint32_t k = 0, na = g.n_aligned[n]; k < na; k++) { const uint32_t a = g.aligned[3 * n + k]; if (a < V_old) f = max(f, g.node2rank[a]); } return f; };
-                    for (uint32_t q = tid; q < L; q += NT) {
-                        const uint32_t n = path[q];
-                        if (n < V_old) continue;
-                        uint32_t X;
-                        if (colref[q] != NONE) X = col_last(colref[q]) + 1;
-                        else {                                                // unaligned new node: the next existing column on the path
-                            uint32_t q2 = q + 1;
-                            while (q2 < L && path[q2] >= V_old && colref[q2] == NONE) q2++;
-                            X = q2 < L ? col_first(path[q2] < V_old ? path[q2] : colref[q2]) : V_old;
-                        }
-                        xq[q] = X;
-                        atomicAdd(&ins[X], 1u);
-                        atomicMin(&firstidx[X], n - V_old);
-                    }
-                }
-                __syncthreads();
-                uint32_t ibase = 0;
-                for (uint32_t base = 0; base <= V_old; base += NT) {      // (lane = old rank, NT at a time: one scan per block with a running base)
-                    const uint32_t r = base + tid;
-                    const uint32_t c = r <= V_old ? ins[r] : 0u;
-                    uint32_t tot;
-                    const uint32_t ex = ibase + block_excl_scan_add(c, lds_u, &tot);
-                    if (r <= V_old) {
-                        ins[r] = ex;                                        // new nodes with X == r start at r + ex
-                        if (r < V_old) tmp_u32[r + ex + c] = g.rank2node[r];    // the old node itself moves behind them
-                    }
-                    ibase += tot;
-                }
-                __syncthreads();
-                for (uint32_t q = tid; q < L; q += NT) {   // nodes with the same insertion point keep path order
-                    const uint32_t n = path[q];
-                    if (n < V_old) continue;
-                    const uint32_t X = xq[q];
-                    tmp_u32[X + ins[X] + (n - V_old - firstidx[X])] = n;
-                }
-                __syncthreads();
-                for (uint32_t r = tid; r < V2; r += NT) g.rank2node[r] = tmp_u32[r];
-            }
-        }
+        order_update(g, V_old, sV, L, lds_u);
         PHASE(4);
         __syncthreads();
         // =================================================== rank-order CSR for the next DP (all lanes): csr_rebuild above
