@@ -829,6 +829,8 @@ struct PoaCall {
         if (pass_on) {
             // cycles per DP row at 2.4 GHz: the DP with 1 .. 4 windows (then per further window), everything else of the chain
             static const uint32_t kLanes[5] = {64, 128, 256, 512, 1024};
+            // (the first dump's figures, 3 200 waves resident: they rank the widths as the final build's do - whose own table, taken where the long chains had been
+            // given the wide workgroups, puts 128 lanes above 64 and moved the choices to 256 lanes: 0.58-0.68 s against 0.55 s - and overestimate its chains by a third)
             static const double kDp[5][4] = {{1470, 2900, 3800, 4435}, {1862, 2685, 3273, 3797}, {1741, 2430, 2900, 3150}, {1900, 2000, 2300, 2600}, {1850, 2000, 2200, 2400}};
             static const double kDpMore[5] = {500, 450, 250, 250, 200}, kRest[5] = {3300, 1900, 1000, 930, 900};
             struct Opt { double ms[5]; uint32_t np[5]; int first, last; };
@@ -857,12 +859,14 @@ struct PoaCall {
             auto pick = [&](const Opt& q, double cap) { int k = q.first; while (k < q.last && (q.np[k] == 0 || q.ms[k] > cap)) k++; while (q.np[k] == 0) k--; return k; };
             double cap = o.poa_chain_ms > 0 ? (double)o.poa_chain_ms : 0;
             if (cap == 0) {
-                double best = 1e300;
-                for (double cq = 100; cq <= 3200; cq *= 1.1892) {   // (a quarter octave apart)
-                    double slot = fixed_slot_ms, longest = 0;
-                    for (const Opt& q : opts) { const int k = pick(q, cq); slot += q.ms[k] * (kLanes[k] / 64); longest = std::max(longest, q.ms[k]); }
-                    const double est = std::max(1.5 * std::max(longest, cq), slot / 3800.0);   // (3 800: the waves resident on average of the 4 096 a chip of 16-wave CUs holds; 1.5: the model's error on one chain, and a chain that starts late)
-                    if (est < best) { best = est; cap = cq; }
+                // the smallest cap that is at least 0.55 of what the call then takes - its wave-slot time over the ~3 800 waves resident. (Measured on the 140 Mb
+                // data, 13 197 edges: caps of 220 / 300 / 350 / 400 ms -> 0.78 / 0.74 / 0.71 / 0.80 s before the graph phases were rebuilt, 300 -> 0.55 s
+                // after; below the balance the wide workgroups cost slots, above it the call waits for its last chains.)
+                cap = 3200;
+                for (double cq = 100; cq <= 3200; cq *= 1.0905) {   // (an eighth of an octave apart)
+                    double slot = fixed_slot_ms;
+                    for (const Opt& q : opts) { const int k = pick(q, cq); slot += q.ms[k] * (kLanes[k] / 64); }
+                    if (cq >= 0.55 * slot / 3800.0) { cap = cq; break; }
                 }
             }
             size_t hist[5] = {};
