@@ -139,29 +139,28 @@ __device__ void toposort(G& g, uint32_t V, uint32_t* out) {
 
 
 constexpr uint32_t SINK_CAP = 1024;      // sink rows whose end score is kept per alignment (more: error)
-constexpr uint32_t TOPO_LCAP = 1024;     // stack window entries
-constexpr uint32_t TOPO_LINES = 64;      // cache lines of 16 records (16 KiB)
 // spoa's traversal (toposort above) by one whole wavefront in lock step - every lane computes the same scalars, the idle ones fetch records cooperatively
 // through a direct-mapped LDS cache of 16-record lines; the mark / check bits of every node sit in one LDS byte, the top of the DFS stack in an LDS window
 // that spills to the HBM stack - on RANKS of the order the DP maintains (any valid topological order with contiguous columns): predecessors have
 // smaller, nearby ranks, so the 16-rank record lines (row_meta, first two predecessor ranks, aligned-rank deltas) hit the LDS cache
 // almost always — node ids are visited in a scattered order, ranks are not. Roots are still taken in node-id order (that is what
 // fixes the reference's result); out[] receives ranks, the caller maps them back to node ids.
-__device__ void toposort_rank(G& g, const uint32_t V, uint8_t* st /* by rank */, uint32_t* lstack, uint4* cache, uint32_t* tags, uint32_t* out) {
+__device__ void toposort_rank(G& g, const uint32_t V, uint8_t* st /* by rank; LDS, or global memory when the graph is larger than the LDS left */, uint32_t* lstack, uint4* cache, uint32_t* tags, uint32_t* out,
+                              const uint32_t LCAP /* entries of the stack window */, const uint32_t LINES /* lines of the record cache: powers of two both */) {
     const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t i = lane; i < TOPO_LINES; i += 64) tags[i] = NONE;
+    for (uint32_t i = lane; i < LINES; i += 64) tags[i] = NONE;
     uint32_t sp = 0, nr = 0, base = 0;
     uint32_t rootV = 0;
     for (uint32_t i = 0; i < V; i++) {
         if ((i & 63u) == 0) rootV = i + lane < V ? g.node2rank[i + lane] : 0;
         const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)rootV, (int)(i & 63u));
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)st[r0]) & 3u) continue;
-        if (lane == 0) lstack[sp & (TOPO_LCAP - 1)] = r0;
+        if (lane == 0) lstack[sp & (LCAP - 1)] = r0;
         sp++;
         while (sp) {
-            if (sp == base) { base--; if (lane == 0) lstack[base & (TOPO_LCAP - 1)] = g.stack[base]; }
-            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)lstack[(sp - 1) & (TOPO_LCAP - 1)]);
-            const uint32_t line = n >> 4, slot = line & (TOPO_LINES - 1);
+            if (sp == base) { base--; if (lane == 0) lstack[base & (LCAP - 1)] = g.stack[base]; }
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)lstack[(sp - 1) & (LCAP - 1)]);
+            const uint32_t line = n >> 4, slot = line & (LINES - 1);
             const uint32_t tg = (uint32_t)__builtin_amdgcn_readfirstlane((int)tags[slot]);
             const uint32_t sn = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[n]);
             if ((sn & 3u) == 2u) { sp--; continue; }     // pushed more than once, finished meanwhile
@@ -183,8 +182,8 @@ __device__ void toposort_rank(G& g, const uint32_t V, uint8_t* st /* by rank */,
                 for (uint32_t p = 0; p < npred; p++) {
                     const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[po + p]) & 0x0fffffffu;
                     if (((uint32_t)__builtin_amdgcn_readfirstlane((int)st[f]) & 3u) != 2u) {
-                        if (sp - base == TOPO_LCAP) { if (lane == 0) g.stack[base] = lstack[base & (TOPO_LCAP - 1)]; base++; }
-                        if (lane == 0) lstack[sp & (TOPO_LCAP - 1)] = f;
+                        if (sp - base == LCAP) { if (lane == 0) g.stack[base] = lstack[base & (LCAP - 1)]; base++; }
+                        if (lane == 0) lstack[sp & (LCAP - 1)] = f;
                         sp++;
                     }
                 }
@@ -198,10 +197,10 @@ __device__ void toposort_rank(G& g, const uint32_t V, uint8_t* st /* by rank */,
             const unsigned long long tm = again ? 0ull : __ballot(todo);
             const uint32_t npush = (uint32_t)__popcll(tm);
             if (npush) {
-                while (sp + npush - base > TOPO_LCAP) { if (lane == 0) g.stack[base] = lstack[base & (TOPO_LCAP - 1)]; base++; }   // make room in the LDS window
+                while (sp + npush - base > LCAP) { if (lane == 0) g.stack[base] = lstack[base & (LCAP - 1)]; base++; }   // make room in the LDS window
                 if (todo) {
                     const uint32_t pos = sp + (uint32_t)__popcll(tm & ((1ull << lane) - 1));
-                    lstack[pos & (TOPO_LCAP - 1)] = cand;
+                    lstack[pos & (LCAP - 1)] = cand;
                     if (lane >= 2) st[cand] &= (uint8_t)~4u;   // an aligned node reached from its column does not check the column again
                 }
                 sp += npush;
@@ -1665,27 +1664,38 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     // The reference's topological order (spoa's DFS, inherently serial) is needed in two places only: to break ties between equally scored
     // end nodes of an alignment, and for the heaviest-bundle traversal of the finished graph. The DP itself runs on a cheaper order that
     // is maintained incrementally (see "order update" below): row values do not depend on which valid topological order is used.
-    const uint32_t topo_fixed = TOPO_LCAP * 4 + TOPO_LINES * 256 + TOPO_LINES * 4;
+    // Geometry of the wave's DFS (toposort_rank) in the LDS the ring leaves: a stack window and a cache of 16-record lines, as large as the launch's LDS allows (a
+    // many-edge call gives a one-wave workgroup 8.3 KB), then the state bytes of the ranks - in LDS when they fit, else in global memory (one more round trip per
+    // visit: still three to four times fewer than the one-lane walk over the node lists, which only a launch with less than 3 KB of LDS falls back to. Round 5: 12 %
+    // of the edges of a 13 000-edge call need the reference's order for their consensus, and with the full geometry only - 21 KB + a byte per node - they almost
+    // all took the one-lane walk: up to 370 M cycles at the end of the longest chains, 6 % of the call's wave cycles).
+    const uint32_t topo_lcap = lds_bytes >= 24 * 1024 ? 1024u : lds_bytes >= 8 * 1024 ? 256u : 128u;
+    const uint32_t topo_lines = lds_bytes >= 24 * 1024 ? 64u : lds_bytes >= 8 * 1024 ? 16u : 8u;
+    const uint32_t topo_fixed = topo_lcap * 4 + topo_lines * 256 + topo_lines * 4;
     uint32_t* t_stack = reinterpret_cast<uint32_t*>(ring);
-    uint4* t_cache = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(ring) + TOPO_LCAP * 4);
-    uint32_t* t_tags = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ring) + TOPO_LCAP * 4 + TOPO_LINES * 256);
+    uint4* t_cache = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(ring) + topo_lcap * 4);
+    uint32_t* t_tags = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ring) + topo_lcap * 4 + topo_lines * 256);
     uint8_t* st_lds = reinterpret_cast<uint8_t*>(ring) + topo_fixed;
     uint32_t* tmp_u32 = reinterpret_cast<uint32_t*>(g.pred);   // vcap+1 words of scratch (heaviest-bundle scratch, free until the end)
     auto exact_order = [&](uint32_t Vn, uint32_t* out) {   // all lanes; leaves spoa's rank->node order of the current graph in out[]
         // (needs the rank-ordered rows of the CURRENT graph: they are rebuilt after every sequence)
-        const bool in_lds = (uint64_t)Vn + topo_fixed + 16 <= lds_bytes;
-        if (in_lds) { for (uint32_t i = tid; i < Vn; i += NT) st_lds[i] = 4u; }                    // mark 0, check 1
+        const bool wave_dfs = topo_fixed + 16 <= lds_bytes;
+        const bool st_in_lds = wave_dfs && (uint64_t)Vn + topo_fixed + 16 <= lds_bytes;
+        uint8_t* st = st_in_lds ? st_lds : g.mark;
+        if (wave_dfs) { for (uint32_t i = tid; i < Vn; i += NT) st[i] = 4u; }                      // mark 0, check 1
         else { for (uint32_t i = tid; i < Vn; i += NT) { g.mark[i] = 0; g.check[i] = 1; } }
+        __threadfence_block();
         __syncthreads();
-        if (in_lds) {
+        if (wave_dfs) {
             uint32_t* ranks = reinterpret_cast<uint32_t*>(g.score);   // free between the CSR build and the graph update
 #if defined(HX_DP_PROF2) && !defined(HX_DP_PROF3)
             long long tq0 = clock64();
 #endif
-            if (tid < 64) toposort_rank(g, Vn, st_lds, t_stack, t_cache, t_tags, ranks);   // wave 0, 64 lanes in lock step
+            if (tid < 64) toposort_rank(g, Vn, st, t_stack, t_cache, t_tags, ranks, topo_lcap, topo_lines);   // wave 0, 64 lanes in lock step
 #if defined(HX_DP_PROF2) && !defined(HX_DP_PROF3)
             if (tid == 0) ph[11] += (unsigned long long)(clock64() - tq0);
 #endif
+            __threadfence_block();
             __syncthreads();
             for (uint32_t i = tid; i < Vn; i += NT) tmp_u32[i] = g.rank2node[ranks[i]];
             __syncthreads();
@@ -2121,12 +2131,15 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     }
     if (mem > 0) return;
     if (GM > 1 && tid == 0 && sOk != 1) st_dev(csy + 0, CL_ABORT);   // release the other members
+    long long t_cns = 0;
+    if (tid == 0) t_cns = clock64();
     if (sOk == 1 && sV) {
         // heaviest bundle: first on the maintained order (exact whenever the heaviest node is unique and a sink); else on the reference's
         // topological order of the finished graph
         if (tid < 64) { const uint32_t cl_ = consensus_fast_wave(g, sV, cns + ED.cns_off); if (tid == 0) sCtl = cl_; }
         __syncthreads();
         if (sCtl == NONE) {
+            if (tid == 0) ph[19] = 1;
             exact_order(sV, g.rank2node);
             for (uint32_t r = tid; r < sV; r += NT) g.node2rank[g.rank2node[r]] = r;
             __syncthreads();
@@ -2165,6 +2178,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
             if (phase) atomicAdd(&ph[11], (unsigned long long)sV << 32);   // statistics: nodes of the finished graph (high word)
 #endif
         }
+        ph[18] = (unsigned long long)(clock64() - t_cns);
         PHASE(3);
         ph[17] = wall_clock64() & ((1ull << 44) - 1);
 #ifdef HX_DP_PROF3

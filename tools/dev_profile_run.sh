@@ -10,7 +10,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 if [ "$WHAT" = all ] || [ "$WHAT" = tests ]; then
-  (cd $R && timeout 900 python -m pytest tests -m gpu -x -q --timeout 300 > $O/gpu_tests.log 2>&1; tail -5 $O/gpu_tests.log)
+  (cd $R && timeout 2400 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; tail -5 $O/gpu_tests.log)
 fi
 if [ "$WHAT" != fly ]; then
 timeout 1500 python $R/bench.py > $O/bench.json 2> $O/bench.log
