@@ -1460,8 +1460,8 @@ extern "C" uint32_t hx_poa_phase_cycles(hx_ctx* c, uint64_t* sum6, uint64_t* max
                 const unsigned long long* q2 = &c->poa_phase[e * PW_];
                 if (!q2[16]) continue;
                 const uint32_t sh = e < c->dbg_shape.size() ? c->dbg_shape[e] : 0;
-                fprintf(stderr, "[hx-edge] %zu lmax %u nseq %u cls %d lanes %u passes %u members %u hw %u begin_us %.1f end_us %.1f decode %llu dp %llu tb %llu graph %llu order %llu csr %llu rows %llu wrows %llu wskip %llu cns %llu refcns %llu\n", e, c->dbg_lmax[e], c->dbg_nseq[e],
-                        e < c->dbg_cls.size() ? c->dbg_cls[e] : 11, sh & 0xffffu, (sh >> 16) & 255u, sh >> 24, (unsigned)(q2[16] >> 44), (double)((q2[16] & M44) - t0) * 0.01, (double)(q2[17] - t0) * 0.01, q2[0], q2[1], q2[2], q2[3], q2[4], q2[5], q2[6], q2[12], q2[13], q2[18], q2[19]);
+                fprintf(stderr, "[hx-edge] %zu lmax %u nseq %u cls %d lanes %u passes %u members %u hw %u begin_us %.1f end_us %.1f decode %llu dp %llu tb %llu graph %llu order %llu csr %llu rows %llu wrows %llu wskip %llu wbulk %llu cns %llu refcns %llu\n", e, c->dbg_lmax[e], c->dbg_nseq[e],
+                        e < c->dbg_cls.size() ? c->dbg_cls[e] : 11, sh & 0xffffu, (sh >> 16) & 255u, sh >> 24, (unsigned)(q2[16] >> 44), (double)((q2[16] & M44) - t0) * 0.01, (double)(q2[17] - t0) * 0.01, q2[0], q2[1], q2[2], q2[3], q2[4], q2[5], q2[6], q2[12], q2[13], q2[20], q2[18], q2[19]);
             }
         }
         fprintf(stderr, "[hx] slowest edge %u: lmax=%u nseq=%u | DP rows %llu (multi-pred %llu, ring refs %llu, far refs %llu, kept %llu, more than 4 predecessors %llu, fifth-and-later entries %llu) over %llu sequences\n", c->dbg_slowest,

@@ -143,7 +143,7 @@ inline bool poa_persistent_ok(bool use_dir) { return use_dir; }   // launches th
 // launches of one workgroup per edge (a shared edge's members would have to repeat an attempt together)
 inline bool poa_prune_ok(bool use_dir, int cm) { return use_dir && cm <= 8; }
 constexpr int32_t PRUNE_OFF = -(1 << 24);   // a threshold no real cell is below (|scores| < 2^24: the host checks 8 (nodes + columns))
-constexpr int POA_PHASE_WORDS = 20;         // per edge: 6 phase cycle counters, 6 row statistics, 4 of the pruning (wave-rows, wave-rows skipped, attempts repeated, alignments with a threshold), the edge's begin and end on the 100 MHz wall clock, cycles of the final consensus and whether it took the reference's order
+constexpr int POA_PHASE_WORDS = 21;         // per edge: 6 phase cycle counters, 6 row statistics, 4 of the pruning (wave-rows, wave-rows skipped, attempts repeated, alignments with a threshold), the edge's begin and end on the 100 MHz wall clock, cycles of the final consensus and whether it took the reference's order, wave-rows skipped a batch at a time
 // One launch of a class. counter == nullptr: one workgroup per entry of `order` (edge | member << 24; shared edges, each in its own slot
 // PoaEdge::slot); else PERSISTENT: n_blocks workgroups, workgroup b owns slots[b]; the n_items edges of `order` come in nb buckets of workspace need
 // (largest first), bucket k = order[item_begin[k] .. item_begin[k + 1]) behind counter[k], its workgroups = the slots [slot_end[k - 1], slot_end[k]);

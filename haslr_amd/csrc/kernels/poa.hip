@@ -814,7 +814,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     // row 0, 15 a row read back from HBM (always set: a skipped row with a far reader stores "nothing" there, so it may be read). Predecessors
     // whose flag is clear are not read at all (their registers / ring slot hold an older row). T is the caller's: poa_edge checks S >= T
     // afterwards and repeats the alignment otherwise. (kernels.h: PRUNE_OFF; oracle.cpp prune_sim = this rule on the CPU, a statistic.)
-    int thr_lane = 0; uint32_t FM = 0xffffu, n_dead = 0, lazy = 0; int thr_cin = 0;
+    int thr_lane = 0; uint32_t FM = 0xffffu, n_dead = 0, n_bulk = 0, lazy = 0; int thr_cin = 0;
     if constexpr (PRUNE) {
         const int mg = match - gap, thr_base = thrT - match * (int)L;
         const int c0 = (int)(gw * 64u * CM);
@@ -928,7 +928,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                             if (out_l != 0u) st_wg64(mb_out_l + ((i0 + lane) & (WAVE_MBOX - 1)), ent);
                             if (out_h != 0u) st_dev64(mb_out_h + i0 + lane, ent);
                         }
-                        n_dead += nb;
+                        n_dead += nb; n_bulk += nb;
                         const unsigned long long dp_ = (((unsigned long long)dhi << 32) | dlo) + (unsigned long long)dstep_s * nb;
                         dlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dp_); dhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dp_ >> 32));
                         lazy = lazy_on;
@@ -1151,7 +1151,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
         }
     }
     if (owns_last) nSinkOut = nsink;
-    if constexpr (PRUNE) { if (lane == 0 && pstat) { atomicAdd(&pstat[0], (unsigned long long)V); atomicAdd(&pstat[1], (unsigned long long)n_dead); } }
+    if constexpr (PRUNE) { if (lane == 0 && pstat) { atomicAdd(&pstat[0], (unsigned long long)V); atomicAdd(&pstat[1], (unsigned long long)n_dead); atomicAdd(&pstat[8], (unsigned long long)n_bulk); } }
 }
 
 // =================================================== rank-order CSR for the next DP (all lanes)
@@ -1395,7 +1395,8 @@ __device__ __forceinline__ void csr_rebuild(const G& g_in, const uint32_t V2, co
     }
 
 // spoa Graph::add_alignment by all lanes (poa_edge: "graph update"); the views' pointers as scalars, like the CSR rebuild
-__device__ __forceinline__ void graph_update(const G& g_in, const uint8_t* seq_, const uint32_t L, const uint32_t na, uint32_t* lds_u, uint32_t* sV_, uint32_t* sE_, uint32_t* sNcand_, uint32_t* sOk_) {
+__device__ __forceinline__ void graph_update(const G& g_in, const uint8_t* seq_, const uint32_t L, const uint32_t na, const uint32_t nw /* leading entries in the traceback walk's (rank, column) form */,
+                                             const uint32_t w_ie, const uint32_t w_je /* where the walk stopped */, uint32_t* lds_u, uint32_t* sV_, uint32_t* sE_, uint32_t* sNcand_, uint32_t* sOk_) {
     G g = g_in;
     g.stack = uptr(g.stack); g.aln_pos = uptr(g.aln_pos); g.aln_node = uptr(g.aln_node); g.code = uptr(g.code); g.n_aligned = uptr(g.n_aligned); g.aligned = uptr(g.aligned);
     g.score = uptr(g.score); g.row_pred1 = uptr(g.row_pred1); g.nrec = uptr(g.nrec); g.nrec2 = uptr(g.nrec2); g.out_head = uptr(g.out_head); g.out_tail = uptr(g.out_tail);
@@ -1417,14 +1418,42 @@ __device__ __forceinline__ void graph_update(const G& g_in, const uint8_t* seq_,
         if (tid == 0) (*sNcand_) = 0;
         for (uint32_t p = tid; p < L; p += NT) anode[p] = -2;
         __syncthreads();
+        // the alignment scattered to the bases, four entries per lane and iteration (their loads together: an iteration is two round trips). Entry k of the walk
+        // = the cell it stood on before move k: the node of its row unless the move stayed in the row, its column unless the move stayed in the column.
         uint32_t nv = 0;
-        for (uint32_t k = tid; k < na; k += NT) { const int32_t pos = g.aln_pos[k]; if (pos != -1) { anode[pos] = g.aln_node[k]; nv++; } }
+        g.rank2node = uptr(g.rank2node);
+        for (uint32_t base = 0; base < na; base += 4 * NT) {
+            int32_t r[4], c[4], r2[4], c2[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t k = base + u * NT + tid, kc = k < na ? k : 0u, kn = k + 1 < nw ? k + 1 : kc;
+                r[u] = g.aln_node[kc]; c[u] = g.aln_pos[kc]; r2[u] = g.aln_node[kn]; c2[u] = g.aln_pos[kn];
+                if (k + 1 >= nw) { r2[u] = (int32_t)w_ie; c2[u] = (int32_t)w_je; }
+            }
+            int32_t nd[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) { const uint32_t k = base + u * NT + tid; nd[u] = (int32_t)g.rank2node[k < nw && r[u] != r2[u] ? (uint32_t)(r[u] - 1) : 0u]; }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t k = base + u * NT + tid;
+                if (k >= na) continue;
+                int32_t node = r[u], pos = c[u];
+                if (k < nw) { node = r[u] == r2[u] ? -1 : nd[u]; pos = c[u] == c2[u] ? -1 : c[u] - 1; }
+                if (pos != -1) { anode[pos] = node; nv++; }
+            }
+        }
         if (nv) atomicAdd(&(*sNcand_), nv);
         __syncthreads();
         const bool chain = na == 0;                 // empty graph: the sequence becomes a chain
         const bool par = chain || (*sNcand_) == L;      // always true for a global alignment
         if (!par) {                                 // (kept for safety: the serial walk handles any alignment shape)
-            if (tid == 0) { uint32_t V2 = V0, E2 = E0; if (!add_alignment(g, V2, E2, na, seq, L, path, colref)) (*sOk_) = 0; else { (*sV_) = V2; (*sE_) = E2; } }
+            if (tid == 0) {
+                for (uint32_t k = 0; k < nw; k++) {   // the walk's entries into the alignment's form, in place (entry k + 1 is read before it is rewritten)
+                    const int32_t r = g.aln_node[k], c = g.aln_pos[k], r2 = k + 1 < nw ? g.aln_node[k + 1] : (int32_t)w_ie, c2 = k + 1 < nw ? g.aln_pos[k + 1] : (int32_t)w_je;
+                    g.aln_node[k] = r == r2 ? -1 : (int32_t)g.rank2node[r - 1]; g.aln_pos[k] = c == c2 ? -1 : c - 1;
+                }
+                uint32_t V2 = V0, E2 = E0; if (!add_alignment(g, V2, E2, na, seq, L, path, colref)) (*sOk_) = 0; else { (*sV_) = V2; (*sE_) = E2; }
+            }
         } else {
             // (round 5: lane = base. Bases are taken NT at a time - coalesced accesses by position, one scan per block with a running base for the ids -
             // where round 1 dealt them out in contiguous chunks per thread: every load of a wave then touched 64 different cache lines)
@@ -1638,7 +1667,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     constexpr uint32_t SINK_LDS = MAXNT <= 256 ? 128 : MAXNT < 1024 ? 256 : SINK_CAP;
     __shared__ WaveMailT<MAXNT / 64> wmail;
     __shared__ uint32_t lds_u[16];
-    __shared__ uint32_t sV, sE, sNaln, sOk, sNsink, sNcand, sBestKey;
+    __shared__ uint32_t sV, sE, sNaln, sOk, sNsink, sNcand, sBestKey, sWalkN, sWalkI, sWalkJ;   // (sWalk*: entries of the traceback walk still in (rank, column) form, and where the walk stopped)
     __shared__ int sBestI;
     __shared__ uint32_t sink_row[SINK_LDS];
     __shared__ int sink_score[SINK_LDS];
@@ -2055,16 +2084,9 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                     asm volatile("" :: "v"(sink));
                 }
                 __syncthreads();
-                {   // entry k of the walk: the node of its row unless the move stayed in the row, its column unless the move stayed in the column
-                    const uint32_t nw = lds_u[0], ie = lds_u[1], je = lds_u[2];
-                    for (uint32_t base = 0; base < nw; base += NT) {
-                        const uint32_t k = base + tid;
-                        int32_t r = 0, c = 0, r2 = 0, c2 = 0;
-                        if (k < nw) { r = g.aln_node[k]; c = g.aln_pos[k]; if (k + 1 < nw) { r2 = g.aln_node[k + 1]; c2 = g.aln_pos[k + 1]; } else { r2 = (int32_t)ie; c2 = (int32_t)je; } }
-                        __syncthreads();   // (entry k + 1 is another thread's to rewrite)
-                        if (k < nw) { g.aln_node[k] = r == r2 ? -1 : (int32_t)g.rank2node[r - 1]; g.aln_pos[k] = c == c2 ? -1 : c - 1; }
-                    }
-                }
+                // (the walk's entries - the cell it stood on before every move - become alignment entries in graph_update: "the node of its row unless the move
+                // stayed in the row, its column unless the move stayed in the column" is read off neighbouring entries there, on the way to the bases)
+                if (tid == 0) { sWalkN = lds_u[0]; sWalkI = lds_u[1]; sWalkJ = lds_u[2]; }
                 __syncthreads();
             } else if (tid == 0) {
                 sCells += (unsigned long long)V * L;
@@ -2096,10 +2118,10 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                     na++;
                     i = pi_; j = pj_;
                 }
-                sNaln = na;
+                sNaln = na; sWalkN = 0;
             }
         } else {
-            if (tid == 0) sNaln = 0;
+            if (tid == 0) { sNaln = 0; sWalkN = 0; }
             if (GM > 1) {   // nothing to align against yet: the other members only count the sequence (and must have read V = 0 before it changes)
                 __syncthreads();
                 if (tid == 0) {
@@ -2117,7 +2139,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
         PHASE(2);
         // =================================================== graph update + order update (all lanes): graph_update / order_update above
         const uint32_t V_old = sV;
-        graph_update(g, seq, L, sNaln, lds_u, &sV, &sE, &sNcand, &sOk);
+        graph_update(g, seq, L, sNaln, sWalkN, sWalkI, sWalkJ, lds_u, &sV, &sE, &sNcand, &sOk);
         PHASE(3);
         __syncthreads();
         if (sOk != 1) break;
@@ -2143,23 +2165,11 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
             exact_order(sV, g.rank2node);
             for (uint32_t r = tid; r < sV; r += NT) g.node2rank[g.rank2node[r]] = r;
             __syncthreads();
-            {   // bundle_rows: the rank-ordered in-edge rows (predecessor ranks, weights, letter, sink flag) of THIS order, all lanes
-                const uint32_t V2 = sV, CH = (V2 + NT - 1) / NT, r0 = min(tid * CH, V2), r1 = min(r0 + CH, V2);
-                uint32_t cnt = 0;
-                for (uint32_t r = r0; r < r1; r++) for (uint32_t e = g.in_head[g.rank2node[r]]; e != NONE; e = g.e_next_in[e]) cnt++;
-                uint32_t tot;
-                uint32_t off = block_excl_scan_add(cnt, lds_u, &tot);
-                for (uint32_t r = r0; r < r1; r++) {
-                    const uint32_t n = g.rank2node[r];
-                    g.row_pred_off[r] = off;
-                    uint32_t np = 0;
-                    for (uint32_t e = g.in_head[n]; e != NONE; e = g.e_next_in[e]) { g.pred_rank[off] = g.node2rank[g.e_from[e]]; g.pred_w[off] = g.e_w[e]; off++; np++; }
-                    g.row_meta[r] = (uint32_t)g.code[n] | (g.out_head[n] == NONE ? 4u : 0u) | (np << META_NP);
-                }
-                if (tid == NT - 1) g.row_pred_off[V2] = tot;
-                __threadfence_block();
-                __syncthreads();
-            }
+            // the rank-ordered in-edge rows (predecessor ranks, weights, letter, sink flag) of THIS order: the CSR rebuild again (its ring slots and far / wide rows
+            // mean nothing here and must not fail the edge: no limits)
+            csr_rebuild<MAXNT, DIR>(g, sV, R, 0xffffffffu, 0xffffffffu, 0xffffffffu, lds_u, &sOk, ph, false, eidx, false, false);
+            __threadfence_block();
+            __syncthreads();
             if (tid < 64) { const uint32_t cl_ = consensus_wave(g, sV, cns + ED.cns_off); if (tid == 0) sCtl = cl_; }
             __syncthreads();
         }

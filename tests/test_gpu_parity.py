@@ -398,7 +398,12 @@ def test_in_degree_retry_with_score_matrix(sim, ctx):
                                             ("-1", {"HX_POA_PRUNE": "95", "HX_POA_WAVE_MAX": "64", "HX_POA_PASS_LANES": "64", "HX_POA_CLUSTER_MIN": "100000"}),
                                             ("1", {"HX_POA_PRUNE": "95", "HX_POA_WAVE_MAX": "64", "HX_POA_PASS_LANES": "128", "HX_POA_CLUSTER_MIN": "100000", "HX_POA_COLS": "8", "HX_POA_SLOTS": "2"}),
                                             ("0", {"HX_POA_PRUNE": "1", "HX_POA_WAVE_MAX": "64", "HX_POA_PASS_LANES": "64", "HX_POA_CLUSTER_MIN": "100000", "HX_POA_PRUNE_LAZY": "0"}),
-                                            ("2", {"HX_POA_PRUNE": "108", "HX_POA_WAVE_MAX": "128", "HX_POA_PASS_LANES": "128", "HX_POA_SLOTS": "3", "HX_POA_RING_KB": "1"})])
+                                            ("2", {"HX_POA_PRUNE": "108", "HX_POA_WAVE_MAX": "128", "HX_POA_PASS_LANES": "128", "HX_POA_SLOTS": "3", "HX_POA_RING_KB": "1"}),
+                                            # ... with the workgroup width chosen by the edge's estimated chain time (the default of a pruned call; caps that a small data set
+                                            # reaches, so that every width from 64 lanes up gets edges), the need buckets of an instance in one launch, few slots per bucket
+                                            ("-1", {"HX_POA_PRUNE": "95", "HX_POA_WAVE_MAX": "64", "HX_POA_CHAIN_MS": "1", "HX_POA_CLUSTER_MIN": "100000"}),
+                                            ("1", {"HX_POA_PRUNE": "95", "HX_POA_WAVE_MAX": "64", "HX_POA_CHAIN_MS": "4", "HX_POA_CLUSTER_MIN": "100000", "HX_POA_SLOTS": "2"}),
+                                            ("-1", {"HX_POA_PRUNE": "100", "HX_POA_WAVE_MAX": "128", "HX_POA_CHAIN_MS": "20", "HX_POA_SLOTS": "3", "HX_POA_RING_KB": "1"})])
 def test_far_row_estimate_overflow_is_retried(sim, ctx, far_rows, shape):
     """with direction bytes H keeps only the rows that a successor reads after they left the LDS ring, in as many rows as the host
     estimated; an edge that needs more comes back and is redone with room for every row. Forced here by an estimate of 0..2 rows

@@ -15,7 +15,7 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = hip.HipContext(0)
 os.makedirs('/tmp/fz', exist_ok=True)
 bad = 0
-KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS', 'HX_POA_BATCHES', 'HX_POA_NODE_EST_PCT', 'HX_POA_RING_KB', 'HX_POA_COLS', 'HX_POA_CLUSTER_TOPK', 'HX_POA_SLOTS', 'HX_POA_WORKSPACE_GB', 'HX_POA_FORCE_CM', 'HX_POA_RING_ZERO', 'HX_POA_WIDE_MEMBERS', 'HX_POA_PRUNE', 'HX_POA_PRUNE_LANES', 'HX_POA_PASS_LANES', 'HX_POA_PRUNE_LAZY')
+KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS', 'HX_POA_BATCHES', 'HX_POA_NODE_EST_PCT', 'HX_POA_RING_KB', 'HX_POA_COLS', 'HX_POA_CLUSTER_TOPK', 'HX_POA_SLOTS', 'HX_POA_WORKSPACE_GB', 'HX_POA_FORCE_CM', 'HX_POA_RING_ZERO', 'HX_POA_WIDE_MEMBERS', 'HX_POA_PRUNE', 'HX_POA_PRUNE_LANES', 'HX_POA_PASS_LANES', 'HX_POA_PRUNE_LAZY', 'HX_POA_CHAIN_MS')
 for it in range(n):
     big = os.environ.get('FUZZ_BIG') is not None   # long gaps at real sizes: the default launch shapes (512-lane cluster members) get real work
     glen = rng.choice([400000, 700000, 1000000]) if big else rng.choice([40000, 60000, 90000, 150000, 250000])
@@ -59,7 +59,9 @@ for it in range(n):
     if rng.random() < 0.6:
         env['HX_POA_PRUNE'] = str(rng.choice([80, 95, 95, 100, 104, 115]))   # exact score-bound pruning (round 5): thresholds below / at / above the previous alignment's score per base (above: repeats)
         env['HX_POA_PRUNE_LANES'] = str(rng.choice([64, 128, 128, 256]))
-        env['HX_POA_PASS_LANES'] = str(rng.choice([0, 64, 64, 128, 256]))     # column passes: the columns of a sequence window by window in a narrow workgroup
+        env['HX_POA_PASS_LANES'] = str(rng.choice([0, 64, 64, 128, 256, -1, -1, -1]))     # column passes: the columns of a sequence window by window in a narrow workgroup (-1: width by estimated chain time)
+        if env['HX_POA_PASS_LANES'] == '-1':
+            env['HX_POA_CHAIN_MS'] = str(rng.choice([-1, 1, 3, 10, 40]))      # ... under a cap that small data sets reach: every width from 64 to 1024 lanes gets edges
         env['HX_POA_PRUNE_LAZY'] = str(rng.choice([0, 1, 1]))
         if 'HX_POA_WAVE_MAX' not in env and rng.random() < 0.7:
             env['HX_POA_WAVE_MAX'] = str(rng.choice([64, 128, 256]))          # several waves per workgroup on the short gaps of a small data set
