@@ -127,6 +127,7 @@ struct HxOptions {
     int poa_prune = -1;            // exact score-bound pruning of the DP: -1 automatic (calls of thousands of edges), 0 never, else the threshold's percentage of the previous alignment's score per base
     int poa_pass_lanes = -1;       // column passes: unshared multi-wave edges run in workgroups of this many lanes, their DP columns in windows taken one after the other (-1 automatic: by
                                    // estimated chain length, where the rows are pruned; 0 never)
+    int poa_big_first = 1;         // few-edge calls: the unshared classes of 512 lanes and more leave before the shared edges' 256-lane members (0: behind them, as before round 5)
     int poa_chain_ms = -1;         // ... the automatic choice: the narrowest workgroup whose estimated chain (size_edges: DP rows x what a row costs at that width and number of
                                    // windows) stays below this many milliseconds; -1: the cap that balances the longest chain against the call's wave-slot time
     int poa_prune_lazy = 1;        // ... a wave that skipped a whole batch of rows polls for the next one rarely (0: like any wave)
@@ -144,7 +145,7 @@ const OptDesc kOptions[] = {
     {"poa_balance_pct", &HxOptions::poa_balance_pct, nullptr}, {"poa_balance_lanes", &HxOptions::poa_balance_lanes, nullptr}, {"poa_slots_pct", &HxOptions::poa_slots_pct, nullptr},
     {"poa_slots", &HxOptions::poa_slots, nullptr}, {"poa_batches", &HxOptions::poa_batches, nullptr}, {"poa_force_cm", &HxOptions::poa_force_cm, nullptr},
     {"poa_no_xcd_map", &HxOptions::poa_no_xcd_map, nullptr}, {"poa_streams", &HxOptions::poa_streams, nullptr}, {"poa_wide_delay_us", &HxOptions::poa_wide_delay_us, nullptr},
-    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"poa_chain_ms", &HxOptions::poa_chain_ms, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
+    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"poa_chain_ms", &HxOptions::poa_chain_ms, nullptr}, {"poa_big_first", &HxOptions::poa_big_first, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
 };
 }  // namespace
 
@@ -972,9 +973,16 @@ struct PoaCall {
             cls_of(false, nt, cmq, !full_h[e], 0, pb, pass_on && !full_h[e] && cmq > 4).edges.push_back(e);   // (pk: with column passes every 8-column launch is the pruned instance - one launch per width)
         }
         // order of the launches: shared edges first (they set the duration), then by lanes; score-matrix launches after their direction-byte twins
-        const bool bal = balanced;
-        std::stable_sort(classes.begin(), classes.end(), [bal](const Cls& a, const Cls& b) {
+        const bool bal = balanced, bigf = !many_edges && o.poa_big_first != 0;
+        std::stable_sort(classes.begin(), classes.end(), [bal, bigf](const Cls& a, const Cls& b) {
             if (a.dir != b.dir) return a.dir;
+            // (few-edge calls: the 900 member workgroups of the shared edges used to go out first and fill every CU's LDS; the 512-lane workgroups of the unshared
+            // edges - chains of up to 100 ms of a 163 ms call - then began when two members on some CU had ended, 65-85 ms into the call, and most passes
+            // took 182 ms instead of 163: tools/dev_r05_ab.py, 12 Mb, five passes each way)
+            if (bigf) {   // wide members, then the large unshared workgroups, then the 256-lane members, then the rest
+                auto grp = [](const Cls& q) { return q.shared && q.nt >= 1024 ? 0 : !q.shared && q.nt >= 512 ? 1 : q.shared ? 2 : 3; };
+                if (grp(a) != grp(b)) return grp(a) < grp(b);
+            }
             // (balanced launch: the 1024-lane workgroups - a whole CU each - go out before anything else sits anywhere; they share no SIMD with
             // the shared edges' members, which stay the oldest waves wherever they land)
             if (bal && (a.nt >= 1024 && !a.shared) != (b.nt >= 1024 && !b.shared)) return a.nt >= 1024 && !a.shared;
