@@ -860,14 +860,16 @@ struct PoaCall {
             auto pick = [&](const Opt& q, double cap) { int k = q.first; while (k < q.last && (q.np[k] == 0 || q.ms[k] > cap)) k++; while (q.np[k] == 0) k--; return k; };
             double cap = o.poa_chain_ms > 0 ? (double)o.poa_chain_ms : 0;
             if (cap == 0) {
-                // the smallest cap that is at least 0.55 of what the call then takes - its wave-slot time over the ~3 800 waves resident. (Measured on the 140 Mb
+                // the smallest cap that is at least 0.65 of what the call then takes - its wave-slot time over the ~3 800 waves resident. (0.55 until the dead rows of
+                // a window left in runs: the chains of the narrow workgroups - many windows, most of them dead - got shorter than this table says, and the sweep
+                // moved: caps of 283 (= 0.55) / 310 / 330 / 360 / 400 / 450 ms -> 0.543-0.564 / 0.517-0.565 / 0.530-0.536 / 0.542-0.568 / 0.577 / 0.612 s. Before: measured on the 140 Mb
                 // data, 13 197 edges: caps of 220 / 300 / 350 / 400 ms -> 0.78 / 0.74 / 0.71 / 0.80 s before the graph phases were rebuilt, 300 -> 0.55 s
                 // after; below the balance the wide workgroups cost slots, above it the call waits for its last chains.)
                 cap = 3200;
                 for (double cq = 100; cq <= 3200; cq *= 1.0905) {   // (an eighth of an octave apart)
                     double slot = fixed_slot_ms;
                     for (const Opt& q : opts) { const int k = pick(q, cq); slot += q.ms[k] * (kLanes[k] / 64); }
-                    if (cq >= 0.55 * slot / 3800.0) { cap = cq; break; }
+                    if (cq >= 0.65 * slot / 3800.0) { cap = cq; break; }
                 }
             }
             size_t hist[5] = {};

@@ -586,6 +586,12 @@ __device__ __forceinline__ int wave_incl_max_fill(int v, uint32_t i, uint32_t ta
     dlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)dlo); dhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)dhi);
     return x;
 }
+// 1 if a >= b, else 0, both wave-uniform: a scalar compare and select
+__device__ __forceinline__ uint32_t s_ge_i32(int a, int b) {
+    uint32_t r;
+    asm("s_cmp_ge_i32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(a), "s"(b) : "scc");
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+}
 // byte 0 of four registers -> one dword
 __device__ __forceinline__ uint32_t pack_b0(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     const uint32_t ab = __builtin_amdgcn_perm(b, a, 0x0c0c0400u), cd = __builtin_amdgcn_perm(d, c, 0x0c0c0400u);
@@ -642,7 +648,13 @@ template <int CM> __device__ __forceinline__ void store_nibbles_buf(__amdgpu_buf
         uint32_t w[CM / 8];
 #pragma unroll
         for (int q = 0; q < CM / 8; q++) w[q] = pack_b0(b[4 * q], b[4 * q + 1], b[4 * q + 2], b[4 * q + 3]);
-        if constexpr (CM == 8) __builtin_amdgcn_raw_buffer_store_b32(w[0], r, (int)off, 0, 0);
+        // (8 columns per lane = the instances of the many-edge regime: the nibble rows leave as NON-TEMPORAL stores. A 13 000-edge call writes 0.45 TB of them, of
+        // which the traceback reads back one byte in a few thousand; streamed past the L2 they leave it to the graph arrays and the far rows, whose round trips
+        // are what the serial phases are made of - wave cycles of all workgroups of the 140 Mb call: -2.8 %. aux 2 = nt on gfx940/gfx950.)
+#ifndef HX_NIB_AUX
+#define HX_NIB_AUX 2
+#endif
+        if constexpr (CM == 8) __builtin_amdgcn_raw_buffer_store_b32(w[0], r, (int)off, 0, HX_NIB_AUX);
         else if constexpr (CM == 16) { typedef uint32_t u32x2 __attribute__((ext_vector_type(2))); __builtin_amdgcn_raw_buffer_store_b64((u32x2){w[0], w[1]}, r, (int)off, 0, 0); }
         else { typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[0], w[1], w[2], w[3]}, r, (int)off, 0, 0); }
     }
@@ -666,7 +678,8 @@ template <int CM, bool DIR, bool PRUNE>
 __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, uint8_t* __restrict__ Dwide, const uint32_t W, const uint32_t WH, const uint8_t* __restrict__ seq,
                         const uint32_t L_, const uint32_t V_, int32_t* ring, const uint32_t R_, const uint32_t ring_w_, const int match, const int mismatch, const int gap,
                         unsigned long long* wm_box, uint32_t* wm_cons, uint32_t* sink_row, int* sink_score, const uint32_t sink_cap, uint32_t& nSinkOut, const DpCl& cl, unsigned long long* prof,
-                        const int thrT /* PRUNE: score threshold T of this alignment (PRUNE_OFF: nothing real is below it) */, const uint32_t lazy_on /* PRUNE: skipped waves poll rarely */, unsigned long long* pstat /* PRUNE: wave-rows, wave-rows skipped */) {
+                        const int thrT /* PRUNE: score threshold T of this alignment (PRUNE_OFF: nothing real is below it) */, const uint32_t lazy_on /* PRUNE: skipped waves poll rarely */, unsigned long long* pstat /* PRUNE: wave-rows, wave-rows skipped */,
+                        const uint32_t far_n /* PRUNE: rows of H (far-read rows) of the edge */) {
     static_assert(!PRUNE || DIR, "pruned rows: direction-byte flavour only");
 #if defined(HX_DP_PROF) && !defined(HX_DP_PROF2)
     long long tprev = clock64();
@@ -823,6 +836,15 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
         const uint32_t f0 = (uint32_t)(match * (int)L - mg * max(c0 - 1, 0) >= thrT);
         FM = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0x8000u | (f0 << 14)));   // nothing in the ring, no previous row yet
     }
+    // PRUNE: the flags of the rows kept in HBM ("far" rows, code 15), one bit per row of H in ONE register of the wave (lane = slot / 32: 2 048 slots; an edge with
+    // more has every bit set for good - its far rows are read as they always were). A far row whose flag is clear is not fetched: its reader takes "nothing",
+    // like the readers of an unflagged ring row do - in a dead region of the matrix that was an HBM round trip (~2 us under load) on the path of a row that came
+    // out dead anyway, one row in forty.
+    const bool far_bits = PRUNE && far_n <= 2048u;
+    uint32_t farbits = far_bits ? 0u : 0xffffffffu;
+    auto far_set = [&](const uint32_t slot, const uint32_t fl) {   // (slot, fl: wave-uniform)
+        if (far_bits && lane == ((slot >> 5) & 63u)) farbits = (farbits & ~(1u << (slot & 31u))) | (fl << (slot & 31u));
+    };
     auto pred_row = [&](const uint32_t ent, int (&hp)[CM], int& left, const bool slot_known) {
         const uint32_t loc = ent >> 28;
         if (__builtin_expect(loc == 13u, 1)) {   // the previous row: registers (the likely case falls through: a taken scalar branch costs a lone wave ~35 cycles)
@@ -843,6 +865,15 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             // - columns beyond the sequence, last wave only - read the row's first chunk instead: their keys reach no real column)
             // with direction bytes only the rows a far successor reads are in HBM, in the slots the CSR build gave them
             const uint32_t hr = DIR ? (slot_known ? ent & 0x0fffffffu : farslot[ent & 0x0fffffffu]) : (ent & 0x0fffffffu) + 1;
+            if constexpr (PRUNE) {
+                const uint32_t hs = (uint32_t)__builtin_amdgcn_readfirstlane((int)hr);
+                if ((((uint32_t)__builtin_amdgcn_readlane((int)farbits, (int)((hs >> 5) & 63u)) >> (hs & 31u)) & 1u) == 0u) {   // an unflagged far row: not read
+#pragma unroll
+                    for (int k = 0; k < CM; k++) hp[k] = NEGK;
+                    left = NEGK;
+                    return;
+                }
+            }
             const int32_t* Grow = H + (uint64_t)hr * WH;
             const uint32_t jl = live ? j0 : 0u;
             const int32_t* Gp = Grow + jl;
@@ -863,6 +894,9 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             asm volatile("" : "+v"(left));
         }
     };
+    // (a one-wave workgroup has no LDS mailbox on either side - its carries come from and go to HBM, window by window - and takes the 64 rows of a record batch
+    // at once: half as many round trips for the carries, which is what a dead batch costs now that its rows leave in runs)
+    const uint32_t cbatch = (uint32_t)__builtin_amdgcn_readfirstlane((int)(NW == 1u ? 64u : CARRY_BATCH));
     for (uint32_t ib = 0; ib < V; ib += 64) {
         // the batches move up (the only waits for these loads: everything was requested at least 64 rows ago), another one goes in flight
         mC = mN; aC = aN; bC = bN; oC = oN; cC = cN; dC = dN; fC = fN;
@@ -874,7 +908,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
         for (uint32_t rb = 0; rb < ie; rb += nb) {
             // rows i0 .. i0 + nb - 1: up to CARRY_BATCH rows of the record batch - as many as have their carries in the mailbox, at least CARRY_MIN (a
             // wave follows its left neighbour at that distance when it keeps up, and the mailbox's 64 entries still absorb a neighbour's hiccup)
-            const uint32_t want = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(CARRY_BATCH, ie - rb)), i0 = ib + rb + 1;
+            const uint32_t want = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(cbatch, ie - rb)), i0 = ib + rb + 1;
             nb = want;
             int cinV = NEGK;     // lane r: carry into this wave for row i0 + r
             if (has_in) {
@@ -913,32 +947,44 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             }
             // (a row's record words are read out of their lane during the row BEFORE: a scalar instruction that consumes a readlane's result at once
             // waits ~14 cycles for it)
+            // PRUNE: rows skipped in RUNS. `bad` = the rows of the batch that cannot be skipped without a look at them (bit r = row i0 + r): a live carry, or
+            // a record that names a predecessor outside the ring and the previous row (the virtual row 0 where this wave has it flagged, a row in HBM, a
+            // fifth predecessor) or that is itself read back from HBM (it has to store "nothing" there) - all of it read off the 64 row records in their
+            // lanes, once per batch. Wherever nothing in the ring or the previous row is flagged (FM), the rows up to the next bad one are dead and leave
+            // together: their carries go out as one vector store. (Round 5, second half: the first version skipped whole batches only, and one risky row in
+            // fourteen left 45 % of the dead rows to the row-by-row path at ~750 cycles each under load.)
+            unsigned long long bad = 0;
             if constexpr (PRUNE) {
-                // A whole batch skipped at once: nothing in the ring or the previous row is flagged (FM), no carry of the batch is live, and no row of it
-                // names a predecessor outside those (the virtual row 0, a row in HBM, a fifth predecessor) or is itself read back from HBM (it would have
-                // to store "nothing" there) - all of it read off the 64 row records in their lanes. The batch's carries go out as one vector store.
-                if ((FM & 0x3ffeu) == 0u) {
-                    const bool in_b = lane >= rb && lane < rb + nb;                                   // this lane's record belongs to the batch
-                    const uint32_t np_l = mC >> META_NP;
-                    const bool risky = in_b && ((aC >> 28) >= 14u || (np_l > 1u && (bC >> 28) >= 14u) || (np_l > 2u && (cC >> 28) >= 14u) || (np_l > 3u && (dC >> 28) >= 14u) || np_l > 4u || (mC & 8u) != 0u);
-                    const bool clive = lane < nb && cinV >= thr_cin;
-                    if (__builtin_amdgcn_ballot_w64(risky || clive) == 0ull) {
-                        if (lane < nb) {
-                            const unsigned long long ent = (unsigned long long)(tag0_s + i0 + lane) | ((unsigned long long)(uint32_t)cinV << 32);
-                            if (out_l != 0u) st_wg64(mb_out_l + ((i0 + lane) & (WAVE_MBOX - 1)), ent);
-                            if (out_h != 0u) st_dev64(mb_out_h + i0 + lane, ent);
-                        }
-                        n_dead += nb; n_bulk += nb;
-                        const unsigned long long dp_ = (((unsigned long long)dhi << 32) | dlo) + (unsigned long long)dstep_s * nb;
-                        dlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dp_); dhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dp_ >> 32));
-                        lazy = lazy_on;
-                        continue;
-                    }
-                }
+                const uint32_t np_l = mC >> META_NP;
+                const uint32_t far0 = (FM >> 14) & 1u ? 14u : 15u;                                // (the virtual row 0 is dead for this wave's columns: code 14 names nothing live)
+                const bool risky = (aC >> 28) >= far0 || (np_l > 1u && (bC >> 28) >= far0) || (np_l > 2u && (cC >> 28) >= far0) || (np_l > 3u && (dC >> 28) >= far0) || np_l > 4u || (mC & 8u) != 0u;
+                const bool clive = lane < nb && cinV >= thr_cin;
+                bad = (__builtin_amdgcn_ballot_w64(risky) >> rb) | __builtin_amdgcn_ballot_w64(clive);
+                if (nb < 64u) bad &= (1ull << nb) - 1ull;
             }
-            uint32_t meta_nx = __builtin_amdgcn_readlane(mC, rb), p0_nx = __builtin_amdgcn_readlane(aC, rb);
+            // (the run is looked for where one can begin - at the batch's first row and behind a row that was skipped by itself - not on the path of a live row: as a
+            // test at the head of every row it cost ten scalar instructions, and a 13 000-edge call 4 %)
+            auto skip_run = [&](const uint32_t from) -> uint32_t {
+                if ((FM & 0x3ffeu) != 0u || from >= nb) return 0u;
+                const unsigned long long rest = bad >> from;
+                const uint32_t run = rest ? (uint32_t)__builtin_ctzll(rest) : nb - from;
+                if (run != 0u) {
+                    if (lane >= from && lane < from + run) {
+                        const unsigned long long ent = (unsigned long long)(tag0_s + i0 + lane) | ((unsigned long long)(uint32_t)cinV << 32);
+                        if (out_l != 0u) st_wg64(mb_out_l + ((i0 + lane) & (WAVE_MBOX - 1)), ent);
+                        if (out_h != 0u) st_dev64(mb_out_h + i0 + lane, ent);
+                    }
+                    n_dead += run; n_bulk += run;
+                    const unsigned long long dp_ = (((unsigned long long)dhi << 32) | dlo) + (unsigned long long)dstep_s * run;
+                    dlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dp_); dhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dp_ >> 32));
+                }
+                return run;
+            };
             const uint32_t dead_before = n_dead;
-            for (uint32_t rj = 0; rj < nb; rj++) {
+            uint32_t rj0 = 0;
+            if constexpr (PRUNE) rj0 = skip_run(0u);
+            uint32_t meta_nx = __builtin_amdgcn_readlane(mC, (rb + rj0) & 63u), p0_nx = __builtin_amdgcn_readlane(aC, (rb + rj0) & 63u);
+            for (uint32_t rj = rj0; rj < nb; rj++) {
                 const uint32_t ri = rb + rj, i = ib + ri + 1;
                 const uint32_t meta = meta_nx, p0 = p0_nx;
                 const uint32_t npred = meta >> META_NP;
@@ -946,14 +992,14 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 if constexpr (PRUNE) {
                     // does anything this wave can read for the row still reach T? (all scalar: flags of the predecessor entries, the carry's test)
                     const int cin_e = __builtin_amdgcn_readlane(cinV, rj);
-                    cin_live = (uint32_t)(cin_e >= thr_cin);
+                    cin_live = s_ge_i32(cin_e, thr_cin);   // (as a C comparison the flag became a lane mask and the whole test vector code: v_cndmask, v_or, v_cmp_ne, a vcc branch)
                     fl0 = (FM >> (p0 >> 28)) & 1u;
                     uint32_t act = cin_live | fl0;
                     if (npred > 1) {
                         flB = (FM >> ((uint32_t)__builtin_amdgcn_readlane(bC, ri) >> 28)) & 1u; act |= flB;
                         if (npred > 2) {
                             flC = (FM >> ((uint32_t)__builtin_amdgcn_readlane(cC, ri) >> 28)) & 1u; act |= flC;
-                            if (npred > 3) { flD = (FM >> ((uint32_t)__builtin_amdgcn_readlane(dC, ri) >> 28)) & 1u; act |= flD | (uint32_t)(npred > 4); }
+                            if (npred > 3) { flD = (FM >> ((uint32_t)__builtin_amdgcn_readlane(dC, ri) >> 28)) & 1u; act |= flD | ((npred + 3u) >> 3); }   // (non-zero for a fifth predecessor)
                         }
                     }
                     if (act == 0u) {
@@ -973,6 +1019,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                         }
                         if (__builtin_expect((meta & 8u) != 0u, 0)) {   // a far successor will read this row from HBM: keys of "nothing" (its flag is always taken for set)
                             const uint32_t fslot = __builtin_amdgcn_readlane(fC, ri);
+                            far_set(fslot, 0u);
                             if (live) {
                                 int32_t* F = H + (uint64_t)fslot * WH;
                                 int ng[CM];
@@ -981,6 +1028,10 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                                 store_chunk_i32<CM>(F + j0, ng);
                                 if (lane == 0 && has_in) F[hleft] = NEGK;
                             }
+                        }
+                        {   // the rows behind this one, up to the next that needs a look
+                            const uint32_t run = skip_run(rj + 1u);
+                            if (run != 0u) { rj += run; meta_nx = __builtin_amdgcn_readlane(mC, (rb + rj + 1u) & 63u); p0_nx = __builtin_amdgcn_readlane(aC, (rb + rj + 1u) & 63u); }
                         }
                         continue;
                     }
@@ -1011,10 +1062,23 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 DP_T(0);   // row decode
                 int m[CM];
                 if (!PRUNE || __builtin_expect(fl0 != 0u, 1)) {   // the first predecessor (or row 0): diagonal and vertical move
-                    int hp[CM], left;
-                    pred_row(p0, hp, left, true);
+#ifndef HX_NO_PREV_DIRECT
+                    if (PRUNE && __builtin_expect((p0 >> 28) == 13u, 1)) {   // (PRUNE = the instances of the many-edge regime; the row of the 4-column instances a lone wave runs got 14 % SLOWER with this block: 292 -> 332 M cycles on the longest 12 Mb edge)
+                        // the previous row: its cells straight from the registers they are in. (Through pred_row the three sources of a predecessor row join
+                        // in ONE set of registers and the compiler copies the previous row into them - ten v_mov per row of the 8-column instances. The
+                        // statement at the end keeps this block from being merged with the general one below.)
+                        const int left = wave_shift_up1(tp[CM - 1], lnp);
 #pragma unroll
-                    for (int k = 0; k < CM; k++) m[k] = max((k == 0 ? left : hp[k - 1]) + score_of(k), hp[k] + gv);
+                        for (int k = 0; k < CM; k++) m[k] = max((k == 0 ? left : tp[k - 1]) + score_of(k), tp[k] + gv);
+                        asm volatile("" : "+v"(m[CM - 1]));
+                    } else
+#endif
+                    {
+                        int hp[CM], left;
+                        pred_row(p0, hp, left, true);
+#pragma unroll
+                        for (int k = 0; k < CM; k++) m[k] = max((k == 0 ? left : hp[k - 1]) + score_of(k), hp[k] + gv);
+                    }
                 } else {                                          // (PRUNE: a skipped row is not read)
 #pragma unroll
                     for (int k = 0; k < CM; k++) m[k] = NEGK;
@@ -1096,8 +1160,10 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
 #pragma unroll
                 for (int k = 0; k < CM; k++) tp[k] = t[k];
                 lnp = left_now;
+                uint32_t row_fl = 1u;
                 if constexpr (PRUNE) {   // the row's flag for its successors: a lane whose last key, taken at its first column, reaches T - or a live carry-in (the column left of the wave)
                     const uint32_t fl = (uint32_t)(__builtin_amdgcn_ballot_w64(t[CM - 1] >= thr_lane) != 0ull) | cin_live;
+                    row_fl = fl;
                     FM = (FM & ~(0x2000u | (2u << slot))) | (fl << 13) | ((fl << 1) << slot);
                 }
                 DP_T(4);   // carry applied, ring copy
@@ -1130,6 +1196,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                         // (the slot is read out of its lane HERE, where every lane is active: inside the divergent block below a register
                         // that was spilled is reloaded for the active lanes only, and lane ri need not be one of them)
                         const uint32_t fslot = DIR ? __builtin_amdgcn_readlane(fC, ri) : 0u;
+                        if constexpr (PRUNE) far_set(fslot, row_fl);
                         if (DIR && live
                             ) {
                             int32_t* F = H + (uint64_t)fslot * WH;
@@ -1688,7 +1755,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     constexpr uint32_t CL_ABORT = 0xffffffffu;
 #define HX_DP_DISPATCH(Lq, Vq, nsq, Tq) do { \
         if (((Lq) + 1 + GM * NP * DL - 1) / (GM * NP * DL) <= (uint32_t)CM) {    /* the host puts an edge into a launch whose columns per lane hold its longest sequence */ \
-            dp_rows<CM, DIR, PRUNE>(g, H, Dm, Dw, W, WH, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, wmail.box, wmail.consumed, sink_row, sink_score, SINK_LDS, nsq, cl, ph + 6, Tq, (prune_pct >> 16) & 1u, ph + 12); \
+            dp_rows<CM, DIR, PRUNE>(g, H, Dm, Dw, W, WH, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, wmail.box, wmail.consumed, sink_row, sink_score, SINK_LDS, nsq, cl, ph + 6, Tq, (prune_pct >> 16) & 1u, ph + 12, ED.hrows); \
         } else sOk = 2; } while (0)
     // The reference's topological order (spoa's DFS, inherently serial) is needed in two places only: to break ties between equally scored
     // end nodes of an alignment, and for the heaviest-bundle traversal of the finished graph. The DP itself runs on a cheaper order that
