@@ -674,7 +674,12 @@ template <int CM> __device__ __forceinline__ void store_nibbles_buf(__amdgpu_buf
 // predecessor lives (registers / LDS ring / anything else), then straight-line code: rare events (row spilled to HBM, sink row) share
 // one not-taken branch, only rows with a non-adjacent reader are copied to the LDS ring (slot from the row's record), selects are
 // arithmetic.
-template <int CM, bool DIR, bool PRUNE>
+#ifdef HX_FARREAD_STORE   // (development: dead far-read rows store "nothing" and need a look, flags or not - as before the sticky far bit)
+#define HX_FARREAD_RISKY(fb) true
+#else
+#define HX_FARREAD_RISKY(fb) (!(fb))
+#endif
+template <int CM, bool DIR, bool PRUNE, bool ONEW /* the workgroup is one wave (the 64-lane instances): no LDS mailbox on either side, no relay - known at compile time, the row loses its tests of them */>
 __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uint8_t* __restrict__ D, uint8_t* __restrict__ Dwide, const uint32_t W, const uint32_t WH, const uint8_t* __restrict__ seq,
                         const uint32_t L_, const uint32_t V_, int32_t* ring, const uint32_t R_, const uint32_t ring_w_, const int match, const int mismatch, const int gap,
                         unsigned long long* wm_box, uint32_t* wm_cons, uint32_t* sink_row, int* sink_score, const uint32_t sink_cap, uint32_t& nSinkOut, const DpCl& cl, unsigned long long* prof,
@@ -688,13 +693,13 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     // registers they turn the loop control, the ring slot arithmetic and the carry hand-over into scalar instructions and branches
     const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)L_), V = (uint32_t)__builtin_amdgcn_readfirstlane((int)V_);
     const uint32_t R = (uint32_t)__builtin_amdgcn_readfirstlane((int)R_), ring_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)ring_w_);
-    const uint32_t tid = threadIdx.x, NT = blockDim.x, lane = tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), NW = cl.lanes >> 6;
+    const uint32_t tid = threadIdx.x, NT = ONEW ? 64u : blockDim.x, lane = tid & 63u, wv = ONEW ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), NW = ONEW ? 1u : cl.lanes >> 6;
     const uint32_t ncol = L + 1;
     // A wide member (1024 lanes, NW of its 16 waves in the DP) other than the first lets a spare wave RELAY the carries that arrive through HBM
     // into an LDS mailbox: its first DP wave then takes them like any wave takes its left neighbour's (an LDS round trip per batch of rows
     // instead of a device-scope load, ~1.7 us, that it would sit through - and the pipeline runs at the speed of its slowest wave).
     constexpr uint32_t RELAY_BOX = MAX_WAVES - 2;                             // mailbox / consumed word of the relay (the 1024-lane instances have them; boundaries 0 .. NW-2 are the DP's)
-    const bool relay_mode = NT == 1024u && NW + 2u <= 16u && cl.mem > 0;
+    const bool relay_mode = !ONEW && NT == 1024u && NW + 2u <= 16u && cl.mem > 0;
     if (wv >= NW) {                                                           // (a wave of a wide member that sits the DP out)
         if (relay_mode && wv == NW + 1u && (uint64_t)(cl.mem * NW) * 64u * CM < ncol) {   // (wave NW + 1: not the SIMD of the wave it feeds)
             const unsigned long long* src = cl.mbox + (uint64_t)(cl.mem - 1) * cl.stride;
@@ -734,9 +739,9 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     if ((uint64_t)gw * 64u * CM >= ncol) return;                              // the wave owns no real column of this sequence
     const uint32_t gt = gw * 64u + lane;                                      // lane index over all waves
     const bool has_in = gw > 0;                                               // a wave on the left feeds the horizontal carry ...
-    const bool in_lds = wv > 0 || relay_mode;                                 // ... through the workgroup's LDS mailbox, or (first wave of a member without a relay wave) through HBM
+    const bool in_lds = !ONEW && (wv > 0 || relay_mode);                                 // ... through the workgroup's LDS mailbox, or (first wave of a member without a relay wave) through HBM
     const bool has_out = (uint64_t)(gw + 1) * 64u * CM < ncol;                // a wave on the right owns real columns (the host sized the pipeline for the longest sequence)
-    const bool out_lds = wv + 1 < NW;
+    const bool out_lds = !ONEW && wv + 1 < NW;
     // (wave-uniform tests of the row loop as 32-bit scalars: a test of a lane-mask boolean is `s_andn2 vcc` + a vcc branch, ~32 cycles for a lone
     // wave against ~15 for `s_cmp` + an scc branch: tools/dev_lonebench.hip)
     const uint32_t out_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(has_out && out_lds)), out_h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(has_out && !out_lds));
@@ -831,10 +836,15 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     if constexpr (PRUNE) {
         const int mg = match - gap, thr_base = thrT - match * (int)L;
         const int c0 = (int)(gw * 64u * CM);
-        thr_lane = (thr_base + mg * (int)j0) * 64;
+        // (padding lanes - no real column: the last wave's - never flag a row. They read the FIRST chunk of a far row, another wave's, and what stands there when
+        // that wave had no reason to store the row is whatever the slot held before: harmless for the cells, but a flag from it made the pruning counters differ
+        // from run to run)
+        thr_lane = live ? (thr_base + mg * (int)j0) * 64 : INT32_MAX;
         thr_cin = __builtin_amdgcn_readfirstlane((thr_base + mg * (c0 - 1)) * 64);
         const uint32_t f0 = (uint32_t)(match * (int)L - mg * max(c0 - 1, 0) >= thrT);
-        FM = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0x8000u | (f0 << 14)));   // nothing in the ring, no previous row yet
+        // (bit 15, "a row in HBM": set for good where the far rows have no flags of their own; else it is raised by the first far row this wave stores LIVE - until
+        // then every far row it could name is dead, and above the band of the matrix a record that names one is as dead as its neighbours)
+        FM = (uint32_t)__builtin_amdgcn_readfirstlane((int)((far_n <= 2048u ? 0u : 0x8000u) | (f0 << 14)));   // nothing in the ring, no previous row yet
     }
     // PRUNE: the flags of the rows kept in HBM ("far" rows, code 15), one bit per row of H in ONE register of the wave (lane = slot / 32: 2 048 slots; an edge with
     // more has every bit set for good - its far rows are read as they always were). A far row whose flag is clear is not fetched: its reader takes "nothing",
@@ -953,14 +963,20 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             // lanes, once per batch. Wherever nothing in the ring or the previous row is flagged (FM), the rows up to the next bad one are dead and leave
             // together: their carries go out as one vector store. (Round 5, second half: the first version skipped whole batches only, and one risky row in
             // fourteen left 45 % of the dead rows to the row-by-row path at ~750 cycles each under load.)
-            unsigned long long bad = 0;
+            unsigned long long bad = 0, farref = 0;
             if constexpr (PRUNE) {
                 const uint32_t np_l = mC >> META_NP;
-                const uint32_t far0 = (FM >> 14) & 1u ? 14u : 15u;                                // (the virtual row 0 is dead for this wave's columns: code 14 names nothing live)
-                const bool risky = (aC >> 28) >= far0 || (np_l > 1u && (bC >> 28) >= far0) || (np_l > 2u && (cC >> 28) >= far0) || (np_l > 3u && (dC >> 28) >= far0) || np_l > 4u || (mC & 8u) != 0u;
+                // (codes 14 and 15 - the virtual row 0, a row in HBM - name something live only where this wave has their bit of FM set. A row that is itself read back
+                // from HBM needs a look only where the far rows have no flags: with them its bit is clear until somebody stores it live, and nobody fetches it)
+                auto outside = [&](const uint32_t ent) -> bool { const uint32_t c = ent >> 28; return c >= 14u && ((FM >> c) & 1u) != 0u; };
+                const bool risky = outside(aC) || (np_l > 1u && outside(bC)) || (np_l > 2u && outside(cC)) || (np_l > 3u && outside(dC)) || np_l > 4u || (HX_FARREAD_RISKY(far_bits) && (mC & 8u) != 0u);
                 const bool clive = lane < nb && cinV >= thr_cin;
                 bad = (__builtin_amdgcn_ballot_w64(risky) >> rb) | __builtin_amdgcn_ballot_w64(clive);
-                if (nb < 64u) bad &= (1ull << nb) - 1ull;
+                if ((FM & 0x8000u) == 0u) {   // the rows that name a far row: they need a look from the moment one is stored live (below)
+                    const bool refs_far = (aC >> 28) == 15u || (np_l > 1u && (bC >> 28) == 15u) || (np_l > 2u && (cC >> 28) == 15u) || (np_l > 3u && (dC >> 28) == 15u);
+                    farref = __builtin_amdgcn_ballot_w64(refs_far) >> rb;
+                }
+                if (nb < 64u) { bad &= (1ull << nb) - 1ull; farref &= (1ull << nb) - 1ull; }   // (a bit beyond the batch would send a run past its end)
             }
             // (the run is looked for where one can begin - at the batch's first row and behind a row that was skipped by itself - not on the path of a live row: as a
             // test at the head of every row it cost ten scalar instructions, and a 13 000-edge call 4 %)
@@ -1019,8 +1035,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                         }
                         if (__builtin_expect((meta & 8u) != 0u, 0)) {   // a far successor will read this row from HBM: keys of "nothing" (its flag is always taken for set)
                             const uint32_t fslot = __builtin_amdgcn_readlane(fC, ri);
-                            far_set(fslot, 0u);
-                            if (live) {
+                            if (HX_FARREAD_RISKY(far_bits) && live) {   // (with flags: the row's bit is clear - every DP begins with none set - and nobody fetches an unflagged row)
                                 int32_t* F = H + (uint64_t)fslot * WH;
                                 int ng[CM];
 #pragma unroll
@@ -1196,7 +1211,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                         // (the slot is read out of its lane HERE, where every lane is active: inside the divergent block below a register
                         // that was spilled is reloaded for the active lanes only, and lane ri need not be one of them)
                         const uint32_t fslot = DIR ? __builtin_amdgcn_readlane(fC, ri) : 0u;
-                        if constexpr (PRUNE) far_set(fslot, row_fl);
+                        if constexpr (PRUNE) { far_set(fslot, row_fl); if (row_fl != 0u && (FM & 0x8000u) == 0u) { FM |= 0x8000u; bad |= farref; } }
                         if (DIR && live
                             ) {
                             int32_t* F = H + (uint64_t)fslot * WH;
@@ -1755,7 +1770,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
     constexpr uint32_t CL_ABORT = 0xffffffffu;
 #define HX_DP_DISPATCH(Lq, Vq, nsq, Tq) do { \
         if (((Lq) + 1 + GM * NP * DL - 1) / (GM * NP * DL) <= (uint32_t)CM) {    /* the host puts an edge into a launch whose columns per lane hold its longest sequence */ \
-            dp_rows<CM, DIR, PRUNE>(g, H, Dm, Dw, W, WH, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, wmail.box, wmail.consumed, sink_row, sink_score, SINK_LDS, nsq, cl, ph + 6, Tq, (prune_pct >> 16) & 1u, ph + 12, ED.hrows); \
+            dp_rows<CM, DIR, PRUNE, MAXNT == 64>(g, H, Dm, Dw, W, WH, seq, Lq, Vq, ring, R, ring_w, match, mismatch, gap, wmail.box, wmail.consumed, sink_row, sink_score, SINK_LDS, nsq, cl, ph + 6, Tq, (prune_pct >> 16) & 1u, ph + 12, ED.hrows); \
         } else sOk = 2; } while (0)
     // The reference's topological order (spoa's DFS, inherently serial) is needed in two places only: to break ties between equally scored
     // end nodes of an alignment, and for the heaviest-bundle traversal of the finished graph. The DP itself runs on a cheaper order that

@@ -12,6 +12,9 @@ import orclib  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+if os.environ.get('FUZZ_LIBDIR'):   # a variant build of libhaslr_hip.so (tools/dev_variant.sh)
+    hip._LIBDIR = os.path.join(ROOT, os.environ['FUZZ_LIBDIR'])
+only = set(int(x) for x in os.environ['FUZZ_ONLY'].split(',')) if os.environ.get('FUZZ_ONLY') else None   # run these cases of the sequence only (the others still draw their random numbers)
 ctx = hip.HipContext(0)
 os.makedirs('/tmp/fz', exist_ok=True)
 bad = 0
@@ -23,7 +26,9 @@ for it in range(n):
             '--variant-per-mb', str(rng.choice([0, 5, 30])), '--gap-median', str(rng.choice([2500, 4000, 6000]) if big else rng.choice([300, 600, 1500, 3000])), '--out-prefix', '/tmp/fz/s']
     if rng.random() < 0.3:
         args[-2:-2] = ['--hairpin-frac', str(rng.choice([0.02, 0.1]))]
-    subprocess.check_call([ROOT + '/tools/hxsim'] + args, stderr=subprocess.DEVNULL)
+    skip = only is not None and it not in only
+    if not skip:
+        subprocess.check_call([ROOT + '/tools/hxsim'] + args, stderr=subprocess.DEVNULL)
     env = {}
     shape = rng.choice(['default', 'default', 'small-members', 'block']) if big else rng.choice(['default', 'small-members', 'one-wave', 'block'])
     for k in KNOBS:
@@ -67,9 +72,13 @@ for it in range(n):
             env['HX_POA_WAVE_MAX'] = str(rng.choice([64, 128, 256]))          # several waves per workgroup on the short gaps of a small data set
     if rng.random() < 0.25:
         env['HX_POA_NODE_EST_PCT'] = str(rng.choice([2, 10, 30, 60]))
+    pk = dict(min_aln_block=rng.choice([250, 500, 500, 1000]), min_aln_sim=rng.choice([0.8, 0.85, 0.85, 0.9]), min_edge_sup=rng.choice([2, 3, 3, 5]), max_uniq_dev=rng.choice([0.15, 0.15, 0.3]))
+    if skip:
+        continue
+    if only is not None:
+        print(it, 'RUN', ' '.join(args[:-2]), shape, env, pk, flush=True)
     ctx.set_options(**env)
     ds = host.Dataset('/tmp/fz/s.contigs.fa', '/tmp/fz/s.reads.fa', '/tmp/fz/s.paf')
-    pk = dict(min_aln_block=rng.choice([250, 500, 500, 1000]), min_aln_sim=rng.choice([0.8, 0.85, 0.85, 0.9]), min_edge_sup=rng.choice([2, 3, 3, 5]), max_uniq_dev=rng.choice([0.15, 0.15, 0.3]))
     env = dict(env, **{k: str(v) for k, v in pk.items()})   # (printed with the knobs)
     be = orclib.OracleBackend(ds, 16)
     ro = host.Run(ds, ds.params(**pk), be.table, None)
