@@ -730,11 +730,7 @@ struct PoaCall {
         // Column passes (kernels/poa.hip): with the rows pruned, an edge's wave slots are mostly held by waves that skip - so the unshared multi-wave edges run
         // in workgroups of `pass_lanes` lanes and take their columns window by window. The call is bound by wave-slot time (thousands of edges, every slot
         // taken): an edge of 8 000 columns holds 4 waves instead of 16 for little more than the same time.
-        // (not with a forced block size - a testing switch: size_edges gives such edges no passes, and the launch classes of a call with passes - one pruned
-        // instance per width, need buckets - are laid out for workgroups that hold their gap at 8 columns per lane. Round 5's fuzz found the combination, with one
-        // persistent slot and a starved node estimate, ending in a memory access fault in the retries after "rows read back from HBM outgrew H"; the automatic
-        // shape under the same knobs is fine. Root cause not found: DESIGN.md, open items.)
-        pass_on = prune_pct != 0 && cols_per_lane <= 8 && o.poa_pass_lanes != 0 && !c->poa_block;
+        pass_on = prune_pct != 0 && cols_per_lane <= 8 && o.poa_pass_lanes != 0;
         pass_lanes = !pass_on || o.poa_pass_lanes < 0 ? 0u : (uint32_t)o.poa_pass_lanes;   // (0 with pass_on: by gap length, size_edges)
         if (pass_lanes != 0 && pass_lanes != 64 && pass_lanes != 128 && pass_lanes != 256 && pass_lanes != 512 && pass_lanes != 1024) return fail("option poa_pass_lanes must be 0, 64, 128, 256, 512 or 1024");
         if (cl_lanes != 64 && cl_lanes != 128 && cl_lanes != 256 && cl_lanes != 512 && cl_lanes != 1024) return fail("option poa_member_lanes must be 64, 128, 256, 512 or 1024");
@@ -1008,6 +1004,17 @@ struct PoaCall {
             total_cost += q.share;
         }
         for (Cls& q : classes) q.share = total_cost > 0 ? q.share / total_cost : 0;
+        // The need buckets of one kernel instance share a launch, and a workgroup serves its own bucket AND every smaller one out of the slot it owns: the slot
+        // must hold the largest of every component - nodes, edges, H rows, wide rows ... - over all those buckets, not only over its own. A bucket is a power of two
+        // of the TOTAL bytes, and the components usually grow together; an edge that is redone with sixteen times the H rows (far rows outgrew the estimate) or a
+        // larger wide-row pool is small in all and large in one - and ran, in the slot of a larger bucket, over that slot's share of the pool (round 5's fuzz: a GPU
+        // memory access fault in the retries after "rows read back from HBM outgrew H"; once a consensus that differed from the oracle's).
+        if (pass_on)
+            for (size_t k = classes.size(); k-- > 1;) {
+                Cls& a = classes[k - 1];
+                const Cls& b = classes[k];
+                if (!a.shared && !b.shared && a.nt == b.nt && a.cm == b.cm && a.dir == b.dir && a.dpl == b.dpl && a.pk == b.pk) need_max(a.need, b.need);
+            }
         return 0;
     }
     // Slots of a persistent class: as many workgroups as the chip holds of that size at 16 waves per CU (all classes share the CUs, but when the

@@ -448,6 +448,31 @@ def test_persistent_workgroups_on_many_edges(sim, ctx):
 
 
 @pytest.mark.gpu
+def test_need_buckets_with_edges_redone_in_one_component(sim, ctx):
+    """the launch of a call with column passes: the need buckets of one kernel instance share it, and a workgroup serves its bucket and every smaller one out
+    of its own slot. An edge that is redone with a multiple of the H rows (far rows outgrew the estimate) or of the wide-row pool is small in total bytes and
+    large in ONE component - the slot of a larger bucket must still hold it (round 5's fuzz case: one persistent slot per class, a node estimate starved to 2 %,
+    pruning and passes on, forced block size 128 - a GPU memory access fault until every bucket's slot took the component-wise maximum over the smaller ones)"""
+    pre = sim("--genome-len", "1000000", "--seed", "331118", "--model", "pacbio", "--cov", "70", "--variant-per-mb", "0", "--gap-median", "6000", "--hairpin-frac", "0.1")
+    ds = host.Dataset(pre + ".contigs.fa", pre + ".reads.fa", pre + ".paf")
+    prm = ds.params(min_aln_block=500, min_aln_sim=0.85, min_edge_sup=3, max_uniq_dev=0.15)
+    be = orclib.OracleBackend(ds, os.cpu_count() or 8)
+    ro = host.Run(ds, prm, be.table, None)
+    ro.all()
+    ctx.upload(ds)
+    ctx.set_poa_block(128)
+    try:
+        with ctx.options(poa_slots=1, poa_prune=95, poa_prune_lanes=128, poa_node_est_pct=2):
+            rg = host.Run(ds, prm, ctx.backend(), None)
+            rg.all()
+    finally:
+        ctx.set_poa_block(0)
+    assert rg.n_edges > 30
+    assert ro.cns_out() == rg.cns_out() and ro.assembly_fasta() == rg.assembly_fasta()
+    rg.close(); ro.close(); be.close(); ds.close()
+
+
+@pytest.mark.gpu
 def test_cli_reuses_index_caches(sim, built, tmp_path):
     """like the reference (main.cpp:39-103) the binary leaves index.contig / index.longread in -d and a second run loads them instead of
     the text files (which may be gone): same outputs"""
