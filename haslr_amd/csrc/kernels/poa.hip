@@ -592,6 +592,12 @@ __device__ __forceinline__ uint32_t s_ge_i32(int a, int b) {
     asm("s_cmp_ge_i32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(a), "s"(b) : "scc");
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
 }
+// 1 if the lane mask has a bit set, else 0
+__device__ __forceinline__ uint32_t s_nz_u64(unsigned long long m) {
+    uint32_t r;
+    asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(m) : "scc");
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+}
 // byte 0 of four registers -> one dword
 __device__ __forceinline__ uint32_t pack_b0(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     const uint32_t ab = __builtin_amdgcn_perm(b, a, 0x0c0c0400u), cd = __builtin_amdgcn_perm(d, c, 0x0c0c0400u);
@@ -1177,9 +1183,9 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 lnp = left_now;
                 uint32_t row_fl = 1u;
                 if constexpr (PRUNE) {   // the row's flag for its successors: a lane whose last key, taken at its first column, reaches T - or a live carry-in (the column left of the wave)
-                    const uint32_t fl = (uint32_t)(__builtin_amdgcn_ballot_w64(t[CM - 1] >= thr_lane) != 0ull) | cin_live;
+                    const uint32_t fl = s_nz_u64(__builtin_amdgcn_ballot_w64(t[CM - 1] >= thr_lane)) | cin_live;   // (as a C comparison: s_cselect_b64, v_cndmask, v_readfirstlane)
                     row_fl = fl;
-                    FM = (FM & ~(0x2000u | (2u << slot))) | (fl << 13) | ((fl << 1) << slot);
+                    { const uint32_t mk = 0x2000u | (2u << slot); FM = (FM & ~mk) | (mk * fl); }   // (the previous row's bit and the ring slot's: both the row's flag)
                 }
                 DP_T(4);   // carry applied, ring copy
                 if (DIR) {
