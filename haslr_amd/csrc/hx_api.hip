@@ -926,7 +926,7 @@ struct PoaCall {
         const uint64_t rwh = rw + (waves > 1 ? (waves + 3) & ~3ull : 0);       // rows of H end with one word per wave of the edge's pipeline
         Need n;
         n.nn = (uint64_t)E.vcap + 1; n.ec = E.ecap; n.dc = full_h[e] ? 0 : n.nn * (rw / 2); n.hc = (uint64_t)E.hrows * rwh; n.wc = full_h[e] ? 0 : (uint64_t)E.wrows * rw;
-        n.lm = E.lmax; n.st = 4 * n.nn + E.ecap; n.al = n.nn + E.lmax + 2;
+        n.lm = E.lmax; n.st = 4 * n.nn + E.ecap; n.al = n.nn + E.lmax + 2 + 64;   // (+ 64: the traceback's guard against a walk that does not end looks once per tile)
         n.mb = E.passes > 1 ? (uint64_t)E.passes * n.nn : 0;   // the carries handed from one column pass to the next
         return n;
     }

@@ -2066,6 +2066,10 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                     uint32_t nwalk = 0, iend = 0, jend = 0;   // entries of the walk proper, and where it stopped
                     bool tail = false;
                     while (!(i == 0 && j == 0)) {
+                        // (every step leaves a row or a column behind: a walk of more entries than rows + columns is walking a matrix that is not one - a bug somewhere
+                        // else. It ends here, the edge comes back with an internal error and the call fails loudly, instead of a kernel that never ends; the entry
+                        // arrays have 64 entries of slack for the tile that runs over: need_of)
+                        if (__builtin_expect(na > V + L + 2u, 0)) { if (ln == 0) sOk = 2; break; }
                         if (i == 0) {   // only horizontal moves are left in the virtual row: written in their final form
                             if (na & 63u) { const uint32_t base = na & ~63u; if (ln < na - base) { g.aln_node[base + ln] = pn; g.aln_pos[base + ln] = pp; } }
                             tail = true;
@@ -2224,6 +2228,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
             }
         }
         __syncthreads();
+        if (sOk != 1) break;                                        // (a walk that did not end: see there)
         PHASE(2);
         // =================================================== graph update + order update (all lanes): graph_update / order_update above
         const uint32_t V_old = sV;
