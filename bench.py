@@ -98,6 +98,84 @@ def gfa_digest(out_dir):
     return {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest() for f in files}
 
 
+def bench_dir():
+    d = os.environ.get("HASLR_BENCH_DIR", "/tmp/haslr_bench")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def cli_e2e(pre, tag):
+    """ONE run of the drop-in binary on the text files, in a process of its own: what a user of bin/haslr.py:66 waits for (the reference is a run-once
+    program, main.cpp:28-228). Wall time of the process + the binary's own account of it (HASLR_STAGE_TIMES). The input files were just written by
+    the simulator (page cache warm); index.contig / index.longread are written as in any first run; -t = min(64, cores)."""
+    import shutil
+    exe = os.path.join(ROOT, "haslr_amd", "bin", "haslr_assemble")
+    out = os.path.join(bench_dir(), f"cli_{tag}")
+    shutil.rmtree(out, ignore_errors=True)
+    times = os.path.join(bench_dir(), f"cli_{tag}.times.json")
+    threads = min(64, os.cpu_count() or 1)
+    env = dict(os.environ, HASLR_STAGE_TIMES=times)
+    env.pop("HX_DEBUG", None)
+    t0 = time.perf_counter()
+    r = subprocess.run([exe, "-t", str(threads), "-c", pre + ".contigs.fa", "-l", pre + ".reads.fa", "-m", pre + ".paf", "-d", out], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    wall = time.perf_counter() - t0
+    if r.returncode != 0:
+        return {"error": r.stderr[-600:]}
+    res = {"cli_e2e_s": wall, "threads": threads, "command": "haslr_assemble -t %d -c .. -l .. -m .. -d .. (fresh process, fresh output directory)" % threads}
+    try:
+        res["stages_s"] = json.load(open(times))
+    except Exception as e:  # noqa: BLE001
+        res["stages_s"] = {"error": str(e)}
+    try:
+        res["asm_final_fa_sha256"] = hashlib.sha256(open(os.path.join(out, "asm.final.fa"), "rb").read()).hexdigest()
+        res["gfa"] = gfa_digest(out)
+    except Exception as e:  # noqa: BLE001
+        res["asm_final_fa_sha256"] = "error: " + str(e)
+    shutil.rmtree(out, ignore_errors=True)
+    return res
+
+
+def reserve_bytes_for(ds):
+    """the arena haslr_assemble reserves beside its parse: 32 B of consensus workspace per long-read base, at most what a call ever settles on (main.cpp of the build)"""
+    return min(142 << 30, 32 * int(ds.total_read_bases))
+
+
+def upload_and_reserve(ctx, ds):
+    """inputs to HBM while a second thread reserves the consensus workspace's arena - the start-up of the product binary (hx_poa_reserve beside the
+    parse / upload). HASLR_BENCH_NO_RESERVE=1: no reservation (the first consensus call allocates, as before round 6)."""
+    import threading
+    t0 = time.perf_counter()
+    th, t_res = None, [0.0]
+    if os.environ.get("HASLR_BENCH_NO_RESERVE") != "1":
+        def work():
+            a = time.perf_counter()
+            ctx.poa_reserve(reserve_bytes_for(ds))
+            t_res[0] = time.perf_counter() - a
+        th = threading.Thread(target=work)
+        th.start()
+    ctx.upload(ds)
+    t_up = time.perf_counter() - t0
+    if th:
+        th.join()
+    return {"upload_s": t_up, "workspace_reserve_s": t_res[0], "upload_and_reserve_s": time.perf_counter() - t0, "reserved_bytes": ctx.poa_arena_stats()["bytes"]}
+
+
+def cold_pass(ctx, ds, prm, table):
+    """the FIRST pass of a fresh context over a data set (untimed for `value`; what a one-shot program pays): every scratch array is allocated, every
+    kernel runs for the first time. The consensus workspace's arena was reserved beside the upload (upload_and_reserve), as the binary does."""
+    from haslr_amd import host
+    t0 = time.perf_counter()
+    run = host.Run(ds, prm, table, None)
+    run.chain(); run.graph(); run.coords(); run.consensus()
+    dt = time.perf_counter() - t0
+    tm = run.timings()
+    res = {"cold_first_pass_ms": dt * 1e3, "cold_consensus_ms": tm.get("consensus", 0) * 1e3, "cold_stage_ms": {k: v * 1e3 for k, v in tm.items()},
+           "cold_poa_host_ms": ctx.poa_host_times(), "workspace_arena": ctx.poa_arena_stats(), "poa_workspace_bytes": ctx.poa_workspace_bytes()}
+    run.close()
+    return res
+
+
 def cpu_baseline(ds, gpu_cns, gpu_gfa=None, work_dir=None):
     """The oracle (kind "port": the CPU restatement of the reference path, AVX2 row kernels where the host has them,
     edges dealt to the threads costliest first) on the SAME data set and timed region as the GPU line, twice:
@@ -169,12 +247,40 @@ def measure(ctx, ds, prm, table, steps, warmup, world, rank, sync, gather, lr_be
     return time.perf_counter() - t0, last
 
 
+def cpu_sample(ds, share=8):
+    """CPU oracle on a BOUNDED sample of the data set of a multi-GPU line: chain + graph over everything (seconds), coordinates + consensus over the LPT
+    share 1 / `share` of the edges; the whole-data-set rate is extrapolated from it (consensus is > 95 % of the CPU pass) and says so."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from haslr_amd import host
+    import orclib
+    threads = min(64, os.cpu_count() or 1)
+    be = orclib.OracleBackend(ds, threads)
+    run = host.Run(ds, ds.params(), be.table, None)
+    run.set_edge_shard(0, share)
+    t0 = time.perf_counter()
+    run.chain(); run.graph()
+    t_front = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    run.coords(); run.consensus()
+    t_share = time.perf_counter() - t0
+    n_share, n_all = run.n_edges, run.n_edges_total
+    cells = run.cns_stats()["dp_cells"]
+    run.close(); be.close()
+    est = t_front + t_share * share
+    return {"value": ds.total_read_bases / est, "unit": "long-read bases/s", "cores": threads, "kind": "port", "extrapolated": True,
+            "sample": f"chain + graph over the whole data set ({t_front:.2f} s), coordinates + consensus over the LPT share 1/{share} of the edges ({n_share} of {n_all}, "
+                      f"{cells:.3g} cells, {t_share:.2f} s); whole-data-set time estimated as {t_front:.2f} + {share} x {t_share:.2f} = {est:.1f} s; oracle/liboracle.so, {threads} threads",
+            "gcups_on_sample": cells / t_share / 1e9, "see": "the N = 1 line carries the CPU leg on a whole data set with the consensus compared"}
+
+
 def run_group(args):
     """`--gpus N` without a launcher: the product binary's multi-GPU path driven from here - N ranks INSIDE this process (hx_group_create: one context +
     one RCCL communicator per rank; HASLR_GROUP_TRANSPORT=host stages the exchange through host memory and lets the ranks share a device: the
     rehearsal on a one-GPU box), hxh_runs_all_sharded = one host thread per rank: chain (own reads) -> hx_edge_merge (ONE ncclAllGather of the packed
     records) -> cleaning (redundant) -> coordinates + consensus (own share of the queue, LPT) -> results through the process's memory -> rank 0
-    assembles. A step is timed from its start to the end of the consensus stage (the assembly that the call also makes is outside the metric)."""
+    assembles. A step is timed from its start to the end of the consensus stage (the assembly that the call also makes is outside the metric).
+    The line carries what the N = 1 line carries: `roofline` (algorithmic bytes of all ranks over the slowest rank's POA launch group), `cpu_baseline`
+    (a bounded sample, extrapolated), and an N = 1 pass of the plain path over the same data on rank 0's device (`n1_same_data`)."""
     import ctypes as C
 
     from haslr_amd import ctypes_defs as T
@@ -193,11 +299,14 @@ def run_group(args):
     if L.hx_group_create(n, None, tr.encode() if tr else None, C.byref(g)) != 0:
         raise SystemExit("bench.py --gpus %d (in-process group): %s" % (n, L.hx_last_error().decode()))
     transport = L.hx_group_transport(g).decode()
+    rr = (C.c_int * n)()
+    L.hx_group_rccl_ranks(g, rr)
     bounds = host.shard_bounds(ds, n)
     tables = [T.Backend() for _ in range(n)]
+    ctxs = [L.hx_group_ctx(g, r) for r in range(n)]
     t1 = time.perf_counter()
     for r in range(n):
-        c = L.hx_group_ctx(g, r)
+        c = ctxs[r]
         for k, v in hip.env_options().items():
             if L.hx_set_option(c, k.encode(), str(v).encode()) != 0:
                 raise SystemExit(L.hx_last_error().decode())
@@ -221,6 +330,8 @@ def run_group(args):
     for _ in range(args.warmup):
         for r in step()[0]:
             r.close()
+    for c in ctxs:
+        L.hx_timing_reset(c)
     total, last, stages = 0.0, None, None
     for _ in range(args.steps):
         if last:
@@ -233,32 +344,63 @@ def run_group(args):
     L.hx_group_exchange_stats(g, C.byref(by), C.byref(ms))
     fasta = last[0].assembly_fasta()
     sha = hashlib.sha256(fasta.encode()).hexdigest()
-    cells = sum(r.cns_stats()["dp_cells"] for r in last)
+    st_all = [r.cns_stats() for r in last]
+    cells = sum(x["dp_cells"] for x in st_all)
+    alg_bytes = sum((x["seq_bases"] + 3) // 4 for x in st_all) + sum(sum(len(q) for q in r.cns_out()) for r in last)   # SURVEY 8d, all ranks
+    poa_ms_rank = []
+    for c in ctxs:
+        tm, nl = (C.c_double * 4)(), (C.c_uint64 * 4)()
+        L.hx_timing_get(c, C.byref(tm), C.byref(nl))
+        poa_ms_rank.append(tm[3] / max(1, nl[3]))
+    poa_ms = max(poa_ms_rank)   # (the slowest rank's POA launch group per step)
     n_edges = last[0].n_edges_total
-    # the same data through ONE rank (device 0, plain context): the sharded assembly must equal it
+    # the same data through ONE rank (device 0, plain context): the sharded assembly must equal it, and its steady step is this line's N = 1 reference
     for r in last:
         r.close()
     L.hx_group_destroy(g)
     ctx = hip.HipContext(0)
-    ctx.upload(ds)
+    upload_and_reserve(ctx, ds)
     solo = host.Run(ds, prm, ctx.backend(), None)
     t0 = time.perf_counter()
     solo.all()
     t_solo = time.perf_counter() - t0
     same = hashlib.sha256(solo.assembly_fasta().encode()).hexdigest() == sha
-    solo.close(); ctx.close()
-    line = {"metric": "long-read bases/sec through backbone+consensus; GFA match + FASTA %identity", "value": ds.total_read_bases * args.steps / total, "unit": "long-read bases/s",
+    solo.close()
+    import torch
+
+    def sync():
+        torch.cuda.synchronize()
+    dt1, run1 = measure(ctx, ds, prm, ctx.backend(), args.steps, 0, 1, 0, sync, None, 0, sharded=False)   # (the solo pass above was the warm-up)
+    n1 = {"value": ds.total_read_bases * args.steps / dt1, "ms_per_step": dt1 / args.steps * 1e3, "steps": args.steps,
+          "what": "the plain single-context path (bench.py's N = 1 step) over the same data on device 0, timed here after the group's steps"}
+    run1.close(); ctx.close()
+    value = ds.total_read_bases * args.steps / total
+    achieved = alg_bytes / (poa_ms / 1e3) / 1e9 if poa_ms > 0 else 0.0
+    gcups = cells / (poa_ms / 1e3) / 1e9 if poa_ms > 0 else 0.0
+    valu_bound = VALU_PEAK_LANE_OPS / VALU_OPS_PER_CELL_MODEL / 1e9
+    line = {"metric": "long-read bases/sec through backbone+consensus; GFA match + FASTA %identity", "value": value, "unit": "long-read bases/s",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": total / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "fixed-size (configs[3] as named)" if as_named else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "scaling": "single GPU" if n == 1 else "fixed-size (configs[3] as named)" if as_named else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{wl['name']}: {glen} bp genome in {chroms} chromosome(s), {wl['model']}-like 25x long reads + PAF vs short-read contigs (BASELINE.json configs[{wl['config']}]"
                                    + (", read-sharded over %d GPUs as BASELINE names it)" % n if as_named else " x%d, read-sharded)" % n),
                        "launch": f"in-process group: {n} ranks as threads of this process (hx_group_create / hx_edge_merge / hxh_runs_all_sharded = haslr_assemble --gpus {n}), transport {transport}",
                        "reads": ds.reads.n, "long_read_bases": ds.total_read_bases, "paf_records": ds.hits.n, "edges": int(n_edges),
                        "parallelism": f"reads+edges sharded x{n}, 1 all-gather of edge records ({transport}), results through process memory",
-                       "edge_record_exchange_bytes": by.value, "edge_record_exchange_ms": ms.value},
-            "stage_s": stages, "dp_cells_per_step": cells,
+                       "rccl_ranks": list(rr), "edge_record_exchange_bytes": by.value, "edge_record_exchange_ms": ms.value,
+                       "n1_same_data_value": n1["value"], "value_over_n1_same_data": value / n1["value"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * n, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * n), "traffic": None,
+                         "kernel": "k_poa (launch group of the slowest rank)", "kernel_ms_per_launch": poa_ms, "kernel_ms_per_launch_by_rank": poa_ms_rank,
+                         "algorithmic_bytes_per_launch": alg_bytes, "gcups": gcups, "dp_cells_per_launch": cells, "valu_bound_gcups": valu_bound * n, "frac_of_valu_bound": gcups / (valu_bound * n),
+                         "note": "all ranks' algorithmic bytes / cells over the slowest rank's POA launch group; peak = N x one GPU's"
+                                 + ("; the ranks SHARE one device in this rehearsal (transport host): their kernels interleave, the figure says nothing about N devices" if transport == "host" and n > 1 else "")},
+            "stage_s": stages, "dp_cells_per_step": cells, "n1_same_data": n1,
             "assembly": {"sha256": sha, "contigs": fasta.count(">"), "matches_single_gpu": same, "single_gpu_pass_s": t_solo},
             "ingest": {"seconds": t_parse, "upload_seconds_all_ranks": t_upload}}
+    if not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_sample(ds, share=max(8, 4 * n))
+        except Exception as e:  # noqa: BLE001
+            line["cpu_baseline"] = {"error": str(e)}
     print(json.dumps(line), flush=True)
     if not same:
         raise SystemExit("in-process group: the sharded assembly differs from the single-GPU pass")
@@ -275,6 +417,7 @@ def main():
     ap.add_argument("--poa-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs1", action="store_true", help="skip the extra E. coli-size (configs[1]) measurement")
+    ap.add_argument("--no-one-shot", action="store_true", help="skip the one-shot figures (haslr_assemble end to end in a process of its own, the cold first pass of a fresh context)")
     ap.add_argument("--no-configs3", action="store_true", help="skip the extra D. melanogaster-size (configs[3], 140 Mb on this one GPU: the many-edge regime) measurement")
     args = ap.parse_args()
 
@@ -288,8 +431,8 @@ def main():
     # HASLR_BENCH_FORCE_DIST=1 (testing): the N>1 code path - process group, record all-gather, results exchange - with whatever world size the launcher
     # gave, also 1: a one-GPU box then executes the RCCL collectives of the multi-GPU path for real
     dist_on = world > 1 or os.environ.get("HASLR_BENCH_FORCE_DIST") == "1"
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        return run_group(args)                     # no launcher: the ranks live inside this process, like haslr_assemble --gpus N
+    if world == 1 and (args.gpus > 1 or os.environ.get("HASLR_BENCH_FORCE_GROUP") == "1"):
+        return run_group(args)                     # no launcher: the ranks live inside this process, like haslr_assemble --gpus N (HASLR_BENCH_FORCE_GROUP=1: also for one rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     # HASLR_DIST_BACKEND=gloo (testing): the N>1 path on a box with fewer GPUs than ranks - ranks share devices, collectives go through host memory
@@ -319,13 +462,21 @@ def main():
     t_parse = time.perf_counter() - t0
     in_bytes = sum(os.path.getsize(pre + x) for x in (".contigs.fa", ".reads.fa", ".paf"))
     prm = ds.params()
+    one_shot = {}
+    if world == 1 and not dist_on and not args.no_one_shot:
+        # the drop-in binary, once, in a process of its own - before this process holds a context (the device is the binary's alone, as in real use)
+        one_shot["cli"] = cli_e2e(pre, args.workload)
+        log(f"[rank {rank}] haslr_assemble end to end: {one_shot['cli']}")
     ctx = hip.HipContext(dev_index)
     if args.poa_block:
         ctx.set_poa_block(args.poa_block)
-    t1 = time.perf_counter()
-    ctx.upload(ds)   # inputs resident in HBM before the timed region
-    t_upload = time.perf_counter() - t1
-    log(f"[rank {rank}] dataset {pre}: {ds.reads.n} reads, {ds.total_read_bases} bases, {ds.hits.n} PAF records; parse {t_parse:.2f} s ({in_bytes / 1e6 / t_parse:.0f} MB/s), upload {t_upload:.2f} s")
+    up = upload_and_reserve(ctx, ds)   # inputs resident in HBM before the timed region
+    t_upload = up["upload_s"]
+    log(f"[rank {rank}] dataset {pre}: {ds.reads.n} reads, {ds.total_read_bases} bases, {ds.hits.n} PAF records; parse {t_parse:.2f} s ({in_bytes / 1e6 / t_parse:.0f} MB/s), upload {t_upload:.2f} s, workspace reserved beside it in {up['workspace_reserve_s']:.2f} s")
+    if world == 1 and not dist_on and not args.no_one_shot:
+        one_shot.update(cold_pass(ctx, ds, prm, ctx.backend()))
+        one_shot["start_up"] = up
+        log(f"[rank {rank}] cold first pass {one_shot['cold_first_pass_ms']:.1f} ms (consensus {one_shot['cold_consensus_ms']:.1f} ms; host parts {one_shot['cold_poa_host_ms']}; arena {one_shot['workspace_arena']})")
 
     lr_begin, gathered = 0, [0]
     if dist_on:
@@ -369,6 +520,7 @@ def main():
     achieved = alg_bytes / (poa_ms / 1e3) / 1e9 if poa_ms > 0 else 0.0
     phase = ctx.poa_phase_cycles()
     stage_ms = {k: v * 1e3 for k, v in last.timings().items()}
+    poa_host = ctx.poa_host_times()   # of the last step's consensus call
     kernel_ms = {k: v["ms"] / max(1, v["launches"]) for k, v in tim.items()}
 
     # ---- the assembly (outside the timed region): every rank stitches; N>1: identical on all ranks and equal to a single-GPU pass
@@ -420,7 +572,7 @@ def main():
     if rank == 0:
         value = ds.total_read_bases * args.steps / dt
         gcups = cells / (poa_ms / 1e3) / 1e9 if poa_ms > 0 else 0.0
-        valu_bound = VALU_PEAK_LANE_OPS / VALU_OPS_PER_CELL_MODEL / 1e9
+        valu_bound = VALU_PEAK_LANE_OPS / VALU_OPS_PER_CELL_MODEL / 1e9 * world   # (N > 1: all ranks' cells over the slowest rank's launch group, against N GPUs)
         # the longest edge's serial chain of {decode, DP, traceback, graph update, order update, CSR rebuild}: lane-0 cycle counters of the kernel
         critical_ms = sum(phase["slowest_edge"].values()) / SHADER_CLOCK_HZ * 1e3
         # SQ counters of the POA launch group, collected offline for exactly this workload (profiles/*_sq_counters.json: separate --pmc passes)
@@ -457,7 +609,7 @@ def main():
                                    f"(BASELINE.json configs[{wl['config']}]{(', read-sharded over %d GPUs as BASELINE names it' % world) if as_named else ((' x%d = %d chromosomes, read-sharded' % (world, chroms)) + ('; the shape of configs[4] at %.2f x its size' % (glen / 3.1e9) if world == 8 else '') if world > 1 else '')})",
                        "reads": ds.reads.n, "long_read_bases": ds.total_read_bases, "paf_records": ds.hits.n, "edges": int(n_edges),
                        "poa_block_threads": args.poa_block or "auto", "parallelism": f"reads+edges sharded x{world}, 1 all-gather of edge records + 1 of results" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * world),
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_poa (launch group: one kernel per lane-count class, concurrent)", "kernel_ms_per_launch": poa_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "gcups": gcups, "dp_cells_per_launch": cells, "poa_workspace_bytes": ctx.poa_workspace_bytes(), "valu_bound_gcups": valu_bound, "frac_of_valu_bound": gcups / valu_bound,
                          "valu_peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "valu_ops_per_cell_model": VALU_OPS_PER_CELL_MODEL, **sq_fig,
@@ -465,10 +617,25 @@ def main():
                          "note": "POA is an O(L^2) integer DP over O(L) bytes: HBM fraction is low by construction (SURVEY.md 8d); GCUPS against the VALU issue bound "
                                  "(256 CU x 4 SIMD-32 x 2.4 GHz lane-ops/s / 10 lane-ops per cell) is the figure of merit; valu_lane_ops_per_cell / valu_issue_util / wait_share are "
                                  "what the SQ counters of the committed profile say the kernel really issues; critical_path_ms = the slowest edge's serial chain (its lane-0 cycle counters / 2.4 GHz)"},
-            "stage_ms": stage_ms, "kernel_ms": kernel_ms, "poa_phase_cycles": {"edges": phase["edges"], "slowest_edge": phase["slowest_edge"]}, "assembly": assembly, "gfa": gfa_gpu,
+            "stage_ms": stage_ms, "kernel_ms": kernel_ms, "consensus_host_ms": {**poa_host, "stage_minus_launch_group_ms": stage_ms.get("consensus", 0) - poa_ms}, "poa_phase_cycles": {"edges": phase["edges"], "slowest_edge": phase["slowest_edge"]}, "assembly": assembly, "gfa": gfa_gpu,
             # outside the timed region (the metric starts with parsed, resident inputs): text ingest and the PCIe upload
             "ingest": {"seconds": t_parse, "input_mb": in_bytes / 1e6, "mb_per_s": in_bytes / 1e6 / t_parse, "threads": os.environ.get("HASLR_IO_THREADS", "auto (<= 16)"), "upload_seconds": t_upload},
         }
+        if world > 1:
+            line["config"].update({"edge_record_exchange_ms": assembly.get("edge_record_exchange_ms"), "edge_record_exchange_bytes": assembly.get("edge_record_exchange_bytes"),
+                                   "rccl_ranks": dist.get_world_size() if backend_name == "nccl" else 0})
+            if not args.no_cpu_baseline:
+                try:
+                    line["cpu_baseline"] = cpu_sample(ds, share=max(8, 4 * world))
+                except Exception as e:  # noqa: BLE001
+                    line["cpu_baseline"] = {"error": str(e)}
+        if one_shot:
+            line["one_shot"] = one_shot
+            ms_step = line["ms_per_step"]
+            line["config"].update({"cold_first_pass_ms": one_shot.get("cold_first_pass_ms"), "cold_consensus_ms": one_shot.get("cold_consensus_ms"),
+                                   "cold_over_steady": (one_shot["cold_first_pass_ms"] / ms_step) if one_shot.get("cold_first_pass_ms") else None,
+                                   "cli_e2e_s": one_shot.get("cli", {}).get("cli_e2e_s"), "cli_stages_s": one_shot.get("cli", {}).get("stages_s"),
+                                   "cli_assembly_equals_in_process": one_shot.get("cli", {}).get("asm_final_fa_sha256") == sha})
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(ds, cns, gfa_gpu, work_dir)
@@ -509,11 +676,24 @@ def main():
                 t0 = time.perf_counter()
                 pre3 = make_dataset(w3, w3["genome"], "gpu")
                 t_sim = time.perf_counter() - t0
+                # a FRESH context for this leg (the one-shot figures need one), and before it exists the binary itself, once, on the same files
+                ctx.close()
+                torch.cuda.empty_cache()
+                one3 = {}
+                if not args.no_one_shot:
+                    one3["cli"] = cli_e2e(pre3, "fly")
+                    log(f"[configs3] haslr_assemble end to end: {one3['cli']}")
                 t0 = time.perf_counter()
                 ds3 = host.Dataset(pre3 + ".contigs.fa", pre3 + ".reads.fa", pre3 + ".paf")
                 t_parse3 = time.perf_counter() - t0
-                ctx.upload(ds3)
+                ctx = hip.HipContext(dev_index)
+                up3 = upload_and_reserve(ctx, ds3)
+                if not args.no_one_shot:
+                    one3.update(cold_pass(ctx, ds3, ds3.params(), ctx.backend()))
+                    one3["start_up"] = up3
+                    log(f"[configs3] cold first pass {one3['cold_first_pass_ms']:.1f} ms (consensus {one3['cold_consensus_ms']:.1f} ms; host parts {one3['cold_poa_host_ms']}; arena {one3['workspace_arena']})")
                 dt3, run3 = measure(ctx, ds3, ds3.params(), ctx.backend(), 2, 1, 1, 0, sync, None, 0)
+                host3 = ctx.poa_host_times()
                 tm3 = ctx.timing()
                 st3 = run3.cns_stats()
                 p3 = tm3["poa"]["ms"] / max(1, tm3["poa"]["launches"])
@@ -538,8 +718,14 @@ def main():
                                     "kernel_ms_per_launch": p3, "gcups": st3["dp_cells"] / (p3 / 1e3) / 1e9, "dp_cells_per_launch": st3["dp_cells"],
                                     "long_read_bases": ds3.total_read_bases, "poa_workspace_bytes": ctx.poa_workspace_bytes(), "consensus_sha256": h3.hexdigest(),
                                     "critical_path_ms": sum(ph3["slowest_edge"].values()) / SHADER_CLOCK_HZ * 1e3, "stage_ms": {k: v * 1e3 for k, v in run3.timings().items()},
-                                    "simulate_s": t_sim, "parse_s": t_parse3, "pruning": ctx.poa_prune_stats(), **sq3}
+                                    "simulate_s": t_sim, "parse_s": t_parse3, "pruning": ctx.poa_prune_stats(), **sq3,
+                                    "consensus_host_ms": {**host3, "stage_minus_launch_group_ms": run3.timings()["consensus"] * 1e3 - p3}, "one_shot": one3}
                 # the many-edge figures inside `config` and `roofline`, the objects the driver's record keeps (BENCH_rNN.json.parsed)
+                if one3:
+                    line["config"].update({"configs3_cold_first_pass_ms": one3.get("cold_first_pass_ms"), "configs3_cold_consensus_ms": one3.get("cold_consensus_ms"),
+                                           "configs3_cold_over_steady": one3["cold_first_pass_ms"] / line["configs3"]["ms_per_step"] if one3.get("cold_first_pass_ms") else None,
+                                           "configs3_cli_e2e_s": one3.get("cli", {}).get("cli_e2e_s"), "configs3_cli_stages_s": one3.get("cli", {}).get("stages_s"),
+                                           "configs3_consensus_stage_minus_launch_group_ms": line["configs3"]["consensus_host_ms"]["stage_minus_launch_group_ms"]})
                 line["config"].update({"configs3_ms_per_step": line["configs3"]["ms_per_step"], "configs3_gcups": line["configs3"]["gcups"], "configs3_edges": run3.n_edges,
                                        "configs3_value": line["configs3"]["value"], "configs3_consensus_sha256": h3.hexdigest()})
                 pr3 = line["configs3"]["pruning"]

@@ -42,6 +42,21 @@ static double real_time() {
     return t.tv_sec + t.tv_usec / 1e6;
 }
 
+// HASLR_STAGE_TIMES=<file>: what a one-shot run spent where, as one JSON object (bench.py's cli_e2e leg reads it; the stderr lines stay the reference's)
+struct StageTimes {
+    std::vector<std::pair<std::string, double>> v;
+    void add(const char* k, double s) { v.emplace_back(k, s); }
+    void write(const char* path) const {
+        FILE* f = path && *path ? fopen(path, "w") : nullptr;
+        if (!f) return;
+        fprintf(f, "{");
+        for (size_t i = 0; i < v.size(); i++) fprintf(f, "%s\"%s\": %.6f", i ? ", " : "", v[i].first.c_str(), v[i].second);
+        fprintf(f, "}\n");
+        fclose(f);
+    }
+};
+static uint64_t file_bytes(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode) ? (uint64_t)st.st_size : 0; }
+
 static void help_short() { fprintf(stderr, "usage: haslr_assemble -c contig.fasta -l longread.fasta -m lr2contig.paf -d outdir [options]\n"); }
 
 static void help(const hx_params& p) {
@@ -129,24 +144,33 @@ int main(int argc, char* argv[]) {
     auto elapsed = [&]() { fprintf(stderr, "       elapsed time %.2lf CPU seconds (%.2lf real seconds)\n\n", cpu_time() - c0, real_time() - r0); };
 
     setenv("GPU_MAX_HW_QUEUES", "8", 0);   // before HIP initialises: the POA launch classes overlap on separate hardware queues (include/haslr_hip.h)
+    StageTimes st;
     // --gpus N > 1 (or HASLR_FORCE_GROUP=1, which sends one GPU through the same code): a group of contexts, one rank per GPU
     const bool grouped = gpus > 1 || getenv("HASLR_FORCE_GROUP");
     hx_ctx* ctx = nullptr;
     hx_group* group = nullptr;
-    if (grouped) {
-        std::vector<int> devs((size_t)gpus);
-        for (int r = 0; r < gpus; r++) devs[(size_t)r] = device + r;   // --device with --gpus N: the ranks run on devices device .. device + N - 1
-        if (hx_group_create(gpus, device ? devs.data() : nullptr, getenv("HASLR_GROUP_TRANSPORT"), &group) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
-        if (const char* ts = getenv("HASLR_GROUP_TIMEOUT_S")) hx_group_set_timeout(group, atof(ts));
-        fprintf(stderr, "[NOTE] %d GPU ranks in this process, edge-record exchange over %s\n\n", gpus, hx_group_transport(group));
-        ctx = hx_group_ctx(group, 0);
-        if (poa_block) for (int r = 0; r < gpus; r++) hx_set_poa_block(hx_group_ctx(group, r), poa_block);
-    } else {
-        if (hx_ctx_create(device, nullptr, &ctx) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
-        if (poa_block) hx_set_poa_block(ctx, poa_block);
-    }
-    // The library reads no environment: this APPLICATION hands the HX_* variables that name library options (hx_option_names) to its contexts, once
-    {
+    // The device side of the start-up runs on a thread of its own BESIDE the parse of the text inputs (this program runs once: main.cpp:28-228 of the
+    // reference; what a user of haslr.py:66 waits for is the whole run, not the hot path): the HIP runtime and the context(s), the options, and the arena
+    // of the consensus workspace (hx_poa_reserve: up to 140 GB for a genome of 10^8 bases and more - seconds of allocation that used to sit inside the
+    // consensus stage). The estimate is 32 bytes of workspace per long-read base (12 Mb: 9.2 GB for 3.0e8 bases), at most what a call ever settles on.
+    std::string gpu_error;
+    double t_gpu_init = 0, t_reserve = 0;
+    const uint64_t lr_bytes = long_fofn ? 0 : file_bytes(long_path);
+    const uint64_t reserve_bytes = getenv("HASLR_NO_RESERVE") ? 0 : std::min<uint64_t>(142ull << 30, lr_bytes * 32);
+    auto gpu_start = [&]() {
+        const double g0 = real_time();
+        if (grouped) {
+            std::vector<int> devs((size_t)gpus);
+            for (int r = 0; r < gpus; r++) devs[(size_t)r] = device + r;   // --device with --gpus N: the ranks run on devices device .. device + N - 1
+            if (hx_group_create(gpus, device ? devs.data() : nullptr, getenv("HASLR_GROUP_TRANSPORT"), &group) != 0) { gpu_error = hx_last_error(); return; }
+            if (const char* ts = getenv("HASLR_GROUP_TIMEOUT_S")) hx_group_set_timeout(group, atof(ts));
+            ctx = hx_group_ctx(group, 0);
+            if (poa_block) for (int r = 0; r < gpus; r++) hx_set_poa_block(hx_group_ctx(group, r), poa_block);
+        } else {
+            if (hx_ctx_create(device, nullptr, &ctx) != 0) { gpu_error = hx_last_error(); return; }
+            if (poa_block) hx_set_poa_block(ctx, poa_block);
+        }
+        // The library reads no environment: this APPLICATION hands the HX_* variables that name library options (hx_option_names) to its contexts, once
         const std::string names = std::string(",") + hx_option_names() + ",prof1,prof2,prof3,";
         for (char** ev = environ; ev && *ev; ev++) {
             if (strncmp(*ev, "HX_", 3) != 0) continue;
@@ -156,19 +180,35 @@ int main(int argc, char* argv[]) {
             for (char& ch : key) ch = (char)tolower((unsigned char)ch);
             if (names.find("," + key + ",") == std::string::npos) { fprintf(stderr, "[WARNING] %.*s is not an option of this build (ignored)\n", (int)(eq - *ev), *ev); continue; }
             for (int r = 0; r < (grouped ? gpus : 1); r++)
-                if (hx_set_option(grouped ? hx_group_ctx(group, r) : ctx, key.c_str(), eq + 1) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
+                if (hx_set_option(grouped ? hx_group_ctx(group, r) : ctx, key.c_str(), eq + 1) != 0) { gpu_error = hx_last_error(); return; }
         }
-    }
+        t_gpu_init = real_time() - g0;
+        if (reserve_bytes) {
+            const double r0 = real_time();
+            std::vector<std::thread> rs;
+            for (int r = 0; r < (grouped ? gpus : 1); r++) rs.emplace_back([&, r]() { (void)hx_poa_reserve(grouped ? hx_group_ctx(group, r) : ctx, reserve_bytes); });   // (best effort: the consensus call allocates what is missing)
+            for (auto& t : rs) t.join();
+            t_reserve = real_time() - r0;
+        }
+    };
+    std::thread gpu_thread(gpu_start);
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } gpu_joiner{gpu_thread};
 
     fprintf(stderr, "[NOTE] loading contig sequences, long read sequences and alignments...\n");
     // index.contig / index.longread of the output directory are loaded when they exist, written when they do not (main.cpp:39-103)
     int used_ci = 0, used_li = 0;
+    const double tl0 = real_time();
     hxh_dataset* ds = hxh_dataset_load_cached(out_dir.c_str(), contig_path.c_str(), long_path.c_str(), long_fofn, mapping_path.c_str(), mapping_fofn, num_threads /* -t */,
                                               &used_ci, &used_li);
     if (!ds) { fprintf(stderr, "%s\n", hxh_last_error()); return EXIT_FAILURE; }
+    st.add("load_s", real_time() - tl0);
     if (used_ci) fprintf(stderr, "[NOTE] reading contig index: %s/index.contig...\n", out_dir.c_str());
     if (used_li) fprintf(stderr, "[NOTE] reading long read and alignment index: %s/index.longread...\n", out_dir.c_str());
-    if (!used_ci && hxh_dataset_write_contig_index(ds, (out_dir + "/index.contig").c_str()) != 0) { fprintf(stderr, "%s\n", hxh_last_error()); return EXIT_FAILURE; }
+    {
+        const double t0 = real_time();
+        if (!used_ci && hxh_dataset_write_contig_index(ds, (out_dir + "/index.contig").c_str()) != 0) { fprintf(stderr, "%s\n", hxh_last_error()); return EXIT_FAILURE; }
+        st.add("index_contig_write_s", real_time() - t0);
+    }
     hx_contigs vc; hx_reads vr; hx_hits vh; const uint64_t* rho;
     hxh_dataset_views(ds, &vc, &vr, &vh, &rho);
     // the reference prints ONE "loaded N alignments" line, N = the records that survive the load-time filters (main.cpp:70,103). From an
@@ -177,6 +217,13 @@ int main(int argc, char* argv[]) {
     if (used_li) fprintf(stderr, "       loaded %lu alignments\n", (unsigned long)vh.n);
     prm.uniq_freq = hxh_dataset_uniq_freq(ds);
     fprintf(stderr, "[NOTE] calculating kmer frequency of unique contigs\n       mean: %.2lf\n", prm.uniq_freq);
+    {   // the device side of the start-up has had the whole parse to itself
+        const double t0 = real_time();
+        gpu_thread.join();
+        st.add("gpu_init_s", t_gpu_init); st.add("workspace_reserve_s", t_reserve); st.add("gpu_start_wait_after_load_s", real_time() - t0);
+        if (!gpu_error.empty()) { fprintf(stderr, "[ERROR] %s\n", gpu_error.c_str()); return EXIT_FAILURE; }
+        if (grouped) fprintf(stderr, "[NOTE] %d GPU ranks in this process, edge-record exchange over %s\n", gpus, hx_group_transport(group));
+    }
     elapsed();
     if (grouped) {
         // inputs are replicated on every GPU (they fit: DESIGN.md 3); reads are sharded by id range, edges by estimated DP cost
@@ -224,7 +271,11 @@ int main(int argc, char* argv[]) {
         if (tooling_attached()) { for (hxh_run* r : runs) hxh_run_free(r); hxh_dataset_free(ds); hx_group_destroy(group); return EXIT_SUCCESS; }   // (profilers, sanitizers, leak checks: the ordinary exit)
         _exit(EXIT_SUCCESS);
     }
-    if (hx_upload(ctx, &vc, &vr, &vh, rho) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
+    {
+        const double t0 = real_time();
+        if (hx_upload(ctx, &vc, &vr, &vh, rho) != 0) { fprintf(stderr, "[ERROR] %s\n", hx_last_error()); return EXIT_FAILURE; }
+        st.add("upload_s", real_time() - t0);
+    }
     hx_set_prefiltered(ctx, used_li);
 
     hx_backend be;
@@ -237,8 +288,9 @@ int main(int argc, char* argv[]) {
         {"[NOTE] calculating long read coordinates between anchors...", hxh_run_coords},
         {"[NOTE] calling consensus sequence between anchors...", hxh_run_consensus},
         {"[NOTE] generating the assembly from the cleaned backbone graph...", hxh_run_assemble}};
-    // index.longread: written when the filtered set is known, before the GPU stages go on, like the reference does. HASLR_INDEX_ASYNC=1
-    // writes it on a thread of its own beside the later stages instead (measured: see DESIGN.md 9.2; not the default).
+    // index.longread: written when the filtered set is known (the reference writes it at load time, main.cpp:65-89) - on a thread of its own beside the
+    // later stages (round 6: the default; it is a gigabyte at 140 Mb and nothing later reads it), joined before the program ends. HASLR_INDEX_SYNC=1
+    // writes it before the GPU stages go on, as before.
     std::thread index_writer;
     std::string index_error;
     auto finish_index = [&]() -> bool {
@@ -246,26 +298,38 @@ int main(int argc, char* argv[]) {
         if (!index_error.empty()) { fprintf(stderr, "%s\n", index_error.c_str()); return false; }
         return true;
     };
-    for (auto& st : stages) {
-        fprintf(stderr, "%s\n", st.note);
-        if (st.fn(run) != 0) {
+    static const char* stage_keys[5] = {"chain_s", "graph_s", "coords_s", "consensus_s", "assemble_s"};
+    int stage_no = 0;
+    for (auto& sg : stages) {
+        fprintf(stderr, "%s\n", sg.note);
+        const double ts0 = real_time();
+        if (sg.fn(run) != 0) {
             fprintf(stderr, "[ERROR] %s\n", hxh_last_error());
             finish_index();
             hxh_run_free(run);   // joins the GFA writer threads: nothing streams into backbone.0x.gfa while the static destructors run
             return EXIT_FAILURE;
         }
-        if (st.fn == hxh_run_chain && !used_li) fprintf(stderr, "       loaded %lu alignments\n", (unsigned long)hxh_run_chain_out(run)->n_aln);   // (the count the reference prints at load time)
-        if (st.fn == hxh_run_chain && !used_li) {
+        st.add(stage_keys[stage_no++], real_time() - ts0);
+        if (sg.fn == hxh_run_chain && !used_li) fprintf(stderr, "       loaded %lu alignments\n", (unsigned long)hxh_run_chain_out(run)->n_aln);   // (the count the reference prints at load time)
+        if (sg.fn == hxh_run_chain && !used_li) {
             const std::string path = out_dir + "/index.longread";
-            if (getenv("HASLR_INDEX_ASYNC"))
+            const double tw0 = real_time();
+            if (!getenv("HASLR_INDEX_SYNC"))
                 index_writer = std::thread([run, path, &index_error]() {
                     if (hxh_run_write_longread_index(run, path.c_str()) != 0) { index_error = hxh_last_error(); if (index_error.empty()) index_error = "[ERROR] could not write " + path; remove(path.c_str()); }
                 });
             else if (hxh_run_write_longread_index(run, path.c_str()) != 0) { fprintf(stderr, "%s\n", hxh_last_error()); return EXIT_FAILURE; }
+            st.add("index_longread_write_sync_s", real_time() - tw0);
         }
         elapsed();
     }
-    if (!finish_index()) return EXIT_FAILURE;
+    {
+        const double t0 = real_time();
+        if (!finish_index()) return EXIT_FAILURE;
+        st.add("index_longread_join_s", real_time() - t0);
+    }
+    st.add("total_s", real_time() - r0);
+    st.write(getenv("HASLR_STAGE_TIMES"));
     fprintf(stderr, "[NOTE] cleaning up the memory!\n");
     if (!tooling_attached()) {   // everything is written and closed: the release of up to ~250 GB of device memory and of the host arrays is left
                                             // to the end of the process (1.5-2 s of a 10 s run at 140 Mb); HASLR_FULL_TEARDOWN=1 frees object by object (leak checks)

@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 #include <array>
+#include <mutex>
 
 #include "../../include/haslr_hip.h"
 #include "host/haslr_host.h"
@@ -91,21 +92,37 @@ struct PoaPlan {
     std::vector<uint32_t> nseq;
 };
 
+// The POA workspace is ONE device allocation (round 6): an arena that every pool of a batch is carved out of. Forty pools used to be forty synchronous
+// hipMalloc calls inside the first consensus call of a context - seconds of a one-shot run at 140 Mb (215 GB), against a 0.5 s hot path. The arena can be
+// reserved ahead of the first call (hx_poa_reserve: the CLI does it on a thread of its own while the text inputs are parsed), grows when a batch needs
+// more (never shrinks), and is carved anew for every batch: nothing in it outlives a batch.
+template <class T> struct AP { T* p = nullptr; size_t off = 0; };   // a pool: pointer into the arena, byte offset of the current carving
 struct PoaPoolBufs {
-    DV<uint8_t> code, n_aligned, mark, check, row_code, row_sink, seq;
-    DV<uint32_t> aligned, in_head, in_tail, out_head, out_tail, rank2node, node2rank, stack, row_pred_off, pred_rank, e_from, e_to, e_next_in, e_next_out;
-    DV<int32_t> score, pred, e_w, aln_node, aln_pos, H, pred_w;
-    DV<uint32_t> row_meta, row_pred0, row_pred1;
-    DV<uint4> nrec, nrec2;
-    DV<uint8_t> dir, dirw; DV<uint32_t> wslot;
-    DV<unsigned long long> mbox; DV<int32_t> sinkbuf; DV<uint32_t> csync; DV<uint16_t> row_al;   // cluster mode (edges shared by several workgroups)
-    void release_all() {
-        code.release(); n_aligned.release(); mark.release(); check.release(); row_code.release(); row_sink.release(); seq.release();
-        aligned.release(); in_head.release(); in_tail.release(); out_head.release(); out_tail.release(); rank2node.release(); node2rank.release();
-        stack.release(); row_pred_off.release(); pred_rank.release(); e_from.release(); e_to.release(); e_next_in.release(); e_next_out.release();
-        score.release(); pred.release(); e_w.release(); aln_node.release(); aln_pos.release(); H.release(); row_meta.release(); row_pred0.release();
-        row_pred1.release(); nrec.release(); nrec2.release(); pred_w.release(); dir.release(); dirw.release(); wslot.release(); mbox.release(); sinkbuf.release(); csync.release(); row_al.release();
+    AP<uint8_t> code, n_aligned, mark, check, row_code, row_sink, seq;
+    AP<uint32_t> aligned, in_head, in_tail, out_head, out_tail, rank2node, node2rank, stack, row_pred_off, pred_rank, e_from, e_to, e_next_in, e_next_out;
+    AP<int32_t> score, pred, e_w, aln_node, aln_pos, H, pred_w;
+    AP<uint32_t> row_meta, row_pred0, row_pred1;
+    AP<uint4> nrec, nrec2;
+    AP<uint8_t> dir, dirw; AP<uint32_t> wslot;
+    AP<unsigned long long> mbox; AP<int32_t> sinkbuf; AP<uint32_t> csync; AP<uint16_t> row_al;   // cluster mode (edges shared by several workgroups)
+    AP<char> cns;                                                                                  // consensus strings as the kernels leave them (capacity = node estimate per edge)
+};
+struct PoaArena {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    uint64_t n_alloc = 0;       // device allocations made for it so far
+    double alloc_ms = 0;        // ... and the wall time they took
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    hipError_t ensure(size_t bytes) {   // at least `bytes`; the contents are not kept
+        if (bytes <= cap && p) return hipSuccess;
+        const auto t0 = std::chrono::steady_clock::now();
+        release();
+        const hipError_t e = hipMalloc((void**)&p, std::max<size_t>(bytes, 256));
+        if (e == hipSuccess) cap = std::max<size_t>(bytes, 256); else p = nullptr;
+        n_alloc++; alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return e;
     }
+    ~PoaArena() { release(); }
 };
 }  // namespace
 
@@ -208,6 +225,9 @@ struct hx_ctx {
     struct { DV<uint32_t> sel, nsupp, t_lr, t_sp, t_ep, best_list; DV<uint64_t> cap, out_off, b1, e1, b2, e2; DV<uint8_t> cur; } sc_coords;
     // POA workspace lives as long as the context: allocating tens of GB per call costs more than the kernel
     PoaPoolBufs poa_pools;
+    PoaArena poa_arena;
+    std::mutex poa_arena_mu;            // hx_poa_reserve may run on a thread of its own beside the upload and the first stages
+    double poa_host_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // host wall time of the last consensus call: plan, workspace, enqueue, device wait, collect, finish, (unused), total
     uint64_t poa_budget = 0;
     DV<hxk::PoaEdge> poa_edges;
     DV<hxk::PoaSeq> poa_seqs;
@@ -216,7 +236,8 @@ struct hx_ctx {
     uint64_t poa_workspace_bytes = 0;   // largest POA workspace (pools) a call of this context has used
     uint64_t poa_last_workspace_bytes = 0, poa_free_at_first_call = 0;   // ... the last call's; free device memory when the budget was taken
     HxOptions opt;
-    DV<char> poa_cns;
+    DV<uint32_t> poa_gather;            // collection: (source offset lo / hi, destination offset lo / hi, length) of every finished edge's consensus
+    DV<char> poa_cns_dense;             // ... the strings side by side, as they are downloaded
     DV<unsigned long long> poa_phase_d, poa_cells_d;
     std::vector<unsigned long long> poa_phase;   // per edge x 6, cycles of the last hx_poa_batch
 
@@ -289,7 +310,19 @@ static int up(DV<T>& d, const T* h, size_t n) {
     return 0;
 }
 
+static int upload_inputs(hx_ctx* c, const hx_contigs* ctg, const hx_reads* rd, const hx_hits* h, const uint64_t* rho);
 extern "C" int hx_upload(hx_ctx* c, const hx_contigs* ctg, const hx_reads* rd, const hx_hits* h, const uint64_t* rho) {
+    if (upload_inputs(c, ctg, rd, h, rho) == 0) return 0;
+    // a consensus arena reserved ahead of the inputs (hx_poa_reserve) must never be what keeps them out: give it back and try once more
+    {
+        std::lock_guard<std::mutex> lk(c->poa_arena_mu);
+        if (!c->poa_arena.cap) return -1;
+        (void)hipGetLastError();
+        c->poa_arena.release();
+    }
+    return upload_inputs(c, ctg, rd, h, rho);
+}
+static int upload_inputs(hx_ctx* c, const hx_contigs* ctg, const hx_reads* rd, const hx_hits* h, const uint64_t* rho) {
     HIPCHK(hipSetDevice(c->device));
     c->n_contigs = ctg->n; c->n_reads = rd->n; c->n_hits = h->n; c->n_ops = h->cg_off[h->n];
     if (up(c->km, ctg->mean_kmer, ctg->n) || up(c->clen, ctg->len, ctg->n)) return -1;
@@ -634,6 +667,7 @@ constexpr int NCLS = 11;
 constexpr uint64_t kPoaLdsMax = 140 * 1024;   // dynamic LDS of a POA workgroup at most (160 KB per CU less the 1024-lane kernel's static 16.5 KB: sink lists, wave mailboxes)
 const int kClassNT[NCLS] = {0, 1024, 512, 256, 128, 64, 1024, 512, 256, 128, 64};
 constexpr size_t kManyEdges = 3000;
+constexpr uint64_t kPoaAutoCapBytes = 140ull * 1000 * 1000 * 1000;   // workspace a call takes at most when option poa_workspace_gb is not set
 
 // One consensus call: the PLAN (sub-sequences, per-edge capacities, launch classes, workspace slots and batches against the memory budget), the
 // LAUNCH of a batch, and the COLLECTION of its results with the verdict on every edge (done / again with more room / again another way).
@@ -664,6 +698,7 @@ struct PoaCall {
     uint64_t ring_kb_wave = 0;
     double balance_f = 1.25;
     uint32_t balance_nt = 512;
+    uint64_t score_abs_max = 8;        // largest |match|, |mismatch|, |gap| of the call: |score| <= that x (nodes + columns) must fit the keys
 
     PoaCall(hx_ctx* c_, const PoaInput& in_, const hx_poa_params* pp_) : c(c_), in(in_), pp(pp_), o(c_->opt), ne(in_.n_edge) {}
     double ms_since_start() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
@@ -727,6 +762,10 @@ struct PoaCall {
         // multi-wave launches of a call whose CUs are all busy; a chain-bound call (hundreds of edges, the longest one is the step) gains nothing
         // from it - a row stays a row - so there the full-matrix instances run. poa_prune: -1 automatic, 0 never, else the percentage.
         prune_pct = o.poa_prune < 0 ? (many_edges ? 95u : 0u) : (uint32_t)o.poa_prune;
+        // The bound U = H + match x (columns left) and the lane test behind it are exact for scores of the usual signs only: gap <= 0, mismatch <= match,
+        // gap <= match (hx_poa_sequences and spoa_hx.hpp take any int8 triple). Anything else runs the full-matrix instances.
+        if (!(pp->gap <= 0 && pp->mismatch <= pp->match && pp->gap <= pp->match && pp->match >= 0)) prune_pct = 0;
+        score_abs_max = std::max<uint64_t>({1, (uint64_t)std::abs((int)pp->match), (uint64_t)std::abs((int)pp->mismatch), (uint64_t)std::abs((int)pp->gap)});
         // Column passes (kernels/poa.hip): with the rows pruned, an edge's wave slots are mostly held by waves that skip - so the unshared multi-wave edges run
         // in workgroups of `pass_lanes` lanes and take their columns window by window. The call is bound by wave-slot time (thousands of edges, every slot
         // taken): an edge of 8 000 columns holds 4 waves instead of 16 for little more than the same time.
@@ -785,7 +824,7 @@ struct PoaCall {
             const uint64_t vc = std::max<uint64_t>(std::min<uint64_t>(P.sumL[e], est), E.lmax);   // (never below one sequence: per-base scratch shares the node pools)
             if (vc >= 0x7fffffffULL) return fail("hx_poa_batch: POA graph too large");
             // DP cells are keys = 64 x score + 6 tie-break bits in an int32: |score| <= 8 * (nodes + columns) must stay below 2^24
-            if (vc + E.lmax + 2 >= (1ull << 21)) return fail("hx_poa_batch: POA graph of an edge exceeds 2^21 nodes + columns (score keys would overflow)");
+            if ((vc + E.lmax + 2) * score_abs_max >= (1ull << 24)) return fail("hx_poa_batch: POA graph of an edge exceeds 2^24 / " + std::to_string(score_abs_max) + " nodes + columns (score keys would overflow)");
             E.vcap = (uint32_t)vc; E.ecap = (uint32_t)(P.sumL[e] + P.nseq[e] + 1);
             // rows of H. The score-matrix traceback keeps every row; with direction bytes only rows that a successor reads after they left
             // the LDS ring go to HBM (about 1 row in 1000 on PacBio-like data): a sixteenth of the rows is the estimate, all of them the retry
@@ -1134,31 +1173,34 @@ struct PoaCall {
         lb.cns_bytes = co;
         const uint64_t bytes = no * 106 + eo * 28 + ho * 4 + dro + wo + so + sto * 4 + ao * 8 + clo * 8 + co;
         lb.bytes = bytes;
-        // Pools grow and never shrink, each to the largest batch it has seen: after batches of different shapes (direction bytes for one,
-        // the whole score matrix for a retry) the capacities together can exceed the device although this batch alone fits the budget.
-        // Then everything is released and reserved again at this batch's sizes.
-        auto reserve_pools = [&]() -> hipError_t {
-            hipError_t e;
-#define HX_RSV(buf, n) do { if ((e = (buf).reserve(n)) != hipSuccess) return e; } while (0)
-            HX_RSV(B.H, std::max<uint64_t>(1, ho)); HX_RSV(B.dir, std::max<uint64_t>(1, dro)); HX_RSV(B.dirw, std::max<uint64_t>(1, wo)); HX_RSV(B.wslot, no);
-            HX_RSV(B.code, no); HX_RSV(B.n_aligned, no); HX_RSV(B.mark, no); HX_RSV(B.check, no); HX_RSV(B.row_code, no); HX_RSV(B.row_sink, no); HX_RSV(B.row_al, no);
-            HX_RSV(B.aligned, 3 * no); HX_RSV(B.in_head, no); HX_RSV(B.in_tail, no); HX_RSV(B.out_head, no); HX_RSV(B.out_tail, no); HX_RSV(B.rank2node, no);
-            HX_RSV(B.node2rank, no); HX_RSV(B.row_pred_off, no); HX_RSV(B.score, no); HX_RSV(B.pred, no); HX_RSV(B.pred_rank, eo); HX_RSV(B.pred_w, eo); HX_RSV(B.e_from, eo);
-            HX_RSV(B.e_to, eo); HX_RSV(B.e_next_in, eo); HX_RSV(B.e_next_out, eo); HX_RSV(B.e_w, eo); HX_RSV(B.stack, sto); HX_RSV(B.aln_node, ao); HX_RSV(B.aln_pos, ao);
-            HX_RSV(B.row_meta, no); HX_RSV(B.row_pred0, no); HX_RSV(B.row_pred1, no); HX_RSV(B.nrec, no); HX_RSV(B.nrec2, no); HX_RSV(B.seq, so); HX_RSV(c->poa_cns, co);
-            HX_RSV(B.mbox, std::max<uint64_t>(1, clo));
-            HX_RSV(B.csync, (size_t)ne * 8); HX_RSV(B.sinkbuf, (size_t)ne * (1 + 2 * 1024));
-#undef HX_RSV
-            return hipSuccess;
-        };
-        if (reserve_pools() != hipSuccess) {
-            (void)hipGetLastError();
-            HIPCHK(hipStreamSynchronize(s));
-            B.release_all(); c->poa_cns.release();
-            HIPCHK(reserve_pools());
+        // The pools of the batch, carved out of the context's arena (256-byte aligned). The arena grows when a batch needs more than it holds - by an eighth
+        // more than asked, so that the retries of a call (a few edges with more room) do not each allocate again - and never shrinks.
+        {
+            const auto tw0 = std::chrono::steady_clock::now();
+            size_t at = 0;
+            auto place = [&at](auto& buf, uint64_t n) { buf.off = at; at += (std::max<uint64_t>(1, n) * sizeof(*buf.p) + 255) & ~(size_t)255; };
+            auto bind = [this](auto& buf, uint64_t) { buf.p = reinterpret_cast<decltype(buf.p)>(c->poa_arena.p + buf.off); };
+#define HX_POOLS(F) \
+            F(B.H, ho); F(B.dir, dro); F(B.dirw, wo); F(B.wslot, no); F(B.code, no); F(B.n_aligned, no); F(B.mark, no); F(B.check, no); F(B.row_code, no); F(B.row_sink, no); \
+            F(B.row_al, no); F(B.aligned, 3 * no); F(B.in_head, no); F(B.in_tail, no); F(B.out_head, no); F(B.out_tail, no); F(B.rank2node, no); F(B.node2rank, no); \
+            F(B.row_pred_off, no); F(B.score, no); F(B.pred, no); F(B.pred_rank, eo); F(B.pred_w, eo); F(B.e_from, eo); F(B.e_to, eo); F(B.e_next_in, eo); F(B.e_next_out, eo); \
+            F(B.e_w, eo); F(B.stack, sto); F(B.aln_node, ao); F(B.aln_pos, ao); F(B.row_meta, no); F(B.row_pred0, no); F(B.row_pred1, no); F(B.nrec, no); F(B.nrec2, no); \
+            F(B.seq, so); F(B.cns, co); F(B.mbox, clo); F(B.csync, (uint64_t)ne * 8); F(B.sinkbuf, (uint64_t)ne * (1 + 2 * 1024));
+            HX_POOLS(place)
+            std::lock_guard<std::mutex> lk(c->poa_arena_mu);
+            if (at > c->poa_arena.cap) {
+                HIPCHK(hipStreamSynchronize(s));   // (nothing of an earlier batch is in flight: collect_batch has read its results)
+                hipError_t e = c->poa_arena.ensure(std::min<size_t>(at + at / 8, std::max<size_t>(at, (size_t)budget + (size_t)ne * 8400)));
+                if (e != hipSuccess) { (void)hipGetLastError(); e = c->poa_arena.ensure(at); }
+                if (e != hipSuccess) { (void)hipGetLastError(); return fail("hx_poa_batch: cannot allocate " + std::to_string(at >> 20) + " MB of POA workspace: " + hipGetErrorString(e)); }
+            }
+            HX_POOLS(bind)
+#undef HX_POOLS
+            c->poa_host_ms[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
         }
         c->poa_workspace_bytes = std::max<uint64_t>(c->poa_workspace_bytes, bytes);
         c->poa_last_workspace_bytes = std::max<uint64_t>(c->poa_last_workspace_bytes, bytes);
+        const auto te0 = std::chrono::steady_clock::now();
         HIPCHK(hipMemsetAsync(B.csync.p, 0, (size_t)ne * 8 * 4, s));
         if (clo) HIPCHK(hipMemsetAsync(B.mbox.p, 0, clo * 8, s));   // tag 0 = nothing published
         HIPCHK(c->poa_edges.reserve(ne)); HIPCHK(c->poa_len.reserve(ne)); HIPCHK(c->poa_status.reserve(ne));
@@ -1252,7 +1294,7 @@ struct PoaCall {
             L.slots = c->poa_slots.p + (q.persistent ? q.slot_at : 0); L.counter = q.persistent ? c->poa_counters.p + ci : nullptr; L.n_blocks = (uint32_t)g_blocks;
             L.btab = q.persistent ? c->poa_btab.p + grp[2] : nullptr;
             L.seqs = c->poa_seqs.p; L.packed = in.d_packed; L.read_off = in.d_roff; L.read_len = in.d_rlen; L.pools = pools;
-            L.match = pp->match; L.mismatch = pp->mismatch; L.gap = pp->gap; L.cns = c->poa_cns.p; L.cns_len = c->poa_len.p; L.status = c->poa_status.p;
+            L.match = pp->match; L.mismatch = pp->mismatch; L.gap = pp->gap; L.cns = B.cns.p; L.cns_len = c->poa_len.p; L.status = c->poa_status.p;
             L.cells = c->poa_cells_d.p; L.phase = c->poa_phase_d.p; L.block_threads = (int)q.nt; L.cm = (int)q.cm; L.poll_limit = (uint32_t)o.poa_poll_limit; L.ring_bytes = (uint32_t)lds_bytes;
             L.use_dir = q.dir; L.max_indeg = (uint32_t)std::min(16, std::max(1, o.poa_max_indeg)); L.dp_lanes = q.dpl;
             L.prune_pct = launch_pruned(q) ? (std::min<uint32_t>(prune_pct, 1000u) | (o.poa_prune_lazy ? 1u << 16 : 0u)) : 0u;
@@ -1269,7 +1311,10 @@ struct PoaCall {
             }
             gi++;
         }
+        const auto te1 = std::chrono::steady_clock::now();
         c->tock(3);
+        c->poa_host_ms[2] += std::chrono::duration<double, std::milli>(te1 - te0).count();
+        c->poa_host_ms[3] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te1).count();
         HIPCHK(hipGetLastError());
         if (o.debug) {
             HIPCHK(hipStreamSynchronize(s));
@@ -1283,18 +1328,41 @@ struct PoaCall {
 
     // ---- collection: consensus strings of the edges that are done; the others go to `retry` (worst-case workspace next) / `retry_same` (another way)
     int collect_batch(const Launched& lb, std::vector<uint32_t>& retry, std::vector<uint32_t>& retry_same) {
+        const auto tc0 = std::chrono::steady_clock::now();
+        hipStream_t s = c->stream;
         std::vector<uint32_t> h_len(ne), h_status(ne);
         HIPCHK(hipMemcpy(h_len.data(), c->poa_len.p, (size_t)ne * 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(h_status.data(), c->poa_status.p, (size_t)ne * 4, hipMemcpyDeviceToHost));
-        std::vector<char> h_cns(lb.cns_bytes);
-        if (lb.cns_bytes) HIPCHK(hipMemcpy(h_cns.data(), c->poa_cns.p, lb.cns_bytes, hipMemcpyDeviceToHost));
+        // the finished strings, moved side by side on the device before the download: the buffer the kernels write into is sized by the node estimates
+        // (100 MB for the 13 000 edges of a 140 Mb genome, of which 30 MB are consensus)
+        std::vector<uint32_t> desc;
+        std::vector<uint64_t> dense_off(lb.edges.size() + 1, 0);
+        desc.reserve(lb.edges.size() * 5);
+        for (size_t i = 0; i < lb.edges.size(); i++) {
+            const uint32_t e = lb.edges[i];
+            const uint32_t n = h_status[e] ? 0u : std::min<uint32_t>(h_len[e], P.edges[e].vcap);
+            dense_off[i + 1] = dense_off[i] + n;
+            if (!n) continue;
+            const uint64_t so = P.edges[e].cns_off, to = dense_off[i];
+            desc.insert(desc.end(), {(uint32_t)so, (uint32_t)(so >> 32), (uint32_t)to, (uint32_t)(to >> 32), n});
+        }
+        std::vector<char> h_cns(dense_off.back());
+        if (!desc.empty()) {
+            HIPCHK(c->poa_gather.reserve(desc.size())); HIPCHK(c->poa_cns_dense.reserve(dense_off.back()));
+            HIPCHK(hipMemcpyAsync(c->poa_gather.p, desc.data(), desc.size() * 4, hipMemcpyHostToDevice, s));
+            hxk::gather_bytes(c->poa_pools.cns.p, c->poa_gather.p, (uint32_t)(desc.size() / 5), c->poa_cns_dense.p, s);
+            HIPCHK(hipMemcpyAsync(h_cns.data(), c->poa_cns_dense.p, dense_off.back(), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
+        struct Lap { double& ms; std::chrono::steady_clock::time_point t0; ~Lap() { ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } lap{c->poa_host_ms[4], tc0};
         if (o.debug) {
             size_t n_far = 0, n_nodir = 0, n_over = 0, n_wide = 0, n_sinks = 0, n_stall = 0;
             for (uint32_t e : lb.edges) { n_far += !!(h_status[e] & HXE_POA_FARROWS); n_nodir += !!(h_status[e] & HXE_POA_NODIR); n_over += !!(h_status[e] & HXE_POA_OVERFLOW); n_wide += !!(h_status[e] & HXE_POA_WIDEROWS); n_sinks += !!(h_status[e] & HXE_POA_SINKS); n_stall += !!(h_status[e] & HXE_POA_STALLED); }
             if (n_far + n_nodir + n_over + n_wide + n_sinks + n_stall) fprintf(stderr, "[hx] POA batch: to be redone: %zu (rows read back from HBM outgrew H), %zu (in-degree above the direction bytes' limit), %zu (graph outgrew its workspace), %zu (rows with more than 4 predecessors outgrew the wide-row pool), %zu (more sink rows than the launch keeps), %zu (members of a shared edge not resident together%s: unshared next)\n",
                                                                        n_far, n_nodir, n_over, n_wide, n_sinks, n_stall, balanced ? ", in a balanced launch" : "");
         }
-        for (uint32_t e : lb.edges) {
+        for (size_t i = 0; i < lb.edges.size(); i++) {
+            const uint32_t e = lb.edges[i];
             if (h_status[e] & HXE_POA_FARROWS) { if (P.edges[e].hrows >= P.edges[e].vcap + 1) return fail("hx_poa_batch: internal error (far-row retry)"); far_full[e]++; retry_same.push_back(e); continue; }
             if (h_status[e] & HXE_POA_STALLED) {
                 if (P.edges[e].members < 2) return fail("hx_poa_batch: internal error (a wave of an unshared edge gave up waiting)");
@@ -1308,7 +1376,7 @@ struct PoaCall {
                 if (P.edges[e].vcap >= P.sumL[e]) return fail("hx_poa_batch: POA workspace overflow at worst-case size (internal error)");
                 grow[e]++;
                 retry.push_back(e);
-            } else cns[e].assign(h_cns.data() + P.edges[e].cns_off, h_len[e]);
+            } else cns[e].assign(h_cns.data() + dense_off[i], dense_off[i + 1] - dense_off[i]);
         }
         return 0;
     }
@@ -1322,7 +1390,10 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     PoaCall K(c, in, pp);
     const uint32_t ne = K.ne;
     std::vector<uint32_t> todo;
+    for (double& v : c->poa_host_ms) v = 0;
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     if (K.plan_input(todo)) return -1;
+    c->poa_host_ms[0] += K.ms_since_start();
     if (c->opt.debug) fprintf(stderr, "[hx] POA call: %u edges prepared in %.1f ms\n", (unsigned)ne, K.ms_since_start());
     c->dbg_cls.assign(ne, 11); for (int k = 0; k < 11; k++) c->dbg_ring[k] = 0;
     c->dbg_shape.assign(ne, 0);
@@ -1334,21 +1405,26 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     if (!c->poa_budget) {   // measured once: later calls would count the context's own (persistent) workspace as used
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        { std::lock_guard<std::mutex> lk(c->poa_arena_mu); free_b += c->poa_arena.cap; }   // (an arena reserved ahead - hx_poa_reserve - is the workspace's own)
         c->poa_budget = (uint64_t)(free_b * 0.9);
         c->poa_free_at_first_call = free_b;
     }
     // option poa_workspace_gb: cap of the POA workspace (default: 90 % of what was free when the context first ran a consensus). The workgroups in
     // flight per launch class are scaled down until the slots fit. Measured at 140 Mb (13 230 edges): 257 GB 2.0-2.1 s, 138 GB 2.10-2.13 s (and
     // the first call, which allocates the pools, 4.1 instead of 5-7.6 s), 39 GB 4.6 s, 22 GB 8.5 s; a 400 Mb genome (37 608 edges): 148 GB 6.7 s.
-    K.budget = c->opt.poa_workspace_gb > 0 ? (uint64_t)(c->opt.poa_workspace_gb * 1e9) : c->poa_budget;
+    // Round 6: left alone, the workspace is also capped at 140 GB - what a one-shot run reserves ahead (hx_poa_reserve) must be what the call then settles
+    // on, and a call of 13 000 edges is as fast in 140 GB as in the 215 GB it used to take (measured: DESIGN.md 4).
+    K.budget = c->opt.poa_workspace_gb > 0 ? (uint64_t)(c->opt.poa_workspace_gb * 1e9) : std::min<uint64_t>(c->poa_budget, kPoaAutoCapBytes);
     c->poa_last_workspace_bytes = 0;
     HIPCHK(c->poa_phase_d.reserve((size_t)ne * hxk::POA_PHASE_WORDS));
     HIPCHK(hipMemsetAsync(c->poa_phase_d.p, 0, std::max<size_t>(1, (size_t)ne * hxk::POA_PHASE_WORDS) * 8, s));
     while (!todo.empty()) {
+        const auto tp0 = std::chrono::steady_clock::now();
         if (K.knobs(todo.size()) || K.size_edges(todo)) return -1;
         std::vector<std::vector<uint32_t>> batches;
         std::vector<uint32_t> batch_shrink;
         if (K.plan_batches(todo, batches, batch_shrink)) return -1;
+        c->poa_host_ms[0] += since(tp0);
         std::vector<uint32_t> retry, retry_same;   // retry with the worst-case workspace / with the score-matrix traceback
         for (size_t bi = 0; bi < batches.size(); bi++) {
             if (batches[bi].empty()) continue;
@@ -1358,6 +1434,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
         todo.swap(retry);
         todo.insert(todo.end(), retry_same.begin(), retry_same.end());
     }
+    const auto tf0 = std::chrono::steady_clock::now();
     unsigned long long cells = 0;
     HIPCHK(hipMemcpy(&cells, c->poa_cells_d.p, 8, hipMemcpyDeviceToHost));
     c->poa_phase.assign((size_t)ne * hxk::POA_PHASE_WORDS, 0);
@@ -1369,6 +1446,9 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     out->cns = (char*)malloc(std::max<uint64_t>(1, off[ne]));
     for (uint32_t e = 0; e < ne; e++) memcpy(out->cns + off[e], K.cns[e].data(), K.cns[e].size());
     out->dp_cells = cells; out->seq_bases = K.seq_bases; out->n_aligned = K.n_aligned;
+    c->poa_host_ms[5] = since(tf0); c->poa_host_ms[7] = K.ms_since_start();
+    if (c->opt.debug) fprintf(stderr, "[hx] POA call, host wall time: plan %.1f ms, workspace %.1f ms (%llu device allocations so far, %.0f ms), enqueue %.1f ms, device %.1f ms, collect %.1f ms, finish %.1f ms, total %.1f ms\n",
+                              c->poa_host_ms[0], c->poa_host_ms[1], (unsigned long long)c->poa_arena.n_alloc, c->poa_arena.alloc_ms, c->poa_host_ms[2], c->poa_host_ms[3], c->poa_host_ms[4], c->poa_host_ms[5], c->poa_host_ms[7]);
     return 0;
 }
 
@@ -1537,10 +1617,25 @@ extern "C" uint64_t hx_poa_workspace_bytes(const hx_ctx* c) { return c->poa_work
 extern "C" int hx_poa_release_workspace(hx_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->poa_pools.release_all(); c->poa_cns.release();
+    { std::lock_guard<std::mutex> lk(c->poa_arena_mu); c->poa_arena.release(); }
     c->poa_budget = 0;   // taken again, from what is free then, by the next consensus call
     return 0;
 }
+extern "C" int hx_poa_reserve(hx_ctx* c, uint64_t bytes) {
+    // the arena of the consensus workspace, ahead of the first call (the CLI: on a thread of its own, beside the parse of the text inputs): at most half of
+    // what is free now, so that the inputs still fit beside it whatever the caller guessed; a later call that needs more allocates again
+    HIPCHK(hipSetDevice(c->device));
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    std::lock_guard<std::mutex> lk(c->poa_arena_mu);
+    const size_t want = (size_t)std::min<uint64_t>(bytes, (uint64_t)((free_b + c->poa_arena.cap) / 2));
+    if (want <= c->poa_arena.cap) return 0;
+    const hipError_t e = c->poa_arena.ensure(want);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(std::string("hx_poa_reserve: ") + hipGetErrorString(e)); }
+    return 0;
+}
+extern "C" void hx_poa_host_times(const hx_ctx* c, double* ms8) { for (int k = 0; k < 8; k++) ms8[k] = c->poa_host_ms[k]; }
+extern "C" void hx_poa_arena_stats(const hx_ctx* c, uint64_t* capacity, uint64_t* allocations, double* alloc_ms) { *capacity = c->poa_arena.cap; *allocations = c->poa_arena.n_alloc; *alloc_ms = c->poa_arena.alloc_ms; }
 extern "C" void hx_poa_memory_stats(const hx_ctx* c, uint64_t* free_at_first_call, uint64_t* budget, uint64_t* last_call_workspace) {
     *free_at_first_call = c->poa_free_at_first_call; *budget = c->poa_budget; *last_call_workspace = c->poa_last_workspace_bytes;
 }
@@ -1598,9 +1693,10 @@ struct hx_group {
     ncclResult_t (*p_all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*p_destroy)(ncclComm_t) = nullptr;
     ncclResult_t (*p_abort)(ncclComm_t) = nullptr;
+    ncclResult_t (*p_count)(const ncclComm_t, int*) = nullptr;
     const char* (*p_errstr)(ncclResult_t) = nullptr;
     std::atomic<int> abort_flag{0};               // a rank failed inside the collective: the ranks still waiting on their streams abort their communicators
-    bool broken = false;                          // ... after which the group refuses further exchanges
+    std::atomic<bool> broken{false};              // ... after which the group refuses further exchanges (written and read by the rank threads)
     double timeout_s = 300;                       // bound of the wait for the collective (hx_group_set_timeout)
     int fault_rank = -1;                          // (testing, hx_group_inject_fault: this rank's all-gather "returns an error")
     // rendezvous of the rank threads: everybody arrives with a status, everybody leaves with the worst one (so that no rank enters a
@@ -1661,6 +1757,7 @@ extern "C" int hx_group_create(int n, const int* devices, const char* transport,
         g->p_destroy = (decltype(g->p_destroy))dlsym(g->lib, "ncclCommDestroy");
         g->p_errstr = (decltype(g->p_errstr))dlsym(g->lib, "ncclGetErrorString");
         g->p_abort = (decltype(g->p_abort))dlsym(g->lib, "ncclCommAbort");
+        g->p_count = (decltype(g->p_count))dlsym(g->lib, "ncclCommCount");
         if (!g->p_init_all || !g->p_all_gather || !g->p_destroy || !g->p_errstr) { for (hx_ctx* c : g->ctx) hx_ctx_destroy(c); return fail("hx_group_create: librccl lacks ncclCommInitAll / ncclAllGather"); }
         g->comm.assign(n, nullptr);
         const ncclResult_t rc = g->p_init_all(g->comm.data(), n, g->dev.data());
@@ -1672,7 +1769,9 @@ extern "C" int hx_group_create(int n, const int* devices, const char* transport,
 
 extern "C" void hx_group_destroy(hx_group* g) {
     if (!g) return;
-    if (g->rccl) for (int r = 0; r < g->n; r++) if (g->comm[r]) { (void)hipSetDevice(g->dev[r]); (void)g->p_destroy(g->comm[r]); }
+    // (a group whose collective failed has had its communicators aborted by their own ranks - hx_edge_merge - and whatever is left of it is aborted too:
+    // ncclCommDestroy on a communicator whose peers are gone may wait for them)
+    if (g->rccl) for (int r = 0; r < g->n; r++) if (g->comm[r]) { (void)hipSetDevice(g->dev[r]); if (g->broken.load() && g->p_abort) (void)g->p_abort(g->comm[r]); else (void)g->p_destroy(g->comm[r]); g->comm[r] = nullptr; }
     for (int r = 0; r < g->n; r++) { (void)hipSetDevice(g->dev[r]); g->sendb[r]->release(); g->recvb[r]->release(); g->merged[r]->release(); }
     for (hx_ctx* c : g->ctx) hx_ctx_destroy(c);
     // (librccl stays mapped: unloading it while the HIP runtime is alive buys nothing)
@@ -1683,12 +1782,19 @@ extern "C" void hx_group_inject_fault(hx_group* g, int rank) { g->fault_rank = r
 extern "C" void hx_group_set_timeout(hx_group* g, double seconds) { g->timeout_s = seconds > 0 ? seconds : 300; }
 extern "C" hx_ctx* hx_group_ctx(hx_group* g, int rank) { return rank >= 0 && rank < g->n ? g->ctx[rank] : nullptr; }
 extern "C" const char* hx_group_transport(const hx_group* g) { return g->rccl ? "rccl" : "host"; }
+extern "C" int hx_group_rccl_ranks(const hx_group* g, int* out) {   // what ncclCommCount says on every rank's communicator (0 for every rank: host transport)
+    for (int r = 0; r < g->n; r++) {
+        out[r] = 0;
+        if (g->rccl && g->p_count && g->comm[r] && g->p_count(g->comm[r], &out[r]) != ncclSuccess) out[r] = -1;
+    }
+    return g->rccl ? 1 : 0;
+}
 extern "C" void hx_group_exchange_stats(const hx_group* g, uint64_t* bytes, double* ms) { *bytes = g->last_bytes; *ms = g->last_ms; }
 
 extern "C" int hx_edge_merge(hx_group* g, int rank, const hx_params* prm, hx_edges_out* out) {
     memset(out, 0, sizeof(*out));
     if (rank < 0 || rank >= g->n) return fail("hx_edge_merge: rank out of range");
-    if (g->broken) return fail("hx_edge_merge: the group's collective failed earlier (communicators aborted): create a new group");
+    if (g->broken.load()) return fail("hx_edge_merge: the group's collective failed earlier (communicators aborted): create a new group");
     hx_ctx* c = g->ctx[rank];
     const uint32_t rb = hx_edge_records_bytes();
     uint64_t n = 0;
@@ -1713,7 +1819,9 @@ extern "C" int hx_edge_merge(hx_group* g, int rank, const hx_params* prm, hx_edg
         // whose ncclAllGather returns an error (or whose stream faults, or whose wait runs out) raises the group's abort flag, every rank that sees it
         // aborts its communicator (ncclCommAbort ends the kernels of the collective on its device) and all of them meet at the rendezvous below with
         // the failure. The group is unusable afterwards (hx_edge_merge refuses).
-        const ncclResult_t nr = g->fault_rank == rank ? ncclInternalError : g->p_all_gather(sb.p, rv.p, cap, ncclUint8, g->comm[rank], c->stream);
+        const bool injected = g->fault_rank == rank;
+        if (injected) g->fault_rank = -1;   // (one shot)
+        const ncclResult_t nr = injected ? ncclInternalError : g->p_all_gather(sb.p, rv.p, cap, ncclUint8, g->comm[rank], c->stream);
         if (nr != ncclSuccess) { rc = -1; own_err = std::string("ncclAllGather: ") + g->p_errstr(nr); g->abort_flag.store(1); }
         else {
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(g->timeout_s);
@@ -1739,7 +1847,17 @@ extern "C" int hx_edge_merge(hx_group* g, int rank, const hx_params* prm, hx_edg
         for (int r = 0; r < g->n && !rc; r++)
             if (hipMemcpy(rv.p + (uint64_t)r * cap, g->stage[r].data(), cap, hipMemcpyHostToDevice) != hipSuccess) { rc = -1; own_err = "hx_edge_merge: copy from the host staging buffer failed"; }
     }
-    if (g->rendezvous(rc != 0)) { if (g->rccl) g->broken = true; return fail(rc ? own_err : "hx_edge_merge: another rank failed in the exchange"); }
+    if (g->rendezvous(rc != 0)) {
+        if (g->rccl) {
+            // EVERY rank leaves a failed collective with its own communicator aborted - the rank whose call returned the error and the ranks whose part
+            // had already completed included (their peers are gone: ncclCommDestroy on such a communicator may wait for them) - and the group refuses
+            // further exchanges
+            g->broken.store(true);
+            if (g->p_abort && g->comm[rank]) { (void)g->p_abort(g->comm[rank]); g->comm[rank] = nullptr; }
+            (void)hipStreamSynchronize(c->stream);
+        }
+        return fail(rc ? own_err : "hx_edge_merge: another rank failed in the exchange");
+    }
     if (rank == 0) { g->last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); g->last_bytes = total * rb; }
     const uint8_t* src = rv.p;
     if (!equal) {   // cut the padding out: rank order = ascending read ids, which the stable key sort relies on

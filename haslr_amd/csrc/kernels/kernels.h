@@ -28,6 +28,9 @@ void exclusive_scan_u32(const uint32_t* in, uint64_t* out, uint64_t n, hipStream
 void radix_sort_pairs(uint64_t* key, uint32_t* val, uint64_t* key_tmp, uint32_t* val_tmp, uint64_t n,
                       int bits_lo, int bits_hi, hipStream_t s, Workspace& ws);
 
+// strings scattered over `src` moved side by side into `dst`: desc = n_items x (source offset lo / hi, destination offset lo / hi, length)
+void gather_bytes(const char* src, const uint32_t* desc, uint32_t n_items, char* dst, hipStream_t s);
+
 // ---- chain.hip (K0-K3)
 struct ChainScratch {   // all sized by the number of raw hits in the shard (+1)
     uint32_t *hit, *qs, *qe, *ts, *te, *nm, *nb, *skf, *skb;

@@ -201,4 +201,17 @@ void radix_sort_pairs(uint64_t* key, uint32_t* val, uint64_t* key_tmp, uint32_t*
     }
 }
 
+// Consensus collection (hx_api.hip collect_batch): the kernels leave every edge's string at its own offset of a buffer sized by the node ESTIMATES (a
+// hundred megabytes for 13 000 edges); the finished strings are moved side by side before they cross PCIe. One workgroup per string;
+// desc = (source offset lo / hi, destination offset lo / hi, length).
+__global__ void __launch_bounds__(256) k_gather_bytes(const char* __restrict__ src, const uint32_t* __restrict__ desc, char* __restrict__ dst) {
+    const uint32_t* d = desc + (size_t)blockIdx.x * 5;
+    const uint64_t so = (uint64_t)d[0] | (uint64_t)d[1] << 32, to = (uint64_t)d[2] | (uint64_t)d[3] << 32;
+    const uint32_t n = d[4];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) dst[to + i] = src[so + i];
+}
+void gather_bytes(const char* src, const uint32_t* desc, uint32_t n_items, char* dst, hipStream_t s) {
+    if (n_items) k_gather_bytes<<<n_items, 256, 0, s>>>(src, desc, dst);
+}
+
 }  // namespace hxk

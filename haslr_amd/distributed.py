@@ -215,6 +215,9 @@ def sharded_stages(run, device, group=None, backend=None, with_text=False):
         raise TypeError("sharded_stages needs the rank's ShardedBackend (failure agreement of the record exchange goes through it)")
     backend.exchanged = False
     backend.stopped = None
+    backend.error = None                   # (the first error of THIS pass is the one a count round reports, not one left over from an earlier pass)
+    if hasattr(backend, "pending_error"):
+        backend.pending_error = None
     err = None
     try:
         run.chain()

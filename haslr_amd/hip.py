@@ -16,7 +16,7 @@ SYMBOLS = ["hx_last_error", "hx_device_count", "hx_ctx_create", "hx_ctx_destroy"
            "hx_chain_reads", "hx_edge_support", "hx_edge_coords", "hx_poa_batch", "hx_free_chain", "hx_free_edges",
            "hx_free_coords", "hx_free_cns", "hx_edge_emit", "hx_edge_records_bytes", "hx_edge_records_export",
            "hx_edge_records_import", "hx_poa_supports", "hx_poa_sequences", "hx_timing_reset", "hx_timing_get", "hx_set_poa_block", "hx_backend_fill", "hx_poa_phase_cycles", "hx_set_poa_traceback", "hx_poa_workspace_bytes",
-           "hx_set_option", "hx_get_option", "hx_option_names", "hx_poa_memory_stats", "hx_poa_release_workspace", "hx_poa_prune_stats", "hx_group_set_timeout", "hx_group_inject_fault",
+           "hx_set_option", "hx_get_option", "hx_option_names", "hx_poa_memory_stats", "hx_poa_release_workspace", "hx_poa_prune_stats", "hx_group_set_timeout", "hx_group_inject_fault", "hx_poa_reserve", "hx_poa_host_times", "hx_poa_arena_stats", "hx_group_rccl_ranks",
            "hx_group_create", "hx_group_destroy", "hx_group_size", "hx_group_ctx", "hx_group_transport", "hx_edge_merge", "hx_group_backend_fill", "hx_group_exchange_stats"]
 
 
@@ -66,10 +66,17 @@ def lib():
         L.hx_option_names.restype = C.c_char_p
         L.hx_poa_memory_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.hx_poa_release_workspace.argtypes = [C.c_void_p]
+        L.hx_poa_reserve.argtypes = [C.c_void_p, C.c_uint64]
+        L.hx_poa_host_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 8)]
+        L.hx_poa_host_times.restype = None
+        L.hx_poa_arena_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        L.hx_poa_arena_stats.restype = None
         L.hx_poa_prune_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 4)]
         L.hx_group_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_char_p, C.POINTER(C.c_void_p)]
         L.hx_group_set_timeout.argtypes = [C.c_void_p, C.c_double]
+        L.hx_group_set_timeout.restype = None
         L.hx_group_inject_fault.argtypes = [C.c_void_p, C.c_int]
+        L.hx_group_inject_fault.restype = None
         L.hx_group_destroy.argtypes = [C.c_void_p]
         L.hx_group_size.argtypes = [C.c_void_p]
         L.hx_group_ctx.argtypes = [C.c_void_p, C.c_int]
@@ -79,6 +86,7 @@ def lib():
         L.hx_edge_merge.argtypes = [C.c_void_p, C.c_int, C.POINTER(T.Params), C.POINTER(T.EdgesOut)]
         L.hx_group_backend_fill.argtypes = [C.c_void_p, C.c_int, C.POINTER(T.Backend)]
         L.hx_group_exchange_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        L.hx_group_rccl_ranks.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -107,10 +115,20 @@ class HipContext:
         self._ds = None
         self.table = T.Backend()
         L.hx_backend_fill(self._h, C.byref(self.table))
-        if use_env:
-            self.set_options(**env_options())   # (this Python process is the application: its HX_* variables are the context's options, copied ONCE)
-        if options:
-            self.set_options(**options)
+        try:
+            if use_env:   # (this Python process is the application: its HX_* variables are the context's options, copied ONCE; a malformed value is
+                          # reported and ignored - explicit set_option calls stay strict)
+                for k, v in env_options().items():
+                    try:
+                        self.set_option(k, v)
+                    except HipError as e:
+                        import warnings
+                        warnings.warn(f"HX_{k.upper()}={v!r} ignored: {e}")
+            if options:
+                self.set_options(**options)
+        except Exception:
+            self.close()
+            raise
 
     def set_option(self, name, value):
         """tuning / test switch of this context (include/haslr_hip.h: hx_set_option); value None = back to the default"""
@@ -148,6 +166,20 @@ class HipContext:
 
     def poa_release_workspace(self):
         self._chk(lib().hx_poa_release_workspace(self._h))
+
+    def poa_reserve(self, nbytes):
+        """the consensus workspace's arena, ahead of the first call (include/haslr_hip.h: hx_poa_reserve)"""
+        self._chk(lib().hx_poa_reserve(self._h, int(nbytes)))
+
+    def poa_host_times(self):
+        o = (C.c_double * 8)()
+        lib().hx_poa_host_times(self._h, C.byref(o))
+        return {"plan_ms": o[0], "workspace_ms": o[1], "enqueue_ms": o[2], "device_wait_ms": o[3], "collect_ms": o[4], "finish_ms": o[5], "total_ms": o[7]}
+
+    def poa_arena_stats(self):
+        cap, n, ms = C.c_uint64(), C.c_uint64(), C.c_double()
+        lib().hx_poa_arena_stats(self._h, C.byref(cap), C.byref(n), C.byref(ms))
+        return {"bytes": cap.value, "allocations": n.value, "alloc_ms": ms.value}
 
     def poa_prune_stats(self):
         o = (C.c_uint64 * 4)()

@@ -50,11 +50,11 @@ void hx_ctx_destroy(hx_ctx*);
  *   hx_set_option    name = an entry of hx_option_names() (the old spelling works too: "HX_POA_SLOTS" = "poa_slots"), value = a number as text;
  *                    NULL or "" = back to the default. Unknown name or malformed value: error. Takes effect with the next operator call.
  *   hx_get_option    current value as a double
- *   hx_option_names  comma-separated list: debug, prof, poa_workspace_gb (cap of the consensus workspace, GB; 0 = 90 % of the free memory),
+ *   hx_option_names  comma-separated list: debug, prof, poa_workspace_gb (cap of the consensus workspace, GB; 0 = 90 % of the free memory, at most 140 GB),
  *                    poa_prune (exact score-bound pruning of the DP: -1 automatic = calls of thousands of edges, 0 never, else the threshold as a
  *                    percentage of the previous alignment's score per base), launch-shape knobs (poa_cols, poa_member_lanes, poa_cluster_min /
  *                    _max / _topk / _cols, poa_wide_members, poa_wave_max, poa_ring_kb, poa_balance, poa_balance_pct, poa_balance_lanes, poa_streams,
- *                    poa_wide_delay_us, poa_prune_lanes) and test switches that force rare paths (poa_poll_limit, poa_max_indeg, poa_node_est_pct,
+ *                    poa_wide_delay_us, poa_prune_lanes, poa_prune_lazy, poa_pass_lanes, poa_chain_ms, poa_big_first) and test switches that force rare paths (poa_poll_limit, poa_max_indeg, poa_node_est_pct,
  *                    poa_far_rows, poa_ring_zero, poa_slots, poa_slots_pct, poa_batches, poa_force_cm, poa_no_xcd_map, coords_lds_supp).
  *                    Results never depend on any of them. */
 int hx_set_option(hx_ctx*, const char* name, const char* value);
@@ -131,6 +131,7 @@ const char* hx_group_transport(const hx_group*); /* "rccl" or "host" */
 int hx_edge_merge(hx_group*, int rank, const hx_params*, hx_edges_out* out);
 int hx_group_backend_fill(hx_group*, int rank, void* backend_table);
 void hx_group_exchange_stats(const hx_group*, uint64_t* bytes, double* ms);
+int hx_group_rccl_ranks(const hx_group*, int* ranks_per_communicator /* hx_group_size entries */); /* ncclCommCount of every rank's communicator (0s: host transport); returns 1 over RCCL, 0 over host memory */
 
 /* kernel timing measured with hipEvents on the context's stream, accumulated per kernel family since the
  * last reset: 0 chain, 1 edges (emit+sort+segment), 2 coords, 3 poa. ms[] and launches[] have 4 entries. */
@@ -148,6 +149,18 @@ uint64_t hx_poa_workspace_bytes(const hx_ctx*);
 /* frees the consensus workspace (the pools grow to the largest call and otherwise live as long as the context) and forgets the memory budget: the next
  * consensus call takes it again from what is free then, and allocates anew */
 int hx_poa_release_workspace(hx_ctx*);
+/* The consensus workspace is ONE device allocation (an arena every pool of a batch is carved from), made by the first hx_poa_batch that needs it - or
+ * ahead of it by hx_poa_reserve(bytes): a one-shot program (the reference is one, main.cpp:28-228: every stage runs exactly once, the consensus at :207)
+ * calls it on a thread of its own while it still parses its text inputs, so that the allocation of 10^2 GB is not part of its consensus stage. At most
+ * half of the device memory that is free at the time is taken; hx_upload gives the arena back if the inputs do not fit beside it; a call that needs more
+ * than was reserved allocates again. Thread-safe against the operators of the same context.
+ *   hx_poa_host_times   host wall time (ms) of the LAST consensus call, by part: [0] plan, [1] workspace (arena allocation + carving), [2] enqueue
+ *                       (tables to the device, launches), [3] waiting for the device, [4] collection (status + consensus strings), [5] results
+ *                       assembled, [6] unused, [7] the whole call
+ *   hx_poa_arena_stats  bytes the arena holds, device allocations made for it so far, and their wall time */
+int hx_poa_reserve(hx_ctx*, uint64_t bytes);
+void hx_poa_host_times(const hx_ctx*, double* ms8);
+void hx_poa_arena_stats(const hx_ctx*, uint64_t* capacity, uint64_t* allocations, double* alloc_ms);
 void hx_poa_memory_stats(const hx_ctx*, uint64_t* free_at_first_call, uint64_t* budget, uint64_t* last_call_workspace);
 /* pruning statistics of the last hx_poa_batch, summed over the pruned launches: [wave-rows, wave-rows skipped, attempts repeated, alignments with a threshold] */
 void hx_poa_prune_stats(const hx_ctx*, uint64_t* out4);

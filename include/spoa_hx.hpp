@@ -60,7 +60,7 @@ struct Device {
     hx_ctx* ctx = nullptr;
     std::mutex mu;                    // guards ctx and every call into it
     // flat combining of concurrent generate_consensus() calls
-    struct Request { const std::vector<std::string>* seqs; std::int8_t m, n, g; std::string result, error; bool done; };
+    struct Request { const std::vector<std::string>* seqs; std::int8_t m, n, g; std::string result, error; bool done, answered; };   // answered: result or error is final (an empty consensus is a result)
     std::mutex qmu;
     std::condition_variable qcv;
     std::vector<Request*> queue;
@@ -128,7 +128,7 @@ inline std::string consensus_combined(const std::vector<std::string>& seqs, std:
     Device& d = device();
     static const long window_us = std::getenv("HASLR_SPOA_BATCH_US") ? std::atol(std::getenv("HASLR_SPOA_BATCH_US")) : 200;
     static const std::size_t batch_max = std::getenv("HASLR_SPOA_BATCH") ? (std::size_t)std::max(1L, std::atol(std::getenv("HASLR_SPOA_BATCH"))) : 256;
-    Device::Request me{&seqs, m, n, g, std::string(), std::string(), false};
+    Device::Request me{&seqs, m, n, g, std::string(), std::string(), false, false};
     std::unique_lock<std::mutex> lk(d.qmu);
     d.queue.push_back(&me);
     d.arrivals++;
@@ -162,17 +162,24 @@ inline std::string consensus_combined(const std::vector<std::string>& seqs, std:
                     if (!served[j] && batch[j]->m == batch[i]->m && batch[j]->n == batch[i]->n && batch[j]->g == batch[i]->g) { idx.push_back(j); sets.push_back(batch[j]->seqs); served[j] = 1; }
                 try {
                     std::vector<std::string> res = consensus_batch(sets, batch[i]->m, batch[i]->n, batch[i]->g);
-                    for (std::size_t q = 0; q < idx.size(); q++) batch[idx[q]]->result.swap(res[q]);
+                    for (std::size_t q = 0; q < idx.size(); q++) { batch[idx[q]]->result.swap(res[q]); batch[idx[q]]->answered = true; }
                     calls++;
                 } catch (const std::exception& e) {
-                    // one bad set must not fail the callers that happened to share its launch: every set of the group again, on its own
-                    if (idx.size() == 1) batch[idx[0]]->error = e.what();
-                    else
+                    // one bad set must not fail the callers that happened to share its launch: every set of the group again, on its own - until two in a
+                    // row have failed the way the whole group did (a device fault is sticky: the other 250 sets would fail one call at a time)
+                    const std::string group_error = e.what();
+                    if (idx.size() == 1) { batch[idx[0]]->error = group_error; batch[idx[0]]->answered = true; }
+                    else {
+                        int same = 0;
                         for (std::size_t q = 0; q < idx.size(); q++) {
-                            try { batch[idx[q]]->result = consensus_batch(std::vector<const std::vector<std::string>*>{sets[q]}, batch[i]->m, batch[i]->n, batch[i]->g)[0]; }
-                            catch (const std::exception& e1) { batch[idx[q]]->error = e1.what(); }
+                            Device::Request* r = batch[idx[q]];
+                            if (same >= 2) { r->error = group_error; r->answered = true; continue; }
+                            try { r->result = consensus_batch(std::vector<const std::vector<std::string>*>{sets[q]}, batch[i]->m, batch[i]->n, batch[i]->g)[0]; same = 0; }
+                            catch (const std::exception& e1) { r->error = e1.what(); same = r->error == group_error ? same + 1 : 0; }
+                            r->answered = true;
                             calls++;
                         }
+                    }
                     calls++;
                 }
             }
@@ -180,10 +187,14 @@ inline std::string consensus_combined(const std::vector<std::string>& seqs, std:
             d.calls += calls; d.sets += batch.size();
         } catch (...) {
             if (!lk.owns_lock()) lk.lock();
-            for (Device::Request* r : batch) if (r->result.empty() && r->error.empty()) r->error = "spoa_hx: the submitting thread failed before the device call (out of memory?)";
-            if (batch.empty()) me.error = "spoa_hx: the submitting thread failed while collecting a batch (out of memory?)";
-            for (std::size_t q = 0; q < d.queue.size(); q++) if (d.queue[q] == &me) { d.queue.erase(d.queue.begin() + (std::ptrdiff_t)q); break; }
-            me.done = true;
+            // requests of the batch that have no answer yet get the error (an EMPTY consensus that was served is an answer and stays)
+            for (Device::Request* r : batch) if (!r->answered) { r->error = "spoa_hx: the submitting thread failed before the device call (out of memory?)"; r->answered = true; }
+            if (batch.empty()) {   // failed while collecting: nothing was taken - this caller gets the error and leaves the queue
+                me.error = "spoa_hx: the submitting thread failed while collecting a batch (out of memory?)";
+                for (std::size_t q = 0; q < d.queue.size(); q++) if (d.queue[q] == &me) { d.queue.erase(d.queue.begin() + (std::ptrdiff_t)q); break; }
+                me.done = true;
+            }
+            // (a batch cut at batch_max may have left this caller's own request in the queue: it stays there for the next submitter - possibly this thread)
         }
         for (Device::Request* r : batch) r->done = true;
         d.company = batch.size() > 1 || d.arrivals > 0;         // did this batch have, or did its device call see, anybody else?
