@@ -120,6 +120,7 @@ def cli_e2e(pre, tag):
     r = subprocess.run([exe, "-t", str(threads), "-c", pre + ".contigs.fa", "-l", pre + ".reads.fa", "-m", pre + ".paf", "-d", out], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     wall = time.perf_counter() - t0
+    open(os.path.join(bench_dir(), f"cli_{tag}.stderr.txt"), "w").write(r.stderr)
     if r.returncode != 0:
         return {"error": r.stderr[-600:]}
     res = {"cli_e2e_s": wall, "threads": threads, "command": "haslr_assemble -t %d -c .. -l .. -m .. -d .. (fresh process, fresh output directory)" % threads}
@@ -137,8 +138,8 @@ def cli_e2e(pre, tag):
 
 
 def reserve_bytes_for(ds):
-    """the arena haslr_assemble reserves beside its parse: 32 B of consensus workspace per long-read base, at most what a call ever settles on (main.cpp of the build)"""
-    return min(142 << 30, 32 * int(ds.total_read_bases))
+    """the arena haslr_assemble reserves beside its parse: 64 B of consensus workspace per long-read base, at most what a call ever settles on (main.cpp of the build)"""
+    return min(232 << 30, 64 * int(ds.total_read_bases))
 
 
 def upload_and_reserve(ctx, ds):

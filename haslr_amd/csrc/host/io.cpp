@@ -504,10 +504,23 @@ Dataset* load_dataset_cached(const char* index_dir, const char* contig_path, con
     const bool use_ci = index_dir && file_exists(ci), use_li = index_dir && file_exists(li);
     if (used_contig_index) *used_contig_index = use_ci;
     if (used_longread_index) *used_longread_index = use_li;
-    if (use_ci) { if (!read_contig_index(*d, ci)) return nullptr; }
-    else if (!load_contigs(*d, contig_path)) return nullptr;
+    // the contigs (one streaming reader) and the long reads (the parallel loader) touch different arrays of the data set: with several threads the contigs
+    // are read on a thread of their own beside the reads (0.3 s of a 1.7 s load at 140 Mb); an error of the contig file is reported first, as before
+    std::string contig_error;
+    bool contigs_ok = true;
+    auto contigs = [&]() {
+        contigs_ok = use_ci ? read_contig_index(*d, ci) : load_contigs(*d, contig_path);
+        if (!contigs_ok) contig_error = g_err;
+    };
+    std::thread contig_thread;
+    if (g_io_threads > 1 && !use_li) contig_thread = std::thread(contigs); else contigs();
+    struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join_contigs{contig_thread};
+    if (!contig_thread.joinable() && !contigs_ok) return nullptr;
     if (use_li) { if (!read_longread_index(*d, li)) return nullptr; return d.release(); }
-    if (!for_each_path(long_path, long_fofn, [&](const std::string& p) { return load_reads_file(*d, p); }, "Longread::load_longread_compressed_fofn")) return nullptr;
+    const bool reads_ok = for_each_path(long_path, long_fofn, [&](const std::string& p) { return load_reads_file(*d, p); }, "Longread::load_longread_compressed_fofn");
+    if (contig_thread.joinable()) contig_thread.join();
+    if (!contigs_ok) { g_err = contig_error; return nullptr; }
+    if (!reads_ok) return nullptr;
     d->read_off.push_back(d->read_packed.size());
     if (!for_each_path(mapping_path, mapping_fofn, [&](const std::string& p) { return load_paf_file(*d, p); }, "Longread::load_alignment_fofn")) return nullptr;
     d->cg_off.push_back(d->cg_ops.size());

@@ -152,11 +152,15 @@ int main(int argc, char* argv[]) {
     // The device side of the start-up runs on a thread of its own BESIDE the parse of the text inputs (this program runs once: main.cpp:28-228 of the
     // reference; what a user of haslr.py:66 waits for is the whole run, not the hot path): the HIP runtime and the context(s), the options, and the arena
     // of the consensus workspace (hx_poa_reserve: up to 140 GB for a genome of 10^8 bases and more - seconds of allocation that used to sit inside the
-    // consensus stage). The estimate is 32 bytes of workspace per long-read base (12 Mb: 9.2 GB for 3.0e8 bases), at most what a call ever settles on.
+    // consensus stage). The estimate is 64 bytes of workspace per long-read base (12 Mb: 9.2 GB for 3.0e8 bases; 140 Mb: 215 GB for 3.5e9), at most what a call
+    // ever settles on; hx_poa_reserve itself stops at 80 % of what is free.
     std::string gpu_error;
     double t_gpu_init = 0, t_reserve = 0;
     const uint64_t lr_bytes = long_fofn ? 0 : file_bytes(long_path);
-    const uint64_t reserve_bytes = getenv("HASLR_NO_RESERVE") ? 0 : std::min<uint64_t>(142ull << 30, lr_bytes * 32);
+    // (ranks that may SHARE a device - transport "host", the rehearsal of the multi-GPU logic on a box with fewer GPUs than ranks - reserve nothing: each would
+    // take its share of what is free when it looks, and together they would leave no room for the inputs)
+    const bool shared_devices = grouped && getenv("HASLR_GROUP_TRANSPORT") && !strcmp(getenv("HASLR_GROUP_TRANSPORT"), "host");
+    const uint64_t reserve_bytes = getenv("HASLR_NO_RESERVE") || shared_devices ? 0 : std::min<uint64_t>(232ull << 30, lr_bytes * 64);
     auto gpu_start = [&]() {
         const double g0 = real_time();
         if (grouped) {

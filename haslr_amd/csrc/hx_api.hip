@@ -667,7 +667,6 @@ constexpr int NCLS = 11;
 constexpr uint64_t kPoaLdsMax = 140 * 1024;   // dynamic LDS of a POA workgroup at most (160 KB per CU less the 1024-lane kernel's static 16.5 KB: sink lists, wave mailboxes)
 const int kClassNT[NCLS] = {0, 1024, 512, 256, 128, 64, 1024, 512, 256, 128, 64};
 constexpr size_t kManyEdges = 3000;
-constexpr uint64_t kPoaAutoCapBytes = 140ull * 1000 * 1000 * 1000;   // workspace a call takes at most when option poa_workspace_gb is not set
 
 // One consensus call: the PLAN (sub-sequences, per-edge capacities, launch classes, workspace slots and batches against the memory budget), the
 // LAUNCH of a batch, and the COLLECTION of its results with the verdict on every edge (done / again with more room / again another way).
@@ -1412,9 +1411,9 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     // option poa_workspace_gb: cap of the POA workspace (default: 90 % of what was free when the context first ran a consensus). The workgroups in
     // flight per launch class are scaled down until the slots fit. Measured at 140 Mb (13 230 edges): 257 GB 2.0-2.1 s, 138 GB 2.10-2.13 s (and
     // the first call, which allocates the pools, 4.1 instead of 5-7.6 s), 39 GB 4.6 s, 22 GB 8.5 s; a 400 Mb genome (37 608 edges): 148 GB 6.7 s.
-    // Round 6: left alone, the workspace is also capped at 140 GB - what a one-shot run reserves ahead (hx_poa_reserve) must be what the call then settles
-    // on, and a call of 13 000 edges is as fast in 140 GB as in the 215 GB it used to take (measured: DESIGN.md 4).
-    K.budget = c->opt.poa_workspace_gb > 0 ? (uint64_t)(c->opt.poa_workspace_gb * 1e9) : std::min<uint64_t>(c->poa_budget, kPoaAutoCapBytes);
+    // (Round 6, measured on the 140 Mb data set, 13 197 edges: 0.50 s with the 215 GB the plan takes of a 257 GB budget, 0.75-0.90 s under a cap of 140 GB, 1.04 s
+    // under 100 GB - the slot counts of the one-wave classes are what shrinks. No cap of its own, then: 90 % of what is free.)
+    K.budget = c->opt.poa_workspace_gb > 0 ? (uint64_t)(c->opt.poa_workspace_gb * 1e9) : c->poa_budget;
     c->poa_last_workspace_bytes = 0;
     HIPCHK(c->poa_phase_d.reserve((size_t)ne * hxk::POA_PHASE_WORDS));
     HIPCHK(hipMemsetAsync(c->poa_phase_d.p, 0, std::max<size_t>(1, (size_t)ne * hxk::POA_PHASE_WORDS) * 8, s));
@@ -1628,7 +1627,9 @@ extern "C" int hx_poa_reserve(hx_ctx* c, uint64_t bytes) {
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     std::lock_guard<std::mutex> lk(c->poa_arena_mu);
-    const size_t want = (size_t)std::min<uint64_t>(bytes, (uint64_t)((free_b + c->poa_arena.cap) / 2));
+    uint64_t cap_b = (uint64_t)((double)(free_b + c->poa_arena.cap) * 0.8);                             // (the inputs go beside it: hx_upload gives the arena back if they do not fit)
+    if (c->opt.poa_workspace_gb > 0) cap_b = std::min<uint64_t>(cap_b, (uint64_t)(c->opt.poa_workspace_gb * 1.02e9) + (64ull << 20));   // (option poa_workspace_gb: no call will take more)
+    const size_t want = (size_t)std::min<uint64_t>(bytes, cap_b);
     if (want <= c->poa_arena.cap) return 0;
     const hipError_t e = c->poa_arena.ensure(want);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(std::string("hx_poa_reserve: ") + hipGetErrorString(e)); }

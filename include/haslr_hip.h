@@ -50,7 +50,7 @@ void hx_ctx_destroy(hx_ctx*);
  *   hx_set_option    name = an entry of hx_option_names() (the old spelling works too: "HX_POA_SLOTS" = "poa_slots"), value = a number as text;
  *                    NULL or "" = back to the default. Unknown name or malformed value: error. Takes effect with the next operator call.
  *   hx_get_option    current value as a double
- *   hx_option_names  comma-separated list: debug, prof, poa_workspace_gb (cap of the consensus workspace, GB; 0 = 90 % of the free memory, at most 140 GB),
+ *   hx_option_names  comma-separated list: debug, prof, poa_workspace_gb (cap of the consensus workspace, GB; 0 = 90 % of the free memory),
  *                    poa_prune (exact score-bound pruning of the DP: -1 automatic = calls of thousands of edges, 0 never, else the threshold as a
  *                    percentage of the previous alignment's score per base), launch-shape knobs (poa_cols, poa_member_lanes, poa_cluster_min /
  *                    _max / _topk / _cols, poa_wide_members, poa_wave_max, poa_ring_kb, poa_balance, poa_balance_pct, poa_balance_lanes, poa_streams,
@@ -152,7 +152,7 @@ int hx_poa_release_workspace(hx_ctx*);
 /* The consensus workspace is ONE device allocation (an arena every pool of a batch is carved from), made by the first hx_poa_batch that needs it - or
  * ahead of it by hx_poa_reserve(bytes): a one-shot program (the reference is one, main.cpp:28-228: every stage runs exactly once, the consensus at :207)
  * calls it on a thread of its own while it still parses its text inputs, so that the allocation of 10^2 GB is not part of its consensus stage. At most
- * half of the device memory that is free at the time is taken; hx_upload gives the arena back if the inputs do not fit beside it; a call that needs more
+ * 80 % of the device memory that is free at the time is taken (and no more than option poa_workspace_gb allows, when it is set); hx_upload gives the arena back if the inputs do not fit beside it; a call that needs more
  * than was reserved allocates again. Thread-safe against the operators of the same context.
  *   hx_poa_host_times   host wall time (ms) of the LAST consensus call, by part: [0] plan, [1] workspace (arena allocation + carving), [2] enqueue
  *                       (tables to the device, launches), [3] waiting for the device, [4] collection (status + consensus strings), [5] results

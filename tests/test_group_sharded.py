@@ -117,10 +117,9 @@ def test_binary_with_eight_ranks_on_the_140mb_data_set(sim, built, tmp_path):
     ranks on the one device of the box and the record exchange staged through host memory (what one GPU per lease allows) - every rank uploads
     the whole input, chains its eighth of the reads, merges 1/8 of the records, aligns its LPT share of ~13 000 edges inside an eighth of the workspace -
     and every output file equals the --gpus 1 run's."""
-    # (the same data set as test_configs3_full_size_against_oracle, which deletes its files when it is done: the arguments in another order are
-    # another key of the session's cache, so the files are made again)
-    args = ("--seed", hex(0x4841534C + 3), "--genome-len", "140000000", "--model", "pacbio", "--cov", "25", "--variant-per-mb", "1.5")
-    pre = sim(*args)
+    # (the data set of tests/test_gpu_parity.py::test_configs3_full_size_against_oracle under the same key of the session's simulator cache: made once per
+    # session, removed here - this test runs after that one)
+    pre = sim(*util.CONFIGS3_ARGS)
     try:
         base = ["-t", "16", "-c", pre + ".contigs.fa", "-l", pre + ".reads.fa", "-m", pre + ".paf"]
         one = _cli(base + ["-d", str(tmp_path / "one")])
@@ -233,3 +232,23 @@ def test_a_failure_inside_the_collective_ends_the_exchange_with_an_error(sim, bu
     assert L.hx_edge_merge(g, 0, C.byref(prm), C.byref(e)) != 0 and b"failed earlier" in L.hx_last_error()   # the group is broken for good
     L.hx_group_destroy(g)
     ds.close()
+
+
+@pytest.mark.gpu
+def test_bench_through_the_group_code_reproduces_the_plain_step(built, tmp_path):
+    """`bench.py --gpus 1` sent through the in-process group (HASLR_BENCH_FORCE_GROUP=1, host transport: hx_group_create / hx_edge_merge /
+    hxh_runs_all_sharded with one rank) against the plain single-context step over the same data in the same process (`n1_same_data`): the group code adds the
+    record export / import and the results hand-over, and must cost nothing beside a step (2 %); the line carries what an N = 1 line carries."""
+    import json
+    import sys
+    env = dict(os.environ, HASLR_BENCH_FORCE_GROUP="1", HASLR_GROUP_TRANSPORT="host", HASLR_BENCH_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "1", "--no-cpu-baseline"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().split("\n")[-1])
+    assert line["n_gpus"] == 1 and line["assembly"]["matches_single_gpu"]
+    for key in ("achieved", "peak", "frac", "kernel_ms_per_launch", "algorithmic_bytes_per_launch", "gcups"):
+        assert line["roofline"][key] is not None and line["roofline"][key] > 0, key
+    assert line["config"]["rccl_ranks"] == [0] and "edge_record_exchange_ms" in line["config"]
+    ratio = line["value"] / line["n1_same_data"]["value"]
+    assert 0.98 <= ratio <= 1.03, (line["value"], line["n1_same_data"])

@@ -151,3 +151,9 @@ class DeviceBallast:
         for p in self._blocks:
             self._hip.hipFree(p)
         self._blocks, self.bytes = [], 0
+
+
+# BASELINE configs[3]'s data set (140 Mb, PacBio-like 25x, seed 0x4841534c + 3: bench.py --workload fly) as the session's simulator cache keys it - ONE argument
+# list for every test that uses it, so that it is made once per session (test_gpu_parity.py checks it against the oracle, test_group_sharded.py runs the binary
+# with eight ranks over it and removes the files)
+CONFIGS3_ARGS = ("--genome-len", "140000000", "--seed", hex(0x4841534C + 3), "--model", "pacbio", "--cov", "25", "--variant-per-mb", "1.5")

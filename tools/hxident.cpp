@@ -10,7 +10,8 @@
 #include <cstring>
 #include <fstream>
 #include <string>
-#include <unordered_map>
+#include <cstdint>
+#include <climits>
 #include <vector>
 
 static std::vector<std::pair<std::string, std::string>> read_fa(const char* p) {
@@ -56,9 +57,60 @@ static long banded_ed(const std::string& q, const std::string& t, long B) {
     return best;
 }
 
+// Seed index of the genome: every 7th 24-mer (ACGT only) packed into 48 bits, with its position, sorted by (key, position) - a lookup returns the FIRST position
+// of the key, what the hash map of the first version (emplace in ascending order) kept. Round 6: that map took minutes on a 400 Mb genome (57 M std::string
+// keys, built on one thread); this builds on every thread (buckets by the key's top byte, each sorted on its own) and holds 16 bytes per seed.
+struct SeedIndex {
+    std::vector<std::pair<uint64_t, int64_t>> v;
+    static bool pack(const char* p, int K, uint64_t& key) {
+        key = 0;
+        for (int i = 0; i < K; i++) {
+            const char c = p[i];
+            const uint64_t b = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
+            if (b > 3) return false;
+            key = key << 2 | b;
+        }
+        return true;
+    }
+    void build(const std::string& G, int K, long step, unsigned T) {
+        const long n = (long)G.size() >= K ? ((long)G.size() - K) / step + 1 : 0;
+        std::vector<std::vector<std::pair<uint64_t, int64_t>>> part(T);
+        std::vector<std::thread> th;
+        auto scan = [&](unsigned t) {
+            auto& o = part[t];
+            o.reserve((size_t)(n / T + 1));
+            for (long q = n * t / T; q < n * (t + 1) / T; q++) { uint64_t k; if (pack(G.data() + q * step, K, k)) o.push_back({k, q * step}); }
+        };
+        for (unsigned t = 1; t < T; t++) th.emplace_back(scan, t);
+        scan(0);
+        for (auto& x : th) x.join();
+        th.clear();
+        const int shift = 2 * K - 8;
+        std::vector<size_t> cnt(257, 0);
+        for (auto& o : part) for (auto& e : o) cnt[(e.first >> shift) + 1]++;
+        for (int b = 0; b < 256; b++) cnt[b + 1] += cnt[b];
+        v.resize(cnt[256]);
+        {
+            std::vector<size_t> at(cnt.begin(), cnt.end() - 1);
+            for (auto& o : part) { for (auto& e : o) v[at[e.first >> shift]++] = e; std::vector<std::pair<uint64_t, int64_t>>().swap(o); }   // (parts in position order: equal keys stay in ascending position)
+        }
+        std::atomic<int> next{0};
+        auto sorter = [&]() { for (;;) { const int b = next.fetch_add(1); if (b >= 256) return; std::sort(v.begin() + (long)cnt[b], v.begin() + (long)cnt[b + 1]); } };
+        for (unsigned t = 1; t < T; t++) th.emplace_back(sorter);
+        sorter();
+        for (auto& x : th) x.join();
+    }
+    long find(const char* p, int K) const {   // first position of the 24-mer at p, -1 if it is not a seed
+        uint64_t k;
+        if (!pack(p, K, k)) return -1;
+        auto it = std::lower_bound(v.begin(), v.end(), std::make_pair(k, (int64_t)INT64_MIN));
+        return it != v.end() && it->first == k ? (long)it->second : -1;
+    }
+};
+
 // identity of one record on one strand; hits = windows that found a placement
 struct StrandResult { long ed = 0, len = 0, bad = 0; };
-static StrandResult eval_strand(const std::string& q, const std::string& G, const std::unordered_map<std::string, long>& idx, int K, long B) {
+static StrandResult eval_strand(const std::string& q, const std::string& G, const SeedIndex& idx, int K, long B) {
     StrandResult r;
     const long WIN = 20000;
     // windows are placed independently (seeded inside the window), so cumulative indel drift never leaves the band
@@ -68,8 +120,8 @@ static StrandResult eval_strand(const std::string& q, const std::string& G, cons
         // offset by majority vote of seeds spread over the window (a single seed may sit in a repeat copy or straddle an error)
         std::vector<long> offs;
         for (long i = 0; i + K <= wl; i += 31) {
-            auto it = idx.find(win.substr(i, K));
-            if (it != idx.end()) offs.push_back(it->second - i);
+            const long at = idx.find(win.data() + i, K);
+            if (at >= 0) offs.push_back(at - i);
         }
         long off = -1000000000L;
         if (!offs.empty()) {
@@ -97,10 +149,18 @@ int main(int argc, char** argv) {
     long B = argc > 3 ? atol(argv[3]) : 400;
     unsigned T = argc > 4 ? (unsigned)atoi(argv[4]) : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
     if (g.empty()) return 2;
-    const std::string& G = g[0].second;
+    // a genome of several records (hxsim --chromosomes) is searched as one sequence, the records a thousand N apart (no seed, no window spans two)
+    std::string joined;
+    if (g.size() > 1) {
+        size_t tot = 0;
+        for (auto& r : g) tot += r.second.size() + 1000;
+        joined.reserve(tot);
+        for (auto& r : g) { joined += r.second; joined.append(1000, 'N'); std::string().swap(r.second); }
+    }
+    const std::string& G = g.size() > 1 ? joined : g[0].second;
     const int K = 24;
-    std::unordered_map<std::string, long> idx;
-    for (long i = 0; i + K <= (long)G.size(); i += 7) idx.emplace(G.substr(i, K), i);
+    SeedIndex idx;
+    idx.build(G, K, 7, T);
     // records are independent: dealt to threads, reported in file order
     struct Out { std::string line; double ident = 0; long len = 0; bool placed = false; };
     std::vector<Out> out(qs.size());
@@ -116,7 +176,7 @@ int main(int argc, char** argv) {
             for (int s2 = 0; s2 < 2; s2++) {
                 const std::string& q = s2 == 0 ? rec.second : r;
                 const long lim = std::min<long>((long)q.size(), 200000);
-                for (long i = 0; i + K <= lim; i += 13) votes[s2] += idx.count(q.substr(i, K));
+                for (long i = 0; i + K <= lim; i += 13) votes[s2] += idx.find(q.data() + i, K) >= 0;
             }
             char buf[256];
             if (!votes[0] && !votes[1]) { snprintf(buf, sizeof buf, "%s\tlen=%zu\tUNPLACED\n", rec.first.c_str(), rec.second.size()); out[k].line = buf; continue; }

@@ -1,0 +1,36 @@
+#!/bin/bash
+# round 6, GPU call 2: what the allocation of the consensus workspace costs and how it can be split, the one-shot binary before / after, the GPU suite with
+# durations, and configs[4]'s whole workload on the one GPU
+set -u
+O=gpurun_out/r06_2
+mkdir -p $O
+export HASLR_BENCH_DIR=/tmp/haslr_bench
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/allocbench tools/dev_allocbench.hip -lpthread 2> $O/allocbench_build.err
+timeout 600 /tmp/allocbench 208 > $O/allocbench.txt 2>&1
+timeout 900 python bench.py --workload fly --steps 3 --warmup 1 --no-cpu-baseline --no-configs1 > $O/bench_fly.json 2> $O/bench_fly.err
+cp /tmp/haslr_bench/cli_fly.stderr.txt $O/ 2>/dev/null
+FLY=/tmp/haslr_bench/gpu_pacbio_g140000000_s4841534f
+cli() { # tag prefix env...
+  tag=$1; pre=$2; shift 2
+  rm -rf /tmp/cli_$tag
+  s=$(date +%s.%N)
+  env "$@" HASLR_STAGE_TIMES=$O/cli_$tag.json haslr_amd/bin/haslr_assemble -t 64 -c $pre.contigs.fa -l $pre.reads.fa -m $pre.paf -d /tmp/cli_$tag > /dev/null 2> $O/cli_$tag.err
+  e=$(date +%s.%N)
+  echo "$tag wall $(echo "$e - $s" | bc) s : $(cat $O/cli_$tag.json)"
+  rm -rf /tmp/cli_$tag
+}
+for i in 1 2; do
+  cli fly_old_$i $FLY HASLR_NO_RESERVE=1 HASLR_INDEX_SYNC=1
+  cli fly_new_$i $FLY A=1
+done > $O/cli_ab.txt 2>&1
+HX_DEBUG=1 HASLR_IO_DEBUG=1 haslr_amd/bin/haslr_assemble -t 64 -c $FLY.contigs.fa -l $FLY.reads.fa -m $FLY.paf -d /tmp/cli_dbg > /dev/null 2> $O/cli_fly_debug.err; rm -rf /tmp/cli_dbg
+grep -v "hx-edge" $O/cli_fly_debug.err > $O/cli_fly_debug.txt; rm -f $O/cli_fly_debug.err
+timeout 1500 python -m pytest tests -m gpu -x -q --durations=25 > $O/gpu_tests.log 2>&1
+tail -5 $O/gpu_tests.log
+rm -rf /tmp/haslr_bench /tmp/pytest-of-root
+timeout 300 python tools/full_size_check.py chm1_rehearsal > $O/chm1_rehearsal.json 2> $O/chm1_rehearsal.err
+tail -3 $O/chm1_rehearsal.err
+rm -rf /tmp/full_size /dev/shm/full_size
+timeout 2700 python tools/full_size_check.py chm1 > $O/chm1.json 2> $O/chm1.err
+tail -5 $O/chm1.err
+rm -rf /dev/shm/full_size /tmp/full_size
