@@ -792,7 +792,7 @@ struct PoaCall {
         return k;
     }
     uint32_t lanes_of(uint32_t e) const { return P.edges[e].members > 1 ? mlanes[e] : (uint32_t)kClassNT[class_of(e)]; }   // lanes of the edge's workgroup(s)
-    static uint32_t cm_round(uint32_t ncol, uint32_t lanes) { uint32_t cm = (ncol + lanes - 1) / lanes, r = 4; while (r < cm) r <<= 1; return r; }
+    static uint32_t cm_round(uint32_t ncol, uint32_t lanes, uint32_t r = 4) { const uint32_t cm = (ncol + lanes - 1) / lanes; while (r < cm) r <<= 1; return r; }   // (r: the narrowest instance that exists for the launch)
     // kept rows the LDS ring holds; row_bytes returns the LDS bytes of the ring
     uint32_t ring_rows_of(uint32_t nt, uint32_t cm, uint64_t& row_bytes) const {
         row_bytes = (uint64_t)cm * (nt / 64) * 65 * 4;   // planes of 65 words per wave
@@ -935,7 +935,7 @@ struct PoaCall {
             hxk::PoaEdge& E = P.edges[e];
             const uint32_t ncol = E.lmax + 1, nt = lanes_of(e);
             uint64_t rb;
-            const uint32_t cmq = cm_round(ncol, E.members > 1 ? E.members * nt : nt * std::max<uint32_t>(1, E.passes));
+            const uint32_t cmq = cm_round(ncol, E.members > 1 ? E.members * nt : nt * std::max<uint32_t>(1, E.passes), E.members > 1 && cl_cols < 4 ? 2u : 4u);
             const uint32_t Rp = ring_rows_of(nt, cmq, rb);
             // measured on PacBio-like data, rows read back from HBM per DP row: 0.15-0.4 % with 8 ring rows, 3-5 % with 4, 16-25 % on average
             // with 2 (single edges: up to every kept row, ~60 % of the rows). Graphs fill ~70 % of the node estimate these are fractions of.
@@ -991,7 +991,8 @@ struct PoaCall {
             const uint32_t ncol = P.edges[e].lmax + 1;
             if (P.edges[e].members > 1) {
                 const uint32_t ml = mlanes[e];
-                const uint32_t cmr = cm_round(ncol, P.edges[e].members * ml);
+                uint32_t cmr = cm_round(ncol, P.edges[e].members * ml, cl_cols < 4 ? 2u : 4u);
+                if (cmr < 4 && hxk::poa_kernel_min_cm(n_wide < wide_k && ml < 1024 ? 1024 : (int)ml, true, true) > 2) cmr = 4;
                 if (cmr > (uint32_t)hxk::poa_kernel_max_cm((int)ml)) return fail("hx_poa_batch: gap too long for the configured cluster size (raise option poa_cluster_max)");
                 // the costliest shared edges run with WIDE members: workgroups of 1024 lanes of which the first cl_lanes take part in the DP (one
                 // wave per SIMD, as before) and all sixteen waves in the graph phases of member 0 (graph update, CSR build, orders: latency-bound

@@ -141,6 +141,9 @@ struct PoaPools {
 // kernel instance (largest workgroup it is compiled for) that serves workgroups of `block_threads` lanes, and the columns per lane it can be had with
 inline int poa_kernel_lanes(int block_threads) { return block_threads <= 64 ? 64 : block_threads <= 256 ? 256 : block_threads <= 512 ? 512 : 1024; }
 inline int poa_kernel_max_cm(int block_threads) { return block_threads <= 256 ? 32 : block_threads <= 512 ? 16 : 32; }
+// (2 columns per lane: instances for the members of shared edges only - 256-lane workgroups and the 1024-lane wide members, direction bytes, one workgroup per
+// entry of the launch. A lone wave's row is bound by its instruction count, and a row of 2 columns is ~28 instructions shorter than one of 4.)
+inline int poa_kernel_min_cm(int block_threads, bool shared, bool use_dir) { return shared && use_dir && (block_threads == 256 || block_threads == 1024) ? 2 : 4; }
 inline bool poa_persistent_ok(bool use_dir) { return use_dir; }   // launches that can run persistent (the score-matrix flavour is rare: one workgroup per edge)
 // Exact score-bound pruning of the DP (kernels/poa.hip "PRUNE"): instances exist for the direction-byte flavour with 4 or 8 columns per lane, for
 // launches of one workgroup per edge (a shared edge's members would have to repeat an attempt together)

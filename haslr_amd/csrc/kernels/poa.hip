@@ -645,11 +645,12 @@ template <int CM> __device__ __forceinline__ void store_nibbles(uint8_t* p, cons
 #endif
 // (the row's resource covers W / 2 bytes = exactly the pitch of the nibble matrix: dp_rows steps its row pointer by the same W >> 1)
 template <int CM> __device__ __forceinline__ void store_nibbles_buf(__amdgpu_buffer_rsrc_t r, const uint32_t off, const uint32_t (&v)[CM]) {
-    static_assert(CM >= 4 && CM % 4 == 0, "4, 8, 16 or 32 columns per lane");
+    static_assert(CM == 2 || (CM >= 4 && CM % 4 == 0), "2, 4, 8, 16 or 32 columns per lane");
     uint32_t b[CM / 2];
 #pragma unroll
     for (int q = 0; q < CM / 2; q++) b[q] = (v[2 * q] & 15u) | (v[2 * q + 1] << 4);
-    if constexpr (CM == 4) __builtin_amdgcn_raw_buffer_store_b16((short)__builtin_amdgcn_perm(b[1], b[0], 0x0c0c0400u), r, (int)off, 0, 0);
+    if constexpr (CM == 2) __builtin_amdgcn_raw_buffer_store_b8((char)b[0], r, (int)off, 0, 0);   // (two columns per lane - the members of the few-edge regime's shared edges: a byte per lane)
+    else if constexpr (CM == 4) __builtin_amdgcn_raw_buffer_store_b16((short)__builtin_amdgcn_perm(b[1], b[0], 0x0c0c0400u), r, (int)off, 0, 0);
     else {
         uint32_t w[CM / 8];
 #pragma unroll
@@ -1006,7 +1007,14 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             uint32_t rj0 = 0;
             if constexpr (PRUNE) rj0 = skip_run(0u);
             uint32_t meta_nx = __builtin_amdgcn_readlane(mC, (rb + rj0) & 63u), p0_nx = __builtin_amdgcn_readlane(aC, (rb + rj0) & 63u);
-            for (uint32_t rj = rj0; rj < nb; rj++) {
+            // The row, in two forms of one body. FAST (direction bytes, no pruning: the instances of the few-edge regime, where ONE wave's instruction count per row is
+            // what the call waits for) = a row whose record names ONE predecessor, the previous row: three rows in five. Such rows run in a loop of their own
+            // (below): the cells come straight out of the previous row's registers (as one of three sources joined in one set of registers the compiler copies them:
+            // six v_mov), the row format's constants are the 4-bit ones, and neither the dispatch on the first predecessor's location nor the branch around the
+            // later predecessors exists. (Round 5 tried the same cells as a block inside the one loop: + 14 %, through the two taken branches around it.)
+            uint32_t rj = rj0;
+            auto row = [&](auto fast_tag) __attribute__((always_inline)) {
+                constexpr bool FAST = decltype(fast_tag)::value;
                 const uint32_t ri = rb + rj, i = ib + ri + 1;
                 const uint32_t meta = meta_nx, p0 = p0_nx;
                 const uint32_t npred = meta >> META_NP;
@@ -1054,7 +1062,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                             const uint32_t run = skip_run(rj + 1u);
                             if (run != 0u) { rj += run; meta_nx = __builtin_amdgcn_readlane(mC, (rb + rj + 1u) & 63u); p0_nx = __builtin_amdgcn_readlane(aC, (rb + rj + 1u) & 63u); }
                         }
-                        continue;
+                        return;
                     }
                 }
                 // mismatch bits of this row: bit 2k set <=> the base under column k differs from the row's letter
@@ -1068,11 +1076,16 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 // Move codes (the low 6 bits of a key while a row is computed; they are masked off before the row is used as a predecessor, so the
                 // format is the row's own). A row with at most 4 predecessors uses 4 bits - type * 4 + 3 - predecessor slot - which are its
                 // traceback nibble as they are; a "wide" row (rare) uses type * 16 + 15 - slot and stores a byte per cell in a side pool.
-                const bool wide = !DIR || (meta & 32u);
+                const bool wide = !FAST && (!DIR || (meta & 32u));   // (a fast row has one predecessor: never the wide format)
                 // (a diagonal move leaves the ramp of column j - 1 for that of column j; a finished key carries KHC; both formats' constants wait in
                 // scalar registers: one bit test and three selects per row)
                 const int md = wide ? mdW : mdN, gv = wide ? gvW : gvN, mmd = wide ? mdW + (mm64 - m64) : mdN + (mm64 - m64);
                 auto score_of = [&](int k) -> int {   // 64 x substitution score of column k + the diagonal move code
+                    if constexpr (CM <= 8 && FAST) {   // (the bit field through an asm statement: with constant terms around it the compiler turns one of the cells into v_and + v_cmp + two v_mov + v_cndmask)
+                        int bit;
+                        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(bit) : "v"(hit), "n"((4 * k) & 31));
+                        return mmd + ((m64 - mm64) & bit);
+                    }
                     if constexpr (CM <= 8) return mmd + ((m64 - mm64) & __builtin_amdgcn_sbfe((int)hit, (4 * k) & 31, 1));   // (-1 on a match)
                     int neg;   // -1 on a mismatch, 0 on a match
                     if constexpr (CM <= 16) neg = __builtin_amdgcn_sbfe((int)mis, 2 * k, 1);
@@ -1082,6 +1095,13 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 hrow += WH;
                 DP_T(0);   // row decode
                 int m[CM];
+                if constexpr (FAST) {
+                    // (see the loops below: ONE predecessor, the previous row - its cells straight from the registers they are in, the 4-bit row format's constants,
+                    // no dispatch, nothing behind the cells to skip)
+                    const int left = wave_shift_up1(tp[CM - 1], lnp);
+#pragma unroll
+                    for (int k = 0; k < CM; k++) m[k] = max((k == 0 ? left : tp[k - 1]) + score_of(k), tp[k] + gv);
+                } else
                 if (!PRUNE || __builtin_expect(fl0 != 0u, 1)) {   // the first predecessor (or row 0): diagonal and vertical move
 #ifndef HX_NO_PREV_DIRECT
                     if (PRUNE && __builtin_expect((p0 >> 28) == 13u, 1)) {   // (PRUNE = the instances of the many-edge regime; the row of the 4-column instances a lone wave runs got 14 % SLOWER with this block: 292 -> 332 M cycles on the longest 12 Mb edge)
@@ -1104,7 +1124,7 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
 #pragma unroll
                     for (int k = 0; k < CM; k++) m[k] = NEGK;
                 }
-                if (npred > 1) {   // (two rows in five at 25-45x)
+                if (!FAST && npred > 1) {   // (two rows in five at 25-45x)
                     // the maximum over the predecessors: the low bits carry the move type and 15 - p, so ONE running maximum does it all
                     // (a diagonal beats a vertical move of the same score, the first predecessor in in-edge order beats the later ones).
                     // The second, third and fourth predecessor are spelled out - their entries come with the row records, one readlane each, and most of
@@ -1234,6 +1254,26 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                         nsink++;
                     }
                 }
+            };
+            constexpr bool FAST_OK = DIR && !PRUNE;
+            // fast <=> one predecessor (meta >> META_NP == 1) with the location code 13 (the previous row). Which rows of the batch are is read off the 64 records in
+            // their lanes ONCE, as a mask (bit r = row i0 + r, nothing beyond the batch); a run of fast rows is then a counted loop - its back edge is s_sub + s_cmp +
+            // one branch (as a test of the next row's record after every row it was a flag-guarded pair of branches and five scalar instructions).
+            unsigned long long fastm = 0;
+            if constexpr (FAST_OK) {
+                fastm = __builtin_amdgcn_ballot_w64(((mC >> META_NP) << 4 | (aC >> 28)) == (1u << 4 | 13u)) >> rb;
+                if (nb < 64u) fastm &= (1ull << nb) - 1ull;
+            }
+            while (rj < nb) {
+                if constexpr (FAST_OK) {
+                    uint32_t run = (uint32_t)__builtin_ctzll(~(fastm >> rj));   // (bit nb - rj of the complement is set: the run ends with the batch at the latest)
+                    if (__builtin_expect(run != 0u, 1)) {
+                        do { row(std::true_type{}); rj++; } while (--run != 0u);
+                        continue;
+                    }
+                }
+                row(std::false_type{});
+                rj++;
             }
             if constexpr (PRUNE) lazy = (uint32_t)(n_dead - dead_before == nb) & lazy_on;
         }
@@ -2382,6 +2422,7 @@ __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const P
     void poa_run_##MNT(const PoaLaunch& q, hipStream_t s, bool prune) { \
         const int cm = q.cm; \
         if (prune) { if (cm <= 4) HX_LAUNCH_PR(MNT, 4); else HX_LAUNCH_PR(MNT, 8); return; } \
+        if constexpr (MNT == 256 || MNT == 1024) { if (cm <= 2 && q.use_dir && !q.counter) { HX_LAUNCH(MNT, 2, true, false, false); return; } }   /* (2 columns per lane: the members of shared edges, poa_kernel_min_cm) */ \
         if (cm <= 4) HX_LAUNCH_CM(MNT, 4); else if (cm <= 8) HX_LAUNCH_CM(MNT, 8); else if (cm <= 16 || LAST_CM == 16) HX_LAUNCH_CM(MNT, 16); else HX_LAUNCH_CM(MNT, LAST_CM); \
     }
 #ifdef HX_POA_HAS_64

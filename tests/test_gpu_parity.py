@@ -335,7 +335,9 @@ def test_score_matrix_traceback_matches_direction_bytes(sim, ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [("300", "64", "8", "8", "0"), ("300", "64", "4", "3", "100"), ("500", "128", "4", "4", "2"), ("400", "256", "8", "8", "100"),
-                                 ("300", "64", "4", "3", "0"), ("400", "256", "8", "8", "0")])
+                                 ("300", "64", "4", "3", "0"), ("400", "256", "8", "8", "0"),
+                                 # two columns per lane (round 6: the members of the few-edge regime's shared edges): 256-lane members, wide members, members without a column
+                                 ("300", "256", "2", "8", "0"), ("200", "256", "2", "3", "100"), ("400", "256", "2", "16", "2")])
 def test_shared_edges_cluster_mode(sim, ctx, cfg):
     """cluster mode: the DP columns of an edge spread over several workgroups (forced here on short gaps with small members, so that
     every variant — single-wave members, multi-wave members, members without columns for a short read, sink rows in another member —
