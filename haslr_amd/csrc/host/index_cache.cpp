@@ -19,6 +19,8 @@
 // text-parse results, and the files it writes load here into the arrays a text parse gives (tests/test_index_cache.py).
 #include "host_internal.h"
 
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstring>
 
@@ -141,14 +143,14 @@ bool write_longread_index(const Dataset& d, const hx_chain_out& ch, const std::s
         put32(p + 24, (uint32_t)(ch.read_off[i + 1] - ch.read_off[i]));
         seqs += comp_len_of(d.read_len[i]);
     }
-    // The two big blocks (every read re-coded, every kept CIGAR spelled out: gigabytes at full size) are produced and written in CHUNKS
-    // of a few dozen megabytes through buffers that are reused: the CLI runs this beside the GPU stages, and gigabytes of freshly
-    // faulted-in host memory there slowed the device allocations of the consensus stage by seconds. Within a chunk the records are
-    // dealt to a few threads. The alignment records carry the length of their text, so the lengths are counted first.
-    const unsigned T = std::max(1u, std::min(g_io_threads, 8u));
+    // The two big blocks (every read re-coded, every kept CIGAR spelled out: 3.3 GB at 140 Mb) are produced and written by several threads AT ONCE, each its own
+    // range of the file (round 6; the lengths of every text are counted first - the alignment records carry them - so every byte's place in the file is known
+    // before any is produced): chunks of a few megabytes through a buffer per thread that is reused, positional writes. (Until round 5: eight threads produced a
+    // chunk, one wrote it: 1.35 s at 140 Mb, more than what is left of a one-shot run when the filtered set is known.)
+    const unsigned T = std::max(1u, std::min(g_io_threads, 16u));
     const uint64_t na = ch.n_aln;
     std::vector<uint8_t> al(na * 48, 0);
-    std::vector<uint64_t> cgl_part(T, 0);
+    std::vector<uint64_t> cg_at(na + 1, 0);   // place of every alignment's text in the block (each text is followed by a NUL)
     run_parallel(T, [&](unsigned t) {
         for (uint64_t a = na * t / T; a < na * (t + 1) / T; a++) {
             const uint32_t h = ch.hit[a];
@@ -161,43 +163,54 @@ bool write_longread_index(const Dataset& d, const hx_chain_out& ch, const std::s
             if (it != d.cg_text_odd.end()) len = it->second.size();
             else for (uint64_t k = d.cg_off[h]; k < d.cg_off[h + 1]; k++) { const uint32_t v = HX_CG_LEN(d.cg_ops[k]); len += 2 + (v >= 10) + (v >= 100) + (v >= 1000) + (v >= 10000) + (v >= 100000) + (v >= 1000000) + (v >= 10000000) + (v >= 100000000) + (v >= 1000000000); }
             put32(p + 36, (uint32_t)len);
-            cgl_part[t] += len + 1;
+            cg_at[a + 1] = len + 1;
         }
     });
-    uint64_t cs = 0;
-    for (uint64_t x : cgl_part) cs += x;
-    bool ok = f.w(&n, 8) && f.w(recs.data(), recs.size()) && f.w(&seqs, 8);
-    {   // sequences
-        const uint64_t CHUNK = 48ull << 20;
+    for (uint64_t a = 0; a < na; a++) cg_at[a + 1] += cg_at[a];
+    const uint64_t cs = cg_at[na];
+    std::vector<uint64_t> sq_at(n + 1, 0);
+    for (uint64_t i = 0; i < n; i++) sq_at[i + 1] = sq_at[i] + comp_len_of(d.read_len[i]);
+    // layout: n | records | seqs | <sequences> | na | alignments | cs | <texts>
+    const uint64_t o_seq = 8 + recs.size() + 8, o_na = o_seq + seqs, o_cg = o_na + 8 + al.size() + 8;
+    bool ok = f.w(&n, 8) && f.w(recs.data(), recs.size()) && f.w(&seqs, 8) && fflush(f.fp) == 0;
+    const int fd = fileno(f.fp);
+    auto put = [fd](const void* p, uint64_t bytes, uint64_t at) -> bool {
+        const char* q = (const char*)p;
+        while (bytes) {
+            const ssize_t w = pwrite(fd, q, bytes, (off_t)at);
+            if (w <= 0) return false;
+            q += w; at += (uint64_t)w; bytes -= (uint64_t)w;
+        }
+        return true;
+    };
+    ok = ok && put(&na, 8, o_na) && put(al.data(), al.size(), o_na + 8) && put(&cs, 8, o_na + 8 + al.size());
+    std::vector<uint8_t> bad(T, 0);
+    run_parallel(T, [&](unsigned t) {
+        const uint64_t CHUNK = 8ull << 20;
         U8Arena buf;
-        std::vector<uint64_t> off;
-        for (uint64_t i0 = 0; ok && i0 < n;) {
-            uint64_t i1 = i0, bytes = 0;
-            off.clear();
-            while (i1 < n && (bytes < CHUNK || i1 == i0)) { off.push_back(bytes); bytes += comp_len_of(d.read_len[i1]); i1++; }
+        // sequences of this thread's reads, a chunk at a time
+        for (uint64_t i0 = n * t / T, iend = n * (t + 1) / T; i0 < iend && !bad[t];) {
+            uint64_t i1 = i0;
+            while (i1 < iend && (sq_at[i1] - sq_at[i0] < CHUNK || i1 == i0)) i1++;
+            const uint64_t bytes = sq_at[i1] - sq_at[i0];
             if (buf.size() < bytes) buf.resize(bytes);
-            const uint64_t m = i1 - i0;
-            run_parallel(T, [&](unsigned t) {
-                for (uint64_t k = m * t / T; k < m * (t + 1) / T; k++) to_ref_codec(d.read_packed.data() + d.read_off[i0 + k], d.read_len[i0 + k], buf.data() + off[k]);
-            });
-            ok = f.w(buf.data(), bytes);
+            for (uint64_t i = i0; i < i1; i++) to_ref_codec(d.read_packed.data() + d.read_off[i], d.read_len[i], buf.data() + (sq_at[i] - sq_at[i0]));
+            if (!put(buf.data(), bytes, o_seq + sq_at[i0])) bad[t] = 1;
             i0 = i1;
         }
-    }
-    ok = ok && f.w(&na, 8) && f.w(al.data(), al.size()) && f.w(&cs, 8);
-    {   // CIGAR texts, each followed by a NUL
-        const uint64_t PER = 16384;   // alignments per chunk
-        std::vector<std::string> part(T);
-        for (uint64_t a0 = 0; ok && a0 < na; a0 += PER) {
-            const uint64_t m = std::min<uint64_t>(PER, na - a0);
-            run_parallel(T, [&](unsigned t) {
-                std::string& out = part[t];
-                out.clear();
-                for (uint64_t k = m * t / T; k < m * (t + 1) / T; k++) { append_cigar_text(d, ch.hit[a0 + k], out); out.push_back('\0'); }
-            });
-            for (const std::string& x : part) ok = ok && (x.empty() || f.w(x.data(), x.size()));
+        // CIGAR texts of this thread's alignments, each followed by a NUL
+        std::string out;
+        for (uint64_t a0 = na * t / T, aend = na * (t + 1) / T; a0 < aend && !bad[t];) {
+            uint64_t a1 = a0;
+            while (a1 < aend && (cg_at[a1] - cg_at[a0] < CHUNK || a1 == a0)) a1++;
+            out.clear();
+            for (uint64_t a = a0; a < a1; a++) { append_cigar_text(d, ch.hit[a], out); out.push_back('\0'); }
+            if (out.size() != cg_at[a1] - cg_at[a0] || !put(out.data(), out.size(), o_cg + cg_at[a0])) bad[t] = 1;
+            a0 = a1;
         }
-    }
+    });
+    for (uint8_t x : bad) ok = ok && !x;
+    if (ok && o_cg + cs > 0 && cs == 0) ok = ftruncate(fd, (off_t)o_cg) == 0;   // (no alignment at all: the file still ends behind the empty block's size word)
     if (!ok || !f.commit()) { g_err = "[ERROR] could not write " + path; return false; }
     return true;
 }

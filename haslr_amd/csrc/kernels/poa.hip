@@ -1255,7 +1255,11 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                     }
                 }
             };
+#ifdef HX_NO_FAST_ROWS   // (development: A/B against the one-loop form)
+            constexpr bool FAST_OK = false;
+#else
             constexpr bool FAST_OK = DIR && !PRUNE;
+#endif
             // fast <=> one predecessor (meta >> META_NP == 1) with the location code 13 (the previous row). Which rows of the batch are is read off the 64 records in
             // their lanes ONCE, as a mask (bit r = row i0 + r, nothing beyond the batch); a run of fast rows is then a counted loop - its back edge is s_sub + s_cmp +
             // one branch (as a test of the next row's record after every row it was a flag-guarded pair of branches and five scalar instructions).
