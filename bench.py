@@ -284,8 +284,12 @@ def run_group(args):
     (a bounded sample, extrapolated), and an N = 1 pass of the plain path over the same data on rank 0's device (`n1_same_data`)."""
     import ctypes as C
 
+    import torch
     from haslr_amd import ctypes_defs as T
     from haslr_amd import hip, host
+    if torch.cuda.is_available():
+        torch.zeros(1, device="cuda")   # torch's HIP context first, as in the launcher path (it bundles its own runtime)
+        torch.cuda.synchronize()
     n = args.gpus
     workload, glen, chroms, as_named = multi_gpu_workload(n, args.workload, args.genome_len)
     wl = WORKLOADS[workload]

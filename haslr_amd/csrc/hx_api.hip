@@ -137,6 +137,7 @@ struct HxOptions {
     int poa_poll_limit = 1 << 24;  // polls before a wave gives up waiting for another member (testing: forces the unshared retry)
     int poa_max_indeg = 16;        // in-degree the direction bytes hold (testing: forces the score-matrix retry earlier)
     int poa_member_lanes = 256, poa_cluster_min = 2048, poa_cluster_max = -1, poa_cluster_topk = -1, poa_wide_members = -1, poa_cluster_cols = -1;
+    int poa_cols2_top = -1;        // the costliest shared edges of a call whose members take 2 columns per lane (twice the members, a shorter row): how many (-1: 4 in a few-edge call, else none)
     int poa_node_est_pct = 100, poa_far_rows = -1;
     int poa_wave_max = 512, poa_cols = -1, poa_ring_kb = -1, poa_ring_zero = 0;
     int poa_balance = 1, poa_balance_pct = 125, poa_balance_lanes = 512;
@@ -156,7 +157,7 @@ const OptDesc kOptions[] = {
     {"debug", &HxOptions::debug, nullptr}, {"prof", &HxOptions::prof, nullptr}, {"poa_workspace_gb", nullptr, &HxOptions::poa_workspace_gb},
     {"poa_poll_limit", &HxOptions::poa_poll_limit, nullptr}, {"poa_max_indeg", &HxOptions::poa_max_indeg, nullptr}, {"poa_member_lanes", &HxOptions::poa_member_lanes, nullptr},
     {"poa_cluster_min", &HxOptions::poa_cluster_min, nullptr}, {"poa_cluster_max", &HxOptions::poa_cluster_max, nullptr}, {"poa_cluster_topk", &HxOptions::poa_cluster_topk, nullptr},
-    {"poa_wide_members", &HxOptions::poa_wide_members, nullptr}, {"poa_cluster_cols", &HxOptions::poa_cluster_cols, nullptr}, {"poa_node_est_pct", &HxOptions::poa_node_est_pct, nullptr},
+    {"poa_wide_members", &HxOptions::poa_wide_members, nullptr}, {"poa_cluster_cols", &HxOptions::poa_cluster_cols, nullptr}, {"poa_cols2_top", &HxOptions::poa_cols2_top, nullptr}, {"poa_node_est_pct", &HxOptions::poa_node_est_pct, nullptr},
     {"poa_far_rows", &HxOptions::poa_far_rows, nullptr}, {"poa_wave_max", &HxOptions::poa_wave_max, nullptr}, {"poa_cols", &HxOptions::poa_cols, nullptr},
     {"poa_ring_kb", &HxOptions::poa_ring_kb, nullptr}, {"poa_ring_zero", &HxOptions::poa_ring_zero, nullptr}, {"poa_balance", &HxOptions::poa_balance, nullptr},
     {"poa_balance_pct", &HxOptions::poa_balance_pct, nullptr}, {"poa_balance_lanes", &HxOptions::poa_balance_lanes, nullptr}, {"poa_slots_pct", &HxOptions::poa_slots_pct, nullptr},
@@ -687,6 +688,7 @@ struct PoaCall {
     std::vector<uint8_t> no_share;     // edges whose members did not get through together: one workgroup from now on
     std::vector<uint8_t> many_sinks;   // edges with more sink rows than the smaller kernels keep in LDS: one 1024-lane workgroup
     std::vector<uint8_t> far_full;     // times an edge's far rows outgrew the estimate: four times the room each time
+    std::vector<uint8_t> ecols;        // shared edges: columns per lane their members aim at (cl_cols, or 2 for the costliest: option poa_cols2_top)
     std::vector<uint32_t> mlanes;      // shared edges: lanes per member (the option's, or 1024 where the gap needs them to fit at all)
     // knobs of this round (the option, or what the number of edges in the call asks for)
     bool many_edges = false, balanced = false;
@@ -724,7 +726,7 @@ struct PoaCall {
         for (uint32_t e = 0; e < ne; e++) if (P.nseq[e]) todo.push_back(e);
         cns.assign(ne, std::string());
         grow.assign(ne, 0); force_nodir.assign(ne, 0); full_h.assign(ne, 0); wide_grow.assign(ne, 0); no_share.assign(ne, 0); many_sinks.assign(ne, 0); far_full.assign(ne, 0);
-        mlanes.assign(ne, 0); plane.assign(ne, 0); chain_ms.assign(ne, 0.f);
+        mlanes.assign(ne, 0); plane.assign(ne, 0); chain_ms.assign(ne, 0.f); ecols.assign(ne, 4);
         return 0;
     }
 
@@ -828,6 +830,22 @@ struct PoaCall {
             // rows of H. The score-matrix traceback keeps every row; with direction bytes only rows that a successor reads after they left
             // the LDS ring go to HBM (about 1 row in 1000 on PacBio-like data): a sixteenth of the rows is the estimate, all of them the retry
             full_h[e] = c->poa_no_dir || force_nodir[e];   // (any number of sequences: the kernel reports an in-degree the direction bytes cannot hold, see max_indeg)
+        }
+        // (option poa_cols2_top, few-edge calls: the costliest edges that will be shared get members of 2 columns per lane - the kernel instances of the 256-lane
+        // members and the 1024-lane wide members exist with 2 columns)
+        for (uint32_t e : todo) ecols[e] = (uint8_t)cl_cols;
+        // Measured (round 6, A/B in one GPU call): the longest 12 Mb edge's chain 159.6 -> 150 ms with 2 columns per lane (its row is ~28 instructions shorter, its
+        // members twice as many); as the shape of ALL 192 shared edges the step got worse, 0.164 -> 0.195 s (twice the member waves crowd the chip: edges start
+        // late); for the 4 costliest - the ones that get wide members - 0.164 -> 0.159 s (8: 0.161, 16: 0.164, 32: 0.175), 4.6 Mb 0.113 -> 0.110 s.
+        const int cols2_top = o.poa_cols2_top >= 0 ? o.poa_cols2_top : (ne > kManyEdges ? 0 : 4);
+        if (cols2_top > 0 && cl_lanes == 256) {
+            std::vector<uint32_t> cand;
+            for (uint32_t e : todo) if (P.edges[e].lmax + 1 > cl_min && !c->poa_block && !c->poa_no_dir && !force_nodir[e] && !many_sinks[e] && !no_share[e]) cand.push_back(e);
+            std::sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) { const uint64_t ca = edge_cost(a), cb = edge_cost(b); return ca != cb ? ca > cb : a < b; });
+            for (size_t q = 0; q < cand.size() && q < (size_t)cols2_top; q++) ecols[cand[q]] = 2;
+        }
+        for (uint32_t e : todo) {
+            hxk::PoaEdge& E = P.edges[e];
             // long gaps: the DP columns of the edge are shared by several workgroups (one CU each). Members of cl_lanes lanes x up to 32 columns per
             // lane x up to cl_max members hold 131 071 columns by default; a longer gap sub-sequence (the u32 wrap of Assemble.cpp:530 makes "the whole
             // tail of a read" a real case) gets 1024-lane members, 16 of which hold 524 287 columns.
@@ -835,8 +853,9 @@ struct PoaCall {
             const uint32_t ncol = E.lmax + 1;
             const bool may_share = !c->poa_block && !c->poa_no_dir && !force_nodir[e] && !many_sinks[e] && !no_share[e];
             if (may_share && ncol > cl_min) {
+                const uint64_t ecl = ecols[e];
                 auto members_for = [&](uint32_t lanes) -> uint64_t {
-                    return std::min<uint64_t>(cl_max, std::max<uint64_t>(std::min<uint64_t>(cl_pref, (ncol + (uint64_t)lanes * cl_cols - 1) / ((uint64_t)lanes * cl_cols)), (ncol + (uint64_t)lanes * 32 - 1) / ((uint64_t)lanes * 32)));
+                    return std::min<uint64_t>(cl_max, std::max<uint64_t>(std::min<uint64_t>(cl_pref, (ncol + (uint64_t)lanes * ecl - 1) / ((uint64_t)lanes * ecl)), (ncol + (uint64_t)lanes * 32 - 1) / ((uint64_t)lanes * 32)));
                 };
                 uint64_t mb = members_for(cl_lanes);
                 if (((uint64_t)ncol + mb * cl_lanes - 1) / (mb * cl_lanes) > 32 && cl_lanes < 1024) { mlanes[e] = 1024; mb = members_for(1024); }   // (the gap does not fit the configured members)
@@ -935,7 +954,7 @@ struct PoaCall {
             hxk::PoaEdge& E = P.edges[e];
             const uint32_t ncol = E.lmax + 1, nt = lanes_of(e);
             uint64_t rb;
-            const uint32_t cmq = cm_round(ncol, E.members > 1 ? E.members * nt : nt * std::max<uint32_t>(1, E.passes), E.members > 1 && cl_cols < 4 ? 2u : 4u);
+            const uint32_t cmq = cm_round(ncol, E.members > 1 ? E.members * nt : nt * std::max<uint32_t>(1, E.passes), E.members > 1 && ecols[e] < 4 ? 2u : 4u);
             const uint32_t Rp = ring_rows_of(nt, cmq, rb);
             // measured on PacBio-like data, rows read back from HBM per DP row: 0.15-0.4 % with 8 ring rows, 3-5 % with 4, 16-25 % on average
             // with 2 (single edges: up to every kept row, ~60 % of the rows). Graphs fill ~70 % of the node estimate these are fractions of.
@@ -991,7 +1010,7 @@ struct PoaCall {
             const uint32_t ncol = P.edges[e].lmax + 1;
             if (P.edges[e].members > 1) {
                 const uint32_t ml = mlanes[e];
-                uint32_t cmr = cm_round(ncol, P.edges[e].members * ml, cl_cols < 4 ? 2u : 4u);
+                uint32_t cmr = cm_round(ncol, P.edges[e].members * ml, ecols[e] < 4 ? 2u : 4u);
                 if (cmr < 4 && hxk::poa_kernel_min_cm(n_wide < wide_k && ml < 1024 ? 1024 : (int)ml, true, true) > 2) cmr = 4;
                 if (cmr > (uint32_t)hxk::poa_kernel_max_cm((int)ml)) return fail("hx_poa_batch: gap too long for the configured cluster size (raise option poa_cluster_max)");
                 // the costliest shared edges run with WIDE members: workgroups of 1024 lanes of which the first cl_lanes take part in the DP (one

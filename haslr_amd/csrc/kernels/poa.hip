@@ -1178,7 +1178,8 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 int ex = wave_shift_up1(inc, NEGK);
                 DP_T(2);   // wave scan
                 const int cin = __builtin_amdgcn_readlane(cinV, rj);   // NEGK without a wave on the left
-                meta_nx = __builtin_amdgcn_readlane(mC, (ri + 1) & 63u); p0_nx = __builtin_amdgcn_readlane(aC, (ri + 1) & 63u);   // (the next row's record; beyond the batch: unused)
+                meta_nx = __builtin_amdgcn_readlane(mC, (ri + 1) & 63u);   // (the next row's record; beyond the batch: unused)
+                if constexpr (!FAST) p0_nx = __builtin_amdgcn_readlane(aC, (ri + 1) & 63u);   // (inside a run of fast rows the first predecessor is known; read again behind the run)
                 // the carry of this row for the wave on the right: the prefix maximum through this wave's last column (lane 63 holds it)
                 if (out_l != 0u) { if (lane == 63) *(volatile __attribute__((address_space(3))) unsigned long long*)(uintptr_t)mb_addr = (unsigned long long)mb_tag | ((unsigned long long)(uint32_t)max(cin, inc) << 32); }
                 if (out_h != 0u) { if (lane == 63) st_dev64(mb_out_h + i, (unsigned long long)mb_tag | ((unsigned long long)(uint32_t)max(cin, inc) << 32)); }
@@ -1255,10 +1256,14 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                     }
                 }
             };
-#ifdef HX_NO_FAST_ROWS   // (development: A/B against the one-loop form)
-            constexpr bool FAST_OK = false;
-#else
+            // Measured (round 6, 12 Mb, A/B of two builds in one GPU call): SLOWER - the longest edge's DP 284 -> 322 M cycles, the step 164 -> 180 ms. Its 303 916 rows
+            // are 42 % rows with several predecessors, 30 % rows whose one predecessor sits in the ring (bubbles interleave in rank order), and only 28 % fast rows, in
+            // runs of 1.3: what a run costs to set up (mask shift, count, the first predecessor's entry read again: ~100 cycles) and what every other row pays for the
+            // test is more than the ~25 instructions a fast row saves. Kept behind -DHX_FAST_ROWS (off) as the measured alternative it is.
+#ifdef HX_FAST_ROWS
             constexpr bool FAST_OK = DIR && !PRUNE;
+#else
+            constexpr bool FAST_OK = false;
 #endif
             // fast <=> one predecessor (meta >> META_NP == 1) with the location code 13 (the previous row). Which rows of the batch are is read off the 64 records in
             // their lanes ONCE, as a mask (bit r = row i0 + r, nothing beyond the batch); a run of fast rows is then a counted loop - its back edge is s_sub + s_cmp +
@@ -1270,9 +1275,13 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
             }
             while (rj < nb) {
                 if constexpr (FAST_OK) {
-                    uint32_t run = (uint32_t)__builtin_ctzll(~(fastm >> rj));   // (bit nb - rj of the complement is set: the run ends with the batch at the latest)
+                    // (bit nb - rj of the complement is set, so the run ends with the batch at the latest - except for a batch of 64 fast rows seen from its first
+                    // row: the complement is zero there, and the count of trailing zeros of zero is not 64 but whatever the instruction leaves)
+                    const unsigned long long inv = ~(fastm >> rj);
+                    uint32_t run = inv ? (uint32_t)__builtin_ctzll(inv) : 64u;
                     if (__builtin_expect(run != 0u, 1)) {
                         do { row(std::true_type{}); rj++; } while (--run != 0u);
+                        p0_nx = __builtin_amdgcn_readlane(aC, (rb + rj) & 63u);
                         continue;
                     }
                 }
