@@ -299,6 +299,43 @@ def run_group(args):
     t_parse = time.perf_counter() - t0
     prm = ds.params()
     L, H = hip.lib(), host.lib()
+    def sync():
+        torch.cuda.synchronize()
+
+    def solo_reference(warm):
+        """the plain single-context path (bench.py's N = 1 step) over the same data on device 0: the sharded assembly must equal its assembly, its steady step is this line's N = 1 reference"""
+        ctx = hip.HipContext(0)
+        upload_and_reserve(ctx, ds)
+        solo = host.Run(ds, prm, ctx.backend(), None)
+        t0 = time.perf_counter()
+        solo.all()
+        t_solo = time.perf_counter() - t0
+        sha1 = hashlib.sha256(solo.assembly_fasta().encode()).hexdigest()
+        solo.close()
+        dt1, run1 = measure(ctx, ds, prm, ctx.backend(), args.steps, warm, 1, 0, sync, None, 0, sharded=False)
+        run1.close(); ctx.close()
+        return sha1, t_solo, {"value": ds.total_read_bases * args.steps / dt1, "ms_per_step": dt1 / args.steps * 1e3, "steps": args.steps}
+    # One rank (the group code at N = 1, HASLR_BENCH_FORCE_GROUP): the N = 1 reference is the plain bench.py line of A PROCESS OF ITS OWN over the same files. Within one
+    # process whichever context is created second runs the 12 Mb step slower (measured both ways round: plain 184.6 ms after the group's 162.1 ms; group 172-219 ms
+    # after the plain pass's 153 ms) - the launch classes' streams of a second context do not get hardware queues of their own - which says nothing about either path:
+    # the product creates one context (or one group) per process. Several ranks: in this process, afterwards, when the group has given its memory back (a reference for
+    # the assembly and a rough N = 1 figure).
+    solo_first = n == 1
+    if solo_first:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(max(1, args.warmup)), "--no-cpu-baseline", "--no-configs1", "--no-configs3", "--no-one-shot"]
+        if args.workload:
+            cmd += ["--workload", args.workload]
+        if args.genome_len:
+            cmd += ["--genome-len", str(args.genome_len)]
+        env = {k: v for k, v in os.environ.items() if k != "HASLR_BENCH_FORCE_GROUP"}
+        t0 = time.perf_counter()
+        pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if pr.returncode != 0:
+            raise SystemExit("bench.py (plain N = 1 reference in a process of its own): " + pr.stderr[-800:])
+        ref = json.loads(pr.stdout.strip().split("\n")[-1])
+        solo_sha, t_solo = ref["assembly"]["sha256"], time.perf_counter() - t0
+        n1 = {"value": ref["value"], "ms_per_step": ref["ms_per_step"], "steps": ref["steps"],
+              "what": "the plain bench.py line (N = 1 step, single context) of a process of its own over the same files, run before the group was created"}
     g = C.c_void_p()
     tr = os.environ.get("HASLR_GROUP_TRANSPORT")
     if L.hx_group_create(n, None, tr.encode() if tr else None, C.byref(g)) != 0:
@@ -359,26 +396,13 @@ def run_group(args):
         poa_ms_rank.append(tm[3] / max(1, nl[3]))
     poa_ms = max(poa_ms_rank)   # (the slowest rank's POA launch group per step)
     n_edges = last[0].n_edges_total
-    # the same data through ONE rank (device 0, plain context): the sharded assembly must equal it, and its steady step is this line's N = 1 reference
     for r in last:
         r.close()
     L.hx_group_destroy(g)
-    ctx = hip.HipContext(0)
-    upload_and_reserve(ctx, ds)
-    solo = host.Run(ds, prm, ctx.backend(), None)
-    t0 = time.perf_counter()
-    solo.all()
-    t_solo = time.perf_counter() - t0
-    same = hashlib.sha256(solo.assembly_fasta().encode()).hexdigest() == sha
-    solo.close()
-    import torch
-
-    def sync():
-        torch.cuda.synchronize()
-    dt1, run1 = measure(ctx, ds, prm, ctx.backend(), args.steps, 0, 1, 0, sync, None, 0, sharded=False)   # (the solo pass above was the warm-up)
-    n1 = {"value": ds.total_read_bases * args.steps / dt1, "ms_per_step": dt1 / args.steps * 1e3, "steps": args.steps,
-          "what": "the plain single-context path (bench.py's N = 1 step) over the same data on device 0, timed here after the group's steps"}
-    run1.close(); ctx.close()
+    if not solo_first:
+        solo_sha, t_solo, n1 = solo_reference(0)   # (its first whole pass is the warm-up)
+        n1["what"] = "the plain single-context path (bench.py's N = 1 step) over the same data on device 0, timed here after the group's steps"
+    same = solo_sha == sha
     value = ds.total_read_bases * args.steps / total
     achieved = alg_bytes / (poa_ms / 1e3) / 1e9 if poa_ms > 0 else 0.0
     gcups = cells / (poa_ms / 1e3) / 1e9 if poa_ms > 0 else 0.0

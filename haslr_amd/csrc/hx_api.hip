@@ -145,6 +145,7 @@ struct HxOptions {
     int poa_prune = -1;            // exact score-bound pruning of the DP: -1 automatic (calls of thousands of edges), 0 never, else the threshold's percentage of the previous alignment's score per base
     int poa_pass_lanes = -1;       // column passes: unshared multi-wave edges run in workgroups of this many lanes, their DP columns in windows taken one after the other (-1 automatic: by
                                    // estimated chain length, where the rows are pruned; 0 never)
+    int poa_order_by_cells = 0;    // few-edge calls: the launch lists in the order of the edges' DP cells (until round 6) instead of the rows of their chains
     int poa_big_first = 1;         // few-edge calls: the unshared classes of 512 lanes and more leave before the shared edges' 256-lane members (0: behind them, as before round 5)
     int poa_chain_ms = -1;         // ... the automatic choice: the narrowest workgroup whose estimated chain (size_edges: DP rows x what a row costs at that width and number of
                                    // windows) stays below this many milliseconds; -1: the cap that balances the longest chain against the call's wave-slot time
@@ -163,7 +164,7 @@ const OptDesc kOptions[] = {
     {"poa_balance_pct", &HxOptions::poa_balance_pct, nullptr}, {"poa_balance_lanes", &HxOptions::poa_balance_lanes, nullptr}, {"poa_slots_pct", &HxOptions::poa_slots_pct, nullptr},
     {"poa_slots", &HxOptions::poa_slots, nullptr}, {"poa_batches", &HxOptions::poa_batches, nullptr}, {"poa_force_cm", &HxOptions::poa_force_cm, nullptr},
     {"poa_no_xcd_map", &HxOptions::poa_no_xcd_map, nullptr}, {"poa_streams", &HxOptions::poa_streams, nullptr}, {"poa_wide_delay_us", &HxOptions::poa_wide_delay_us, nullptr},
-    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"poa_chain_ms", &HxOptions::poa_chain_ms, nullptr}, {"poa_big_first", &HxOptions::poa_big_first, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
+    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"poa_chain_ms", &HxOptions::poa_chain_ms, nullptr}, {"poa_big_first", &HxOptions::poa_big_first, nullptr}, {"poa_order_by_cells", &HxOptions::poa_order_by_cells, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
 };
 }  // namespace
 
@@ -811,6 +812,10 @@ struct PoaCall {
     // (final nodes) x (longest sequence) x (sequences). vcap < 2^21, lmax < 2^20, nseq < 2^24: no overflow
     uint64_t edge_cost(uint32_t e) const { return (uint64_t)P.edges[e].vcap * P.edges[e].lmax * std::max<uint32_t>(1, P.nseq[e]); }
 
+    // DP rows of an edge's serial chain ~ the nodes of its graph before each sequence, summed (the model of the column passes: measured / model 1.10 .. 1.23). A call of
+    // hundreds of edges ends when its last CHAIN ends, and a chain's duration goes with its rows, not with its cells: the order of the launch lists in such a call.
+    double chain_rows(uint32_t e) const { const double S = std::max<uint32_t>(1, P.nseq[e]); return (double)P.edges[e].lmax * (S - 1.0) * (1.0 + 0.0275 * S) + (double)P.edges[e].lmax; }
+
     // ---- plan, part 3: per-edge capacities, members, far / wide row estimates; orders `todo` costliest first
     int size_edges(std::vector<uint32_t>& todo) {
         const uint64_t est_pct = (uint64_t)std::max(1, o.poa_node_est_pct);   // (testing: scales the node estimate)
@@ -841,7 +846,7 @@ struct PoaCall {
         if (cols2_top > 0 && cl_lanes == 256) {
             std::vector<uint32_t> cand;
             for (uint32_t e : todo) if (P.edges[e].lmax + 1 > cl_min && !c->poa_block && !c->poa_no_dir && !force_nodir[e] && !many_sinks[e] && !no_share[e]) cand.push_back(e);
-            std::sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) { const uint64_t ca = edge_cost(a), cb = edge_cost(b); return ca != cb ? ca > cb : a < b; });
+            std::sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) { const double ca = chain_rows(a), cb = chain_rows(b); return ca != cb ? ca > cb : a < b; });   // (the longest chains)
             for (size_t q = 0; q < cand.size() && q < (size_t)cols2_top; q++) ecols[cand[q]] = 2;
         }
         for (uint32_t e : todo) {
@@ -967,6 +972,10 @@ struct PoaCall {
         }
         // largest first (block scheduling is in grid order): cost ~ rows x columns x sequences; with column passes: the longest estimated chain first
         if (pass_on) std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) { return chain_ms[a] != chain_ms[b] ? chain_ms[a] > chain_ms[b] : a < b; });
+        // (round 6, few-edge calls: by the rows of the chain, not by the cells. Per-edge timeline of the 12 Mb call, HX_DEBUG=2: with the longest chain at 150 ms the call
+        // ended at 156 ms - with an edge of 2 088 columns x 21 reads that BEGAN at 109 ms and one of 2 470 x 25, 71 ms of chain, that began at 66 ms: in cell order
+        // they stood behind wide gaps aligned by a few reads, whose chains are short)
+        else if (!many_edges && !o.poa_order_by_cells) std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) { const double ca = chain_rows(a), cb = chain_rows(b); return ca != cb ? ca > cb : a < b; });
         else std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) { const uint64_t ca = edge_cost(a), cb = edge_cost(b); return ca != cb ? ca > cb : a < b; });
         return 0;
     }
@@ -1211,7 +1220,13 @@ struct PoaCall {
                 HIPCHK(hipStreamSynchronize(s));   // (nothing of an earlier batch is in flight: collect_batch has read its results)
                 hipError_t e = c->poa_arena.ensure(std::min<size_t>(at + at / 8, std::max<size_t>(at, (size_t)budget + (size_t)ne * 8400)));
                 if (e != hipSuccess) { (void)hipGetLastError(); e = c->poa_arena.ensure(at); }
-                if (e != hipSuccess) { (void)hipGetLastError(); return fail("hx_poa_batch: cannot allocate " + std::to_string(at >> 20) + " MB of POA workspace: " + hipGetErrorString(e)); }
+                if (e != hipSuccess) {
+                    // the budget was taken from what hipMemGetInfo called free - which somebody else (another context on this device: ranks that share a GPU, another
+                    // process) has taken since. The caller looks again and plans anew with what is there now.
+                    (void)hipGetLastError();
+                    g_err = "hx_poa_batch: cannot allocate " + std::to_string(at >> 20) + " MB of POA workspace: " + hipGetErrorString(e);
+                    return 1;
+                }
             }
             HX_POOLS(bind)
 #undef HX_POOLS
@@ -1448,7 +1463,20 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
         for (size_t bi = 0; bi < batches.size(); bi++) {
             if (batches[bi].empty()) continue;
             PoaCall::Launched lb;
-            if (K.launch_batch(batches[bi], batch_shrink[bi], lb) || K.collect_batch(lb, retry, retry_same)) return -1;
+            const int rc = K.launch_batch(batches[bi], batch_shrink[bi], lb);
+            if (rc == 1) {   // the arena could not be had at the planned size: the budget again from what is free NOW, the rest of the round planned anew
+                size_t free_b = 0, total_b = 0;
+                HIPCHK(hipMemGetInfo(&free_b, &total_b));
+                uint64_t now_b;
+                { std::lock_guard<std::mutex> lk(c->poa_arena_mu); now_b = (uint64_t)((double)(free_b + c->poa_arena.cap) * 0.9); }
+                if (now_b + (now_b >> 6) >= K.budget) return -1;   // (nothing changed: the error stands)
+                if (c->opt.debug) fprintf(stderr, "[hx] POA workspace: %.1f GB could not be allocated; %.1f GB are free now, budget %.1f -> %.1f GB\n", lb.bytes / 1e9, free_b / 1e9, K.budget / 1e9, now_b / 1e9);
+                K.budget = now_b;
+                if (c->opt.poa_workspace_gb <= 0) c->poa_budget = now_b;
+                for (size_t bj = bi; bj < batches.size(); bj++) retry_same.insert(retry_same.end(), batches[bj].begin(), batches[bj].end());
+                break;
+            }
+            if (rc || K.collect_batch(lb, retry, retry_same)) return -1;
         }
         todo.swap(retry);
         todo.insert(todo.end(), retry_same.begin(), retry_same.end());
