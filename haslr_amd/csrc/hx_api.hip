@@ -149,6 +149,10 @@ struct HxOptions {
     int poa_big_first = 1;         // few-edge calls: the unshared classes of 512 lanes and more leave before the shared edges' 256-lane members (0: behind them, as before round 5)
     int poa_chain_ms = -1;         // ... the automatic choice: the narrowest workgroup whose estimated chain (size_edges: DP rows x what a row costs at that width and number of
                                    // windows) stays below this many milliseconds; -1: the cap that balances the longest chain against the call's wave-slot time
+    int poa_prune_shared = 0;      // ... of the edges shared by several workgroups (round 6: their members take DP ATTEMPTS, not sequences, so a missed threshold is repeated by all of
+                                   // them): 0 never (the default), else the percentage. Measured at 12 Mb / 4.6 Mb with 95: 65 % of the wave-rows skipped, same consensus - and the longest
+                                   // chain 154 -> 207 ms / 106 -> 142 ms: in a pipeline of waves every row is live in SOME wave, which sets the pace of that row for all of them;
+                                   // what a skipped wave-row frees is issue slots, and a lone chain is not short of those
     int poa_prune_lazy = 1;        // ... a wave that skipped a whole batch of rows polls for the next one rarely (0: like any wave)
     int poa_prune_lanes = 128;     // ... in launches of workgroups of at least this many lanes (a one-wave workgroup has no block to skip)
     int coords_lds_supp = -1;      // supports per edge the coordinate kernel sorts in LDS (testing: 0 sends every edge through the global scratch)
@@ -164,7 +168,7 @@ const OptDesc kOptions[] = {
     {"poa_balance_pct", &HxOptions::poa_balance_pct, nullptr}, {"poa_balance_lanes", &HxOptions::poa_balance_lanes, nullptr}, {"poa_slots_pct", &HxOptions::poa_slots_pct, nullptr},
     {"poa_slots", &HxOptions::poa_slots, nullptr}, {"poa_batches", &HxOptions::poa_batches, nullptr}, {"poa_force_cm", &HxOptions::poa_force_cm, nullptr},
     {"poa_no_xcd_map", &HxOptions::poa_no_xcd_map, nullptr}, {"poa_streams", &HxOptions::poa_streams, nullptr}, {"poa_wide_delay_us", &HxOptions::poa_wide_delay_us, nullptr},
-    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"poa_chain_ms", &HxOptions::poa_chain_ms, nullptr}, {"poa_big_first", &HxOptions::poa_big_first, nullptr}, {"poa_order_by_cells", &HxOptions::poa_order_by_cells, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
+    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_prune_shared", &HxOptions::poa_prune_shared, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"poa_chain_ms", &HxOptions::poa_chain_ms, nullptr}, {"poa_big_first", &HxOptions::poa_big_first, nullptr}, {"poa_order_by_cells", &HxOptions::poa_order_by_cells, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
 };
 }  // namespace
 
@@ -693,7 +697,7 @@ struct PoaCall {
     std::vector<uint32_t> mlanes;      // shared edges: lanes per member (the option's, or 1024 where the gap needs them to fit at all)
     // knobs of this round (the option, or what the number of edges in the call asks for)
     bool many_edges = false, balanced = false;
-    uint32_t cl_lanes = 256, cl_min = 2048, cl_max = 16, cl_pref = 16, cl_topk = 192, wide_k = 0, cl_cols = 4, cols_per_lane = 4, wave_max = 512, prune_pct = 0, pass_lanes = 0;
+    uint32_t cl_lanes = 256, cl_min = 2048, cl_max = 16, cl_pref = 16, cl_topk = 192, wide_k = 0, cl_cols = 4, cols_per_lane = 4, wave_max = 512, prune_pct = 0, prune_shared_pct = 0, pass_lanes = 0;
     bool pass_on = false;
     std::vector<uint16_t> plane;       // unshared edges with column passes: lanes of their workgroup
     std::vector<float> chain_ms;       // estimated duration of the edge's chain (size_edges): the order of the launch lists
@@ -766,7 +770,8 @@ struct PoaCall {
         prune_pct = o.poa_prune < 0 ? (many_edges ? 95u : 0u) : (uint32_t)o.poa_prune;
         // The bound U = H + match x (columns left) and the lane test behind it are exact for scores of the usual signs only: gap <= 0, mismatch <= match,
         // gap <= match (hx_poa_sequences and spoa_hx.hpp take any int8 triple). Anything else runs the full-matrix instances.
-        if (!(pp->gap <= 0 && pp->mismatch <= pp->match && pp->gap <= pp->match && pp->match >= 0)) prune_pct = 0;
+        prune_shared_pct = (uint32_t)std::max(0, o.poa_prune_shared);
+        if (!(pp->gap <= 0 && pp->mismatch <= pp->match && pp->gap <= pp->match && pp->match >= 0)) prune_pct = prune_shared_pct = 0;
         score_abs_max = std::max<uint64_t>({1, (uint64_t)std::abs((int)pp->match), (uint64_t)std::abs((int)pp->mismatch), (uint64_t)std::abs((int)pp->gap)});
         // Column passes (kernels/poa.hip): with the rows pruned, an edge's wave slots are mostly held by waves that skip - so the unshared multi-wave edges run
         // in workgroups of `pass_lanes` lanes and take their columns window by window. The call is bound by wave-slot time (thousands of edges, every slot
@@ -1170,7 +1175,10 @@ struct PoaCall {
 
     // the pruned instance: unshared edges, direction bytes, 4 or 8 columns per lane, a workgroup of several waves - or of any width when its edges take their
     // columns in passes (a one-wave workgroup that holds its gap has nothing to skip: its rows are whole rows)
-    bool launch_pruned(const Cls& q) const { return !q.shared && hxk::poa_prune_ok(q.dir, (int)q.cm) && (q.nt >= (uint32_t)o.poa_prune_lanes || q.pk) && prune_pct != 0; }
+    bool launch_pruned(const Cls& q) const {
+        if (q.shared) return hxk::poa_prune_ok(q.dir, (int)q.cm) && prune_shared_pct != 0;
+        return hxk::poa_prune_ok(q.dir, (int)q.cm) && (q.nt >= (uint32_t)o.poa_prune_lanes || q.pk) && prune_pct != 0;
+    }
     // ---- launch of one batch; what the collection needs afterwards
     struct Launched { std::vector<uint32_t> edges; uint64_t cns_bytes = 0, bytes = 0; std::vector<Cls> classes; };
     int launch_batch(const std::vector<uint32_t>& batch, uint32_t shrink, Launched& lb) {
@@ -1331,7 +1339,7 @@ struct PoaCall {
             L.match = pp->match; L.mismatch = pp->mismatch; L.gap = pp->gap; L.cns = B.cns.p; L.cns_len = c->poa_len.p; L.status = c->poa_status.p;
             L.cells = c->poa_cells_d.p; L.phase = c->poa_phase_d.p; L.block_threads = (int)q.nt; L.cm = (int)q.cm; L.poll_limit = (uint32_t)o.poa_poll_limit; L.ring_bytes = (uint32_t)lds_bytes;
             L.use_dir = q.dir; L.max_indeg = (uint32_t)std::min(16, std::max(1, o.poa_max_indeg)); L.dp_lanes = q.dpl;
-            L.prune_pct = launch_pruned(q) ? (std::min<uint32_t>(prune_pct, 1000u) | (o.poa_prune_lazy ? 1u << 16 : 0u)) : 0u;
+            L.prune_pct = launch_pruned(q) ? (std::min<uint32_t>(q.shared ? prune_shared_pct : prune_pct, 1000u) | (o.poa_prune_lazy ? 1u << 16 : 0u)) : 0u;
             if (o.debug) { int occ = 0; L.occupancy = &occ; hxk::poa_run(L, c->poa_streams[sk]); L.occupancy = nullptr; fprintf(stderr, "[hx] launch %zu: %zu workgroups of %u lanes, %.1f KB of ring: %d workgroups per CU\n", gi, g_blocks, q.nt, lds_bytes / 1024.0, occ); }
             hxk::poa_run(L, c->poa_streams[sk]);
             HIPCHK(hipEventRecord(c->poa_ev[sk], c->poa_streams[sk]));

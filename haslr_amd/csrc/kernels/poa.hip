@@ -1874,7 +1874,11 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
         __syncthreads();
     };
 
-    for (uint32_t k = ED.seq_begin; k < ED.seq_end; k++) {
+    // Cluster protocol (round 6: DP ATTEMPTS, not sequences). Member 0 publishes every DP it wants - a new sequence, or the same one again under another threshold
+    // (PRUNE) - as {V, L, threshold} and a rising attempt number in csy[0]; the other members run one DP per attempt, whatever it is, add themselves to csy[1], and wait
+    // for the next number or for the release (CL_ABORT, written by member 0 when it leaves the loop for whatever reason). They do not count sequences.
+    uint32_t att = 0;   // DP attempts of this edge so far (uniform; member 0 publishes att, the others wait for att + 1)
+    for (uint32_t k = ED.seq_begin; mem > 0 || k < ED.seq_end; k += (mem == 0 ? 1u : 0u)) {
         uint32_t L, V;
         if (mem == 0 && sOk != 1) break;
         if (mem == 0) {
@@ -1894,18 +1898,13 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
             PHASE(0);
             V = sV;
             SUBT0();
-            if (GM > 1) {   // publish this sequence to the other members: graph rows (CSR), decoded sequence, V, L
-                __threadfence();
-                __syncthreads();
-                if (tid == 0) { st_dev(csy + 2, V); st_dev(csy + 3, L); __threadfence(); st_dev(csy + 0, k - ED.seq_begin + 1); }
-            }
         } else {
             // ---- other member of a cluster: only the DP, over its own columns; everything else happens in member 0
             if (tid == 0) {
                 uint32_t v = 0;
                 for (uint32_t spin = 0;; spin++) {
                     v = ld_dev(csy + 0);
-                    if (v == CL_ABORT || v >= k - ED.seq_begin + 1) break;
+                    if (v == CL_ABORT || v >= att + 1) break;
                     if (spin > poll_limit) { st_dev(csy + 4, 1u); v = CL_ABORT; break; }
                     __builtin_amdgcn_s_sleep(32);
                 }
@@ -1923,7 +1922,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
         // best sink of a pruned matrix is a real path's score, and an attempt that stays below its threshold is repeated with exactly that score.
         int thrT = PRUNE_OFF;
         if constexpr (PRUNE) {
-            if (GM == 1 && prune_pct != 0u && sPrevLen != 0u && V < (1u << 20)) {   // (2^20 rows: "nothing" keys lose at most a vertical move per row and must not wrap)
+            if (mem == 0 && (prune_pct & 0xffffu) != 0u && sPrevLen != 0u && V < (1u << 20)) {   // (2^20 rows: "nothing" keys lose at most a vertical move per row and must not wrap)
                 const float f = (float)(prune_pct & 0xffffu) * 0.01f;
                 float e = (float)sPrevScore * (float)L / (float)sPrevLen;
                 e = e >= 0.f ? e * f : e * (2.f - f);
@@ -1931,6 +1930,14 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
             }
         }
     redo_dp:
+        att++;
+        if (GM > 1) {
+            if (mem == 0) {   // publish this attempt to the other members: graph rows (CSR), decoded sequence, V, L, the threshold
+                __threadfence();
+                __syncthreads();
+                if (tid == 0) { st_dev(csy + 2, V); st_dev(csy + 3, L); st_dev(csy + 5, (uint32_t)thrT); __threadfence(); st_dev(csy + 0, att); }
+            } else if constexpr (PRUNE) thrT = (int)ld_dev(csy + 5);
+        }
         if (V > 0) {
             uint32_t ns = 0xffffffffu;
 #ifdef HX_DP_PROF3
@@ -1971,7 +1978,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                 if (GM > 1) {   // wait for the other members' columns (direction bytes, sinks)
                     __syncthreads();
                     if (tid == 0) {
-                        const uint32_t need = (GM - 1) * (k - ED.seq_begin + 1);
+                        const uint32_t need = (GM - 1) * att;
                         for (uint32_t spin = 0;; spin++) {
                             if (ld_dev(csy + 1) >= need) break;
                             if (spin > poll_limit) { st_dev(csy + 4, 1u); break; }
@@ -2270,7 +2277,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
             if (GM > 1) {   // nothing to align against yet: the other members only count the sequence (and must have read V = 0 before it changes)
                 __syncthreads();
                 if (tid == 0) {
-                    const uint32_t need = (GM - 1) * (k - ED.seq_begin + 1);
+                    const uint32_t need = (GM - 1) * att;
                     for (uint32_t spin = 0;; spin++) {
                         if (ld_dev(csy + 1) >= need) break;
                         if (spin > poll_limit) { st_dev(csy + 4, 1u); break; }
@@ -2298,7 +2305,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
         PHASE(5);
     }
     if (mem > 0) return;
-    if (GM > 1 && tid == 0 && sOk != 1) st_dev(csy + 0, CL_ABORT);   // release the other members
+    if (GM > 1 && tid == 0) st_dev(csy + 0, CL_ABORT);   // release the other members (they wait for the next attempt: done or not, there is none)
     long long t_cns = 0;
     if (tid == 0) t_cns = clock64();
     if (sOk == 1 && sV) {
@@ -2434,6 +2441,7 @@ __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const P
 #define HX_POA_RUN_PART(MNT, LAST_CM) \
     void poa_run_##MNT(const PoaLaunch& q, hipStream_t s, bool prune) { \
         const int cm = q.cm; \
+        if constexpr (MNT == 256 || MNT == 1024) { if (prune && cm <= 2 && !q.counter) { HX_LAUNCH(MNT, 2, true, false, true); return; } } \
         if (prune) { if (cm <= 4) HX_LAUNCH_PR(MNT, 4); else HX_LAUNCH_PR(MNT, 8); return; } \
         if constexpr (MNT == 256 || MNT == 1024) { if (cm <= 2 && q.use_dir && !q.counter) { HX_LAUNCH(MNT, 2, true, false, false); return; } }   /* (2 columns per lane: the members of shared edges, poa_kernel_min_cm) */ \
         if (cm <= 4) HX_LAUNCH_CM(MNT, 4); else if (cm <= 8) HX_LAUNCH_CM(MNT, 8); else if (cm <= 16 || LAST_CM == 16) HX_LAUNCH_CM(MNT, 16); else HX_LAUNCH_CM(MNT, LAST_CM); \

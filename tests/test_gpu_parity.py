@@ -337,7 +337,10 @@ def test_score_matrix_traceback_matches_direction_bytes(sim, ctx):
 @pytest.mark.parametrize("cfg", [("300", "64", "8", "8", "0"), ("300", "64", "4", "3", "100"), ("500", "128", "4", "4", "2"), ("400", "256", "8", "8", "100"),
                                  ("300", "64", "4", "3", "0"), ("400", "256", "8", "8", "0"),
                                  # two columns per lane (round 6: the members of the few-edge regime's shared edges): 256-lane members, wide members, members without a column
-                                 ("300", "256", "2", "8", "0"), ("200", "256", "2", "3", "100"), ("400", "256", "2", "16", "2")])
+                                 ("300", "256", "2", "8", "0"), ("200", "256", "2", "3", "100"), ("400", "256", "2", "16", "2"),
+                                 # exact pruning inside shared edges (off by default; the members run DP attempts, a missed threshold is repeated by all of them): an honest
+                                 # threshold, an optimistic one (most alignments repeated), wide members, 2 / 4 / 8 columns per lane
+                                 ("300", "64", "8", "8", "0", "95"), ("300", "128", "4", "4", "2", "108"), ("300", "256", "2", "8", "100", "95"), ("400", "256", "8", "8", "0", "104")])
 def test_shared_edges_cluster_mode(sim, ctx, cfg):
     """cluster mode: the DP columns of an edge spread over several workgroups (forced here on short gaps with small members, so that
     every variant — single-wave members, multi-wave members, members without columns for a short read, sink rows in another member —
@@ -351,7 +354,7 @@ def test_shared_edges_cluster_mode(sim, ctx, cfg):
     ro = host.Run(ds, prm, be.table, None)
     ro.all()
     ctx.upload(ds)
-    keys = ("poa_cluster_min", "poa_member_lanes", "poa_cluster_cols", "poa_cluster_max", "poa_wide_members")
+    keys = ("poa_cluster_min", "poa_member_lanes", "poa_cluster_cols", "poa_cluster_max", "poa_wide_members", "poa_prune_shared")
     with ctx.options(**dict(zip(keys, cfg))):
         rg = host.Run(ds, prm, ctx.backend(), None)
         rg.all()
