@@ -139,12 +139,14 @@ struct HxOptions {
     int poa_member_lanes = 256, poa_cluster_min = 2048, poa_cluster_max = -1, poa_cluster_topk = -1, poa_wide_members = -1, poa_cluster_cols = -1;
     int poa_cols2_top = -1;        // the costliest shared edges of a call whose members take 2 columns per lane (twice the members, a shorter row): how many (-1: 4 in a few-edge call, else none)
     int poa_node_est_pct = 100, poa_far_rows = -1;
+    int poa_far_shift = 3;         // rings of 4 kept rows (the many-edge regime): rows of H (rows read back from HBM) per edge = nodes >> this, + 256; an edge that needs more is redone with 4 x the room
     int poa_wave_max = 512, poa_cols = -1, poa_ring_kb = -1, poa_ring_zero = 0;
     int poa_balance = 1, poa_balance_pct = 125, poa_balance_lanes = 512;
     int poa_slots_pct = 100, poa_slots = 0, poa_batches = 0, poa_force_cm = 0, poa_no_xcd_map = 0, poa_streams = 8, poa_wide_delay_us = 60;
     int poa_prune = -1;            // exact score-bound pruning of the DP: -1 automatic (calls of thousands of edges), 0 never, else the threshold's percentage of the previous alignment's score per base
     int poa_pass_lanes = -1;       // column passes: unshared multi-wave edges run in workgroups of this many lanes, their DP columns in windows taken one after the other (-1 automatic: by
                                    // estimated chain length, where the rows are pruned; 0 never)
+    int poa_slots_by_work = 1;     // many-edge calls: the slots of an instance's need buckets in proportion to the buckets' estimated work (0: from the largest need down, as until round 6)
     int poa_order_by_cells = 0;    // few-edge calls: the launch lists in the order of the edges' DP cells (until round 6) instead of the rows of their chains
     int poa_big_first = 1;         // few-edge calls: the unshared classes of 512 lanes and more leave before the shared edges' 256-lane members (0: behind them, as before round 5)
     int poa_chain_ms = -1;         // ... the automatic choice: the narrowest workgroup whose estimated chain (size_edges: DP rows x what a row costs at that width and number of
@@ -163,12 +165,12 @@ const OptDesc kOptions[] = {
     {"poa_poll_limit", &HxOptions::poa_poll_limit, nullptr}, {"poa_max_indeg", &HxOptions::poa_max_indeg, nullptr}, {"poa_member_lanes", &HxOptions::poa_member_lanes, nullptr},
     {"poa_cluster_min", &HxOptions::poa_cluster_min, nullptr}, {"poa_cluster_max", &HxOptions::poa_cluster_max, nullptr}, {"poa_cluster_topk", &HxOptions::poa_cluster_topk, nullptr},
     {"poa_wide_members", &HxOptions::poa_wide_members, nullptr}, {"poa_cluster_cols", &HxOptions::poa_cluster_cols, nullptr}, {"poa_cols2_top", &HxOptions::poa_cols2_top, nullptr}, {"poa_node_est_pct", &HxOptions::poa_node_est_pct, nullptr},
-    {"poa_far_rows", &HxOptions::poa_far_rows, nullptr}, {"poa_wave_max", &HxOptions::poa_wave_max, nullptr}, {"poa_cols", &HxOptions::poa_cols, nullptr},
+    {"poa_far_rows", &HxOptions::poa_far_rows, nullptr}, {"poa_far_shift", &HxOptions::poa_far_shift, nullptr}, {"poa_wave_max", &HxOptions::poa_wave_max, nullptr}, {"poa_cols", &HxOptions::poa_cols, nullptr},
     {"poa_ring_kb", &HxOptions::poa_ring_kb, nullptr}, {"poa_ring_zero", &HxOptions::poa_ring_zero, nullptr}, {"poa_balance", &HxOptions::poa_balance, nullptr},
     {"poa_balance_pct", &HxOptions::poa_balance_pct, nullptr}, {"poa_balance_lanes", &HxOptions::poa_balance_lanes, nullptr}, {"poa_slots_pct", &HxOptions::poa_slots_pct, nullptr},
     {"poa_slots", &HxOptions::poa_slots, nullptr}, {"poa_batches", &HxOptions::poa_batches, nullptr}, {"poa_force_cm", &HxOptions::poa_force_cm, nullptr},
     {"poa_no_xcd_map", &HxOptions::poa_no_xcd_map, nullptr}, {"poa_streams", &HxOptions::poa_streams, nullptr}, {"poa_wide_delay_us", &HxOptions::poa_wide_delay_us, nullptr},
-    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_prune_shared", &HxOptions::poa_prune_shared, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"poa_chain_ms", &HxOptions::poa_chain_ms, nullptr}, {"poa_big_first", &HxOptions::poa_big_first, nullptr}, {"poa_order_by_cells", &HxOptions::poa_order_by_cells, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
+    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_prune_shared", &HxOptions::poa_prune_shared, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"poa_chain_ms", &HxOptions::poa_chain_ms, nullptr}, {"poa_big_first", &HxOptions::poa_big_first, nullptr}, {"poa_order_by_cells", &HxOptions::poa_order_by_cells, nullptr}, {"poa_slots_by_work", &HxOptions::poa_slots_by_work, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
 };
 }  // namespace
 
@@ -700,10 +702,12 @@ struct PoaCall {
     uint32_t cl_lanes = 256, cl_min = 2048, cl_max = 16, cl_pref = 16, cl_topk = 192, wide_k = 0, cl_cols = 4, cols_per_lane = 4, wave_max = 512, prune_pct = 0, prune_shared_pct = 0, pass_lanes = 0;
     bool pass_on = false;
     std::vector<uint16_t> plane;       // unshared edges with column passes: lanes of their workgroup
+    std::vector<uint8_t> batch_by_work; // per batch of the current plan: the slot policy plan_batches settled on
     std::vector<float> chain_ms;       // estimated duration of the edge's chain (size_edges): the order of the launch lists
     uint64_t ring_kb_wave = 0;
     double balance_f = 1.25;
     uint32_t balance_nt = 512;
+    mutable bool by_work = false;      // slots of the need buckets in proportion to their work (arrange): chosen per batch by plan_batches - where the memory budget binds
     uint64_t score_abs_max = 8;        // largest |match|, |mismatch|, |gap| of the call: |score| <= that x (nodes + columns) must fit the keys
 
     PoaCall(hx_ctx* c_, const PoaInput& in_, const hx_poa_params* pp_) : c(c_), in(in_), pp(pp_), o(c_->opt), ne(in_.n_edge) {}
@@ -936,7 +940,7 @@ struct PoaCall {
                 for (double cq = 100; cq <= 3200; cq *= 1.0905) {   // (an eighth of an octave apart)
                     double slot = fixed_slot_ms;
                     for (const Opt& q : opts) { const int k = pick(q, cq); slot += q.ms[k] * (kLanes[k] / 64); }
-                    if (cq >= 0.65 * slot / 3800.0) { cap = cq; break; }
+                    if (cq >= 0.60 * slot / 3800.0) { cap = cq; break; }   // (round 6, same data, caps of 260 / 290 / 315 / 336 = 0.65 / 340 / 370 ms: 0.597 / 0.480 / 0.476 / 0.496-0.509 / 0.493 / 0.508 s)
                 }
             }
             size_t hist[5] = {};
@@ -968,7 +972,7 @@ struct PoaCall {
             const uint32_t Rp = ring_rows_of(nt, cmq, rb);
             // measured on PacBio-like data, rows read back from HBM per DP row: 0.15-0.4 % with 8 ring rows, 3-5 % with 4, 16-25 % on average
             // with 2 (single edges: up to every kept row, ~60 % of the rows). Graphs fill ~70 % of the node estimate these are fractions of.
-            uint32_t est = o.poa_far_rows >= 0 ? (uint32_t)o.poa_far_rows : Rp >= 8 ? E.vcap / 32 + 256 : Rp >= 4 ? E.vcap / 8 + 256 : Rp >= 2 ? E.vcap / 2 + 256 : E.vcap + 1;
+            uint32_t est = o.poa_far_rows >= 0 ? (uint32_t)o.poa_far_rows : Rp >= 8 ? E.vcap / 32 + 256 : Rp >= 4 ? (E.vcap >> std::min(8, std::max(0, o.poa_far_shift))) + 256 : Rp >= 2 ? E.vcap / 2 + 256 : E.vcap + 1;
             E.hrows = full_h[e] || far_full[e] >= 3 ? E.vcap + 1 : (uint32_t)std::min<uint64_t>((uint64_t)E.vcap + 1, far_full[e] ? (uint64_t)std::max<uint32_t>(est, 256) << (2 * far_full[e]) : est);   // (a fourth attempt gets a row per node)
             // rows with more than 4 predecessors (a move byte per cell instead of a nibble): 1-2 % of the rows the DPs of 25- to 45-fold edges run
             // over, up to ~10 % of a finished deep graph; a 16th of the node estimate (graphs fill about a third of it) is the room, four times
@@ -1119,19 +1123,36 @@ struct PoaCall {
             q.persistent = !q.shared && (q.n_slots < q.edges.size() || pass_on) && hxk::poa_persistent_ok(q.dir);   // (pass_on: the need buckets of an instance share a launch)
             if (!q.persistent) q.n_slots = q.edges.size();
         }
-        // the need buckets of one kernel instance share a launch and the chip: workgroups for 5/4 of what the chip holds of that width in all, dealt from the
-        // largest need down (a workgroup serves its bucket and every smaller one, not the other way round); a bucket keeps a few workgroups of its own
+        // The need buckets of one kernel instance share a launch and the chip: workgroups for 5/4 of what the chip holds of that width in all (a workgroup serves its
+        // bucket and every smaller one, not the other way round; a bucket keeps a few workgroups of its own). Round 6: dealt IN PROPORTION TO THE BUCKETS' WORK (the
+        // estimated chain time of their edges), not from the largest need down. Dealt top-down, the buckets of large need took a slot per edge and the memory with
+        // them: a 400 Mb genome (37 936 edges, HX_DEBUG=1) ran with 1 208 slots of 137 MB for one bucket's 1 771 edges, EIGHT slots each for the 33 000 edges of
+        // 37 MB and less, and 1 558 one-wave workgroups resident in all where the chip holds 4 096 - 258 GB of workspace and a chip at 40 %. With every bucket
+        // finishing at about the same time, the same memory buys several times the workgroups (option poa_slots_by_work=0: as before).
         if (pass_on)
             for (size_t i = 0; i < classes.size();) {
                 size_t j = i + 1;
                 while (j < classes.size() && same_instance(classes[i], classes[j])) j++;
                 if (classes[i].persistent && j - i > 1 && !o.poa_slots) {
                     size_t left = std::max<size_t>(1, ((size_t)4096 / (classes[i].nt / 64)) * 5 / 4 * shrink / 1000);
-                    for (size_t k = i; k < j; k++) {
-                        Cls& q = classes[k];
-                        q.n_slots = std::min(q.n_slots, std::max<size_t>(left, std::min<size_t>(q.edges.size(), 8)));
-                        left -= std::min(left, q.n_slots);
-                    }
+                    if (by_work) {
+                        std::vector<double> w(j - i, 0.0);
+                        double w_left = 0;
+                        for (size_t k = i; k < j; k++) { for (uint32_t e : classes[k].edges) w[k - i] += std::max(1e-3, (double)chain_ms[e]); w_left += w[k - i]; }
+                        for (size_t k = i; k < j; k++) {
+                            Cls& q = classes[k];
+                            const size_t floor_k = std::min<size_t>(q.edges.size(), 8);
+                            const size_t share = w_left > 0 ? (size_t)((double)left * w[k - i] / w_left + 0.999) : 0;
+                            q.n_slots = std::min(q.edges.size(), std::max(floor_k, std::min(share, left)));
+                            left -= std::min(left, q.n_slots);
+                            w_left -= w[k - i];
+                        }
+                    } else
+                        for (size_t k = i; k < j; k++) {
+                            Cls& q = classes[k];
+                            q.n_slots = std::min(q.n_slots, std::max<size_t>(left, std::min<size_t>(q.edges.size(), 8)));
+                            left -= std::min(left, q.n_slots);
+                        }
                 }
                 i = j;
             }
@@ -1152,13 +1173,19 @@ struct PoaCall {
         const size_t forced = o.poa_batches > 0 ? (size_t)o.poa_batches : 0;   // (testing)
         for (size_t nb = std::max<size_t>(1, forced);; nb++) {
             nb = std::min(nb, std::max<size_t>(1, todo.size()));
-            batches.assign(nb, {}); batch_shrink.assign(nb, 1000);
+            batches.assign(nb, {}); batch_shrink.assign(nb, 1000); batch_by_work.assign(nb, 0);
             for (size_t i = 0; i < todo.size(); i++) batches[i % nb].push_back(todo[i]);   // dealt in cost order: every batch has its share of the large edges
             bool fits = true;
             for (size_t bi = 0; bi < nb && fits; bi++) {
                 std::vector<Cls> cl;
                 if (build_classes(batches[bi], cl)) return -1;
                 uint32_t sh = 1000;   // per mille of the full slot counts: the largest that fits (down to 1 %: below that, more batches)
+                // (the slots of the need buckets: from the largest need down while everything fits - at 140 Mb, 215 GB of a 257 GB budget, that is 3 % faster: the
+                // long chains of the large buckets all start at once, 0.499 against 0.515 s - and in proportion to the buckets' work as soon as the budget binds:
+                // 0.595 against 0.731 s under 140 GB, and one rank's 400 Mb share of configs[4] 2.00 against 2.95 s in its 260 GB)
+                by_work = false;
+                if (o.poa_slots_by_work && total_bytes(cl, sh) > budget) by_work = true;
+                batch_by_work[bi] = by_work;
                 if (total_bytes(cl, sh) > budget) {
                     uint32_t lo = 10, hi = 1000;
                     while (hi - lo > 10) { const uint32_t mid = (lo + hi) / 2; if (total_bytes(cl, mid) <= budget) lo = mid; else hi = mid; }
@@ -1471,6 +1498,7 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
         for (size_t bi = 0; bi < batches.size(); bi++) {
             if (batches[bi].empty()) continue;
             PoaCall::Launched lb;
+            K.by_work = bi < K.batch_by_work.size() && K.batch_by_work[bi] != 0;
             const int rc = K.launch_batch(batches[bi], batch_shrink[bi], lb);
             if (rc == 1) {   // the arena could not be had at the planned size: the budget again from what is free NOW, the rest of the round planned anew
                 size_t free_b = 0, total_b = 0;

@@ -31,6 +31,7 @@ PRESETS = {"yeast": dict(genome_len=12_000_000, model="nanopore", cov=25), "fly"
            # the 3.1 Gb run needs ~190 GB of text and as much again parsed, and the box is lost to the OOM killer three minutes into the simulation). 800 Mb in 8
            # chromosomes: 50 GB of text on /tmp, 4.6e9 CIGAR words (word offsets above 2^32), ~75 000 edges in one consensus call
            "chm1_quarter": dict(genome_len=800_000_000, model="pacbio", cov=25, chromosomes=8, seed=0x4841534C + 4, sample=16),
+           "chm1_eighth": dict(genome_len=400_000_000, model="pacbio", cov=25, chromosomes=4, seed=0x4841534C + 4, sample=8),   # (one rank's share of the 8-GPU configuration)
            "chm1_rehearsal": dict(genome_len=60_000_000, model="pacbio", cov=25, chromosomes=4, seed=0x4841534C + 4, sample=4)}   # (the chm1 code path at a size that takes a minute)
 
 
@@ -63,6 +64,7 @@ def main():
     ap.add_argument("--seed", type=int, default=11)
     ap.add_argument("--name")
     ap.add_argument("--no-oracle", action="store_true", help="skip the CPU oracle run (parity fields are null)")
+    ap.add_argument("--no-sample", action="store_true", help="skip the CPU oracle's sample leg of the chm1 presets")
     ap.add_argument("--no-identity", action="store_true", help="skip the placement of the assembly on the truth genome")
     ap.add_argument("--passes", type=int, default=2)
     ap.add_argument("--cli", action="store_true", help="also run the haslr_assemble binary on the same files (wall time, same assembly)")
@@ -73,7 +75,7 @@ def main():
     name = a.name or a.preset or "custom"
     if "seed" in cfg:
         a.seed = cfg["seed"]
-    big = cfg["genome_len"] >= 500_000_000 or name == "chm1_rehearsal"
+    big = cfg["genome_len"] >= 300_000_000 or name == "chm1_rehearsal"
     if big:
         a.no_oracle = True                                        # (the whole data set through the oracle would take most of an hour: a sample below)
         a.passes = max(a.passes, 3)                               # one cold + two steady
@@ -173,7 +175,7 @@ def main():
         ro.close(); be.close()
     else:
         res["parity"] = None
-    if cfg.get("sample"):   # the CPU oracle on a stated sample: chain + graph over everything, coordinates + consensus over the LPT share 1 / sample of the edges, 64 threads
+    if cfg.get("sample") and not a.no_sample:   # the CPU oracle on a stated sample: chain + graph over everything, coordinates + consensus over the LPT share 1 / sample of the edges, 64 threads
         import orclib
         k = int(cfg["sample"])
         threads = min(64, os.cpu_count() or 1)
