@@ -2,6 +2,7 @@
 // the four hot-path operators (kernel orchestration + result download), multi-GPU record exchange, timing.
 // There is no CPU fallback here: without a usable HIP device every entry point fails with an error.
 #include <chrono>
+#include <cmath>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -146,6 +147,7 @@ struct HxOptions {
     int poa_prune = -1;            // exact score-bound pruning of the DP: -1 automatic (calls of thousands of edges), 0 never, else the threshold's percentage of the previous alignment's score per base
     int poa_pass_lanes = -1;       // column passes: unshared multi-wave edges run in workgroups of this many lanes, their DP columns in windows taken one after the other (-1 automatic: by
                                    // estimated chain length, where the rows are pruned; 0 never)
+    int poa_bucket_half_octaves = 1;   // need buckets of the persistent launches half an octave apart (0: an octave, as until round 6)
     int poa_slots_by_work = 1;     // many-edge calls: the slots of an instance's need buckets in proportion to the buckets' estimated work (0: from the largest need down, as until round 6)
     int poa_order_by_cells = 0;    // few-edge calls: the launch lists in the order of the edges' DP cells (until round 6) instead of the rows of their chains
     int poa_big_first = 1;         // few-edge calls: the unshared classes of 512 lanes and more leave before the shared edges' 256-lane members (0: behind them, as before round 5)
@@ -170,7 +172,7 @@ const OptDesc kOptions[] = {
     {"poa_balance_pct", &HxOptions::poa_balance_pct, nullptr}, {"poa_balance_lanes", &HxOptions::poa_balance_lanes, nullptr}, {"poa_slots_pct", &HxOptions::poa_slots_pct, nullptr},
     {"poa_slots", &HxOptions::poa_slots, nullptr}, {"poa_batches", &HxOptions::poa_batches, nullptr}, {"poa_force_cm", &HxOptions::poa_force_cm, nullptr},
     {"poa_no_xcd_map", &HxOptions::poa_no_xcd_map, nullptr}, {"poa_streams", &HxOptions::poa_streams, nullptr}, {"poa_wide_delay_us", &HxOptions::poa_wide_delay_us, nullptr},
-    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_prune_shared", &HxOptions::poa_prune_shared, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"poa_chain_ms", &HxOptions::poa_chain_ms, nullptr}, {"poa_big_first", &HxOptions::poa_big_first, nullptr}, {"poa_order_by_cells", &HxOptions::poa_order_by_cells, nullptr}, {"poa_slots_by_work", &HxOptions::poa_slots_by_work, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
+    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_prune_shared", &HxOptions::poa_prune_shared, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"poa_chain_ms", &HxOptions::poa_chain_ms, nullptr}, {"poa_big_first", &HxOptions::poa_big_first, nullptr}, {"poa_order_by_cells", &HxOptions::poa_order_by_cells, nullptr}, {"poa_slots_by_work", &HxOptions::poa_slots_by_work, nullptr}, {"poa_bucket_half_octaves", &HxOptions::poa_bucket_half_octaves, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
 };
 }  // namespace
 
@@ -1047,7 +1049,13 @@ struct PoaCall {
             // (calls with column passes: a class per power of two of workspace need - a persistent workgroup's slot is sized for the largest edge of its
             // class, and a narrow workgroup may now hold a gap of any length; the classes of one kernel instance leave in one launch: launch_batch)
             uint32_t pb = 0;
-            if (pass_on && !full_h[e]) { const uint64_t mb = need_bytes(need_of(e)) >> 20; while ((1ull << pb) <= mb) pb++; }
+            // (round 6: buckets HALF an octave apart where the memory budget binds - a slot holds the largest edge of its bucket, and with buckets an octave apart a
+            // quarter of the slots' memory is slack on average)
+            if (pass_on && !full_h[e]) {
+                const uint64_t nb_ = need_bytes(need_of(e));
+                if (o.poa_bucket_half_octaves) { const double l = std::log2((double)(nb_ >> 10) + 1.0) - 10.0; pb = l <= 0 ? 0u : (uint32_t)std::ceil(l * 2.0); }
+                else { const uint64_t mb = nb_ >> 20; while ((1ull << pb) <= mb) pb++; }
+            }
             cls_of(false, nt, cmq, !full_h[e], 0, pb, pass_on && !full_h[e] && cmq > 4).edges.push_back(e);   // (pk: with column passes every 8-column launch is the pruned instance - one launch per width)
         }
         // order of the launches: shared edges first (they set the duration), then by lanes; score-matrix launches after their direction-byte twins
