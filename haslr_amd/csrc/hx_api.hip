@@ -858,7 +858,7 @@ struct PoaCall {
             std::vector<uint32_t> cand;
             for (uint32_t e : todo) if (P.edges[e].lmax + 1 > cl_min && !c->poa_block && !c->poa_no_dir && !force_nodir[e] && !many_sinks[e] && !no_share[e]) cand.push_back(e);
             std::sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) { const double ca = chain_rows(a), cb = chain_rows(b); return ca != cb ? ca > cb : a < b; });   // (the longest chains)
-            for (size_t q = 0; q < cand.size() && q < (size_t)cols2_top; q++) ecols[cand[q]] = 2;
+            for (size_t q = 0; q < cand.size() && q < (size_t)cols2_top; q++) ecols[cand[q]] = (uint8_t)(cl_cols >= 8 ? cl_cols / 2 : 2);   // (a many-edge call, whose members aim at 8 columns, when the option asks for it there: 4)
         }
         for (uint32_t e : todo) {
             hxk::PoaEdge& E = P.edges[e];
@@ -869,9 +869,9 @@ struct PoaCall {
             const uint32_t ncol = E.lmax + 1;
             const bool may_share = !c->poa_block && !c->poa_no_dir && !force_nodir[e] && !many_sinks[e] && !no_share[e];
             if (may_share && ncol > cl_min) {
-                const uint64_t ecl = ecols[e];
+                const uint64_t ecl = ecols[e], pref = ecl < cl_cols ? cl_max : cl_pref;   // (the longest chains, fewer columns per lane: as many members as that takes)
                 auto members_for = [&](uint32_t lanes) -> uint64_t {
-                    return std::min<uint64_t>(cl_max, std::max<uint64_t>(std::min<uint64_t>(cl_pref, (ncol + (uint64_t)lanes * ecl - 1) / ((uint64_t)lanes * ecl)), (ncol + (uint64_t)lanes * 32 - 1) / ((uint64_t)lanes * 32)));
+                    return std::min<uint64_t>(cl_max, std::max<uint64_t>(std::min<uint64_t>(pref, (ncol + (uint64_t)lanes * ecl - 1) / ((uint64_t)lanes * ecl)), (ncol + (uint64_t)lanes * 32 - 1) / ((uint64_t)lanes * 32)));
                 };
                 uint64_t mb = members_for(cl_lanes);
                 if (((uint64_t)ncol + mb * cl_lanes - 1) / (mb * cl_lanes) > 32 && cl_lanes < 1024) { mlanes[e] = 1024; mb = members_for(1024); }   // (the gap does not fit the configured members)

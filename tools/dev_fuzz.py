@@ -18,7 +18,7 @@ only = set(int(x) for x in os.environ['FUZZ_ONLY'].split(',')) if os.environ.get
 ctx = hip.HipContext(0)
 os.makedirs('/tmp/fz', exist_ok=True)
 bad = 0
-KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS', 'HX_POA_BATCHES', 'HX_POA_NODE_EST_PCT', 'HX_POA_RING_KB', 'HX_POA_COLS', 'HX_POA_CLUSTER_TOPK', 'HX_POA_SLOTS', 'HX_POA_WORKSPACE_GB', 'HX_POA_FORCE_CM', 'HX_POA_RING_ZERO', 'HX_POA_WIDE_MEMBERS', 'HX_POA_PRUNE', 'HX_POA_PRUNE_LANES', 'HX_POA_PASS_LANES', 'HX_POA_PRUNE_LAZY', 'HX_POA_CHAIN_MS')
+KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS', 'HX_POA_BATCHES', 'HX_POA_NODE_EST_PCT', 'HX_POA_RING_KB', 'HX_POA_COLS', 'HX_POA_CLUSTER_TOPK', 'HX_POA_SLOTS', 'HX_POA_WORKSPACE_GB', 'HX_POA_FORCE_CM', 'HX_POA_RING_ZERO', 'HX_POA_WIDE_MEMBERS', 'HX_POA_PRUNE', 'HX_POA_PRUNE_LANES', 'HX_POA_PASS_LANES', 'HX_POA_PRUNE_LAZY', 'HX_POA_CHAIN_MS', 'HX_POA_COLS2_TOP', 'HX_POA_PRUNE_SHARED', 'HX_POA_SLOTS_BY_WORK', 'HX_POA_BUCKET_HALF_OCTAVES', 'HX_POA_ORDER_BY_CELLS', 'HX_POA_FAR_SHIFT')
 for it in range(n):
     big = os.environ.get('FUZZ_BIG') is not None   # long gaps at real sizes: the default launch shapes (512-lane cluster members) get real work
     glen = rng.choice([400000, 700000, 1000000]) if big else rng.choice([40000, 60000, 90000, 150000, 250000])
@@ -36,7 +36,7 @@ for it in range(n):
     ctx.set_poa_block(0)
     if shape == 'small-members':
         env = {'HX_POA_CLUSTER_MIN': str(rng.choice([200, 400, 800])), 'HX_POA_MEMBER_LANES': str(rng.choice([64, 128, 256])),
-               'HX_POA_CLUSTER_COLS': str(rng.choice([4, 8])), 'HX_POA_CLUSTER_MAX': str(rng.choice([2, 3, 8]))}
+               'HX_POA_CLUSTER_COLS': str(rng.choice([2, 4, 8])), 'HX_POA_CLUSTER_MAX': str(rng.choice([2, 3, 8, 16]))}
     elif shape == 'one-wave':
         env = {'HX_POA_WAVE_MAX': str(rng.choice([128, 256, 2048])), 'HX_POA_MAX_INDEG': str(rng.choice([2, 3, 16]))}
     elif shape == 'block':
@@ -70,6 +70,18 @@ for it in range(n):
         env['HX_POA_PRUNE_LAZY'] = str(rng.choice([0, 1, 1]))
         if 'HX_POA_WAVE_MAX' not in env and rng.random() < 0.7:
             env['HX_POA_WAVE_MAX'] = str(rng.choice([64, 128, 256]))          # several waves per workgroup on the short gaps of a small data set
+    # round 6: 2 columns per lane for the longest chains, exact pruning inside shared edges (members run DP attempts), the slot policies of the need buckets, the launch order
+    if rng.random() < 0.4:
+        env['HX_POA_COLS2_TOP'] = str(rng.choice([0, 1, 4, 1000]))
+    if rng.random() < 0.35:
+        env['HX_POA_PRUNE_SHARED'] = str(rng.choice([90, 95, 104, 112]))
+    if rng.random() < 0.3:
+        env['HX_POA_SLOTS_BY_WORK'] = str(rng.choice([0, 1]))
+        env['HX_POA_BUCKET_HALF_OCTAVES'] = str(rng.choice([0, 1]))
+    if rng.random() < 0.2:
+        env['HX_POA_ORDER_BY_CELLS'] = '1'
+    if rng.random() < 0.15:
+        env['HX_POA_FAR_SHIFT'] = str(rng.choice([2, 4, 6]))
     if rng.random() < 0.25:
         env['HX_POA_NODE_EST_PCT'] = str(rng.choice([2, 10, 30, 60]))
     pk = dict(min_aln_block=rng.choice([250, 500, 500, 1000]), min_aln_sim=rng.choice([0.8, 0.85, 0.85, 0.9]), min_edge_sup=rng.choice([2, 3, 3, 5]), max_uniq_dev=rng.choice([0.15, 0.15, 0.3]))
