@@ -315,11 +315,10 @@ def run_group(args):
         dt1, run1 = measure(ctx, ds, prm, ctx.backend(), args.steps, warm, 1, 0, sync, None, 0, sharded=False)
         run1.close(); ctx.close()
         return sha1, t_solo, {"value": ds.total_read_bases * args.steps / dt1, "ms_per_step": dt1 / args.steps * 1e3, "steps": args.steps}
-    # One rank (the group code at N = 1, HASLR_BENCH_FORCE_GROUP): the N = 1 reference is the plain bench.py line of A PROCESS OF ITS OWN over the same files. Within one
-    # process whichever context is created second runs the 12 Mb step slower (measured both ways round: plain 184.6 ms after the group's 162.1 ms; group 172-219 ms
-    # after the plain pass's 153 ms) - the launch classes' streams of a second context do not get hardware queues of their own - which says nothing about either path:
-    # the product creates one context (or one group) per process. Several ranks: in this process, afterwards, when the group has given its memory back (a reference for
-    # the assembly and a rough N = 1 figure).
+    # One rank (the group code at N = 1, HASLR_BENCH_FORCE_GROUP): the N = 1 reference is the plain bench.py line of A PROCESS OF ITS OWN over the same files, so that
+    # neither pass inherits anything of the other's (until the launch classes' streams became the process's - hx_ctx_create - whichever context was created second in a
+    # process ran the 12 Mb step 13 % slower: plain 184.6 ms after the group's 162.1 ms, group 172-219 ms after the plain pass's 153 ms). Several ranks: in this process,
+    # afterwards, when the group has given its memory back (a reference for the assembly and a rough N = 1 figure).
     solo_first = n == 1
     if solo_first:
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(max(1, args.warmup)), "--no-cpu-baseline", "--no-configs1", "--no-configs3", "--no-one-shot"]

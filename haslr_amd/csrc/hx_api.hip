@@ -287,13 +287,23 @@ extern "C" int hx_ctx_create(int device, void* stream, hx_ctx** out) {
     else { HIPCHK(hipStreamCreate(&c->stream)); c->own_stream = true; }
     HIPCHK(hipEventCreate(&c->tm.a));
     HIPCHK(hipEventCreate(&c->tm.b));
-    {   // distinct priorities map to distinct hardware queues, so the lane-count classes really run side by side
-        int lo = 0, hi = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least priority (largest number), hi = greatest
-        for (int i = 0; i < 8; i++) {
-            int pr = hi + i; if (pr > lo) pr = lo;
-            HIPCHK(hipStreamCreateWithPriority(&c->poa_streams[i], hipStreamNonBlocking, pr));
+    {   // distinct priorities map to distinct hardware queues, so the lane-count classes really run side by side.
+        // Round 6: the eight streams of the launch classes are the PROCESS's, one set per device, created by the first context on it and handed to every later
+        // one (never destroyed). A second context of a process used to run the 12 Mb step 13 % slower, whichever path it was - streams created when
+        // the first context's had already taken the hardware queues do not get queues of their own, and destroying the first context did not give them back.
+        static std::mutex pool_mu;
+        static std::vector<std::array<hipStream_t, 8>> pool;   // by device
+        std::lock_guard<std::mutex> lk(pool_mu);
+        if ((int)pool.size() <= device) pool.resize((size_t)device + 1, std::array<hipStream_t, 8>{});
+        if (!pool[(size_t)device][0]) {
+            int lo = 0, hi = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least priority (largest number), hi = greatest
+            for (int i = 0; i < 8; i++) {
+                int pr = hi + i; if (pr > lo) pr = lo;
+                HIPCHK(hipStreamCreateWithPriority(&pool[(size_t)device][(size_t)i], hipStreamNonBlocking, pr));
+            }
         }
+        for (int i = 0; i < 8; i++) c->poa_streams[i] = pool[(size_t)device][(size_t)i];
     }
     for (int i = 0; i < 9; i++) HIPCHK(hipEventCreateWithFlags(&c->poa_ev[i], hipEventDisableTiming));
     HIPCHK(c->err.reserve(1));
@@ -307,7 +317,6 @@ extern "C" void hx_ctx_destroy(hx_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->tm.a) (void)hipEventDestroy(c->tm.a);
     if (c->tm.b) (void)hipEventDestroy(c->tm.b);
-    for (int i = 0; i < 8; i++) if (c->poa_streams[i]) (void)hipStreamDestroy(c->poa_streams[i]);
     for (int i = 0; i < 9; i++) if (c->poa_ev[i]) (void)hipEventDestroy(c->poa_ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
