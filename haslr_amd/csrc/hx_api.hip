@@ -782,7 +782,9 @@ struct PoaCall {
         // Exact score-bound pruning (kernels/poa.hip PRUNE) skips the (row, wave) blocks that cannot reach the alignment's score: work saved in the
         // multi-wave launches of a call whose CUs are all busy; a chain-bound call (hundreds of edges, the longest one is the step) gains nothing
         // from it - a row stays a row - so there the full-matrix instances run. poa_prune: -1 automatic, 0 never, else the percentage.
-        prune_pct = o.poa_prune < 0 ? (many_edges ? 95u : 0u) : (uint32_t)o.poa_prune;
+        // (round 6: automatic also in a few-edge call, for its unshared multi-wave classes and without the column passes - the step is the shared edges' and neither gains nor
+        // loses, 164.98 against 165.54 ms at 12 Mb, but the dead wave-rows' nibble rows are not written)
+        prune_pct = o.poa_prune < 0 ? 95u : (uint32_t)o.poa_prune;
         // The bound U = H + match x (columns left) and the lane test behind it are exact for scores of the usual signs only: gap <= 0, mismatch <= match,
         // gap <= match (hx_poa_sequences and spoa_hx.hpp take any int8 triple). Anything else runs the full-matrix instances.
         prune_shared_pct = (uint32_t)std::max(0, o.poa_prune_shared);
@@ -791,7 +793,7 @@ struct PoaCall {
         // Column passes (kernels/poa.hip): with the rows pruned, an edge's wave slots are mostly held by waves that skip - so the unshared multi-wave edges run
         // in workgroups of `pass_lanes` lanes and take their columns window by window. The call is bound by wave-slot time (thousands of edges, every slot
         // taken): an edge of 8 000 columns holds 4 waves instead of 16 for little more than the same time.
-        pass_on = prune_pct != 0 && cols_per_lane <= 8 && o.poa_pass_lanes != 0;
+        pass_on = prune_pct != 0 && cols_per_lane <= 8 && o.poa_pass_lanes != 0 && (many_edges || o.poa_prune >= 0 || o.poa_pass_lanes > 0);   // (the automatic pruning of a few-edge call: without passes)
         pass_lanes = !pass_on || o.poa_pass_lanes < 0 ? 0u : (uint32_t)o.poa_pass_lanes;   // (0 with pass_on: by gap length, size_edges)
         if (pass_lanes != 0 && pass_lanes != 64 && pass_lanes != 128 && pass_lanes != 256 && pass_lanes != 512 && pass_lanes != 1024) return fail("option poa_pass_lanes must be 0, 64, 128, 256, 512 or 1024");
         if (cl_lanes != 64 && cl_lanes != 128 && cl_lanes != 256 && cl_lanes != 512 && cl_lanes != 1024) return fail("option poa_member_lanes must be 64, 128, 256, 512 or 1024");
