@@ -499,6 +499,17 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
     auto far_set = [&](const uint32_t slot, const uint32_t fl) {   // (slot, fl: wave-uniform)
         if (far_bits && lane == ((slot >> 5) & 63u)) farbits = (farbits & ~(1u << (slot & 31u))) | (fl << (slot & 31u));
     };
+#ifdef HX_RING_PREFETCH
+    // (development, round 6: the ring rows the NEXT row names as its first / second predecessor are requested while the current row is in its scan - an LDS round trip
+    // is ~100 cycles for a lone wave and a row makes 1.14 of them. pf_row = the row they were requested for.)
+    constexpr bool PF = !PRUNE && DIR;
+    int q0[CM], q0l = NEGK, q1[CM], q1l = NEGK;
+    uint32_t pf_row = 0xffffffffu, pf_s0 = 0xffu, pf_s1 = 0xffu;   // ... and the ring slots (location codes) they were read from
+#pragma unroll
+    for (int k = 0; k < CM; k++) { q0[k] = NEGK; q1[k] = NEGK; }
+#else
+    constexpr bool PF = false;
+#endif
     auto pred_row = [&](const uint32_t ent, int (&hp)[CM], int& left, const bool slot_known) {
         const uint32_t loc = ent >> 28;
         if (__builtin_expect(loc == 13u, 1)) {   // the previous row: registers (the likely case falls through: a taken scalar branch costs a lone wave ~35 cycles)
@@ -753,6 +764,13 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
 #endif
                     {
                         int hp[CM], left;
+#ifdef HX_RING_PREFETCH
+                        if (PF && pf_row == i && pf_s0 == (p0 >> 28)) {
+#pragma unroll
+                            for (int k = 0; k < CM; k++) hp[k] = q0[k];
+                            left = q0l;
+                        } else
+#endif
                         pred_row(p0, hp, left, true);
 #pragma unroll
                         for (int k = 0; k < CM; k++) m[k] = max((k == 0 ? left : hp[k - 1]) + score_of(k), hp[k] + gv);
@@ -787,7 +805,20 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                             m[k] = max(m[k], max(dg, hp[k] + gvp));
                         }
                     };
+#ifdef HX_RING_PREFETCH
+                    const uint32_t entB_ = __builtin_amdgcn_readlane(bC, ri);
+                    if (PF && pf_row == i && pf_s1 == (entB_ >> 28)) {
+                        const int gvp = gv - 1;
+#pragma unroll
+                        for (int k = 0; k < CM; k++) {
+                            int dg;
+                            asm("v_add3_u32 %0, %1, %2, %3" : "=v"(dg) : "v"(k == 0 ? q1l : q1[k - 1]), "v"(score_of(k)), "s"(-1));
+                            m[k] = max(m[k], max(dg, q1[k] + gvp));
+                        }
+                    } else if (!PRUNE || flB != 0u) more(entB_, DIR ? 1 : 0, true);
+#else
                     if (!PRUNE || flB != 0u) more(__builtin_amdgcn_readlane(bC, ri), DIR ? 1 : 0, true);
+#endif
                     if (npred > 2) {
                         if (!PRUNE || flC != 0u) more(__builtin_amdgcn_readlane(cC, ri), DIR ? 2 : 0, false);
                         if (npred > 3) {
@@ -817,6 +848,24 @@ __device__ __forceinline__ void dp_rows(const G& g, int32_t* __restrict__ H, uin
                 const int cin = __builtin_amdgcn_readlane(cinV, rj);   // NEGK without a wave on the left
                 meta_nx = __builtin_amdgcn_readlane(mC, (ri + 1) & 63u);   // (the next row's record; beyond the batch: unused)
                 if constexpr (!FAST) p0_nx = __builtin_amdgcn_readlane(aC, (ri + 1) & 63u);   // (inside a run of fast rows the first predecessor is known; read again behind the run)
+#ifdef HX_RING_PREFETCH
+                if constexpr (PF) {   // the next row's ring predecessors (within the batch): requested now, used when the row comes
+                    pf_row = 0xffffffffu;
+                    if (rj + 1 < nb) {
+                        const uint32_t l0 = p0_nx >> 28, npn = meta_nx >> META_NP;
+                        const uint32_t entN = __builtin_amdgcn_readlane(bC, (ri + 1) & 63u), l1 = npn > 1u ? entN >> 28 : 0xffu;
+                        const bool r0 = l0 - 1u < 12u, r1 = l1 - 1u < 12u;
+                        if (r0 | r1) {
+                            const int32_t* S0 = ring_me + (size_t)(r0 ? l0 - 1u : 0u) * ring_w;
+                            const int32_t* S1 = ring_me + (size_t)(r1 ? l1 - 1u : 0u) * ring_w;
+#pragma unroll
+                            for (int k = 0; k < CM; k++) { q0[k] = S0[k * PW + 1]; q1[k] = S1[k * PW + 1]; }
+                            q0l = S0[(CM - 1) * PW]; q1l = S1[(CM - 1) * PW];
+                            pf_row = i + 1; pf_s0 = r0 ? l0 : 0xffu; pf_s1 = r1 ? l1 : 0xffu;
+                        }
+                    }
+                }
+#endif
                 // the carry of this row for the wave on the right: the prefix maximum through this wave's last column (lane 63 holds it)
                 if (out_l != 0u) { if (lane == 63) *(volatile __attribute__((address_space(3))) unsigned long long*)(uintptr_t)mb_addr = (unsigned long long)mb_tag | ((unsigned long long)(uint32_t)max(cin, inc) << 32); }
                 if (out_h != 0u) { if (lane == 63) st_dev64(mb_out_h + i, (unsigned long long)mb_tag | ((unsigned long long)(uint32_t)max(cin, inc) << 32)); }
