@@ -148,6 +148,8 @@ struct HxOptions {
     int poa_pass_lanes = -1;       // column passes: unshared multi-wave edges run in workgroups of this many lanes, their DP columns in windows taken one after the other (-1 automatic: by
                                    // estimated chain length, where the rows are pruned; 0 never)
     int poa_bucket_half_octaves = 1;   // need buckets of the persistent launches half an octave apart (0: an octave, as until round 6)
+    int poa_own_bucket_first = 1;  // a persistent workgroup takes the edges of its OWN need bucket before those of the smaller buckets it can also serve (0: whichever next edge has the longest chain, as until round 6 - see k_poa)
+    int poa_resident_first = 0;    // bit 0: the shared edges' launch of a many-edge call, bit 1: the wide persistent launches (512 lanes and more) - the next launch leaves when their workgroups have all begun (each adds itself to a word in host memory), not after a fixed delay. Measured at 140 Mb: the 37 workgroups of the 512-lane launch have all begun 40 us after it (the fixed delay is 60), and the one pass in five that took 550-620 ms was not about arrival at all (poa_own_bucket_first); 0 stays the default, the best pass is 0.459 against 0.480 s
     int poa_slots_by_work = 1;     // many-edge calls: the slots of an instance's need buckets in proportion to the buckets' estimated work (0: from the largest need down, as until round 6)
     int poa_order_by_cells = 0;    // few-edge calls: the launch lists in the order of the edges' DP cells (until round 6) instead of the rows of their chains
     int poa_big_first = 1;         // few-edge calls: the unshared classes of 512 lanes and more leave before the shared edges' 256-lane members (0: behind them, as before round 5)
@@ -172,7 +174,7 @@ const OptDesc kOptions[] = {
     {"poa_balance_pct", &HxOptions::poa_balance_pct, nullptr}, {"poa_balance_lanes", &HxOptions::poa_balance_lanes, nullptr}, {"poa_slots_pct", &HxOptions::poa_slots_pct, nullptr},
     {"poa_slots", &HxOptions::poa_slots, nullptr}, {"poa_batches", &HxOptions::poa_batches, nullptr}, {"poa_force_cm", &HxOptions::poa_force_cm, nullptr},
     {"poa_no_xcd_map", &HxOptions::poa_no_xcd_map, nullptr}, {"poa_streams", &HxOptions::poa_streams, nullptr}, {"poa_wide_delay_us", &HxOptions::poa_wide_delay_us, nullptr},
-    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_prune_shared", &HxOptions::poa_prune_shared, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"poa_chain_ms", &HxOptions::poa_chain_ms, nullptr}, {"poa_big_first", &HxOptions::poa_big_first, nullptr}, {"poa_order_by_cells", &HxOptions::poa_order_by_cells, nullptr}, {"poa_slots_by_work", &HxOptions::poa_slots_by_work, nullptr}, {"poa_bucket_half_octaves", &HxOptions::poa_bucket_half_octaves, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
+    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_prune_shared", &HxOptions::poa_prune_shared, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"poa_chain_ms", &HxOptions::poa_chain_ms, nullptr}, {"poa_big_first", &HxOptions::poa_big_first, nullptr}, {"poa_order_by_cells", &HxOptions::poa_order_by_cells, nullptr}, {"poa_slots_by_work", &HxOptions::poa_slots_by_work, nullptr}, {"poa_resident_first", &HxOptions::poa_resident_first, nullptr}, {"poa_own_bucket_first", &HxOptions::poa_own_bucket_first, nullptr}, {"poa_bucket_half_octaves", &HxOptions::poa_bucket_half_octaves, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
 };
 }  // namespace
 
@@ -221,6 +223,7 @@ struct hx_ctx {
     bool poa_no_dir = false;   // diagnostics: force the score-matrix traceback
     int poa_block = 0;   // 0 = automatic (lanes per edge chosen from the gap length)
     hipStream_t poa_streams[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t* poa_started = nullptr;    // 16 words of mapped host memory: workgroups that have begun, per launch of a batch (kernels/poa.hip k_poa)
     hipEvent_t poa_ev[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     Timer tm;
     // scratch of the chain / edge / coordinate operators lives as long as the context too (grows, never shrinks): no allocation, free or
@@ -306,6 +309,7 @@ extern "C" int hx_ctx_create(int device, void* stream, hx_ctx** out) {
         for (int i = 0; i < 8; i++) c->poa_streams[i] = pool[(size_t)device][(size_t)i];
     }
     for (int i = 0; i < 9; i++) HIPCHK(hipEventCreateWithFlags(&c->poa_ev[i], hipEventDisableTiming));
+    HIPCHK(hipHostMalloc((void**)&c->poa_started, 16 * sizeof(uint32_t), hipHostMallocMapped));
     HIPCHK(c->err.reserve(1));
     *out = c;
     return 0;
@@ -319,6 +323,7 @@ extern "C" void hx_ctx_destroy(hx_ctx* c) {
     if (c->tm.b) (void)hipEventDestroy(c->tm.b);
     for (int i = 0; i < 9; i++) if (c->poa_ev[i]) (void)hipEventDestroy(c->poa_ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    if (c->poa_started) (void)hipHostFree(c->poa_started);
     delete c;
 }
 
@@ -1061,10 +1066,11 @@ struct PoaCall {
             // class, and a narrow workgroup may now hold a gap of any length; the classes of one kernel instance leave in one launch: launch_batch)
             uint32_t pb = 0;
             // (round 6: buckets HALF an octave apart where the memory budget binds - a slot holds the largest edge of its bucket, and with buckets an octave apart a
-            // quarter of the slots' memory is slack on average)
+            // quarter of the slots' memory is slack on average. Where everything fits the octave stays: 140 Mb, alternating, five passes each: best 0.473 / 0.473 s in
+            // 216 GB against 0.488 / 0.501 / 0.512 s in 183 GB)
             if (pass_on && !full_h[e]) {
                 const uint64_t nb_ = need_bytes(need_of(e));
-                if (o.poa_bucket_half_octaves) { const double l = std::log2((double)(nb_ >> 10) + 1.0) - 10.0; pb = l <= 0 ? 0u : (uint32_t)std::ceil(l * 2.0); }
+                if (o.poa_bucket_half_octaves && by_work) { const double l = std::log2((double)(nb_ >> 10) + 1.0) - 10.0; pb = l <= 0 ? 0u : (uint32_t)std::ceil(l * 2.0); }
                 else { const uint64_t mb = nb_ >> 20; while ((1ull << pb) <= mb) pb++; }
             }
             cls_of(false, nt, cmq, !full_h[e], 0, pb, pass_on && !full_h[e] && cmq > 4).edges.push_back(e);   // (pk: with column passes every 8-column launch is the pruned instance - one launch per width)
@@ -1197,13 +1203,13 @@ struct PoaCall {
             bool fits = true;
             for (size_t bi = 0; bi < nb && fits; bi++) {
                 std::vector<Cls> cl;
+                by_work = false;
                 if (build_classes(batches[bi], cl)) return -1;
                 uint32_t sh = 1000;   // per mille of the full slot counts: the largest that fits (down to 1 %: below that, more batches)
                 // (the slots of the need buckets: from the largest need down while everything fits - at 140 Mb, 215 GB of a 257 GB budget, that is 3 % faster: the
                 // long chains of the large buckets all start at once, 0.499 against 0.515 s - and in proportion to the buckets' work as soon as the budget binds:
                 // 0.595 against 0.731 s under 140 GB, and one rank's 400 Mb share of configs[4] 2.00 against 2.95 s in its 260 GB)
-                by_work = false;
-                if (o.poa_slots_by_work && total_bytes(cl, sh) > budget) by_work = true;
+                if (o.poa_slots_by_work && total_bytes(cl, sh) > budget) { by_work = true; if (build_classes(batches[bi], cl)) return -1; }   // (... and the buckets half an octave apart)
                 batch_by_work[bi] = by_work;
                 if (total_bytes(cl, sh) > budget) {
                     uint32_t lo = 10, hi = 1000;
@@ -1338,7 +1344,7 @@ struct PoaCall {
             while (j < classes.size() && same_instance(a, classes[j])) j++;
             groups.push_back({i, j, h_btab.size()});
             if (a.persistent) {
-                h_btab.push_back((uint32_t)(j - i));
+                h_btab.push_back((uint32_t)(j - i) | (o.poa_own_bucket_first ? 1u << 16 : 0u));
                 uint32_t se = 0, ib = 0;
                 for (size_t k = i; k < j; k++) { se += (uint32_t)classes[k].blocks; h_btab.push_back(se); }
                 for (size_t k = i; k < j; k++) { h_btab.push_back(ib); ib += (uint32_t)classes[k].edges.size(); }
@@ -1385,17 +1391,28 @@ struct PoaCall {
             L.match = pp->match; L.mismatch = pp->mismatch; L.gap = pp->gap; L.cns = B.cns.p; L.cns_len = c->poa_len.p; L.status = c->poa_status.p;
             L.cells = c->poa_cells_d.p; L.phase = c->poa_phase_d.p; L.block_threads = (int)q.nt; L.cm = (int)q.cm; L.poll_limit = (uint32_t)o.poa_poll_limit; L.ring_bytes = (uint32_t)lds_bytes;
             L.use_dir = q.dir; L.max_indeg = (uint32_t)std::min(16, std::max(1, o.poa_max_indeg)); L.dp_lanes = q.dpl;
+            const bool wide_q = q.dpl || (balanced && q.nt >= balance_nt && q.nt >= 512 && q.persistent), shared_first = many_edges && q.shared && (o.poa_resident_first & 1);
+            L.started = ((wide_q && (o.poa_resident_first & 2)) || shared_first) && gi < 16 ? c->poa_started + gi : nullptr;
+            if (L.started) *(volatile uint32_t*)L.started = 0u;
             L.prune_pct = launch_pruned(q) ? (std::min<uint32_t>(q.shared ? prune_shared_pct : prune_pct, 1000u) | (o.poa_prune_lazy ? 1u << 16 : 0u)) : 0u;
             if (o.debug) { int occ = 0; L.occupancy = &occ; hxk::poa_run(L, c->poa_streams[sk]); L.occupancy = nullptr; fprintf(stderr, "[hx] launch %zu: %zu workgroups of %u lanes, %.1f KB of ring: %d workgroups per CU\n", gi, g_blocks, q.nt, lds_bytes / 1024.0, occ); }
             hxk::poa_run(L, c->poa_streams[sk]);
             HIPCHK(hipEventRecord(c->poa_ev[sk], c->poa_streams[sk]));
             HIPCHK(hipStreamWaitEvent(s, c->poa_ev[sk], 0));
-            if (q.dpl || (balanced && q.nt >= balance_nt && q.nt >= 512 && q.persistent)) {
+            if (wide_q || shared_first) {
                 // a 1024-lane workgroup needs an EMPTY CU: give the dispatcher a head start before the other launches fill the chip with small
                 // workgroups (once they have, a CU only empties when its longest resident workgroup ends)
                 HIPCHK(hipEventSynchronize(c->poa_ev[8]));   // (what precedes the launches on `s` is done: the wide launch is starting)
                 const auto tw = std::chrono::steady_clock::now();
-                while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw).count() < o.poa_wide_delay_us) { }
+                if (L.started) {
+                    // (round 6: not a fixed delay but the launch's own word - every workgroup adds itself when it begins. One pass in five of the 140 Mb call took 610-650 ms
+                    // instead of 440-470: no edge redone, the same launches - in another order of arrival on the CUs. The shared edges' members and the wide classes
+                    // must be the oldest waves where they sit; the next launch leaves when they have all begun, or after 2 ms)
+                    volatile uint32_t* w = L.started;
+                    while (*w < L.n_blocks && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw).count() < 2000.0) { }
+                    if (o.debug) fprintf(stderr, "[hx] launch %zu: %u of %u workgroups had begun %.0f us after the launch\n", gi, (unsigned)*w, L.n_blocks, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw).count());
+                } else
+                    while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw).count() < o.poa_wide_delay_us) { }
             }
             gi++;
         }

@@ -166,6 +166,7 @@ struct PoaLaunch {
     bool use_dir /* direction-byte traceback (in-degrees <= max_indeg <= 16, else the edge comes back with HXE_POA_NODIR) */;
     uint32_t max_indeg, dp_lanes /* 0: every lane of the workgroup; else the lanes that take part in the DP (a wide cluster member) */;
     int* occupancy /* not null: no launch - the workgroups of this launch's shape a CU holds (hipOccupancyMaxActiveBlocksPerMultiprocessor), for the debug output */;
+    uint32_t* started /* null, or a word of HOST memory (mapped): every workgroup of the launch adds 1 when it begins */;
     uint32_t prune_pct /* 0: full matrix; else the pruned instance (poa_prune_ok, unshared edges) with thresholds at this percentage of the previous alignment's score per base */;
 };
 void poa_run(const PoaLaunch& q, hipStream_t s);

@@ -670,11 +670,14 @@ __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const P
                                             const uint32_t* __restrict__ btab /* persistent: buckets, slot ends, item begins (PoaLaunch) */, const PoaSeq* __restrict__ seqs, const uint8_t* __restrict__ packed, const uint64_t* __restrict__ read_off,
                                             const uint32_t* __restrict__ read_len, PoaPools P, int32_t match, int32_t mismatch, int32_t gap,
                                             char* cns, uint32_t* cns_len, uint32_t* status, unsigned long long* cells, unsigned long long* phase,
-                                            uint32_t poll_limit, uint32_t lds_bytes, uint32_t max_indeg, uint32_t dp_lanes, uint32_t prune_pct) {
+                                            uint32_t poll_limit, uint32_t lds_bytes, uint32_t max_indeg, uint32_t dp_lanes, uint32_t prune_pct,
+                                            uint32_t* __restrict__ started /* null, or a word in host memory: every workgroup adds itself when it begins (the host waits for the launches that must be resident first) */) {
     __shared__ uint32_t sNext;
+    if (started && threadIdx.x == 0) __hip_atomic_fetch_add(started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // persistent launch: the bucket whose slot this workgroup owns (slots are laid out bucket by bucket, largest workspace need first)
     uint32_t kb = 0, nbk = 0;
-    if (PERSIST) { nbk = btab[0]; while (kb + 1 < nbk && blockIdx.x >= btab[1 + kb]) kb++; }
+    bool own_first = false;
+    if (PERSIST) { nbk = btab[0] & 0xffffu; own_first = (btab[0] >> 16) & 1u; while (kb + 1 < nbk && blockIdx.x >= btab[1 + kb]) kb++; }
     for (uint32_t round = 0;; round++) {   // (one call site of the edge body for both kinds of launch)
         uint32_t eidx, mem = 0;
         PoaSlot SL;
@@ -689,7 +692,11 @@ __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const P
             if (round) __syncthreads();                   // (the previous edge has left the LDS)
             if (threadIdx.x == 0) {
                 // ... of the buckets it can serve, the one whose next edge has the longest estimated chain (est[]: beside the lists): the call ends when its
-                // longest chains end, and a long chain of little need must not wait behind its bucket's thousands
+                // longest chains end, and a long chain of little need must not wait behind its bucket's thousands.
+                // Round 6 (`own_first`, bit 16 of btab[0]): its OWN bucket first while that has edges left - they are the edges the fewest workgroups can take
+                // (least flexible job first). By the longest chain alone, a workgroup of a large bucket took a longer edge of a smaller bucket, the smaller bucket's
+                // workgroup then found its list empty and LEFT, and the large bucket's own edge waited for one of the few slots that hold it: one pass in five of the
+                // 140 Mb call ran 37 edges of the 512-lane class on 31 of its 37 workgroups, the last one third in line - 615 ms instead of 450.
                 const uint32_t* ib = btab + 1 + nbk;
                 const uint32_t* est = ib + nbk + 1;
                 uint32_t idx = 0xffffffffu;
@@ -700,6 +707,7 @@ __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const P
                         if (cur >= b1 - b0) continue;
                         const uint32_t v = est[b0 + cur];
                         if (best == 0xffffffffu || v > bv) { best = k; bv = v; }
+                        if (own_first && k == kb) break;
                     }
                     if (best == 0xffffffffu) break;       // every bucket this workgroup can serve is empty
                     const uint32_t t = ib[best] + atomicAdd(counter + best, 1u);
@@ -738,7 +746,7 @@ __global__ void __launch_bounds__(MAXNT, (CM == 8 && DIR ? 4 : 1)) k_poa(const P
         (void)hipFuncSetAttribute((const void*)k_poa<MNT, CMV, DIRV, PERS, PRN>, hipFuncAttributeMaxDynamicSharedMemorySize, 142 * 1024); \
         if (q.occupancy) { (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(q.occupancy, (const void*)k_poa<MNT, CMV, DIRV, PERS, PRN>, q.block_threads, q.ring_bytes); break; } \
         k_poa<MNT, CMV, DIRV, PERS, PRN><<<q.n_blocks, q.block_threads, q.ring_bytes, s>>>(q.edges, q.order, q.n_items, q.slots, q.counter, q.btab, q.seqs, q.packed, q.read_off, q.read_len, q.pools, q.match, q.mismatch, q.gap, \
-                                                                       q.cns, q.cns_len, q.status, q.cells, q.phase, q.poll_limit, q.ring_bytes, q.max_indeg, q.dp_lanes, q.prune_pct); } while (0)
+                                                                       q.cns, q.cns_len, q.status, q.cells, q.phase, q.poll_limit, q.ring_bytes, q.max_indeg, q.dp_lanes, q.prune_pct, q.started); } while (0)
 // (persistent instances exist for the direction-byte flavour only: poa_persistent_ok; pruned ones for it with 4 or 8 columns per lane: poa_prune_ok)
 #define HX_LAUNCH_CM(MNT, CMV) do { if (q.use_dir && q.counter) HX_LAUNCH(MNT, CMV, true, true, false); else if (q.use_dir) HX_LAUNCH(MNT, CMV, true, false, false); else HX_LAUNCH(MNT, CMV, false, false, false); } while (0)
 #define HX_LAUNCH_PR(MNT, CMV) do { if (q.counter) HX_LAUNCH(MNT, CMV, true, true, true); else HX_LAUNCH(MNT, CMV, true, false, true); } while (0)

@@ -18,7 +18,7 @@ only = set(int(x) for x in os.environ['FUZZ_ONLY'].split(',')) if os.environ.get
 ctx = hip.HipContext(0)
 os.makedirs('/tmp/fz', exist_ok=True)
 bad = 0
-KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS', 'HX_POA_BATCHES', 'HX_POA_NODE_EST_PCT', 'HX_POA_RING_KB', 'HX_POA_COLS', 'HX_POA_CLUSTER_TOPK', 'HX_POA_SLOTS', 'HX_POA_WORKSPACE_GB', 'HX_POA_FORCE_CM', 'HX_POA_RING_ZERO', 'HX_POA_WIDE_MEMBERS', 'HX_POA_PRUNE', 'HX_POA_PRUNE_LANES', 'HX_POA_PASS_LANES', 'HX_POA_PRUNE_LAZY', 'HX_POA_CHAIN_MS', 'HX_POA_COLS2_TOP', 'HX_POA_PRUNE_SHARED', 'HX_POA_SLOTS_BY_WORK', 'HX_POA_BUCKET_HALF_OCTAVES', 'HX_POA_ORDER_BY_CELLS', 'HX_POA_FAR_SHIFT')
+KNOBS = ('HX_POA_CLUSTER_MIN', 'HX_POA_MEMBER_LANES', 'HX_POA_CLUSTER_COLS', 'HX_POA_CLUSTER_MAX', 'HX_POA_MAX_INDEG', 'HX_POA_WAVE_MAX', 'HX_POA_FAR_ROWS', 'HX_POA_BATCHES', 'HX_POA_NODE_EST_PCT', 'HX_POA_RING_KB', 'HX_POA_COLS', 'HX_POA_CLUSTER_TOPK', 'HX_POA_SLOTS', 'HX_POA_WORKSPACE_GB', 'HX_POA_FORCE_CM', 'HX_POA_RING_ZERO', 'HX_POA_WIDE_MEMBERS', 'HX_POA_PRUNE', 'HX_POA_PRUNE_LANES', 'HX_POA_PASS_LANES', 'HX_POA_PRUNE_LAZY', 'HX_POA_CHAIN_MS', 'HX_POA_COLS2_TOP', 'HX_POA_PRUNE_SHARED', 'HX_POA_SLOTS_BY_WORK', 'HX_POA_BUCKET_HALF_OCTAVES', 'HX_POA_ORDER_BY_CELLS', 'HX_POA_FAR_SHIFT', 'HX_POA_OWN_BUCKET_FIRST', 'HX_POA_RESIDENT_FIRST')
 for it in range(n):
     big = os.environ.get('FUZZ_BIG') is not None   # long gaps at real sizes: the default launch shapes (512-lane cluster members) get real work
     glen = rng.choice([400000, 700000, 1000000]) if big else rng.choice([40000, 60000, 90000, 150000, 250000])
@@ -80,6 +80,10 @@ for it in range(n):
         env['HX_POA_BUCKET_HALF_OCTAVES'] = str(rng.choice([0, 1]))
     if rng.random() < 0.2:
         env['HX_POA_ORDER_BY_CELLS'] = '1'
+    if rng.random() < 0.25:
+        env['HX_POA_OWN_BUCKET_FIRST'] = str(rng.choice([0, 1]))
+    if rng.random() < 0.15:
+        env['HX_POA_RESIDENT_FIRST'] = str(rng.choice([1, 2, 3]))
     if rng.random() < 0.15:
         env['HX_POA_FAR_SHIFT'] = str(rng.choice([2, 4, 6]))
     if rng.random() < 0.25:

@@ -43,7 +43,9 @@ for spec in sys.argv[1:] or ["-"]:
                 ph = ctx.poa_phase_cycles()
                 mem = ctx.poa_memory_stats()
             best = dt if best is None else min(best, dt)
-            print(f"[{spec}] pass {it}: step {dt:.3f} s, poa kernel {tm['poa']['ms']:.1f} ms", flush=True)
+            phq = ctx.poa_phase_cycles() if os.environ.get("AB_PHASES") else None
+            extra = "" if phq is None else f", slowest edge {sum(phq['slowest_edge'].values()) / 2.4e6:.1f} ms (dp {phq['slowest_edge']['dp'] / 2.4e6:.1f}), all edges {sum(phq['sum'].values()) / 1e9:.1f} Gcycles"
+            print(f"[{spec}] pass {it}: step {dt:.3f} s, poa kernel {tm['poa']['ms']:.1f} ms{extra}", flush=True)
             run.close()
         skipped = pr["wave_rows_skipped"] / pr["wave_rows"] if pr["wave_rows"] else 0.0
         print(f"RESULT [{spec}] best step {best:.3f} s | edges {ph['edges']} cells {st['dp_cells']:.4g} gcups {st['dp_cells'] / best / 1e9:.0f} | pruned wave-rows {pr['wave_rows']:.4g} skipped {skipped:.3f} "
