@@ -153,6 +153,7 @@ struct HxOptions {
     int poa_slots_by_work = 1;     // many-edge calls: the slots of an instance's need buckets in proportion to the buckets' estimated work (0: from the largest need down, as until round 6)
     int poa_order_by_cells = 0;    // few-edge calls: the launch lists in the order of the edges' DP cells (until round 6) instead of the rows of their chains
     int poa_big_first = 1;         // few-edge calls: the unshared classes of 512 lanes and more leave before the shared edges' 256-lane members (0: behind them, as before round 5)
+    int poa_chain_pct = 70;        // the automatic chain cap: the smallest one that is at least this percentage of the call's estimated wave-slot time over the waves resident (size_edges; 60 until the persistent workgroups took their own bucket first)
     int poa_chain_ms = -1;         // ... the automatic choice: the narrowest workgroup whose estimated chain (size_edges: DP rows x what a row costs at that width and number of
                                    // windows) stays below this many milliseconds; -1: the cap that balances the longest chain against the call's wave-slot time
     int poa_prune_shared = 0;      // ... of the edges shared by several workgroups (round 6: their members take DP ATTEMPTS, not sequences, so a missed threshold is repeated by all of
@@ -174,7 +175,7 @@ const OptDesc kOptions[] = {
     {"poa_balance_pct", &HxOptions::poa_balance_pct, nullptr}, {"poa_balance_lanes", &HxOptions::poa_balance_lanes, nullptr}, {"poa_slots_pct", &HxOptions::poa_slots_pct, nullptr},
     {"poa_slots", &HxOptions::poa_slots, nullptr}, {"poa_batches", &HxOptions::poa_batches, nullptr}, {"poa_force_cm", &HxOptions::poa_force_cm, nullptr},
     {"poa_no_xcd_map", &HxOptions::poa_no_xcd_map, nullptr}, {"poa_streams", &HxOptions::poa_streams, nullptr}, {"poa_wide_delay_us", &HxOptions::poa_wide_delay_us, nullptr},
-    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_prune_shared", &HxOptions::poa_prune_shared, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"poa_chain_ms", &HxOptions::poa_chain_ms, nullptr}, {"poa_big_first", &HxOptions::poa_big_first, nullptr}, {"poa_order_by_cells", &HxOptions::poa_order_by_cells, nullptr}, {"poa_slots_by_work", &HxOptions::poa_slots_by_work, nullptr}, {"poa_resident_first", &HxOptions::poa_resident_first, nullptr}, {"poa_own_bucket_first", &HxOptions::poa_own_bucket_first, nullptr}, {"poa_bucket_half_octaves", &HxOptions::poa_bucket_half_octaves, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
+    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_prune_shared", &HxOptions::poa_prune_shared, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"poa_chain_ms", &HxOptions::poa_chain_ms, nullptr}, {"poa_chain_pct", &HxOptions::poa_chain_pct, nullptr}, {"poa_big_first", &HxOptions::poa_big_first, nullptr}, {"poa_order_by_cells", &HxOptions::poa_order_by_cells, nullptr}, {"poa_slots_by_work", &HxOptions::poa_slots_by_work, nullptr}, {"poa_resident_first", &HxOptions::poa_resident_first, nullptr}, {"poa_own_bucket_first", &HxOptions::poa_own_bucket_first, nullptr}, {"poa_bucket_half_octaves", &HxOptions::poa_bucket_half_octaves, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
 };
 }  // namespace
 
@@ -958,7 +959,11 @@ struct PoaCall {
                 for (double cq = 100; cq <= 3200; cq *= 1.0905) {   // (an eighth of an octave apart)
                     double slot = fixed_slot_ms;
                     for (const Opt& q : opts) { const int k = pick(q, cq); slot += q.ms[k] * (kLanes[k] / 64); }
-                    if (cq >= 0.60 * slot / 3800.0) { cap = cq; break; }   // (round 6, same data, caps of 260 / 290 / 315 / 336 = 0.65 / 340 / 370 ms: 0.597 / 0.480 / 0.476 / 0.496-0.509 / 0.493 / 0.508 s)
+                    // (round 6, once the persistent workgroups took their own bucket first - the slow passes of the earlier sweeps were that, not the cap: 60 / 70 / 80 / 90 / 100 %
+                    // = caps of 308 / 366 / 399 / 435 / 475 ms at 140 Mb: 0.461 / 0.434 / 0.426 / 0.426 / 0.438 s, five passes each; at 400 Mb, 40 / 50 / 60 / 70 / 80 / 100 % =
+                    // 872 / 1037 / 1234 / 1467 / 1744 / 2074 ms: 1.84 / 1.81 / 1.77 / 1.76 / 1.89-2.26 / 2.10 s. 70: profiles/r06_chain_cap_sweep.txt)
+                    if (o.debug > 1) fprintf(stderr, "[hx] chain cap %.0f ms: wave-slot time over 3 800 waves %.0f ms\n", cq, slot / 3800.0);
+                    if (cq >= std::max(10, o.poa_chain_pct) / 100.0 * slot / 3800.0) { cap = cq; break; }   // (round 6, same data, caps of 260 / 290 / 315 / 336 = 0.65 / 340 / 370 ms: 0.597 / 0.480 / 0.476 / 0.496-0.509 / 0.493 / 0.508 s)
                 }
             }
             size_t hist[5] = {};
