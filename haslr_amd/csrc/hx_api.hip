@@ -153,6 +153,7 @@ struct HxOptions {
     int poa_slots_by_work = 1;     // many-edge calls: the slots of an instance's need buckets in proportion to the buckets' estimated work (0: from the largest need down, as until round 6)
     int poa_order_by_cells = 0;    // few-edge calls: the launch lists in the order of the edges' DP cells (until round 6) instead of the rows of their chains
     int poa_big_first = 1;         // few-edge calls: the unshared classes of 512 lanes and more leave before the shared edges' 256-lane members (0: behind them, as before round 5)
+    int poa_scratch_warm = 1;      // the streams' hardware queues are taken to the largest scratch size any POA instance needs before the first launches of a process (launch_batch)
     int poa_chain_pct = 70;        // the automatic chain cap: the smallest one that is at least this percentage of the call's estimated wave-slot time over the waves resident (size_edges; 60 until the persistent workgroups took their own bucket first)
     int poa_chain_ms = -1;         // ... the automatic choice: the narrowest workgroup whose estimated chain (size_edges: DP rows x what a row costs at that width and number of
                                    // windows) stays below this many milliseconds; -1: the cap that balances the longest chain against the call's wave-slot time
@@ -175,7 +176,7 @@ const OptDesc kOptions[] = {
     {"poa_balance_pct", &HxOptions::poa_balance_pct, nullptr}, {"poa_balance_lanes", &HxOptions::poa_balance_lanes, nullptr}, {"poa_slots_pct", &HxOptions::poa_slots_pct, nullptr},
     {"poa_slots", &HxOptions::poa_slots, nullptr}, {"poa_batches", &HxOptions::poa_batches, nullptr}, {"poa_force_cm", &HxOptions::poa_force_cm, nullptr},
     {"poa_no_xcd_map", &HxOptions::poa_no_xcd_map, nullptr}, {"poa_streams", &HxOptions::poa_streams, nullptr}, {"poa_wide_delay_us", &HxOptions::poa_wide_delay_us, nullptr},
-    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_prune_shared", &HxOptions::poa_prune_shared, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"poa_chain_ms", &HxOptions::poa_chain_ms, nullptr}, {"poa_chain_pct", &HxOptions::poa_chain_pct, nullptr}, {"poa_big_first", &HxOptions::poa_big_first, nullptr}, {"poa_order_by_cells", &HxOptions::poa_order_by_cells, nullptr}, {"poa_slots_by_work", &HxOptions::poa_slots_by_work, nullptr}, {"poa_resident_first", &HxOptions::poa_resident_first, nullptr}, {"poa_own_bucket_first", &HxOptions::poa_own_bucket_first, nullptr}, {"poa_bucket_half_octaves", &HxOptions::poa_bucket_half_octaves, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
+    {"poa_prune", &HxOptions::poa_prune, nullptr}, {"poa_prune_lanes", &HxOptions::poa_prune_lanes, nullptr}, {"poa_prune_lazy", &HxOptions::poa_prune_lazy, nullptr}, {"poa_prune_shared", &HxOptions::poa_prune_shared, nullptr}, {"poa_pass_lanes", &HxOptions::poa_pass_lanes, nullptr}, {"poa_chain_ms", &HxOptions::poa_chain_ms, nullptr}, {"poa_chain_pct", &HxOptions::poa_chain_pct, nullptr}, {"poa_scratch_warm", &HxOptions::poa_scratch_warm, nullptr}, {"poa_big_first", &HxOptions::poa_big_first, nullptr}, {"poa_order_by_cells", &HxOptions::poa_order_by_cells, nullptr}, {"poa_slots_by_work", &HxOptions::poa_slots_by_work, nullptr}, {"poa_resident_first", &HxOptions::poa_resident_first, nullptr}, {"poa_own_bucket_first", &HxOptions::poa_own_bucket_first, nullptr}, {"poa_bucket_half_octaves", &HxOptions::poa_bucket_half_octaves, nullptr}, {"coords_lds_supp", &HxOptions::coords_lds_supp, nullptr},
 };
 }  // namespace
 
@@ -268,6 +269,24 @@ struct hx_ctx {
         tm.ms[k] += ms; tm.launches[k]++;
     }
 };
+
+// Every k_poa instance uses private memory (288 to 928 bytes per lane: spills, a by-value argument), and a hardware queue grows its scratch when a
+// dispatch asks for more per wave than the queue has had - a trip through the runtime (an allocation of device memory: slow while the driver is still
+// wiping what another process freed) that holds THAT launch back. In a process that has run the few-edge instances, the first many-edge call then had
+// some of its launches held and others not, they reached the CUs in another order, and the call took 600-640 ms instead of 415-440 (tools/dev_cold.py:
+// a 12 Mb context, then the 140 Mb one; bench.py's configs[3] leg: five runs of five). Once per process and device, every stream of the pool runs one
+// wave that asks for the most: from hx_poa_reserve (beside the parse) or, without a reservation, before the first launches.
+static int scratch_warm_once(hx_ctx* c) {
+    static std::mutex warm_mu;
+    static std::vector<char> warmed;
+    std::lock_guard<std::mutex> lk(warm_mu);
+    if ((int)warmed.size() <= c->device) warmed.resize((size_t)c->device + 1, 0);
+    if (!c->opt.poa_scratch_warm || warmed[(size_t)c->device]) return 0;
+    for (int i = 0; i < 8; i++) hxk::scratch_warm(c->poa_streams[i]);
+    for (int i = 0; i < 8; i++) HIPCHK(hipStreamSynchronize(c->poa_streams[i]));
+    warmed[(size_t)c->device] = 1;
+    return 0;
+}
 
 extern "C" const char* hx_last_error(void) { return g_err.c_str(); }
 
@@ -1360,6 +1379,7 @@ struct PoaCall {
         }
         HIPCHK(c->poa_btab.reserve(std::max<size_t>(1, h_btab.size())));
         if (!h_btab.empty()) HIPCHK(hipMemcpyAsync(c->poa_btab.p, h_btab.data(), h_btab.size() * 4, hipMemcpyHostToDevice, s));
+        if (scratch_warm_once(c)) return -1;
         HIPCHK(hipEventRecord(c->poa_ev[8], s));
         size_t gi = 0;
         for (const auto& grp : groups) {
@@ -1758,6 +1778,7 @@ extern "C" int hx_poa_reserve(hx_ctx* c, uint64_t bytes) {
     if (want <= c->poa_arena.cap) return 0;
     const hipError_t e = c->poa_arena.ensure(want);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(std::string("hx_poa_reserve: ") + hipGetErrorString(e)); }
+    if (scratch_warm_once(c)) return -1;
     return 0;
 }
 extern "C" void hx_poa_host_times(const hx_ctx* c, double* ms8) { for (int k = 0; k < 8; k++) ms8[k] = c->poa_host_ms[k]; }

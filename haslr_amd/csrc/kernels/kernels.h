@@ -30,6 +30,8 @@ void radix_sort_pairs(uint64_t* key, uint32_t* val, uint64_t* key_tmp, uint32_t*
 
 // strings scattered over `src` moved side by side into `dst`: desc = n_items x (source offset lo / hi, destination offset lo / hi, length)
 void gather_bytes(const char* src, const uint32_t* desc, uint32_t n_items, char* dst, hipStream_t s);
+// one wave with 1 KB of private memory per lane: the stream's hardware queue grows its scratch to the largest any POA instance needs
+void scratch_warm(hipStream_t s);
 
 // ---- chain.hip (K0-K3)
 struct ChainScratch {   // all sized by the number of raw hits in the shard (+1)

@@ -214,4 +214,15 @@ void gather_bytes(const char* src, const uint32_t* desc, uint32_t n_items, char*
     if (n_items) k_gather_bytes<<<n_items, 256, 0, s>>>(src, desc, dst);
 }
 
+// One wave with as much private memory per lane as the largest k_poa instance spills (kernels/poa.hip: 288 to 928 bytes per lane): run once on a
+// stream, it takes the stream's hardware queue to that scratch size. See hx_api.hip (poa_scratch_warm) for why.
+__global__ void __launch_bounds__(64) k_scratch_warm(uint32_t* out, uint32_t n) {
+    volatile uint32_t a[256];
+    for (uint32_t i = 0; i < 256; i++) a[i] = i * n;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < n; i++) sum += a[(i * 7u) & 255u];
+    if (out) *out = sum;
+}
+void scratch_warm(hipStream_t s) { k_scratch_warm<<<1, 64, 0, s>>>(nullptr, 3u); }
+
 }  // namespace hxk

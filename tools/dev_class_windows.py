@@ -4,7 +4,7 @@ passes, cur = [], []
 for line in open(sys.argv[1]):
     if line.startswith("[hx-edge]"):
         t = line.split(); d = {t[i]: float(t[i + 1]) for i in range(2, len(t) - 1, 2)}; cur.append(d)
-    elif "] pass " in line and cur:
+    elif ("] pass " in line or "cold first pass" in line or "] step " in line) and cur:
         passes.append((line.strip()[:60], cur)); cur = []
 for name, E in passes:
     end = max(d["end_us"] for d in E)
@@ -22,3 +22,5 @@ for name, E in passes:
         if k[1] >= 512:
             for d in sorted(by[k], key=lambda x: x["begin_us"]):
                 print("      edge lmax %d nseq %d passes %d begin %.1f ms end %.1f ms chain %.1f ms %s" % (d["lmax"], d["nseq"], d["passes"], d["begin_us"] / 1e3, d["end_us"] / 1e3, (d["end_us"] - d["begin_us"]) / 1e3, hw(d["hw"])))
+    for d in sorted(E, key=lambda x: -x["end_us"])[:8]:
+        print("      late edge: class %d lanes %d members %d lmax %d nseq %d passes %d begin %.1f ms end %.1f ms %s" % (d["cls"], d["lanes"], d.get("members", 0), d["lmax"], d["nseq"], d["passes"], d["begin_us"] / 1e3, d["end_us"] / 1e3, hw(d["hw"])))
