@@ -290,16 +290,34 @@ __device__ void bundle_pass(G& g, const uint32_t V, const uint32_t r_begin, cons
     }
 }
 
-// the walk back from rank `best` along the chosen predecessors; lane 0 writes, every lane gets the length
+// The walk back from rank `best` along the chosen predecessors, by the whole wavefront: every lane gets the length. A lane on its own pays a dependent
+// round trip per node, twice (length first, then the bases back to front): 4-5 M cycles of the 14 M the consensus of the longest 12 Mb edge took. Here the
+// predecessors and bases of the 64 ranks around the walk are fetched at once, the walk inside them runs on v_readlane, the bases are kept back to front
+// in the alignment-entry array (free by now, a word per node at least: need_of) and turned round by all lanes.
 __device__ uint32_t bundle_backtrack(G& g, const uint32_t best, char* out) {
+    const uint32_t lane = threadIdx.x & 63u;
     const int32_t* pr_r = g.pred;
+    int32_t* rev = g.aln_node;
+    int32_t r = __builtin_amdgcn_readfirstlane((int)best);
     uint32_t len = 0;
-    if ((threadIdx.x & 63u) == 0) {
-        for (int32_t r = (int32_t)best; r != -1; r = pr_r[r]) len++;
-        uint32_t w = len;
-        for (int32_t r = (int32_t)best; r != -1; r = pr_r[r]) out[--w] = "ACGT"[g.row_meta[r] & 3u];
+    int acc = 0;
+    while (r != -1) {
+        const uint32_t cb = (uint32_t)r & ~63u, idx = min(cb + lane, (uint32_t)r);   // (ranks above the walk are never looked at)
+        const int p = pr_r[idx], b = (int)(g.row_meta[idx] & 3u);
+        while (r >= (int32_t)cb) {
+            const int l = r - (int32_t)cb;
+            const int bl = __builtin_amdgcn_readlane(b, l);
+            acc = lane == (len & 63u) ? bl : acc;
+            len++;
+            if ((len & 63u) == 0) rev[len - 64 + lane] = acc;
+            r = __builtin_amdgcn_readlane(p, l);
+        }
     }
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
+    if (lane < (len & 63u)) rev[(len & ~63u) + lane] = acc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (uint32_t k = lane; k < len; k += 64) out[k] = "ACGT"[rev[len - 1 - k] & 3];
+    return len;
 }
 
 __device__ uint32_t consensus_fast_wave(G& g, const uint32_t V, char* out) {

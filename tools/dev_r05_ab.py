@@ -44,7 +44,8 @@ for spec in sys.argv[1:] or ["-"]:
                 mem = ctx.poa_memory_stats()
             best = dt if best is None else min(best, dt)
             phq = ctx.poa_phase_cycles() if os.environ.get("AB_PHASES") else None
-            extra = "" if phq is None else f", slowest edge {sum(phq['slowest_edge'].values()) / 2.4e6:.1f} ms (dp {phq['slowest_edge']['dp'] / 2.4e6:.1f}), all edges {sum(phq['sum'].values()) / 1e9:.1f} Gcycles"
+            parts = "" if phq is None else ", ".join("%s %.1f" % (k, v / 2.4e6) for k, v in phq["slowest_edge"].items())
+            extra = "" if phq is None else f", slowest edge {sum(phq['slowest_edge'].values()) / 2.4e6:.1f} ms ({parts}), all edges {sum(phq['sum'].values()) / 1e9:.1f} Gcycles"
             print(f"[{spec}] pass {it}: step {dt:.3f} s, poa kernel {tm['poa']['ms']:.1f} ms{extra}", flush=True)
             run.close()
         skipped = pr["wave_rows_skipped"] / pr["wave_rows"] if pr["wave_rows"] else 0.0
