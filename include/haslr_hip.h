@@ -54,7 +54,8 @@ void hx_ctx_destroy(hx_ctx*);
  *                    poa_prune (exact score-bound pruning of the DP: -1 automatic = calls of thousands of edges, 0 never, else the threshold as a
  *                    percentage of the previous alignment's score per base), launch-shape knobs (poa_cols, poa_cols2_top, poa_member_lanes, poa_cluster_min /
  *                    _max / _topk / _cols, poa_wide_members, poa_wave_max, poa_ring_kb, poa_balance, poa_balance_pct, poa_balance_lanes, poa_streams,
- *                    poa_wide_delay_us, poa_prune_lanes, poa_prune_shared, poa_prune_lazy, poa_order_by_cells, poa_pass_lanes, poa_chain_ms, poa_big_first) and test switches that force rare paths (poa_poll_limit, poa_max_indeg, poa_node_est_pct,
+ *                    poa_wide_delay_us, poa_prune_lanes, poa_prune_shared, poa_prune_lazy, poa_order_by_cells, poa_pass_lanes, poa_chain_ms, poa_chain_pct, poa_big_first,
+ *                    poa_slots_by_work, poa_bucket_half_octaves, poa_own_bucket_first, poa_resident_first, poa_far_shift, poa_scratch_warm) and test switches that force rare paths (poa_poll_limit, poa_max_indeg, poa_node_est_pct,
  *                    poa_far_rows, poa_ring_zero, poa_slots, poa_slots_pct, poa_batches, poa_force_cm, poa_no_xcd_map, coords_lds_supp).
  *                    Results never depend on any of them. */
 int hx_set_option(hx_ctx*, const char* name, const char* value);
