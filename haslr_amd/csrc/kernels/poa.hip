@@ -460,10 +460,12 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                             pv0 = (mt >> META_NP) == 0 ? 0u : (g.row_pred0[rr] & 0x0fffffffu) + 1;   // (a source node continues in the virtual row 0)
                             pv1 = (g.row_pred1[rr] & 0x0fffffffu) + 1;
                         }
-                        const uint32_t ilo = ti > 31u ? ti - 31u : 1u;                 // the walk goes on while i >= ilo (rows of the tile, never row 0) ...
+                        uint32_t ilo = ti > 31u ? ti - 31u : 1u;                       // the walk goes on while i >= ilo (rows of the tile, never row 0) ...
+                        asm volatile("" : "+s"(ilo));                                // (... as ONE subtraction per step: the compiler otherwise takes the constant apart again)
                         const int32_t jb0 = 2 * bs;                                  // ... and j >= first column of the tile
                         // (bit dr: the tile's row dr has more than 4 predecessors - a scalar bit test per step instead of a readlane of the row's record)
                         const uint32_t wmask = (uint32_t)__ballot(ln < 32 && (mt & 32u) != 0);
+                        if ((wmask >> r0) & 1u) w0 = 0x88888888u;   // a row with more than 4 predecessors: every cell reads as code 8, one of the rare moves - its real move is in the wide-row pool
                         for (;;) {
                             const uint32_t dr = ti - i, jb = (uint32_t)((int32_t)j - jb0);   // row and column inside the tile (0..31, 0..15)
                             const uint32_t wsel = (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)(dr * 2 + (jb >> 3)));
@@ -472,14 +474,16 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                             // keeps type * 16 + 15 - slot in the wide-row pool
                             // (a move into the third or a later predecessor - codes 8, 9, 12, 13 of a 4-bit row - has to fetch that predecessor's rank)
                             uint32_t type = n4 >> 2, slot = 3u - (n4 & 3u);
+                            uint32_t ml = (0xf0ffu >> n4) & 1u;   // a column to the left unless the move is vertical (type 2: codes 8-11) - read off the code, one shift (the compiler turns "type != 2" into five scalar instructions)
                             // (both candidates read, the choice made by arithmetic: the compiler turns the obvious select into two branches and a flag test)
                             const uint32_t pva = (uint32_t)__builtin_amdgcn_readlane((int)pv0, (int)dr), pvb = (uint32_t)__builtin_amdgcn_readlane((int)pv1, (int)dr);
-                            uint32_t pv = pvb ^ ((pva ^ pvb) & (0u - (uint32_t)(slot == 0)));
-                            if (__builtin_expect((((0x3300u >> n4) | (wmask >> dr)) & 1u) != 0, 0)) {   // ONE test for the rare moves: a wide row, a third or later predecessor
-                                uint32_t later = (0x3300u >> n4) & 1u;
+                            uint32_t pv = (~n4 & 3u) != 0 ? pvb : pva;   // (slot 0 = both low bits of the code set)
+                            bool up = (n4 & 8u) != 0;             // the move leaves the row (types 2 and 3: codes 8-15)
+                            if (__builtin_expect((n4 & 10u) == 8u, 0)) {   // ONE test for the rare moves: codes 8, 9, 12, 13 = a third or later predecessor, or (code 8 by the line above) a wide row
+                                uint32_t later = 1u;
                                 if ((wmask >> dr) & 1u) {
                                     const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)Dw[(uint64_t)__builtin_amdgcn_readlane((int)qw, (int)dr) * W + j]);
-                                    type = d >> 4; slot = 15u - (d & 15u); later = slot >= 2 && type > 1u;
+                                    type = d >> 4; slot = 15u - (d & 15u); later = slot >= 2 && type > 1u; ml = (uint32_t)(type != 2u); up = type > 1u;
                                     pv = slot == 0 ? (uint32_t)__builtin_amdgcn_readlane((int)pv0, (int)dr) : (uint32_t)__builtin_amdgcn_readlane((int)pv1, (int)dr);
                                 }
                                 if (later != 0)
@@ -494,13 +498,13 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                                 asm volatile("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\ts_mov_b32 m0, %2"
                                              : "+v"(pn), "+v"(pp), "=&s"(m0_keep) : "s"(el), "s"(i), "s"(j));
                             }
-                            na++;
-                            if (type > 1u) i = pv;                // (a horizontal move is type 1 from the int32 rows, type 0 from the packed ones)
-                            j -= type != 2u;                      // (horizontal and diagonal moves go a column to the left, a vertical one does not)
-                            if (__builtin_expect((na & 63u) == 0, 0)) {   // 64 entries: out they go (a store per step cost more than the step itself)
+                            if (__builtin_expect((na & 63u) == 63u, 0)) {   // 64 entries: out they go (a store per step cost more than the step itself)
                                 asm volatile("" ::: "memory");
-                                g.aln_node[na - 64 + ln] = pn; g.aln_pos[na - 64 + ln] = pp;
+                                g.aln_node[na - 63 + ln] = pn; g.aln_pos[na - 63 + ln] = pp;
                             }
+                            na++;
+                            if (up) i = pv;                       // (a horizontal move is type 1 from the int32 rows, type 0 from the packed ones)
+                            j -= ml;                              // (horizontal and diagonal moves go a column to the left, a vertical one does not)
                             if ((int32_t)((i - ilo) | (uint32_t)((int32_t)j - jb0)) < 0) break;   // left the tile's rows or columns
                         }
                     }
