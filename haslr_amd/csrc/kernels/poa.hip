@@ -443,32 +443,33 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                             na += j; j = 0;
                             break;
                         }
-                        // tile: 32 rows (ranks ti .. ti-31) x 16 columns (ct-15 .. ct, ct = tj made odd: whole bytes of two nibbles); lane = (row, half):
-                        // the 4 bytes = 8 columns of one row in one register
-                        const uint32_t ti = i, ct = j | 1u, r0 = ln >> 1, hf = ln & 1u;
+                        // tile: 64 rows (ranks ti .. ti-63) x 16 columns (ct-15 .. ct, ct = tj made odd: whole bytes of two nibbles); lane = row: the 8 bytes =
+                        // 16 columns of one row in two registers. (32 rows x 16 columns, lane = (row, half), until round 6: graphs have ~2 ranks per column, the
+                        // walk left such a tile through its rows after ~12 steps - and a tile is a round trip to memory.)
+                        const uint32_t ti = i, ct = j | 1u;
                         if (NT > 64 && ln == 0) { st_wg(&lds_u[8], ti); st_wg(&lds_u[9], ct); }   // (where the walk is: the helper wave fetches ahead of it)
                         const int32_t bs = ((int32_t)ct - 15) >> 1;   // first byte of the tile in its rows (ct < 15: negative - bytes before the row, never looked at)
-                        uint32_t w0 = 0, mt = 0, pv0 = 0, pv1 = 0, qo = 0, qw = 0;
-                        if (ti > r0) {
-                            // one unaligned dword load per lane (bytes bs + 4 hf .. + 3 of the row; columns below 0 read the end of the previous row - row 0 exists)
-                            const uint8_t* rowp = Dm + (uint64_t)(ti - r0) * (W >> 1) + bs + 4 * (int32_t)hf;
-                            __builtin_memcpy(&w0, rowp, 4);
-                        }
-                        if (ln < 32 && ti > ln) {   // the records of the tile's rows: where a move into the first / second predecessor leads (lanes = rows)
+                        uint32_t w0 = 0, w1 = 0, mt = 0, pv0 = 0, pv1 = 0, qo = 0, qw = 0;
+                        if (ti > ln) {
+                            // two unaligned dword loads per lane (bytes bs .. bs + 7 of the row; columns below 0 read the end of the previous row - row 0 exists)
+                            const uint8_t* rowp = Dm + (uint64_t)(ti - ln) * (W >> 1) + bs;
+                            __builtin_memcpy(&w0, rowp, 4); __builtin_memcpy(&w1, rowp + 4, 4);
+                            // the records of the tile's rows: where a move into the first / second predecessor leads
                             const uint32_t rr = ti - 1 - ln;
                             mt = g.row_meta[rr]; qo = g.row_pred_off[rr]; if (mt & 32u) qw = g.wslot[rr];
                             pv0 = (mt >> META_NP) == 0 ? 0u : (g.row_pred0[rr] & 0x0fffffffu) + 1;   // (a source node continues in the virtual row 0)
                             pv1 = (g.row_pred1[rr] & 0x0fffffffu) + 1;
                         }
-                        uint32_t ilo = ti > 31u ? ti - 31u : 1u;                       // the walk goes on while i >= ilo (rows of the tile, never row 0) ...
+                        uint32_t ilo = ti > 63u ? ti - 63u : 1u;                       // the walk goes on while i >= ilo (rows of the tile, never row 0) ...
                         asm volatile("" : "+s"(ilo));                                // (... as ONE subtraction per step: the compiler otherwise takes the constant apart again)
                         const int32_t jb0 = 2 * bs;                                  // ... and j >= first column of the tile
                         // (bit dr: the tile's row dr has more than 4 predecessors - a scalar bit test per step instead of a readlane of the row's record)
-                        const uint32_t wmask = (uint32_t)__ballot(ln < 32 && (mt & 32u) != 0);
-                        if ((wmask >> r0) & 1u) w0 = 0x88888888u;   // a row with more than 4 predecessors: every cell reads as code 8, one of the rare moves - its real move is in the wide-row pool
+                        const unsigned long long wmask = __ballot((mt & 32u) != 0);
+                        if (mt & 32u) { w0 = 0x88888888u; w1 = 0x88888888u; }   // a row with more than 4 predecessors: every cell reads as code 8, one of the rare moves - its real move is in the wide-row pool
                         for (;;) {
-                            const uint32_t dr = ti - i, jb = (uint32_t)((int32_t)j - jb0);   // row and column inside the tile (0..31, 0..15)
-                            const uint32_t wsel = (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)(dr * 2 + (jb >> 3)));
+                            const uint32_t dr = ti - i, jb = (uint32_t)((int32_t)j - jb0);   // row and column inside the tile (0..63, 0..15)
+                            const uint32_t wsa = (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)dr), wsb = (uint32_t)__builtin_amdgcn_readlane((int)w1, (int)dr);
+                            const uint32_t wsel = (jb & 8u) ? wsb : wsa;
                             const uint32_t n4 = (wsel >> (4 * (jb & 7u))) & 15u;
                             // move code: type (3 diagonal / 2 vertical / 1 horizontal) * 4 + 3 - predecessor slot; a row with more than 4 predecessors
                             // keeps type * 16 + 15 - slot in the wide-row pool
@@ -481,7 +482,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                             bool up = (n4 & 8u) != 0;             // the move leaves the row (types 2 and 3: codes 8-15)
                             if (__builtin_expect((n4 & 10u) == 8u, 0)) {   // ONE test for the rare moves: codes 8, 9, 12, 13 = a third or later predecessor, or (code 8 by the line above) a wide row
                                 uint32_t later = 1u;
-                                if ((wmask >> dr) & 1u) {
+                                if ((uint32_t)(wmask >> dr) & 1u) {
                                     const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)Dw[(uint64_t)__builtin_amdgcn_readlane((int)qw, (int)dr) * W + j]);
                                     type = d >> 4; slot = 15u - (d & 15u); later = slot >= 2 && type > 1u; ml = (uint32_t)(type != 2u); up = type > 1u;
                                     pv = slot == 0 ? (uint32_t)__builtin_amdgcn_readlane((int)pv0, (int)dr) : (uint32_t)__builtin_amdgcn_readlane((int)pv1, (int)dr);
@@ -527,8 +528,8 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                         const uint32_t pi_ = ld_wg(&lds_u[8]), pc = ld_wg(&lds_u[9]);
                         if (pi_ == last_i) { __builtin_amdgcn_s_sleep(8); continue; }
                         last_i = pi_;
-                        for (uint32_t hk = 0; hk < 2; hk++) {                        // rows pi_ - 32 .. pi_ - 159, 64 at a time
-                        const uint32_t d = 32u + hl + 64u * hk;
+                        for (uint32_t hk = 0; hk < 2; hk++) {                        // rows pi_ - 64 .. pi_ - 191, 64 at a time
+                        const uint32_t d = 64u + hl + 64u * hk;
                         if (pi_ > d) {
                             const uint32_t r = pi_ - d, rr = r - 1;
                             const uint8_t* rowp = Dm + (uint64_t)r * (W >> 1);
