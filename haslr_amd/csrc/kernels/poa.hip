@@ -469,26 +469,31 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                         for (;;) {
                             const uint32_t dr = ti - i, jb = (uint32_t)((int32_t)j - jb0);   // row and column inside the tile (0..63, 0..15)
                             const uint32_t wsa = (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)dr), wsb = (uint32_t)__builtin_amdgcn_readlane((int)w1, (int)dr);
-                            const uint32_t wsel = (jb & 8u) ? wsb : wsa;
-                            const uint32_t n4 = (wsel >> (4 * (jb & 7u))) & 15u;
+                            const uint32_t wsh = ((jb & 8u) ? wsb : wsa) >> (4 * (jb & 7u));   // the cell's code in bits 0-3
+                            const uint32_t n4 = wsh & 15u;
                             // move code: type (3 diagonal / 2 vertical / 1 horizontal) * 4 + 3 - predecessor slot; a row with more than 4 predecessors
                             // keeps type * 16 + 15 - slot in the wide-row pool
                             // (a move into the third or a later predecessor - codes 8, 9, 12, 13 of a 4-bit row - has to fetch that predecessor's rank)
-                            uint32_t type = n4 >> 2, slot = 3u - (n4 & 3u);
-                            uint32_t ml = (0xf0ffu >> n4) & 1u;   // a column to the left unless the move is vertical (type 2: codes 8-11) - read off the code, one shift (the compiler turns "type != 2" into five scalar instructions)
-                            // (both candidates read, the choice made by arithmetic: the compiler turns the obvious select into two branches and a flag test)
                             const uint32_t pva = (uint32_t)__builtin_amdgcn_readlane((int)pv0, (int)dr), pvb = (uint32_t)__builtin_amdgcn_readlane((int)pv1, (int)dr);
-                            uint32_t pv = (~n4 & 3u) != 0 ? pvb : pva;   // (slot 0 = both low bits of the code set)
-                            bool up = (n4 & 8u) != 0;             // the move leaves the row (types 2 and 3: codes 8-15)
-                            if (__builtin_expect((n4 & 10u) == 8u, 0)) {   // ONE test for the rare moves: codes 8, 9, 12, 13 = a third or later predecessor, or (code 8 by the line above) a wide row
-                                uint32_t later = 1u;
+                            // What the step waits for is its chain of DEPENDENT instructions from one (row, column) to the next, ~20 cycles each for a lone wave
+                            // (docs/poa_kernel_notes.md); the compiler spends 7 on "which row next" and 5 on "which column next". Spelled out, 4 and 3:
+                            //   row:    not slot 0 (a low bit of the code clear)? second predecessor : first; bit 3 (types 2 and 3: the move leaves the row)? that : this row
+                            //   column: type 2 (bits 3-2 = 10: vertical)? this column : one to the left
+                            uint32_t ni, nj;
+                            asm("s_andn2_b32 %0, 3, %2\n\ts_cselect_b32 %0, %4, %3\n\ts_bitcmp1_b32 %2, 3\n\ts_cselect_b32 %0, %0, %5\n\t"
+                                "s_and_b32 %1, %2, 12\n\ts_cmp_lg_u32 %1, 8\n\ts_subb_u32 %1, %6, 0"
+                                : "=&s"(ni), "=&s"(nj) : "s"(wsh), "s"(pva), "s"(pvb), "s"(i), "s"(j) : "scc");
+                            if (__builtin_expect((n4 & 10u) == 8u, 0)) {   // ONE test for the rare moves: codes 8, 9, 12, 13 = a third or later predecessor, or (code 8 by the line above the loop) a wide row
+                                uint32_t type = n4 >> 2, slot = 3u - (n4 & 3u), later = 1u, pv = slot == 0 ? pva : pvb;
                                 if ((uint32_t)(wmask >> dr) & 1u) {
                                     const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)Dw[(uint64_t)__builtin_amdgcn_readlane((int)qw, (int)dr) * W + j]);
-                                    type = d >> 4; slot = 15u - (d & 15u); later = slot >= 2 && type > 1u; ml = (uint32_t)(type != 2u); up = type > 1u;
-                                    pv = slot == 0 ? (uint32_t)__builtin_amdgcn_readlane((int)pv0, (int)dr) : (uint32_t)__builtin_amdgcn_readlane((int)pv1, (int)dr);
+                                    type = d >> 4; slot = 15u - (d & 15u); later = slot >= 2 && type > 1u;
+                                    pv = slot == 0 ? pva : pvb;
                                 }
                                 if (later != 0)
                                     pv = ((uint32_t)__builtin_amdgcn_readfirstlane((int)g.pred_rank[(uint32_t)__builtin_amdgcn_readlane((int)qo, (int)dr) + slot]) & 0x0fffffffu) + 1;
+                                ni = type > 1u ? pv : i;          // (a horizontal move is type 1 from the int32 rows, type 0 from the packed ones)
+                                nj = j - (uint32_t)(type != 2u);  // (horizontal and diagonal moves go a column to the left, a vertical one does not)
                             }
                             {
                                 const int el = (int)(na & 63u);
@@ -504,8 +509,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                                 g.aln_node[na - 63 + ln] = pn; g.aln_pos[na - 63 + ln] = pp;
                             }
                             na++;
-                            if (up) i = pv;                       // (a horizontal move is type 1 from the int32 rows, type 0 from the packed ones)
-                            j -= ml;                              // (horizontal and diagonal moves go a column to the left, a vertical one does not)
+                            i = ni; j = nj;
                             if ((int32_t)((i - ilo) | (uint32_t)((int32_t)j - jb0)) < 0) break;   // left the tile's rows or columns
                         }
                     }
