@@ -1,6 +1,9 @@
 // hx_api.hip — implementation of the C-ABI in include/haslr_hip.h: device context, resident inputs,
 // the four hot-path operators (kernel orchestration + result download), multi-GPU record exchange, timing.
 // There is no CPU fallback here: without a usable HIP device every entry point fails with an error.
+#include <atomic>
+#include <thread>
+#include <memory>
 #include <chrono>
 #include <cmath>
 #include <hip/hip_runtime.h>
@@ -723,7 +726,9 @@ struct PoaCall {
     const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     PoaPlan P;
     uint64_t seq_bases = 0, n_aligned = 0, budget = 0;
-    std::vector<std::string> cns;
+    struct CnsView { const char* p = nullptr; size_t n = 0; const char* data() const { return p; } size_t size() const { return n; } };
+    std::vector<CnsView> cns;                            // per edge: where its finished consensus lies in ...
+    std::vector<std::unique_ptr<char[]>> cns_blocks;     // ... the download of its batch (kept to the end of the call: no copy per edge, no zero fill)
     std::vector<uint8_t> grow;         // times an edge's graph outgrew its workspace: the node estimate doubles each time
     std::vector<uint8_t> force_nodir;  // edges whose in-degrees outgrew the direction bytes
     std::vector<uint8_t> full_h;       // edges that run with the score-matrix traceback
@@ -752,24 +757,50 @@ struct PoaCall {
     // ---- plan, part 1: the sub-sequence rule of Assemble.cpp:530-537 (u32 wrap + substr clamp; empty ones skipped)
     int plan_input(std::vector<uint32_t>& todo) {
         P.edges.resize(ne); P.sumL.assign(ne, 0); P.nseq.assign(ne, 0);
-        for (uint32_t e = 0; e < ne; e++) {
-            hxk::PoaEdge& E = P.edges[e];
-            memset(&E, 0, sizeof(E));
-            E.seq_begin = (uint32_t)P.seqs.size();
-            for (uint64_t k = in.supp_off[e]; k < in.supp_off[e + 1]; k++) {
-                uint32_t rid = in.supp_lr[k] & 0x7fffffffu, strand = in.supp_lr[k] >> 31;
-                uint32_t rl = in.h_rlen[rid], sp = in.spos[k], ep = in.epos[k];
-                if (sp > rl) return fail("hx_poa_batch: consensus support starts beyond its read (the reference would throw std::out_of_range, Assemble.cpp:530)");
-                uint32_t want = ep - sp + 1, n = std::min(want, rl - sp);
-                if (n == 0) continue;
-                P.seqs.push_back({rid, strand, sp, n});
-                P.sumL[e] += n; P.nseq[e]++; E.lmax = std::max(E.lmax, n);
-                seq_bases += n; n_aligned++;
+        // (330 000 sequences of 13 000 edges at 140 Mb, a read-length lookup each: counted and filled by a few threads, each its range of the edges - 3.6 ms on one)
+        const uint64_t n_supp = ne ? in.supp_off[ne] - in.supp_off[0] : 0;
+        const uint32_t nt = n_supp > 50000 ? 8u : 1u;
+        std::vector<uint64_t> t_seqs(nt + 1, 0), t_bases(nt, 0);
+        std::atomic<int> bad{0};
+        auto range = [&](uint32_t t, bool fill) {
+            const uint32_t e0 = (uint32_t)((uint64_t)ne * t / nt), e1 = (uint32_t)((uint64_t)ne * (t + 1) / nt);
+            uint64_t at = fill ? t_seqs[t] : 0, bases = 0;
+            for (uint32_t e = e0; e < e1; e++) {
+                hxk::PoaEdge& E = P.edges[e];
+                if (fill) { memset(&E, 0, sizeof(E)); E.seq_begin = (uint32_t)at; }
+                uint32_t cnt = 0, lmax = 0; uint64_t sum = 0;
+                for (uint64_t k = in.supp_off[e]; k < in.supp_off[e + 1]; k++) {
+                    const uint32_t rid = in.supp_lr[k] & 0x7fffffffu, strand = in.supp_lr[k] >> 31;
+                    const uint32_t rl = in.h_rlen[rid], sp = in.spos[k], ep = in.epos[k];
+                    if (sp > rl) { bad = 1; return; }
+                    const uint32_t want = ep - sp + 1, n = std::min(want, rl - sp);
+                    if (n == 0) continue;
+                    if (fill) P.seqs[at] = hxk::PoaSeq{rid, strand, sp, n};
+                    at++; cnt++; sum += n; lmax = std::max(lmax, n);
+                }
+                if (fill) { E.seq_end = (uint32_t)at; E.lmax = lmax; P.sumL[e] = sum; P.nseq[e] = cnt; bases += sum; }
             }
-            E.seq_end = (uint32_t)P.seqs.size();
+            if (fill) t_bases[t] = bases; else t_seqs[t + 1] = at;   // (counting pass: `at` started at 0 - the range's own count)
+        };
+        auto all = [&](bool fill) {
+            std::vector<std::thread> th;
+            for (uint32_t t = 1; t < nt; t++) th.emplace_back(range, t, fill);
+            range(0, fill);
+            for (std::thread& x : th) x.join();
+        };
+        all(false);
+        if (bad) return fail("hx_poa_batch: consensus support starts beyond its read (the reference would throw std::out_of_range, Assemble.cpp:530)");
+        {   // the ranges' counts -> where each range's sequences begin
+            uint64_t run = P.seqs.size();
+            for (uint32_t t = 0; t < nt; t++) { const uint64_t n = t_seqs[t + 1]; t_seqs[t] = run; run += n; }
+            t_seqs[nt] = run;
+            P.seqs.resize(run);
         }
+        all(true);
+        for (uint32_t t = 0; t < nt; t++) seq_bases += t_bases[t];
+        n_aligned += t_seqs[nt] - t_seqs[0];
         for (uint32_t e = 0; e < ne; e++) if (P.nseq[e]) todo.push_back(e);
-        cns.assign(ne, std::string());
+        cns.assign(ne, CnsView{});
         grow.assign(ne, 0); force_nodir.assign(ne, 0); full_h.assign(ne, 0); wide_grow.assign(ne, 0); no_share.assign(ne, 0); many_sinks.assign(ne, 0); far_full.assign(ne, 0);
         mlanes.assign(ne, 0); plane.assign(ne, 0); chain_ms.assign(ne, 0.f); ecols.assign(ne, 4);
         return 0;
@@ -1476,12 +1507,13 @@ struct PoaCall {
             const uint64_t so = P.edges[e].cns_off, to = dense_off[i];
             desc.insert(desc.end(), {(uint32_t)so, (uint32_t)(so >> 32), (uint32_t)to, (uint32_t)(to >> 32), n});
         }
-        std::vector<char> h_cns(dense_off.back());
+        cns_blocks.emplace_back(new char[std::max<uint64_t>(1, dense_off.back())]);
+        const char* h_cns = cns_blocks.back().get();
         if (!desc.empty()) {
             HIPCHK(c->poa_gather.reserve(desc.size())); HIPCHK(c->poa_cns_dense.reserve(dense_off.back()));
             HIPCHK(hipMemcpyAsync(c->poa_gather.p, desc.data(), desc.size() * 4, hipMemcpyHostToDevice, s));
             hxk::gather_bytes(c->poa_pools.cns.p, c->poa_gather.p, (uint32_t)(desc.size() / 5), c->poa_cns_dense.p, s);
-            HIPCHK(hipMemcpyAsync(h_cns.data(), c->poa_cns_dense.p, dense_off.back(), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(cns_blocks.back().get(), c->poa_cns_dense.p, dense_off.back(), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
         }
         struct Lap { double& ms; std::chrono::steady_clock::time_point t0; ~Lap() { ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } lap{c->poa_host_ms[4], tc0};
@@ -1506,7 +1538,7 @@ struct PoaCall {
                 if (P.edges[e].vcap >= P.sumL[e]) return fail("hx_poa_batch: POA workspace overflow at worst-case size (internal error)");
                 grow[e]++;
                 retry.push_back(e);
-            } else cns[e].assign(h_cns.data() + dense_off[i], dense_off[i + 1] - dense_off[i]);
+            } else cns[e] = CnsView{h_cns + dense_off[i], (size_t)(dense_off[i + 1] - dense_off[i])};
         }
         return 0;
     }
@@ -1551,10 +1583,12 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     while (!todo.empty()) {
         const auto tp0 = std::chrono::steady_clock::now();
         if (K.knobs(todo.size()) || K.size_edges(todo)) return -1;
+        const double t_size = since(tp0);
         std::vector<std::vector<uint32_t>> batches;
         std::vector<uint32_t> batch_shrink;
         if (K.plan_batches(todo, batches, batch_shrink)) return -1;
         c->poa_host_ms[0] += since(tp0);
+        if (c->opt.debug) fprintf(stderr, "[hx] POA plan: widths and rooms of %zu edges %.2f ms, batches and slots %.2f ms\n", todo.size(), t_size, since(tp0) - t_size);
         std::vector<uint32_t> retry, retry_same;   // retry with the worst-case workspace / with the score-matrix traceback
         for (size_t bi = 0; bi < batches.size(); bi++) {
             if (batches[bi].empty()) continue;
@@ -1581,14 +1615,21 @@ static int poa_consensus(hx_ctx* c, const PoaInput& in, const hx_poa_params* pp,
     const auto tf0 = std::chrono::steady_clock::now();
     unsigned long long cells = 0;
     HIPCHK(hipMemcpy(&cells, c->poa_cells_d.p, 8, hipMemcpyDeviceToHost));
-    c->poa_phase.assign((size_t)ne * hxk::POA_PHASE_WORDS, 0);
+    c->poa_phase.resize((size_t)ne * hxk::POA_PHASE_WORDS);
     if (ne) HIPCHK(hipMemcpy(c->poa_phase.data(), c->poa_phase_d.p, (size_t)ne * hxk::POA_PHASE_WORDS * 8, hipMemcpyDeviceToHost));
     std::vector<uint64_t> off((size_t)ne + 1, 0);
     for (uint32_t e = 0; e < ne; e++) off[e + 1] = off[e] + K.cns[e].size();
     out->n_edge = ne;
     out->cns_off = (uint64_t*)malloc(((size_t)ne + 1) * 8); memcpy(out->cns_off, off.data(), ((size_t)ne + 1) * 8);
     out->cns = (char*)malloc(std::max<uint64_t>(1, off[ne]));
-    for (uint32_t e = 0; e < ne; e++) memcpy(out->cns + off[e], K.cns[e].data(), K.cns[e].size());
+    {   // (30 MB of strings at 140 Mb: a few threads, each its range of the edges)
+        const uint32_t nt = off[ne] > (4u << 20) ? 4u : 1u;
+        auto part = [&](uint32_t t) { for (uint32_t e = (uint32_t)((uint64_t)ne * t / nt); e < (uint32_t)((uint64_t)ne * (t + 1) / nt); e++) if (K.cns[e].size()) memcpy(out->cns + off[e], K.cns[e].data(), K.cns[e].size()); };
+        std::vector<std::thread> th;
+        for (uint32_t t = 1; t < nt; t++) th.emplace_back(part, t);
+        part(0);
+        for (std::thread& x : th) x.join();
+    }
     out->dp_cells = cells; out->seq_bases = K.seq_bases; out->n_aligned = K.n_aligned;
     c->poa_host_ms[5] = since(tf0); c->poa_host_ms[7] = K.ms_since_start();
     if (c->opt.debug) fprintf(stderr, "[hx] POA call, host wall time: plan %.1f ms, workspace %.1f ms (%llu device allocations so far, %.0f ms), enqueue %.1f ms, device %.1f ms, collect %.1f ms, finish %.1f ms, total %.1f ms\n",
