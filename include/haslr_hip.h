@@ -154,7 +154,9 @@ int hx_poa_release_workspace(hx_ctx*);
  * ahead of it by hx_poa_reserve(bytes): a one-shot program (the reference is one, main.cpp:28-228: every stage runs exactly once, the consensus at :207)
  * calls it on a thread of its own while it still parses its text inputs, so that the allocation of 10^2 GB is not part of its consensus stage. At most
  * 80 % of the device memory that is free at the time is taken (and no more than option poa_workspace_gb allows, when it is set); hx_upload gives the arena back if the inputs do not fit beside it; a call that needs more
- * than was reserved allocates again. Thread-safe against the operators of the same context.
+ * than was reserved allocates again. Thread-safe against the operators of the same context. The first reservation (or, without one, the first consensus call) of a
+ * process also takes the hardware queues of the launch streams to the scratch size the largest kernel instance asks for - one wave each, once per process and
+ * device (option poa_scratch_warm=0: not): queues that grow their scratch in the middle of a call hold some of its launches back.
  *   hx_poa_host_times   host wall time (ms) of the LAST consensus call, by part: [0] plan, [1] workspace (arena allocation + carving), [2] enqueue
  *                       (tables to the device, launches), [3] waiting for the device, [4] collection (status + consensus strings), [5] results
  *                       assembled, [6] unused, [7] the whole call
