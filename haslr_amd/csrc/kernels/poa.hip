@@ -417,7 +417,7 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
             PHASE(1);
             // =================================================== traceback, stored reversed
             if (DIR) {
-                // Direction bytes: the first wavefront walks the path together. A tile of 32 rows x 16 columns of direction bytes (two registers)
+                // Direction bytes: the first wavefront walks the path together. A tile of 64 rows x 32 columns of direction nibbles (four registers)
                 // and the records of those 32 rows are fetched with one round of loads; the walk inside the tile runs on v_readlane, i.e. one
                 // memory round trip per ~12 steps instead of 3-4 dependent ones per step. Ranks are turned into node ids by all lanes afterwards.
                 if (tid < 64) {
@@ -443,17 +443,18 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                             na += j; j = 0;
                             break;
                         }
-                        // tile: 64 rows (ranks ti .. ti-63) x 16 columns (ct-15 .. ct, ct = tj made odd: whole bytes of two nibbles); lane = row: the 8 bytes =
-                        // 16 columns of one row in two registers. (32 rows x 16 columns, lane = (row, half), until round 6: graphs have ~2 ranks per column, the
-                        // walk left such a tile through its rows after ~12 steps - and a tile is a round trip to memory.)
+                        // tile: 64 rows (ranks ti .. ti-63) x 32 columns (ct-31 .. ct, ct = tj made odd: whole bytes of two nibbles); lane = row: the 16 bytes =
+                        // 32 columns of one row in four registers. (32 rows x 16 columns, lane = (row, half), until round 6. A tile is a round trip to memory - 2 000
+                        // cycles with the helper wave ahead of the walk, 30 % of a walk's time - and graphs have ~2 ranks per column: the walk left a tile of 16
+                        // columns through its columns after 16.5 steps on average, whatever its rows; 64 x 32 is the shape it leaves through both at once.)
                         const uint32_t ti = i, ct = j | 1u;
                         if (NT > 64 && ln == 0) { st_wg(&lds_u[8], ti); st_wg(&lds_u[9], ct); }   // (where the walk is: the helper wave fetches ahead of it)
-                        const int32_t bs = ((int32_t)ct - 15) >> 1;   // first byte of the tile in its rows (ct < 15: negative - bytes before the row, never looked at)
-                        uint32_t w0 = 0, w1 = 0, mt = 0, pv0 = 0, pv1 = 0, qo = 0, qw = 0;
+                        const int32_t bs = ((int32_t)ct - 31) >> 1;   // first byte of the tile in its rows (ct < 31: negative - bytes before the row, never looked at)
+                        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, mt = 0, pv0 = 0, pv1 = 0, qo = 0, qw = 0;
                         if (ti > ln) {
-                            // two unaligned dword loads per lane (bytes bs .. bs + 7 of the row; columns below 0 read the end of the previous row - row 0 exists)
+                            // four unaligned dword loads per lane (bytes bs .. bs + 15 of the row; columns below 0 read the end of the previous row - row 0 exists)
                             const uint8_t* rowp = Dm + (uint64_t)(ti - ln) * (W >> 1) + bs;
-                            __builtin_memcpy(&w0, rowp, 4); __builtin_memcpy(&w1, rowp + 4, 4);
+                            __builtin_memcpy(&w0, rowp, 4); __builtin_memcpy(&w1, rowp + 4, 4); __builtin_memcpy(&w2, rowp + 8, 4); __builtin_memcpy(&w3, rowp + 12, 4);
                             // the records of the tile's rows: where a move into the first / second predecessor leads
                             const uint32_t rr = ti - 1 - ln;
                             mt = g.row_meta[rr]; qo = g.row_pred_off[rr]; if (mt & 32u) qw = g.wslot[rr];
@@ -465,11 +466,12 @@ __device__ __forceinline__ void poa_edge(const uint32_t eidx, const uint32_t mem
                         const int32_t jb0 = 2 * bs;                                  // ... and j >= first column of the tile
                         // (bit dr: the tile's row dr has more than 4 predecessors - a scalar bit test per step instead of a readlane of the row's record)
                         const unsigned long long wmask = __ballot((mt & 32u) != 0);
-                        if (mt & 32u) { w0 = 0x88888888u; w1 = 0x88888888u; }   // a row with more than 4 predecessors: every cell reads as code 8, one of the rare moves - its real move is in the wide-row pool
+                        if (mt & 32u) { w0 = 0x88888888u; w1 = 0x88888888u; w2 = 0x88888888u; w3 = 0x88888888u; }   // a row with more than 4 predecessors: every cell reads as code 8, one of the rare moves - its real move is in the wide-row pool
                         for (;;) {
-                            const uint32_t dr = ti - i, jb = (uint32_t)((int32_t)j - jb0);   // row and column inside the tile (0..63, 0..15)
+                            const uint32_t dr = ti - i, jb = (uint32_t)((int32_t)j - jb0);   // row and column inside the tile (0..63, 0..31)
                             const uint32_t wsa = (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)dr), wsb = (uint32_t)__builtin_amdgcn_readlane((int)w1, (int)dr);
-                            const uint32_t wsh = ((jb & 8u) ? wsb : wsa) >> (4 * (jb & 7u));   // the cell's code in bits 0-3
+                            const uint32_t wsc = (uint32_t)__builtin_amdgcn_readlane((int)w2, (int)dr), wsd = (uint32_t)__builtin_amdgcn_readlane((int)w3, (int)dr);
+                            const uint32_t wsh = ((jb & 16u) ? ((jb & 8u) ? wsd : wsc) : ((jb & 8u) ? wsb : wsa)) >> (4 * (jb & 7u));   // the cell's code in bits 0-3
                             const uint32_t n4 = wsh & 15u;
                             // move code: type (3 diagonal / 2 vertical / 1 horizontal) * 4 + 3 - predecessor slot; a row with more than 4 predecessors
                             // keeps type * 16 + 15 - slot in the wide-row pool
