@@ -237,15 +237,18 @@ def measure(ctx, ds, prm, table, steps, warmup, world, rank, sync, gather, lr_be
     ctx.timing_reset()
     sync()
     t0 = time.perf_counter()
-    last = None
-    for _ in range(steps):
-        if last is not None:
-            last.close()
+    runs, marks = [], []
+    for _ in range(steps):   # (the timed region is the passes themselves: the results of the earlier ones are freed, and the per-step lines printed, after it)
         ts = time.perf_counter()
-        last = step()
-        log(f"[rank {rank}] step {time.perf_counter() - ts:.3f} s  stages {last.timings()}")
+        runs.append(step())
+        marks.append(time.perf_counter() - ts)
     sync()
-    return time.perf_counter() - t0, last
+    dt = time.perf_counter() - t0
+    for run, m in zip(runs, marks):
+        log(f"[rank {rank}] step {m:.3f} s  stages {run.timings()}")
+    for run in runs[:-1]:
+        run.close()
+    return dt, runs[-1]
 
 
 def cpu_sample(ds, share=8):
