@@ -237,29 +237,15 @@ def measure(ctx, ds, prm, table, steps, warmup, world, rank, sync, gather, lr_be
     ctx.timing_reset()
     sync()
     t0 = time.perf_counter()
-    # The timed region is the passes. What is NOT a pass - reading a finished run's stage times, freeing its result arrays (0.4 ms together at 12 Mb) - runs on a
-    # thread of its own while the next pass waits for the GPU; the arrays are free again before the pass after that allocates its own (kept to the end instead,
-    # every pass faults 10 MB of fresh pages in and takes 1 ms longer).
-    import threading
-    last, lines, closers = None, [], []
-
-    def retire(run, seconds):
-        lines.append(f"[rank {rank}] step {seconds:.3f} s  stages {run.timings()}")
-        run.close()
-
+    last, lines = None, []
     for _ in range(steps):
         if last is not None:
-            closers.append(threading.Thread(target=retire, args=(last, took)))
-            closers[-1].start()
+            last.close()      # (inside the timed region on purpose: the next pass's result arrays then reuse these pages - kept to the end instead, every pass faults its 10 MB in anew and takes 1 ms longer)
         ts = time.perf_counter()
         last = step()
-        took = time.perf_counter() - ts
+        lines.append(f"[rank {rank}] step {time.perf_counter() - ts:.3f} s  stages {last.timings()}")
     sync()
     dt = time.perf_counter() - t0
-    for th in closers:
-        th.join()
-    if last is not None:
-        lines.append(f"[rank {rank}] step {took:.3f} s  stages {last.timings()}")
     for line in lines:
         log(line)
     return dt, last
